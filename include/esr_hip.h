@@ -1,0 +1,128 @@
+/*
+ * esr_hip.h -- C ABI of libesr_hip.so, the MI355X (gfx950) implementation of the
+ * NTIRE2022_ESR test_demo.py forward path.
+ *
+ * The reference has no FFI: its boundary is the torch.nn.Module protocol
+ * (select_model test_demo.py:13-341, forward test_demo.py:364-391).  This header
+ * is what a from-scratch binding of that path calls underneath `model(x)`:
+ * plain pointers and sizes, an explicit HIP stream, status codes, no allocation,
+ * no host synchronisation, no torch types.  The Python host side
+ * (ntire2022_esr_amd/) binds it with ctypes; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Activation tensors between ops are NHWC fp32 with an explicit channel pitch
+ * (floats per pixel) and a first-channel offset, so torch.split / torch.cat on
+ * the channel axis (models/basicblock.py:260-264, models/rfdn_baseline/block.py:163,
+ * RFDN.py:36) are free: producers store straight into a slice of the consumer's
+ * buffer.  The network input/output stay NCHW fp32 exactly as `model(x)` sees them.
+ *
+ * All entry points return ESR_OK (0) or a negative esr_status; none throws.
+ */
+#ifndef ESR_HIP_H
+#define ESR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESR_ABI_VERSION 1
+
+typedef enum esr_status {
+    ESR_OK = 0,
+    ESR_ERR_BAD_ARG = -1,      /* NULL pointer, non-positive size, unsupported combination */
+    ESR_ERR_UNSUPPORTED = -2,  /* shape outside what the kernels implement (e.g. cout > 64) */
+    ESR_ERR_LAUNCH = -3,       /* hipLaunchKernel reported an error (see esr_last_hip_error) */
+    ESR_ERR_TOO_SMALL = -4     /* ESA needs H,W >= 15 (models/rfdn_baseline/block.py:119-120) */
+} esr_status;
+
+/* nn.LeakyReLU(0.05) models/basicblock.py:77 | nn.ReLU rfdn_baseline/block.py:115 |
+ * nn.GELU() (erf form) models/team18_bsrn.py:107 */
+typedef enum esr_act { ESR_ACT_NONE = 0, ESR_ACT_LRELU = 1, ESR_ACT_RELU = 2, ESR_ACT_GELU = 3 } esr_act;
+
+/* where the residual enters relative to the activation:
+ *   PRE : act(conv(x) + r)   RFDB  rfdn_baseline/block.py:151 ; ShortcutBlock basicblock.py:197-199 (act none)
+ *   POST: act(conv(x)) + r   RLFB  team04_rlfn.py:117-119 */
+typedef enum esr_res { ESR_RES_NONE = 0, ESR_RES_PRE_ACT = 1, ESR_RES_POST_ACT = 2 } esr_res;
+
+typedef enum esr_layout {
+    ESR_NHWC = 0,            /* [n][h][w][pitch] fp32, channel slice [coff, coff+c) */
+    ESR_NCHW_IN = 1,         /* network input  N x cin x H x W contiguous (uint2tensor4 output, utils_image.py:190-193) */
+    ESR_NCHW_SHUFFLE4 = 2    /* network output N x cout/16 x 4H x 4W: conv + nn.PixelShuffle(4) fused
+                                (basicblock.py:446-449,84-85): out[n,c,4h+i,4w+j] = conv[n,16c+4i+j,h,w] */
+} esr_layout;
+
+/* One NHWC view: device pointer + channel pitch + first channel. */
+typedef struct esr_view {
+    void*   ptr;
+    int32_t pitch;   /* floats per pixel (>= coff + channels, multiple of 4) */
+    int32_t coff;    /* first channel of the slice (multiple of 4) */
+} esr_view;
+
+/*
+ * esr_conv2d_f32 -- nn.Conv2d(k in {1,3}, stride 1, padding (k-1)/2, bias) + fused epilogue.
+ * Replaces every full-resolution conv call on the path: basicblock.conv 'C'/'CL'
+ * (models/basicblock.py:61-98), rfdn conv_layer (models/rfdn_baseline/block.py:7-10),
+ * rlfn conv_layer (models/team04_rlfn.py:7-10) and the 1x1 "fusion" convs that follow a
+ * torch.cat.  fp32 in, fp32 accumulate on v_mfma_f32_16x16x4_f32 (exact fmaf chain), fp32 out.
+ *
+ *   y = epilogue(bias + sum_{c,i,j} W[o,c,i,j] * x[n, h+i-p, w+j-p, c])
+ *   channels [0, split) of the result go to out0, channels [split, cout) to out1
+ *   (torch.split(t,(d,r),dim=1) basicblock.py:260-262); split == cout -> single output.
+ */
+typedef struct esr_conv_desc {
+    int32_t n, h, w;            /* batch, input height, width (output spatial = same; x4 for SHUFFLE4) */
+    int32_t cin, cout;          /* logical channels; cin <= 512, cout <= 64 */
+    int32_t ksize;              /* 1 or 3 */
+    int32_t in_layout;          /* ESR_NHWC | ESR_NCHW_IN (cin <= 4 only) */
+    int32_t out_layout;         /* ESR_NHWC | ESR_NCHW_SHUFFLE4 (cout == 48 -> 3 x 4H x 4W) */
+    int32_t act;                /* esr_act */
+    float   slope;              /* LeakyReLU negative slope */
+    int32_t res_mode;           /* esr_res */
+    int32_t split;              /* multiple of 4, 0 < split <= cout */
+    esr_view in;                /* pitch/coff ignored for ESR_NCHW_IN */
+    esr_view res;               /* residual, NHWC, `cout` channels from coff; unused if ESR_RES_NONE */
+    esr_view out0, out1;        /* out0.ptr is the NCHW tensor for ESR_NCHW_SHUFFLE4 */
+    const void* wpacked;        /* device pointer to esr_pack_conv_f32 output */
+} esr_conv_desc;
+
+/* Host-side weight packer (the K10 "weight packer" of SURVEY 7.2): OIHW fp32 (the layout of every
+ * Conv2d in the reference state_dicts; nn.Linear [out,in] is the k=1 case) + bias -> the MFMA-tiled,
+ * zero-padded blob esr_conv2d_f32 consumes.  `cin_map` (may be NULL = identity) gives, for each of
+ * `cin_phys` physical input-channel slots, the logical input channel it carries or -1 for a padding
+ * slot: that is how padded concat buffers are described.  Pure CPU code: callable without a GPU. */
+size_t esr_packed_conv_bytes(int cin_phys, int cout, int ksize);
+int    esr_pack_conv_f32(const float* w_oihw, const float* bias, int cin, int cout, int ksize,
+                         const int32_t* cin_map, int cin_phys, void* out, size_t out_bytes);
+/* inverse, for tests: recovers OIHW + bias from a packed blob */
+int    esr_unpack_conv_f32(const void* packed, size_t bytes, int cin, int cout, int ksize,
+                           const int32_t* cin_map, int cin_phys, float* w_oihw, float* bias);
+
+int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream);
+
+/*
+ * A forward pass is a flat list of ops executed in order on one stream: the native
+ * replacement for test_demo.py's `model(img_lq)` (forward(), test_demo.py:364-367).
+ * The Python host builds the list once per (model, N, H, W) and replays it.
+ */
+typedef enum esr_op_kind { ESR_OP_CONV = 0 } esr_op_kind;
+
+typedef struct esr_op {
+    int32_t kind;               /* esr_op_kind */
+    int32_t reserved;
+    esr_conv_desc conv;
+} esr_op;
+
+int esr_run_ops(const esr_op* ops, int n_ops, void* hip_stream);
+
+/* diagnostics */
+int         esr_abi_version(void);
+const char* esr_last_hip_error(void);     /* thread-local, "" if none */
+const char* esr_build_info(void);         /* e.g. "gfx950 f32-mfma16x16x4 tile16x16 chunk8" */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESR_HIP_H */

@@ -1,0 +1,88 @@
+"""ctypes binding of libesr_hip.so (C ABI: include/esr_hip.h).
+
+There is deliberately NO fallback: if the HIP library cannot be loaded, every
+op raises.  A product path that silently ran on the CPU or on eager PyTorch
+would void the parity claims.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libesr_hip.so")
+
+ESR_OK = 0
+STATUS = {0: "ESR_OK", -1: "ESR_ERR_BAD_ARG", -2: "ESR_ERR_UNSUPPORTED", -3: "ESR_ERR_LAUNCH", -4: "ESR_ERR_TOO_SMALL"}
+
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
+RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
+NHWC, NCHW_IN, NCHW_SHUFFLE4 = 0, 1, 2
+OP_CONV = 0
+
+
+class View(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("pitch", ctypes.c_int32), ("coff", ctypes.c_int32)]
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_int32), ("h", ctypes.c_int32), ("w", ctypes.c_int32),
+        ("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("ksize", ctypes.c_int32),
+        ("in_layout", ctypes.c_int32), ("out_layout", ctypes.c_int32),
+        ("act", ctypes.c_int32), ("slope", ctypes.c_float),
+        ("res_mode", ctypes.c_int32), ("split", ctypes.c_int32),
+        ("inp", View), ("res", View), ("out0", View), ("out1", View),
+        ("wpacked", ctypes.c_void_p),
+    ]
+
+
+class Op(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("conv", ConvDesc)]
+
+
+# every symbol include/esr_hip.h declares (tests check the .so exports all of them)
+EXPORTS = [
+    "esr_abi_version", "esr_last_hip_error", "esr_build_info",
+    "esr_packed_conv_bytes", "esr_pack_conv_f32", "esr_unpack_conv_f32",
+    "esr_conv2d_f32", "esr_run_ops",
+]
+
+_lib = None
+
+
+class EsrError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libesr_hip.so or raise.  Never returns None."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise EsrError(f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = ctypes.CDLL(SO_PATH)
+    vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    L.esr_abi_version.restype = ci
+    L.esr_last_hip_error.restype = ctypes.c_char_p
+    L.esr_build_info.restype = ctypes.c_char_p
+    L.esr_packed_conv_bytes.argtypes = [ci, ci, ci]
+    L.esr_packed_conv_bytes.restype = sz
+    L.esr_pack_conv_f32.argtypes = [vp, vp, ci, ci, ci, vp, ci, vp, sz]
+    L.esr_pack_conv_f32.restype = ci
+    L.esr_unpack_conv_f32.argtypes = [vp, sz, ci, ci, ci, vp, ci, vp, vp]
+    L.esr_unpack_conv_f32.restype = ci
+    L.esr_conv2d_f32.argtypes = [ctypes.POINTER(ConvDesc), vp]
+    L.esr_conv2d_f32.restype = ci
+    L.esr_run_ops.argtypes = [ctypes.POINTER(Op), ci, vp]
+    L.esr_run_ops.restype = ci
+    if L.esr_abi_version() != 1:
+        raise EsrError("libesr_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != ESR_OK:
+        msg = lib().esr_last_hip_error().decode()
+        raise EsrError(f"{what} failed: {STATUS.get(rc, rc)} {msg}")

@@ -1,0 +1,426 @@
+// esr_hip.hip -- gfx950 (MI355X / CDNA4) kernels + C ABI for the NTIRE2022_ESR forward path.
+// Interface: include/esr_hip.h.  Design notes: DESIGN.md.
+//
+// conv_f32_kernel: NHWC implicit-GEMM convolution (k=1|3, stride 1, same padding) in exact fp32
+// on v_mfma_f32_16x16x4_f32.
+//   GEMM view    D[cout][pixel] = sum_k W[cout][k] * X[k][pixel],  k = (cin chunk, tap, cin in chunk)
+//   MFMA A       = weights  (lane l: A[i = l&15][k = l>>4])      16 output channels
+//   MFMA B       = pixels   (lane l: B[k = l>>4][j = l&15])      16 pixels of one image row
+//   MFMA D       lane l holds D[(l>>4)*4 + r][l&15], r=0..3  -> 4 CONSECUTIVE output channels of ONE
+//                pixel per lane: the NHWC store is one dwordx4, and with 16c+4i+j channel order the
+//                PixelShuffle(4) store is one dwordx4 of 4 horizontally adjacent HR pixels.
+//   block        256 threads = 4 waves, 16x16 output pixels x (NT*16) output channels;
+//                wave wv owns rows 4wv..4wv+3 (4 pixel tiles) x NT channel tiles -> 4*NT accumulators.
+//   K loop       input channels in chunks of 8: per chunk the (16+2)^2 halo tile (8 ch) and the
+//                chunk's weights for all taps/tiles are staged global->VGPR->LDS, double buffered,
+//                one barrier per chunk; 2 blocks/CU (57.6 KB LDS each) overlap each other's staging.
+//   LDS images   input  [half h][halo pixel][4 ch]   (h = channels 0-3 | 4-7 of the chunk)
+//                weight [tap][tile][lane][2]          (lane-linear: conflict-free ds_read_b64)
+//                a lane (p, kq) reads channels c0+2kq+{0,1}: k-slot kq of MFMA j <-> channel c0+2kq+j,
+//                identical on the A and B side by construction of the packer below.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "esr_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int TILE = 16;      // output tile edge (pixels)
+constexpr int CHUNK = 8;      // input channels per K stage
+constexpr int THREADS = 256;
+
+struct ConvK {
+    const float* x;
+    const float* wp;      // packed weights
+    const float* bias;    // NT*16 floats (inside the packed blob)
+    const float* res;
+    float* y0;
+    float* y1;
+    int N, H, W;
+    int nchunks;          // ceil(cin_phys / 8)
+    int cin;              // logical cin (NCHW input only)
+    int in_pitch, in_coff;
+    int res_pitch, res_coff;
+    int y0_pitch, y0_coff, y1_pitch, y1_coff;
+    int cout_store;       // round_up4(cout): channels >= this are never stored
+    int split;
+    int act;
+    float slope;
+    int res_mode;
+    int out_layout;
+    int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope)
+{
+    switch (act) {
+        case ESR_ACT_LRELU: return v >= 0.f ? v : slope * v;
+        case ESR_ACT_RELU: return v > 0.f ? v : 0.f;
+        case ESR_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        default: return v;
+    }
+}
+
+template <int NT, int KS, bool IN_NCHW>
+__global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
+{
+    constexpr int HALO = KS / 2;
+    constexpr int TH = TILE + 2 * HALO;
+    constexpr int NPX = TH * TH;
+    constexpr int TAPS = KS * KS;
+    constexpr int IN_ITEMS = 2 * NPX;                 // 16-byte items per stage (input)
+    constexpr int IN_BYTES = IN_ITEMS * 16;
+    constexpr int W_ITEMS = TAPS * NT * 32;           // 16-byte items per stage (weights)
+    constexpr int W_FLOATS = W_ITEMS * 4;
+    constexpr int STAGE_BYTES = IN_BYTES + W_ITEMS * 16;
+    constexpr int IN_ROUNDS = (IN_ITEMS + THREADS - 1) / THREADS;
+    constexpr int W_ROUNDS = (W_ITEMS + THREADS - 1) / THREADS;
+
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int px = lane & 15;
+    const int kq = lane >> 4;
+
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int n = bid / p.tiles_y;
+    const int x0 = tx * TILE, y0 = ty * TILE;
+
+    // ---- per-thread staging descriptors (chunk invariant) -------------------------------
+    int in_off[IN_ROUNDS];     // float offset of this thread's item in x for chunk 0, or -1
+#pragma unroll
+    for (int r = 0; r < IN_ROUNDS; ++r) {
+        const int idx = tid + r * THREADS;
+        const int half = idx / NPX;
+        const int pl = idx - half * NPX;
+        const int ly = pl / TH, lx = pl - ly * TH;
+        const int gy = y0 - HALO + ly, gx = x0 - HALO + lx;
+        const bool ok = idx < IN_ITEMS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        if (IN_NCHW)
+            in_off[r] = ok ? (half == 0 ? (gy * p.W + gx) : -2) : -1;    // -2: in-image but zero half
+        else
+            in_off[r] = ok ? (((n * p.H + gy) * p.W + gx) * p.in_pitch + p.in_coff + 4 * half) : -1;
+    }
+
+    f32x4 in_reg[IN_ROUNDS];
+    f32x4 w_reg[W_ROUNDS];
+
+    auto load_stage = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < IN_ROUNDS; ++r) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (IN_NCHW) {
+                if (in_off[r] >= 0) {
+                    const size_t plane = (size_t)p.H * p.W;
+                    const float* b = p.x + (size_t)n * p.cin * plane + in_off[r];
+                    v.x = b[0];
+                    if (p.cin > 1) v.y = b[plane];
+                    if (p.cin > 2) v.z = b[2 * plane];
+                    if (p.cin > 3) v.w = b[3 * plane];
+                }
+            } else {
+                if (in_off[r] >= 0) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)in_off[r] + c * CHUNK);
+            }
+            in_reg[r] = v;
+        }
+        const float* wsrc = p.wp + (size_t)c * W_FLOATS;
+#pragma unroll
+        for (int r = 0; r < W_ROUNDS; ++r) {
+            const int idx = tid + r * THREADS;
+            if (W_ITEMS % THREADS == 0 || idx < W_ITEMS)
+                w_reg[r] = *reinterpret_cast<const f32x4*>(wsrc + idx * 4);
+        }
+    };
+    auto store_stage = [&](int buf) {
+        char* s = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int r = 0; r < IN_ROUNDS; ++r) {
+            const int idx = tid + r * THREADS;
+            if (IN_ITEMS % THREADS == 0 || idx < IN_ITEMS)
+                *reinterpret_cast<f32x4*>(s + idx * 16) = in_reg[r];
+        }
+#pragma unroll
+        for (int r = 0; r < W_ROUNDS; ++r) {
+            const int idx = tid + r * THREADS;
+            if (W_ITEMS % THREADS == 0 || idx < W_ITEMS)
+                *reinterpret_cast<f32x4*>(s + IN_BYTES + idx * 16) = w_reg[r];
+        }
+    };
+
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // lane-constant LDS byte offsets
+    const int b_base = (kq >> 1) * (NPX * 16) + ((wv * 4) * TH + px) * 16 + (kq & 1) * 8;
+    const int a_base = IN_BYTES + lane * 8;
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+
+    for (int c = 0; c < p.nchunks; ++c) {
+        const bool more = c + 1 < p.nchunks;
+        if (more) load_stage(c + 1);
+        const char* s = smem + (c & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dy = tap / KS, dx = tap - dy * KS;
+            f32x2 a[NT], b[4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                a[t] = *reinterpret_cast<const f32x2*>(s + a_base + (tap * NT + t) * 512);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                b[r] = *reinterpret_cast<const f32x2*>(s + b_base + ((r + dy) * TH + dx) * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j], b[r][j], acc[t][r], 0, 0, 0);
+        }
+        if (more) store_stage((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias -> (+res) -> act -> (+res) -> store ------------------------------
+    const int gx = x0 + px;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int cb = t * 16 + kq * 4;                 // first of this lane's 4 output channels
+        if (cb >= p.cout_store) continue;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + cb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gy = y0 + wv * 4 + r;
+            if (gy >= p.H || gx >= p.W) continue;
+            const size_t pix = ((size_t)n * p.H + gy) * p.W + gx;
+            f32x4 v = acc[t][r] + bv;
+            f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+            if (p.res_mode != ESR_RES_NONE)
+                rv = *reinterpret_cast<const f32x4*>(p.res + pix * p.res_pitch + p.res_coff + cb);
+            if (p.res_mode == ESR_RES_PRE_ACT) v += rv;
+            v.x = act_apply(v.x, p.act, p.slope);
+            v.y = act_apply(v.y, p.act, p.slope);
+            v.z = act_apply(v.z, p.act, p.slope);
+            v.w = act_apply(v.w, p.act, p.slope);
+            if (p.res_mode == ESR_RES_POST_ACT) v += rv;
+            if (p.out_layout == ESR_NCHW_SHUFFLE4) {
+                // out[n, t, 4gy+kq, 4gx+0..3]  (channel 16t + 4kq + j)
+                const size_t W4 = (size_t)p.W * 4, H4 = (size_t)p.H * 4;
+                const int nco = p.cout_store / 16;
+                float* dst = p.y0 + (((size_t)n * nco + t) * H4 + (size_t)gy * 4 + kq) * W4 + (size_t)gx * 4;
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else if (cb < p.split) {
+                *reinterpret_cast<f32x4*>(p.y0 + pix * p.y0_pitch + p.y0_coff + cb) = v;
+            } else {
+                *reinterpret_cast<f32x4*>(p.y1 + pix * p.y1_pitch + p.y1_coff + (cb - p.split)) = v;
+            }
+        }
+    }
+}
+
+thread_local char g_err[256] = "";
+
+void set_err(const char* what, hipError_t e)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+template <int NT, int KS, bool IN_NCHW>
+int launch_conv(const ConvK& k, hipStream_t st)
+{
+    const int grid = k.N * k.tiles_x * k.tiles_y;
+    hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW>), dim3(grid), dim3(THREADS), 0, st, k);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_err("conv_f32_kernel launch", e);
+        return ESR_ERR_LAUNCH;
+    }
+    return ESR_OK;
+}
+
+template <int KS, bool IN_NCHW>
+int launch_conv_nt(int nt, const ConvK& k, hipStream_t st)
+{
+    switch (nt) {
+        case 1: return launch_conv<1, KS, IN_NCHW>(k, st);
+        case 2: return launch_conv<2, KS, IN_NCHW>(k, st);
+        case 3: return launch_conv<3, KS, IN_NCHW>(k, st);
+        case 4: return launch_conv<4, KS, IN_NCHW>(k, st);
+    }
+    return ESR_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int esr_abi_version(void) { return ESR_ABI_VERSION; }
+const char* esr_last_hip_error(void) { return g_err; }
+const char* esr_build_info(void) { return "gfx950 f32 v_mfma_f32_16x16x4_f32 tile16x16 chunk8 regstage-dbuf"; }
+
+size_t esr_packed_conv_bytes(int cin_phys, int cout, int ksize)
+{
+    if (cin_phys <= 0 || cout <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    const size_t nt = (size_t)round_up(cout, 16) / 16;
+    const size_t nchunks = (size_t)round_up(cin_phys, CHUNK) / CHUNK;
+    return (nchunks * ksize * ksize * nt * 128 + nt * 16) * sizeof(float);
+}
+
+static int pack_index(int nt, int taps, int slot, int tap, int o, int* j_out)
+{
+    const int chunk = slot / CHUNK, within = slot % CHUNK;
+    const int kq = within / 2, j = within % 2;
+    const int t = o / 16, i = o % 16;
+    *j_out = j;
+    return (((chunk * taps + tap) * nt + t) * 64 + kq * 16 + i) * 2 + j;
+}
+
+int esr_pack_conv_f32(const float* w, const float* bias, int cin, int cout, int ksize,
+                      const int32_t* cin_map, int cin_phys, void* out, size_t out_bytes)
+{
+    if (!w || !out || cin <= 0 || cout <= 0 || (ksize != 1 && ksize != 3)) return ESR_ERR_BAD_ARG;
+    if (!cin_map && cin_phys < cin) return ESR_ERR_BAD_ARG;
+    const size_t need = esr_packed_conv_bytes(cin_phys, cout, ksize);
+    if (need == 0 || out_bytes < need) return ESR_ERR_BAD_ARG;
+    const int nt = round_up(cout, 16) / 16, taps = ksize * ksize;
+    float* o = static_cast<float*>(out);
+    memset(o, 0, need);
+    for (int s = 0; s < cin_phys; ++s) {
+        const int c = cin_map ? cin_map[s] : (s < cin ? s : -1);
+        if (c < 0) continue;
+        if (c >= cin) return ESR_ERR_BAD_ARG;
+        for (int oc = 0; oc < cout; ++oc)
+            for (int tap = 0; tap < taps; ++tap) {
+                int j;
+                o[pack_index(nt, taps, s, tap, oc, &j)] = w[((size_t)oc * cin + c) * taps + tap];
+            }
+    }
+    float* bo = o + (size_t)(round_up(cin_phys, CHUNK) / CHUNK) * taps * nt * 128;
+    if (bias)
+        for (int oc = 0; oc < cout; ++oc) bo[oc] = bias[oc];
+    return ESR_OK;
+}
+
+int esr_unpack_conv_f32(const void* packed, size_t bytes, int cin, int cout, int ksize,
+                        const int32_t* cin_map, int cin_phys, float* w, float* bias)
+{
+    if (!packed || !w || cin <= 0 || cout <= 0 || (ksize != 1 && ksize != 3)) return ESR_ERR_BAD_ARG;
+    if (bytes < esr_packed_conv_bytes(cin_phys, cout, ksize)) return ESR_ERR_BAD_ARG;
+    const int nt = round_up(cout, 16) / 16, taps = ksize * ksize;
+    const float* o = static_cast<const float*>(packed);
+    memset(w, 0, sizeof(float) * (size_t)cout * cin * taps);
+    for (int s = 0; s < cin_phys; ++s) {
+        const int c = cin_map ? cin_map[s] : (s < cin ? s : -1);
+        if (c < 0) continue;
+        for (int oc = 0; oc < cout; ++oc)
+            for (int tap = 0; tap < taps; ++tap) {
+                int j;
+                w[((size_t)oc * cin + c) * taps + tap] = o[pack_index(nt, taps, s, tap, oc, &j)];
+            }
+    }
+    if (bias) {
+        const float* bo = o + (size_t)(round_up(cin_phys, CHUNK) / CHUNK) * taps * nt * 128;
+        for (int oc = 0; oc < cout; ++oc) bias[oc] = bo[oc];
+    }
+    return ESR_OK;
+}
+
+int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
+{
+    if (!d || !d->in.ptr || !d->out0.ptr || !d->wpacked) return ESR_ERR_BAD_ARG;
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->cout <= 0) return ESR_ERR_BAD_ARG;
+    if (d->ksize != 1 && d->ksize != 3) return ESR_ERR_UNSUPPORTED;
+    if (d->cout > 64) return ESR_ERR_UNSUPPORTED;
+    const bool in_nchw = d->in_layout == ESR_NCHW_IN;
+    if (in_nchw && (d->cin > 4 || d->ksize != 3)) return ESR_ERR_UNSUPPORTED;
+    if (!in_nchw && d->in_layout != ESR_NHWC) return ESR_ERR_BAD_ARG;
+    if (!in_nchw && ((d->in.pitch & 3) || (d->in.coff & 3))) return ESR_ERR_BAD_ARG;
+    const int cin_phys = in_nchw ? CHUNK : round_up(d->cin, CHUNK);
+    if (!in_nchw && d->in.coff + cin_phys > d->in.pitch) return ESR_ERR_BAD_ARG;   // chunk reads stay inside the pixel
+    const int cout4 = round_up(d->cout, 4);
+    int split = d->split <= 0 ? cout4 : d->split;
+    if (split >= d->cout) split = cout4;
+    if (split & 3) return ESR_ERR_BAD_ARG;
+    if (d->out_layout == ESR_NCHW_SHUFFLE4) {
+        if (d->cout % 16) return ESR_ERR_UNSUPPORTED;
+    } else if (d->out_layout == ESR_NHWC) {
+        if ((d->out0.pitch & 3) || (d->out0.coff & 3) || d->out0.coff + split > d->out0.pitch) return ESR_ERR_BAD_ARG;
+        if (split < cout4) {
+            if (!d->out1.ptr || (d->out1.pitch & 3) || (d->out1.coff & 3) ||
+                d->out1.coff + (cout4 - split) > d->out1.pitch)
+                return ESR_ERR_BAD_ARG;
+        }
+    } else {
+        return ESR_ERR_BAD_ARG;
+    }
+    if (d->res_mode != ESR_RES_NONE) {
+        if (!d->res.ptr || (d->res.pitch & 3) || (d->res.coff & 3) || d->res.coff + cout4 > d->res.pitch)
+            return ESR_ERR_BAD_ARG;
+    }
+    // 32-bit element offsets inside the kernel
+    if ((double)d->n * d->h * d->w * (in_nchw ? 4 : d->in.pitch) >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
+
+    const int nt = round_up(d->cout, 16) / 16;
+    const int taps = d->ksize * d->ksize;
+    ConvK k;
+    k.x = static_cast<const float*>(d->in.ptr);
+    k.wp = static_cast<const float*>(d->wpacked);
+    k.nchunks = cin_phys / CHUNK;
+    k.bias = k.wp + (size_t)k.nchunks * taps * nt * 128;
+    k.res = static_cast<const float*>(d->res.ptr);
+    k.y0 = static_cast<float*>(d->out0.ptr);
+    k.y1 = static_cast<float*>(d->out1.ptr);
+    k.N = d->n; k.H = d->h; k.W = d->w;
+    k.cin = d->cin;
+    k.in_pitch = d->in.pitch; k.in_coff = d->in.coff;
+    k.res_pitch = d->res.pitch; k.res_coff = d->res.coff;
+    k.y0_pitch = d->out0.pitch; k.y0_coff = d->out0.coff;
+    k.y1_pitch = d->out1.pitch; k.y1_coff = d->out1.coff;
+    k.cout_store = cout4;
+    k.split = split;
+    k.act = d->act; k.slope = d->slope; k.res_mode = d->res_mode;
+    k.out_layout = d->out_layout;
+    k.tiles_x = (d->w + TILE - 1) / TILE;
+    k.tiles_y = (d->h + TILE - 1) / TILE;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (in_nchw) return launch_conv_nt<3, true>(nt, k, st);
+    if (d->ksize == 3) return launch_conv_nt<3, false>(nt, k, st);
+    return launch_conv_nt<1, false>(nt, k, st);
+}
+
+int esr_run_ops(const esr_op* ops, int n_ops, void* hip_stream)
+{
+    if (!ops || n_ops < 0) return ESR_ERR_BAD_ARG;
+    for (int i = 0; i < n_ops; ++i) {
+        int rc;
+        switch (ops[i].kind) {
+            case ESR_OP_CONV: rc = esr_conv2d_f32(&ops[i].conv, hip_stream); break;
+            default: rc = ESR_ERR_BAD_ARG;
+        }
+        if (rc != ESR_OK) return rc;
+    }
+    return ESR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+"""IMDN (x4) on the HIP engine -- drop-in for `models.imdn_baseline.IMDN`.
+
+Same constructor keywords (models/imdn_baseline.py:33) and the same 86 state_dict keys
+(`model.0.*`, `model.1.sub.{i}.conv{1,2,3}.0.*`, `.conv4.*`, `.conv1x1.*`, `model.1.sub.{nb}.*`,
+`model.2.*`) so `load_state_dict(torch.load('model_zoo/imdn_baseline.pth'), strict=True)`
+(test_demo.py:22-23; id 26 = nb 7, test_demo.py:203-209) works unchanged.
+
+Forward = 3 + 5*nb kernel launches, no split/cat/add kernels:
+  head     3->nc        NCHW in, NHWC out (FEA, kept for the global shortcut)
+  block i  conv1 nc->nc  LReLU, split store: [0,d) -> CAT[0:d),   [d,nc) -> R1      basicblock.py:260
+           conv2 r->nc   LReLU, split store:        CAT[d:2d),            R2        :261
+           conv3 r->nc   LReLU, split store:        CAT[2d:3d),           R1        :262
+           conv4 r->d    no act                     CAT[3d:4d)                      :263
+           1x1  4d->nc   + block input (residual)   -> ping-pong X                  :264-265
+  tail     nc->nc 3x3 + FEA (ShortcutBlock, basicblock.py:197-199)
+  up       nc->out_nc*16 3x3 fused with PixelShuffle(4) -> NCHW output             basicblock.py:446-449
+"""
+from . import _lib as L
+from .engine import INPUT, OUTPUT, HipSRModel
+
+
+class IMDN(HipSRModel):
+    def __init__(self, in_nc=3, out_nc=3, nc=64, nb=8, upscale=4, act_mode='L',
+                 upsample_mode='pixelshuffle', negative_slope=0.05):
+        super().__init__()
+        if 'R' not in act_mode and 'L' not in act_mode:
+            raise AssertionError('Examples of activation function: R, L, BR, BL, IR, IL')
+        if upsample_mode != 'pixelshuffle':
+            raise NotImplementedError('upsample mode [{:s}] is not found'.format(upsample_mode))
+        if upscale != 4 or nc % 16 or nc > 64 or in_nc > 4 or (out_nc * 16) > 64:
+            raise NotImplementedError('HIP IMDN supports upscale=4, nc in {16,32,48,64}, in_nc<=4, out_nc<=4')
+        self.in_nc, self.out_nc, self.nc, self.nb, self.upscale = in_nc, out_nc, nc, nb, upscale
+        self.act = L.ACT_LRELU if 'L' in act_mode else L.ACT_RELU
+        self.slope = negative_slope
+        self.d_nc = int(nc * 0.25)
+        self.r_nc = nc - self.d_nc
+        self._add_conv('model.0', in_nc, nc, 3)
+        for i in range(nb):
+            p = f'model.1.sub.{i}.'
+            self._add_conv(p + 'conv1.0', nc, nc, 3)
+            self._add_conv(p + 'conv2.0', self.r_nc, nc, 3)
+            self._add_conv(p + 'conv3.0', self.r_nc, nc, 3)
+            self._add_conv(p + 'conv4', self.r_nc, self.d_nc, 3)
+            self._add_conv(p + 'conv1x1', self.d_nc * 4, nc, 1)
+        self._add_conv(f'model.1.sub.{nb}', nc, nc, 3)
+        self._add_conv('model.2', nc, out_nc * upscale * upscale, 3)
+
+    def _build_plan(self, plan, c):
+        if c != self.in_nc:
+            raise L.EsrError(f'IMDN expects {self.in_nc} input channels, got {c}')
+        nc, d, r = self.nc, self.d_nc, self.r_nc
+        fea = plan.buffer('fea', nc)
+        xa, xb = plan.buffer('xa', nc), plan.buffer('xb', nc)
+        cat = plan.buffer('cat', 4 * d)
+        r1, r2 = plan.buffer('r1', r), plan.buffer('r2', r)
+        act = dict(act=self.act, slope=self.slope)
+        plan.conv('model.0', INPUT, fea, self.in_nc, nc)
+        cur, nxt = fea, xa
+        for i in range(self.nb):
+            p = f'model.1.sub.{i}.'
+            plan.conv(p + 'conv1.0', cur, cat[0:d], nc, nc, split=d, dst1=r1, **act)
+            plan.conv(p + 'conv2.0', r1, cat[d:2 * d], r, nc, split=d, dst1=r2, **act)
+            plan.conv(p + 'conv3.0', r2, cat[2 * d:3 * d], r, nc, split=d, dst1=r1, **act)
+            plan.conv(p + 'conv4', r1, cat[3 * d:4 * d], r, d)
+            plan.conv(p + 'conv1x1', cat, nxt, 4 * d, nc, k=1, res=cur, res_mode=L.RES_PRE_ACT)
+            cur = nxt
+            nxt = xb if cur is xa else xa
+        plan.conv(f'model.1.sub.{self.nb}', cur, nxt, nc, nc, res=fea, res_mode=L.RES_PRE_ACT)
+        plan.conv('model.2', nxt, OUTPUT, nc, self.out_nc * 16)

@@ -1,0 +1,63 @@
+"""Single-op entry points over the C ABI (used by the parity tests and by callers that
+want one fused convolution rather than a whole network).  Tensors are torch CUDA tensors;
+only their data_ptr()/stream cross the boundary."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from .engine import pack_conv
+
+
+def _view(t, coff=0):
+    """NHWC tensor [N,H,W,pitch] -> esr_view at channel offset coff."""
+    return L.View(ctypes.c_void_p(t.data_ptr()), t.shape[-1], coff)
+
+
+def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.RES_NONE,
+           in_nchw=False, shuffle_out=False, out=None, out_coff=0, in_coff=0, cin=None,
+           split=0, out1=None, out1_coff=0, res_coff=0, packed=None, cin_map=None):
+    """Fused conv (k=1|3, stride 1, same padding) on the current stream.
+
+    x       NHWC [N,H,W,pitch] (channels [in_coff, in_coff+cin) are read) or NCHW if in_nchw
+    returns NHWC [N,H,W,cout] (or `out`), or NCHW [N,cout/16,4H,4W] if shuffle_out
+    """
+    if not x.is_cuda:
+        raise L.EsrError("conv2d: tensors must live on the GPU; there is no CPU fallback")
+    lib = L.lib()
+    w4 = weight if weight.dim() == 4 else weight[:, :, None, None]
+    cout, wcin, k, _ = w4.shape
+    if packed is None:
+        packed = pack_conv(weight, bias, cin_map=cin_map).to(x.device)
+    d = L.ConvDesc()
+    if in_nchw:
+        n, c, h, w = x.shape
+        d.in_layout, cin = L.NCHW_IN, c
+        d.inp = L.View(ctypes.c_void_p(x.data_ptr()), 0, 0)
+    else:
+        n, h, w, _ = x.shape
+        cin = wcin if cin is None else cin
+        d.in_layout = L.NHWC
+        d.inp = _view(x, in_coff)
+    d.n, d.h, d.w, d.cin, d.cout, d.ksize = n, h, w, cin, cout, k
+    d.act, d.slope, d.res_mode, d.split = act, slope, res_mode, split
+    if shuffle_out:
+        y = torch.empty((n, cout // 16, 4 * h, 4 * w), dtype=torch.float32, device=x.device) if out is None else out
+        d.out_layout = L.NCHW_SHUFFLE4
+        d.out0 = L.View(ctypes.c_void_p(y.data_ptr()), 0, 0)
+    else:
+        if out is None:
+            c_store = (min(split, cout) if split else cout)
+            y = torch.zeros((n, h, w, (c_store + 3) // 4 * 4), dtype=torch.float32, device=x.device)
+        else:
+            y = out
+        d.out_layout = L.NHWC
+        d.out0 = _view(y, out_coff)
+        if out1 is not None:
+            d.out1 = _view(out1, out1_coff)
+    if res is not None:
+        d.res = _view(res, res_coff)
+    d.wpacked = ctypes.c_void_p(packed.data_ptr())
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    L.check(lib.esr_conv2d_f32(ctypes.byref(d), ctypes.c_void_p(stream)), "esr_conv2d_f32")
+    return y

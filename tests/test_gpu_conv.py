@@ -1,0 +1,125 @@
+"""-m gpu: the HIP convolution (through the C ABI) against the ATen fp32 op it replaces,
+evaluated on the CPU -- floating-point kernel, so a torch fp32 reference is the per-op
+oracle; tolerance 2e-5 * scale (fp32 noise floor 2e-6..5e-6)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ACTS = {0: lambda v: v, 1: lambda v: F.leaky_relu(v, 0.05), 2: F.relu, 3: F.gelu}
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu-marked test needs an MI355X"
+    return torch.device("cuda:0")
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _check(y_gpu_nhwc, ref_nchw, scale=None):
+    y = y_gpu_nhwc.cpu().permute(0, 3, 1, 2)[:, :ref_nchw.shape[1]]
+    s = max(1.0, float(ref_nchw.abs().max())) if scale is None else scale
+    err = float((y - ref_nchw).abs().max()) / s
+    assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("cin,cout,k", [(64, 64, 3), (48, 64, 3), (48, 16, 3), (64, 48, 3), (64, 64, 1),
+                                        (16, 32, 3), (8, 16, 1), (40, 48, 3), (128, 64, 1)])
+@pytest.mark.parametrize("hw", [(16, 16), (17, 15), (40, 56), (5, 3), (1, 1), (33, 64)])
+def test_conv_plain(cin, cout, k, hw):
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(cin * 1000 + cout * 10 + k + hw[0])
+    x = torch.randn(2, cin, *hw, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, w, b, padding=k // 2)
+    y = ops.conv2d(_nhwc(x).to(dev), w, b)
+    _check(y, ref)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+@pytest.mark.parametrize("res_mode", [0, 1, 2])
+def test_conv_epilogues(act, res_mode):
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(7 + act * 3 + res_mode)
+    x = torch.randn(1, 48, 23, 37, generator=g)
+    r = torch.randn(1, 64, 23, 37, generator=g)
+    w = torch.randn(64, 48, 3, 3, generator=g) * 0.1
+    b = torch.randn(64, generator=g)
+    c = F.conv2d(x, w, b, padding=1)
+    ref = {0: ACTS[act](c), 1: ACTS[act](c + r), 2: ACTS[act](c) + r}[res_mode]
+    y = ops.conv2d(_nhwc(x).to(dev), w, b, act=act, slope=0.05,
+                   res=_nhwc(r).to(dev) if res_mode else None, res_mode=res_mode)
+    _check(y, ref)
+
+
+def test_conv_channel_slices_and_split_store():
+    """torch.split / torch.cat become pitch+offset views: IMDBlock conv1 (basicblock.py:260)."""
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    big = torch.randn(2, 64, 19, 21, generator=g)          # read channels 16..63 of a 64-pitch buffer
+    w = torch.randn(64, 48, 3, 3, generator=g) * 0.1
+    b = torch.randn(64, generator=g)
+    ref = F.leaky_relu(F.conv2d(big[:, 16:], w, b, padding=1), 0.05)
+    cat = torch.full((2, 19, 21, 64), 7.0, device=dev)
+    rem = torch.full((2, 19, 21, 48), 9.0, device=dev)
+    ops.conv2d(_nhwc(big).to(dev), w, b, act=1, in_coff=16, cin=48, split=16,
+               out=cat, out_coff=32, out1=rem, out1_coff=0)
+    cat_c, rem_c = cat.cpu(), rem.cpu()
+    assert torch.all(cat_c[..., :32] == 7.0) and torch.all(cat_c[..., 48:] == 7.0)   # untouched slices
+    _check(cat_c[..., 32:48], ref[:, :16])
+    _check(rem_c, ref[:, 16:])
+
+
+def test_conv_head_nchw_and_tail_pixelshuffle():
+    """head reads the NCHW network input (uint2tensor4 layout); tail fuses nn.PixelShuffle(4)."""
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 21, 30, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(64, generator=g)
+    y = ops.conv2d(x.to(dev), w, b, in_nchw=True)
+    _check(y, F.conv2d(x, w, b, padding=1))
+    t = torch.randn(2, 64, 21, 30, generator=g)
+    w2 = torch.randn(48, 64, 3, 3, generator=g) * 0.05
+    b2 = torch.randn(48, generator=g)
+    ref = F.pixel_shuffle(F.conv2d(t, w2, b2, padding=1), 4)
+    out = ops.conv2d(_nhwc(t).to(dev), w2, b2, shuffle_out=True).cpu()
+    assert out.shape == ref.shape
+    assert float((out - ref).abs().max()) / max(1.0, float(ref.abs().max())) < 2e-5
+
+
+def test_conv_padded_concat_map():
+    """cin_map: physical slots carrying logical channels / zero pads (padded concat buffers)."""
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 20, 18, 18, generator=g)
+    w = torch.randn(32, 20, 1, 1, generator=g)
+    b = torch.randn(32, generator=g)
+    # physical layout: [0..9] <- ch 0..9, [10,11] pad, [12..21] <- ch 10..19, [22,23] pad (NaN-free garbage = 0)
+    cmap = list(range(10)) + [-1, -1] + list(range(10, 20)) + [-1, -1]
+    xp = torch.zeros(1, 24, 18, 18)
+    xp[:, 0:10], xp[:, 12:22] = x[:, :10], x[:, 10:]
+    y = ops.conv2d(_nhwc(xp).to(dev), w, b, cin=24, cin_map=cmap)
+    _check(y, F.conv2d(x, w, b))
+
+
+def test_bad_arguments_are_rejected():
+    from ntire2022_esr_amd import _lib as L, ops
+    dev = _dev()
+    x = torch.randn(1, 8, 8, 62, device=dev)             # pitch not a multiple of 4
+    with pytest.raises(L.EsrError):
+        ops.conv2d(x, torch.randn(16, 62, 3, 3), torch.randn(16))
+    with pytest.raises(L.EsrError):
+        ops.conv2d(torch.randn(1, 8, 8, 64, device=dev), torch.randn(80, 64, 3, 3), torch.randn(80))  # cout > 64
+    with pytest.raises(L.EsrError):
+        ops.conv2d(torch.randn(1, 8, 8, 64), torch.randn(16, 64, 3, 3), torch.randn(16))            # CPU tensor

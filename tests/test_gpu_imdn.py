@@ -1,0 +1,90 @@
+"""-m gpu: IMDN end to end on the HIP engine vs (1) the committed reference outputs
+(tests/golden, produced by the real reference) and (2) the C oracle on the same inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, load_sd_numpy, load_sd_torch, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5          # * data_range
+
+
+@pytest.fixture(scope="module")
+def model():
+    from ntire2022_esr_amd import IMDN
+    assert torch.cuda.is_available()
+    m = IMDN(in_nc=3, out_nc=3, nc=64, nb=8, upscale=4)
+    m.load_state_dict(load_sd_torch("imdn_baseline"), strict=True)
+    m.eval()
+    for p in m.parameters():
+        p.requires_grad = False
+    return m.to("cuda:0")
+
+
+def test_golden_e2e(model):
+    g = np.load(os.path.join(GOLD, "e2e_imdn_baseline.npz"))
+    for k in ("a", "b", "c"):
+        x = torch.from_numpy(g["x" + k]).to("cuda:0")
+        x0 = x.clone()
+        y = model(x)
+        assert y.shape == g["y" + k].shape and y.dtype == torch.float32 and y.is_cuda
+        assert torch.equal(x, x0), "input must not be mutated"
+        assert rel_err(y.cpu().numpy(), g["y" + k], 1.0) < TOL, k
+
+
+def test_vs_c_oracle_ragged(model):
+    from oracle import models as OM
+    sd = load_sd_numpy("imdn_baseline")
+    rng = np.random.RandomState(4)
+    for shape in [(1, 3, 1, 1), (1, 3, 16, 16), (3, 3, 31, 18), (1, 3, 33, 47)]:
+        x = rng.rand(*shape).astype(np.float32)
+        y = model(torch.from_numpy(x).to("cuda:0")).cpu().numpy()
+        assert rel_err(y, OM.imdn(sd, x), 1.0) < TOL, shape
+
+
+def test_natural_image_full_size(model):
+    """utils/test.bmp at the bench shape 1x3x256x256 -> 1x3x1024x1024 vs the reference's output."""
+    from PIL import Image
+    g = np.load(os.path.join(GOLD, "img_imdn_baseline.npz"))
+    img = np.array(Image.open(os.path.join(GOLD, "test.bmp")).convert("RGB"))
+    x = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float().div(255.0).unsqueeze(0)
+    y = model(x.to("cuda:0"))
+    assert tuple(y.shape) == (1, 3, 1024, 1024)
+    yc = y.cpu()
+    assert rel_err(yc[0, :, ::5, ::5].numpy(), g["sr_sample"], 1.0) < TOL
+    assert abs(float(yc.double().mean()) - float(g["sr_mean"])) < 1e-6
+    u8 = (yc[0].clamp(0, 1).permute(1, 2, 0).numpy() * 255.0).round().astype(np.uint8)
+    crop = u8[400:528, 300:428]
+    assert np.mean(crop != g["sr_u8_crop"]) < 2e-4 and np.max(np.abs(crop.astype(int) - g["sr_u8_crop"].astype(int))) <= 1
+    assert abs(int(u8.astype(np.int64).sum()) - int(g["sr_u8_sum"])) < 200
+
+
+def test_batch_equals_per_image(model):
+    """size-independent property at the bench shape: images in a batch are independent."""
+    torch.manual_seed(0)
+    x = torch.rand(4, 3, 256, 256, device="cuda:0")
+    y = model(x)
+    for i in (0, 3):
+        assert torch.equal(y[i:i + 1], model(x[i:i + 1].contiguous()))
+    # translation property of a conv net away from borders: shifting the input by one 16-px tile
+    # shifts the interior of the output by 64 px (exercises tile seams / halo staging)
+    xs = torch.roll(x[:1], shifts=(16, 16), dims=(2, 3))
+    ys = model(xs)
+    a = y[0, :, 256:768, 256:768]
+    b = ys[0, :, 256 + 64:768 + 64, 256 + 64:768 + 64]
+    assert float((a - b).abs().max()) < 1e-5
+
+
+def test_strict_state_dict_surface():
+    from ntire2022_esr_amd import IMDN
+    import json
+    man = json.load(open(os.path.join(os.path.dirname(GOLD), "..", "weights", "manifest.json")))
+    m = IMDN()
+    sd = m.state_dict()
+    want = man["imdn_baseline"]["keys"]
+    assert set(sd.keys()) == set(want.keys())
+    for k, shp in want.items():
+        assert list(sd[k].shape) == shp, k

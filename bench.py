@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- images/s of the IMDN x4 fp32 forward (256x256 -> 1024x1024) on N MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path (test_demo.py forward(), :364-367) over one batch of
+synthetic LR tiles already resident in HBM.  Image-level data parallelism: every
+rank holds a full replica and its own batch, there is no collective inside the timed region
+("scaling": "weak"); the only communication is the MAX-reduction of the elapsed time.
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline      dominant kernel (3x3 conv, 64 output channels, fp32 MFMA): algorithmic FLOPs per
+                launch / average launch duration from HIP events recorded on the launch stream
+                during the timed steps, against the dense fp32 MFMA peak (157.3 TFLOP/s)
+  cpu_baseline  the reference's CPU path restated (oracle/torch_port.py: the same ATen op sequence)
+                timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch
+
+FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-in MFMA
+MODELS = {
+    # name -> (data_range, algorithmic GFLOP per 256x256 image: BASELINE.md section 2)
+    "imdn_baseline": (1.0, 116.86),
+}
+
+
+def build_model(name, device):
+    from safetensors.torch import load_file
+    from ntire2022_esr_amd import IMDN
+    m = IMDN(in_nc=3, out_nc=3, nc=64, nb=8, upscale=4)
+    path = os.path.join(REPO, "weights", name + ".safetensors")
+    weights = "checkpoint"
+    if os.path.exists(path):
+        m.load_state_dict(load_file(path), strict=True)
+    else:
+        weights = "random-init"
+    m.eval()
+    for p in m.parameters():
+        p.requires_grad = False
+    return m.to(device), weights
+
+
+def cpu_baseline(name, budget_s=14.0):
+    """The reference's PyTorch CPU path, restated op for op (oracle/torch_port.py), batch 1, fp32,
+    1x3x256x256.  A thread-count sweep first (oneDNN over-threads badly on a
+    256x256 tile: all physical cores is NOT the fastest setting on a 2x64-core host), then the best
+    setting is timed for the rest of the budget; `cores` = the thread count of the reported number."""
+    from safetensors.torch import load_file
+    from oracle import torch_port as TP
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        phys = os.cpu_count()
+    sd = load_file(os.path.join(REPO, "weights", name + ".safetensors"))
+    dr = MODELS[name][0]
+    x = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(0)) * dr
+    fwd = TP.FORWARD[name]
+    cands = sorted({c for c in (8, 16, 32, 64, phys) if c <= phys})
+    sweep = {}
+    with torch.no_grad():
+        for c in cands:
+            torch.set_num_threads(c)
+            fwd(sd, x)
+            ts = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                fwd(sd, x)
+                ts.append(time.perf_counter() - t0)
+            sweep[c] = min(ts)
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+        fwd(sd, x)
+        times = []
+        t_end = time.perf_counter() + max(3.0, budget_s - 3.2 * sum(sweep.values()))
+        while (time.perf_counter() < t_end and len(times) < 200) or len(times) < 5:
+            t0 = time.perf_counter()
+            fwd(sd, x)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(1.0 / med, 3), "unit": "images/s", "cores": int(best), "kind": "port",
+            "sample": f"{len(times)} forwards of 1x3x256x256 fp32 (median {med * 1e3:.1f} ms) with "
+                      f"torch.set_num_threads({best}) = best of sweep "
+                      + ", ".join(f"{c}t:{v * 1e3:.0f}ms" for c, v in sweep.items())
+                      + f"; host has {phys} physical cores; oracle/torch_port.py = the reference's ATen op "
+                        "sequence on oneDNN"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="LR tiles per GPU per step")
+    ap.add_argument("--model", default="imdn_baseline", choices=sorted(MODELS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not record per-kernel HIP events during the timed steps")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; the engine has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    dr, gflop_per_img = MODELS[args.model]
+    model, weights = build_model(args.model, device)
+    B = args.batch
+    x = (torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(rank)) * dr).to(device)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            y = model(x)
+        if not args.no_kernel_events:
+            model.enable_profiling(args.steps)
+            model(x)                       # creates the events outside the timed region
+            torch.cuda.synchronize(device)
+            model.collect_profile()        # discard
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = model(x)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    assert tuple(y.shape) == (B, 3, 1024, 1024)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    roofline = None
+    if not args.no_kernel_events:
+        prof = model.collect_profile()
+        model.disable_profiling()
+        # dominant kernel = the 3x3 conv with 4 output-channel tiles (all 64-output-channel 3x3 convs)
+        dom = [o for o in prof if o["kernel"] == "conv_f32_kernel<NT=4,KS=3,NCHW_IN=0>"]
+        launches = sum(o["passes"] for o in dom)
+        ms = sum(o["ms_sum"] for o in dom)
+        flops = sum(o["flops"] * o["passes"] for o in dom)
+        total_ms = sum(o["ms_sum"] for o in prof)
+        avg_ms = ms / launches
+        achieved = flops / launches / (avg_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("conv_f32_kernel<NT=4,KS=3,NCHW_IN=0>", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "mfma", "kernel": "conv_f32_kernel<4,3,false> (3x3 conv, 64 out ch, fp32 16x16x4 MFMA)",
+                    "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "launches": launches, "avg_launch_ms": round(avg_ms, 4),
+                    "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
+                    "share_of_kernel_time": round(ms / total_ms, 4)}
+
+    if rank == 0:
+        imgs = world * B * args.steps
+        value = imgs / elapsed
+        out = {
+            "metric": "images/sec (256x256->1024x1024 x4)",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": f"synthetic (uniform [0,{dr:g}) LR tiles resident in HBM; weights: {weights})",
+            "config": {"workload": f"{args.model} x4 fp32, {B}x3x256x256 LR batch per GPU -> {B}x3x1024x1024",
+                       "batch_per_gpu": B, "parallelism": f"image-parallel replicas x{world}",
+                       "algorithmic_gflop_per_image": gflop_per_img},
+            "model_tflops": round(value * gflop_per_img / 1e3, 2),
+            "model_frac_of_fp32_mfma_peak": round(value * gflop_per_img / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.model)
+            out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

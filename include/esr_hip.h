@@ -117,6 +117,18 @@ typedef struct esr_op {
 
 int esr_run_ops(const esr_op* ops, int n_ops, void* hip_stream);
 
+/*
+ * In-stream per-op timing (what test_demo.py:413-433 does per image with a CUDA event pair, done
+ * per kernel): esr_run_ops_profiled records a HIP event pair around every op ON THE LAUNCH STREAM
+ * and never synchronises; esr_prof_collect (call after the stream is idle) adds each op's elapsed
+ * milliseconds over all recorded passes into ms_sum[n_ops] and returns the pass count.
+ */
+typedef struct esr_profiler esr_profiler;
+int  esr_prof_create(int n_ops, int max_passes, esr_profiler** out);
+int  esr_run_ops_profiled(const esr_op* ops, int n_ops, void* hip_stream, esr_profiler* prof);
+int  esr_prof_collect(esr_profiler* prof, double* ms_sum, int n_ops, int* passes);
+void esr_prof_destroy(esr_profiler* prof);
+
 /* diagnostics */
 int         esr_abi_version(void);
 const char* esr_last_hip_error(void);     /* thread-local, "" if none */

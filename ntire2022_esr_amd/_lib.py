@@ -44,6 +44,7 @@ EXPORTS = [
     "esr_abi_version", "esr_last_hip_error", "esr_build_info",
     "esr_packed_conv_bytes", "esr_pack_conv_f32", "esr_unpack_conv_f32",
     "esr_conv2d_f32", "esr_run_ops",
+    "esr_prof_create", "esr_run_ops_profiled", "esr_prof_collect", "esr_prof_destroy",
 ]
 
 _lib = None
@@ -76,6 +77,14 @@ def lib():
     L.esr_conv2d_f32.restype = ci
     L.esr_run_ops.argtypes = [ctypes.POINTER(Op), ci, vp]
     L.esr_run_ops.restype = ci
+    L.esr_prof_create.argtypes = [ci, ci, ctypes.POINTER(vp)]
+    L.esr_prof_create.restype = ci
+    L.esr_run_ops_profiled.argtypes = [ctypes.POINTER(Op), ci, vp, vp]
+    L.esr_run_ops_profiled.restype = ci
+    L.esr_prof_collect.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ci, ctypes.POINTER(ci)]
+    L.esr_prof_collect.restype = ci
+    L.esr_prof_destroy.argtypes = [vp]
+    L.esr_prof_destroy.restype = None
     if L.esr_abi_version() != 1:
         raise EsrError("libesr_hip.so ABI version mismatch")
     _lib = L

@@ -409,6 +409,77 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
     return launch_conv_nt<1, false>(nt, k, st);
 }
 
+struct esr_profiler {
+    int n_ops, max_passes, passes;
+    hipEvent_t* ev;   // [max_passes][n_ops][2]
+};
+
+int esr_prof_create(int n_ops, int max_passes, esr_profiler** out)
+{
+    if (!out || n_ops <= 0 || max_passes <= 0) return ESR_ERR_BAD_ARG;
+    esr_profiler* p = new esr_profiler{n_ops, max_passes, 0, nullptr};
+    const size_t n = (size_t)n_ops * max_passes * 2;
+    p->ev = new hipEvent_t[n];
+    for (size_t i = 0; i < n; ++i) {
+        const hipError_t e = hipEventCreate(&p->ev[i]);
+        if (e != hipSuccess) {
+            set_err("hipEventCreate", e);
+            for (size_t j = 0; j < i; ++j) (void)hipEventDestroy(p->ev[j]);
+            delete[] p->ev;
+            delete p;
+            return ESR_ERR_LAUNCH;
+        }
+    }
+    *out = p;
+    return ESR_OK;
+}
+
+void esr_prof_destroy(esr_profiler* p)
+{
+    if (!p) return;
+    const size_t n = (size_t)p->n_ops * p->max_passes * 2;
+    for (size_t i = 0; i < n; ++i) (void)hipEventDestroy(p->ev[i]);
+    delete[] p->ev;
+    delete p;
+}
+
+int esr_run_ops_profiled(const esr_op* ops, int n_ops, void* hip_stream, esr_profiler* p)
+{
+    if (!ops || !p || n_ops != p->n_ops) return ESR_ERR_BAD_ARG;
+    if (p->passes >= p->max_passes) return esr_run_ops(ops, n_ops, hip_stream);   // full: run untimed
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipEvent_t* ev = p->ev + (size_t)p->passes * n_ops * 2;
+    for (int i = 0; i < n_ops; ++i) {
+        (void)hipEventRecord(ev[2 * i], st);
+        const int rc = ops[i].kind == ESR_OP_CONV ? esr_conv2d_f32(&ops[i].conv, hip_stream) : ESR_ERR_BAD_ARG;
+        (void)hipEventRecord(ev[2 * i + 1], st);
+        if (rc != ESR_OK) return rc;
+    }
+    p->passes++;
+    return ESR_OK;
+}
+
+int esr_prof_collect(esr_profiler* p, double* ms_sum, int n_ops, int* passes)
+{
+    if (!p || !ms_sum || n_ops != p->n_ops) return ESR_ERR_BAD_ARG;
+    for (int i = 0; i < n_ops; ++i) ms_sum[i] = 0.0;
+    for (int k = 0; k < p->passes; ++k) {
+        hipEvent_t* ev = p->ev + (size_t)k * n_ops * 2;
+        for (int i = 0; i < n_ops; ++i) {
+            float ms = 0.f;
+            const hipError_t e = hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+            if (e != hipSuccess) {
+                set_err("hipEventElapsedTime", e);
+                return ESR_ERR_LAUNCH;
+            }
+            ms_sum[i] += ms;
+        }
+    }
+    if (passes) *passes = p->passes;
+    p->passes = 0;
+    return ESR_OK;
+}
+
 int esr_run_ops(const esr_op* ops, int n_ops, void* hip_stream)
 {
     if (!ops || n_ops < 0) return ESR_ERR_BAD_ARG;

@@ -155,6 +155,8 @@ class HipSRModel(nn.Module):
         self._packed = None        # path -> device blob
         self._packed_sig = None
         self._plans = {}
+        self._prof_passes = 0      # >0: record HIP events around every op (bench roofline leg)
+        self._profs = {}
 
     # -- parameter registration: same key names as the reference state_dict -------------------
     def _add_conv(self, path, cin, cout, k, cin_map=None, linear=False):
@@ -228,8 +230,46 @@ class HipSRModel(nn.Module):
         for i in out_idx:
             arr[i].conv.out0.ptr = y.data_ptr()
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        L.check(lib.esr_run_ops(arr, len(arr), ctypes.c_void_p(stream)), f"{type(self).__name__}.forward")
+        if self._prof_passes > 0:
+            prof = self._profs.get(key)
+            if prof is None:
+                prof = ctypes.c_void_p()
+                L.check(lib.esr_prof_create(len(arr), self._prof_passes, ctypes.byref(prof)), "esr_prof_create")
+                self._profs[key] = prof
+            rc = lib.esr_run_ops_profiled(arr, len(arr), ctypes.c_void_p(stream), prof)
+        else:
+            rc = lib.esr_run_ops(arr, len(arr), ctypes.c_void_p(stream))
+        L.check(rc, f"{type(self).__name__}.forward")
         return y
+
+    # -- per-kernel timing (HIP events on the launch stream; see esr_run_ops_profiled) ---------
+    def enable_profiling(self, max_passes):
+        self.disable_profiling()
+        self._prof_passes = int(max_passes)
+
+    def disable_profiling(self):
+        for prof in self._profs.values():
+            L.lib().esr_prof_destroy(prof)
+        self._profs = {}
+        self._prof_passes = 0
+
+    def collect_profile(self):
+        """After a device synchronise: list of dicts {name, kernel, flops, ms_sum, passes} per op, summed
+        over the recorded passes of every cached shape."""
+        out = []
+        for key, prof in self._profs.items():
+            arr, _, _, _, plan = self._plans[key]
+            n = len(arr)
+            ms = (ctypes.c_double * n)()
+            passes = ctypes.c_int(0)
+            L.check(L.lib().esr_prof_collect(prof, ms, n, ctypes.byref(passes)), "esr_prof_collect")
+            for i, o in enumerate(plan.ops):
+                nt = (o["cout"] + 15) // 16
+                kern = f"conv_f32_kernel<NT={nt},KS={o['k']},NCHW_IN={int(o['src'] is INPUT)}>"
+                out.append(dict(name=o["w"], kernel=kern, cin=o["cin"], cout=o["cout"], k=o["k"],
+                                flops=2.0 * plan.npix * o["cin"] * o["cout"] * o["k"] * o["k"],
+                                ms_sum=ms[i], passes=passes.value))
+        return out
 
     def workspace_bytes(self, n, h, w, c=3):
         plan = Plan(n, h, w)

@@ -56,13 +56,64 @@ struct ConvK {
     int tiles_x, tiles_y;
 };
 
-__device__ __forceinline__ float act_apply(float v, int act, float slope)
+template <int ACT>
+__device__ __forceinline__ f32x4 act4(f32x4 v, float slope)
 {
-    switch (act) {
-        case ESR_ACT_LRELU: return v >= 0.f ? v : slope * v;
-        case ESR_ACT_RELU: return v > 0.f ? v : 0.f;
-        case ESR_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-        default: return v;
+    if (ACT == ESR_ACT_LRELU) {
+        // 0 <= slope <= 1  =>  leaky_relu(v) = max(v, slope*v): 2 VALU per element, no compare/select
+        const f32x4 m = v * slope;
+        v.x = fmaxf(v.x, m.x); v.y = fmaxf(v.y, m.y); v.z = fmaxf(v.z, m.z); v.w = fmaxf(v.w, m.w);
+    } else if (ACT == ESR_ACT_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    } else if (ACT == ESR_ACT_GELU) {
+        v.x = 0.5f * v.x * (1.f + erff(v.x * 0.70710678118654752440f));
+        v.y = 0.5f * v.y * (1.f + erff(v.y * 0.70710678118654752440f));
+        v.z = 0.5f * v.z * (1.f + erff(v.z * 0.70710678118654752440f));
+        v.w = 0.5f * v.w * (1.f + erff(v.w * 0.70710678118654752440f));
+    }
+    return v;
+}
+
+// Epilogue for one activation kind (selected by ONE wave-uniform switch in the kernel, so no
+// per-element branching): (+res) -> act -> (+res) -> store.  Bias is already in the accumulators.
+// Kept lean on purpose: VALU work issued while the SIMD partner streams fp32 MFMAs costs ~an
+// MFMA slot (32 cycles) per instruction.
+template <int ACT, int NT>
+__device__ __forceinline__ void epilogue(const ConvK& p, f32x4 (&acc)[NT][4], int n, int x0, int y0, int wv,
+                                         int px, int kq)
+{
+    const int gx = x0 + px;
+    if (gx >= p.W) return;
+    const bool shuffle = p.out_layout == ESR_NCHW_SHUFFLE4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gy = y0 + wv * 4 + r;
+        if (gy >= p.H) continue;
+        const int pix = (n * p.H + gy) * p.W + gx;          // < 2^31 / pitch (checked on the host)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int cb = t * 16 + kq * 4;                 // first of this lane's 4 output channels
+            if (cb >= p.cout_store) continue;
+            f32x4 v = acc[t][r];
+            if (p.res_mode != ESR_RES_NONE) {
+                const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (size_t)(pix * p.res_pitch + p.res_coff + cb));
+                if (p.res_mode == ESR_RES_PRE_ACT) v = act4<ACT>(v + rv, p.slope);
+                else v = act4<ACT>(v, p.slope) + rv;
+            } else {
+                v = act4<ACT>(v, p.slope);
+            }
+            if (shuffle) {
+                // out[n, t, 4gy+kq, 4gx+0..3]  (channel 16t + 4kq + j)
+                const size_t W4 = (size_t)p.W * 4, H4 = (size_t)p.H * 4;
+                const int nco = p.cout_store / 16;
+                float* dst = p.y0 + (((size_t)n * nco + t) * H4 + (size_t)gy * 4 + kq) * W4 + (size_t)gx * 4;
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else if (cb < p.split) {
+                *reinterpret_cast<f32x4*>(p.y0 + (size_t)(pix * p.y0_pitch + p.y0_coff + cb)) = v;
+            } else {
+                *reinterpret_cast<f32x4*>(p.y1 + (size_t)(pix * p.y1_pitch + p.y1_coff + (cb - p.split))) = v;
+            }
+        }
     }
 }
 
@@ -80,8 +131,14 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
     constexpr int STAGE_BYTES = IN_BYTES + W_ITEMS * 16;
     constexpr int IN_ROUNDS = (IN_ITEMS + THREADS - 1) / THREADS;
     constexpr int W_ROUNDS = (W_ITEMS + THREADS - 1) / THREADS;
+    constexpr unsigned OOB = 0x80000000u;             // > any per-image byte offset (host checks < 2 GiB)
 
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+
+    // Issue priority: a wave streaming fp32 MFMAs back to back starves its SIMD partner's VALU/LDS/
+    // VMEM instructions (s_memtime probe: ~one instruction per 32-cycle MFMA slot).  Everything that
+    // is not the MFMA stream runs at raised priority and is kept to a handful of instructions.
+    __builtin_amdgcn_s_setprio(3);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -96,8 +153,12 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
     const int n = bid / p.tiles_y;
     const int x0 = tx * TILE, y0 = ty * TILE;
 
-    // ---- per-thread staging descriptors (chunk invariant) -------------------------------
-    int in_off[IN_ROUNDS];     // float offset of this thread's item in x for chunk 0, or -1
+    // ---- staging descriptors (chunk invariant) ------------------------------------------
+    // NHWC input: one raw buffer per image; a lane's byte offset is chunk invariant, the chunk
+    // advances through the SGPR soffset, and out-of-image halo items use an out-of-range offset so
+    // the hardware returns zeros: no per-chunk address VALU, no select, no branch (a per-item
+    // `if (ok) load` makes hipcc branch around every load and serialise them with vmcnt waits).
+    unsigned in_voff[IN_ROUNDS];
 #pragma unroll
     for (int r = 0; r < IN_ROUNDS; ++r) {
         const int idx = tid + r * THREADS;
@@ -107,10 +168,17 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
         const int gy = y0 - HALO + ly, gx = x0 - HALO + lx;
         const bool ok = idx < IN_ITEMS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         if (IN_NCHW)
-            in_off[r] = ok ? (half == 0 ? (gy * p.W + gx) : -2) : -1;    // -2: in-image but zero half
+            in_voff[r] = (ok && half == 0) ? (unsigned)(gy * p.W + gx) * 4u : OOB;
         else
-            in_off[r] = ok ? (((n * p.H + gy) * p.W + gx) * p.in_pitch + p.in_coff + 4 * half) : -1;
+            in_voff[r] = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff + 4 * half) * 4u : OOB;
     }
+    const size_t img_floats = (size_t)p.H * p.W * (IN_NCHW ? 1 : p.in_pitch);
+    const float* xn = p.x + (size_t)n * img_floats * (IN_NCHW ? p.cin : 1);
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, (int)(img_floats * (IN_NCHW ? p.cin : 1) * 4), 0x00020000);
+
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, p.nchunks * (W_FLOATS * 4), 0x00020000);
 
     f32x4 in_reg[IN_ROUNDS];
     f32x4 w_reg[W_ROUNDS];
@@ -118,27 +186,22 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
     auto load_stage = [&](int c) {
 #pragma unroll
         for (int r = 0; r < IN_ROUNDS; ++r) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (IN_NCHW) {
-                if (in_off[r] >= 0) {
-                    const size_t plane = (size_t)p.H * p.W;
-                    const float* b = p.x + (size_t)n * p.cin * plane + in_off[r];
-                    v.x = b[0];
-                    if (p.cin > 1) v.y = b[plane];
-                    if (p.cin > 2) v.z = b[2 * plane];
-                    if (p.cin > 3) v.w = b[3 * plane];
-                }
+                const unsigned plane = (unsigned)(p.H * p.W) * 4u;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, in_voff[r], 0, 0));
+                if (p.cin > 1) v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, in_voff[r], plane, 0));
+                if (p.cin > 2) v.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, in_voff[r], 2 * plane, 0));
+                if (p.cin > 3) v.w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, in_voff[r], 3 * plane, 0));
+                in_reg[r] = v;
             } else {
-                if (in_off[r] >= 0) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)in_off[r] + c * CHUNK);
+                in_reg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, in_voff[r], c * (CHUNK * 4), 0));
             }
-            in_reg[r] = v;
         }
-        const float* wsrc = p.wp + (size_t)c * W_FLOATS;
 #pragma unroll
         for (int r = 0; r < W_ROUNDS; ++r) {
-            const int idx = tid + r * THREADS;
-            if (W_ITEMS % THREADS == 0 || idx < W_ITEMS)
-                w_reg[r] = *reinterpret_cast<const f32x4*>(wsrc + idx * 4);
+            const unsigned voff = (unsigned)min(tid + r * THREADS, W_ITEMS - 1) * 16u;
+            w_reg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, c * (W_FLOATS * 4), 0));
         }
     };
     auto store_stage = [&](int buf) {
@@ -157,80 +220,64 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
         }
     };
 
+    load_stage(0);
+
+    // accumulators start at the bias (lane's 4 output channels per tile): no bias add in the epilogue
     f32x4 acc[NT][4];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + t * 16 + kq * 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 4; ++r) acc[t][r] = bv;
+    }
 
     // lane-constant LDS byte offsets
     const int b_base = (kq >> 1) * (NPX * 16) + ((wv * 4) * TH + px) * 16 + (kq & 1) * 8;
     const int a_base = IN_BYTES + lane * 8;
 
-    load_stage(0);
     store_stage(0);
     __syncthreads();
 
     for (int c = 0; c < p.nchunks; ++c) {
         const bool more = c + 1 < p.nchunks;
         if (more) load_stage(c + 1);
+        __builtin_amdgcn_s_setprio(0);
         const char* s = smem + (c & 1) * STAGE_BYTES;
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
+        // fragment reads run one tap ahead of the MFMAs that consume them
+        f32x2 a[2][NT], b[2][4];
+        auto load_frag = [&](int slot, int tap) {
             const int dy = tap / KS, dx = tap - dy * KS;
-            f32x2 a[NT], b[4];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                a[t] = *reinterpret_cast<const f32x2*>(s + a_base + (tap * NT + t) * 512);
+                a[slot][t] = *reinterpret_cast<const f32x2*>(s + a_base + (tap * NT + t) * 512);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                b[r] = *reinterpret_cast<const f32x2*>(s + b_base + ((r + dy) * TH + dx) * 16);
+                b[slot][r] = *reinterpret_cast<const f32x2*>(s + b_base + ((r + dy) * TH + dx) * 16);
+        };
+        load_frag(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int cur = tap & 1;
+            if (tap + 1 < TAPS) load_frag(cur ^ 1, tap + 1);
+            __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ABOVE this tap's MFMAs
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j], b[r][j], acc[t][r], 0, 0, 0);
+                        acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][t][j], b[cur][r][j], acc[t][r], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(3);
         if (more) store_stage((c + 1) & 1);
         __syncthreads();
     }
 
-    // ---- epilogue: bias -> (+res) -> act -> (+res) -> store ------------------------------
-    const int gx = x0 + px;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int cb = t * 16 + kq * 4;                 // first of this lane's 4 output channels
-        if (cb >= p.cout_store) continue;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + cb);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gy = y0 + wv * 4 + r;
-            if (gy >= p.H || gx >= p.W) continue;
-            const size_t pix = ((size_t)n * p.H + gy) * p.W + gx;
-            f32x4 v = acc[t][r] + bv;
-            f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-            if (p.res_mode != ESR_RES_NONE)
-                rv = *reinterpret_cast<const f32x4*>(p.res + pix * p.res_pitch + p.res_coff + cb);
-            if (p.res_mode == ESR_RES_PRE_ACT) v += rv;
-            v.x = act_apply(v.x, p.act, p.slope);
-            v.y = act_apply(v.y, p.act, p.slope);
-            v.z = act_apply(v.z, p.act, p.slope);
-            v.w = act_apply(v.w, p.act, p.slope);
-            if (p.res_mode == ESR_RES_POST_ACT) v += rv;
-            if (p.out_layout == ESR_NCHW_SHUFFLE4) {
-                // out[n, t, 4gy+kq, 4gx+0..3]  (channel 16t + 4kq + j)
-                const size_t W4 = (size_t)p.W * 4, H4 = (size_t)p.H * 4;
-                const int nco = p.cout_store / 16;
-                float* dst = p.y0 + (((size_t)n * nco + t) * H4 + (size_t)gy * 4 + kq) * W4 + (size_t)gx * 4;
-                *reinterpret_cast<f32x4*>(dst) = v;
-            } else if (cb < p.split) {
-                *reinterpret_cast<f32x4*>(p.y0 + pix * p.y0_pitch + p.y0_coff + cb) = v;
-            } else {
-                *reinterpret_cast<f32x4*>(p.y1 + pix * p.y1_pitch + p.y1_coff + (cb - p.split)) = v;
-            }
-        }
+    switch (p.act) {
+        case ESR_ACT_LRELU: epilogue<ESR_ACT_LRELU, NT>(p, acc, n, x0, y0, wv, px, kq); break;
+        case ESR_ACT_RELU: epilogue<ESR_ACT_RELU, NT>(p, acc, n, x0, y0, wv, px, kq); break;
+        case ESR_ACT_GELU: epilogue<ESR_ACT_GELU, NT>(p, acc, n, x0, y0, wv, px, kq); break;
+        default: epilogue<ESR_ACT_NONE, NT>(p, acc, n, x0, y0, wv, px, kq); break;
     }
 }
 
@@ -378,8 +425,16 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
         if (!d->res.ptr || (d->res.pitch & 3) || (d->res.coff & 3) || d->res.coff + cout4 > d->res.pitch)
             return ESR_ERR_BAD_ARG;
     }
-    // 32-bit element offsets inside the kernel
-    if ((double)d->n * d->h * d->w * (in_nchw ? 4 : d->in.pitch) >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
+    // 32-bit element offsets inside the kernel; per-image raw buffers < 2 GiB (OOB offset 0x80000000)
+    {
+        const double px_all = (double)d->n * d->h * d->w, px_img = (double)d->h * d->w;
+        int maxpitch = in_nchw ? 4 : d->in.pitch;
+        if (d->out_layout == ESR_NHWC) maxpitch = maxpitch > d->out0.pitch ? maxpitch : d->out0.pitch;
+        if (d->out_layout == ESR_NHWC && d->out1.ptr) maxpitch = maxpitch > d->out1.pitch ? maxpitch : d->out1.pitch;
+        if (d->res_mode != ESR_RES_NONE) maxpitch = maxpitch > d->res.pitch ? maxpitch : d->res.pitch;
+        if (px_all * maxpitch >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
+        if (px_img * (in_nchw ? d->cin : d->in.pitch) * 4.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
+    }
 
     const int nt = round_up(d->cout, 16) / 16;
     const int taps = d->ksize * d->ksize;

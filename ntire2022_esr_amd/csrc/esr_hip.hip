@@ -85,23 +85,48 @@ __device__ __forceinline__ void epilogue(const ConvK& p, f32x4 (&acc)[NT][4], in
     const int gx = x0 + px;
     if (gx >= p.W) return;
     const bool shuffle = p.out_layout == ESR_NCHW_SHUFFLE4;
+    int pix[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pix[r] = (n * p.H + min(y0 + wv * 4 + r, p.H - 1)) * p.W + gx;   // < 2^31 / pitch (host-checked)
+
+    // All residual loads are issued up front: a load->wait->add->store chain per float4 would
+    // serialise 16 round trips (vmcnt counts the preceding store too).
+    if (p.res_mode != ESR_RES_NONE) {
+        f32x4 rv[NT][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int cb = min(t * 16 + kq * 4, p.cout_store - 4);
+                rv[t][r] = *reinterpret_cast<const f32x4*>(p.res + (size_t)(pix[r] * p.res_pitch + p.res_coff + cb));
+            }
+        if (p.res_mode == ESR_RES_PRE_ACT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t][r] = act4<ACT>(acc[t][r] + rv[t][r], p.slope);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t][r] = act4<ACT>(acc[t][r], p.slope) + rv[t][r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t][r] = act4<ACT>(acc[t][r], p.slope);
+    }
+
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int gy = y0 + wv * 4 + r;
         if (gy >= p.H) continue;
-        const int pix = (n * p.H + gy) * p.W + gx;          // < 2^31 / pitch (checked on the host)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int cb = t * 16 + kq * 4;                 // first of this lane's 4 output channels
             if (cb >= p.cout_store) continue;
-            f32x4 v = acc[t][r];
-            if (p.res_mode != ESR_RES_NONE) {
-                const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (size_t)(pix * p.res_pitch + p.res_coff + cb));
-                if (p.res_mode == ESR_RES_PRE_ACT) v = act4<ACT>(v + rv, p.slope);
-                else v = act4<ACT>(v, p.slope) + rv;
-            } else {
-                v = act4<ACT>(v, p.slope);
-            }
+            const f32x4 v = acc[t][r];
             if (shuffle) {
                 // out[n, t, 4gy+kq, 4gx+0..3]  (channel 16t + 4kq + j)
                 const size_t W4 = (size_t)p.W * 4, H4 = (size_t)p.H * 4;
@@ -109,9 +134,9 @@ __device__ __forceinline__ void epilogue(const ConvK& p, f32x4 (&acc)[NT][4], in
                 float* dst = p.y0 + (((size_t)n * nco + t) * H4 + (size_t)gy * 4 + kq) * W4 + (size_t)gx * 4;
                 *reinterpret_cast<f32x4*>(dst) = v;
             } else if (cb < p.split) {
-                *reinterpret_cast<f32x4*>(p.y0 + (size_t)(pix * p.y0_pitch + p.y0_coff + cb)) = v;
+                *reinterpret_cast<f32x4*>(p.y0 + (size_t)(pix[r] * p.y0_pitch + p.y0_coff + cb)) = v;
             } else {
-                *reinterpret_cast<f32x4*>(p.y1 + (size_t)(pix * p.y1_pitch + p.y1_coff + (cb - p.split))) = v;
+                *reinterpret_cast<f32x4*>(p.y1 + (size_t)(pix[r] * p.y1_pitch + p.y1_coff + (cb - p.split))) = v;
             }
         }
     }

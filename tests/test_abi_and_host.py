@@ -1,0 +1,126 @@
+"""CPU-only (-m "not gpu"): the C-ABI library loads and exports every symbol include/esr_hip.h
+declares, the host-side packer round-trips, argument validation rejects bad descriptors without a
+GPU, and the product refuses to run without one (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_sd_torch
+
+
+def _header_symbols():
+    txt = open(os.path.join(REPO, "include", "esr_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(esr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ntire2022_esr_amd import _lib as L
+    lib = L.lib()
+    syms = _header_symbols()
+    assert len(syms) >= 10
+    for s in syms:
+        assert hasattr(lib, s), f"libesr_hip.so does not export {s}"
+    assert set(L.EXPORTS) == set(syms), (set(L.EXPORTS) ^ set(syms))
+    assert lib.esr_abi_version() == 1
+    assert b"gfx950" in lib.esr_build_info()
+
+
+def test_no_reference_or_oracle_import_in_product():
+    """The product path must never route through oracle/ (or /root/reference)."""
+    pkg = os.path.join(REPO, "ntire2022_esr_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+                assert "/root/reference" not in src, f
+
+
+@pytest.mark.parametrize("cin,cout,k", [(64, 64, 3), (48, 16, 3), (3, 64, 3), (100, 50, 1), (50, 25, 1), (12, 12, 3)])
+def test_pack_roundtrip(cin, cout, k):
+    from ntire2022_esr_amd.engine import pack_conv, unpack_conv
+    g = torch.Generator().manual_seed(cin + cout + k)
+    w, b = torch.randn(cout, cin, k, k, generator=g), torch.randn(cout, generator=g)
+    blob = pack_conv(w, b)
+    w2, b2 = unpack_conv(blob, cin, cout, k)
+    assert torch.equal(w, w2) and torch.equal(b, b2)
+    # padded lanes are exactly zero (keeps pad channels at act(0)=0 downstream)
+    nz = int((blob != 0).sum())
+    assert nz <= w.numel() + b.numel()
+
+
+def test_pack_with_channel_map():
+    from ntire2022_esr_amd.engine import pack_conv, unpack_conv
+    w, b = torch.randn(32, 20, 1, 1), torch.randn(32)
+    cmap = list(range(10)) + [-1, -1] + list(range(10, 20)) + [-1, -1]
+    blob = pack_conv(w, b, cin_map=cmap)
+    w2, b2 = unpack_conv(blob, 20, 32, 1, cin_map=cmap)
+    assert torch.equal(w, w2) and torch.equal(b, b2)
+
+
+def test_linear_weights_pack_as_1x1():
+    from ntire2022_esr_amd.engine import pack_conv
+    w, b = torch.randn(24, 48), torch.randn(24)
+    assert torch.equal(pack_conv(w, b), pack_conv(w[:, :, None, None], b))
+
+
+def test_descriptor_validation_without_gpu():
+    """esr_conv2d_f32 validates before it launches: bad descriptors fail identically on a CPU-only host."""
+    from ntire2022_esr_amd import _lib as L
+    lib = L.lib()
+    d = L.ConvDesc()
+    assert lib.esr_conv2d_f32(ctypes.byref(d), None) == -1          # null pointers
+    assert lib.esr_conv2d_f32(None, None) == -1
+    buf = (ctypes.c_float * 16)()
+    d.inp = L.View(ctypes.addressof(buf), 64, 0)
+    d.out0 = L.View(ctypes.addressof(buf), 64, 0)
+    d.wpacked = ctypes.addressof(buf)
+    d.n, d.h, d.w, d.cin, d.cout, d.ksize = 1, 4, 4, 64, 64, 5
+    assert lib.esr_conv2d_f32(ctypes.byref(d), None) == -2          # k = 5 unsupported
+    d.ksize, d.cout = 3, 80
+    assert lib.esr_conv2d_f32(ctypes.byref(d), None) == -2          # cout > 64
+    d.cout, d.inp.pitch = 64, 62
+    assert lib.esr_conv2d_f32(ctypes.byref(d), None) == -1          # pitch not a multiple of 4
+    d.inp.pitch, d.inp.coff = 64, 16
+    assert lib.esr_conv2d_f32(ctypes.byref(d), None) == -1          # chunked reads would leave the pixel
+    assert lib.esr_run_ops(None, 1, None) == -1
+    assert lib.esr_packed_conv_bytes(64, 64, 2) == 0
+
+
+def test_module_surface_and_no_cpu_fallback():
+    from ntire2022_esr_amd import IMDN, _lib as L
+    m = IMDN(in_nc=3, out_nc=3, nc=64, nb=8, upscale=4, act_mode='L', upsample_mode='pixelshuffle', negative_slope=0.05)
+    missing, unexpected = m.load_state_dict(load_sd_torch("imdn_baseline"), strict=True)
+    assert not missing and not unexpected
+    assert sum(p.numel() for p in m.parameters()) == 893936                # figs/results.png: 0.894 M
+    m.eval()
+    for _, v in m.named_parameters():                                        # test_demo.py:338-339
+        v.requires_grad = False
+    assert list(m.parameters())[-1].device.type == "cpu"                    # model_summary.py:37 idiom
+    with pytest.raises(L.EsrError, match="no CPU fallback"):
+        m(torch.rand(1, 3, 16, 16))
+    with pytest.raises(NotImplementedError):
+        IMDN(upsample_mode="upconv")
+    with pytest.raises(AssertionError):
+        IMDN(act_mode="X")
+    m7 = IMDN(nb=7)                                                           # id 26, test_demo.py:203-209
+    assert len(m7.state_dict()) == 86 - 10
+
+
+def test_imdn_plan_shape():
+    """The op list is 3 + 5*nb launches and its workspace matches the documented layout."""
+    from ntire2022_esr_amd import IMDN
+    from ntire2022_esr_amd.engine import Plan
+    m = IMDN()
+    plan = Plan(2, 40, 56)
+    m._build_plan(plan, 3)
+    assert len(plan.ops) == 3 + 5 * 8
+    assert plan.total == 2 * 40 * 56 * (64 * 4 + 48 * 2)
+    assert m.workspace_bytes(2, 40, 56) == plan.total * 4
+    total_macs = sum(o["cin"] * o["cout"] * o["k"] ** 2 for o in plan.ops)
+    assert total_macs == 891584                                                # MAC per LR pixel

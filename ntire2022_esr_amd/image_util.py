@@ -1,0 +1,72 @@
+"""Host-side image conversion and metric helpers around the forward path.
+
+Restates the six `utils/utils_image.py` functions `test_demo.run()` calls
+with PIL instead of cv2 (PNG/BMP decoding is lossless, so the arrays are identical):
+  imread_uint :122-134   imsave :137-141   uint2tensor4 :190-193
+  tensor2uint :204-208   modcrop :442-455  calculate_psnr :490-503
+Pinned against the reference's own outputs in tests/test_harness.py (tests/golden/metrics.*).
+"""
+import math
+import os
+
+import numpy as np
+import torch
+from PIL import Image
+
+
+def imread_uint(path, n_channels=3):
+    """HxWx3 uint8 RGB (gray images become GGG), or HxWx1 for n_channels=1."""
+    img = Image.open(path)
+    if n_channels == 1:
+        return np.expand_dims(np.array(img.convert("L")), axis=2)
+    if img.mode in ("L", "1", "I;16", "I"):
+        g = np.array(img.convert("L"))
+        return np.stack([g, g, g], axis=2)
+    return np.array(img.convert("RGB"))
+
+
+def imsave(img, img_path):
+    img = np.squeeze(img)
+    os.makedirs(os.path.dirname(os.path.abspath(img_path)), exist_ok=True)
+    Image.fromarray(img).save(img_path)
+
+
+def uint2tensor4(img, data_range):
+    """HWC uint8 -> 1xCxHxW fp32 scaled to [0, data_range] (division by 255/data_range in fp32)."""
+    if img.ndim == 2:
+        img = np.expand_dims(img, axis=2)
+    return torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float().div(255. / data_range).unsqueeze(0)
+
+
+def tensor2uint(img, data_range):
+    """clamp(0, data_range) -> *255/data_range in fp32 -> round half to even -> uint8, HWC.
+    Unlike the reference (which clamps its argument IN PLACE through views, utils_image.py:205) the
+    input tensor is left untouched; the returned array is identical."""
+    t = img.detach().squeeze().float().clamp(0, 1 * data_range).cpu().numpy()
+    if t.ndim == 3:
+        t = np.transpose(t, (1, 2, 0))
+    return np.uint8((t * 255.0 / data_range).round())
+
+
+def modcrop(img_in, scale):
+    img = np.copy(img_in)
+    if img.ndim == 2:
+        h, w = img.shape
+        return img[:h - h % scale, :w - w % scale]
+    if img.ndim == 3:
+        h, w, _ = img.shape
+        return img[:h - h % scale, :w - w % scale, :]
+    raise ValueError('Wrong img ndim: [{:d}].'.format(img.ndim))
+
+
+def calculate_psnr(img1, img2, border=0):
+    """RGB PSNR on uint8 arrays in [0,255]: crop `border`, fp64 MSE over all samples, inf when identical."""
+    if not img1.shape == img2.shape:
+        raise ValueError('Input images must have the same dimensions.')
+    h, w = img1.shape[:2]
+    a = img1[border:h - border, border:w - border].astype(np.float64)
+    b = img2[border:h - border, border:w - border].astype(np.float64)
+    mse = np.mean((a - b) ** 2)
+    if mse == 0:
+        return float('inf')
+    return 20 * math.log10(255.0 / math.sqrt(mse))

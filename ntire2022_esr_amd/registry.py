@@ -1,0 +1,46 @@
+"""Model registry for the hot-path networks: the entries of `select_model` (test_demo.py:13-341)
+this engine implements.  Returns (model, name, data_range, tile) like the reference; weights come from
+`model_zoo/<ckpt>.pth` when a reference checkout is given, else from this repo's exported
+`weights/<ckpt>.safetensors` (same tensors, key for key)."""
+import os
+
+import torch
+
+_REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# model_id -> (display name, checkpoint stem, data_range, tile, ctor)
+def _entries():
+    from .imdn import IMDN
+    return {
+        -1: ("IMDN_baseline", "imdn_baseline", 1.0, None, lambda: IMDN(in_nc=3, out_nc=3, nc=64, nb=8, upscale=4)),
+    }
+
+
+def supported_ids():
+    return sorted(_entries())
+
+
+def load_checkpoint(stem, model_zoo=None):
+    """state_dict for `stem`; unwraps the containers the reference unwraps (test_demo.py:157 'params')."""
+    if model_zoo is not None:
+        for ext in (".pth", ".pt"):
+            p = os.path.join(model_zoo, stem + ext)
+            if os.path.exists(p):
+                sd = torch.load(p, map_location="cpu", weights_only=False)   # imdn_baseline.pth holds CUDA storages
+                return sd["params"] if isinstance(sd, dict) and "params" in sd and len(sd) == 1 else sd
+    from safetensors.torch import load_file
+    return load_file(os.path.join(_REPO, "weights", stem + ".safetensors"))
+
+
+def select_model(model_id, device, model_zoo=None):
+    ent = _entries().get(model_id)
+    if ent is None:
+        raise NotImplementedError(f"Model {model_id} is not implemented.")       # test_demo.py:333
+    disp, stem, data_range, tile, ctor = ent
+    name = f"{model_id:02}_{disp}"
+    model = ctor()
+    model.load_state_dict(load_checkpoint(stem, model_zoo), strict=True)
+    model.eval()
+    for _, v in model.named_parameters():
+        v.requires_grad = False
+    return model.to(device), name, data_range, tile

@@ -1,0 +1,37 @@
+"""-m gpu: the evaluation loop end to end on the HIP engine over the committed 3-image DIV2K-shaped set,
+against the PSNRs the real reference produced for the same files."""
+import json
+import logging
+import os
+import types
+
+import pytest
+import torch
+
+from conftest import GOLD
+
+pytestmark = pytest.mark.gpu
+
+
+def test_harness_on_mini_div2k(tmp_path):
+    from ntire2022_esr_amd import harness as H
+    from ntire2022_esr_amd.registry import select_model, supported_ids
+    assert -1 in supported_ids()
+    dev = torch.device("cuda:0")
+    model, name, data_range, tile = select_model(-1, dev)
+    assert name == "-1_IMDN_baseline" and data_range == 1.0 and tile is None
+    with pytest.raises(NotImplementedError):
+        select_model(99, dev)
+    args = types.SimpleNamespace(data_dir=os.path.join(GOLD, "mini_div2k"), save_dir=str(tmp_path), rank=0, world=1)
+    pairs = H.select_dataset(args.data_dir, "valid")[:3]
+    res = H.run(model, name, data_range, tile, logging.getLogger("gpu"), dev, args, mode="valid", pairs=pairs)
+    ref = json.load(open(os.path.join(GOLD, "mini_div2k", "reference_psnr.json")))["imdn_baseline"]
+    for a, b in zip(res["valid_psnr"], ref["valid_psnr"]):
+        assert abs(a - b) < 0.002
+    assert abs(res["valid_ave_psnr"] - ref["valid_ave_psnr"]) < 0.002
+    assert res["valid_memory"] > 0 and all(t > 0 for t in res["valid_runtime"])
+    # tiled forward (test_demo.py:368-389) agrees with whole-image inference away from tile seams' halo
+    x = torch.rand(1, 3, 96, 80, device=dev)
+    whole = H.forward(x, model, None)
+    tiled = H.forward(x, model, tile=64, tile_overlap=32)
+    assert tiled.shape == whole.shape and float((tiled - whole).abs().mean()) < 0.05

@@ -1,0 +1,147 @@
+"""Host logic around the path (CPU, -m "not gpu"): image/metric helpers vs the reference's pinned outputs,
+analytic complexity counters vs model_summary's numbers, results.txt layout, round-robin sharding and the
+gathered run() under a 2-process gloo group (the oracle port stands in for the model on CPU)."""
+import json
+import logging
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, REPO, load_sd_torch
+from ntire2022_esr_amd import dist as D
+from ntire2022_esr_amd import harness as H
+from ntire2022_esr_amd import image_util as util
+
+
+def test_image_util_matches_reference_pins():
+    m = np.load(os.path.join(GOLD, "metrics.npz"))
+    mj = json.load(open(os.path.join(GOLD, "metrics.json")))
+    for dr in (1, 255):
+        assert np.array_equal(util.uint2tensor4(m["a"], float(dr)).numpy(), m[f"u2t_{dr}"])
+        x = torch.from_numpy(m[f"t2u_in_{dr}"].copy())
+        x0 = x.clone()
+        assert np.array_equal(util.tensor2uint(x, float(dr)), m[f"t2u_out_{dr}"])    # incl. .5 ties (half-to-even)
+        assert torch.equal(x, x0), "tensor2uint must not clamp its argument in place"
+    assert util.calculate_psnr(m["a"], m["b"], border=4) == mj["psnr_ab_border4"]
+    assert util.calculate_psnr(m["a"], m["b"], border=0) == mj["psnr_ab_border0"]
+    assert util.calculate_psnr(m["p1"], m["p2"], border=4) == mj["psnr_p1p2_border4"]
+    assert util.calculate_psnr(m["a"], m["a"], border=4) == float("inf")
+    with pytest.raises(ValueError):
+        util.calculate_psnr(m["a"], m["p1"])
+    assert list(util.modcrop(np.zeros((1357, 2041, 3), np.uint8), 4).shape) == mj["modcrop_1357x2041x3"]
+    assert list(util.modcrop(np.zeros((30, 30), np.uint8), 4).shape) == mj["modcrop_30x30"]
+    with pytest.raises(ValueError):
+        util.modcrop(np.zeros((2, 2, 2, 2)), 4)
+
+
+def test_imread_imsave_roundtrip(tmp_path):
+    img = np.random.RandomState(0).randint(0, 256, (13, 17, 3)).astype(np.uint8)
+    p = str(tmp_path / "sub" / "x.png")
+    util.imsave(img, p)
+    assert np.array_equal(util.imread_uint(p, 3), img)
+    from PIL import Image
+    Image.fromarray(img[..., 0]).save(str(tmp_path / "g.png"))
+    g = util.imread_uint(str(tmp_path / "g.png"), 3)
+    assert g.shape == (13, 17, 3) and np.array_equal(g[..., 0], g[..., 2])          # gray -> GGG
+    assert util.imread_uint(str(tmp_path / "g.png"), 1).shape == (13, 17, 1)
+
+
+def test_complexity_counters_match_model_summary():
+    from ntire2022_esr_amd import IMDN
+    from ntire2022_esr_amd.summary import model_complexity
+    want = json.load(open(os.path.join(GOLD, "summary.json")))["imdn_baseline"]
+    assert model_complexity(IMDN(), (3, 256, 256)) == want
+    # published table (figs/results.png): 0.894 M / 58.53 G / 154.14 M / 43
+    assert round(want["flops"] / 1e9, 2) == 58.53 and round(want["activations"] / 1e6, 2) == 154.14
+
+
+def test_results_table_layout():
+    r = {"-1_IMDN_baseline": dict(valid_ave_psnr=29.1312, valid_ave_runtime=1.2345, num_parameters=0.893936,
+                                  flops=58.5315, activations=154.1407, valid_memory=471.76, num_conv=43,
+                                  test_ave_psnr=28.78, test_ave_runtime=2.0)}
+    t = H.results_table(r, include_test=False).split("\n")
+    assert t[0].split("\t")[0].strip() == "Model" and len(t[0].split("\t")) == 8
+    cells = [c.strip() for c in t[1].split("\t")]
+    assert cells == ["-1_IMDN_baseline", "29.13", "1.23", "0.894", "58.53", "154.14", "471.76", "43"]
+    t2 = H.results_table(r, include_test=True).split("\n")
+    assert len(t2[0].split("\t")) == 11 and [c.strip() for c in t2[1].split("\t")][5] == "1.62"
+
+
+def test_select_dataset_paths():
+    v = H.select_dataset("/d", "valid")
+    assert len(v) == 100 and v[0] == ("/d/DIV2K_valid_LR/0801x4.png", "/d/DIV2K_valid_HR/0801.png")
+    t = H.select_dataset("/d", "test")
+    assert t[-1] == ("/d/DIV2K_test_LR/1000.png", "/d/DIV2K_test_HR/1000.png")
+
+
+def test_tiled_forward_equals_whole_image_for_a_pointwise_model():
+    up = torch.nn.Upsample(scale_factor=4, mode="nearest")
+    x = torch.rand(1, 3, 70, 90)
+    assert torch.allclose(H.forward(x, up, tile=48, tile_overlap=32), up(x))
+    assert torch.equal(H.forward(x, up, tile=None), up(x))
+
+
+def test_shard_and_gather_single_process():
+    assert D.shard(10, 1, 4) == [1, 5, 9] and D.shard(3, 3, 4) == []
+    rows = [(i, 1.0 + i, 30.0 + i, float("nan")) for i in range(5)]
+    a = D.gather_rows(rows, 5, 0, 1, torch.device("cpu"))
+    assert a.shape == (5, 4) and list(a[:, 0]) == [0, 1, 2, 3, 4]
+    with pytest.raises(RuntimeError):
+        D.gather_rows(rows[:4], 5, 0, 1, torch.device("cpu"))
+    assert D.ordered_mean([0.1, 0.2, 0.3]) == sum([0.1, 0.2, 0.3]) / 3
+
+
+class _OracleModel:
+    """CPU stand-in for the GPU module in host-logic tests: the pinned oracle port."""
+    def __init__(self):
+        from oracle import torch_port as TP
+        self.sd, self.f = load_sd_torch("imdn_baseline"), TP.imdn
+
+    def __call__(self, x):
+        with torch.no_grad():
+            return self.f(self.sd, x)
+
+
+def _run_rank(rank, world, port, save_dir, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    torch.set_num_threads(2)
+    r, w, _ = D.init_from_env(use_cuda=False)
+    args = types.SimpleNamespace(data_dir=os.path.join(GOLD, "mini_div2k"), save_dir=save_dir, rank=r, world=w)
+    pairs = H.select_dataset(args.data_dir, "valid")[:3]
+    logger = logging.getLogger(f"t{rank}")
+    res = H.run(_OracleModel(), "imdn", 1.0, None, logger, torch.device("cpu"), args, mode="valid", pairs=pairs)
+    if r == 0:
+        json.dump(res, open(out, "w"))
+    if w > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_run_world2_gloo_equals_world1_and_reference(tmp_path):
+    import torch.multiprocessing as mp
+    ref = json.load(open(os.path.join(GOLD, "mini_div2k", "reference_psnr.json")))["imdn_baseline"]
+    out1, out2 = str(tmp_path / "w1.json"), str(tmp_path / "w2.json")
+    _run_rank(0, 1, 0, str(tmp_path / "s1"), out1)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    mp.spawn(_run_rank, args=(2, 29533, str(tmp_path / "s2"), out2), nprocs=2, join=True)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    r1, r2 = json.load(open(out1)), json.load(open(out2))
+    assert r1["valid_psnr"] == r2["valid_psnr"]                      # bit-identical for W in {1,2}
+    assert r1["valid_ave_psnr"] == r2["valid_ave_psnr"]
+    assert len(r2["valid_runtime"]) == 3 and set(r2) == {"valid_runtime", "valid_psnr", "valid_memory",
+                                                          "valid_ave_runtime", "valid_ave_psnr"}
+    for a, b in zip(r1["valid_psnr"], ref["valid_psnr"]):
+        assert abs(a - b) < 0.002                                    # per-image |dPSNR| budget
+    assert abs(r1["valid_ave_psnr"] - ref["valid_ave_psnr"]) < 0.002
+    # every rank wrote its own SR PNGs under save_dir/<model>/valid/
+    assert sorted(os.listdir(str(tmp_path / "s2" / "imdn" / "valid"))) == ["0801.png", "0802.png", "0803.png"]

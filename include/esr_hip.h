@@ -103,16 +103,54 @@ int    esr_unpack_conv_f32(const void* packed, size_t bytes, int cin, int cout, 
 int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream);
 
 /*
+ * ESA (enhanced spatial attention) -- models/rfdn_baseline/block.py:103-129, models/team04_rlfn.py:62-89,
+ * models/team18_bsrn.py:91-122.  The f = n_feats/4 (12) or esa_channels (16) wide maps live in NHWC buffers of
+ * pitch ESR_ESA_FP = 16 whose pad channels are zero.  Small dense weights use the plain layout written by
+ * esr_pack_dense_f32: [tap][cin_p][cout_p] floats followed by bias[cout_p].
+ *
+ *   esr_conv3x3s2_f32   conv2: nn.Conv2d(f, f, 3, stride 2, padding 0)   H2 = (H-3)/2+1  (block.py:110,119)
+ *   esr_maxpool7s3_f32  F.max_pool2d(kernel_size=7, stride=3)             H3 = (H2-7)/3+1 (block.py:120)
+ *   esr_esa_apply_f32   y = x * sigmoid(conv4(bilinear(c3 -> HxW, align_corners=False) + conv_f(c1_)))
+ *                       (block.py:124-129): one full-resolution pass, x read once, y written once.
+ */
+#define ESR_ESA_FP 16
+
+size_t esr_packed_dense_bytes(int cin_p, int cout_p, int ksize);
+int    esr_pack_dense_f32(const float* w_oihw, const float* bias, int cin, int cout, int ksize,
+                          int cin_p, int cout_p, void* out, size_t out_bytes);
+
+typedef struct esr_esa_desc {
+    int32_t n, h, w;            /* full-resolution dims */
+    int32_t c;                  /* n_feats (logical channels of x / y) */
+    int32_t f;                  /* ESA width (<= 16) */
+    int32_t h_lo, w_lo;         /* dims of the low-resolution map (source of the op) */
+    int32_t reserved;
+    esr_view x;                 /* apply: block input x ; conv3x3s2 / maxpool: source map (pitch 16) */
+    esr_view y;                 /* destination */
+    const void* c1;             /* apply: c1_ = conv1(x), [n*h*w][16] */
+    const void* c3;             /* apply: low-res map [n][h_lo][w_lo][16] */
+    const void* w0;             /* conv3x3s2: packed dense k=3 ; apply: conv_f packed dense k=1 (16 x 16) */
+    const void* w1;             /* apply: conv4 packed dense k=1 (16 x round_up(c,4)) */
+} esr_esa_desc;
+
+int esr_conv3x3s2_f32(const esr_esa_desc* d, void* hip_stream);   /* x: [n][h][w][16] -> y: [n][h_lo][w_lo][16] */
+int esr_maxpool7s3_f32(const esr_esa_desc* d, void* hip_stream);  /* x: [n][h][w][16] -> y: [n][h_lo][w_lo][16] */
+int esr_esa_apply_f32(const esr_esa_desc* d, void* hip_stream);
+
+/*
  * A forward pass is a flat list of ops executed in order on one stream: the native
  * replacement for test_demo.py's `model(img_lq)` (forward(), test_demo.py:364-367).
  * The Python host builds the list once per (model, N, H, W) and replays it.
  */
-typedef enum esr_op_kind { ESR_OP_CONV = 0 } esr_op_kind;
+typedef enum esr_op_kind {
+    ESR_OP_CONV = 0, ESR_OP_CONV3X3S2 = 1, ESR_OP_MAXPOOL7S3 = 2, ESR_OP_ESA_APPLY = 3
+} esr_op_kind;
 
 typedef struct esr_op {
     int32_t kind;               /* esr_op_kind */
     int32_t reserved;
-    esr_conv_desc conv;
+    esr_conv_desc conv;         /* ESR_OP_CONV */
+    esr_esa_desc esa;           /* the three ESA kinds */
 } esr_op;
 
 int esr_run_ops(const esr_op* ops, int n_ops, void* hip_stream);

@@ -7,5 +7,7 @@ Package contents (only what the path needs):
   imdn.py ...  drop-in nn.Modules with the reference's ctor / state_dict surface
 """
 from .imdn import IMDN  # noqa: F401
+from .rfdn import RFDN  # noqa: F401
+from .rlfn import RLFN_cut  # noqa: F401
 
-__all__ = ["IMDN"]
+__all__ = ["IMDN", "RFDN", "RLFN_cut"]

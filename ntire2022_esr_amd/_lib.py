@@ -16,7 +16,8 @@ STATUS = {0: "ESR_OK", -1: "ESR_ERR_BAD_ARG", -2: "ESR_ERR_UNSUPPORTED", -3: "ES
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
 RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
 NHWC, NCHW_IN, NCHW_SHUFFLE4 = 0, 1, 2
-OP_CONV = 0
+OP_CONV, OP_CONV3X3S2, OP_MAXPOOL7S3, OP_ESA_APPLY = 0, 1, 2, 3
+ESA_FP = 16
 
 
 class View(ctypes.Structure):
@@ -35,8 +36,18 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class EsaDesc(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_int32), ("h", ctypes.c_int32), ("w", ctypes.c_int32),
+        ("c", ctypes.c_int32), ("f", ctypes.c_int32), ("h_lo", ctypes.c_int32), ("w_lo", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("x", View), ("y", View),
+        ("c1", ctypes.c_void_p), ("c3", ctypes.c_void_p), ("w0", ctypes.c_void_p), ("w1", ctypes.c_void_p),
+    ]
+
+
 class Op(ctypes.Structure):
-    _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("conv", ConvDesc)]
+    _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("conv", ConvDesc), ("esa", EsaDesc)]
 
 
 # every symbol include/esr_hip.h declares (tests check the .so exports all of them)
@@ -45,6 +56,8 @@ EXPORTS = [
     "esr_packed_conv_bytes", "esr_pack_conv_f32", "esr_unpack_conv_f32",
     "esr_conv2d_f32", "esr_run_ops",
     "esr_prof_create", "esr_run_ops_profiled", "esr_prof_collect", "esr_prof_destroy",
+    "esr_packed_dense_bytes", "esr_pack_dense_f32",
+    "esr_conv3x3s2_f32", "esr_maxpool7s3_f32", "esr_esa_apply_f32",
 ]
 
 _lib = None
@@ -77,6 +90,13 @@ def lib():
     L.esr_conv2d_f32.restype = ci
     L.esr_run_ops.argtypes = [ctypes.POINTER(Op), ci, vp]
     L.esr_run_ops.restype = ci
+    L.esr_packed_dense_bytes.argtypes = [ci, ci, ci]
+    L.esr_packed_dense_bytes.restype = sz
+    L.esr_pack_dense_f32.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, sz]
+    L.esr_pack_dense_f32.restype = ci
+    for fn in (L.esr_conv3x3s2_f32, L.esr_maxpool7s3_f32, L.esr_esa_apply_f32):
+        fn.argtypes = [ctypes.POINTER(EsaDesc), vp]
+        fn.restype = ci
     L.esr_prof_create.argtypes = [ci, ci, ctypes.POINTER(vp)]
     L.esr_prof_create.restype = ci
     L.esr_run_ops_profiled.argtypes = [ctypes.POINTER(Op), ci, vp, vp]

@@ -1,0 +1,239 @@
+// esr_esa.hip -- the ESA (enhanced spatial attention) kernels of libesr_hip.so.  Interface: include/esr_hip.h.
+//
+// ESA.forward (models/rfdn_baseline/block.py:117-129, models/team04_rlfn.py:76-89):
+//     c1_ = conv1(x)                      1x1 C->f           -> conv_f32_kernel (esr_hip.hip)
+//     c1  = conv2(c1_)                    3x3 s2 p0 f->f     -> conv3x3s2_kernel
+//     v   = max_pool2d(c1, 7, 3)                             -> maxpool7s3_kernel
+//     c3  = conv stack on v (41x41)       3x3 p1 f->f        -> conv_f32_kernel
+//     y   = x * sigmoid(conv4(bilinear(c3) + conv_f(c1_)))   -> esa_apply_kernel (one full-res pass)
+// All three are memory/latency-bound VALU kernels (<= 1 % of a network's MACs); the f-wide maps are
+// NHWC with pitch 16 and zero pad channels, so every access is a float4.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include "esr_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int FP = ESR_ESA_FP;   // 16
+
+// ---- 3x3 stride 2, no padding, FP -> FP --------------------------------------------------------
+// thread = (output pixel, quad of 4 output channels); weights [tap][cin][cout] in LDS.
+__global__ __launch_bounds__(256) void conv3x3s2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                        float* __restrict__ y, int N, int H, int W, int Ho, int Wo)
+{
+    __shared__ __attribute__((aligned(16))) float sw[9 * FP * FP + FP];
+    for (int i = threadIdx.x; i < 9 * FP * FP + FP; i += 256) sw[i] = wp[i];
+    __syncthreads();
+    const int q = threadIdx.x & 3;
+    const long long pix = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
+    if (pix >= (long long)N * Ho * Wo) return;
+    const int ox = (int)(pix % Wo);
+    const int oy = (int)((pix / Wo) % Ho);
+    const int n = (int)(pix / ((long long)Wo * Ho));
+    f32x4 acc = *reinterpret_cast<const f32x4*>(sw + 9 * FP * FP + q * 4);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float* xp = x + (((size_t)n * H + (oy * 2 + ky)) * W + (ox * 2 + kx)) * FP;
+            const float* wt = sw + (ky * 3 + kx) * FP * FP + q * 4;
+#pragma unroll
+            for (int cq = 0; cq < FP / 4; ++cq) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + cq * 4);
+                acc += xv.x * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 0) * FP);
+                acc += xv.y * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 1) * FP);
+                acc += xv.z * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 2) * FP);
+                acc += xv.w * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 3) * FP);
+            }
+        }
+    *reinterpret_cast<f32x4*>(y + (size_t)pix * FP + q * 4) = acc;
+}
+
+// ---- max pool 7x7 stride 3, floor mode, no padding ---------------------------------------------
+__global__ __launch_bounds__(256) void maxpool7s3_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H,
+                                                         int W, int Ho, int Wo)
+{
+    const int q = threadIdx.x & 3;
+    const long long pix = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
+    if (pix >= (long long)N * Ho * Wo) return;
+    const int ox = (int)(pix % Wo);
+    const int oy = (int)((pix / Wo) % Ho);
+    const int n = (int)(pix / ((long long)Wo * Ho));
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int ky = 0; ky < 7; ++ky) {
+        const float* row = x + (((size_t)n * H + (oy * 3 + ky)) * W + ox * 3) * FP + q * 4;
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + kx * FP);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    *reinterpret_cast<f32x4*>(y + (size_t)pix * FP + q * 4) = m;
+}
+
+// ---- fused ESA tail ------------------------------------------------------------------------------
+// 16 lanes per pixel (4 pixels per wave); lane g handles output channels 4g..4g+3.  Every lane rebuilds
+// the FP-wide vector s = bilinear(c3) + conv_f(c1_) of its pixel (redundant across the 16 lanes: ~400
+// FMAs, cheaper than a cross-lane exchange and far below the memory time of the pass).
+struct EsaK {
+    const float* x; const float* c1; const float* c3; const float* wf; const float* w4; float* y;
+    int x_pitch, x_coff, y_pitch, y_coff;
+    int N, H, W, Cp4, cp, h3, w3;
+    float sh, sw;
+};
+
+__global__ __launch_bounds__(256) void esa_apply_kernel(const EsaK p)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // wf: FP*FP + FP ; w4: FP*cp + cp
+    const int nwf = FP * FP + FP, nw4 = FP * p.cp + p.cp;
+    for (int i = threadIdx.x; i < nwf; i += 256) sm[i] = p.wf[i];
+    for (int i = threadIdx.x; i < nw4; i += 256) sm[nwf + i] = p.w4[i];
+    __syncthreads();
+    const int g = threadIdx.x & 15;
+    const long long pix = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (pix >= (long long)p.N * p.H * p.W || g * 4 >= p.Cp4) return;
+    const int ox = (int)(pix % p.W);
+    const int oy = (int)((pix / p.W) % p.H);
+    const int n = (int)(pix / ((long long)p.W * p.H));
+
+    // bilinear source coordinates: ATen area_pixel_compute_source_index, fused multiply-add (see oracle)
+    float fy = fmaf((float)oy + 0.5f, p.sh, -0.5f);
+    fy = fy < 0.f ? 0.f : fy;
+    const int y0 = (int)fy, y1 = y0 + (y0 < p.h3 - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, hy = 1.f - ly;
+    float fx = fmaf((float)ox + 0.5f, p.sw, -0.5f);
+    fx = fx < 0.f ? 0.f : fx;
+    const int x0 = (int)fx, x1 = x0 + (x0 < p.w3 - 1 ? 1 : 0);
+    const float lx = fx - (float)x0, hx = 1.f - lx;
+    const float* c00 = p.c3 + (((size_t)n * p.h3 + y0) * p.w3 + x0) * FP;
+    const float* c01 = p.c3 + (((size_t)n * p.h3 + y0) * p.w3 + x1) * FP;
+    const float* c10 = p.c3 + (((size_t)n * p.h3 + y1) * p.w3 + x0) * FP;
+    const float* c11 = p.c3 + (((size_t)n * p.h3 + y1) * p.w3 + x1) * FP;
+    const float* c1p = p.c1 + (size_t)pix * FP;
+
+    float s[FP];
+#pragma unroll
+    for (int qd = 0; qd < FP / 4; ++qd) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(c00 + qd * 4), b = *reinterpret_cast<const f32x4*>(c01 + qd * 4);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(c10 + qd * 4), d = *reinterpret_cast<const f32x4*>(c11 + qd * 4);
+        const f32x4 bf = *reinterpret_cast<const f32x4*>(sm + FP * FP + qd * 4);
+        const f32x4 v = hy * (hx * a + lx * b) + ly * (hx * c + lx * d) + bf;
+        s[qd * 4 + 0] = v.x; s[qd * 4 + 1] = v.y; s[qd * 4 + 2] = v.z; s[qd * 4 + 3] = v.w;
+    }
+    // + conv_f(c1_):  s[o] += sum_i c1[i] * Wf[i][o]
+#pragma unroll
+    for (int iq = 0; iq < FP / 4; ++iq) {
+        const f32x4 cv = *reinterpret_cast<const f32x4*>(c1p + iq * 4);
+        const float ci[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float* wr = sm + (iq * 4 + k) * FP;
+#pragma unroll
+            for (int o = 0; o < FP; ++o) s[o] = fmaf(ci[k], wr[o], s[o]);
+        }
+    }
+    // conv4 for this lane's 4 channels, sigmoid, multiply
+    const float* w4 = sm + nwf;
+    f32x4 m = *reinterpret_cast<const f32x4*>(w4 + FP * p.cp + g * 4);
+#pragma unroll
+    for (int i = 0; i < FP; ++i) m += s[i] * *reinterpret_cast<const f32x4*>(w4 + i * p.cp + g * 4);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + (size_t)pix * p.x_pitch + p.x_coff + g * 4);
+    f32x4 o;
+    o.x = xv.x * (1.f / (1.f + expf(-m.x)));
+    o.y = xv.y * (1.f / (1.f + expf(-m.y)));
+    o.z = xv.z * (1.f / (1.f + expf(-m.z)));
+    o.w = xv.w * (1.f / (1.f + expf(-m.w)));
+    *reinterpret_cast<f32x4*>(p.y + (size_t)pix * p.y_pitch + p.y_coff + g * 4) = o;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t esr_packed_dense_bytes(int cin_p, int cout_p, int ksize)
+{
+    if (cin_p <= 0 || cout_p <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    return ((size_t)ksize * ksize * cin_p * cout_p + cout_p) * sizeof(float);
+}
+
+int esr_pack_dense_f32(const float* w, const float* bias, int cin, int cout, int ksize, int cin_p, int cout_p,
+                       void* out, size_t out_bytes)
+{
+    if (!w || !out || cin <= 0 || cout <= 0 || cin > cin_p || cout > cout_p) return ESR_ERR_BAD_ARG;
+    const size_t need = esr_packed_dense_bytes(cin_p, cout_p, ksize);
+    if (need == 0 || out_bytes < need) return ESR_ERR_BAD_ARG;
+    float* o = static_cast<float*>(out);
+    memset(o, 0, need);
+    const int taps = ksize * ksize;
+    for (int oc = 0; oc < cout; ++oc)
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < taps; ++t)
+                o[((size_t)t * cin_p + c) * cout_p + oc] = w[((size_t)oc * cin + c) * taps + t];
+    if (bias)
+        for (int oc = 0; oc < cout; ++oc) o[(size_t)taps * cin_p * cout_p + oc] = bias[oc];
+    return ESR_OK;
+}
+
+static int lowres_args_ok(const esr_esa_desc* d)
+{
+    if (!d || !d->x.ptr || !d->y.ptr) return ESR_ERR_BAD_ARG;
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0) return ESR_ERR_BAD_ARG;
+    if (d->x.pitch != FP || d->y.pitch != FP || d->x.coff || d->y.coff) return ESR_ERR_BAD_ARG;
+    return ESR_OK;
+}
+
+int esr_conv3x3s2_f32(const esr_esa_desc* d, void* hip_stream)
+{
+    int rc = lowres_args_ok(d);
+    if (rc != ESR_OK) return rc;
+    if (!d->w0) return ESR_ERR_BAD_ARG;
+    if (d->h < 3 || d->w < 3) return ESR_ERR_TOO_SMALL;
+    const int Ho = (d->h - 3) / 2 + 1, Wo = (d->w - 3) / 2 + 1;
+    if (d->h_lo != Ho || d->w_lo != Wo) return ESR_ERR_BAD_ARG;
+    const long long npix = (long long)d->n * Ho * Wo;
+    hipLaunchKernelGGL(conv3x3s2_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                       static_cast<const float*>(d->x.ptr), static_cast<const float*>(d->w0), static_cast<float*>(d->y.ptr),
+                       d->n, d->h, d->w, Ho, Wo);
+    return esr_check_launch("conv3x3s2_kernel launch");
+}
+
+int esr_maxpool7s3_f32(const esr_esa_desc* d, void* hip_stream)
+{
+    int rc = lowres_args_ok(d);
+    if (rc != ESR_OK) return rc;
+    if (d->h < 7 || d->w < 7) return ESR_ERR_TOO_SMALL;
+    const int Ho = (d->h - 7) / 3 + 1, Wo = (d->w - 7) / 3 + 1;
+    if (d->h_lo != Ho || d->w_lo != Wo) return ESR_ERR_BAD_ARG;
+    const long long npix = (long long)d->n * Ho * Wo;
+    hipLaunchKernelGGL(maxpool7s3_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                       static_cast<const float*>(d->x.ptr), static_cast<float*>(d->y.ptr), d->n, d->h, d->w, Ho, Wo);
+    return esr_check_launch("maxpool7s3_kernel launch");
+}
+
+int esr_esa_apply_f32(const esr_esa_desc* d, void* hip_stream)
+{
+    if (!d || !d->x.ptr || !d->y.ptr || !d->c1 || !d->c3 || !d->w0 || !d->w1) return ESR_ERR_BAD_ARG;
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->c <= 0 || d->c > 64 || d->f <= 0 || d->f > FP) return ESR_ERR_BAD_ARG;
+    if (d->h_lo <= 0 || d->w_lo <= 0) return ESR_ERR_TOO_SMALL;
+    const int cp4 = esr_round_up(d->c, 4);
+    if ((d->x.pitch & 3) || (d->x.coff & 3) || d->x.coff + cp4 > d->x.pitch) return ESR_ERR_BAD_ARG;
+    if ((d->y.pitch & 3) || (d->y.coff & 3) || d->y.coff + cp4 > d->y.pitch) return ESR_ERR_BAD_ARG;
+    EsaK k;
+    k.x = static_cast<const float*>(d->x.ptr); k.c1 = static_cast<const float*>(d->c1);
+    k.c3 = static_cast<const float*>(d->c3); k.wf = static_cast<const float*>(d->w0);
+    k.w4 = static_cast<const float*>(d->w1); k.y = static_cast<float*>(d->y.ptr);
+    k.x_pitch = d->x.pitch; k.x_coff = d->x.coff; k.y_pitch = d->y.pitch; k.y_coff = d->y.coff;
+    k.N = d->n; k.H = d->h; k.W = d->w; k.Cp4 = cp4; k.cp = cp4; k.h3 = d->h_lo; k.w3 = d->w_lo;
+    k.sh = (float)d->h_lo / (float)d->h;      // ATen area_pixel_compute_scale: float(in) / out
+    k.sw = (float)d->w_lo / (float)d->w;
+    const long long npix = (long long)d->n * d->h * d->w;
+    const size_t lds = ((size_t)FP * FP + FP + (size_t)FP * cp4 + cp4) * sizeof(float);
+    hipLaunchKernelGGL(esa_apply_kernel, dim3((unsigned)((npix + 15) / 16)), dim3(256), lds, static_cast<hipStream_t>(hip_stream), k);
+    return esr_check_launch("esa_apply_kernel launch");
+}
+
+}  // extern "C"

@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include "esr_hip.h"
+#include "esr_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -308,12 +309,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
 
 thread_local char g_err[256] = "";
 
-void set_err(const char* what, hipError_t e)
-{
-    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
-}
-
-inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline void set_err(const char* what, hipError_t e) { esr_set_err(what, e); }
+inline int round_up(int v, int m) { return esr_round_up(v, m); }
 
 template <int NT, int KS, bool IN_NCHW>
 int launch_conv(const ConvK& k, hipStream_t st)
@@ -341,6 +338,21 @@ int launch_conv_nt(int nt, const ConvK& k, hipStream_t st)
 }
 
 }  // namespace
+
+void esr_set_err(const char* what, hipError_t e)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+}
+
+int esr_check_launch(const char* what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        esr_set_err(what, e);
+        return ESR_ERR_LAUNCH;
+    }
+    return ESR_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // C ABI
@@ -489,6 +501,17 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
     return launch_conv_nt<1, false>(nt, k, st);
 }
 
+static int run_one(const esr_op& op, void* hip_stream)
+{
+    switch (op.kind) {
+        case ESR_OP_CONV: return esr_conv2d_f32(&op.conv, hip_stream);
+        case ESR_OP_CONV3X3S2: return esr_conv3x3s2_f32(&op.esa, hip_stream);
+        case ESR_OP_MAXPOOL7S3: return esr_maxpool7s3_f32(&op.esa, hip_stream);
+        case ESR_OP_ESA_APPLY: return esr_esa_apply_f32(&op.esa, hip_stream);
+        default: return ESR_ERR_BAD_ARG;
+    }
+}
+
 struct esr_profiler {
     int n_ops, max_passes, passes;
     hipEvent_t* ev;   // [max_passes][n_ops][2]
@@ -531,7 +554,7 @@ int esr_run_ops_profiled(const esr_op* ops, int n_ops, void* hip_stream, esr_pro
     hipEvent_t* ev = p->ev + (size_t)p->passes * n_ops * 2;
     for (int i = 0; i < n_ops; ++i) {
         (void)hipEventRecord(ev[2 * i], st);
-        const int rc = ops[i].kind == ESR_OP_CONV ? esr_conv2d_f32(&ops[i].conv, hip_stream) : ESR_ERR_BAD_ARG;
+        const int rc = run_one(ops[i], hip_stream);
         (void)hipEventRecord(ev[2 * i + 1], st);
         if (rc != ESR_OK) return rc;
     }
@@ -564,11 +587,7 @@ int esr_run_ops(const esr_op* ops, int n_ops, void* hip_stream)
 {
     if (!ops || n_ops < 0) return ESR_ERR_BAD_ARG;
     for (int i = 0; i < n_ops; ++i) {
-        int rc;
-        switch (ops[i].kind) {
-            case ESR_OP_CONV: rc = esr_conv2d_f32(&ops[i].conv, hip_stream); break;
-            default: rc = ESR_ERR_BAD_ARG;
-        }
+        const int rc = run_one(ops[i], hip_stream);
         if (rc != ESR_OK) return rc;
     }
     return ESR_OK;

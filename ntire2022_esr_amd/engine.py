@@ -49,6 +49,21 @@ def pack_conv(weight, bias, cin_map=None, cin_phys=None):
     return out
 
 
+def pack_dense(weight, bias, cin_p, cout_p):
+    """Plain [tap][cin_p][cout_p] + bias[cout_p] layout of the small ESA kernels (esr_pack_dense_f32)."""
+    lib = L.lib()
+    w = weight.detach().to("cpu", torch.float32).contiguous()
+    if w.dim() == 2:
+        w = w[:, :, None, None].contiguous()
+    cout, cin, k, _ = w.shape
+    b = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
+    nbytes = lib.esr_packed_dense_bytes(cin_p, cout_p, k)
+    out = torch.empty(nbytes // 4, dtype=torch.float32)
+    L.check(lib.esr_pack_dense_f32(_ptr(w), _ptr(b) if b is not None else None, cin, cout, k, cin_p, cout_p,
+                                   _ptr(out), nbytes), "esr_pack_dense_f32")
+    return out
+
+
 def unpack_conv(blob, cin, cout, k, cin_map=None, cin_phys=None):
     lib = L.lib()
     blob = blob.detach().to("cpu", torch.float32).contiguous()
@@ -66,10 +81,10 @@ def unpack_conv(blob, cin, cout, k, cin_map=None, cin_phys=None):
 
 
 class Buffer:
-    """An NHWC fp32 activation buffer inside the workspace: [N*H*W][pitch]."""
+    """An NHWC fp32 activation buffer inside the workspace: [n][h][w][pitch]."""
 
-    def __init__(self, name, pitch, offset_floats):
-        self.name, self.pitch, self.offset = name, pitch, offset_floats
+    def __init__(self, name, pitch, offset_floats, h=None, w=None):
+        self.name, self.pitch, self.offset, self.h, self.w = name, pitch, offset_floats, h, w
 
     def __getitem__(self, sl):
         """buf[a:b] -> channel slice view (coff=a, channels=b-a)."""
@@ -92,18 +107,33 @@ class Plan:
         self.buffers = []
         self.ops = []          # python dicts until finalize()
 
-    def buffer(self, name, pitch):
+    def buffer(self, name, pitch, h=None, w=None):
+        """Full-resolution buffer by default; (h, w) gives a low-resolution one (ESA maps)."""
         assert pitch % 4 == 0
-        b = Buffer(name, pitch, self.total)
-        self.total += self.npix * pitch
+        h = self.h if h is None else h
+        w = self.w if w is None else w
+        b = Buffer(name, pitch, self.total, h, w)
+        self.total += self.n * h * w * pitch
         self.buffers.append(b)
         return b
 
     def conv(self, wname, src, dst, cin, cout, k=3, act=L.ACT_NONE, slope=0.05,
-             res=None, res_mode=L.RES_NONE, dst1=None, split=0):
-        """src/dst/res: INPUT | OUTPUT | Buffer | (Buffer, coff, channels)."""
-        self.ops.append(dict(w=wname, src=src, dst=dst, dst1=dst1, cin=cin, cout=cout, k=k, act=act,
-                             slope=slope, res=res, res_mode=res_mode, split=split))
+             res=None, res_mode=L.RES_NONE, dst1=None, split=0, hw=None, counted=True):
+        """src/dst/res: INPUT | OUTPUT | Buffer | (Buffer, coff, channels).  hw: spatial dims if not full-res.
+        counted=False marks launches that are not an nn.Conv2d call of the reference (complexity counters)."""
+        self.ops.append(dict(kind="conv", w=wname, src=src, dst=dst, dst1=dst1, cin=cin, cout=cout, k=k, act=act,
+                             slope=slope, res=res, res_mode=res_mode, split=split, hw=hw, counted=counted))
+
+    def conv3x3s2(self, wname, src, dst, f):
+        self.ops.append(dict(kind="s2", w=wname, src=src, dst=dst, f=f, cin=f, cout=f, k=3, act=L.ACT_NONE,
+                             hw=(dst.h, dst.w), counted=True))
+
+    def maxpool7s3(self, src, dst):
+        self.ops.append(dict(kind="pool", src=src, dst=dst))
+
+    def esa_apply(self, wf, w4, x, c1, c3, dst, c, f):
+        """y = x * sigmoid(conv4(bilinear(c3) + conv_f(c1)));  two nn.Conv2d calls of the reference."""
+        self.ops.append(dict(kind="apply", wf=wf, w4=w4, x=x, c1=c1, c3=c3, dst=dst, c=c, f=f))
 
     @staticmethod
     def _view(v, base_ptr):
@@ -119,9 +149,32 @@ class Plan:
         base = workspace.data_ptr() if workspace is not None else 0
         for i, o in enumerate(self.ops):
             op = arr[i]
+            if o["kind"] != "conv":
+                e = op.esa
+                e.n = self.n
+                if o["kind"] == "apply":
+                    op.kind = L.OP_ESA_APPLY
+                    e.h, e.w, e.c, e.f = self.h, self.w, o["c"], o["f"]
+                    e.h_lo, e.w_lo = o["c3"].h, o["c3"].w
+                    e.x, e.y = self._view(o["x"], base), self._view(o["dst"], base)
+                    e.c1 = ctypes.c_void_p(base + o["c1"].offset * 4)
+                    e.c3 = ctypes.c_void_p(base + o["c3"].offset * 4)
+                    e.w0 = ctypes.c_void_p(weights[o["wf"]].data_ptr())
+                    e.w1 = ctypes.c_void_p(weights[o["w4"]].data_ptr())
+                else:
+                    op.kind = L.OP_CONV3X3S2 if o["kind"] == "s2" else L.OP_MAXPOOL7S3
+                    e.h, e.w = o["src"].h, o["src"].w
+                    e.h_lo, e.w_lo = o["dst"].h, o["dst"].w
+                    e.x, e.y = self._view(o["src"], base), self._view(o["dst"], base)
+                    if o["kind"] == "s2":
+                        e.f = o["f"]
+                        e.w0 = ctypes.c_void_p(weights[o["w"]].data_ptr())
+                continue
             op.kind = L.OP_CONV
             d = op.conv
             d.n, d.h, d.w = self.n, self.h, self.w
+            if o["hw"] is not None:
+                d.h, d.w = o["hw"]
             d.cin, d.cout, d.ksize = o["cin"], o["cout"], o["k"]
             d.act, d.slope, d.res_mode = o["act"], o["slope"], o["res_mode"]
             d.split = o["split"]
@@ -152,6 +205,7 @@ class HipSRModel(nn.Module):
     def __init__(self):
         super().__init__()
         self._conv_specs = {}      # path -> (cin, cout, k, cin_map)
+        self._dense_specs = {}     # path -> (cin_p, cout_p): small ESA weights in the plain dense layout
         self._packed = None        # path -> device blob
         self._packed_sig = None
         self._plans = {}
@@ -159,7 +213,7 @@ class HipSRModel(nn.Module):
         self._profs = {}
 
     # -- parameter registration: same key names as the reference state_dict -------------------
-    def _add_conv(self, path, cin, cout, k, cin_map=None, linear=False):
+    def _add_conv(self, path, cin, cout, k, cin_map=None, linear=False, dense=None, stride=1, padding=None):
         """Create nested containers so that `path + '.weight'` / `path + '.bias'` are the
         state_dict keys (e.g. 'model.1.sub.0.conv1.0').  The leaf is an nn.Conv2d / nn.Linear
         used purely as a parameter holder with the reference's shapes and default init."""
@@ -169,9 +223,12 @@ class HipSRModel(nn.Module):
             if p not in mod._modules:
                 mod.add_module(p, nn.Module())
             mod = mod._modules[p]
-        leaf = nn.Linear(cin, cout) if linear else nn.Conv2d(cin, cout, k, 1, (k - 1) // 2)
+        leaf = nn.Linear(cin, cout) if linear else nn.Conv2d(cin, cout, k, stride, (k - 1) // 2 if padding is None else padding)
         mod.add_module(parts[-1], leaf)
-        self._conv_specs[path] = (cin, cout, k, cin_map)
+        if dense is not None:
+            self._dense_specs[path] = dense
+        else:
+            self._conv_specs[path] = (cin, cout, k, cin_map)
 
     def _leaf(self, path):
         mod = self
@@ -188,6 +245,9 @@ class HipSRModel(nn.Module):
         for path, (cin, cout, k, cin_map) in self._conv_specs.items():
             leaf = self._leaf(path)
             packed[path] = pack_conv(leaf.weight, leaf.bias, cin_map=cin_map).to(device)
+        for path, (cin_p, cout_p) in self._dense_specs.items():
+            leaf = self._leaf(path)
+            packed[path] = pack_dense(leaf.weight, leaf.bias, cin_p, cout_p).to(device)
         self._extra_pack(packed, device)
         self._packed = packed
         self._packed_sig = self._signature()
@@ -217,7 +277,7 @@ class HipSRModel(nn.Module):
         if ent is None:
             plan = Plan(n, h, w)
             self._build_plan(plan, c)
-            ws = torch.empty(max(plan.total, 4), dtype=torch.float32, device=x.device)
+            ws = torch.zeros(max(plan.total, 4), dtype=torch.float32, device=x.device)   # pad channels must be 0
             arr, in_idx, out_idx = plan.finalize(ws, self._packed)
             ent = (arr, in_idx, out_idx, ws, plan)
             if len(self._plans) > 8:
@@ -264,12 +324,32 @@ class HipSRModel(nn.Module):
             passes = ctypes.c_int(0)
             L.check(L.lib().esr_prof_collect(prof, ms, n, ctypes.byref(passes)), "esr_prof_collect")
             for i, o in enumerate(plan.ops):
+                if o["kind"] != "conv":
+                    kern = {"s2": "conv3x3s2_kernel", "pool": "maxpool7s3_kernel", "apply": "esa_apply_kernel"}[o["kind"]]
+                    out.append(dict(name=o.get("w", o["kind"]), kernel=kern, cin=0, cout=0, k=0, flops=0.0,
+                                    ms_sum=ms[i], passes=passes.value))
+                    continue
                 nt = (o["cout"] + 15) // 16
                 kern = f"conv_f32_kernel<NT={nt},KS={o['k']},NCHW_IN={int(o['src'] is INPUT)}>"
+                npix = plan.npix if o["hw"] is None else plan.n * o["hw"][0] * o["hw"][1]
                 out.append(dict(name=o["w"], kernel=kern, cin=o["cin"], cout=o["cout"], k=o["k"],
-                                flops=2.0 * plan.npix * o["cin"] * o["cout"] * o["k"] * o["k"],
+                                flops=2.0 * npix * o["cin"] * o["cout"] * o["k"] * o["k"],
                                 ms_sum=ms[i], passes=passes.value))
         return out
+
+    def _counted_convs(self, plan, o):
+        """nn.Conv2d calls of the REFERENCE graph that op `o` stands for: (cin, cout, k, pixels, act) tuples
+        (logical channel counts as the reference's hooks see them)."""
+        if o["kind"] == "conv":
+            if not o.get("counted", True):
+                return []
+            npix = plan.npix if o["hw"] is None else plan.n * o["hw"][0] * o["hw"][1]
+            return [(o["cin"], o["cout"], o["k"], npix, o["act"])]
+        if o["kind"] == "s2":
+            return [(o["f"], o["f"], 3, plan.n * o["dst"].h * o["dst"].w, L.ACT_NONE)]
+        if o["kind"] == "apply":   # conv_f (f->f) and conv4 (f->c), both full resolution
+            return [(o["f"], o["f"], 1, plan.npix, L.ACT_NONE), (o["f"], o["c"], 1, plan.npix, L.ACT_NONE)]
+        return []
 
     def workspace_bytes(self, n, h, w, c=3):
         plan = Plan(n, h, w)

@@ -1,0 +1,103 @@
+"""RFDN (x4) on the HIP engine -- drop-in for `models.rfdn_baseline.RFDN.RFDN` (RFDN.py:11-41; ids 0, 6, 22).
+
+Same constructor keywords and the same 128 state_dict keys.  nf=50 lives in NHWC buffers of pitch 56 (six
+zero pad channels); the 25-channel distilled maps are stored as 28-wide slices of one 112-wide concat buffer
+and the four block outputs as 56-wide slices of one 224-wide buffer, so neither torch.cat
+(rfdn_baseline/block.py:163, RFDN.py:36) exists as a kernel: the following 1x1 convs are packed with a
+`cin_map` that skips the pad slots.  Per RFDB (block.py:148-166): {1x1 distil + LeakyReLU, 3x3 + input
+residual + LeakyReLU} x3, 3x3 50->25 + LeakyReLU, 1x1 c5 over the concat, ESA.
+"""
+from . import _lib as L
+from .engine import INPUT, OUTPUT, HipSRModel
+from .rlfn import FP, _lowres, _pad8
+
+
+def _slice_map(n_slices, logical, padded):
+    """physical slot -> logical channel for `n_slices` slices of `logical` channels padded to `padded`."""
+    return [(s // padded) * logical + s % padded if s % padded < logical else -1 for s in range(n_slices * padded)]
+
+
+class RFDN(HipSRModel):
+    def __init__(self, in_nc=3, nf=50, num_modules=4, out_nc=3, upscale=4):
+        super().__init__()
+        if upscale != 4 or nf > 64 or in_nc > 4 or out_nc * 16 > 64 or num_modules != 4:
+            raise NotImplementedError('HIP RFDN supports upscale=4, nf <= 64, 4 modules, in_nc <= 4, out_nc <= 4')
+        self.in_nc, self.out_nc, self.nf, self.num_modules, self.upscale = in_nc, out_nc, nf, num_modules, upscale
+        self.dc = nf // 2
+        self.f = nf // 4
+        self.scale_idx = 0
+        nf, dc, f = self.nf, self.dc, self.f
+        self.P, self.DP = _pad8(nf), (dc + 3) // 4 * 4
+        cp4 = (nf + 3) // 4 * 4
+        self._add_conv('fea_conv', in_nc, nf, 3)
+        for k in range(1, 5):
+            b = f'B{k}.'
+            for j in (1, 2, 3):
+                self._add_conv(b + f'c{j}_d', nf, dc, 1)
+                self._add_conv(b + f'c{j}_r', nf, nf, 3)
+            self._add_conv(b + 'c4', nf, dc, 3)
+            self._add_conv(b + 'c5', dc * 4, nf, 1, cin_map=_slice_map(4, dc, self.DP))
+            self._add_conv(b + 'esa.conv1', nf, f, 1)
+            self._add_conv(b + 'esa.conv_f', f, f, 1, dense=(FP, FP))
+            self._add_conv(b + 'esa.conv_max', f, f, 3)
+            self._add_conv(b + 'esa.conv2', f, f, 3, dense=(FP, FP), stride=2, padding=0)
+            self._add_conv(b + 'esa.conv3', f, f, 3)
+            self._add_conv(b + 'esa.conv3_', f, f, 3)
+            self._add_conv(b + 'esa.conv4', f, nf, 1, dense=(FP, cp4))
+        self._add_conv('c.0', nf * num_modules, nf, 1, cin_map=_slice_map(num_modules, nf, self.P))
+        self._add_conv('LR_conv', nf, nf, 3)
+        self._add_conv('upsampler.0', nf, out_nc * upscale * upscale, 3)
+
+    def set_scale(self, scale_idx):
+        self.scale_idx = scale_idx
+
+    def _build_plan(self, plan, c):
+        if c != self.in_nc:
+            raise L.EsrError(f'RFDN expects {self.in_nc} input channels, got {c}')
+        if plan.h < 15 or plan.w < 15:
+            raise L.EsrError('ESA needs H, W >= 15 (3x3/s2 then 7x7/s3 pooling)')
+        nf, dc, f, P, DP = self.nf, self.dc, self.f, self.P, self.DP
+        h2, w2, h3, w3 = _lowres(plan.h, plan.w)
+        fea = plan.buffer('fea', P)
+        bcat = plan.buffer('bcat', 4 * P)                 # the four block outputs, RFDN.py:36
+        cat = plan.buffer('cat', _pad8(4 * DP))           # d1 d2 d3 r4, block.py:163
+        r1, r2 = plan.buffer('r1', P), plan.buffer('r2', P)
+        v = plan.buffer('v', P)
+        c1 = plan.buffer('esa_c1', FP)
+        lo2 = plan.buffer('esa_s2', FP, h2, w2)
+        la, lb = plan.buffer('esa_a', FP, h3, w3), plan.buffer('esa_b', FP, h3, w3)
+        act = dict(act=L.ACT_LRELU, slope=0.05)
+        lo = dict(hw=(h3, w3))
+        plan.conv('fea_conv', INPUT, fea, self.in_nc, nf)
+        cur = fea
+        for k in range(1, 5):
+            b = f'B{k}.'
+            plan.conv(b + 'c1_d', cur, cat[0:DP], nf, dc, k=1, **act)
+            plan.conv(b + 'c1_r', cur, r1, nf, nf, res=cur, res_mode=L.RES_PRE_ACT, **act)
+            plan.conv(b + 'c2_d', r1, cat[DP:2 * DP], nf, dc, k=1, **act)
+            plan.conv(b + 'c2_r', r1, r2, nf, nf, res=r1, res_mode=L.RES_PRE_ACT, **act)
+            plan.conv(b + 'c3_d', r2, cat[2 * DP:3 * DP], nf, dc, k=1, **act)
+            plan.conv(b + 'c3_r', r2, r1, nf, nf, res=r2, res_mode=L.RES_PRE_ACT, **act)
+            plan.conv(b + 'c4', r1, cat[3 * DP:4 * DP], nf, dc, **act)
+            plan.conv(b + 'c5', cat, v, 4 * DP, nf, k=1)
+            plan.conv(b + 'esa.conv1', v, c1, nf, f, k=1)
+            plan.conv3x3s2(b + 'esa.conv2', c1, lo2, f)
+            plan.maxpool7s3(lo2, la)
+            plan.conv(b + 'esa.conv_max', la, lb, f, f, act=L.ACT_RELU, **lo)
+            plan.conv(b + 'esa.conv3', lb, la, f, f, act=L.ACT_RELU, **lo)
+            plan.conv(b + 'esa.conv3_', la, lb, f, f, **lo)
+            out = bcat[(k - 1) * P:k * P]
+            plan.esa_apply(b + 'esa.conv_f', b + 'esa.conv4', v, c1, lb, out, nf, f)
+            cur = out
+        plan.conv('c.0', bcat, v, 4 * P, nf, k=1, **act)
+        plan.conv('LR_conv', v, r1, nf, nf, res=fea, res_mode=L.RES_PRE_ACT)
+        plan.conv('upsampler.0', r1, OUTPUT, nf, self.out_nc * 16)
+
+    def _counted_convs(self, plan, o):
+        """logical channel counts for the padded-concat 1x1 convs (the reference sees 100 / 200 inputs)."""
+        r = super()._counted_convs(plan, o)
+        if o["kind"] == "conv" and o["w"].endswith('.c5'):
+            return [(self.dc * 4, o["cout"], 1, plan.npix, o["act"])]
+        if o["kind"] == "conv" and o["w"] == 'c.0':
+            return [(self.nf * self.num_modules, o["cout"], 1, plan.npix, o["act"])]
+        return r

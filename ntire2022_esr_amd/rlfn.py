@@ -1,0 +1,85 @@
+"""RLFN_cut (x4) on the HIP engine -- drop-in for `models.team04_rlfn.RLFN_cut` (team04_rlfn.py:124-155).
+
+Same constructor keywords and the same 78 state_dict keys (`fea_conv`, `B{k}.{c1_r,c2_r,c3_r,c5}`,
+`B{k}.esa.{conv1,conv_f,conv2,conv3,conv4}`, `LR_conv`, `upsampler.0`).  nf=46 lives in NHWC buffers of
+pitch 48 with two zero pad channels.  Per RLFB (team04_rlfn.py:109-122): three fused 3x3+LeakyReLU (the third
+adds the block input AFTER the activation), the 1x1 c5, then ESA as 1x1 conv1 -> 3x3/s2 -> maxpool 7/3 ->
+3x3 at ~H/6 -> one fused full-resolution tail (bilinear + conv_f + conv4 + sigmoid * x).
+"""
+from . import _lib as L
+from .engine import INPUT, OUTPUT, HipSRModel
+
+FP = L.ESA_FP
+
+
+def _pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def _lowres(h, w):
+    h2, w2 = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+    return h2, w2, (h2 - 7) // 3 + 1, (w2 - 7) // 3 + 1
+
+
+class RLFN_cut(HipSRModel):
+    def __init__(self, in_nc=3, out_nc=3, nf=46, mf=48, upscale=4):
+        super().__init__()
+        if upscale != 4 or nf > 64 or mf > 64 or in_nc > 4 or out_nc * 16 > 64:
+            raise NotImplementedError('HIP RLFN_cut supports upscale=4, nf/mf <= 64, in_nc <= 4, out_nc <= 4')
+        self.in_nc, self.out_nc, self.nf, self.mf, self.upscale = in_nc, out_nc, nf, mf, upscale
+        self.esa_channels = 16
+        self.scale_idx = 0
+        f = self.esa_channels
+        cp4 = (nf + 3) // 4 * 4
+        self._add_conv('fea_conv', in_nc, nf, 3)
+        for k in range(1, 5):
+            b = f'B{k}.'
+            self._add_conv(b + 'c1_r', nf, mf, 3)
+            self._add_conv(b + 'c2_r', mf, mf, 3)
+            self._add_conv(b + 'c3_r', mf, nf, 3)
+            self._add_conv(b + 'c5', nf, nf, 1)
+            self._add_conv(b + 'esa.conv1', nf, f, 1)
+            self._add_conv(b + 'esa.conv_f', f, f, 1, dense=(FP, FP))
+            self._add_conv(b + 'esa.conv2', f, f, 3, dense=(FP, FP), stride=2, padding=0)
+            self._add_conv(b + 'esa.conv3', f, f, 3)
+            self._add_conv(b + 'esa.conv4', f, nf, 1, dense=(FP, cp4))
+        self._add_conv('LR_conv', nf, nf, 3)
+        self._add_conv('upsampler.0', nf, out_nc * upscale * upscale, 3)
+
+    def set_scale(self, scale_idx):
+        self.scale_idx = scale_idx
+
+    def _build_plan(self, plan, c):
+        if c != self.in_nc:
+            raise L.EsrError(f'RLFN_cut expects {self.in_nc} input channels, got {c}')
+        if plan.h < 15 or plan.w < 15:
+            raise L.EsrError('ESA needs H, W >= 15 (3x3/s2 then 7x7/s3 pooling)')
+        nf, mf, f = self.nf, self.mf, self.esa_channels
+        P, M = _pad8(nf), _pad8(mf)
+        h2, w2, h3, w3 = _lowres(plan.h, plan.w)
+        fea = plan.buffer('fea', P)
+        xa, xb = plan.buffer('xa', P), plan.buffer('xb', P)
+        t1, t2 = plan.buffer('t1', M), plan.buffer('t2', M)
+        u, v = plan.buffer('u', P), plan.buffer('v', P)
+        c1 = plan.buffer('esa_c1', FP)
+        lo2 = plan.buffer('esa_s2', FP, h2, w2)
+        lo3 = plan.buffer('esa_pool', FP, h3, w3)
+        lo4 = plan.buffer('esa_c3', FP, h3, w3)
+        act = dict(act=L.ACT_LRELU, slope=0.05)
+        plan.conv('fea_conv', INPUT, fea, self.in_nc, nf)
+        cur, nxt = fea, xa
+        for k in range(1, 5):
+            b = f'B{k}.'
+            plan.conv(b + 'c1_r', cur, t1, nf, mf, **act)
+            plan.conv(b + 'c2_r', t1, t2, mf, mf, **act)
+            plan.conv(b + 'c3_r', t2, u, mf, nf, res=cur, res_mode=L.RES_POST_ACT, **act)
+            plan.conv(b + 'c5', u, v, nf, nf, k=1)
+            plan.conv(b + 'esa.conv1', v, c1, nf, f, k=1)
+            plan.conv3x3s2(b + 'esa.conv2', c1, lo2, f)
+            plan.maxpool7s3(lo2, lo3)
+            plan.conv(b + 'esa.conv3', lo3, lo4, f, f, hw=(h3, w3))
+            plan.esa_apply(b + 'esa.conv_f', b + 'esa.conv4', v, c1, lo4, nxt, nf, f)
+            cur = nxt
+            nxt = xb if cur is xa else xa
+        plan.conv('LR_conv', cur, u, nf, nf, res=fea, res_mode=L.RES_PRE_ACT)
+        plan.conv('upsampler.0', u, OUTPUT, nf, self.out_nc * 16)

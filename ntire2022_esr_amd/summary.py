@@ -19,13 +19,11 @@ def model_complexity(model, input_dim=(3, 256, 256)):
     acts = 0
     nconv = 0
     for o in plan.ops:
-        if o.get("kind", "conv") != "conv":
-            continue
-        npix = plan.npix
-        flops += o["k"] * o["k"] * o["cin"] * o["cout"] * npix
-        acts += o["cout"] * npix
-        nconv += 1
-        if o["act"] in (L.ACT_LRELU, L.ACT_RELU):
-            flops += o["cout"] * npix
+        for (cin, cout, k, npix, act) in model._counted_convs(plan, o):
+            flops += k * k * cin * cout * npix
+            acts += cout * npix
+            nconv += 1
+            if act in (L.ACT_LRELU, L.ACT_RELU):
+                flops += cout * npix
     return {"activations": float(acts), "num_conv": int(nconv), "flops": float(flops),
             "num_parameters": int(sum(p.numel() for p in model.parameters()))}

@@ -1,0 +1,146 @@
+"""-m gpu: ESA kernels per op vs ATen fp32 (CPU), RFDN / RLFN end to end vs the committed reference outputs
+and the C oracle.  Tolerance 2e-5 * data_range; both networks run at data_range 255."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLD, load_sd_numpy, load_sd_torch, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+DEV = "cuda:0"
+
+
+def _nhwc16(t):
+    """NCHW [N,f,H,W] -> NHWC pitch 16 with zero pads, on the GPU."""
+    n, f, h, w = t.shape
+    o = torch.zeros(n, h, w, 16)
+    o[..., :f] = t.permute(0, 2, 3, 1)
+    return o.to(DEV)
+
+
+def _esa_desc(L, n, h, w, h_lo, w_lo, x, y, **kw):
+    d = L.EsaDesc()
+    d.n, d.h, d.w, d.h_lo, d.w_lo = n, h, w, h_lo, w_lo
+    d.x = L.View(ctypes.c_void_p(x.data_ptr()), x.shape[-1], 0)
+    d.y = L.View(ctypes.c_void_p(y.data_ptr()), y.shape[-1], 0)
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d
+
+
+@pytest.mark.parametrize("f,hw", [(12, (31, 30)), (16, (15, 17)), (12, (127, 127)), (16, (64, 37))])
+def test_conv3x3s2_and_maxpool(f, hw):
+    from ntire2022_esr_amd import _lib as L
+    from ntire2022_esr_amd.engine import pack_dense
+    lib = L.lib()
+    g = torch.Generator().manual_seed(f + hw[0])
+    x = torch.randn(2, f, *hw, generator=g)
+    w, b = torch.randn(f, f, 3, 3, generator=g) * 0.2, torch.randn(f, generator=g)
+    ref = F.conv2d(x, w, b, stride=2)
+    h2, w2 = ref.shape[-2:]
+    xg = _nhwc16(x)
+    y = torch.zeros(2, h2, w2, 16, device=DEV)
+    pk = pack_dense(w, b, 16, 16).to(DEV)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d = _esa_desc(L, 2, hw[0], hw[1], h2, w2, xg, y, f=f, w0=pk.data_ptr())
+    L.check(lib.esr_conv3x3s2_f32(ctypes.byref(d), st), "s2")
+    yc = y.cpu()
+    assert float((yc[..., :f].permute(0, 3, 1, 2) - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.all(yc[..., f:] == 0)
+    if h2 >= 7 and w2 >= 7:
+        refp = F.max_pool2d(ref, 7, 3)
+        h3, w3 = refp.shape[-2:]
+        z = torch.zeros(2, h3, w3, 16, device=DEV)
+        d2 = _esa_desc(L, 2, h2, w2, h3, w3, y, z)
+        L.check(lib.esr_maxpool7s3_f32(ctypes.byref(d2), st), "pool")
+        assert torch.equal(z.cpu()[..., :f].permute(0, 3, 1, 2), F.max_pool2d(yc[..., :f].permute(0, 3, 1, 2), 7, 3))
+    d.h_lo += 1
+    assert lib.esr_conv3x3s2_f32(ctypes.byref(d), st) == -1          # inconsistent low-res dims rejected
+
+
+@pytest.mark.parametrize("c,f,hw,lo", [(50, 12, (40, 56), (5, 8)), (46, 16, (33, 17), (4, 1)), (48, 12, (64, 64), (9, 9)),
+                                       (50, 12, (20, 36), (1, 4))])
+def test_esa_apply(c, f, hw, lo):
+    """y = x * sigmoid(conv4(bilinear(c3) + conv_f(c1_)))  (rfdn_baseline/block.py:124-129)."""
+    from ntire2022_esr_amd import _lib as L
+    from ntire2022_esr_amd.engine import pack_dense
+    lib = L.lib()
+    g = torch.Generator().manual_seed(c + f + hw[0])
+    x = torch.randn(2, c, *hw, generator=g) * 30
+    c1 = torch.randn(2, f, *hw, generator=g)
+    c3 = torch.randn(2, f, *lo, generator=g)
+    wf, bf = torch.randn(f, f, 1, 1, generator=g) * 0.3, torch.randn(f, generator=g)
+    w4, b4 = torch.randn(c, f, 1, 1, generator=g) * 0.3, torch.randn(c, generator=g)
+    ref = x * torch.sigmoid(F.conv2d(F.interpolate(c3, hw, mode="bilinear", align_corners=False) + F.conv2d(c1, wf, bf), w4, b4))
+    pitch = (c + 7) // 8 * 8
+    xg = torch.zeros(2, *hw, pitch)
+    xg[..., :c] = x.permute(0, 2, 3, 1)
+    xg = xg.to(DEV)
+    y = torch.full((2, hw[0], hw[1], pitch + 8), 5.0, device=DEV)      # write into a slice of a wider buffer
+    cp4 = (c + 3) // 4 * 4
+    d = L.EsaDesc()
+    d.n, d.h, d.w, d.c, d.f, d.h_lo, d.w_lo = 2, hw[0], hw[1], c, f, lo[0], lo[1]
+    d.x = L.View(ctypes.c_void_p(xg.data_ptr()), pitch, 0)
+    d.y = L.View(ctypes.c_void_p(y.data_ptr()), pitch + 8, 8)
+    c1g, c3g = _nhwc16(c1), _nhwc16(c3)
+    pf, p4 = pack_dense(wf, bf, 16, 16).to(DEV), pack_dense(w4, b4, 16, cp4).to(DEV)
+    d.c1, d.c3, d.w0, d.w1 = c1g.data_ptr(), c3g.data_ptr(), pf.data_ptr(), p4.data_ptr()
+    L.check(lib.esr_esa_apply_f32(ctypes.byref(d), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "apply")
+    yc = y.cpu()
+    got = yc[..., 8:8 + c].permute(0, 3, 1, 2)
+    assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.all(yc[..., :8] == 5.0) and torch.all(yc[..., 8 + cp4:] == 5.0)
+
+
+def _model(name):
+    from ntire2022_esr_amd import RFDN, RLFN_cut
+    m = {"rfdn_baseline": RFDN, "team04_rlfn": lambda: RLFN_cut(in_nc=3, out_nc=3)}[name]()
+    m.load_state_dict(load_sd_torch(name), strict=True)
+    m.eval()
+    for p in m.parameters():
+        p.requires_grad = False
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("name", ["rfdn_baseline", "team04_rlfn"])
+def test_golden_e2e(name):
+    m = _model(name)
+    g = np.load(os.path.join(GOLD, f"e2e_{name}.npz"))
+    dr = float(g["data_range"])
+    for k in ("a", "b", "c"):
+        x = torch.from_numpy(g["x" + k]).to(DEV)
+        x0 = x.clone()
+        y = m(x)
+        assert y.shape == g["y" + k].shape
+        assert torch.equal(x, x0)
+        assert rel_err(y.cpu().numpy(), g["y" + k], dr) < TOL, (name, k)
+
+
+@pytest.mark.parametrize("name", ["rfdn_baseline", "team04_rlfn"])
+def test_vs_c_oracle_and_natural_image(name):
+    from oracle import models as OM
+    from PIL import Image
+    m = _model(name)
+    sd = load_sd_numpy(name)
+    dr = OM.DATA_RANGE[name]
+    rng = np.random.RandomState(7)
+    for shape in [(1, 3, 15, 15), (2, 3, 31, 18), (1, 3, 33, 47)]:
+        x = (rng.rand(*shape) * dr).astype(np.float32)
+        y = m(torch.from_numpy(x).to(DEV)).cpu().numpy()
+        assert rel_err(y, OM.FORWARD[name](sd, x), dr) < TOL, shape
+    with pytest.raises(Exception):
+        m(torch.rand(1, 3, 14, 20, device=DEV))                    # below ESA's minimum size
+    g = np.load(os.path.join(GOLD, f"img_{name}.npz"))
+    img = np.array(Image.open(os.path.join(GOLD, "test.bmp")).convert("RGB"))
+    x = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float().div(255.0 / dr).unsqueeze(0)
+    y = m(x.to(DEV)).cpu()
+    assert tuple(y.shape) == (1, 3, 1024, 1024)
+    assert rel_err(y[0, :, ::5, ::5].numpy(), g["sr_sample"], dr) < TOL
+    u8 = np.uint8((y[0].clamp(0, dr).permute(1, 2, 0).numpy() * 255.0 / dr).round())
+    crop = u8[400:528, 300:428]
+    assert np.mean(crop != g["sr_u8_crop"]) < 2e-4 and np.max(np.abs(crop.astype(int) - g["sr_u8_crop"].astype(int))) <= 1

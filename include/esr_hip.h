@@ -138,18 +138,28 @@ int esr_maxpool7s3_f32(const esr_esa_desc* d, void* hip_stream);  /* x: [n][h][w
 int esr_esa_apply_f32(const esr_esa_desc* d, void* hip_stream);
 
 /*
+ * esr_dwconv3x3_f32 -- depthwise nn.Conv2d(C, C, 3, 1, 1, groups=C, padding_mode="zeros") + the same fused
+ * epilogue as esr_conv2d_f32 (residual PRE/POST, activation).  The second half of BSConvU
+ * (models/team18_bsrn.py:70-88).  Uses esr_conv_desc with cin == cout == C, ksize == 3, NHWC in/out views
+ * (split/out1 unused) and `wpacked` = esr_pack_dw_f32 output: [tap][c_p] floats + bias[c_p], c_p = round_up(C,4).
+ */
+size_t esr_packed_dw_bytes(int c);
+int    esr_pack_dw_f32(const float* w_c133, const float* bias, int c, void* out, size_t out_bytes);
+int    esr_dwconv3x3_f32(const esr_conv_desc* d, void* hip_stream);
+
+/*
  * A forward pass is a flat list of ops executed in order on one stream: the native
  * replacement for test_demo.py's `model(img_lq)` (forward(), test_demo.py:364-367).
  * The Python host builds the list once per (model, N, H, W) and replays it.
  */
 typedef enum esr_op_kind {
-    ESR_OP_CONV = 0, ESR_OP_CONV3X3S2 = 1, ESR_OP_MAXPOOL7S3 = 2, ESR_OP_ESA_APPLY = 3
+    ESR_OP_CONV = 0, ESR_OP_CONV3X3S2 = 1, ESR_OP_MAXPOOL7S3 = 2, ESR_OP_ESA_APPLY = 3, ESR_OP_DWCONV = 4
 } esr_op_kind;
 
 typedef struct esr_op {
     int32_t kind;               /* esr_op_kind */
     int32_t reserved;
-    esr_conv_desc conv;         /* ESR_OP_CONV */
+    esr_conv_desc conv;         /* ESR_OP_CONV, ESR_OP_DWCONV */
     esr_esa_desc esa;           /* the three ESA kinds */
 } esr_op;
 

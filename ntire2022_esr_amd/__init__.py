@@ -6,8 +6,9 @@ Package contents (only what the path needs):
   engine.py    weight packing, workspace, op-list replay
   imdn.py ...  drop-in nn.Modules with the reference's ctor / state_dict surface
 """
+from .bsrn import BSRN  # noqa: F401
 from .imdn import IMDN  # noqa: F401
 from .rfdn import RFDN  # noqa: F401
 from .rlfn import RLFN_cut  # noqa: F401
 
-__all__ = ["IMDN", "RFDN", "RLFN_cut"]
+__all__ = ["BSRN", "IMDN", "RFDN", "RLFN_cut"]

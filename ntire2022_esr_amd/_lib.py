@@ -16,7 +16,7 @@ STATUS = {0: "ESR_OK", -1: "ESR_ERR_BAD_ARG", -2: "ESR_ERR_UNSUPPORTED", -3: "ES
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
 RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
 NHWC, NCHW_IN, NCHW_SHUFFLE4 = 0, 1, 2
-OP_CONV, OP_CONV3X3S2, OP_MAXPOOL7S3, OP_ESA_APPLY = 0, 1, 2, 3
+OP_CONV, OP_CONV3X3S2, OP_MAXPOOL7S3, OP_ESA_APPLY, OP_DWCONV = 0, 1, 2, 3, 4
 ESA_FP = 16
 
 
@@ -58,6 +58,7 @@ EXPORTS = [
     "esr_prof_create", "esr_run_ops_profiled", "esr_prof_collect", "esr_prof_destroy",
     "esr_packed_dense_bytes", "esr_pack_dense_f32",
     "esr_conv3x3s2_f32", "esr_maxpool7s3_f32", "esr_esa_apply_f32",
+    "esr_packed_dw_bytes", "esr_pack_dw_f32", "esr_dwconv3x3_f32",
 ]
 
 _lib = None
@@ -97,6 +98,12 @@ def lib():
     for fn in (L.esr_conv3x3s2_f32, L.esr_maxpool7s3_f32, L.esr_esa_apply_f32):
         fn.argtypes = [ctypes.POINTER(EsaDesc), vp]
         fn.restype = ci
+    L.esr_packed_dw_bytes.argtypes = [ci]
+    L.esr_packed_dw_bytes.restype = sz
+    L.esr_pack_dw_f32.argtypes = [vp, vp, ci, vp, sz]
+    L.esr_pack_dw_f32.restype = ci
+    L.esr_dwconv3x3_f32.argtypes = [ctypes.POINTER(ConvDesc), vp]
+    L.esr_dwconv3x3_f32.restype = ci
     L.esr_prof_create.argtypes = [ci, ci, ctypes.POINTER(vp)]
     L.esr_prof_create.restype = ci
     L.esr_run_ops_profiled.argtypes = [ctypes.POINTER(Op), ci, vp, vp]

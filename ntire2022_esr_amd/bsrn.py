@@ -1,0 +1,134 @@
+"""BSRN (x4) on the HIP engine -- drop-in for `models.team18_bsrn.BSRN` (team18_bsrn.py:182-236).
+
+Same constructor keywords and the same 247 state_dict keys (`*.pw.{weight[out,in],bias}`, `*.dw.weight[C,1,3,3]`,
+`B{k}.cw[1,C]`, `c1.weight[C,5C]`, `upsampler.upsampleOneStep.0.*`, ...).  Every nn.Linear on the permuted NHWC
+tensor is a 1x1 convolution in this engine's native layout (the reference's 131 permutes vanish); BSConvU
+(team18_bsrn.py:82-88) = 1x1 conv + depthwise 3x3 kernel with the residual / GELU fused into the depthwise
+epilogue.  Two load-time folds, both exact up to one fp32 rounding:
+  * `cat([x,x,x,x],1)` (team18_bsrn.py:218) -> the 4 column groups of fea_conv.pw.weight[C,12] are summed to [C,3];
+  * `out * cw` (team18_bsrn.py:169) -> folded into the columns of conv_out.weight.
+"""
+import torch
+
+from . import _lib as L
+from .engine import INPUT, OUTPUT, HipSRModel, pack_conv
+from .rlfn import FP, _lowres, _pad8
+
+
+class BSRN(HipSRModel):
+    def __init__(self, num_in_ch=3, num_feat=50, num_block=4, num_out_ch=3, upscale=4,
+                 conv='BSConvU', upsampler='pixelshuffledirect', p=0.25):
+        super().__init__()
+        if conv != 'BSConvU':
+            raise NotImplementedError('HIP BSRN implements conv="BSConvU" (the registry configuration, test_demo.py:155-156)')
+        if upsampler != 'pixelshuffledirect':
+            raise NotImplementedError(("Check the Upsampeler. None or not support yet"))
+        if upscale != 4 or num_feat > 64 or num_feat % 8 or num_in_ch > 4 or num_out_ch * 16 > 64:
+            raise NotImplementedError('HIP BSRN supports upscale=4, num_feat in {8..64 step 8}, in<=4, out<=4')
+        print(conv)                                               # team18_bsrn.py:189 prints the conv type
+        self.in_nc, self.out_nc, self.C, self.nb, self.upscale = num_in_ch, num_out_ch, num_feat, num_block, upscale
+        C = num_feat
+        self.dc, self.f = C // 2, C // 4
+        dc, f = self.dc, self.f
+        cp4 = (C + 3) // 4 * 4
+        # fea_conv = BSConvU(4*in, C): parameters as in the reference, packed through the folds in _extra_pack
+        self._add_conv('fea_conv.pw', num_in_ch * 4, C, 1, linear=True, custom=True)
+        self._add_dw('fea_conv.dw', C)
+        for k in range(1, num_block + 1):
+            b = f'B{k}.'
+            for j in (1, 2, 3):
+                self._add_conv(b + f'c{j}_d', C, dc, 1, linear=True)
+                self._add_conv(b + f'c{j}_r.pw', C, C, 1, linear=True)
+                self._add_dw(b + f'c{j}_r.dw', C)
+            self._add_conv(b + 'c4.pw', C, dc, 1, linear=True)
+            self._add_dw(b + 'c4.dw', dc)
+            self._add_conv(b + 'c5', dc * 4, C, 1, linear=True)
+            self._add_conv(b + 'esa.conv1', C, f, 1, linear=True)
+            self._add_conv(b + 'esa.conv_f', f, f, 1, linear=True, dense=(FP, FP))
+            for nm in ('conv_max', 'conv3', 'conv3_'):
+                self._add_conv(b + f'esa.{nm}.pw', f, f, 1, linear=True)
+                self._add_dw(b + f'esa.{nm}.dw', f)
+            self._add_conv(b + 'esa.conv2', f, f, 3, dense=(FP, FP), stride=2, padding=0)
+            self._add_conv(b + 'esa.conv4', f, C, 1, linear=True, dense=(FP, cp4))
+            self._leaf(b.rstrip('.')).register_parameter('cw', torch.nn.Parameter(torch.normal(mean=1, std=0.2, size=(1, C))))
+            self._add_conv(b + 'conv_out', C, C, 1, linear=True, custom=True)
+        self._add_conv('c1', C * num_block, C, 1, linear=True)
+        self._add_conv('c2.pw', C, C, 1, linear=True)
+        self._add_dw('c2.dw', C)
+        self._add_conv('upsampler.upsampleOneStep.0', C, num_out_ch * upscale * upscale, 3)
+
+    def _extra_pack(self, packed, device):
+        C, ic = self.C, self.in_nc
+        pw = self._leaf('fea_conv.pw')
+        w = pw.weight.detach().float().reshape(C, 4, ic).sum(dim=1)           # [C,4*ic] -> [C,ic]: input replicated x4
+        w3 = torch.zeros(C, ic, 3, 3)
+        w3[:, :, 1, 1] = w                                                     # 1x1 as the centre tap of the NCHW-input 3x3 path
+        packed['fea_conv.pw'] = pack_conv(w3, pw.bias).to(device)
+        for k in range(1, self.nb + 1):
+            co = self._leaf(f'B{k}.conv_out')
+            cw = self._leaf(f'B{k}').cw.detach().float().reshape(1, C)
+            packed[f'B{k}.conv_out'] = pack_conv(co.weight.detach().float() * cw, co.bias).to(device)
+
+    def _build_plan(self, plan, c):
+        if c != self.in_nc:
+            raise L.EsrError(f'BSRN expects {self.in_nc} input channels, got {c}')
+        if plan.h < 15 or plan.w < 15:
+            raise L.EsrError('ESA needs H, W >= 15 (3x3/s2 then 7x7/s3 pooling)')
+        C, dc, f, nb = self.C, self.dc, self.f, self.nb
+        h2, w2, h3, w3 = _lowres(plan.h, plan.w)
+        g = dict(act=L.ACT_GELU)
+        fea = plan.buffer('fea', C)
+        bcat = plan.buffer('bcat', nb * C)                # block outputs, team18_bsrn.py:226
+        cat = plan.buffer('cat', 4 * dc)                  # d1 d2 d3 r4, team18_bsrn.py:166
+        t = plan.buffer('t', C)                           # pointwise result feeding the depthwise
+        r1, r2, v, u = plan.buffer('r1', C), plan.buffer('r2', C), plan.buffer('v', C), plan.buffer('u', C)
+        c1 = plan.buffer('esa_c1', FP)
+        lo2 = plan.buffer('esa_s2', FP, h2, w2)
+        la, lb, lt = (plan.buffer(n, FP, h3, w3) for n in ('esa_a', 'esa_b', 'esa_t'))
+        lo = (h3, w3)
+        plan.conv('fea_conv.pw', INPUT, t, self.in_nc, C, counted=False)
+        plan.dwconv('fea_conv.dw', t, fea, C)
+        cur = fea
+        for k in range(1, nb + 1):
+            b = f'B{k}.'
+            src = cur
+            for j, (rin, rout) in enumerate(((cur, r1), (r1, r2), (r2, r1)), start=1):
+                plan.conv(b + f'c{j}_d', rin, cat[(j - 1) * dc:j * dc], C, dc, k=1, counted=False, **g)
+                plan.conv(b + f'c{j}_r.pw', rin, t, C, C, k=1, counted=False)
+                plan.dwconv(b + f'c{j}_r.dw', t, rout, C, res=rin, res_mode=L.RES_PRE_ACT, **g)
+            plan.conv(b + 'c4.pw', r1, t[0:dc], C, dc, k=1, counted=False)
+            plan.dwconv(b + 'c4.dw', t[0:dc], cat[3 * dc:4 * dc], dc, **g)
+            plan.conv(b + 'c5', cat, v, 4 * dc, C, k=1, counted=False)
+            plan.conv(b + 'esa.conv1', v, c1, C, f, k=1, counted=False)
+            plan.conv3x3s2(b + 'esa.conv2', c1, lo2, f)
+            plan.maxpool7s3(lo2, la)
+            plan.conv(b + 'esa.conv_max.pw', la, lt, f, f, k=1, hw=lo, counted=False)
+            plan.dwconv(b + 'esa.conv_max.dw', lt, lb, f, hw=lo, **g)
+            plan.conv(b + 'esa.conv3.pw', lb, lt, f, f, k=1, hw=lo, counted=False)
+            plan.dwconv(b + 'esa.conv3.dw', lt, la, f, hw=lo, **g)
+            plan.conv(b + 'esa.conv3_.pw', la, lt, f, f, k=1, hw=lo, counted=False)
+            plan.dwconv(b + 'esa.conv3_.dw', lt, lb, f, hw=lo)
+            plan.esa_apply(b + 'esa.conv_f', b + 'esa.conv4', v, c1, lb, u, C, f)
+            out = bcat[(k - 1) * C:k * C]
+            plan.conv(b + 'conv_out', u, out, C, C, k=1, res=src, res_mode=L.RES_PRE_ACT, counted=False)
+            cur = out
+        plan.conv('c1', bcat, v, nb * C, C, k=1, counted=False, **g)
+        plan.conv('c2.pw', v, t, C, C, k=1, counted=False)
+        plan.dwconv('c2.dw', t, u, C, res=fea, res_mode=L.RES_PRE_ACT)
+        plan.conv('upsampler.upsampleOneStep.0', u, OUTPUT, C, self.out_nc * 16)
+
+    # -- complexity counters: what utils/model_summary.py reports for this graph -----------------------------
+    def _complexity_terms(self, plan, o):
+        """Conv2d hooks fire for the depthwise convs, esa.conv2 and the upsampler conv (43 calls); nn.Linear is
+        counted by linear_flops_counter_hook (model_summary.py:305-312), which for a 4-D NHWC input adds
+        input.shape[0]*input.shape[1]*output.shape[1] = 1*H*H -- the reference's own quirk, reproduced so the
+        table matches (true MACs are 9.43 G); Linear outputs are not 'activations'."""
+        hw = o.get("hw")
+        h, w = (hw if hw else (plan.h, plan.w))
+        if o["kind"] == "dw":
+            return 9 * o["cin"] * plan.n * h * w, o["cout"] * plan.n * h * w, 1
+        if o["kind"] == "conv" and not o.get("counted", True):
+            return plan.n * h * h, 0, 0                                   # a Linear call
+        if o["kind"] == "apply":
+            return 2 * plan.n * plan.h * plan.h, 0, 0                     # conv_f and conv4 are Linear here
+        return super()._complexity_terms(plan, o)

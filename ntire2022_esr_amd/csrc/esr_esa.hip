@@ -150,9 +150,101 @@ __global__ __launch_bounds__(256) void esa_apply_kernel(const EsaK p)
     *reinterpret_cast<f32x4*>(p.y + (size_t)pix * p.y_pitch + p.y_coff + g * 4) = o;
 }
 
+// ---- depthwise 3x3, zero padding, fused residual / activation -------------------------------------
+// thread = (pixel, quad of 4 channels); weights [tap][cp] + bias[cp] in LDS.  Memory-bound: the 9 taps of a
+// pixel are served from L1/L2 (each input float4 is read by 9 neighbouring threads).
+struct DwK {
+    const float* x; const float* wp; const float* res; float* y;
+    int N, H, W, cp, nq;
+    int x_pitch, x_coff, r_pitch, r_coff, y_pitch, y_coff;
+    int act, res_mode;
+    float slope;
+};
+
+__device__ __forceinline__ float dw_act(float v, int act, float slope)
+{
+    if (act == ESR_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    if (act == ESR_ACT_LRELU) return fmaxf(v, v * slope);
+    if (act == ESR_ACT_RELU) return fmaxf(v, 0.f);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const DwK p)
+{
+    extern __shared__ __attribute__((aligned(16))) float sdw[];          // 10 * cp floats
+    for (int i = threadIdx.x; i < 10 * p.cp; i += 256) sdw[i] = p.wp[i];
+    __syncthreads();
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long pix = gid / p.nq;
+    const int q = (int)(gid - pix * p.nq);
+    if (pix >= (long long)p.N * p.H * p.W) return;
+    const int ox = (int)(pix % p.W);
+    const int oy = (int)((pix / p.W) % p.H);
+    f32x4 acc = *reinterpret_cast<const f32x4*>(sdw + 9 * p.cp + q * 4);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy + ky - 1;
+        if (iy < 0 || iy >= p.H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox + kx - 1;
+            if (ix < 0 || ix >= p.W) continue;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(
+                p.x + (size_t)(pix + (long long)(ky - 1) * p.W + (kx - 1)) * p.x_pitch + p.x_coff + q * 4);
+            acc += xv * *reinterpret_cast<const f32x4*>(sdw + (ky * 3 + kx) * p.cp + q * 4);
+        }
+    }
+    f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+    if (p.res_mode != ESR_RES_NONE) rv = *reinterpret_cast<const f32x4*>(p.res + (size_t)pix * p.r_pitch + p.r_coff + q * 4);
+    if (p.res_mode == ESR_RES_PRE_ACT) acc += rv;
+    acc.x = dw_act(acc.x, p.act, p.slope); acc.y = dw_act(acc.y, p.act, p.slope);
+    acc.z = dw_act(acc.z, p.act, p.slope); acc.w = dw_act(acc.w, p.act, p.slope);
+    if (p.res_mode == ESR_RES_POST_ACT) acc += rv;
+    *reinterpret_cast<f32x4*>(p.y + (size_t)pix * p.y_pitch + p.y_coff + q * 4) = acc;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t esr_packed_dw_bytes(int c) { return c <= 0 ? 0 : (size_t)10 * esr_round_up(c, 4) * sizeof(float); }
+
+int esr_pack_dw_f32(const float* w, const float* bias, int c, void* out, size_t out_bytes)
+{
+    if (!w || !out || c <= 0 || out_bytes < esr_packed_dw_bytes(c)) return ESR_ERR_BAD_ARG;
+    const int cp = esr_round_up(c, 4);
+    float* o = static_cast<float*>(out);
+    memset(o, 0, esr_packed_dw_bytes(c));
+    for (int ch = 0; ch < c; ++ch) {
+        for (int t = 0; t < 9; ++t) o[t * cp + ch] = w[ch * 9 + t];
+        if (bias) o[9 * cp + ch] = bias[ch];
+    }
+    return ESR_OK;
+}
+
+int esr_dwconv3x3_f32(const esr_conv_desc* d, void* hip_stream)
+{
+    if (!d || !d->in.ptr || !d->out0.ptr || !d->wpacked) return ESR_ERR_BAD_ARG;
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->cin != d->cout || d->ksize != 3) return ESR_ERR_BAD_ARG;
+    if (d->in_layout != ESR_NHWC || d->out_layout != ESR_NHWC) return ESR_ERR_UNSUPPORTED;
+    const int cp = esr_round_up(d->cin, 4);
+    if ((d->in.pitch & 3) || (d->in.coff & 3) || d->in.coff + cp > d->in.pitch) return ESR_ERR_BAD_ARG;
+    if ((d->out0.pitch & 3) || (d->out0.coff & 3) || d->out0.coff + cp > d->out0.pitch) return ESR_ERR_BAD_ARG;
+    if (d->res_mode != ESR_RES_NONE &&
+        (!d->res.ptr || (d->res.pitch & 3) || (d->res.coff & 3) || d->res.coff + cp > d->res.pitch))
+        return ESR_ERR_BAD_ARG;
+    DwK k;
+    k.x = static_cast<const float*>(d->in.ptr); k.wp = static_cast<const float*>(d->wpacked);
+    k.res = static_cast<const float*>(d->res.ptr); k.y = static_cast<float*>(d->out0.ptr);
+    k.N = d->n; k.H = d->h; k.W = d->w; k.cp = cp; k.nq = cp / 4;
+    k.x_pitch = d->in.pitch; k.x_coff = d->in.coff; k.r_pitch = d->res.pitch; k.r_coff = d->res.coff;
+    k.y_pitch = d->out0.pitch; k.y_coff = d->out0.coff;
+    k.act = d->act; k.res_mode = d->res_mode; k.slope = d->slope;
+    const long long nthreads = (long long)d->n * d->h * d->w * k.nq;
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), (size_t)10 * cp * sizeof(float),
+                       static_cast<hipStream_t>(hip_stream), k);
+    return esr_check_launch("dwconv3x3_kernel launch");
+}
 
 size_t esr_packed_dense_bytes(int cin_p, int cout_p, int ksize)
 {

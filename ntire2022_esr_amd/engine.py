@@ -64,6 +64,18 @@ def pack_dense(weight, bias, cin_p, cout_p):
     return out
 
 
+def pack_dw(weight, bias):
+    """Depthwise [C,1,3,3] weights + bias -> [tap][cp] + bias[cp] (esr_pack_dw_f32)."""
+    lib = L.lib()
+    w = weight.detach().to("cpu", torch.float32).contiguous()
+    c = w.shape[0]
+    b = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
+    nbytes = lib.esr_packed_dw_bytes(c)
+    out = torch.empty(nbytes // 4, dtype=torch.float32)
+    L.check(lib.esr_pack_dw_f32(_ptr(w), _ptr(b) if b is not None else None, c, _ptr(out), nbytes), "esr_pack_dw_f32")
+    return out
+
+
 def unpack_conv(blob, cin, cout, k, cin_map=None, cin_phys=None):
     lib = L.lib()
     blob = blob.detach().to("cpu", torch.float32).contiguous()
@@ -124,6 +136,11 @@ class Plan:
         self.ops.append(dict(kind="conv", w=wname, src=src, dst=dst, dst1=dst1, cin=cin, cout=cout, k=k, act=act,
                              slope=slope, res=res, res_mode=res_mode, split=split, hw=hw, counted=counted))
 
+    def dwconv(self, wname, src, dst, c, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.RES_NONE, hw=None):
+        """depthwise 3x3 + bias (+res) (+act): the dw half of BSConvU."""
+        self.ops.append(dict(kind="dw", w=wname, src=src, dst=dst, dst1=None, cin=c, cout=c, k=3, act=act, slope=slope,
+                             res=res, res_mode=res_mode, split=0, hw=hw, counted=True))
+
     def conv3x3s2(self, wname, src, dst, f):
         self.ops.append(dict(kind="s2", w=wname, src=src, dst=dst, f=f, cin=f, cout=f, k=3, act=L.ACT_NONE,
                              hw=(dst.h, dst.w), counted=True))
@@ -149,7 +166,7 @@ class Plan:
         base = workspace.data_ptr() if workspace is not None else 0
         for i, o in enumerate(self.ops):
             op = arr[i]
-            if o["kind"] != "conv":
+            if o["kind"] not in ("conv", "dw"):
                 e = op.esa
                 e.n = self.n
                 if o["kind"] == "apply":
@@ -170,7 +187,7 @@ class Plan:
                         e.f = o["f"]
                         e.w0 = ctypes.c_void_p(weights[o["w"]].data_ptr())
                 continue
-            op.kind = L.OP_CONV
+            op.kind = L.OP_CONV if o["kind"] == "conv" else L.OP_DWCONV
             d = op.conv
             d.n, d.h, d.w = self.n, self.h, self.w
             if o["hw"] is not None:
@@ -206,6 +223,7 @@ class HipSRModel(nn.Module):
         super().__init__()
         self._conv_specs = {}      # path -> (cin, cout, k, cin_map)
         self._dense_specs = {}     # path -> (cin_p, cout_p): small ESA weights in the plain dense layout
+        self._dw_specs = []        # depthwise 3x3 parameter paths
         self._packed = None        # path -> device blob
         self._packed_sig = None
         self._plans = {}
@@ -213,7 +231,7 @@ class HipSRModel(nn.Module):
         self._profs = {}
 
     # -- parameter registration: same key names as the reference state_dict -------------------
-    def _add_conv(self, path, cin, cout, k, cin_map=None, linear=False, dense=None, stride=1, padding=None):
+    def _add_conv(self, path, cin, cout, k, cin_map=None, linear=False, dense=None, stride=1, padding=None, custom=False):
         """Create nested containers so that `path + '.weight'` / `path + '.bias'` are the
         state_dict keys (e.g. 'model.1.sub.0.conv1.0').  The leaf is an nn.Conv2d / nn.Linear
         used purely as a parameter holder with the reference's shapes and default init."""
@@ -227,8 +245,19 @@ class HipSRModel(nn.Module):
         mod.add_module(parts[-1], leaf)
         if dense is not None:
             self._dense_specs[path] = dense
-        else:
+        elif not custom:
             self._conv_specs[path] = (cin, cout, k, cin_map)
+
+    def _add_dw(self, path, c):
+        """depthwise nn.Conv2d(c, c, 3, 1, 1, groups=c) parameter holder (`path.weight` is [c,1,3,3])."""
+        parts = path.split(".")
+        mod = self
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, nn.Module())
+            mod = mod._modules[p]
+        mod.add_module(parts[-1], nn.Conv2d(c, c, 3, 1, 1, groups=c))
+        self._dw_specs.append(path)
 
     def _leaf(self, path):
         mod = self
@@ -248,6 +277,9 @@ class HipSRModel(nn.Module):
         for path, (cin_p, cout_p) in self._dense_specs.items():
             leaf = self._leaf(path)
             packed[path] = pack_dense(leaf.weight, leaf.bias, cin_p, cout_p).to(device)
+        for path in self._dw_specs:
+            leaf = self._leaf(path)
+            packed[path] = pack_dw(leaf.weight, leaf.bias).to(device)
         self._extra_pack(packed, device)
         self._packed = packed
         self._packed_sig = self._signature()
@@ -325,7 +357,8 @@ class HipSRModel(nn.Module):
             L.check(L.lib().esr_prof_collect(prof, ms, n, ctypes.byref(passes)), "esr_prof_collect")
             for i, o in enumerate(plan.ops):
                 if o["kind"] != "conv":
-                    kern = {"s2": "conv3x3s2_kernel", "pool": "maxpool7s3_kernel", "apply": "esa_apply_kernel"}[o["kind"]]
+                    kern = {"s2": "conv3x3s2_kernel", "pool": "maxpool7s3_kernel", "apply": "esa_apply_kernel",
+                            "dw": "dwconv3x3_kernel"}[o["kind"]]
                     out.append(dict(name=o.get("w", o["kind"]), kernel=kern, cin=0, cout=0, k=0, flops=0.0,
                                     ms_sum=ms[i], passes=passes.value))
                     continue
@@ -336,6 +369,17 @@ class HipSRModel(nn.Module):
                                 flops=2.0 * npix * o["cin"] * o["cout"] * o["k"] * o["k"],
                                 ms_sum=ms[i], passes=passes.value))
         return out
+
+    def _complexity_terms(self, plan, o):
+        """(flops, activations, n_conv) that the reference's model_summary hooks would count for op `o`."""
+        flops = acts = nconv = 0
+        for (cin, cout, k, npix, act) in self._counted_convs(plan, o):
+            flops += k * k * cin * cout * npix
+            acts += cout * npix
+            nconv += 1
+            if act in (L.ACT_LRELU, L.ACT_RELU):
+                flops += cout * npix
+        return flops, acts, nconv
 
     def _counted_convs(self, plan, o):
         """nn.Conv2d calls of the REFERENCE graph that op `o` stands for: (cin, cout, k, pixels, act) tuples

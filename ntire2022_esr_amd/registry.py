@@ -10,6 +10,9 @@ _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # model_id -> (display name, checkpoint stem, data_range, tile, ctor)
 def _entries():
+    import contextlib
+    import io
+    from .bsrn import BSRN
     from .imdn import IMDN
     from .rfdn import RFDN
     from .rlfn import RLFN_cut
@@ -17,6 +20,9 @@ def _entries():
         -1: ("IMDN_baseline", "imdn_baseline", 1.0, None, lambda: IMDN(in_nc=3, out_nc=3, nc=64, nb=8, upscale=4)),
         0: ("RFDN_baseline", "rfdn_baseline", 255.0, None, lambda: RFDN()),                    # test_demo.py:24-30
         4: ("ByteESR", "team04_rlfn", 255.0, None, lambda: RLFN_cut(in_nc=3, out_nc=3)),        # test_demo.py:52-58
+        18: ("XPixel", "team18_bsrn", 1.0, None,                                                 # test_demo.py:150-157
+             lambda: BSRN(num_in_ch=3, num_feat=48, num_block=5, num_out_ch=3, upscale=4, conv='BSConvU',
+                          upsampler='pixelshuffledirect')),
     }
 
 

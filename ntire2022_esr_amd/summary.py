@@ -19,11 +19,7 @@ def model_complexity(model, input_dim=(3, 256, 256)):
     acts = 0
     nconv = 0
     for o in plan.ops:
-        for (cin, cout, k, npix, act) in model._counted_convs(plan, o):
-            flops += k * k * cin * cout * npix
-            acts += cout * npix
-            nconv += 1
-            if act in (L.ACT_LRELU, L.ACT_RELU):
-                flops += cout * npix
+        f, a, n = model._complexity_terms(plan, o)
+        flops, acts, nconv = flops + f, acts + a, nconv + n
     return {"activations": float(acts), "num_conv": int(nconv), "flops": float(flops),
             "num_parameters": int(sum(p.numel() for p in model.parameters()))}

@@ -13,10 +13,26 @@ from conftest import GOLD
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("mid,key,dr", [(0, "rfdn_baseline", 255.0), (4, "team04_rlfn", 255.0), (18, "team18_bsrn", 1.0)])
+def test_harness_other_models(tmp_path, mid, key, dr):
+    from ntire2022_esr_amd import harness as H
+    from ntire2022_esr_amd.registry import select_model
+    dev = torch.device("cuda:0")
+    model, name, data_range, tile = select_model(mid, dev)
+    assert data_range == dr and tile is None and name.startswith(f"{mid:02}_")
+    args = types.SimpleNamespace(data_dir=os.path.join(GOLD, "mini_div2k"), save_dir=str(tmp_path), rank=0, world=1)
+    pairs = H.select_dataset(args.data_dir, "valid")[:3]
+    res = H.run(model, name, data_range, tile, logging.getLogger("gpu"), dev, args, mode="valid", pairs=pairs)
+    ref = json.load(open(os.path.join(GOLD, "mini_div2k", "reference_psnr.json")))[key]
+    for a, b in zip(res["valid_psnr"], ref["valid_psnr"]):
+        assert abs(a - b) < 0.002
+    assert abs(res["valid_ave_psnr"] - ref["valid_ave_psnr"]) < 0.002
+
+
 def test_harness_on_mini_div2k(tmp_path):
     from ntire2022_esr_amd import harness as H
     from ntire2022_esr_amd.registry import select_model, supported_ids
-    assert -1 in supported_ids()
+    assert supported_ids() == [-1, 0, 4, 18]
     dev = torch.device("cuda:0")
     model, name, data_range, tile = select_model(-1, dev)
     assert name == "-1_IMDN_baseline" and data_range == 1.0 and tile is None

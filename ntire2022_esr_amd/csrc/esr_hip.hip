@@ -34,6 +34,7 @@ namespace {
 constexpr int TILE = 16;      // output tile edge (pixels)
 constexpr int CHUNK = 8;      // input channels per K stage
 constexpr int THREADS = 256;
+constexpr int MAX_RESIDENT_BLOCKS = 512;   // 256 CUs x 2 blocks (LDS: 75 KB per block)
 
 struct ConvK {
     const float* x;
@@ -57,6 +58,16 @@ struct ConvK {
     int tiles_x, tiles_y;
 };
 
+__device__ __forceinline__ float act_any(float v, int act, float slope)
+{
+    switch (act) {
+        case ESR_ACT_LRELU: return fmaxf(v, slope * v);
+        case ESR_ACT_RELU: return fmaxf(v, 0.f);
+        case ESR_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        default: return v;
+    }
+}
+
 template <int ACT>
 __device__ __forceinline__ f32x4 act4(f32x4 v, float slope)
 {
@@ -75,74 +86,160 @@ __device__ __forceinline__ f32x4 act4(f32x4 v, float slope)
     return v;
 }
 
-// Epilogue for one activation kind (selected by ONE wave-uniform switch in the kernel, so no
-// per-element branching): (+res) -> act -> (+res) -> store.  Bias is already in the accumulators.
-// Kept lean on purpose: VALU work issued while the SIMD partner streams fp32 MFMAs costs ~an
-// MFMA slot (32 cycles) per instruction.
-template <int ACT, int NT>
-__device__ __forceinline__ void epilogue(const ConvK& p, f32x4 (&acc)[NT][4], int n, int x0, int y0, int wv,
-                                         int px, int kq)
+// ---- epilogues -------------------------------------------------------------------------------------
+// Bias is already in the accumulators.
+// (1) NHWC: the MFMA D fragment gives lane (px, kq) the 4 channels 16t+4kq.. of pixel px, i.e. 16 B from
+//     each of 16 different pixels per store instruction -- 64 separate 16-byte requests (~2x the issue time
+//     of a contiguous store, tools/store_pattern.hip).  Each wave therefore transposes one pixel row at a
+//     time through a private LDS scratch ([16 px][64 ch + 4 pad], conflict-free both ways) so that lane l
+//     owns the 16-byte chunk (l & 15) of pixel (l >> 4) + 4i: residual loads and stores are 256 contiguous
+//     bytes per pixel, 1 KB per instruction for a 64-channel buffer.  All residual loads are issued up
+//     front (a load->wait->add->store chain per float4 serialises: vmcnt counts stores too).
+// (2) PixelShuffle(4) NCHW output: the native fragment is already ideal (16 lanes x 16 B contiguous).
+constexpr int EPI_PITCH = 68;                       // floats per scratch pixel row: 64 + 4 pad
+constexpr int EPI_WAVE_FLOATS = 16 * EPI_PITCH;     // one 16-pixel row per wave
+
+// generic (bounds-checked) version: edge tiles and rarely used activation / residual combinations
+template <int NT>
+__device__ __forceinline__ void epilogue_nhwc_checked(const ConvK& p, f32x4 (&acc)[NT][4], float* scr, int n, int x0, int y0,
+                                                   int wv, int lane)
 {
+    const int px = lane & 15, kq = lane >> 4;       // fragment mapping
+    const int ch = lane & 15, prow = lane >> 4;     // transposed mapping: chunk ch of pixel prow + 4i
+    const int cb = ch * 4;
+    const bool ch_ok = cb < p.cout_store;
+    const bool to0 = cb < p.split;
+    float* const ybase = to0 ? p.y0 + p.y0_coff + cb : p.y1 + p.y1_coff + (cb - p.split);
+    const int ypitch = to0 ? p.y0_pitch : p.y1_pitch;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gy = y0 + wv * 4 + r;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(scr + px * EPI_PITCH + t * 16 + kq * 4) = acc[t][r];
+        for (int i = 0; i < 4; ++i) {
+            const int gx = x0 + 4 * i + prow;
+            f32x4 v = *reinterpret_cast<const f32x4*>(scr + (4 * i + prow) * EPI_PITCH + min(cb, NT * 16 - 4));
+            if (!(ch_ok && gy < p.H && gx < p.W)) continue;
+            const int pix = (n * p.H + gy) * p.W + gx;
+            f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+            if (p.res_mode != ESR_RES_NONE) rv = *reinterpret_cast<const f32x4*>(p.res + (size_t)(pix * p.res_pitch + p.res_coff + cb));
+            if (p.res_mode == ESR_RES_PRE_ACT) v += rv;
+            v.x = act_any(v.x, p.act, p.slope); v.y = act_any(v.y, p.act, p.slope);
+            v.z = act_any(v.z, p.act, p.slope); v.w = act_any(v.w, p.act, p.slope);
+            if (p.res_mode == ESR_RES_POST_ACT) v += rv;
+            *reinterpret_cast<f32x4*>(ybase + (size_t)(pix * ypitch)) = v;
+        }
+    }
+}
+
+// fast path: the 16x16 tile lies inside the image.  Row/pixel-group bases are wave-uniform (scalar), each
+// lane adds one precomputed offset; no bounds checks; activation and residual mode are compile-time.
+template <int ACT, int RES, int NT>
+__device__ __forceinline__ void epilogue_nhwc_fast(const ConvK& p, f32x4 (&acc)[NT][4], float* scr, int n, int x0, int y0,
+                                                   int wv, int lane)
+{
+    const int px = lane & 15, kq = lane >> 4;
+    const int ch = lane & 15, prow = lane >> 4;
+    const int cb = ch * 4;
+    const int pix00 = __builtin_amdgcn_readfirstlane((n * p.H + y0 + wv * 4) * p.W + x0);   // wave-uniform
+    const bool to0 = cb < p.split;
+    const bool to1 = !to0 && cb < p.cout_store;
+    const unsigned off0 = (unsigned)(prow * p.y0_pitch + p.y0_coff + cb);
+    const unsigned off1 = (unsigned)(prow * p.y1_pitch + p.y1_coff + cb - p.split);
+    const bool has_split = p.split < p.cout_store;                                        // uniform
+    const int rd = (NT == 4) ? cb : min(cb, NT * 16 - 4);
+
+    f32x4 rv[4][4];
+    if (RES != ESR_RES_NONE) {
+        const unsigned offr = (unsigned)(prow * p.res_pitch + p.res_coff + min(cb, p.cout_store - 4));
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                rv[r][i] = *reinterpret_cast<const f32x4*>(p.res + (size_t)(pix00 + r * p.W + 4 * i) * p.res_pitch + offr);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(scr + px * EPI_PITCH + t * 16 + kq * 4) = acc[t][r];
+        f32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(scr + (4 * i + prow) * EPI_PITCH + rd);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 o;
+            if (RES == ESR_RES_PRE_ACT) o = act4<ACT>(v[i] + rv[r][i], p.slope);
+            else if (RES == ESR_RES_POST_ACT) o = act4<ACT>(v[i], p.slope) + rv[r][i];
+            else o = act4<ACT>(v[i], p.slope);
+            const size_t pu = (size_t)(pix00 + r * p.W + 4 * i);                            // uniform
+            if (!has_split) {
+                if (NT == 4 || to0) *reinterpret_cast<f32x4*>(p.y0 + pu * p.y0_pitch + off0) = o;
+            } else {
+                if (to0) *reinterpret_cast<f32x4*>(p.y0 + pu * p.y0_pitch + off0) = o;
+                if (to1) *reinterpret_cast<f32x4*>(p.y1 + pu * p.y1_pitch + off1) = o;
+            }
+        }
+    }
+}
+
+template <int ACT, int NT>
+__device__ __forceinline__ void epilogue_nhwc_fast_res(const ConvK& p, f32x4 (&acc)[NT][4], float* scr, int n, int x0, int y0,
+                                                       int wv, int lane)
+{
+    if (p.res_mode == ESR_RES_NONE) epilogue_nhwc_fast<ACT, ESR_RES_NONE, NT>(p, acc, scr, n, x0, y0, wv, lane);
+    else if (p.res_mode == ESR_RES_PRE_ACT) epilogue_nhwc_fast<ACT, ESR_RES_PRE_ACT, NT>(p, acc, scr, n, x0, y0, wv, lane);
+    else epilogue_nhwc_fast<ACT, ESR_RES_POST_ACT, NT>(p, acc, scr, n, x0, y0, wv, lane);
+}
+
+template <int NT>
+__device__ __forceinline__ void epilogue_nhwc(const ConvK& p, f32x4 (&acc)[NT][4], float* scr, int n, int x0, int y0,
+                                              int wv, int lane)
+{
+    const bool inside = x0 + TILE <= p.W && y0 + TILE <= p.H && (NT < 4 || p.cout_store == 64);   // uniform
+    if (inside && p.act == ESR_ACT_LRELU) epilogue_nhwc_fast_res<ESR_ACT_LRELU, NT>(p, acc, scr, n, x0, y0, wv, lane);
+    else if (inside && p.act == ESR_ACT_NONE) epilogue_nhwc_fast_res<ESR_ACT_NONE, NT>(p, acc, scr, n, x0, y0, wv, lane);
+    else if (inside && p.act == ESR_ACT_GELU && p.res_mode == ESR_RES_NONE)
+        epilogue_nhwc_fast<ESR_ACT_GELU, ESR_RES_NONE, NT>(p, acc, scr, n, x0, y0, wv, lane);
+    else epilogue_nhwc_checked<NT>(p, acc, scr, n, x0, y0, wv, lane);
+}
+
+template <int NT>
+__device__ __forceinline__ void epilogue_shuffle(const ConvK& p, f32x4 (&acc)[NT][4], int n, int x0, int y0, int wv, int lane)
+{
+    const int px = lane & 15, kq = lane >> 4;
     const int gx = x0 + px;
     if (gx >= p.W) return;
-    const bool shuffle = p.out_layout == ESR_NCHW_SHUFFLE4;
-    int pix[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pix[r] = (n * p.H + min(y0 + wv * 4 + r, p.H - 1)) * p.W + gx;   // < 2^31 / pitch (host-checked)
-
-    // All residual loads are issued up front: a load->wait->add->store chain per float4 would
-    // serialise 16 round trips (vmcnt counts the preceding store too).
-    if (p.res_mode != ESR_RES_NONE) {
-        f32x4 rv[NT][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int cb = min(t * 16 + kq * 4, p.cout_store - 4);
-                rv[t][r] = *reinterpret_cast<const f32x4*>(p.res + (size_t)(pix[r] * p.res_pitch + p.res_coff + cb));
-            }
-        if (p.res_mode == ESR_RES_PRE_ACT) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t][r] = act4<ACT>(acc[t][r] + rv[t][r], p.slope);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t][r] = act4<ACT>(acc[t][r], p.slope) + rv[t][r];
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t][r] = act4<ACT>(acc[t][r], p.slope);
-    }
-
+    const size_t W4 = (size_t)p.W * 4, H4 = (size_t)p.H * 4;
+    const int nco = p.cout_store / 16;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int gy = y0 + wv * 4 + r;
         if (gy >= p.H) continue;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int cb = t * 16 + kq * 4;                 // first of this lane's 4 output channels
-            if (cb >= p.cout_store) continue;
-            const f32x4 v = acc[t][r];
-            if (shuffle) {
-                // out[n, t, 4gy+kq, 4gx+0..3]  (channel 16t + 4kq + j)
-                const size_t W4 = (size_t)p.W * 4, H4 = (size_t)p.H * 4;
-                const int nco = p.cout_store / 16;
-                float* dst = p.y0 + (((size_t)n * nco + t) * H4 + (size_t)gy * 4 + kq) * W4 + (size_t)gx * 4;
-                *reinterpret_cast<f32x4*>(dst) = v;
-            } else if (cb < p.split) {
-                *reinterpret_cast<f32x4*>(p.y0 + (size_t)(pix[r] * p.y0_pitch + p.y0_coff + cb)) = v;
-            } else {
-                *reinterpret_cast<f32x4*>(p.y1 + (size_t)(pix[r] * p.y1_pitch + p.y1_coff + (cb - p.split))) = v;
+            if (t * 16 + kq * 4 >= p.cout_store) continue;
+            f32x4 v = acc[t][r];
+            if (p.act != ESR_ACT_NONE || p.res_mode != ESR_RES_NONE) {          // not on the networks' path: generic
+                f32x4 rvv = {0.f, 0.f, 0.f, 0.f};
+                if (p.res_mode != ESR_RES_NONE) {
+                    const int pix = (n * p.H + gy) * p.W + gx;
+                    rvv = *reinterpret_cast<const f32x4*>(p.res + (size_t)(pix * p.res_pitch + p.res_coff + t * 16 + kq * 4));
+                }
+                if (p.res_mode == ESR_RES_PRE_ACT) v += rvv;
+                v.x = act_any(v.x, p.act, p.slope); v.y = act_any(v.y, p.act, p.slope);
+                v.z = act_any(v.z, p.act, p.slope); v.w = act_any(v.w, p.act, p.slope);
+                if (p.res_mode == ESR_RES_POST_ACT) v += rvv;
             }
+            // out[n, t, 4gy+kq, 4gx+0..3]  (channel 16t + 4kq + j)
+            float* dst = p.y0 + (((size_t)n * nco + t) * H4 + (size_t)gy * 4 + kq) * W4 + (size_t)gx * 4;
+            *reinterpret_cast<f32x4*>(dst) = v;
         }
     }
 }
 
+// ---- the kernel -------------------------------------------------------------------------------------
+// Persistent over tiles: block b walks tiles b, b+G, b+2G, ... (XCD-aware order) and the last K chunk of
+// tile i stages chunk 0 of tile i+1, so only the very first tile of a block pays a prologue.
 template <int NT, int KS, bool IN_NCHW>
 __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
 {
@@ -159,11 +256,10 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
     constexpr int W_ROUNDS = (W_ITEMS + THREADS - 1) / THREADS;
     constexpr unsigned OOB = 0x80000000u;             // > any per-image byte offset (host checks < 2 GiB)
 
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + 4 * EPI_WAVE_FLOATS * 4];
 
-    // Issue priority: a wave streaming fp32 MFMAs back to back starves its SIMD partner's VALU/LDS/
-    // VMEM instructions (s_memtime probe: ~one instruction per 32-cycle MFMA slot).  Everything that
-    // is not the MFMA stream runs at raised priority and is kept to a handful of instructions.
+    // Issue priority: everything that is not the MFMA stream (staging, barrier, epilogue: a handful of
+    // instructions per 288 MFMAs) runs at raised priority so it is issued ahead of the SIMD partner's stream.
     __builtin_amdgcn_s_setprio(3);
 
     const int tid = threadIdx.x;
@@ -171,57 +267,73 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
     const int wv = tid >> 6;
     const int px = lane & 15;
     const int kq = lane >> 4;
+    float* const scr = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES) + wv * EPI_WAVE_FLOATS;
 
-    int bid = blockIdx.x;
-    const int tx = bid % p.tiles_x;
-    bid /= p.tiles_x;
-    const int ty = bid % p.tiles_y;
-    const int n = bid / p.tiles_y;
-    const int x0 = tx * TILE, y0 = ty * TILE;
+    // ---- tile walk -------------------------------------------------------------------------------
+    const int ntiles = p.N * p.tiles_y * p.tiles_x;
+    const int G = gridDim.x;
+    // Within a full group of G tiles, XCD x (blocks with b % 8 == x, as dispatched on gfx950) takes a
+    // contiguous run of G/8 tiles so that neighbouring tiles share an L2.  Speed only: any map is correct.
+    auto tile_index = [&](int k) -> int {
+        const int base = k * G;
+        if (base >= ntiles) return -1;
+        int off = blockIdx.x;
+        if ((G & 7) == 0 && base + G <= ntiles) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+        const int t = base + off;
+        return t < ntiles ? t : -1;
+    };
 
-    // ---- staging descriptors (chunk invariant) ------------------------------------------
-    // NHWC input: one raw buffer per image; a lane's byte offset is chunk invariant, the chunk
-    // advances through the SGPR soffset, and out-of-image halo items use an out-of-range offset so
-    // the hardware returns zeros: no per-chunk address VALU, no select, no branch (a per-item
-    // `if (ok) load` makes hipcc branch around every load and serialise them with vmcnt waits).
-    unsigned in_voff[IN_ROUNDS];
+    struct TileCtx { int n, x0, y0; unsigned voff[IN_ROUNDS]; };
+    // Staging descriptors.  NHWC input: one raw buffer per image, a lane's byte offset is chunk invariant,
+    // the chunk advances through the SGPR soffset, out-of-image halo items use an out-of-range offset so the
+    // hardware returns zeros.  No per-chunk address VALU, no select, no branch (a per-item `if (ok) load`
+    // makes hipcc branch around every load and serialise them with vmcnt waits).  Item idx = (pixel, half):
+    // adjacent lanes read the two 16-byte halves of one pixel's 32-byte chunk.
+    auto setup_tile = [&](int t, TileCtx& c) {
+        const int tx = t % p.tiles_x;
+        const int tq = t / p.tiles_x;
+        const int ty = tq % p.tiles_y;
+        c.n = tq / p.tiles_y;
+        c.x0 = tx * TILE;
+        c.y0 = ty * TILE;
 #pragma unroll
-    for (int r = 0; r < IN_ROUNDS; ++r) {
-        const int idx = tid + r * THREADS;
-        const int half = idx / NPX;
-        const int pl = idx - half * NPX;
-        const int ly = pl / TH, lx = pl - ly * TH;
-        const int gy = y0 - HALO + ly, gx = x0 - HALO + lx;
-        const bool ok = idx < IN_ITEMS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        if (IN_NCHW)
-            in_voff[r] = (ok && half == 0) ? (unsigned)(gy * p.W + gx) * 4u : OOB;
-        else
-            in_voff[r] = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff + 4 * half) * 4u : OOB;
-    }
-    const size_t img_floats = (size_t)p.H * p.W * (IN_NCHW ? 1 : p.in_pitch);
-    const float* xn = p.x + (size_t)n * img_floats * (IN_NCHW ? p.cin : 1);
-    const __amdgpu_buffer_rsrc_t xrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, (int)(img_floats * (IN_NCHW ? p.cin : 1) * 4), 0x00020000);
-
+        for (int r = 0; r < IN_ROUNDS; ++r) {
+            const int idx = tid + r * THREADS;
+            const int half = idx & 1;
+            const int pl = idx >> 1;
+            const int ly = pl / TH, lx = pl - ly * TH;
+            const int gy = c.y0 - HALO + ly, gx = c.x0 - HALO + lx;
+            const bool ok = idx < IN_ITEMS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            if (IN_NCHW)
+                c.voff[r] = (ok && half == 0) ? (unsigned)(gy * p.W + gx) * 4u : OOB;
+            else
+                c.voff[r] = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff + 4 * half) * 4u : OOB;
+        }
+    };
+    const size_t img_floats = (size_t)p.H * p.W * (IN_NCHW ? p.cin : p.in_pitch);
+    auto image_rsrc = [&](int n) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)n * img_floats), 0, (int)(img_floats * 4), 0x00020000);
+    };
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, p.nchunks * (W_FLOATS * 4), 0x00020000);
 
     f32x4 in_reg[IN_ROUNDS];
     f32x4 w_reg[W_ROUNDS];
 
-    auto load_stage = [&](int c) {
+    auto load_stage = [&](const TileCtx& tc, int c) {
+        const __amdgpu_buffer_rsrc_t xrsrc = image_rsrc(tc.n);
 #pragma unroll
         for (int r = 0; r < IN_ROUNDS; ++r) {
             if (IN_NCHW) {
                 const unsigned plane = (unsigned)(p.H * p.W) * 4u;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, in_voff[r], 0, 0));
-                if (p.cin > 1) v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, in_voff[r], plane, 0));
-                if (p.cin > 2) v.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, in_voff[r], 2 * plane, 0));
-                if (p.cin > 3) v.w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, in_voff[r], 3 * plane, 0));
+                v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, tc.voff[r], 0, 0));
+                if (p.cin > 1) v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, tc.voff[r], plane, 0));
+                if (p.cin > 2) v.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, tc.voff[r], 2 * plane, 0));
+                if (p.cin > 3) v.w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, tc.voff[r], 3 * plane, 0));
                 in_reg[r] = v;
             } else {
-                in_reg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, in_voff[r], c * (CHUNK * 4), 0));
+                in_reg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, tc.voff[r], c * (CHUNK * 4), 0));
             }
         }
 #pragma unroll
@@ -236,7 +348,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
         for (int r = 0; r < IN_ROUNDS; ++r) {
             const int idx = tid + r * THREADS;
             if (IN_ITEMS % THREADS == 0 || idx < IN_ITEMS)
-                *reinterpret_cast<f32x4*>(s + idx * 16) = in_reg[r];
+                *reinterpret_cast<f32x4*>(s + (idx & 1) * (NPX * 16) + (idx >> 1) * 16) = in_reg[r];
         }
 #pragma unroll
         for (int r = 0; r < W_ROUNDS; ++r) {
@@ -246,64 +358,79 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
         }
     };
 
-    load_stage(0);
-
-    // accumulators start at the bias (lane's 4 output channels per tile): no bias add in the epilogue
-    f32x4 acc[NT][4];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + t * 16 + kq * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = bv;
-    }
-
     // lane-constant LDS byte offsets
     const int b_base = (kq >> 1) * (NPX * 16) + ((wv * 4) * TH + px) * 16 + (kq & 1) * 8;
     const int a_base = IN_BYTES + lane * 8;
 
+    int k = 0;
+    int t = tile_index(0);
+    if (t < 0) return;
+    TileCtx cur, nxt;
+    setup_tile(t, cur);
+    load_stage(cur, 0);
     store_stage(0);
     __syncthreads();
+    int sbuf = 0;
 
-    for (int c = 0; c < p.nchunks; ++c) {
-        const bool more = c + 1 < p.nchunks;
-        if (more) load_stage(c + 1);
-        __builtin_amdgcn_s_setprio(0);
-        const char* s = smem + (c & 1) * STAGE_BYTES;
-        // fragment reads run one tap ahead of the MFMAs that consume them
-        f32x2 a[2][NT], b[2][4];
-        auto load_frag = [&](int slot, int tap) {
-            const int dy = tap / KS, dx = tap - dy * KS;
+    for (;;) {
+        const int tn = tile_index(k + 1);
+        const bool has_next = tn >= 0;
+
+        // accumulators start at the bias (lane's 4 output channels per tile): no bias add in the epilogue
+        f32x4 acc[NT][4];
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                a[slot][t] = *reinterpret_cast<const f32x2*>(s + a_base + (tap * NT + t) * 512);
+        for (int tt = 0; tt < NT; ++tt) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + tt * 16 + kq * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                b[slot][r] = *reinterpret_cast<const f32x2*>(s + b_base + ((r + dy) * TH + dx) * 16);
-        };
-        load_frag(0, 0);
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int cur = tap & 1;
-            if (tap + 1 < TAPS) load_frag(cur ^ 1, tap + 1);
-            __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ABOVE this tap's MFMAs
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][t][j], b[cur][r][j], acc[t][r], 0, 0, 0);
+            for (int r = 0; r < 4; ++r) acc[tt][r] = bv;
         }
-        __builtin_amdgcn_s_setprio(3);
-        if (more) store_stage((c + 1) & 1);
-        __syncthreads();
-    }
 
-    switch (p.act) {
-        case ESR_ACT_LRELU: epilogue<ESR_ACT_LRELU, NT>(p, acc, n, x0, y0, wv, px, kq); break;
-        case ESR_ACT_RELU: epilogue<ESR_ACT_RELU, NT>(p, acc, n, x0, y0, wv, px, kq); break;
-        case ESR_ACT_GELU: epilogue<ESR_ACT_GELU, NT>(p, acc, n, x0, y0, wv, px, kq); break;
-        default: epilogue<ESR_ACT_NONE, NT>(p, acc, n, x0, y0, wv, px, kq); break;
+        for (int c = 0; c < p.nchunks; ++c) {
+            const bool more = c + 1 < p.nchunks;
+            if (more) {
+                load_stage(cur, c + 1);
+            } else if (has_next) {          // cross-tile prefetch: next tile's first stage under this tile's last chunk
+                setup_tile(tn, nxt);
+                load_stage(nxt, 0);
+            }
+            const char* s = smem + sbuf * STAGE_BYTES;
+            // fragment reads run one tap ahead of the MFMAs that consume them
+            f32x2 a[2][NT], b[2][4];
+            auto load_frag = [&](int slot, int tap) {
+                const int dy = tap / KS, dx = tap - dy * KS;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+                    a[slot][tt] = *reinterpret_cast<const f32x2*>(s + a_base + (tap * NT + tt) * 512);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    b[slot][r] = *reinterpret_cast<const f32x2*>(s + b_base + ((r + dy) * TH + dx) * 16);
+            };
+            load_frag(0, 0);
+            __builtin_amdgcn_s_setprio(0);             // only the MFMA stream runs at base priority
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int cs = tap & 1;
+                if (tap + 1 < TAPS) load_frag(cs ^ 1, tap + 1);
+                __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ABOVE this tap's MFMAs
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[tt][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cs][tt][j], b[cs][r][j], acc[tt][r], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(3);
+            if (more || has_next) store_stage(sbuf ^ 1);
+            __syncthreads();
+            sbuf ^= 1;
+        }
+
+        if (p.out_layout == ESR_NCHW_SHUFFLE4) epilogue_shuffle<NT>(p, acc, cur.n, cur.x0, cur.y0, wv, lane);
+        else epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane);
+        if (!has_next) break;
+        cur = nxt;
+        ++k;
     }
 }
 
@@ -315,7 +442,9 @@ inline int round_up(int v, int m) { return esr_round_up(v, m); }
 template <int NT, int KS, bool IN_NCHW>
 int launch_conv(const ConvK& k, hipStream_t st)
 {
-    const int grid = k.N * k.tiles_x * k.tiles_y;
+    // persistent: at most 2 blocks per CU (LDS-limited), each walks ntiles/grid tiles
+    const int ntiles = k.N * k.tiles_x * k.tiles_y;
+    const int grid = ntiles < MAX_RESIDENT_BLOCKS ? ntiles : MAX_RESIDENT_BLOCKS;
     hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW>), dim3(grid), dim3(THREADS), 0, st, k);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

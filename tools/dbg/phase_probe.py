@@ -15,8 +15,8 @@ b = torch.randn(64)
 from ntire2022_esr_amd.engine import pack_conv
 pk = pack_conv(w, b).to(dev)
 out = torch.empty(B, 256, 256, 64, device=dev)
-nblk = B * 256
-dbg = torch.zeros(nblk * 4 * 8, dtype=torch.int64, device=dev)
+nblk = min(B * 256, 512)
+dbg = torch.zeros(nblk * 4 * 8 * 2 + 512 * 4 * 8 * 2, dtype=torch.int64, device=dev)
 for it in range(3):
     ops.conv2d(x, w, b, act=1, packed=pk, out=out)
 torch.cuda.synchronize()
@@ -26,4 +26,6 @@ s.record(); ops.conv2d(x, w, b, act=1, packed=pk, out=out); e.record(); torch.cu
 print("instrumented launch ms", s.elapsed_time(e))
 lib.esr_set_dbg(None)
 os.makedirs("gpurun_out/dbg", exist_ok=True)
-np.save("gpurun_out/dbg/phase.npy", dbg.cpu().numpy().reshape(nblk, 4, 8))
+a = dbg.cpu().numpy()
+np.save("gpurun_out/dbg/phase.npy", a[:nblk * 32].reshape(nblk, 4, 8))
+np.save("gpurun_out/dbg/epi.npy", a[512 * 32:512 * 32 + nblk * 32].reshape(nblk, 4, 8))

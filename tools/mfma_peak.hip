@@ -8,6 +8,32 @@
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// same FLOPs per iteration with v_mfma_f32_32x32x2_f32 (4 accumulators x 16 regs, 64-cycle issue)
+__global__ __launch_bounds__(256) void mfma_stream32(const float* in, float* out, int iters, unsigned long long* clk)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    float a[2], b[2];
+    for (int i = 0; i < 2; ++i) { a[i] = in[(tid * 8 + i) & 0xFFFFF]; b[i] = in[(tid * 8 + 4 + i) & 0xFFFFF]; }
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    acc[t * 2 + r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[r], acc[t * 2 + r], 0, 0, 0);
+    }
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
+    out[tid] = s;
+    if (threadIdx.x == 0) { clk[blockIdx.x * 2] = c1 - c0; clk[blockIdx.x * 2 + 1] = w1 - w0; }
+}
+
 template <int WAVES_PER_BLOCK>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void mfma_stream(const float* in, float* out, int iters,
                                                                      unsigned long long* clk)
@@ -69,5 +95,22 @@ int main()
     run<4>("random, 4 waves/SIMD", d_rand, d_out, d_clk, 1024, iters);
     run<4>("zeros,  2 waves/SIMD", d_zero, d_out, d_clk, 512, iters);
     run<4>("random, 2 waves/SIMD again", d_rand, d_out, d_clk, 512, iters);
+    // sustained: ~150 ms per launch, 5 launches back to back
+    run<4>("SUSTAINED 16x16x4 random 2 waves/SIMD", d_rand, d_out, d_clk, 512, 300000);
+    run<4>("SUSTAINED 16x16x4 zeros  2 waves/SIMD", d_zero, d_out, d_clk, 512, 300000);
+    {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        const int it32 = 300000;
+        mfma_stream32<<<512, 256>>>(d_rand, d_out, 1000, d_clk); hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int k = 0; k < 5; ++k) mfma_stream32<<<512, 256>>>(d_rand, d_out, it32, d_clk);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+        std::vector<unsigned long long> clk(1024);
+        hipMemcpy(clk.data(), d_clk, 1024 * 8, hipMemcpyDeviceToHost);
+        double sc = 0, sw = 0; for (int i = 0; i < 512; ++i) { sc += clk[2 * i]; sw += clk[2 * i + 1]; }
+        const double flops = 2.0 * 32 * 32 * 2 * 8.0 * it32 * 512.0 * 4;
+        printf("%-38s %8.3f ms  %7.1f TFLOP/s  shader clk %.3f GHz\n", "SUSTAINED 32x32x2 random 2 waves/SIMD", ms, flops / ms / 1e9, sc / sw * 0.1);
+    }
     return 0;
 }

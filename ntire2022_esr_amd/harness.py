@@ -81,8 +81,13 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
         img_sr = util.tensor2uint(img_sr, data_range)
         img_hr = util.modcrop(util.imread_uint(hr_path, n_channels=3).squeeze(), sf)
         psnr = util.calculate_psnr(img_sr, img_hr, border=border)
-        rows.append((i, ms, psnr, float("nan")))
-        logger.info("{:s} - PSNR: {:.2f} dB".format(img_name + ext, psnr))
+        if getattr(args, "ssim", False):
+            ssim = util.calculate_ssim(img_sr, img_hr, border=border)
+            logger.info("{:s} - PSNR: {:.2f} dB; SSIM: {:.4f}.".format(img_name + ext, psnr, ssim))
+        else:
+            ssim = float("nan")
+            logger.info("{:s} - PSNR: {:.2f} dB".format(img_name + ext, psnr))
+        rows.append((i, ms, psnr, ssim))
         util.imsave(img_sr, os.path.join(save_path, img_name[:4] + ext))
     allrows = D.gather_rows(rows, len(data_path), rank, world, device)
     results = {f"{mode}_runtime": [float(v) for v in allrows[:, 1]],
@@ -96,6 +101,9 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
     results[f"{mode}_memory"] = mem
     results[f"{mode}_ave_runtime"] = D.ordered_mean(results[f"{mode}_runtime"])
     results[f"{mode}_ave_psnr"] = D.ordered_mean(results[f"{mode}_psnr"])
+    if getattr(args, "ssim", False):
+        results[f"{mode}_ssim"] = [float(v) for v in allrows[:, 3]]
+        results[f"{mode}_ave_ssim"] = D.ordered_mean(results[f"{mode}_ssim"])
     logger.info("{:>16s} : {:<.3f} [M]".format("Max Memery", results[f"{mode}_memory"]))
     logger.info("------> Average runtime of ({}) is : {:.6f} seconds".format(
         "test" if mode == "test" else "valid", results[f"{mode}_ave_runtime"]))
@@ -134,8 +142,6 @@ def main(args):
         for h in (logging.FileHandler("NTIRE2022-EfficientSR.log", mode="a"), logging.StreamHandler()):
             h.setFormatter(fmt)
             logger.addHandler(h)
-    if args.ssim:
-        raise SystemExit("--ssim: calculate_ssim (utils_image.py:509-554) is not implemented yet (SURVEY 8f N1)")
     if not torch.cuda.is_available():
         raise SystemExit("the HIP engine needs an MI355X; there is no CPU fallback (use oracle/ for CPU checks)")
     rank, world, local_rank = D.init_from_env(use_cuda=True)

@@ -3,8 +3,10 @@
 Restates the six `utils/utils_image.py` functions `test_demo.run()` calls
 with PIL instead of cv2 (PNG/BMP decoding is lossless, so the arrays are identical):
   imread_uint :122-134   imsave :137-141   uint2tensor4 :190-193
-  tensor2uint :204-208   modcrop :442-455  calculate_psnr :490-503
-Pinned against the reference's own outputs in tests/test_harness.py (tests/golden/metrics.*).
+  tensor2uint :204-208   modcrop :442-455  calculate_psnr :490-503   calculate_ssim / ssim :509-554
+Pinned against the reference's own outputs in tests/test_harness.py (tests/golden/metrics.*) -- except
+SSIM, which needs cv2 to run in the reference and is therefore PARITY-UNPINNED: it is checked against an
+independent dense evaluation of the published formula instead.
 """
 import math
 import os
@@ -70,3 +72,49 @@ def calculate_psnr(img1, img2, border=0):
     if mse == 0:
         return float('inf')
     return 20 * math.log10(255.0 / math.sqrt(mse))
+
+
+def _gaussian_kernel(ksize=11, sigma=1.5):
+    """cv2.getGaussianKernel(11, 1.5): exp(-(i-(k-1)/2)^2 / (2 sigma^2)), normalised to sum 1."""
+    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) / 2.0
+    g = np.exp(-(x * x) / (2.0 * sigma * sigma))
+    return g / g.sum()
+
+
+def _ssim(img1, img2):
+    """ssim() utils_image.py:536-554: 11x11 Gaussian window = outer(k, k), 'valid' region only (the
+    reference crops filter2D's output by 5 px per side, so its border mode never matters), float64."""
+    from scipy.ndimage import correlate1d
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    a, b = img1.astype(np.float64), img2.astype(np.float64)
+    k = _gaussian_kernel()
+
+    def blur(x):
+        y = correlate1d(correlate1d(x, k, axis=0, mode="nearest"), k, axis=1, mode="nearest")
+        return y[5:-5, 5:-5]
+
+    mu1, mu2 = blur(a), blur(b)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1 ** 2, mu2 ** 2, mu1 * mu2
+    s1 = blur(a ** 2) - mu1_sq
+    s2 = blur(b ** 2) - mu2_sq
+    s12 = blur(a * b) - mu1_mu2
+    m = ((2 * mu1_mu2 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
+    return m.mean()
+
+
+def calculate_ssim(img1, img2, border=0):
+    """calculate_ssim utils_image.py:509-533.  For a 3-channel image the reference evaluates ssim() on the
+    WHOLE HxWx3 array three times and averages (its loop index is unused), i.e. one evaluation."""
+    if not img1.shape == img2.shape:
+        raise ValueError('Input images must have the same dimensions.')
+    h, w = img1.shape[:2]
+    img1 = img1[border:h - border, border:w - border]
+    img2 = img2[border:h - border, border:w - border]
+    if img1.ndim == 2:
+        return _ssim(img1, img2)
+    if img1.ndim == 3:
+        if img1.shape[2] == 3:
+            return np.array([_ssim(img1, img2) for _ in range(1)] * 3).mean()
+        if img1.shape[2] == 1:
+            return _ssim(np.squeeze(img1), np.squeeze(img2))
+    raise ValueError('Wrong input image dimensions.')

@@ -145,3 +145,43 @@ def test_run_world2_gloo_equals_world1_and_reference(tmp_path):
     assert abs(r1["valid_ave_psnr"] - ref["valid_ave_psnr"]) < 0.002
     # every rank wrote its own SR PNGs under save_dir/<model>/valid/
     assert sorted(os.listdir(str(tmp_path / "s2" / "imdn" / "valid"))) == ["0801.png", "0802.png", "0803.png"]
+
+
+def test_ssim_formula_and_properties():
+    """SSIM is parity-unpinned (the reference needs cv2): check against a dense 11x11-window evaluation of the
+    published formula, plus identity / symmetry / the 3-channel convention."""
+    rng = np.random.RandomState(5)
+    a = rng.randint(0, 256, (40, 52, 3)).astype(np.uint8)
+    b = np.clip(a.astype(int) + rng.randint(-20, 21, a.shape), 0, 255).astype(np.uint8)
+    assert util.calculate_ssim(a, a, border=4) == pytest.approx(1.0, abs=1e-12)
+    s_ab = util.calculate_ssim(a, b, border=4)
+    assert s_ab == pytest.approx(util.calculate_ssim(b, a, border=4), abs=1e-12) and 0 < s_ab < 1
+    # dense reference: full 2-D window, explicit loops over the valid region of the border-cropped arrays
+    k = util._gaussian_kernel()
+    win = np.outer(k, k)
+    assert abs(k.sum() - 1) < 1e-15 and k[5] == k.max() and np.allclose(k, k[::-1])
+    x, y = a[4:-4, 4:-4].astype(np.float64), b[4:-4, 4:-4].astype(np.float64)
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    vals = []
+    for c in range(3):
+        for i in range(5, x.shape[0] - 5):
+            for j in range(5, x.shape[1] - 5):
+                px, py = x[i - 5:i + 6, j - 5:j + 6, c], y[i - 5:i + 6, j - 5:j + 6, c]
+                m1, m2 = (win * px).sum(), (win * py).sum()
+                v1, v2, v12 = (win * px * px).sum() - m1 * m1, (win * py * py).sum() - m2 * m2, (win * px * py).sum() - m1 * m2
+                vals.append(((2 * m1 * m2 + C1) * (2 * v12 + C2)) / ((m1 * m1 + m2 * m2 + C1) * (v1 + v2 + C2)))
+    assert s_ab == pytest.approx(np.mean(vals), abs=1e-10)
+    g = a[..., 0]
+    assert util.calculate_ssim(g, g) == pytest.approx(1.0, abs=1e-12)
+    with pytest.raises(ValueError):
+        util.calculate_ssim(a, a[:-1])
+
+
+def test_free_rider_registry_surface():
+    """ids 6 / 22 / 26 reuse the RFDN / IMDN graphs with their own checkpoints (test_demo.py:66-72,175-181,203-209)."""
+    from ntire2022_esr_amd import IMDN, RFDN
+    from ntire2022_esr_amd.registry import load_checkpoint, supported_ids
+    assert supported_ids() == [-1, 0, 4, 6, 18, 22, 26]
+    for stem, m in (("team06_v1", RFDN(nf=50)), ("team22_rep_rfdn", RFDN(nf=40)), ("team26_imdn_nb7", IMDN(nb=7))):
+        missing, unexpected = m.load_state_dict(load_checkpoint(stem), strict=True)
+        assert not missing and not unexpected

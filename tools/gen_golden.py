@@ -95,6 +95,28 @@ def load_reference_models():
     return out
 
 
+def load_free_riders():
+    """Registry entries that reuse the in-scope graphs with their own checkpoints:
+    id 6 `v1` and id 22 `RFDN40` are the rfdn_baseline graph (nf=50 / nf=40), id 26 is IMDN with nb=7."""
+    from models.team06_v1 import v1
+    from models.team22_rep_rfdn import RFDN40
+    from models.imdn_baseline import IMDN
+
+    def ld(name):
+        return torch.load(os.path.join(REF, "model_zoo", name), map_location="cpu", weights_only=False)
+
+    out = {}
+    for key, ctor, ck in (("team06_v1", lambda: v1(in_nc=3, nf=50, num_modules=4, out_nc=3, upscale=4), "team06_v1.pth"),
+                          ("team22_rep_rfdn", RFDN40, "team22_rep_rfdn.pth"),
+                          ("team26_imdn_nb7", lambda: IMDN(in_nc=3, out_nc=3, nc=64, nb=7, upscale=4, act_mode='L',
+                                                           upsample_mode='pixelshuffle'), "team26_imdn_nb7.pth")):
+        m = ctor()
+        sd = ld(ck)
+        m.load_state_dict(sd, strict=True)
+        out[key] = (m.eval(), sd, 1.0)
+    return out
+
+
 def sha256(path):
     h = hashlib.sha256()
     with open(path, "rb") as f:
@@ -125,6 +147,23 @@ def main():
             "num_elements": int(sum(v.numel() for v in tensors.values())),
             "keys": {k: list(v.shape) for k, v in tensors.items()},
         }
+    with open(os.path.join(WDIR, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+
+    # ---- free riders: weights + one small seeded vector each -------------------
+    riders = load_free_riders()
+    with torch.no_grad():
+        for name, (m, sd, dr) in riders.items():
+            tensors = {k: v.detach().float().contiguous().clone() for k, v in sd.items()}
+            path = os.path.join(WDIR, name + ".safetensors")
+            save_file(tensors, path)
+            manifest[name] = {"file": name + ".safetensors", "sha256": sha256(path), "data_range": dr,
+                              "num_tensors": len(tensors),
+                              "num_elements": int(sum(v.numel() for v in tensors.values())),
+                              "keys": {k: list(v.shape) for k, v in tensors.items()}}
+            g = torch.Generator().manual_seed(2)
+            xb = torch.rand(2, 3, 20, 36, generator=g) * dr
+            np.savez(os.path.join(GOLD, f"e2e_{name}.npz"), xb=xb.numpy(), yb=m(xb).numpy(), data_range=np.float32(dr))
     with open(os.path.join(WDIR, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESR_ABI_VERSION 1
+#define ESR_ABI_VERSION 2
 
 typedef enum esr_status {
     ESR_OK = 0,
@@ -46,6 +46,12 @@ typedef enum esr_act { ESR_ACT_NONE = 0, ESR_ACT_LRELU = 1, ESR_ACT_RELU = 2, ES
  *   PRE : act(conv(x) + r)   RFDB  rfdn_baseline/block.py:151 ; ShortcutBlock basicblock.py:197-199 (act none)
  *   POST: act(conv(x)) + r   RLFB  team04_rlfn.py:117-119 */
 typedef enum esr_res { ESR_RES_NONE = 0, ESR_RES_PRE_ACT = 1, ESR_RES_POST_ACT = 2 } esr_res;
+
+/* arithmetic of the matrix products (storage and accumulation are always fp32):
+ *   F32   exact fp32 MFMA (v_mfma_f32_16x16x4_f32)
+ *   BF16 / F16   operands rounded (RNE) to bf16 / fp16, v_mfma_f32_16x16x16_{bf16,f16}, fp32 accumulate;
+ *                3x3 NHWC convolutions only; wpacked must come from esr_pack_conv_h16 */
+typedef enum esr_compute { ESR_COMPUTE_F32 = 0, ESR_COMPUTE_BF16 = 1, ESR_COMPUTE_F16 = 2 } esr_compute;
 
 typedef enum esr_layout {
     ESR_NHWC = 0,            /* [n][h][w][pitch] fp32, channel slice [coff, coff+c) */
@@ -85,7 +91,9 @@ typedef struct esr_conv_desc {
     esr_view in;                /* pitch/coff ignored for ESR_NCHW_IN */
     esr_view res;               /* residual, NHWC, `cout` channels from coff; unused if ESR_RES_NONE */
     esr_view out0, out1;        /* out0.ptr is the NCHW tensor for ESR_NCHW_SHUFFLE4 */
-    const void* wpacked;        /* device pointer to esr_pack_conv_f32 output */
+    const void* wpacked;        /* device pointer to esr_pack_conv_f32 (or esr_pack_conv_h16) output */
+    int32_t compute;            /* esr_compute; 0 = fp32 */
+    int32_t reserved;
 } esr_conv_desc;
 
 /* Host-side weight packer (the K10 "weight packer" of SURVEY 7.2): OIHW fp32 (the layout of every
@@ -99,6 +107,12 @@ int    esr_pack_conv_f32(const float* w_oihw, const float* bias, int cin, int co
 /* inverse, for tests: recovers OIHW + bias from a packed blob */
 int    esr_unpack_conv_f32(const void* packed, size_t bytes, int cin, int cout, int ksize,
                            const int32_t* cin_map, int cin_phys, float* w_oihw, float* bias);
+
+/* 16-bit-operand weights for ESR_COMPUTE_BF16 / ESR_COMPUTE_F16 (3x3 only): [cin chunk][tap pair][tile][lane][4]
+ * 16-bit values (RNE from fp32) followed by the fp32 bias.  `compute` selects the operand format. */
+size_t esr_packed_conv_h16_bytes(int cin_phys, int cout);
+int    esr_pack_conv_h16(const float* w_oihw, const float* bias, int cin, int cout, const int32_t* cin_map,
+                         int cin_phys, int compute, void* out, size_t out_bytes);
 
 int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream);
 

@@ -18,6 +18,8 @@ RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
 NHWC, NCHW_IN, NCHW_SHUFFLE4 = 0, 1, 2
 OP_CONV, OP_CONV3X3S2, OP_MAXPOOL7S3, OP_ESA_APPLY, OP_DWCONV = 0, 1, 2, 3, 4
 ESA_FP = 16
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2
+COMPUTE = {"f32": 0, "bf16": 1, "f16": 2}
 
 
 class View(ctypes.Structure):
@@ -33,6 +35,7 @@ class ConvDesc(ctypes.Structure):
         ("res_mode", ctypes.c_int32), ("split", ctypes.c_int32),
         ("inp", View), ("res", View), ("out0", View), ("out1", View),
         ("wpacked", ctypes.c_void_p),
+        ("compute", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
 
@@ -54,6 +57,7 @@ class Op(ctypes.Structure):
 EXPORTS = [
     "esr_abi_version", "esr_last_hip_error", "esr_build_info",
     "esr_packed_conv_bytes", "esr_pack_conv_f32", "esr_unpack_conv_f32",
+    "esr_packed_conv_h16_bytes", "esr_pack_conv_h16",
     "esr_conv2d_f32", "esr_run_ops",
     "esr_prof_create", "esr_run_ops_profiled", "esr_prof_collect", "esr_prof_destroy",
     "esr_packed_dense_bytes", "esr_pack_dense_f32",
@@ -87,6 +91,10 @@ def lib():
     L.esr_pack_conv_f32.restype = ci
     L.esr_unpack_conv_f32.argtypes = [vp, sz, ci, ci, ci, vp, ci, vp, vp]
     L.esr_unpack_conv_f32.restype = ci
+    L.esr_packed_conv_h16_bytes.argtypes = [ci, ci]
+    L.esr_packed_conv_h16_bytes.restype = sz
+    L.esr_pack_conv_h16.argtypes = [vp, vp, ci, ci, vp, ci, ci, vp, sz]
+    L.esr_pack_conv_h16.restype = ci
     L.esr_conv2d_f32.argtypes = [ctypes.POINTER(ConvDesc), vp]
     L.esr_conv2d_f32.restype = ci
     L.esr_run_ops.argtypes = [ctypes.POINTER(Op), ci, vp]
@@ -112,7 +120,7 @@ def lib():
     L.esr_prof_collect.restype = ci
     L.esr_prof_destroy.argtypes = [vp]
     L.esr_prof_destroy.restype = None
-    if L.esr_abi_version() != 1:
+    if L.esr_abi_version() != 2:
         raise EsrError("libesr_hip.so ABI version mismatch")
     _lib = L
     return L

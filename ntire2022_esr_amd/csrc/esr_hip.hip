@@ -434,6 +434,201 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
     }
 }
 
+// ---- 16-bit-operand variant (bf16 or fp16 MFMA operands, fp32 accumulate, fp32 storage) ----------------
+// Same persistent structure as conv_f32_kernel, KS = 3 and NHWC input only.  Activations stay fp32 in HBM and
+// are rounded (RNE) to bf16/fp16 while they are staged into LDS; weights are pre-rounded by esr_pack_conv_h16.
+// K slots of v_mfma_f32_16x16x16_{bf16,f16}: lane (i, kq) holds 4 consecutive k; here k-slot kq carries
+// tap 2*pair + (kq >> 1), channels c0 + 4*(kq & 1) + 0..3 -- one MFMA covers TWO taps x 8 channels, so the 9
+// taps of a chunk take 5 MFMAs (the 10th tap has zero weights) instead of 18 fp32 ones, at 16x the rate:
+// the layer becomes HBM/LDS-bound.  D fragment and epilogues are identical to the fp32 kernel.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
+constexpr int H16_PAIRS = 5;
+
+template <bool BF16>
+__device__ __forceinline__ unsigned long long cvt4(f32x4 v)
+{
+    if (BF16) {
+        b16x4 b;
+        b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
+        return __builtin_bit_cast(unsigned long long, b);
+    } else {
+        h16x4 h;
+        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+        return __builtin_bit_cast(unsigned long long, h);
+    }
+}
+
+template <bool BF16>
+__device__ __forceinline__ f32x4 mfma16(unsigned long long a, unsigned long long b, f32x4 c)
+{
+    if (BF16) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
+}
+
+template <int NT, bool BF16>
+__global__ __launch_bounds__(THREADS, 2) void conv_h16_kernel(const ConvK p)
+{
+    constexpr int TH = TILE + 2;
+    constexpr int NPX = TH * TH;
+    constexpr int IN_ITEMS = 2 * NPX;                 // (pixel, half) items: 16 B fp32 in HBM -> 8 B in LDS
+    constexpr int IN_BYTES = IN_ITEMS * 8;
+    constexpr int W_ITEMS = H16_PAIRS * NT * 32;      // 16-byte items per stage (weights, 16-bit)
+    constexpr int W_BYTES = W_ITEMS * 16;
+    constexpr int STAGE_BYTES = IN_BYTES + W_BYTES;
+    constexpr int IN_ROUNDS = (IN_ITEMS + THREADS - 1) / THREADS;
+    constexpr int W_ROUNDS = (W_ITEMS + THREADS - 1) / THREADS;
+    constexpr unsigned OOB = 0x80000000u;
+
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + 4 * EPI_WAVE_FLOATS * 4];
+
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int px = lane & 15;
+    const int kq = lane >> 4;
+    float* const scr = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES) + wv * EPI_WAVE_FLOATS;
+
+    const int ntiles = p.N * p.tiles_y * p.tiles_x;
+    const int G = gridDim.x;
+    auto tile_index = [&](int k) -> int {
+        const int base = k * G;
+        if (base >= ntiles) return -1;
+        int off = blockIdx.x;
+        if ((G & 7) == 0 && base + G <= ntiles) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+        const int t = base + off;
+        return t < ntiles ? t : -1;
+    };
+    struct TileCtx { int n, x0, y0; unsigned voff[IN_ROUNDS]; };
+    auto setup_tile = [&](int t, TileCtx& c) {
+        const int tx = t % p.tiles_x;
+        const int tq = t / p.tiles_x;
+        const int ty = tq % p.tiles_y;
+        c.n = tq / p.tiles_y;
+        c.x0 = tx * TILE;
+        c.y0 = ty * TILE;
+#pragma unroll
+        for (int r = 0; r < IN_ROUNDS; ++r) {
+            const int idx = tid + r * THREADS;
+            const int half = idx & 1;
+            const int pl = idx >> 1;
+            const int ly = pl / TH, lx = pl - ly * TH;
+            const int gy = c.y0 - 1 + ly, gx = c.x0 - 1 + lx;
+            const bool ok = idx < IN_ITEMS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            c.voff[r] = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff + 4 * half) * 4u : OOB;
+        }
+    };
+    const size_t img_floats = (size_t)p.H * p.W * p.in_pitch;
+    auto image_rsrc = [&](int n) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)n * img_floats), 0, (int)(img_floats * 4), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, p.nchunks * W_BYTES, 0x00020000);
+
+    f32x4 in_reg[IN_ROUNDS];
+    f32x4 w_reg[W_ROUNDS];
+    auto load_stage = [&](const TileCtx& tc, int c) {
+        const __amdgpu_buffer_rsrc_t xrsrc = image_rsrc(tc.n);
+#pragma unroll
+        for (int r = 0; r < IN_ROUNDS; ++r)
+            in_reg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, tc.voff[r], c * (CHUNK * 4), 0));
+#pragma unroll
+        for (int r = 0; r < W_ROUNDS; ++r) {
+            const unsigned voff = (unsigned)min(tid + r * THREADS, W_ITEMS - 1) * 16u;
+            w_reg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, c * W_BYTES, 0));
+        }
+    };
+    auto store_stage = [&](int buf) {
+        char* s = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int r = 0; r < IN_ROUNDS; ++r) {
+            const int idx = tid + r * THREADS;
+            if (IN_ITEMS % THREADS == 0 || idx < IN_ITEMS)
+                *reinterpret_cast<unsigned long long*>(s + (idx & 1) * (NPX * 8) + (idx >> 1) * 8) = cvt4<BF16>(in_reg[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < W_ROUNDS; ++r) {
+            const int idx = tid + r * THREADS;
+            if (W_ITEMS % THREADS == 0 || idx < W_ITEMS)
+                *reinterpret_cast<f32x4*>(s + IN_BYTES + idx * 16) = w_reg[r];
+        }
+    };
+
+    // lane-constant LDS byte offsets: B operand of pair q reads tap min(2q + (kq >> 1), 8), channel half kq & 1
+    const int b_lane = (kq & 1) * (NPX * 8) + ((wv * 4) * TH + px) * 8;
+    int b_pair[H16_PAIRS];
+#pragma unroll
+    for (int q = 0; q < H16_PAIRS; ++q) {
+        const int tap = min(2 * q + (kq >> 1), 8);
+        b_pair[q] = b_lane + ((tap / 3) * TH + (tap % 3)) * 8;
+    }
+    const int a_base = IN_BYTES + lane * 8;
+
+    int k = 0;
+    int t = tile_index(0);
+    if (t < 0) return;
+    TileCtx cur, nxt;
+    setup_tile(t, cur);
+    load_stage(cur, 0);
+    store_stage(0);
+    __syncthreads();
+    int sbuf = 0;
+
+    for (;;) {
+        const int tn = tile_index(k + 1);
+        const bool has_next = tn >= 0;
+        f32x4 acc[NT][4];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + tt * 16 + kq * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[tt][r] = bv;
+        }
+        for (int c = 0; c < p.nchunks; ++c) {
+            const bool more = c + 1 < p.nchunks;
+            if (more) {
+                load_stage(cur, c + 1);
+            } else if (has_next) {
+                setup_tile(tn, nxt);
+                load_stage(nxt, 0);
+            }
+            const char* s = smem + sbuf * STAGE_BYTES;
+            unsigned long long a[2][NT], b[2][4];
+            auto load_frag = [&](int slot, int q) {
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+                    a[slot][tt] = *reinterpret_cast<const unsigned long long*>(s + a_base + (q * NT + tt) * 512);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    b[slot][r] = *reinterpret_cast<const unsigned long long*>(s + b_pair[q] + r * (TH * 8));
+            };
+            load_frag(0, 0);
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int q = 0; q < H16_PAIRS; ++q) {
+                const int cs = q & 1;
+                if (q + 1 < H16_PAIRS) load_frag(cs ^ 1, q + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[tt][r] = mfma16<BF16>(a[cs][tt], b[cs][r], acc[tt][r]);
+            }
+            __builtin_amdgcn_s_setprio(3);
+            if (more || has_next) store_stage(sbuf ^ 1);
+            __syncthreads();
+            sbuf ^= 1;
+        }
+        if (p.out_layout == ESR_NCHW_SHUFFLE4) epilogue_shuffle<NT>(p, acc, cur.n, cur.x0, cur.y0, wv, lane);
+        else epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane);
+        if (!has_next) break;
+        cur = nxt;
+        ++k;
+    }
+}
+
 thread_local char g_err[256] = "";
 
 inline void set_err(const char* what, hipError_t e) { esr_set_err(what, e); }
@@ -466,6 +661,49 @@ int launch_conv_nt(int nt, const ConvK& k, hipStream_t st)
     return ESR_ERR_UNSUPPORTED;
 }
 
+template <int NT, bool BF16>
+int launch_h16(const ConvK& k, hipStream_t st)
+{
+    const int ntiles = k.N * k.tiles_x * k.tiles_y;
+    const int grid = ntiles < MAX_RESIDENT_BLOCKS ? ntiles : MAX_RESIDENT_BLOCKS;
+    hipLaunchKernelGGL((conv_h16_kernel<NT, BF16>), dim3(grid), dim3(THREADS), 0, st, k);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_err("conv_h16_kernel launch", e);
+        return ESR_ERR_LAUNCH;
+    }
+    return ESR_OK;
+}
+
+template <bool BF16>
+int launch_h16_nt(int nt, const ConvK& k, hipStream_t st)
+{
+    switch (nt) {
+        case 1: return launch_h16<1, BF16>(k, st);
+        case 2: return launch_h16<2, BF16>(k, st);
+        case 3: return launch_h16<3, BF16>(k, st);
+        case 4: return launch_h16<4, BF16>(k, st);
+    }
+    return ESR_ERR_UNSUPPORTED;
+}
+
+// host-side RNE conversions for the weight packer
+inline uint16_t f32_to_bf16(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);       // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline uint16_t f32_to_f16(float f)
+{
+    const _Float16 h = (_Float16)f;        // host compiler: IEEE RNE
+    uint16_t r;
+    memcpy(&r, &h, 2);
+    return r;
+}
+
 }  // namespace
 
 void esr_set_err(const char* what, hipError_t e)
@@ -490,7 +728,7 @@ extern "C" {
 
 int esr_abi_version(void) { return ESR_ABI_VERSION; }
 const char* esr_last_hip_error(void) { return g_err; }
-const char* esr_build_info(void) { return "gfx950 f32 v_mfma_f32_16x16x4_f32 tile16x16 chunk8 regstage-dbuf"; }
+const char* esr_build_info(void) { return "gfx950 f32:v_mfma_f32_16x16x4_f32 h16:v_mfma_f32_16x16x16_{bf16,f16} tile16x16 chunk8 persistent"; }
 
 size_t esr_packed_conv_bytes(int cin_phys, int cout, int ksize)
 {
@@ -559,6 +797,45 @@ int esr_unpack_conv_f32(const void* packed, size_t bytes, int cin, int cout, int
     return ESR_OK;
 }
 
+size_t esr_packed_conv_h16_bytes(int cin_phys, int cout)
+{
+    if (cin_phys <= 0 || cout <= 0) return 0;
+    const size_t nt = (size_t)round_up(cout, 16) / 16;
+    const size_t nchunks = (size_t)round_up(cin_phys, CHUNK) / CHUNK;
+    return nchunks * H16_PAIRS * nt * 512 + nt * 16 * sizeof(float);
+}
+
+int esr_pack_conv_h16(const float* w, const float* bias, int cin, int cout, const int32_t* cin_map, int cin_phys,
+                      int compute, void* out, size_t out_bytes)
+{
+    if (!w || !out || cin <= 0 || cout <= 0) return ESR_ERR_BAD_ARG;
+    if (compute != ESR_COMPUTE_BF16 && compute != ESR_COMPUTE_F16) return ESR_ERR_BAD_ARG;
+    if (!cin_map && cin_phys < cin) return ESR_ERR_BAD_ARG;
+    const size_t need = esr_packed_conv_h16_bytes(cin_phys, cout);
+    if (need == 0 || out_bytes < need) return ESR_ERR_BAD_ARG;
+    const int nt = round_up(cout, 16) / 16;
+    const int nchunks = round_up(cin_phys, CHUNK) / CHUNK;
+    memset(out, 0, need);
+    uint16_t* o = static_cast<uint16_t*>(out);
+    for (int s = 0; s < cin_phys; ++s) {
+        const int c = cin_map ? cin_map[s] : (s < cin ? s : -1);
+        if (c < 0) continue;
+        if (c >= cin) return ESR_ERR_BAD_ARG;
+        const int chunk = s / CHUNK, within = s % CHUNK;      // within = 4*(kq & 1) + j
+        for (int oc = 0; oc < cout; ++oc)
+            for (int tap = 0; tap < 9; ++tap) {
+                const int q = tap / 2, kq = (tap & 1) * 2 + within / 4, j = within % 4;
+                const size_t idx = ((((size_t)chunk * H16_PAIRS + q) * nt + oc / 16) * 64 + kq * 16 + oc % 16) * 4 + j;
+                const float v = w[((size_t)oc * cin + c) * 9 + tap];
+                o[idx] = compute == ESR_COMPUTE_BF16 ? f32_to_bf16(v) : f32_to_f16(v);
+            }
+    }
+    float* bo = reinterpret_cast<float*>(static_cast<char*>(out) + (size_t)nchunks * H16_PAIRS * nt * 512);
+    if (bias)
+        for (int oc = 0; oc < cout; ++oc) bo[oc] = bias[oc];
+    return ESR_OK;
+}
+
 int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
 {
     if (!d || !d->in.ptr || !d->out0.ptr || !d->wpacked) return ESR_ERR_BAD_ARG;
@@ -604,11 +881,15 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
 
     const int nt = round_up(d->cout, 16) / 16;
     const int taps = d->ksize * d->ksize;
+    const bool h16 = d->compute == ESR_COMPUTE_BF16 || d->compute == ESR_COMPUTE_F16;
+    if (d->compute != ESR_COMPUTE_F32 && !h16) return ESR_ERR_BAD_ARG;
+    if (h16 && (d->ksize != 3 || in_nchw)) return ESR_ERR_UNSUPPORTED;     // 16-bit operands: full 3x3 NHWC convs only
     ConvK k;
     k.x = static_cast<const float*>(d->in.ptr);
     k.wp = static_cast<const float*>(d->wpacked);
     k.nchunks = cin_phys / CHUNK;
-    k.bias = k.wp + (size_t)k.nchunks * taps * nt * 128;
+    k.bias = h16 ? reinterpret_cast<const float*>(static_cast<const char*>(d->wpacked) + (size_t)k.nchunks * H16_PAIRS * nt * 512)
+                 : k.wp + (size_t)k.nchunks * taps * nt * 128;
     k.res = static_cast<const float*>(d->res.ptr);
     k.y0 = static_cast<float*>(d->out0.ptr);
     k.y1 = static_cast<float*>(d->out1.ptr);
@@ -625,6 +906,7 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
     k.tiles_x = (d->w + TILE - 1) / TILE;
     k.tiles_y = (d->h + TILE - 1) / TILE;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (h16) return d->compute == ESR_COMPUTE_BF16 ? launch_h16_nt<true>(nt, k, st) : launch_h16_nt<false>(nt, k, st);
     if (in_nchw) return launch_conv_nt<3, true>(nt, k, st);
     if (d->ksize == 3) return launch_conv_nt<3, false>(nt, k, st);
     return launch_conv_nt<1, false>(nt, k, st);

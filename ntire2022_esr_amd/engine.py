@@ -49,6 +49,27 @@ def pack_conv(weight, bias, cin_map=None, cin_phys=None):
     return out
 
 
+def pack_conv_h16(weight, bias, compute, cin_map=None, cin_phys=None):
+    """3x3 OIHW fp32 weights -> 16-bit-operand blob (bf16 or fp16, RNE) + fp32 bias (esr_pack_conv_h16)."""
+    lib = L.lib()
+    w = weight.detach().to("cpu", torch.float32).contiguous()
+    cout, cin, k, _ = w.shape
+    assert k == 3
+    b = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
+    if cin_map is not None:
+        cm = np.ascontiguousarray(np.asarray(cin_map, dtype=np.int32))
+        cin_phys, cm_p = len(cm), cm.ctypes.data_as(ctypes.c_void_p)
+    else:
+        cm_p = None
+        cin_phys = cin if cin_phys is None else cin_phys
+    nbytes = lib.esr_packed_conv_h16_bytes(cin_phys, cout)
+    out = torch.empty((nbytes + 3) // 4, dtype=torch.float32)
+    L.check(lib.esr_pack_conv_h16(_ptr(w), _ptr(b) if b is not None else None, cin, cout, cm_p, cin_phys,
+                                  L.COMPUTE[compute] if isinstance(compute, str) else compute, _ptr(out), nbytes),
+            "esr_pack_conv_h16")
+    return out
+
+
 def pack_dense(weight, bias, cin_p, cout_p):
     """Plain [tap][cin_p][cout_p] + bias[cout_p] layout of the small ESA kernels (esr_pack_dense_f32)."""
     lib = L.lib()
@@ -159,7 +180,7 @@ class Plan:
         buf, coff, _ = v
         return L.View(ctypes.c_void_p(base_ptr + buf.offset * 4), buf.pitch, coff)
 
-    def finalize(self, workspace, weights):
+    def finalize(self, workspace, weights, h16=None, compute=0):
         """weights: name -> device blob tensor.  Returns (Op array, input op indices, output op indices)."""
         arr = (L.Op * len(self.ops))()
         in_idx, out_idx = [], []
@@ -211,7 +232,11 @@ class Plan:
                 d.out1 = self._view(o["dst1"], base)
             if o["res"] is not None:
                 d.res = self._view(o["res"], base)
-            d.wpacked = ctypes.c_void_p(weights[o["w"]].data_ptr())
+            if h16 is not None and h16(o):
+                d.wpacked = ctypes.c_void_p(weights[o["w"] + "#h16"].data_ptr())
+                d.compute = compute
+            else:
+                d.wpacked = ctypes.c_void_p(weights[o["w"]].data_ptr())
         return arr, in_idx, out_idx
 
 
@@ -227,6 +252,7 @@ class HipSRModel(nn.Module):
         self._packed = None        # path -> device blob
         self._packed_sig = None
         self._plans = {}
+        self.compute = "f32"       # "f32" | "bf16" | "f16": MFMA operand format of the full-resolution 3x3 convs
         self._prof_passes = 0      # >0: record HIP events around every op (bench roofline leg)
         self._profs = {}
 
@@ -265,6 +291,19 @@ class HipSRModel(nn.Module):
             mod = mod._modules[p]
         return mod
 
+    def set_compute(self, mode):
+        """Operand format of the matrix products in the full-resolution 3x3 convolutions (storage and
+        accumulation stay fp32): 'f32' exact, 'bf16' / 'f16' = 16-bit MFMA operands (BASELINE configs 3-5)."""
+        if mode not in L.COMPUTE:
+            raise ValueError(f"compute must be one of {sorted(L.COMPUTE)}")
+        if mode != self.compute:
+            self.compute = mode
+            self._packed = None
+        return self
+
+    def _uses_h16(self, o):
+        return self.compute != "f32" and o["kind"] == "conv" and o["k"] == 3 and o["hw"] is None and o["src"] is not INPUT
+
     # -- packing ------------------------------------------------------------------------------
     def _signature(self):
         return tuple((p.data_ptr(), p._version, p.device) for p in self.parameters())
@@ -274,6 +313,8 @@ class HipSRModel(nn.Module):
         for path, (cin, cout, k, cin_map) in self._conv_specs.items():
             leaf = self._leaf(path)
             packed[path] = pack_conv(leaf.weight, leaf.bias, cin_map=cin_map).to(device)
+            if self.compute != "f32" and k == 3:
+                packed[path + "#h16"] = pack_conv_h16(leaf.weight, leaf.bias, self.compute, cin_map=cin_map).to(device)
         for path, (cin_p, cout_p) in self._dense_specs.items():
             leaf = self._leaf(path)
             packed[path] = pack_dense(leaf.weight, leaf.bias, cin_p, cout_p).to(device)
@@ -310,7 +351,7 @@ class HipSRModel(nn.Module):
             plan = Plan(n, h, w)
             self._build_plan(plan, c)
             ws = torch.zeros(max(plan.total, 4), dtype=torch.float32, device=x.device)   # pad channels must be 0
-            arr, in_idx, out_idx = plan.finalize(ws, self._packed)
+            arr, in_idx, out_idx = plan.finalize(ws, self._packed, self._uses_h16, L.COMPUTE[self.compute])
             ent = (arr, in_idx, out_idx, ws, plan)
             if len(self._plans) > 8:
                 self._plans.clear()
@@ -364,6 +405,8 @@ class HipSRModel(nn.Module):
                     continue
                 nt = (o["cout"] + 15) // 16
                 kern = f"conv_f32_kernel<NT={nt},KS={o['k']},NCHW_IN={int(o['src'] is INPUT)}>"
+                if self._uses_h16(o):
+                    kern = f"conv_h16_kernel<NT={nt},{self.compute}>"
                 npix = plan.npix if o["hw"] is None else plan.n * o["hw"][0] * o["hw"][1]
                 out.append(dict(name=o["w"], kernel=kern, cin=o["cin"], cout=o["cout"], k=o["k"],
                                 flops=2.0 * npix * o["cin"] * o["cout"] * o["k"] * o["k"],

@@ -6,7 +6,7 @@ import ctypes
 import torch
 
 from . import _lib as L
-from .engine import pack_conv
+from .engine import pack_conv, pack_conv_h16
 
 
 def _view(t, coff=0):
@@ -16,7 +16,7 @@ def _view(t, coff=0):
 
 def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.RES_NONE,
            in_nchw=False, shuffle_out=False, out=None, out_coff=0, in_coff=0, cin=None,
-           split=0, out1=None, out1_coff=0, res_coff=0, packed=None, cin_map=None):
+           split=0, out1=None, out1_coff=0, res_coff=0, packed=None, cin_map=None, compute="f32"):
     """Fused conv (k=1|3, stride 1, same padding) on the current stream.
 
     x       NHWC [N,H,W,pitch] (channels [in_coff, in_coff+cin) are read) or NCHW if in_nchw
@@ -28,7 +28,8 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
     w4 = weight if weight.dim() == 4 else weight[:, :, None, None]
     cout, wcin, k, _ = w4.shape
     if packed is None:
-        packed = pack_conv(weight, bias, cin_map=cin_map).to(x.device)
+        packed = (pack_conv(weight, bias, cin_map=cin_map) if compute == "f32"
+                  else pack_conv_h16(weight, bias, compute, cin_map=cin_map)).to(x.device)
     d = L.ConvDesc()
     if in_nchw:
         n, c, h, w = x.shape
@@ -41,6 +42,7 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
         d.inp = _view(x, in_coff)
     d.n, d.h, d.w, d.cin, d.cout, d.ksize = n, h, w, cin, cout, k
     d.act, d.slope, d.res_mode, d.split = act, slope, res_mode, split
+    d.compute = L.COMPUTE[compute]
     if shuffle_out:
         y = torch.empty((n, cout // 16, 4 * h, 4 * w), dtype=torch.float32, device=x.device) if out is None else out
         d.out_layout = L.NCHW_SHUFFLE4

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libesr_hip.so does not export {s}"
     assert set(L.EXPORTS) == set(syms), (set(L.EXPORTS) ^ set(syms))
-    assert lib.esr_abi_version() == 1
+    assert lib.esr_abi_version() == 2
     assert b"gfx950" in lib.esr_build_info()
 
 
@@ -124,3 +124,25 @@ def test_imdn_plan_shape():
     assert m.workspace_bytes(2, 40, 56) == plan.total * 4
     total_macs = sum(o["cin"] * o["cout"] * o["k"] ** 2 for o in plan.ops)
     assert total_macs == 891584                                                # MAC per LR pixel
+
+
+def test_h16_packer_layout_and_rounding():
+    """esr_pack_conv_h16: RNE to bf16 / fp16, tap-pair layout, zero 10th tap and pad channels, fp32 bias tail."""
+    from ntire2022_esr_amd.engine import pack_conv_h16
+    g = torch.Generator().manual_seed(3)
+    w, b = torch.randn(16, 8, 3, 3, generator=g), torch.randn(16, generator=g)
+    for mode, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        blob = pack_conv_h16(w, b, mode)
+        raw = blob.numpy().view(np.uint16)
+        nw = 1 * 5 * 1 * 64 * 4                                 # chunks x pairs x tiles x lanes x 4
+        vals = torch.from_numpy(raw[:nw].astype(np.int16)).view(dt).float().reshape(5, 64, 4)
+        ref = w.to(dt).float()
+        for tap in range(9):
+            q, hk = tap // 2, tap % 2
+            for half in range(2):
+                kq = hk * 2 + half
+                got = vals[q, kq * 16:(kq + 1) * 16, :]          # [cout i][j]
+                assert torch.equal(got, ref[:, 4 * half:4 * half + 4, tap // 3, tap % 3]), (mode, tap, half)
+        assert torch.all(vals[4, 32:, :] == 0)                   # the padding 10th tap
+        bias = torch.from_numpy(blob.numpy().view(np.uint8)[nw * 2:nw * 2 + 64].copy()).view(torch.float32)
+        assert torch.equal(bias, b)

@@ -28,25 +28,21 @@ import torch
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-in MFMA
 MODELS = {
-    # name -> (data_range, algorithmic GFLOP per 256x256 image: BASELINE.md section 2)
-    "imdn_baseline": (1.0, 116.86),
+    # name -> (registry id, data_range, algorithmic GFLOP per 256x256 image: BASELINE.md section 2)
+    "imdn_baseline": (-1, 1.0, 116.86),       # BASELINE.json configs[1]: the headline workload
+    "rfdn_baseline": (0, 255.0, 54.07),
+    "team04_rlfn": (4, 255.0, 39.32),
+    "team18_bsrn": (18, 1.0, 18.86),
 }
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2516.0, "f16": 2516.0}   # dense MFMA peaks, MI355X_MICROARCH.md
 
 
-def build_model(name, device):
-    from safetensors.torch import load_file
-    from ntire2022_esr_amd import IMDN
-    m = IMDN(in_nc=3, out_nc=3, nc=64, nb=8, upscale=4)
-    path = os.path.join(REPO, "weights", name + ".safetensors")
-    weights = "checkpoint"
-    if os.path.exists(path):
-        m.load_state_dict(load_file(path), strict=True)
-    else:
-        weights = "random-init"
-    m.eval()
-    for p in m.parameters():
-        p.requires_grad = False
-    return m.to(device), weights
+def build_model(name, device, compute):
+    """Registry model with the exported reference checkpoint (weights/<name>.safetensors)."""
+    from ntire2022_esr_amd.registry import select_model
+    m, _, _, _ = select_model(MODELS[name][0], device)
+    m.set_compute(compute)
+    return m, "checkpoint"
 
 
 def cpu_baseline(name, budget_s=14.0):
@@ -62,7 +58,7 @@ def cpu_baseline(name, budget_s=14.0):
     except Exception:
         phys = os.cpu_count()
     sd = load_file(os.path.join(REPO, "weights", name + ".safetensors"))
-    dr = MODELS[name][0]
+    dr = MODELS[name][1]
     x = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(0)) * dr
     fwd = TP.FORWARD[name]
     cands = sorted({c for c in (8, 16, 32, 64, phys) if c <= phys})
@@ -103,6 +99,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="LR tiles per GPU per step")
     ap.add_argument("--model", default="imdn_baseline", choices=sorted(MODELS))
+    ap.add_argument("--compute", default="f32", choices=["f32", "bf16", "f16"],
+                    help="MFMA operand format of the full-resolution 3x3 convs (storage/accumulate fp32); "
+                         "the headline metric is f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not record per-kernel HIP events during the timed steps")
@@ -125,8 +124,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    dr, gflop_per_img = MODELS[args.model]
-    model, weights = build_model(args.model, device)
+    _, dr, gflop_per_img = MODELS[args.model]
+    model, weights = build_model(args.model, device, args.compute)
+    peak = PEAK_TFLOPS[args.compute]
     B = args.batch
     x = (torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(rank)) * dr).to(device)
 
@@ -160,8 +160,13 @@ def main():
     if not args.no_kernel_events:
         prof = model.collect_profile()
         model.disable_profiling()
-        # dominant kernel = the 3x3 conv with 4 output-channel tiles (all 64-output-channel 3x3 convs)
-        dom = [o for o in prof if o["kernel"] == "conv_f32_kernel<NT=4,KS=3,NCHW_IN=0>"]
+        # dominant kernel = the kernel symbol with the largest share of the timed kernel time
+        # (IMDN fp32: the 3x3 conv with 4 output-channel tiles, i.e. all 64-output-channel 3x3 convs)
+        by_kernel = {}
+        for o in prof:
+            by_kernel[o["kernel"]] = by_kernel.get(o["kernel"], 0.0) + o["ms_sum"]
+        dom_name = max(by_kernel, key=by_kernel.get)
+        dom = [o for o in prof if o["kernel"] == dom_name]
         launches = sum(o["passes"] for o in dom)
         ms = sum(o["ms_sum"] for o in dom)
         flops = sum(o["flops"] * o["passes"] for o in dom)
@@ -172,15 +177,24 @@ def main():
         tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("conv_f32_kernel<NT=4,KS=3,NCHW_IN=0>", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch") if args.batch == 32 else None
             except Exception:
                 traffic = None
-        roofline = {"bound": "mfma", "kernel": "conv_f32_kernel<4,3,false> (3x3 conv, 64 out ch, fp32 16x16x4 MFMA)",
-                    "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        if args.compute == "f32" or not dom_name.startswith("conv_"):
+            roofline = {"bound": "mfma", "kernel": dom_name + " (3x3 conv, fp32 v_mfma_f32_16x16x4_f32)",
+                        "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4), "traffic": traffic}
+        else:
+            # 16-bit operands with fp32 storage: the conv is HBM-bound; algorithmic bytes per launch =
+            # input + output activations at 4 B (weights are KBs)
+            gb = sum((o["cin"] + o["cout"]) * 4.0 * B * 65536 * o["passes"] for o in dom) / launches / 1e9
+            roofline = {"bound": "hbm", "kernel": dom_name + " (3x3 conv, 16-bit MFMA operands, fp32 storage)",
+                        "achieved": round(gb / (avg_ms * 1e-3), 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(gb / (avg_ms * 1e-3) / 8000.0, 4), "traffic": None}
+        roofline.update({
                     "launches": launches, "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
-                    "share_of_kernel_time": round(ms / total_ms, 4)}
+                    "share_of_kernel_time": round(ms / total_ms, 4)})
 
     if rank == 0:
         imgs = world * B * args.steps
@@ -189,13 +203,13 @@ def main():
             "metric": "images/sec (256x256->1024x1024 x4)",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.compute,
             "data": f"synthetic (uniform [0,{dr:g}) LR tiles resident in HBM; weights: {weights})",
-            "config": {"workload": f"{args.model} x4 fp32, {B}x3x256x256 LR batch per GPU -> {B}x3x1024x1024",
+            "config": {"workload": f"{args.model} x4 {args.compute}, {B}x3x256x256 LR batch per GPU -> {B}x3x1024x1024",
                        "batch_per_gpu": B, "parallelism": f"image-parallel replicas x{world}",
                        "algorithmic_gflop_per_image": gflop_per_img},
             "model_tflops": round(value * gflop_per_img / 1e3, 2),
-            "model_frac_of_fp32_mfma_peak": round(value * gflop_per_img / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4),
+            "model_frac_of_mfma_peak": round(value * gflop_per_img / 1e3 / (peak * world), 4),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1,32 +1,32 @@
-"""Rough timing of the forward at a few batch sizes (development helper, not the bench)."""
-import sys, os
+"""Rough timing + per-kernel breakdown (development helper, not the bench).
+usage: quick_time.py [model ids ...]   env COMPUTE=f32|bf16|f16, BATCH=32"""
+import sys, os, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ntire2022_esr_amd.registry import select_model
-GF = {-1: 116.86, 0: 54.07, 4: 39.32, 18: 18.86}
+GF = {-1: 116.86, 0: 54.07, 4: 39.32, 18: 18.86, 6: 54.07, 22: 35.2, 26: 103.3}
 ids = [int(a) for a in sys.argv[1:]] or [-1]
+comp = os.environ.get("COMPUTE", "f32")
 for mid in ids:
     m, name, dr, _ = select_model(mid, torch.device("cuda:0"))
-    for B in [1, 8, 32]:
+    m.set_compute(comp)
+    for B in [1, int(os.environ.get("BATCH", "32"))]:
         x = torch.rand(B, 3, 256, 256, device="cuda:0") * dr
         for _ in range(3): y = m(x)
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        it = 10
         s.record()
-        for _ in range(it): y = m(x)
+        for _ in range(10): y = m(x)
         e.record(); torch.cuda.synchronize()
-        ms = s.elapsed_time(e) / it
-        print(f"{name:18s} B={B:3d} {ms:8.3f} ms/fwd {B/ms*1e3:8.1f} img/s {GF[mid]*B/ms:7.1f} TFLOP/s ({GF[mid]*B/ms/157.3*100:.1f}% fp32 MFMA peak)")
-    if len(ids) > 1 or os.environ.get("PROF"):
-        m.enable_profiling(3)
-        for _ in range(3): m(x)
-        torch.cuda.synchronize()
-        import collections
-        agg = collections.defaultdict(lambda: [0.0, 0])
-        for o in m.collect_profile():
-            agg[o["kernel"]][0] += o["ms_sum"]; agg[o["kernel"]][1] += o["passes"]
-        tot = sum(v[0] for v in agg.values())
-        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0]):
-            print(f"      {k:44s} {v[1]//3:3d} launches/fwd {v[0]/3:8.3f} ms/fwd {v[0]/tot*100:5.1f}%")
-        m.disable_profiling()
+        ms = s.elapsed_time(e) / 10
+        print(f"{name:18s} {comp:5s} B={B:3d} {ms:8.3f} ms/fwd {B/ms*1e3:8.1f} img/s {GF[mid]*B/ms:7.1f} TFLOP/s")
+    m.enable_profiling(3)
+    for _ in range(3): m(x)
+    torch.cuda.synchronize()
+    agg = collections.defaultdict(lambda: [0.0, 0, 0.0])
+    for o in m.collect_profile():
+        a = agg[o["kernel"]]; a[0] += o["ms_sum"]; a[1] += o["passes"]; a[2] += o["flops"] * o["passes"]
+    tot = sum(v[0] for v in agg.values())
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+        print(f"      {k:44s} {v[1]//3:3d} launches/fwd {v[0]/3:8.3f} ms/fwd {v[0]/tot*100:5.1f}%  {v[2]/v[0]/1e9 if v[0] else 0:7.1f} TFLOP/s")
+    m.disable_profiling()

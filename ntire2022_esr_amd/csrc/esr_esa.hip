@@ -76,9 +76,10 @@ __global__ __launch_bounds__(256) void maxpool7s3_kernel(const float* __restrict
 }
 
 // ---- fused ESA tail ------------------------------------------------------------------------------
-// 16 lanes per pixel (4 pixels per wave); lane g handles output channels 4g..4g+3.  Every lane rebuilds
-// the FP-wide vector s = bilinear(c3) + conv_f(c1_) of its pixel (redundant across the 16 lanes: ~400
-// FMAs, cheaper than a cross-lane exchange and far below the memory time of the pass).
+// 16 lanes per pixel (4 pixels per wave, 16 per block).  Lane g first builds ONE element of the FP-wide vector
+// s = bilinear(c3) + conv_f(c1_) of its pixel (16 FMAs + one 4-tap lerp), the 16 lanes exchange s through 1 KB
+// of LDS, then lane g produces output channels 4g..4g+3 (16 x 4 FMAs, sigmoid, multiply).  x is read once and
+// y written once, both as contiguous float4 per lane.
 struct EsaK {
     const float* x; const float* c1; const float* c3; const float* wf; const float* w4; float* y;
     int x_pitch, x_coff, y_pitch, y_coff;
@@ -88,14 +89,16 @@ struct EsaK {
 
 __global__ __launch_bounds__(256) void esa_apply_kernel(const EsaK p)
 {
-    extern __shared__ __attribute__((aligned(16))) float sm[];      // wf: FP*FP + FP ; w4: FP*cp + cp
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // wf: FP*FP + FP ; w4: FP*cp + cp ; s: 16*FP
     const int nwf = FP * FP + FP, nw4 = FP * p.cp + p.cp;
     for (int i = threadIdx.x; i < nwf; i += 256) sm[i] = p.wf[i];
     for (int i = threadIdx.x; i < nw4; i += 256) sm[nwf + i] = p.w4[i];
+    float* sx = sm + nwf + ((nw4 + 3) & ~3);
     __syncthreads();
-    const int g = threadIdx.x & 15;
-    const long long pix = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (pix >= (long long)p.N * p.H * p.W || g * 4 >= p.Cp4) return;
+    const int g = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const long long npix = (long long)p.N * p.H * p.W;
+    const long long pix = min((long long)blockIdx.x * 16 + pl, npix - 1);       // clamp: every lane takes part in the exchange
+    const bool live = (long long)blockIdx.x * 16 + pl < npix && g * 4 < p.Cp4;
     const int ox = (int)(pix % p.W);
     const int oy = (int)((pix / p.W) % p.H);
     const int n = (int)(pix / ((long long)p.W * p.H));
@@ -109,38 +112,34 @@ __global__ __launch_bounds__(256) void esa_apply_kernel(const EsaK p)
     fx = fx < 0.f ? 0.f : fx;
     const int x0 = (int)fx, x1 = x0 + (x0 < p.w3 - 1 ? 1 : 0);
     const float lx = fx - (float)x0, hx = 1.f - lx;
-    const float* c00 = p.c3 + (((size_t)n * p.h3 + y0) * p.w3 + x0) * FP;
-    const float* c01 = p.c3 + (((size_t)n * p.h3 + y0) * p.w3 + x1) * FP;
-    const float* c10 = p.c3 + (((size_t)n * p.h3 + y1) * p.w3 + x0) * FP;
-    const float* c11 = p.c3 + (((size_t)n * p.h3 + y1) * p.w3 + x1) * FP;
+    const float* cb = p.c3 + (size_t)n * p.h3 * p.w3 * FP + g;
+    const float a = cb[((size_t)y0 * p.w3 + x0) * FP], b = cb[((size_t)y0 * p.w3 + x1) * FP];
+    const float c = cb[((size_t)y1 * p.w3 + x0) * FP], d = cb[((size_t)y1 * p.w3 + x1) * FP];
+    float sg = hy * (hx * a + lx * b) + ly * (hx * c + lx * d) + sm[FP * FP + g];
+    // + conv_f(c1_)[g] = sum_i c1[i] * Wf[i][g]
     const float* c1p = p.c1 + (size_t)pix * FP;
-
-    float s[FP];
-#pragma unroll
-    for (int qd = 0; qd < FP / 4; ++qd) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(c00 + qd * 4), b = *reinterpret_cast<const f32x4*>(c01 + qd * 4);
-        const f32x4 c = *reinterpret_cast<const f32x4*>(c10 + qd * 4), d = *reinterpret_cast<const f32x4*>(c11 + qd * 4);
-        const f32x4 bf = *reinterpret_cast<const f32x4*>(sm + FP * FP + qd * 4);
-        const f32x4 v = hy * (hx * a + lx * b) + ly * (hx * c + lx * d) + bf;
-        s[qd * 4 + 0] = v.x; s[qd * 4 + 1] = v.y; s[qd * 4 + 2] = v.z; s[qd * 4 + 3] = v.w;
-    }
-    // + conv_f(c1_):  s[o] += sum_i c1[i] * Wf[i][o]
 #pragma unroll
     for (int iq = 0; iq < FP / 4; ++iq) {
         const f32x4 cv = *reinterpret_cast<const f32x4*>(c1p + iq * 4);
-        const float ci[4] = {cv.x, cv.y, cv.z, cv.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float* wr = sm + (iq * 4 + k) * FP;
-#pragma unroll
-            for (int o = 0; o < FP; ++o) s[o] = fmaf(ci[k], wr[o], s[o]);
-        }
+        sg = fmaf(cv.x, sm[(iq * 4 + 0) * FP + g], sg);
+        sg = fmaf(cv.y, sm[(iq * 4 + 1) * FP + g], sg);
+        sg = fmaf(cv.z, sm[(iq * 4 + 2) * FP + g], sg);
+        sg = fmaf(cv.w, sm[(iq * 4 + 3) * FP + g], sg);
     }
+    sx[pl * FP + g] = sg;
+    __syncthreads();
+    if (!live) return;
     // conv4 for this lane's 4 channels, sigmoid, multiply
     const float* w4 = sm + nwf;
     f32x4 m = *reinterpret_cast<const f32x4*>(w4 + FP * p.cp + g * 4);
 #pragma unroll
-    for (int i = 0; i < FP; ++i) m += s[i] * *reinterpret_cast<const f32x4*>(w4 + i * p.cp + g * 4);
+    for (int iq = 0; iq < FP / 4; ++iq) {
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(sx + pl * FP + iq * 4);
+        m += sv.x * *reinterpret_cast<const f32x4*>(w4 + (iq * 4 + 0) * p.cp + g * 4);
+        m += sv.y * *reinterpret_cast<const f32x4*>(w4 + (iq * 4 + 1) * p.cp + g * 4);
+        m += sv.z * *reinterpret_cast<const f32x4*>(w4 + (iq * 4 + 2) * p.cp + g * 4);
+        m += sv.w * *reinterpret_cast<const f32x4*>(w4 + (iq * 4 + 3) * p.cp + g * 4);
+    }
     const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + (size_t)pix * p.x_pitch + p.x_coff + g * 4);
     f32x4 o;
     o.x = xv.x * (1.f / (1.f + expf(-m.x)));
@@ -323,7 +322,7 @@ int esr_esa_apply_f32(const esr_esa_desc* d, void* hip_stream)
     k.sh = (float)d->h_lo / (float)d->h;      // ATen area_pixel_compute_scale: float(in) / out
     k.sw = (float)d->w_lo / (float)d->w;
     const long long npix = (long long)d->n * d->h * d->w;
-    const size_t lds = ((size_t)FP * FP + FP + (size_t)FP * cp4 + cp4) * sizeof(float);
+    const size_t lds = ((size_t)FP * FP + FP + (((size_t)FP * cp4 + cp4 + 3) & ~(size_t)3) + 16 * FP) * sizeof(float);
     hipLaunchKernelGGL(esa_apply_kernel, dim3((unsigned)((npix + 15) / 16)), dim3(256), lds, static_cast<hipStream_t>(hip_stream), k);
     return esr_check_launch("esa_apply_kernel launch");
 }

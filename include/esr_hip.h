@@ -162,6 +162,18 @@ int    esr_pack_dw_f32(const float* w_c133, const float* bias, int c, void* out,
 int    esr_dwconv3x3_f32(const esr_conv_desc* d, void* hip_stream);
 
 /*
+ * Post-processing of run() on the device, so that only the uint8 image (for imsave) and one
+ * scalar leave the GPU:
+ *   esr_tensor2uint_u8   utils_image.tensor2uint (utils/utils_image.py:204-208): NCHW fp32 [C][H][W] (one image)
+ *                        -> clamp(0, data_range) -> * 255/data_range (fp32) -> round half to even -> HWC uint8
+ *   esr_sqerr_u8         sum over the border-cropped region of (a - b)^2 for two HWC uint8 images, as exact
+ *                        uint64 (calculate_psnr :490-503 then is 20*log10(255/sqrt(sum/count)) on the host)
+ */
+int esr_tensor2uint_u8(const float* x_chw, uint8_t* y_hwc, int c, int h, int w, float data_range, void* hip_stream);
+int esr_sqerr_u8(const uint8_t* a_hwc, const uint8_t* b_hwc, int h, int w, int c, int border,
+                 unsigned long long* sum_out /* device, zeroed by the call */, void* hip_stream);
+
+/*
  * A forward pass is a flat list of ops executed in order on one stream: the native
  * replacement for test_demo.py's `model(img_lq)` (forward(), test_demo.py:364-367).
  * The Python host builds the list once per (model, N, H, W) and replays it.

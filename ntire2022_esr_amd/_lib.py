@@ -63,6 +63,7 @@ EXPORTS = [
     "esr_packed_dense_bytes", "esr_pack_dense_f32",
     "esr_conv3x3s2_f32", "esr_maxpool7s3_f32", "esr_esa_apply_f32",
     "esr_packed_dw_bytes", "esr_pack_dw_f32", "esr_dwconv3x3_f32",
+    "esr_tensor2uint_u8", "esr_sqerr_u8",
 ]
 
 _lib = None
@@ -112,6 +113,10 @@ def lib():
     L.esr_pack_dw_f32.restype = ci
     L.esr_dwconv3x3_f32.argtypes = [ctypes.POINTER(ConvDesc), vp]
     L.esr_dwconv3x3_f32.restype = ci
+    L.esr_tensor2uint_u8.argtypes = [vp, vp, ci, ci, ci, ctypes.c_float, vp]
+    L.esr_tensor2uint_u8.restype = ci
+    L.esr_sqerr_u8.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
+    L.esr_sqerr_u8.restype = ci
     L.esr_prof_create.argtypes = [ci, ci, ctypes.POINTER(vp)]
     L.esr_prof_create.restype = ci
     L.esr_run_ops_profiled.argtypes = [ctypes.POINTER(Op), ci, vp, vp]

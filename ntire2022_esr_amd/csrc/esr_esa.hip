@@ -202,9 +202,63 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const DwK p)
     *reinterpret_cast<f32x4*>(p.y + (size_t)pix * p.y_pitch + p.y_coff + q * 4) = acc;
 }
 
+// ---- post-processing: tensor2uint and squared error on uint8 ----------------------------------------
+__global__ __launch_bounds__(256) void tensor2uint_kernel(const float* __restrict__ x, uint8_t* __restrict__ y, int C, int H,
+                                                          int W, float dr, float scale)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;        // output element index (HWC)
+    const long long n = (long long)H * W * C;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const long long hw = i / C;
+    float v = x[(size_t)c * H * W + hw];
+    v = v < 0.f ? 0.f : (v > dr ? dr : v);                                // clamp_(0, data_range); NaN -> propagates like torch? clamp keeps NaN
+    y[i] = (uint8_t)__float2int_rn(__fmul_rn(v, scale));                  // numpy .round(): half to even
+}
+
+__global__ __launch_bounds__(256) void sqerr_u8_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int H, int W,
+                                                       int C, int border, unsigned long long* out)
+{
+    const int hh = H - 2 * border, ww = W - 2 * border;
+    const long long n = (long long)hh * ww * C;
+    unsigned long long acc = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long long p = i / C;
+        const int x = (int)(p % ww) + border, yy = (int)(p / ww) + border;
+        const size_t idx = ((size_t)yy * W + x) * C + c;
+        const int d = (int)a[idx] - (int)b[idx];
+        acc += (unsigned long long)(d * d);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
 }  // namespace
 
 extern "C" {
+
+int esr_tensor2uint_u8(const float* x, uint8_t* y, int c, int h, int w, float data_range, void* hip_stream)
+{
+    if (!x || !y || c <= 0 || h <= 0 || w <= 0 || !(data_range > 0.f)) return ESR_ERR_BAD_ARG;
+    const long long n = (long long)c * h * w;
+    hipLaunchKernelGGL(tensor2uint_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                       x, y, c, h, w, data_range, 255.0f / data_range);
+    return esr_check_launch("tensor2uint_kernel launch");
+}
+
+int esr_sqerr_u8(const uint8_t* a, const uint8_t* b, int h, int w, int c, int border, unsigned long long* sum_out,
+                 void* hip_stream)
+{
+    if (!a || !b || !sum_out || h <= 0 || w <= 0 || c <= 0 || border < 0 || 2 * border >= h || 2 * border >= w)
+        return ESR_ERR_BAD_ARG;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (hipMemsetAsync(sum_out, 0, sizeof(unsigned long long), st) != hipSuccess) return ESR_ERR_LAUNCH;
+    const long long n = (long long)(h - 2 * border) * (w - 2 * border) * c;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(sqerr_u8_kernel, dim3(grid), dim3(256), 0, st, a, b, h, w, c, border, sum_out);
+    return esr_check_launch("sqerr_u8_kernel launch");
+}
 
 size_t esr_packed_dw_bytes(int c) { return c <= 0 ? 0 : (size_t)10 * esr_round_up(c, 4) * sizeof(float); }
 

@@ -78,9 +78,17 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
             t0 = time.perf_counter()
             img_sr = forward(img_lr, model, tile)
             ms = (time.perf_counter() - t0) * 1e3
-        img_sr = util.tensor2uint(img_sr, data_range)
         img_hr = util.modcrop(util.imread_uint(hr_path, n_channels=3).squeeze(), sf)
-        psnr = util.calculate_psnr(img_sr, img_hr, border=border)
+        if use_cuda and getattr(args, "device_metrics", True):
+            # uint8 conversion and the squared-error sum run on the GPU: the SR image crosses PCIe once as uint8
+            # (needed for imsave) and the PSNR as one integer
+            from . import ops
+            sr_dev = ops.tensor2uint_device(img_sr, data_range)
+            psnr = ops.psnr_device(sr_dev, torch.from_numpy(np.ascontiguousarray(img_hr)).to(device), border=border)
+            img_sr = sr_dev.cpu().numpy()
+        else:
+            img_sr = util.tensor2uint(img_sr, data_range)
+            psnr = util.calculate_psnr(img_sr, img_hr, border=border)
         if getattr(args, "ssim", False):
             ssim = util.calculate_ssim(img_sr, img_hr, border=border)
             logger.info("{:s} - PSNR: {:.2f} dB; SSIM: {:.4f}.".format(img_name + ext, psnr, ssim))

@@ -63,3 +63,39 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
     stream = torch.cuda.current_stream(x.device).cuda_stream
     L.check(lib.esr_conv2d_f32(ctypes.byref(d), ctypes.c_void_p(stream)), "esr_conv2d_f32")
     return y
+
+
+def tensor2uint_device(img_sr, data_range):
+    """utils_image.tensor2uint on the GPU: [1,C,H,W] (or [C,H,W]) fp32 -> HWC uint8 tensor on the same device."""
+    if not img_sr.is_cuda:
+        raise L.EsrError("tensor2uint_device: tensor must live on the GPU")
+    t = img_sr.detach()
+    if t.dim() == 4:
+        assert t.shape[0] == 1, "one image at a time, like the reference's run()"
+        t = t[0]
+    t = t.contiguous().float()
+    c, h, w = t.shape
+    out = torch.empty((h, w, c), dtype=torch.uint8, device=t.device)
+    stream = torch.cuda.current_stream(t.device).cuda_stream
+    L.check(L.lib().esr_tensor2uint_u8(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(out.data_ptr()), c, h, w,
+                                       ctypes.c_float(data_range), ctypes.c_void_p(stream)), "esr_tensor2uint_u8")
+    return out
+
+
+def psnr_device(a_u8, b_u8, border=0):
+    """calculate_psnr for two HWC uint8 CUDA tensors: exact integer squared-error sum on the device, one scalar D2H."""
+    import math
+    if a_u8.shape != b_u8.shape:
+        raise ValueError('Input images must have the same dimensions.')
+    a, b = a_u8.contiguous(), b_u8.contiguous()
+    h, w = a.shape[:2]
+    c = a.shape[2] if a.dim() == 3 else 1
+    acc = torch.empty(1, dtype=torch.int64, device=a.device)
+    stream = torch.cuda.current_stream(a.device).cuda_stream
+    L.check(L.lib().esr_sqerr_u8(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), h, w, c, border,
+                                 ctypes.c_void_p(acc.data_ptr()), ctypes.c_void_p(stream)), "esr_sqerr_u8")
+    se = int(acc.item())
+    count = (h - 2 * border) * (w - 2 * border) * c
+    if se == 0:
+        return float('inf')
+    return 20 * math.log10(255.0 / math.sqrt(se / count))

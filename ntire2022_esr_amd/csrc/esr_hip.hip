@@ -314,13 +314,9 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
     auto image_rsrc = [&](int n) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)n * img_floats), 0, (int)(img_floats * 4), 0x00020000);
     };
-    const __amdgpu_buffer_rsrc_t wrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, p.nchunks * (W_FLOATS * 4), 0x00020000);
-
     f32x4 in_reg[IN_ROUNDS];
-    f32x4 w_reg[W_ROUNDS];
 
-    auto load_stage = [&](const TileCtx& tc, int c) {
+    auto load_input = [&](const TileCtx& tc, int c) {
         const __amdgpu_buffer_rsrc_t xrsrc = image_rsrc(tc.n);
 #pragma unroll
         for (int r = 0; r < IN_ROUNDS; ++r) {
@@ -336,10 +332,27 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
                 in_reg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, tc.voff[r], c * (CHUNK * 4), 0));
             }
         }
+    };
+    // weights go global -> LDS directly (their LDS image is lane-linear: item idx at byte idx*16; W_ITEMS is a multiple
+    // of 64, so a wave is entirely inside or outside the range): no staging VGPRs, no ds_write.
+    // The DMA is issued from inline asm on purpose: with the builtin, hipcc assumes every later ds_read may alias the
+    // DMA destination and puts `s_waitcnt vmcnt(0)` in front of the first fragment read of each chunk, stalling the wave
+    // on the weight DMA and on the input loads still in flight.  Hidden from the compiler, its own vmcnt waits can only
+    // over-wait (the asm ops add to the count), and stage_barrier() below waits for the DMA explicitly.
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto load_weights = [&](int c, int dstbuf) {
+        const float* wsrc = p.wp + (size_t)c * W_FLOATS;
+        const unsigned wdst = smem_lds + dstbuf * STAGE_BYTES + IN_BYTES;
 #pragma unroll
         for (int r = 0; r < W_ROUNDS; ++r) {
-            const unsigned voff = (unsigned)min(tid + r * THREADS, W_ITEMS - 1) * 16u;
-            w_reg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, c * (W_FLOATS * 4), 0));
+            const int idx = tid + r * THREADS;
+            if (W_ITEMS % THREADS == 0 || idx < W_ITEMS) {
+                const float* g = wsrc + idx * 4;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(wdst + (unsigned)(idx & ~63) * 16u);   // wave-uniform LDS base
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+            }
         }
     };
     auto store_stage = [&](int buf) {
@@ -350,48 +363,68 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
             if (IN_ITEMS % THREADS == 0 || idx < IN_ITEMS)
                 *reinterpret_cast<f32x4*>(s + (idx & 1) * (NPX * 16) + (idx >> 1) * 16) = in_reg[r];
         }
-#pragma unroll
-        for (int r = 0; r < W_ROUNDS; ++r) {
-            const int idx = tid + r * THREADS;
-            if (W_ITEMS % THREADS == 0 || idx < W_ITEMS)
-                *reinterpret_cast<f32x4*>(s + IN_BYTES + idx * 16) = w_reg[r];
-        }
+    };
+    // End-of-stage synchronisation.  `ahead` = this wave has just issued the IN_ROUNDS input loads of the stage after
+    // next; VMEM loads (LDS-DMA included) return in issue order, so vmcnt(IN_ROUNDS) guarantees the older weight DMA
+    // of the next stage has landed while those newest loads stay in flight across the barrier.
+    auto stage_barrier = [&](bool ahead) {
+        if (ahead) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(IN_ROUNDS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     };
 
     // lane-constant LDS byte offsets
     const int b_base = (kq >> 1) * (NPX * 16) + ((wv * 4) * TH + px) * 16 + (kq & 1) * 8;
     const int a_base = IN_BYTES + lane * 8;
 
+    // Staging pipeline (per block, stages g = (tile, chunk) in order): at the top of a stage body its LDS buffer is
+    // complete and -- when `inflight` -- the INPUT of stage g+1 is already on its way into in_reg (requested before the
+    // previous barrier, so it has the barrier gap plus a whole chunk of MFMAs to arrive: tools/dbg/ablate.py showed
+    // 5 % of the kernel waiting for these loads with a one-chunk lead).  The body requests the weights of g+1 (they can
+    // only start now: they land in the buffer the previous stage was reading), runs the MFMAs, writes in_reg to LDS and
+    // requests the input of stage g+2.
+    constexpr bool AHEAD = !IN_NCHW;            // the NCHW head issues a cin-dependent number of loads: plain vmcnt(0)
     int k = 0;
     int t = tile_index(0);
     if (t < 0) return;
     TileCtx cur, nxt;
+    // bias of this lane's 4 output channels per tile, loaded ONCE: a per-tile reload would make the compiler wait
+    // vmcnt(0) at every tile start, i.e. also for the input loads deliberately left in flight across the barrier
+    f32x4 biasv[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) biasv[tt] = *reinterpret_cast<const f32x4*>(p.bias + tt * 16 + kq * 4);
+
     setup_tile(t, cur);
-    load_stage(cur, 0);
+    int tn = tile_index(1);
+    if (tn >= 0) setup_tile(tn, nxt);
+    load_input(cur, 0);
+    load_weights(0, 0);
     store_stage(0);
-    __syncthreads();
+    bool inflight = false;
+    if (AHEAD) {
+        if (p.nchunks > 1) { load_input(cur, 1); inflight = true; }
+        else if (tn >= 0) { load_input(nxt, 0); inflight = true; }
+    }
+    stage_barrier(inflight);
     int sbuf = 0;
 
     for (;;) {
-        const int tn = tile_index(k + 1);
         const bool has_next = tn >= 0;
 
-        // accumulators start at the bias (lane's 4 output channels per tile): no bias add in the epilogue
+        // accumulators start at the bias: no bias add in the epilogue
         f32x4 acc[NT][4];
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + tt * 16 + kq * 4);
+        for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[tt][r] = bv;
-        }
+            for (int r = 0; r < 4; ++r) acc[tt][r] = biasv[tt];
 
         for (int c = 0; c < p.nchunks; ++c) {
             const bool more = c + 1 < p.nchunks;
-            if (more) {
-                load_stage(cur, c + 1);
-            } else if (has_next) {          // cross-tile prefetch: next tile's first stage under this tile's last chunk
-                setup_tile(tn, nxt);
-                load_stage(nxt, 0);
+            if (more) load_weights(c + 1, sbuf ^ 1);
+            else if (has_next) load_weights(0, sbuf ^ 1);
+            if (!inflight) {                               // one-chunk lead (head conv, or nothing was requested ahead)
+                if (more) load_input(cur, c + 1);
+                else if (has_next) load_input(nxt, 0);
             }
             const char* s = smem + sbuf * STAGE_BYTES;
             // fragment reads run one tap ahead of the MFMAs that consume them
@@ -422,7 +455,12 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
             }
             __builtin_amdgcn_s_setprio(3);
             if (more || has_next) store_stage(sbuf ^ 1);
-            __syncthreads();
+            inflight = false;
+            if (AHEAD) {                                   // input of the stage after next
+                if (c + 2 < p.nchunks) { load_input(cur, c + 2); inflight = true; }
+                else if (has_next && c + 2 - p.nchunks < p.nchunks) { load_input(nxt, c + 2 - p.nchunks); inflight = true; }
+            }
+            stage_barrier(inflight);
             sbuf ^= 1;
         }
 
@@ -431,6 +469,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
         if (!has_next) break;
         cur = nxt;
         ++k;
+        tn = tile_index(k + 1);
+        if (tn >= 0) setup_tile(tn, nxt);
     }
 }
 

@@ -8,6 +8,41 @@ def rep(a, b):
     assert a in s, a[:70]
     s = s.replace(a, b)
 VAR = sys.argv[1] if len(sys.argv) > 1 else 'plain'
+NOEPI = '''        for (int tt = 0; tt < NT; ++tt) for (int r = 0; r < 4; ++r) asm volatile("" :: "v"(acc[tt][r]));'''
+EPI = '''        if (p.out_layout == ESR_NCHW_SHUFFLE4) epilogue_shuffle<NT>(p, acc, cur.n, cur.x0, cur.y0, wv, lane);
+        else epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane);'''
+if VAR in ('nostage', 'nobarrier'):
+    rep('''            if (more) {
+                load_stage(cur, c + 1);
+            } else if (has_next) {          // cross-tile prefetch: next tile's first stage under this tile's last chunk
+                setup_tile(tn, nxt);
+                load_stage(nxt, 0);
+            }''', '''            if (!more && has_next) setup_tile(tn, nxt);''')
+    rep('''            if (more || has_next) store_stage(sbuf ^ 1);
+            __syncthreads();
+            sbuf ^= 1;
+        }
+
+        if (p.out_layout''', '''            %s
+            sbuf ^= 1;
+        }
+
+        if (p.out_layout''' % ('__syncthreads();' if VAR == 'nostage' else ''))
+if VAR == 'nowrite':
+    rep('''                *reinterpret_cast<f32x4*>(s + (idx & 1) * (NPX * 16) + (idx >> 1) * 16) = in_reg[r];''', '''                asm volatile("" :: "v"(in_reg[r]), "v"(s));''')
+    rep('''                *reinterpret_cast<f32x4*>(s + IN_BYTES + idx * 16) = w_reg[r];''', '''                asm volatile("" :: "v"(w_reg[r]), "v"(s));''')
+    rep(EPI, NOEPI)
+if VAR == 'noload':
+    rep('''            if (more || has_next) store_stage(sbuf ^ 1);
+            __syncthreads();
+            sbuf ^= 1;
+        }
+
+        if (p.out_layout''', '''            __syncthreads();
+            sbuf ^= 1;
+        }
+
+        if (p.out_layout''')
 if VAR == 'noepi':
     rep('''        if (p.out_layout == ESR_NCHW_SHUFFLE4) epilogue_shuffle<NT>(p, acc, cur.n, cur.x0, cur.y0, wv, lane);
         else epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane);''',
@@ -28,6 +63,8 @@ if VAR == 'nolds':
         f32x4 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = acc[i % NT][r];''')
+if VAR in ('nostage', 'nobarrier', 'noload'):
+    rep(EPI, NOEPI)
 rep('int esr_abi_version(void) { return ESR_ABI_VERSION; }', 'int esr_abi_version(void) { return ESR_ABI_VERSION; }\nvoid esr_set_dbg(void* p) { (void)p; }')
 src = '/tmp/esr_dbg.hip'
 open(src, 'w').write(s)

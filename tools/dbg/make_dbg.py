@@ -1,71 +1,44 @@
-"""Build an ablated / instrumented variant of csrc/esr_hip.hip -> tools/dbg/libesr_dbg.so
-usage: make_dbg.py [plain|noepi|nostore|nolds]"""
+"""Build an ablated / instrumented variant of csrc/esr_hip.hip -> tools/dbg/libesr_dbg_<variant>.so
+usage: make_dbg.py [plain|noepi|waits]"""
 import os, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 s = open(os.path.join(R, 'ntire2022_esr_amd/csrc/esr_hip.hip')).read()
-def rep(a, b):
+def rep(a, b, count=1):
     global s
     assert a in s, a[:70]
-    s = s.replace(a, b)
+    s = s.replace(a, b, count)
 VAR = sys.argv[1] if len(sys.argv) > 1 else 'plain'
-NOEPI = '''        for (int tt = 0; tt < NT; ++tt) for (int r = 0; r < 4; ++r) asm volatile("" :: "v"(acc[tt][r]));'''
+SB = "__builtin_amdgcn_sched_barrier(0);"
 EPI = '''        if (p.out_layout == ESR_NCHW_SHUFFLE4) epilogue_shuffle<NT>(p, acc, cur.n, cur.x0, cur.y0, wv, lane);
         else epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane);'''
-if VAR in ('nostage', 'nobarrier'):
-    rep('''            if (more) {
-                load_stage(cur, c + 1);
-            } else if (has_next) {          // cross-tile prefetch: next tile's first stage under this tile's last chunk
-                setup_tile(tn, nxt);
-                load_stage(nxt, 0);
-            }''', '''            if (!more && has_next) setup_tile(tn, nxt);''')
-    rep('''            if (more || has_next) store_stage(sbuf ^ 1);
-            __syncthreads();
-            sbuf ^= 1;
-        }
-
-        if (p.out_layout''', '''            %s
-            sbuf ^= 1;
-        }
-
-        if (p.out_layout''' % ('__syncthreads();' if VAR == 'nostage' else ''))
-if VAR == 'nowrite':
-    rep('''                *reinterpret_cast<f32x4*>(s + (idx & 1) * (NPX * 16) + (idx >> 1) * 16) = in_reg[r];''', '''                asm volatile("" :: "v"(in_reg[r]), "v"(s));''')
-    rep('''                *reinterpret_cast<f32x4*>(s + IN_BYTES + idx * 16) = w_reg[r];''', '''                asm volatile("" :: "v"(w_reg[r]), "v"(s));''')
-    rep(EPI, NOEPI)
-if VAR == 'noload':
-    rep('''            if (more || has_next) store_stage(sbuf ^ 1);
-            __syncthreads();
-            sbuf ^= 1;
-        }
-
-        if (p.out_layout''', '''            __syncthreads();
-            sbuf ^= 1;
-        }
-
-        if (p.out_layout''')
 if VAR == 'noepi':
-    rep('''        if (p.out_layout == ESR_NCHW_SHUFFLE4) epilogue_shuffle<NT>(p, acc, cur.n, cur.x0, cur.y0, wv, lane);
-        else epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane);''',
-        '''        for (int tt = 0; tt < NT; ++tt) for (int r = 0; r < 4; ++r) asm volatile("" :: "v"(acc[tt][r]));''')
-if VAR == 'nostore':
-    rep('''            if (!has_split) {
-                if (NT == 4 || to0) *reinterpret_cast<f32x4*>(p.y0 + pu * p.y0_pitch + off0) = o;
-            } else {
-                if (to0) *reinterpret_cast<f32x4*>(p.y0 + pu * p.y0_pitch + off0) = o;
-                if (to1) *reinterpret_cast<f32x4*>(p.y1 + pu * p.y1_pitch + off1) = o;
-            }''', '''            asm volatile("" :: "v"(o), "s"(pu), "v"(off0), "v"(off1), "s"(has_split), "v"(to0 ? 1 : 0), "v"(to1 ? 1 : 0));''')
-if VAR == 'nolds':
-    rep('''        for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(scr + px * EPI_PITCH + t * 16 + kq * 4) = acc[t][r];
-        f32x4 v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(scr + (4 * i + prow) * EPI_PITCH + rd);''',
-        '''        for (int t = 0; t < 1; ++t) {}
-        f32x4 v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = acc[i % NT][r];''')
-if VAR in ('nostage', 'nobarrier', 'noload'):
-    rep(EPI, NOEPI)
-rep('int esr_abi_version(void) { return ESR_ABI_VERSION; }', 'int esr_abi_version(void) { return ESR_ABI_VERSION; }\nvoid esr_set_dbg(void* p) { (void)p; }')
+    rep(EPI, '''        for (int tt = 0; tt < NT; ++tt) for (int r = 0; r < 4; ++r) asm volatile("" :: "v"(acc[tt][r]));''')
+dbg_api = 'void esr_set_dbg(void* p) { (void)p; }'
+if VAR == 'waits':
+    # per-wave cycle sums: [0] wait for in_reg, [1] ds_write issue, [2] request ahead, [3] wait DMA (s_waitcnt), [4] barrier, [5] chunk top (glds issue + first frag), [6] MFMA phase
+    rep("    int tiles_x, tiles_y;\n};", "    int tiles_x, tiles_y;\n    unsigned long long* dbg;\n};")
+    rep("    k.tiles_y = (d->h + TILE - 1) / TILE;\n", "    k.tiles_y = (d->h + TILE - 1) / TILE;\n    k.dbg = g_dbg;\n")
+    rep('thread_local char g_err[256] = "";', 'thread_local char g_err[256] = "";\nunsigned long long* g_dbg = nullptr;')
+    dbg_api = 'void esr_set_dbg(void* p) { g_dbg = (unsigned long long*)p; }'
+    rep("    int sbuf = 0;\n\n    // bias", "    int sbuf = 0;\n    unsigned long long W0 = 0, W1 = 0, W2 = 0, W3 = 0, W4 = 0, W5 = 0, W6 = 0, W7 = 0, W8 = 0, Ta, Tb, Tc, Td; const unsigned long long Tk0 = clock64();\n\n    // bias") if "    int sbuf = 0;\n\n    // bias" in s else None
+    if "unsigned long long W0" not in s:
+        rep("    stage_barrier(inflight);\n    int sbuf = 0;\n", "    stage_barrier(inflight);\n    int sbuf = 0;\n    unsigned long long W0 = 0, W1 = 0, W2 = 0, W3 = 0, W4 = 0, W5 = 0, W6 = 0, W7 = 0, W8 = 0, Ta, Tb, Tc, Td; const unsigned long long Tk0 = clock64();\n")
+    rep("            const bool more = c + 1 < p.nchunks;\n            const bool wnext", f"            const bool more = c + 1 < p.nchunks;\n            {SB} Ta = clock64(); {SB}\n            const bool wnext")
+    rep("            const char* s = smem + sbuf * STAGE_BYTES;\n            // fragment reads run one tap ahead", f"            {SB} Tc = clock64(); W7 += Tc - Ta; {SB}\n            const char* s = smem + sbuf * STAGE_BYTES;\n            // fragment reads run one tap ahead")
+
+    rep("            load_frag(0, 0);\n            __builtin_amdgcn_s_setprio(0);", f"            load_frag(0, 0);\n            {SB} Td = clock64(); W8 += Td - Tc; {SB}\n            asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n            {SB} Tb = clock64(); W5 += Tb - Ta; {SB}\n            __builtin_amdgcn_s_setprio(0);")
+    rep("            __builtin_amdgcn_s_setprio(3);\n            if (more || has_next) store_stage(sbuf ^ 1);\n            inflight = false;",
+        f"            {SB} Ta = clock64(); W6 += Ta - Tb; {SB}\n            __builtin_amdgcn_s_setprio(3);\n            asm volatile(\"s_waitcnt vmcnt(%0)\" :: \"n\"(W_ROUNDS) : \"memory\");\n            {SB} Tb = clock64(); W0 += Tb - Ta; {SB}\n            if (more || has_next) store_stage(sbuf ^ 1);\n            {SB} Ta = clock64(); W1 += Ta - Tb; {SB}\n            inflight = false;")
+    rep("            stage_barrier(inflight);\n            sbuf ^= 1;\n        }", f"            {SB} Tb = clock64(); W2 += Tb - Ta; {SB}\n            if (inflight) asm volatile(\"s_waitcnt vmcnt(%0) lgkmcnt(0)\" ::\"n\"(IN_ROUNDS) : \"memory\"); else asm volatile(\"s_waitcnt vmcnt(0) lgkmcnt(0)\" ::: \"memory\");\n            {SB} Ta = clock64(); W3 += Ta - Tb; {SB}\n            __builtin_amdgcn_s_barrier();\n            {SB} Tb = clock64(); W4 += Tb - Ta; {SB}\n            sbuf ^= 1;\n        }}")
+    rep("        tn = tile_index(k + 1);\n        if (tn >= 0) setup_tile(tn, nxt);\n    }\n}", '''        tn = tile_index(k + 1);
+        if (tn >= 0) setup_tile(tn, nxt);
+    }
+    if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 4 + wv) * 8;
+        d[0] = W0; d[1] = W1; d[2] = W2; d[3] = W3; d[4] = W4; d[5] = W5; d[6] = W6; d[7] = W7 | (W8 << 32);
+    }
+}''')
+rep('int esr_abi_version(void) { return ESR_ABI_VERSION; }', 'int esr_abi_version(void) { return ESR_ABI_VERSION; }\n' + dbg_api)
 src = '/tmp/esr_dbg.hip'
 open(src, 'w').write(s)
 csrc = os.path.join(R, 'ntire2022_esr_amd/csrc')

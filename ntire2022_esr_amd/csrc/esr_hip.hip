@@ -58,6 +58,9 @@ struct ConvK {
     int res_mode;
     int out_layout;
     int tiles_x, tiles_y;
+#ifdef ESR_EXPERIMENTAL_WS
+    int hand_rows;        // accumulator rows (of 4) finished by the loader partner
+#endif
 };
 
 __device__ __forceinline__ float act_any(float v, int act, float slope)
@@ -476,210 +479,9 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
     }
 }
 
-// ---- wave-specialised variant (KS = 3, NHWC input) ---------------------------------------------------
-// One 512-thread block per CU: waves 0-3 ("consumers", one per SIMD) issue nothing but fragment ds_reads,
-// MFMAs, the per-stage barrier and the tile epilogue; waves 4-7 ("loaders", the SIMD partners) do all the
-// global->VGPR->LDS staging.  tools/dbg/phase_probe.py on conv_f32_kernel showed where its missing 17 % goes:
-// every VMEM / LDS-DMA / ds_write a wave issues blocks THAT wave for hundreds of cycles (5-6 k of a 17 k-cycle
-// chunk), and with two symmetric waves per SIMD both are blocked at once often enough to idle the pipe.  Here
-// the blocked time lives in waves that own no MFMAs.
-//   stages      WS_STAGES = 3 LDS buffers; in period g the consumers read stage g, the loaders write stage g+2
-//               (loaded into registers during period g-1) and request stage g+3: one s_barrier per period, and the
-//               loaders always arrive early.  Stage g+1 is already complete during period g, so the consumers
-//               prefetch its first fragments before the barrier.
-//   tile walk   same persistent XCD-aware order as conv_f32_kernel; both roles derive it independently.
-template <int NT, int LW, int WS_STAGES>
-__global__ __launch_bounds__(256 + 64 * LW, LW == 2 ? 3 : 2) void conv_f32_ws_kernel(const ConvK p)
-{
-    constexpr int WS_LOADERS = 64 * LW;
-    constexpr int KS = 3;
-    constexpr int TH = TILE + 2;
-    constexpr int NPX = TH * TH;
-    constexpr int TAPS = 9;
-    constexpr int IN_ITEMS = 2 * NPX;
-    constexpr int IN_BYTES = IN_ITEMS * 16;
-    constexpr int W_ITEMS = TAPS * NT * 32;
-    constexpr int W_FLOATS = W_ITEMS * 4;
-    constexpr int STAGE_BYTES = IN_BYTES + W_ITEMS * 16;
-    constexpr int IN_ROUNDS = (IN_ITEMS + WS_LOADERS - 1) / WS_LOADERS;
-    constexpr int W_ROUNDS = (W_ITEMS + WS_LOADERS - 1) / WS_LOADERS;
-    constexpr unsigned OOB = 0x80000000u;
-
-    __shared__ __attribute__((aligned(16))) char smem[WS_STAGES * STAGE_BYTES + 4 * EPI_WAVE_FLOATS * 4];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = tid >> 6;
-
-    const int ntiles = p.N * p.tiles_y * p.tiles_x;
-    const int G = gridDim.x;
-    auto tile_index = [&](int k) -> int {
-        const int base = k * G;
-        if (base >= ntiles) return -1;
-        int off = blockIdx.x;
-        if ((G & 7) == 0 && base + G <= ntiles) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-        const int t = base + off;
-        return t < ntiles ? t : -1;
-    };
-    const int my_tiles = ntiles / G + ((int)blockIdx.x < ntiles % G ? 1 : 0);
-    const int nstages = my_tiles * p.nchunks;
-
-    if (wv >= 4) {
-        // ------------------------------------------------ loaders ------------------------------------------
-        const int lt = tid - 256;
-        const size_t img_floats = (size_t)p.H * p.W * p.in_pitch;
-        unsigned voff[IN_ROUNDS];
-        __amdgpu_buffer_rsrc_t xrsrc;
-        int k = 0, c = 0;
-        int t = tile_index(0);
-        auto setup_tile = [&]() {
-            const int tx = t % p.tiles_x;
-            const int tq = t / p.tiles_x;
-            const int ty = tq % p.tiles_y;
-            const int n = tq / p.tiles_y;
-            const int x0 = tx * TILE, y0 = ty * TILE;
-#pragma unroll
-            for (int r = 0; r < IN_ROUNDS; ++r) {
-                const int idx = lt + r * WS_LOADERS;
-                const int half = idx & 1;
-                const int pl = idx >> 1;
-                const int ly = pl / TH, lx = pl - ly * TH;
-                const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
-                const bool ok = idx < IN_ITEMS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-                voff[r] = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff + 4 * half) * 4u : OOB;
-            }
-            xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)n * img_floats), 0, (int)(img_floats * 4), 0x00020000);
-        };
-        f32x4 in_reg[IN_ROUNDS], w_reg[W_ROUNDS];
-        // request stage (t, c) into registers and step the iterator
-        auto request = [&]() {
-#pragma unroll
-            for (int r = 0; r < IN_ROUNDS; ++r)
-                in_reg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff[r], c * (CHUNK * 4), 0));
-            const float* wsrc = p.wp + (size_t)c * W_FLOATS;
-#pragma unroll
-            for (int r = 0; r < W_ROUNDS; ++r) {
-                const int idx = lt + r * WS_LOADERS;
-                if (W_ITEMS % WS_LOADERS == 0 || idx < W_ITEMS) w_reg[r] = *reinterpret_cast<const f32x4*>(wsrc + idx * 4);
-            }
-            if (++c == p.nchunks) {
-                c = 0;
-                t = tile_index(++k);
-                if (t >= 0) setup_tile();
-            }
-        };
-        auto write = [&](int buf) {
-            char* s = smem + buf * STAGE_BYTES;
-#pragma unroll
-            for (int r = 0; r < IN_ROUNDS; ++r) {
-                const int idx = lt + r * WS_LOADERS;
-                if (IN_ITEMS % WS_LOADERS == 0 || idx < IN_ITEMS)
-                    *reinterpret_cast<f32x4*>(s + (idx & 1) * (NPX * 16) + (idx >> 1) * 16) = in_reg[r];
-            }
-#pragma unroll
-            for (int r = 0; r < W_ROUNDS; ++r) {
-                const int idx = lt + r * WS_LOADERS;
-                if (W_ITEMS % WS_LOADERS == 0 || idx < W_ITEMS) *reinterpret_cast<f32x4*>(s + IN_BYTES + idx * 16) = w_reg[r];
-            }
-        };
-        if (t >= 0) setup_tile();
-        int issued = 0, wbuf = 0;
-        bool pending = false;                       // a requested stage sits in (or is on its way to) the registers
-        for (int i = 0; i < WS_STAGES - 1; ++i) {
-            if (issued < nstages) { request(); ++issued; write(wbuf); }
-            wbuf = wbuf + 1 == WS_STAGES ? 0 : wbuf + 1;
-        }
-        if (issued < nstages) { request(); ++issued; pending = true; }
-        __syncthreads();
-        for (int g = 0; g < nstages; ++g) {
-            if (pending) {
-                write(wbuf);
-                pending = false;
-                if (issued < nstages) { request(); ++issued; pending = true; }
-            }
-            wbuf = wbuf + 1 == WS_STAGES ? 0 : wbuf + 1;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        return;
-    }
-
-    // ---------------------------------------------------- consumers ----------------------------------------
-    const int px = lane & 15;
-    const int kq = lane >> 4;
-    float* const scr = reinterpret_cast<float*>(smem + WS_STAGES * STAGE_BYTES) + wv * EPI_WAVE_FLOATS;
-    const int b_base = (kq >> 1) * (NPX * 16) + ((wv * 4) * TH + px) * 16 + (kq & 1) * 8;
-    const int a_base = IN_BYTES + lane * 8;
-    f32x4 biasv[NT];
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) biasv[tt] = *reinterpret_cast<const f32x4*>(p.bias + tt * 16 + kq * 4);
-
-    __syncthreads();
-    int rbuf = 0;
-    for (int k = 0; k < my_tiles; ++k) {
-        const int t = tile_index(k);
-        const int tx = t % p.tiles_x;
-        const int tq = t / p.tiles_x;
-        const int ty = tq % p.tiles_y;
-        const int n = tq / p.tiles_y;
-
-        f32x4 acc[NT][4];
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[tt][r] = biasv[tt];
-
-        f32x2 a[2][NT], b[2][4];
-        auto load_frag = [&](const char* s, int slot, int tap) {
-            const int dy = tap / KS, dx = tap - dy * KS;
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-                a[slot][tt] = *reinterpret_cast<const f32x2*>(s + a_base + (tap * NT + tt) * 512);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                b[slot][r] = *reinterpret_cast<const f32x2*>(s + b_base + ((r + dy) * TH + dx) * 16);
-        };
-        // one K chunk; PAR = fragment slot holding tap 0 (9 taps: the parity flips every chunk)
-        auto chunk = [&](auto par, bool more) {
-            constexpr int PAR = decltype(par)::value;
-            const char* s = smem + rbuf * STAGE_BYTES;
-            const int nbuf = rbuf + 1 == WS_STAGES ? 0 : rbuf + 1;
-            const char* sn = smem + nbuf * STAGE_BYTES;
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                const int cs = (tap + PAR) & 1;
-                if (tap + 1 < TAPS) load_frag(s, cs ^ 1, tap + 1);
-                else if (more) load_frag(sn, cs ^ 1, 0);      // next stage of this tile: complete since the last barrier
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            acc[tt][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cs][tt][j], b[cs][r][j], acc[tt][r], 0, 0, 0);
-            }
-            __builtin_amdgcn_s_barrier();
-            rbuf = nbuf;
-        };
-        if (WS_STAGES >= 3) {
-            load_frag(smem + rbuf * STAGE_BYTES, 0, 0);
-            for (int c = 0; c < p.nchunks; ++c) {
-                const bool more = c + 1 < p.nchunks;
-                if (c & 1) chunk(std::integral_constant<int, 1>{}, more);
-                else chunk(std::integral_constant<int, 0>{}, more);
-            }
-        } else {
-            // two stages: the next one is still being written during this period, no fragment prefetch across the barrier
-            for (int c = 0; c < p.nchunks; ++c) {
-                load_frag(smem + rbuf * STAGE_BYTES, 0, 0);
-                chunk(std::integral_constant<int, 0>{}, false);
-            }
-        }
-        if (p.out_layout == ESR_NCHW_SHUFFLE4) epilogue_shuffle<NT>(p, acc, n, tx * TILE, ty * TILE, wv, lane);
-        else epilogue_nhwc<NT>(p, acc, scr, n, tx * TILE, ty * TILE, wv, lane);
-    }
-}
+#ifdef ESR_EXPERIMENTAL_WS
+#include "experimental/conv_ws.inc"        // wave-specialised research variant (tools/dbg builds only)
+#endif
 
 // ---- 16-bit-operand variant (bf16 or fp16 MFMA operands, fp32 accumulate, fp32 storage) ----------------
 // Same persistent structure as conv_f32_kernel, KS = 3 and NHWC input only.  Activations stay fp32 in HBM and
@@ -896,18 +698,16 @@ int launch_conv(const ConvK& k, hipStream_t st)
     return ESR_OK;
 }
 
+#ifdef ESR_EXPERIMENTAL_WS
 template <int NT>
 int launch_conv_ws(const ConvK& k, hipStream_t st)
 {
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
-    static const int mode = getenv("ESR_WS_MODE") ? atoi(getenv("ESR_WS_MODE")) : 2;
-    if (mode == 1) {
-        const int grid = ntiles < 256 ? ntiles : 256;
-        hipLaunchKernelGGL((conv_f32_ws_kernel<NT, 4, 3>), dim3(grid), dim3(512), 0, st, k);
-    } else {
-        const int grid = ntiles < 512 ? ntiles : 512;
-        hipLaunchKernelGGL((conv_f32_ws_kernel<NT, 2, 2>), dim3(grid), dim3(384), 0, st, k);
-    }
+    const int grid = ntiles < WS_MAX_BLOCKS ? ntiles : WS_MAX_BLOCKS;
+    static const int hand_rows = getenv("ESR_WS_HAND_ROWS") ? atoi(getenv("ESR_WS_HAND_ROWS")) : 2;
+    ConvK kk = k;
+    kk.hand_rows = hand_rows;
+    hipLaunchKernelGGL((conv_f32_ws_kernel<NT>), dim3(grid), dim3(WS_THREADS), 0, st, kk);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_err("conv_f32_ws_kernel launch", e);
@@ -915,10 +715,12 @@ int launch_conv_ws(const ConvK& k, hipStream_t st)
     }
     return ESR_OK;
 }
+#endif
 
 template <int KS, bool IN_NCHW>
 int launch_conv_nt(int nt, const ConvK& k, hipStream_t st)
 {
+#ifdef ESR_EXPERIMENTAL_WS
     if (KS == 3 && !IN_NCHW) {
         static const int ws_min_nt = getenv("ESR_WS_MIN_NT") ? atoi(getenv("ESR_WS_MIN_NT")) : 99;
         if (nt >= ws_min_nt) {
@@ -930,6 +732,7 @@ int launch_conv_nt(int nt, const ConvK& k, hipStream_t st)
             }
         }
     }
+#endif
     switch (nt) {
         case 1: return launch_conv<1, KS, IN_NCHW>(k, st);
         case 2: return launch_conv<2, KS, IN_NCHW>(k, st);

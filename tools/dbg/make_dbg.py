@@ -16,14 +16,14 @@ if VAR == 'noepi':
 dbg_api = 'void esr_set_dbg(void* p) { (void)p; }'
 if VAR == 'waits':
     # per-wave cycle sums: [0] wait for in_reg, [1] ds_write issue, [2] request ahead, [3] wait DMA (s_waitcnt), [4] barrier, [5] chunk top (glds issue + first frag), [6] MFMA phase
-    rep("    int tiles_x, tiles_y;\n};", "    int tiles_x, tiles_y;\n    unsigned long long* dbg;\n};")
+    rep("    int tiles_x, tiles_y;\n", "    int tiles_x, tiles_y;\n    unsigned long long* dbg;\n")
     rep("    k.tiles_y = (d->h + TILE - 1) / TILE;\n", "    k.tiles_y = (d->h + TILE - 1) / TILE;\n    k.dbg = g_dbg;\n")
     rep('thread_local char g_err[256] = "";', 'thread_local char g_err[256] = "";\nunsigned long long* g_dbg = nullptr;')
     dbg_api = 'void esr_set_dbg(void* p) { g_dbg = (unsigned long long*)p; }'
     rep("    int sbuf = 0;\n\n    // bias", "    int sbuf = 0;\n    unsigned long long W0 = 0, W1 = 0, W2 = 0, W3 = 0, W4 = 0, W5 = 0, W6 = 0, W7 = 0, W8 = 0, Ta, Tb, Tc, Td; const unsigned long long Tk0 = clock64();\n\n    // bias") if "    int sbuf = 0;\n\n    // bias" in s else None
     if "unsigned long long W0" not in s:
         rep("    stage_barrier(inflight);\n    int sbuf = 0;\n", "    stage_barrier(inflight);\n    int sbuf = 0;\n    unsigned long long W0 = 0, W1 = 0, W2 = 0, W3 = 0, W4 = 0, W5 = 0, W6 = 0, W7 = 0, W8 = 0, Ta, Tb, Tc, Td; const unsigned long long Tk0 = clock64();\n")
-    rep("            const bool more = c + 1 < p.nchunks;\n            const bool wnext", f"            const bool more = c + 1 < p.nchunks;\n            {SB} Ta = clock64(); {SB}\n            const bool wnext")
+    rep("            const bool more = c + 1 < p.nchunks;\n            if (more) load_weights(c + 1, sbuf ^ 1);", f"            const bool more = c + 1 < p.nchunks;\n            {SB} Ta = clock64(); {SB}\n            if (more) load_weights(c + 1, sbuf ^ 1);")
     rep("            const char* s = smem + sbuf * STAGE_BYTES;\n            // fragment reads run one tap ahead", f"            {SB} Tc = clock64(); W7 += Tc - Ta; {SB}\n            const char* s = smem + sbuf * STAGE_BYTES;\n            // fragment reads run one tap ahead")
 
     rep("            load_frag(0, 0);\n            __builtin_amdgcn_s_setprio(0);", f"            load_frag(0, 0);\n            {SB} Td = clock64(); W8 += Td - Tc; {SB}\n            asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n            {SB} Tb = clock64(); W5 += Tb - Ta; {SB}\n            __builtin_amdgcn_s_setprio(0);")

@@ -12,7 +12,7 @@ lib = L.lib(); lib.esr_set_dbg.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda:0")
 x = torch.randn(32, 256, 256, 64, device=dev); w = torch.randn(64, 64, 3, 3) * 0.05; b = torch.randn(64)
 pk = pack_conv(w, b).to(dev); out = torch.empty(32, 256, 256, 64, device=dev)
-MODE = int(os.environ.get("ESR_WS_MODE", "2")); NB = 256 if MODE == 1 else 512
+MODE = 1; NB = 256
 dbg = torch.zeros(NB * 8 * 4, dtype=torch.int64, device=dev)
 for _ in range(20): ops.conv2d(x, w, b, act=1, packed=pk, out=out)
 torch.cuda.synchronize()
@@ -28,10 +28,11 @@ d = dbg.cpu().numpy().reshape(NB, 8, 4).astype(np.float64)
 ntile = 8192 // NB; nchunk = ntile * 8
 c, l = d[:, :4, :], d[:, 4:(8 if MODE == 1 else 6), :]
 def line(n, v): print(f"{n:52s} mean {v.mean():9.0f}  p10 {np.percentile(v,10):9.0f}  p90 {np.percentile(v,90):9.0f}")
-line("consumer: barrier wait / chunk", c[:, :, 0] / nchunk)
+line("consumer: wait for stage counter / chunk", c[:, :, 0] / nchunk)
 line("consumer: chunk loop / chunk (ideal 9216)", c[:, :, 1] / nchunk)
-line("consumer: epilogue / tile", c[:, :, 2] / ntile)
-line("consumer: first-frag wait / tile", c[:, :, 3] / ntile)
-line("loader: barrier wait / chunk", l[:, :, 0] / nchunk)
+line("consumer: hand-over or own epilogue / tile", c[:, :, 2] / ntile)
+line("consumer: wait for loader to free scratch / tile", c[:, :, 3] / ntile)
+line("loader: wait for freed buffer / chunk", l[:, :, 0] / nchunk)
 line("loader: vmcnt wait + ds_write / chunk", l[:, :, 1] / nchunk)
 line("loader: request issue / chunk", l[:, :, 2] / nchunk)
+line("loader: epilogue duty / chunk", l[:, :, 3] / nchunk)

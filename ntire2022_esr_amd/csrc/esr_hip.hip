@@ -198,9 +198,9 @@ __device__ __forceinline__ void epilogue_nhwc_fast_res(const ConvK& p, f32x4 (&a
 
 template <int NT>
 __device__ __forceinline__ void epilogue_nhwc(const ConvK& p, f32x4 (&acc)[NT][4], float* scr, int n, int x0, int y0,
-                                              int wv, int lane)
+                                              int wv, int lane, int tile_h = TILE)
 {
-    const bool inside = x0 + TILE <= p.W && y0 + TILE <= p.H && (NT < 4 || p.cout_store == 64);   // uniform
+    const bool inside = x0 + TILE <= p.W && y0 + tile_h <= p.H && (NT < 4 || p.cout_store == 64);   // uniform
     if (inside && p.act == ESR_ACT_LRELU) epilogue_nhwc_fast_res<ESR_ACT_LRELU, NT>(p, acc, scr, n, x0, y0, wv, lane);
     else if (inside && p.act == ESR_ACT_NONE) epilogue_nhwc_fast_res<ESR_ACT_NONE, NT>(p, acc, scr, n, x0, y0, wv, lane);
     else if (inside && p.act == ESR_ACT_GELU && p.res_mode == ESR_RES_NONE)
@@ -245,12 +245,15 @@ __device__ __forceinline__ void epilogue_shuffle(const ConvK& p, f32x4 (&acc)[NT
 // ---- the kernel -------------------------------------------------------------------------------------
 // Persistent over tiles: block b walks tiles b, b+G, b+2G, ... (XCD-aware order) and the last K chunk of
 // tile i stages chunk 0 of tile i+1, so only the very first tile of a block pays a prologue.
-template <int NT, int KS, bool IN_NCHW>
-__global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
+template <int NT, int KS, bool IN_NCHW, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
 {
+    constexpr int THREADS = 64 * NW;                  // shadows the file-scope constant: NW waves of 4 rows each
+    constexpr int TILE_H = 4 * NW;
     constexpr int HALO = KS / 2;
-    constexpr int TH = TILE + 2 * HALO;
-    constexpr int NPX = TH * TH;
+    constexpr int TH = TILE + 2 * HALO;               // halo tile width (also the LDS row pitch in pixels)
+    constexpr int THY = TILE_H + 2 * HALO;
+    constexpr int NPX = TH * THY;
     constexpr int TAPS = KS * KS;
     constexpr int IN_ITEMS = 2 * NPX;                 // 16-byte items per stage (input)
     constexpr int IN_BYTES = IN_ITEMS * 16;
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
     constexpr int W_ROUNDS = (W_ITEMS + THREADS - 1) / THREADS;
     constexpr unsigned OOB = 0x80000000u;             // > any per-image byte offset (host checks < 2 GiB)
 
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + 4 * EPI_WAVE_FLOATS * 4];
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + NW * EPI_WAVE_FLOATS * 4];
 
     // Issue priority: everything that is not the MFMA stream (staging, barrier, epilogue: a handful of
     // instructions per 288 MFMAs) runs at raised priority so it is issued ahead of the SIMD partner's stream.
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
         const int ty = tq % p.tiles_y;
         c.n = tq / p.tiles_y;
         c.x0 = tx * TILE;
-        c.y0 = ty * TILE;
+        c.y0 = ty * TILE_H;
 #pragma unroll
         for (int r = 0; r < IN_ROUNDS; ++r) {
             const int idx = tid + r * THREADS;
@@ -388,6 +391,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
     // 5 % of the kernel waiting for these loads with a one-chunk lead).  The body requests the weights of g+1 (they can
     // only start now: they land in the buffer the previous stage was reading), runs the MFMAs, writes in_reg to LDS and
     // requests the input of stage g+2.
+    constexpr bool STAGGER = NW == 8;           // implies KS == 3, NHWC input, nchunks >= 2 (host dispatch)
+    const bool late = STAGGER && wv >= 4;
     constexpr bool AHEAD = !IN_NCHW;            // the NCHW head issues a cin-dependent number of loads: plain vmcnt(0)
     int k = 0;
     int t = tile_index(0);
@@ -425,9 +430,23 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
 
         for (int c = 0; c < p.nchunks; ++c) {
             const bool more = c + 1 < p.nchunks;
-            if (more) load_weights(c + 1, sbuf ^ 1);
+            // 8-wave blocks: the two waves of a SIMD belong to the same block and would stage (and then compete for the
+            // MFMA pipe) in lockstep.  Waves 0-3 therefore do all their staging at the top of the chunk, waves 4-7 in the
+            // middle of it; needs nchunks >= 2 so that the input of the next stage is always already in flight.
+            auto staging_block = [&]() {
+                if (more || has_next) {
+                    store_stage(sbuf ^ 1);
+                    load_weights(more ? c + 1 : 0, sbuf ^ 1);
+                }
+                inflight = false;
+                if (c + 2 < p.nchunks) { load_input(cur, c + 2); inflight = true; }
+                else if (has_next && c + 2 - p.nchunks < p.nchunks) { load_input(nxt, c + 2 - p.nchunks); inflight = true; }
+            };
+            if (STAGGER) {
+                if (!late) staging_block();
+            } else if (more) load_weights(c + 1, sbuf ^ 1);
             else if (has_next) load_weights(0, sbuf ^ 1);
-            if (!inflight) {                               // one-chunk lead (head conv, or nothing was requested ahead)
+            if (!STAGGER && !inflight) {                               // one-chunk lead (head conv, or nothing was requested ahead)
                 if (more) load_input(cur, c + 1);
                 else if (has_next) load_input(nxt, 0);
             }
@@ -457,11 +476,16 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             acc[tt][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cs][tt][j], b[cs][r][j], acc[tt][r], 0, 0, 0);
+                if (STAGGER && tap == TAPS / 2 && late) {
+                    __builtin_amdgcn_s_setprio(3);
+                    staging_block();
+                    __builtin_amdgcn_s_setprio(0);
+                }
             }
             __builtin_amdgcn_s_setprio(3);
-            if (more || has_next) store_stage(sbuf ^ 1);
-            inflight = false;
-            if (AHEAD) {                                   // input of the stage after next
+            if (!STAGGER && (more || has_next)) store_stage(sbuf ^ 1);
+            if (!STAGGER) inflight = false;
+            if (AHEAD && !STAGGER) {                                   // input of the stage after next
                 if (c + 2 < p.nchunks) { load_input(cur, c + 2); inflight = true; }
                 else if (has_next && c + 2 - p.nchunks < p.nchunks) { load_input(nxt, c + 2 - p.nchunks); inflight = true; }
             }
@@ -470,7 +494,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_f32_kernel(const ConvK p)
         }
 
         if (p.out_layout == ESR_NCHW_SHUFFLE4) epilogue_shuffle<NT>(p, acc, cur.n, cur.x0, cur.y0, wv, lane);
-        else epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane);
+        else epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE_H);
         if (!has_next) break;
         cur = nxt;
         ++k;
@@ -688,8 +712,26 @@ int launch_conv(const ConvK& k, hipStream_t st)
 {
     // persistent: at most 2 blocks per CU (LDS-limited), each walks ntiles/grid tiles
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
+    // Large 3x3 launches: 8-wave blocks on 16x32-pixel tiles, one per CU.  The eight waves share one weight stage, so
+    // a SIMD issues a third fewer staging instructions per MFMA (they, not the MFMA pipe, bound this kernel: DESIGN.md).
+    constexpr bool CAN_TALL = KS == 3 && !IN_NCHW && NT >= 3;
+    const int tall_y = (k.H + 31) / 32;
+    const int ntall = k.N * k.tiles_x * tall_y;
+    static const int tall_min = getenv("ESR_TALL_MIN") ? atoi(getenv("ESR_TALL_MIN")) : (1 << 30);
+    if (CAN_TALL && k.nchunks >= 2 && ntall >= tall_min) {
+        ConvK kk = k;
+        kk.tiles_y = tall_y;
+        const int grid = ntall < 256 ? ntall : 256;
+        hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, CAN_TALL ? 8 : 4>), dim3(grid), dim3(512), 0, st, kk);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            set_err("conv_f32_kernel (tall) launch", e);
+            return ESR_ERR_LAUNCH;
+        }
+        return ESR_OK;
+    }
     const int grid = ntiles < MAX_RESIDENT_BLOCKS ? ntiles : MAX_RESIDENT_BLOCKS;
-    hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW>), dim3(grid), dim3(THREADS), 0, st, k);
+    hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, 4>), dim3(grid), dim3(THREADS), 0, st, k);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_err("conv_f32_kernel launch", e);

@@ -717,7 +717,7 @@ int launch_conv(const ConvK& k, hipStream_t st)
     constexpr bool CAN_TALL = KS == 3 && !IN_NCHW && NT >= 3;
     const int tall_y = (k.H + 31) / 32;
     const int ntall = k.N * k.tiles_x * tall_y;
-    static const int tall_min = getenv("ESR_TALL_MIN") ? atoi(getenv("ESR_TALL_MIN")) : (1 << 30);
+    static const int tall_min = getenv("ESR_TALL_MIN") ? atoi(getenv("ESR_TALL_MIN")) : 256;
     if (CAN_TALL && k.nchunks >= 2 && ntall >= tall_min) {
         ConvK kk = k;
         kk.tiles_y = tall_y;

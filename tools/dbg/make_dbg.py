@@ -38,6 +38,26 @@ if VAR == 'waits':
         d[0] = W0; d[1] = W1; d[2] = W2; d[3] = W3; d[4] = W4; d[5] = W5; d[6] = W6; d[7] = W7 | (W8 << 32);
     }
 }''')
+if VAR == 'tall':
+    # 8-wave kernel, per-wave cycle sums: [0] staging block, [1] stage-end wait (vmcnt/lgkm), [2] s_barrier, [3] whole chunk, [4] epilogue, [5] first-frag wait
+    rep("    int tiles_x, tiles_y;\n", "    int tiles_x, tiles_y;\n    unsigned long long* dbg;\n")
+    rep("    k.tiles_y = (d->h + TILE - 1) / TILE;\n", "    k.tiles_y = (d->h + TILE - 1) / TILE;\n    k.dbg = g_dbg;\n")
+    rep('thread_local char g_err[256] = "";', 'thread_local char g_err[256] = "";\nunsigned long long* g_dbg = nullptr;')
+    dbg_api = 'void esr_set_dbg(void* p) { g_dbg = (unsigned long long*)p; }'
+    rep("    stage_barrier(inflight);\n    int sbuf = 0;\n", "    stage_barrier(inflight);\n    int sbuf = 0;\n    unsigned long long W0 = 0, W1 = 0, W2 = 0, W3 = 0, W4 = 0, W5 = 0, Ta, Tb, Tc;\n")
+    rep("            if (STAGGER) {\n                if (!late) staging_block();\n", f"            {SB} Tc = clock64(); {SB}\n            if (STAGGER) {{\n                if (!late) {{ staging_block(); {SB} Ta = clock64(); W0 += Ta - Tc; {SB} }}\n")
+    rep("                    staging_block();\n                    __builtin_amdgcn_s_setprio(0);", f"                    {SB} Ta = clock64(); {SB}\n                    staging_block();\n                    {SB} Tb = clock64(); W0 += Tb - Ta; {SB}\n                    __builtin_amdgcn_s_setprio(0);")
+    rep("            load_frag(0, 0);\n            __builtin_amdgcn_s_setprio(0);", f"            {SB} Ta = clock64(); {SB}\n            load_frag(0, 0);\n            asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n            {SB} Tb = clock64(); W5 += Tb - Ta; {SB}\n            __builtin_amdgcn_s_setprio(0);")
+    rep("            stage_barrier(inflight);\n            sbuf ^= 1;\n        }", f"            {SB} Ta = clock64(); {SB}\n            if (inflight) asm volatile(\"s_waitcnt vmcnt(%0) lgkmcnt(0)\" ::\"n\"(IN_ROUNDS) : \"memory\"); else asm volatile(\"s_waitcnt vmcnt(0) lgkmcnt(0)\" ::: \"memory\");\n            {SB} Tb = clock64(); W1 += Tb - Ta; {SB}\n            __builtin_amdgcn_s_barrier();\n            {SB} Ta = clock64(); W2 += Ta - Tb; W3 += Ta - Tc; {SB}\n            sbuf ^= 1;\n        }}")
+    rep("        else epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE_H);\n", f"        else epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE_H);\n        {SB} Tb = clock64(); W4 += Tb - Ta; {SB}\n")
+    rep("        tn = tile_index(k + 1);\n        if (tn >= 0) setup_tile(tn, nxt);\n    }\n}", """        tn = tile_index(k + 1);
+        if (tn >= 0) setup_tile(tn, nxt);
+    }
+    if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wv) * 8;
+        d[0] = W0; d[1] = W1; d[2] = W2; d[3] = W3; d[4] = W4; d[5] = W5;
+    }
+}""")
 rep('int esr_abi_version(void) { return ESR_ABI_VERSION; }', 'int esr_abi_version(void) { return ESR_ABI_VERSION; }\n' + dbg_api)
 src = '/tmp/esr_dbg.hip'
 open(src, 'w').write(s)

@@ -115,6 +115,10 @@ int    esr_pack_conv_h16(const float* w_oihw, const float* bias, int cin, int co
                          int cin_phys, int compute, void* out, size_t out_bytes);
 
 int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream);
+/* Diagnostics: waves per block of the conv_f32_kernel variant esr_conv2d_f32 launches for `d` (4 = 16x16-pixel tiles,
+ * two blocks per CU; 8 = 16x32-pixel tiles, one block per CU, used for large 3x3 launches), 0 for a NULL / empty
+ * descriptor.  Lets a profiler name the device symbol that ran (the reference has torch.profiler for that). */
+int esr_conv_block_waves(const esr_conv_desc* d);
 
 /*
  * ESA (enhanced spatial attention) -- models/rfdn_baseline/block.py:103-129, models/team04_rlfn.py:62-89,

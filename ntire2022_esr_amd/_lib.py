@@ -58,7 +58,7 @@ EXPORTS = [
     "esr_abi_version", "esr_last_hip_error", "esr_build_info",
     "esr_packed_conv_bytes", "esr_pack_conv_f32", "esr_unpack_conv_f32",
     "esr_packed_conv_h16_bytes", "esr_pack_conv_h16",
-    "esr_conv2d_f32", "esr_run_ops",
+    "esr_conv2d_f32", "esr_conv_block_waves", "esr_run_ops",
     "esr_prof_create", "esr_run_ops_profiled", "esr_prof_collect", "esr_prof_destroy",
     "esr_packed_dense_bytes", "esr_pack_dense_f32",
     "esr_conv3x3s2_f32", "esr_maxpool7s3_f32", "esr_esa_apply_f32",
@@ -98,6 +98,8 @@ def lib():
     L.esr_pack_conv_h16.restype = ci
     L.esr_conv2d_f32.argtypes = [ctypes.POINTER(ConvDesc), vp]
     L.esr_conv2d_f32.restype = ci
+    L.esr_conv_block_waves.argtypes = [ctypes.POINTER(ConvDesc)]
+    L.esr_conv_block_waves.restype = ci
     L.esr_run_ops.argtypes = [ctypes.POINTER(Op), ci, vp]
     L.esr_run_ops.restype = ci
     L.esr_packed_dense_bytes.argtypes = [ci, ci, ci]

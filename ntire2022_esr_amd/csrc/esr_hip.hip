@@ -707,18 +707,27 @@ thread_local char g_err[256] = "";
 inline void set_err(const char* what, hipError_t e) { esr_set_err(what, e); }
 inline int round_up(int v, int m) { return esr_round_up(v, m); }
 
+// Which conv_f32_kernel variant a launch takes: 8-wave blocks on 16x32-pixel tiles (one per CU) for large 3x3 NHWC
+// launches, else 4-wave blocks on 16x16 tiles (two per CU).  The eight waves share one weight stage, so a SIMD issues a
+// third fewer staging instructions per MFMA (they, not the MFMA pipe, bound this kernel: DESIGN.md).  ESR_TALL_MIN
+// overrides the launch-size threshold (tuning only).
+inline int conv_block_waves(int ksize, bool in_nchw, int nt, int nchunks, int n, int h, int w)
+{
+    static const int tall_min = getenv("ESR_TALL_MIN") ? atoi(getenv("ESR_TALL_MIN")) : 256;
+    if (ksize != 3 || in_nchw || nt < 3 || nchunks < 2) return 4;
+    const long ntall = (long)n * ((w + TILE - 1) / TILE) * ((h + 31) / 32);
+    return ntall >= tall_min ? 8 : 4;
+}
+
 template <int NT, int KS, bool IN_NCHW>
 int launch_conv(const ConvK& k, hipStream_t st)
 {
     // persistent: at most 2 blocks per CU (LDS-limited), each walks ntiles/grid tiles
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
-    // Large 3x3 launches: 8-wave blocks on 16x32-pixel tiles, one per CU.  The eight waves share one weight stage, so
-    // a SIMD issues a third fewer staging instructions per MFMA (they, not the MFMA pipe, bound this kernel: DESIGN.md).
     constexpr bool CAN_TALL = KS == 3 && !IN_NCHW && NT >= 3;
-    const int tall_y = (k.H + 31) / 32;
-    const int ntall = k.N * k.tiles_x * tall_y;
-    static const int tall_min = getenv("ESR_TALL_MIN") ? atoi(getenv("ESR_TALL_MIN")) : 256;
-    if (CAN_TALL && k.nchunks >= 2 && ntall >= tall_min) {
+    if (CAN_TALL && conv_block_waves(KS, IN_NCHW, NT, k.nchunks, k.N, k.H, k.W) == 8) {
+        const int tall_y = (k.H + 31) / 32;
+        const int ntall = k.N * k.tiles_x * tall_y;
         ConvK kk = k;
         kk.tiles_y = tall_y;
         const int grid = ntall < 256 ? ntall : 256;
@@ -957,6 +966,15 @@ int esr_pack_conv_h16(const float* w, const float* bias, int cin, int cout, cons
     if (bias)
         for (int oc = 0; oc < cout; ++oc) bo[oc] = bias[oc];
     return ESR_OK;
+}
+
+int esr_conv_block_waves(const esr_conv_desc* d)
+{
+    if (!d || d->cin <= 0 || d->cout <= 0) return 0;
+    if (d->compute != ESR_COMPUTE_F32) return 4;
+    const bool in_nchw = d->in_layout == ESR_NCHW_IN;
+    const int cin_phys = in_nchw ? CHUNK : round_up(d->cin, CHUNK);
+    return conv_block_waves(d->ksize, in_nchw, round_up(d->cout, 16) / 16, cin_phys / CHUNK, d->n, d->h, d->w);
 }
 
 int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)

@@ -404,12 +404,16 @@ class HipSRModel(nn.Module):
                                     ms_sum=ms[i], passes=passes.value))
                     continue
                 nt = (o["cout"] + 15) // 16
-                kern = f"conv_f32_kernel<NT={nt},KS={o['k']},NCHW_IN={int(o['src'] is INPUT)}>"
+                nw = L.lib().esr_conv_block_waves(ctypes.byref(arr[i].conv))
+                kern = f"conv_f32_kernel<NT={nt},KS={o['k']},NCHW_IN={int(o['src'] is INPUT)},NW={nw}>"
                 if self._uses_h16(o):
                     kern = f"conv_h16_kernel<NT={nt},{self.compute}>"
                 npix = plan.npix if o["hw"] is None else plan.n * o["hw"][0] * o["hw"][1]
+                # algorithmic HBM bytes: input slice + residual + weights read once, output written once (fp32 storage)
+                rd = 4.0 * (npix * (o["cin"] + (o["cout"] if o["res"] is not None else 0)) + o["cin"] * o["cout"] * o["k"] ** 2)
                 out.append(dict(name=o["w"], kernel=kern, cin=o["cin"], cout=o["cout"], k=o["k"],
                                 flops=2.0 * npix * o["cin"] * o["cout"] * o["k"] * o["k"],
+                                read_bytes=rd, write_bytes=4.0 * npix * o["cout"],
                                 ms_sum=ms[i], passes=passes.value))
         return out
 

@@ -123,3 +123,59 @@ def test_bad_arguments_are_rejected():
         ops.conv2d(torch.randn(1, 8, 8, 64, device=dev), torch.randn(80, 64, 3, 3), torch.randn(80))  # cout > 64
     with pytest.raises(L.EsrError):
         ops.conv2d(torch.randn(1, 8, 8, 64), torch.randn(16, 64, 3, 3), torch.randn(16))            # CPU tensor
+
+
+def _block_waves(n, h, w, cin, cout, k=3):
+    """esr_conv_block_waves for an NHWC fp32 conv of that shape."""
+    import ctypes
+    from ntire2022_esr_amd import _lib as L
+    d = L.ConvDesc()
+    d.n, d.h, d.w, d.cin, d.cout, d.ksize = n, h, w, cin, cout, k
+    d.in_layout = L.NHWC
+    return L.lib().esr_conv_block_waves(ctypes.byref(d))
+
+
+@pytest.mark.parametrize("n,hw,cin,cout", [(5, (200, 136), 64, 64), (3, (250, 250), 48, 64), (9, (97, 130), 40, 48),
+                                           (2, (509, 340), 64, 64)])
+@pytest.mark.parametrize("act,res_mode", [(1, 0), (0, 2), (1, 1)])
+def test_conv_8wave_tall_tiles(n, hw, cin, cout, act, res_mode):
+    """Launches large enough for the 8-wave / 16x32-tile variant (ragged right and bottom edges, rows that are not a
+    multiple of 32), all epilogue families, against ATen."""
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    assert _block_waves(n, *hw, cin, cout) == 8 and _block_waves(1, 64, 64, cin, cout) == 4
+    g = torch.Generator().manual_seed(n * 7 + hw[0] + act + 3 * res_mode)
+    x = torch.randn(n, cin, *hw, generator=g)
+    r = torch.randn(n, cout, *hw, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    c = F.conv2d(x, w, b, padding=1)
+    ref = {0: ACTS[act](c), 1: ACTS[act](c + r), 2: ACTS[act](c) + r}[res_mode]
+    y = ops.conv2d(_nhwc(x).to(dev), w, b, act=act, slope=0.05,
+                   res=_nhwc(r).to(dev) if res_mode else None, res_mode=res_mode)
+    _check(y, ref)
+
+
+def test_conv_8wave_split_store_and_shuffle():
+    """the 8-wave variant through the IMDBlock split store and the PixelShuffle(4) tail"""
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(23)
+    n, h, wd = 6, 160, 144
+    assert _block_waves(n, h, wd, 48, 64) == 8 and _block_waves(n, h, wd, 64, 48) == 8
+    big = torch.randn(n, 64, h, wd, generator=g)
+    w = torch.randn(64, 48, 3, 3, generator=g) * 0.1
+    b = torch.randn(64, generator=g)
+    ref = F.leaky_relu(F.conv2d(big[:, 16:], w, b, padding=1), 0.05)
+    cat = torch.full((n, h, wd, 64), 7.0, device=dev)
+    rem = torch.full((n, h, wd, 48), 9.0, device=dev)
+    ops.conv2d(_nhwc(big).to(dev), w, b, act=1, in_coff=16, cin=48, split=16, out=cat, out_coff=32, out1=rem, out1_coff=0)
+    cat_c, rem_c = cat.cpu(), rem.cpu()
+    assert torch.all(cat_c[..., :32] == 7.0) and torch.all(cat_c[..., 48:] == 7.0)
+    _check(cat_c[..., 32:48], ref[:, :16])
+    _check(rem_c, ref[:, 16:])
+    wt = torch.randn(48, 64, 3, 3, generator=g) * 0.1
+    bt = torch.randn(48, generator=g)
+    ref = F.pixel_shuffle(F.conv2d(big, wt, bt, padding=1), 4)
+    y = ops.conv2d(_nhwc(big).to(dev), wt, bt, shuffle_out=True).cpu()
+    assert float((y - ref).abs().max()) / max(1.0, float(ref.abs().max())) < 2e-5

@@ -97,8 +97,13 @@ __global__ __launch_bounds__(256) void esa_apply_kernel(const EsaK p)
     __syncthreads();
     const int g = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const long long npix = (long long)p.N * p.H * p.W;
-    const long long pix = min((long long)blockIdx.x * 16 + pl, npix - 1);       // clamp: every lane takes part in the exchange
-    const bool live = (long long)blockIdx.x * 16 + pl < npix && g * 4 < p.Cp4;
+    const long long ngroups = (npix + 15) / 16;
+    // grid-stride over groups of 16 pixels: the 4.3 KB of weights above are fetched once per block, not once per 16
+    // pixels.  The 16 lanes of a pixel sit in one wave and sx[pl] is private to them, so the exchange needs no block
+    // barrier: LDS runs a wave's accesses in order, the fences only pin the compiler.
+    for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const long long pix = min(grp * 16 + pl, npix - 1);                         // clamp: every lane takes part in the exchange
+    const bool live = grp * 16 + pl < npix && g * 4 < p.Cp4;
     const int ox = (int)(pix % p.W);
     const int oy = (int)((pix / p.W) % p.H);
     const int n = (int)(pix / ((long long)p.W * p.H));
@@ -126,9 +131,12 @@ __global__ __launch_bounds__(256) void esa_apply_kernel(const EsaK p)
         sg = fmaf(cv.z, sm[(iq * 4 + 2) * FP + g], sg);
         sg = fmaf(cv.w, sm[(iq * 4 + 3) * FP + g], sg);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     sx[pl * FP + g] = sg;
-    __syncthreads();
-    if (!live) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!live) continue;
     // conv4 for this lane's 4 channels, sigmoid, multiply
     const float* w4 = sm + nwf;
     f32x4 m = *reinterpret_cast<const f32x4*>(w4 + FP * p.cp + g * 4);
@@ -147,6 +155,7 @@ __global__ __launch_bounds__(256) void esa_apply_kernel(const EsaK p)
     o.z = xv.z * (1.f / (1.f + expf(-m.z)));
     o.w = xv.w * (1.f / (1.f + expf(-m.w)));
     *reinterpret_cast<f32x4*>(p.y + (size_t)pix * p.y_pitch + p.y_coff + g * 4) = o;
+    }
 }
 
 // ---- depthwise 3x3, zero padding, fused residual / activation -------------------------------------
@@ -377,7 +386,9 @@ int esr_esa_apply_f32(const esr_esa_desc* d, void* hip_stream)
     k.sw = (float)d->w_lo / (float)d->w;
     const long long npix = (long long)d->n * d->h * d->w;
     const size_t lds = ((size_t)FP * FP + FP + (((size_t)FP * cp4 + cp4 + 3) & ~(size_t)3) + 16 * FP) * sizeof(float);
-    hipLaunchKernelGGL(esa_apply_kernel, dim3((unsigned)((npix + 15) / 16)), dim3(256), lds, static_cast<hipStream_t>(hip_stream), k);
+    const long long ngroups = (npix + 15) / 16;
+    const unsigned grid = (unsigned)(ngroups < 8192 ? ngroups : 8192);        // 256 CUs x 8 blocks x 4 rounds
+    hipLaunchKernelGGL(esa_apply_kernel, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(hip_stream), k);
     return esr_check_launch("esa_apply_kernel launch");
 }
 

@@ -1,7 +1,7 @@
 """RFDN (x4) on the HIP engine -- drop-in for `models.rfdn_baseline.RFDN.RFDN` (RFDN.py:11-41; ids 0, 6, 22).
 
 Same constructor keywords and the same 128 state_dict keys.  nf=50 lives in NHWC buffers of pitch 56 (six
-zero pad channels); the 25-channel distilled maps are stored as 28-wide slices of one 112-wide concat buffer
+zero pad channels); the 25-channel distilled maps are stored as 32-wide (one 128-byte line) slices of one 128-wide concat buffer
 and the four block outputs as 56-wide slices of one 224-wide buffer, so neither torch.cat
 (rfdn_baseline/block.py:163, RFDN.py:36) exists as a kernel: the following 1x1 convs are packed with a
 `cin_map` that skips the pad slots.  Per RFDB (block.py:148-166): {1x1 distil + LeakyReLU, 3x3 + input
@@ -27,7 +27,9 @@ class RFDN(HipSRModel):
         self.f = nf // 4
         self.scale_idx = 0
         nf, dc, f = self.nf, self.dc, self.f
-        self.P, self.DP = _pad8(nf), (dc + 3) // 4 * 4
+        # distilled slices are padded to whole 128-byte lines: a 1x1 writing a 112-byte slice of every 448 bytes costs
+        # 17 % more time than one writing 128 of every 512 (partial-line writes), the wider c5 read costs 5 %
+        self.P, self.DP = _pad8(nf), (dc + 31) // 32 * 32
         cp4 = (nf + 3) // 4 * 4
         self._add_conv('fea_conv', in_nc, nf, 3)
         for k in range(1, 5):

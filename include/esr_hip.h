@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESR_ABI_VERSION 2
+#define ESR_ABI_VERSION 3
 
 typedef enum esr_status {
     ESR_OK = 0,
@@ -94,6 +94,19 @@ typedef struct esr_conv_desc {
     const void* wpacked;        /* device pointer to esr_pack_conv_f32 (or esr_pack_conv_h16) output */
     int32_t compute;            /* esr_compute; 0 = fp32 */
     int32_t reserved;
+    /* ABI v3 -- optional fused 1x1 tail: the 3x3 result (cout <= 16, after `tail_mid_act`) never goes to memory; it is
+     * the LAST 16 input channels of a 1x1 convolution whose first `tail_cat_c` input channels are read from `tail_cat`:
+     *     y = W1x1 . concat(tail_cat[0:tail_cat_c), mid_act(conv3x3(in))) + b1x1
+     * and act / res / res_mode / split / out0 / out1 above then describe the epilogue of THAT 1x1 (`tail_cout` output
+     * channels).  This is IMDBlock's conv4 -> cat -> conv1x1 -> + x (models/basicblock.py:263-265) in one kernel.
+     * tail_wpacked = esr_pack_conv_f32 of the 1x1 (cin = tail_cat_c + 16, ksize 1); NULL = no tail.
+     * Supported: ksize 3, NHWC in/out, cout <= 16, tail_cat_c a multiple of 16, 48 < tail_cout <= 64, fp32. */
+    const void* tail_wpacked;
+    esr_view tail_cat;
+    int32_t tail_cat_c;
+    int32_t tail_cout;
+    int32_t tail_mid_act;       /* esr_act applied to the 3x3 result before the 1x1 (slope = `slope`) */
+    int32_t reserved2;
 } esr_conv_desc;
 
 /* Host-side weight packer (the K10 "weight packer" of SURVEY 7.2): OIHW fp32 (the layout of every

@@ -36,6 +36,9 @@ class ConvDesc(ctypes.Structure):
         ("inp", View), ("res", View), ("out0", View), ("out1", View),
         ("wpacked", ctypes.c_void_p),
         ("compute", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("tail_wpacked", ctypes.c_void_p), ("tail_cat", View),
+        ("tail_cat_c", ctypes.c_int32), ("tail_cout", ctypes.c_int32),
+        ("tail_mid_act", ctypes.c_int32), ("reserved2", ctypes.c_int32),
     ]
 
 
@@ -127,7 +130,7 @@ def lib():
     L.esr_prof_collect.restype = ci
     L.esr_prof_destroy.argtypes = [vp]
     L.esr_prof_destroy.restype = None
-    if L.esr_abi_version() != 2:
+    if L.esr_abi_version() != 3:
         raise EsrError("libesr_hip.so ABI version mismatch")
     _lib = L
     return L

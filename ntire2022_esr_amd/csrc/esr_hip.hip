@@ -58,6 +58,12 @@ struct ConvK {
     int res_mode;
     int out_layout;
     int tiles_x, tiles_y;
+    // fused 1x1 tail (TNT > 0 kernels): see esr_conv_desc.tail_*
+    const float* wp2;     // packed 1x1 weights ([chunk of 8][tile][lane][2]) followed by its bias
+    const float* bias2;
+    const float* cat;     // first `cat_chunks`*16 input channels of the 1x1
+    int cat_pitch, cat_coff, cat_chunks;
+    int mid_act;
 #ifdef ESR_EXPERIMENTAL_WS
     int hand_rows;        // accumulator rows (of 4) finished by the loader partner
 #endif
@@ -245,9 +251,17 @@ __device__ __forceinline__ void epilogue_shuffle(const ConvK& p, f32x4 (&acc)[NT
 // ---- the kernel -------------------------------------------------------------------------------------
 // Persistent over tiles: block b walks tiles b, b+G, b+2G, ... (XCD-aware order) and the last K chunk of
 // tile i stages chunk 0 of tile i+1, so only the very first tile of a block pays a prologue.
-template <int NT, int KS, bool IN_NCHW, int NW>
+// TNT > 0: fused 1x1 tail (IMDBlock conv4 -> cat -> conv1x1 -> + x, basicblock.py:263-265).  The D fragment of the 3x3
+// (lane (px, kq): channels 4kq..4kq+3 of pixel px) IS a B fragment of a 16-channel K chunk of the following 1x1, so the
+// 3x3 result goes from accumulator registers straight into the second GEMM; the other K chunks of the 1x1 are read from
+// the concat buffer as B fragments (16 bytes per lane, requested a whole chunk ahead), its weights sit in LDS for the
+// life of the block ([16-channel chunk][tile][lane][4]) and its result takes the ordinary epilogue.
+constexpr int TAIL_C16 = 4;                           // K of the 1x1 <= 64
+
+template <int NT, int KS, bool IN_NCHW, int NW, int TNT = 0>
 __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
 {
+    static_assert(TNT == 0 || (NT == 1 && KS == 3 && !IN_NCHW && NW == 4), "tail: 3x3, <= 16 channels, 4-wave blocks");
     constexpr int THREADS = 64 * NW;                  // shadows the file-scope constant: NW waves of 4 rows each
     constexpr int TILE_H = 4 * NW;
     constexpr int HALO = KS / 2;
@@ -264,7 +278,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
     constexpr int W_ROUNDS = (W_ITEMS + THREADS - 1) / THREADS;
     constexpr unsigned OOB = 0x80000000u;             // > any per-image byte offset (host checks < 2 GiB)
 
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + NW * EPI_WAVE_FLOATS * 4];
+    constexpr int TAIL_FLOATS = TNT ? TAIL_C16 * TNT * 256 + TNT * 16 : 0;     // 1x1 weight image + bias
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + NW * EPI_WAVE_FLOATS * 4 + TAIL_FLOATS * 4];
 
     // Issue priority: everything that is not the MFMA stream (staging, barrier, epilogue: a handful of
     // instructions per 288 MFMAs) runs at raised priority so it is issued ahead of the SIMD partner's stream.
@@ -404,6 +419,23 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) biasv[tt] = *reinterpret_cast<const f32x4*>(p.bias + tt * 16 + kq * 4);
 
+    float* const wl = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES + NW * EPI_WAVE_FLOATS * 4);
+    if (TNT) {
+        // blob order in, (chunk16, tile, lane, j) order out: float4 q = elements (i, j'=0), (i, 1), (i+1, 0), (i+1, 1) of one
+        // (chunk8, tile, kq'); channel 8*chunk8 + 2kq' + j' -> chunk16 = chunk8/2, slot (ch16 >> 2), j = ch16 & 3
+        const int nch8 = 2 * (p.cat_chunks + 1);
+        for (int q = tid; q < nch8 * TNT * 32; q += THREADS) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.wp2 + (size_t)q * 4);
+            const int ip = q & 7, kq8 = (q >> 3) & 3, ct = q >> 5;
+            const int tt = ct % TNT, chunk8 = ct / TNT;
+            const int ch16 = 8 * (chunk8 & 1) + 2 * kq8;
+            float* dst = wl + (((chunk8 >> 1) * TNT + tt) * 64 + (ch16 >> 2) * 16 + 2 * ip) * 4 + (ch16 & 3);
+            dst[0] = v.x; dst[1] = v.y; dst[4] = v.z; dst[5] = v.w;
+        }
+        if (tid < TNT * 16) wl[TAIL_C16 * TNT * 256 + tid] = p.bias2[tid];
+    }
+    const size_t cat_img_floats = (size_t)p.H * p.W * p.cat_pitch;
+
     setup_tile(t, cur);
     int tn = tile_index(1);
     if (tn >= 0) setup_tile(tn, nxt);
@@ -428,8 +460,23 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[tt][r] = biasv[tt];
 
+        f32x4 bc[TNT ? TAIL_C16 - 1 : 1][4];            // tail: B fragments of the concat part of the 1x1
         for (int c = 0; c < p.nchunks; ++c) {
             const bool more = c + 1 < p.nchunks;
+            if (TNT && !more) {
+                // requested a whole chunk before use, and BEFORE this chunk's weight DMA / input requests so that the
+                // counted vmcnt of stage_barrier() still sees the input loads as the newest
+                const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(p.cat + (size_t)cur.n * cat_img_floats), 0, (int)(cat_img_floats * 4), 0x00020000);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gy = cur.y0 + wv * 4 + r, gx = cur.x0 + px;
+                    const unsigned vo = (gy < p.H && gx < p.W) ? (unsigned)((gy * p.W + gx) * p.cat_pitch + p.cat_coff + 4 * kq) * 4u : OOB;
+#pragma unroll
+                    for (int C = 0; C < TAIL_C16 - 1; ++C)
+                        if (C < p.cat_chunks) bc[C][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(crsrc, vo, C * 64, 0));
+                }
+            }
             // 8-wave blocks: the two waves of a SIMD belong to the same block and would stage (and then compete for the
             // MFMA pipe) in lockstep.  Waves 0-3 therefore do all their staging at the top of the chunk, waves 4-7 in the
             // middle of it; needs nchunks >= 2 so that the input of the next stage is always already in flight.
@@ -493,7 +540,38 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
             sbuf ^= 1;
         }
 
-        if (p.out_layout == ESR_NCHW_SHUFFLE4) epilogue_shuffle<NT>(p, acc, cur.n, cur.x0, cur.y0, wv, lane);
+        if (TNT) {
+            // second GEMM: K = concat chunks (from global, requested at the top of the last chunk) + the 3x3 result
+            f32x4 acc2[TNT ? TNT : 1][4];
+#pragma unroll
+            for (int tt = 0; tt < TNT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc2[tt][r] = *reinterpret_cast<const f32x4*>(wl + TAIL_C16 * TNT * 256 + tt * 16 + kq * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x4 v = acc[0][r];
+                v.x = act_any(v.x, p.mid_act, p.slope); v.y = act_any(v.y, p.mid_act, p.slope);
+                v.z = act_any(v.z, p.mid_act, p.slope); v.w = act_any(v.w, p.mid_act, p.slope);
+                acc[0][r] = v;
+            }
+            auto tail_chunk = [&](int C, const f32x4 (&bf)[4]) {
+                f32x4 a2[TNT ? TNT : 1];
+#pragma unroll
+                for (int tt = 0; tt < TNT; ++tt) a2[tt] = *reinterpret_cast<const f32x4*>(wl + ((C * TNT + tt) * 64 + lane) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int tt = 0; tt < TNT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc2[tt][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tt][j], bf[r][j], acc2[tt][r], 0, 0, 0);
+            };
+#pragma unroll
+            for (int C = 0; C < TAIL_C16 - 1; ++C)
+                if (C < p.cat_chunks) tail_chunk(C, bc[C]);
+            tail_chunk(p.cat_chunks, acc[0]);
+            epilogue_nhwc<(TNT ? TNT : 1)>(p, acc2, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE_H);
+        } else if (p.out_layout == ESR_NCHW_SHUFFLE4) epilogue_shuffle<NT>(p, acc, cur.n, cur.x0, cur.y0, wv, lane);
         else epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE_H);
         if (!has_next) break;
         cur = nxt;
@@ -749,6 +827,19 @@ int launch_conv(const ConvK& k, hipStream_t st)
     return ESR_OK;
 }
 
+int launch_conv_tail(const ConvK& k, hipStream_t st)
+{
+    const int ntiles = k.N * k.tiles_x * k.tiles_y;
+    const int grid = ntiles < MAX_RESIDENT_BLOCKS ? ntiles : MAX_RESIDENT_BLOCKS;
+    hipLaunchKernelGGL((conv_f32_kernel<1, 3, false, 4, 4>), dim3(grid), dim3(THREADS), 0, st, k);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_err("conv_f32_kernel (1x1 tail) launch", e);
+        return ESR_ERR_LAUNCH;
+    }
+    return ESR_OK;
+}
+
 #ifdef ESR_EXPERIMENTAL_WS
 template <int NT>
 int launch_conv_ws(const ConvK& k, hipStream_t st)
@@ -989,12 +1080,22 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
     if (!in_nchw && ((d->in.pitch & 3) || (d->in.coff & 3))) return ESR_ERR_BAD_ARG;
     const int cin_phys = in_nchw ? CHUNK : round_up(d->cin, CHUNK);
     if (!in_nchw && d->in.coff + cin_phys > d->in.pitch) return ESR_ERR_BAD_ARG;   // chunk reads stay inside the pixel
-    const int cout4 = round_up(d->cout, 4);
+    // fused 1x1 tail: the epilogue fields describe the 1x1's output
+    const bool tail = d->tail_wpacked != nullptr;
+    if (tail) {
+        if (d->ksize != 3 || in_nchw || d->out_layout != ESR_NHWC || d->cout > 16 || d->compute != ESR_COMPUTE_F32) return ESR_ERR_UNSUPPORTED;
+        if (d->tail_cat_c <= 0 || (d->tail_cat_c & 15) || d->tail_cat_c + 16 > 16 * TAIL_C16) return ESR_ERR_UNSUPPORTED;
+        if (d->tail_cout <= 48 || d->tail_cout > 64) return ESR_ERR_UNSUPPORTED;
+        if (!d->tail_cat.ptr || (d->tail_cat.pitch & 3) || (d->tail_cat.coff & 3) || d->tail_cat.coff + d->tail_cat_c > d->tail_cat.pitch)
+            return ESR_ERR_BAD_ARG;
+    }
+    const int ecout = tail ? d->tail_cout : d->cout;          // channels the epilogue stores
+    const int cout4 = round_up(ecout, 4);
     int split = d->split <= 0 ? cout4 : d->split;
-    if (split >= d->cout) split = cout4;
+    if (split >= ecout) split = cout4;
     if (split & 3) return ESR_ERR_BAD_ARG;
     if (d->out_layout == ESR_NCHW_SHUFFLE4) {
-        if (d->cout % 16) return ESR_ERR_UNSUPPORTED;
+        if (ecout % 16) return ESR_ERR_UNSUPPORTED;
     } else if (d->out_layout == ESR_NHWC) {
         if ((d->out0.pitch & 3) || (d->out0.coff & 3) || d->out0.coff + split > d->out0.pitch) return ESR_ERR_BAD_ARG;
         if (split < cout4) {
@@ -1046,7 +1147,21 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
     k.out_layout = d->out_layout;
     k.tiles_x = (d->w + TILE - 1) / TILE;
     k.tiles_y = (d->h + TILE - 1) / TILE;
+    k.wp2 = nullptr; k.bias2 = nullptr; k.cat = nullptr; k.cat_pitch = k.cat_coff = k.cat_chunks = 0; k.mid_act = ESR_ACT_NONE;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (tail) {
+        k.wp2 = static_cast<const float*>(d->tail_wpacked);
+        k.cat_chunks = d->tail_cat_c / 16;
+        k.bias2 = k.wp2 + (size_t)(2 * (k.cat_chunks + 1)) * 4 * 128;       // [chunk of 8][tap = 1][4 tiles][128]
+        k.cat = static_cast<const float*>(d->tail_cat.ptr);
+        k.cat_pitch = d->tail_cat.pitch; k.cat_coff = d->tail_cat.coff;
+        k.mid_act = d->tail_mid_act;
+        {
+            const double px_all = (double)d->n * d->h * d->w;
+            if (px_all * d->tail_cat.pitch >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
+        }
+        return launch_conv_tail(k, st);
+    }
     if (h16) return d->compute == ESR_COMPUTE_BF16 ? launch_h16_nt<true>(nt, k, st) : launch_h16_nt<false>(nt, k, st);
     if (in_nchw) return launch_conv_nt<3, true>(nt, k, st);
     if (d->ksize == 3) return launch_conv_nt<3, false>(nt, k, st);

@@ -151,11 +151,13 @@ class Plan:
         return b
 
     def conv(self, wname, src, dst, cin, cout, k=3, act=L.ACT_NONE, slope=0.05,
-             res=None, res_mode=L.RES_NONE, dst1=None, split=0, hw=None, counted=True):
+             res=None, res_mode=L.RES_NONE, dst1=None, split=0, hw=None, counted=True, tail=None):
         """src/dst/res: INPUT | OUTPUT | Buffer | (Buffer, coff, channels).  hw: spatial dims if not full-res.
-        counted=False marks launches that are not an nn.Conv2d call of the reference (complexity counters)."""
+        counted=False marks launches that are not an nn.Conv2d call of the reference (complexity counters).
+        tail = dict(w=<1x1 weight name>, cat=<view of its other input channels>, cat_c, cout, mid_act): the 3x3 result
+        (cout <= 16) feeds a fused 1x1 (esr_conv_desc.tail_*); dst/res/act/split then belong to the 1x1."""
         self.ops.append(dict(kind="conv", w=wname, src=src, dst=dst, dst1=dst1, cin=cin, cout=cout, k=k, act=act,
-                             slope=slope, res=res, res_mode=res_mode, split=split, hw=hw, counted=counted))
+                             slope=slope, res=res, res_mode=res_mode, split=split, hw=hw, counted=counted, tail=tail))
 
     def dwconv(self, wname, src, dst, c, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.RES_NONE, hw=None):
         """depthwise 3x3 + bias (+res) (+act): the dw half of BSConvU."""
@@ -237,6 +239,11 @@ class Plan:
                 d.compute = compute
             else:
                 d.wpacked = ctypes.c_void_p(weights[o["w"]].data_ptr())
+            t = o.get("tail")
+            if t is not None:
+                d.tail_wpacked = ctypes.c_void_p(weights[t["w"]].data_ptr())
+                d.tail_cat = self._view(t["cat"], base)
+                d.tail_cat_c, d.tail_cout, d.tail_mid_act = t["cat_c"], t["cout"], t.get("mid_act", L.ACT_NONE)
         return arr, in_idx, out_idx
 
 
@@ -302,7 +309,8 @@ class HipSRModel(nn.Module):
         return self
 
     def _uses_h16(self, o):
-        return self.compute != "f32" and o["kind"] == "conv" and o["k"] == 3 and o["hw"] is None and o["src"] is not INPUT
+        return (self.compute != "f32" and o["kind"] == "conv" and o["k"] == 3 and o["hw"] is None and o["src"] is not INPUT
+                and o.get("tail") is None)        # the fused 3x3 -> 1x1 kernel exists for fp32 MFMA operands only
 
     # -- packing ------------------------------------------------------------------------------
     def _signature(self):
@@ -411,10 +419,18 @@ class HipSRModel(nn.Module):
                 npix = plan.npix if o["hw"] is None else plan.n * o["hw"][0] * o["hw"][1]
                 # algorithmic HBM bytes: input slice + residual + weights read once, output written once (fp32 storage)
                 rd = 4.0 * (npix * (o["cin"] + (o["cout"] if o["res"] is not None else 0)) + o["cin"] * o["cout"] * o["k"] ** 2)
-                out.append(dict(name=o["w"], kernel=kern, cin=o["cin"], cout=o["cout"], k=o["k"],
-                                flops=2.0 * npix * o["cin"] * o["cout"] * o["k"] * o["k"],
-                                read_bytes=rd, write_bytes=4.0 * npix * o["cout"],
-                                ms_sum=ms[i], passes=passes.value))
+                flops = 2.0 * npix * o["cin"] * o["cout"] * o["k"] * o["k"]
+                wr = 4.0 * npix * o["cout"]
+                t = o.get("tail")
+                if t is not None:                   # 3x3 -> 1x1 in one kernel: both GEMMs' flops, the 1x1's traffic
+                    kern = f"conv_f32_kernel<NT={nt},KS=3,NCHW_IN=0,NW=4,TAIL={(t['cout'] + 15) // 16}>"
+                    k1 = t["cat_c"] + o["cout"]
+                    flops += 2.0 * npix * k1 * t["cout"]
+                    rd = 4.0 * (npix * (o["cin"] + t["cat_c"] + (t["cout"] if o["res"] is not None else 0))
+                                + o["cin"] * o["cout"] * 9 + k1 * t["cout"])
+                    wr = 4.0 * npix * t["cout"]
+                out.append(dict(name=o["w"], kernel=kern, cin=o["cin"], cout=o["cout"], k=o["k"], flops=flops,
+                                read_bytes=rd, write_bytes=wr, ms_sum=ms[i], passes=passes.value))
         return out
 
     def _complexity_terms(self, plan, o):
@@ -435,6 +451,10 @@ class HipSRModel(nn.Module):
             if not o.get("counted", True):
                 return []
             npix = plan.npix if o["hw"] is None else plan.n * o["hw"][0] * o["hw"][1]
+            t = o.get("tail")
+            if t is not None:                       # two nn.Conv2d calls of the reference in one launch
+                return [(o["cin"], o["cout"], o["k"], npix, t.get("mid_act", L.ACT_NONE)),
+                        (t["cat_c"] + o["cout"], t["cout"], 1, npix, o["act"])]
             return [(o["cin"], o["cout"], o["k"], npix, o["act"])]
         if o["kind"] == "s2":
             return [(o["f"], o["f"], 3, plan.n * o["dst"].h * o["dst"].w, L.ACT_NONE)]

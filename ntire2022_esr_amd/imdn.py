@@ -5,13 +5,13 @@ Same constructor keywords (models/imdn_baseline.py:33) and the same 86 state_dic
 `model.2.*`) so `load_state_dict(torch.load('model_zoo/imdn_baseline.pth'), strict=True)`
 (test_demo.py:22-23; id 26 = nb 7, test_demo.py:203-209) works unchanged.
 
-Forward = 3 + 5*nb kernel launches, no split/cat/add kernels:
+Forward = 3 + 4*nb kernel launches (3 + 5*nb when nc != 64), no split/cat/add kernels:
   head     3->nc        NCHW in, NHWC out (FEA, kept for the global shortcut)
   block i  conv1 nc->nc  LReLU, split store: [0,d) -> CAT[0:d),   [d,nc) -> R1      basicblock.py:260
            conv2 r->nc   LReLU, split store:        CAT[d:2d),            R2        :261
            conv3 r->nc   LReLU, split store:        CAT[2d:3d),           R1        :262
-           conv4 r->d    no act                     CAT[3d:4d)                      :263
-           1x1  4d->nc   + block input (residual)   -> ping-pong X                  :264-265
+           conv4 r->d    no act                     (accumulators only)             :263
+           1x1  4d->nc   + block input (residual)   -> ping-pong X   same launch    :264-265
   tail     nc->nc 3x3 + FEA (ShortcutBlock, basicblock.py:197-199)
   up       nc->out_nc*16 3x3 fused with PixelShuffle(4) -> NCHW output             basicblock.py:446-449
 """
@@ -61,8 +61,14 @@ class IMDN(HipSRModel):
             plan.conv(p + 'conv1.0', cur, cat[0:d], nc, nc, split=d, dst1=r1, **act)
             plan.conv(p + 'conv2.0', r1, cat[d:2 * d], r, nc, split=d, dst1=r2, **act)
             plan.conv(p + 'conv3.0', r2, cat[2 * d:3 * d], r, nc, split=d, dst1=r1, **act)
-            plan.conv(p + 'conv4', r1, cat[3 * d:4 * d], r, d)
-            plan.conv(p + 'conv1x1', cat, nxt, 4 * d, nc, k=1, res=cur, res_mode=L.RES_PRE_ACT)
+            if d == 16 and 48 < nc <= 64:
+                # conv4 -> cat -> conv1x1 -> + x in one kernel: the 16 conv4 channels go from the 3x3's accumulators
+                # straight into the 1x1's K loop and never reach memory
+                plan.conv(p + 'conv4', r1, nxt, r, d, res=cur, res_mode=L.RES_PRE_ACT,
+                          tail=dict(w=p + 'conv1x1', cat=cat[0:3 * d], cat_c=3 * d, cout=nc))
+            else:
+                plan.conv(p + 'conv4', r1, cat[3 * d:4 * d], r, d)
+                plan.conv(p + 'conv1x1', cat, nxt, 4 * d, nc, k=1, res=cur, res_mode=L.RES_PRE_ACT)
             cur = nxt
             nxt = xb if cur is xa else xa
         plan.conv(f'model.1.sub.{self.nb}', cur, nxt, nc, nc, res=fea, res_mode=L.RES_PRE_ACT)

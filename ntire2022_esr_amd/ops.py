@@ -16,11 +16,14 @@ def _view(t, coff=0):
 
 def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.RES_NONE,
            in_nchw=False, shuffle_out=False, out=None, out_coff=0, in_coff=0, cin=None,
-           split=0, out1=None, out1_coff=0, res_coff=0, packed=None, cin_map=None, compute="f32"):
+           split=0, out1=None, out1_coff=0, res_coff=0, packed=None, cin_map=None, compute="f32",
+           tail_weight=None, tail_bias=None, tail_cat=None, tail_cat_coff=0, tail_mid_act=L.ACT_NONE):
     """Fused conv (k=1|3, stride 1, same padding) on the current stream.
 
     x       NHWC [N,H,W,pitch] (channels [in_coff, in_coff+cin) are read) or NCHW if in_nchw
     returns NHWC [N,H,W,cout] (or `out`), or NCHW [N,cout/16,4H,4W] if shuffle_out
+    tail_*  fused 1x1 (esr_conv_desc.tail_*): tail_weight [cout1, cat_c + 16(, 1, 1)] over concat(tail_cat slice,
+            mid_act(this 3x3 conv)); act / res / out then apply to the 1x1, whose output is returned
     """
     if not x.is_cuda:
         raise L.EsrError("conv2d: tensors must live on the GPU; there is no CPU fallback")
@@ -41,6 +44,14 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
         d.in_layout = L.NHWC
         d.inp = _view(x, in_coff)
     d.n, d.h, d.w, d.cin, d.cout, d.ksize = n, h, w, cin, cout, k
+    keep = None
+    if tail_weight is not None:
+        tw = tail_weight if tail_weight.dim() == 4 else tail_weight[:, :, None, None]
+        keep = pack_conv(tw, tail_bias).to(x.device)
+        d.tail_wpacked = ctypes.c_void_p(keep.data_ptr())
+        d.tail_cat = _view(tail_cat, tail_cat_coff)
+        d.tail_cat_c, d.tail_cout, d.tail_mid_act = tw.shape[1] - 16, tw.shape[0], tail_mid_act
+        cout = tw.shape[0]                      # what the epilogue stores
     d.act, d.slope, d.res_mode, d.split = act, slope, res_mode, split
     d.compute = L.COMPUTE[compute]
     if shuffle_out:

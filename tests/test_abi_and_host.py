@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libesr_hip.so does not export {s}"
     assert set(L.EXPORTS) == set(syms), (set(L.EXPORTS) ^ set(syms))
-    assert lib.esr_abi_version() == 2
+    assert lib.esr_abi_version() == 3
     assert b"gfx950" in lib.esr_build_info()
 
 
@@ -113,17 +113,22 @@ def test_module_surface_and_no_cpu_fallback():
 
 
 def test_imdn_plan_shape():
-    """The op list is 3 + 5*nb launches and its workspace matches the documented layout."""
+    """The op list is 3 + 4*nb launches (conv4 and the 1x1 share one) and its workspace matches the documented layout."""
     from ntire2022_esr_amd import IMDN
     from ntire2022_esr_amd.engine import Plan
     m = IMDN()
     plan = Plan(2, 40, 56)
     m._build_plan(plan, 3)
-    assert len(plan.ops) == 3 + 5 * 8
+    assert len(plan.ops) == 3 + 4 * 8
+    assert sum(o.get("tail") is not None for o in plan.ops) == 8
     assert plan.total == 2 * 40 * 56 * (64 * 4 + 48 * 2)
     assert m.workspace_bytes(2, 40, 56) == plan.total * 4
-    total_macs = sum(o["cin"] * o["cout"] * o["k"] ** 2 for o in plan.ops)
+    total_macs = sum(cin * cout * k * k for o in plan.ops for (cin, cout, k, _, _) in m._counted_convs(plan, o))
     assert total_macs == 891584                                                # SURVEY 8d: MAC per LR pixel
+    m48 = IMDN(nc=48)                                                          # no 16-channel distillation: unfused
+    plan = Plan(1, 40, 56)
+    m48._build_plan(plan, 3)
+    assert len(plan.ops) == 3 + 5 * 8 and all(o.get("tail") is None for o in plan.ops)
 
 
 def test_h16_packer_layout_and_rounding():

@@ -179,3 +179,43 @@ def test_conv_8wave_split_store_and_shuffle():
     ref = F.pixel_shuffle(F.conv2d(big, wt, bt, padding=1), 4)
     y = ops.conv2d(_nhwc(big).to(dev), wt, bt, shuffle_out=True).cpu()
     assert float((y - ref).abs().max()) / max(1.0, float(ref.abs().max())) < 2e-5
+
+
+@pytest.mark.parametrize("n,hw", [(1, (16, 16)), (2, (37, 45)), (3, (130, 96))])
+@pytest.mark.parametrize("mid_act,res_mode,cat_c", [(0, 1, 48), (1, 0, 48), (0, 2, 32)])
+def test_conv3x3_with_fused_1x1_tail(n, hw, mid_act, res_mode, cat_c):
+    """esr_conv_desc.tail_*: IMDBlock's conv4 -> cat -> conv1x1 -> + x (basicblock.py:263-265) in one launch, against
+    the three ATen ops; the concat part is a channel slice of a wider buffer."""
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(n + hw[0] + 5 * mid_act + res_mode + cat_c)
+    x = torch.randn(n, 48, *hw, generator=g)
+    cat = torch.randn(n, 64, *hw, generator=g)                    # channels [8, 8 + cat_c) are the 1x1's other inputs
+    r = torch.randn(n, 64, *hw, generator=g)
+    w3 = torch.randn(16, 48, 3, 3, generator=g) * 0.1
+    b3 = torch.randn(16, generator=g)
+    w1 = torch.randn(64, cat_c + 16, 1, 1, generator=g) * 0.1
+    b1 = torch.randn(64, generator=g)
+    c4 = ACTS[mid_act](F.conv2d(x, w3, b3, padding=1))
+    y1 = F.conv2d(torch.cat([cat[:, 8:8 + cat_c], c4], 1), w1, b1)
+    ref = {0: y1, 1: y1 + r, 2: F.leaky_relu(y1, 0.05) + r}[res_mode]
+    y = ops.conv2d(_nhwc(x).to(dev), w3, b3, act=1 if res_mode == 2 else 0, slope=0.05,
+                   res=_nhwc(r).to(dev) if res_mode else None, res_mode=res_mode,
+                   tail_weight=w1, tail_bias=b1, tail_cat=_nhwc(cat).to(dev), tail_cat_coff=8, tail_mid_act=mid_act)
+    assert y.shape[-1] == 64
+    _check(y, ref)
+
+
+def test_fused_tail_argument_checks():
+    import ctypes
+    from ntire2022_esr_amd import _lib as L
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    x = torch.randn(1, 8, 8, 48, device=dev)
+    cat = torch.randn(1, 8, 8, 64, device=dev)
+    w3, b3 = torch.randn(32, 48, 3, 3), torch.randn(32)            # 3x3 with more than 16 outputs: unsupported
+    with pytest.raises(L.EsrError):
+        ops.conv2d(x, w3, b3, tail_weight=torch.randn(64, 64), tail_bias=torch.randn(64), tail_cat=cat)
+    w3, b3 = torch.randn(16, 48, 3, 3), torch.randn(16)
+    with pytest.raises(L.EsrError):                                 # 1x1 with too few outputs for the 4-tile tail
+        ops.conv2d(x, w3, b3, tail_weight=torch.randn(32, 64), tail_bias=torch.randn(32), tail_cat=cat)

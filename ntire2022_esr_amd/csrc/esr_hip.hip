@@ -565,6 +565,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             acc2[tt][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tt][j], bf[r][j], acc2[tt][r], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);          // one chunk's A fragments at a time (register budget)
             };
 #pragma unroll
             for (int C = 0; C < TAIL_C16 - 1; ++C)

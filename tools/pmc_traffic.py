@@ -25,10 +25,11 @@ def per_kernel(d, counter):
 
 
 def label(sym):
-    m = re.search(r"conv_f32_kernel<(\d+), (\d+), (true|false), (\d+)>", sym)
+    m = re.search(r"conv_f32_kernel<(\d+), (\d+), (true|false), (\d+), (\d+)>", sym)
     if not m:
         return None
-    return f"conv_f32_kernel<NT={m.group(1)},KS={m.group(2)},NCHW_IN={int(m.group(3) == 'true')},NW={m.group(4)}>"
+    base = f"conv_f32_kernel<NT={m.group(1)},KS={m.group(2)},NCHW_IN={int(m.group(3) == 'true')},NW={m.group(4)}"
+    return base + (f",TAIL={m.group(5)}>" if m.group(5) != "0" else ">")
 
 
 def main():

@@ -61,7 +61,7 @@ class IMDN(HipSRModel):
             plan.conv(p + 'conv1.0', cur, cat[0:d], nc, nc, split=d, dst1=r1, **act)
             plan.conv(p + 'conv2.0', r1, cat[d:2 * d], r, nc, split=d, dst1=r2, **act)
             plan.conv(p + 'conv3.0', r2, cat[2 * d:3 * d], r, nc, split=d, dst1=r1, **act)
-            if d == 16 and 48 < nc <= 64:
+            if d == 16 and 48 < nc <= 64 and self.compute == 'f32':      # 16-bit operand modes keep conv4 on the 16-bit kernel
                 # conv4 -> cat -> conv1x1 -> + x in one kernel: the 16 conv4 channels go from the 3x3's accumulators
                 # straight into the 1x1's K loop and never reach memory
                 plan.conv(p + 'conv4', r1, nxt, r, d, res=cur, res_mode=L.RES_PRE_ACT,

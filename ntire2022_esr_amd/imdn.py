@@ -51,7 +51,8 @@ class IMDN(HipSRModel):
         nc, d, r = self.nc, self.d_nc, self.r_nc
         fea = plan.buffer('fea', nc)
         xa, xb = plan.buffer('xa', nc), plan.buffer('xb', nc)
-        cat = plan.buffer('cat', 4 * d)
+        fused = d == 16 and 48 < nc <= 64 and self.compute == 'f32'    # conv4 + 1x1 in one launch (16-bit modes keep conv4 on the 16-bit kernel)
+        cat = plan.buffer('cat', 3 * d if fused else 4 * d)              # fused: conv4's slot never reaches memory
         r1, r2 = plan.buffer('r1', r), plan.buffer('r2', r)
         act = dict(act=self.act, slope=self.slope)
         plan.conv('model.0', INPUT, fea, self.in_nc, nc)
@@ -61,7 +62,7 @@ class IMDN(HipSRModel):
             plan.conv(p + 'conv1.0', cur, cat[0:d], nc, nc, split=d, dst1=r1, **act)
             plan.conv(p + 'conv2.0', r1, cat[d:2 * d], r, nc, split=d, dst1=r2, **act)
             plan.conv(p + 'conv3.0', r2, cat[2 * d:3 * d], r, nc, split=d, dst1=r1, **act)
-            if d == 16 and 48 < nc <= 64 and self.compute == 'f32':      # 16-bit operand modes keep conv4 on the 16-bit kernel
+            if fused:
                 # conv4 -> cat -> conv1x1 -> + x in one kernel: the 16 conv4 channels go from the 3x3's accumulators
                 # straight into the 1x1's K loop and never reach memory
                 plan.conv(p + 'conv4', r1, nxt, r, d, res=cur, res_mode=L.RES_PRE_ACT,

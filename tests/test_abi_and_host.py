@@ -121,7 +121,7 @@ def test_imdn_plan_shape():
     m._build_plan(plan, 3)
     assert len(plan.ops) == 3 + 4 * 8
     assert sum(o.get("tail") is not None for o in plan.ops) == 8
-    assert plan.total == 2 * 40 * 56 * (64 * 4 + 48 * 2)
+    assert plan.total == 2 * 40 * 56 * (64 * 3 + 48 * 3)                      # fea, xa, xb | cat (d1 d2 d3), r1, r2
     assert m.workspace_bytes(2, 40, 56) == plan.total * 4
     total_macs = sum(cin * cout * k * k for o in plan.ops for (cin, cout, k, _, _) in m._counted_convs(plan, o))
     assert total_macs == 891584                                                # MAC per LR pixel

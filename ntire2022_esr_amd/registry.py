@@ -23,6 +23,10 @@ def _entries():
         # free riders: same graphs, own checkpoints (test_demo.py:66-72, 175-181, 203-209)
         6: ("V1", "team06_v1", 1.0, None, lambda: RFDN(in_nc=3, nf=50, num_modules=4, out_nc=3, upscale=4)),
         22: ("RFDN40", "team22_rep_rfdn", 1.0, None, lambda: RFDN(in_nc=3, nf=40, num_modules=4, out_nc=3, upscale=4)),
+        # near riders: the RFDN graph with two switches (test_demo.py:76-82, 302-308)
+        8: ("RFDN", "team08_sfdn", 1.0, None, lambda: RFDN(block_residual=False, esa_conv_f=False)),
+        40: ("RFDNPrune", "team40_rfdn_pruned", 255.0, None,
+             lambda: RFDN(in_nc=3, nf=40, num_modules=4, out_nc=3, upscale=4, block_residual=False, esa_f=12)),
         26: ("IMDN", "team26_imdn_nb7", 1.0, None, lambda: IMDN(in_nc=3, out_nc=3, nc=64, nb=7, upscale=4, act_mode='L',
                                                                 upsample_mode='pixelshuffle')),
         18: ("XPixel", "team18_bsrn", 1.0, None,                                                 # test_demo.py:150-157

@@ -18,13 +18,20 @@ def _slice_map(n_slices, logical, padded):
 
 
 class RFDN(HipSRModel):
-    def __init__(self, in_nc=3, nf=50, num_modules=4, out_nc=3, upscale=4):
+    def __init__(self, in_nc=3, nf=50, num_modules=4, out_nc=3, upscale=4, block_residual=True, esa_f=None,
+                 esa_conv_f=True):
+        """The last three keywords are not in the reference's constructor; they select its two RFDN derivatives
+        (SURVEY 8f N2): `models.team40_rfdn_pruned.RFDN` = RFDN(nf=40, block_residual=False, esa_f=12)
+        (team40_rfdn_pruned.py:148-166 has no `+ input` in the refinement convs, :106 fixes the ESA width at 50 // 4) and
+        `models.team08_sfdn.RFDN` = RFDN(block_residual=False, esa_conv_f=False) (team08_sfdn.py:137-147; its ESA adds
+        conv1's output itself where the baseline adds conv_f of it, :118-129; the checkpoint is re-parameterised)."""
         super().__init__()
         if upscale != 4 or nf > 64 or in_nc > 4 or out_nc * 16 > 64 or num_modules != 4:
             raise NotImplementedError('HIP RFDN supports upscale=4, nf <= 64, 4 modules, in_nc <= 4, out_nc <= 4')
         self.in_nc, self.out_nc, self.nf, self.num_modules, self.upscale = in_nc, out_nc, nf, num_modules, upscale
         self.dc = nf // 2
-        self.f = nf // 4
+        self.f = nf // 4 if esa_f is None else esa_f
+        self.block_residual, self.esa_conv_f = block_residual, esa_conv_f
         self.scale_idx = 0
         nf, dc, f = self.nf, self.dc, self.f
         # distilled slices are padded to whole 128-byte lines: a 1x1 writing a 112-byte slice of every 448 bytes costs
@@ -40,7 +47,8 @@ class RFDN(HipSRModel):
             self._add_conv(b + 'c4', nf, dc, 3)
             self._add_conv(b + 'c5', dc * 4, nf, 1, cin_map=_slice_map(4, dc, self.DP))
             self._add_conv(b + 'esa.conv1', nf, f, 1)
-            self._add_conv(b + 'esa.conv_f', f, f, 1, dense=(FP, FP))
+            if esa_conv_f:
+                self._add_conv(b + 'esa.conv_f', f, f, 1, dense=(FP, FP))
             self._add_conv(b + 'esa.conv_max', f, f, 3)
             self._add_conv(b + 'esa.conv2', f, f, 3, dense=(FP, FP), stride=2, padding=0)
             self._add_conv(b + 'esa.conv3', f, f, 3)
@@ -70,16 +78,17 @@ class RFDN(HipSRModel):
         la, lb = plan.buffer('esa_a', FP, h3, w3), plan.buffer('esa_b', FP, h3, w3)
         act = dict(act=L.ACT_LRELU, slope=0.05)
         lo = dict(hw=(h3, w3))
+        res = (lambda v: dict(res=v, res_mode=L.RES_PRE_ACT)) if self.block_residual else (lambda v: {})
         plan.conv('fea_conv', INPUT, fea, self.in_nc, nf)
         cur = fea
         for k in range(1, 5):
             b = f'B{k}.'
             plan.conv(b + 'c1_d', cur, cat[0:DP], nf, dc, k=1, **act)
-            plan.conv(b + 'c1_r', cur, r1, nf, nf, res=cur, res_mode=L.RES_PRE_ACT, **act)
+            plan.conv(b + 'c1_r', cur, r1, nf, nf, **res(cur), **act)
             plan.conv(b + 'c2_d', r1, cat[DP:2 * DP], nf, dc, k=1, **act)
-            plan.conv(b + 'c2_r', r1, r2, nf, nf, res=r1, res_mode=L.RES_PRE_ACT, **act)
+            plan.conv(b + 'c2_r', r1, r2, nf, nf, **res(r1), **act)
             plan.conv(b + 'c3_d', r2, cat[2 * DP:3 * DP], nf, dc, k=1, **act)
-            plan.conv(b + 'c3_r', r2, r1, nf, nf, res=r2, res_mode=L.RES_PRE_ACT, **act)
+            plan.conv(b + 'c3_r', r2, r1, nf, nf, **res(r2), **act)
             plan.conv(b + 'c4', r1, cat[3 * DP:4 * DP], nf, dc, **act)
             plan.conv(b + 'c5', cat, v, 4 * DP, nf, k=1)
             plan.conv(b + 'esa.conv1', v, c1, nf, f, k=1)
@@ -95,9 +104,18 @@ class RFDN(HipSRModel):
         plan.conv('LR_conv', v, r1, nf, nf, res=fea, res_mode=L.RES_PRE_ACT)
         plan.conv('upsampler.0', r1, OUTPUT, nf, self.out_nc * 16)
 
+    def _extra_pack(self, packed, device):
+        if not self.esa_conv_f:                  # SFDN: c3 + c1_  ==  c3 + conv_f(c1_) with conv_f = identity
+            import torch
+            from .engine import pack_dense
+            for k in range(1, 5):
+                packed[f'B{k}.esa.conv_f'] = pack_dense(torch.eye(self.f)[:, :, None, None], torch.zeros(self.f), FP, FP).to(device)
+
     def _counted_convs(self, plan, o):
         """logical channel counts for the padded-concat 1x1 convs (the reference sees 100 / 200 inputs)."""
         r = super()._counted_convs(plan, o)
+        if o["kind"] == "apply" and not self.esa_conv_f:
+            return r[1:]                         # no conv_f call in the reference graph
         if o["kind"] == "conv" and o["w"].endswith('.c5'):
             return [(self.dc * 4, o["cout"], 1, plan.npix, o["act"])]
         if o["kind"] == "conv" and o["w"] == 'c.0':

@@ -32,7 +32,7 @@ def test_harness_other_models(tmp_path, mid, key, dr):
 def test_harness_on_mini_div2k(tmp_path):
     from ntire2022_esr_amd import harness as H
     from ntire2022_esr_amd.registry import select_model, supported_ids
-    assert supported_ids() == [-1, 0, 4, 6, 18, 22, 26]
+    assert supported_ids() == [-1, 0, 4, 6, 8, 18, 22, 26, 40]
     dev = torch.device("cuda:0")
     model, name, data_range, tile = select_model(-1, dev)
     assert name == "-1_IMDN_baseline" and data_range == 1.0 and tile is None
@@ -53,7 +53,8 @@ def test_harness_on_mini_div2k(tmp_path):
     assert tiled.shape == whole.shape and float((tiled - whole).abs().mean()) < 0.05
 
 
-@pytest.mark.parametrize("mid,stem", [(6, "team06_v1"), (22, "team22_rep_rfdn"), (26, "team26_imdn_nb7")])
+@pytest.mark.parametrize("mid,stem", [(6, "team06_v1"), (22, "team22_rep_rfdn"), (26, "team26_imdn_nb7"),
+                                      (40, "team40_rfdn_pruned"), (8, "team08_sfdn")])
 def test_free_riders_match_reference(mid, stem):
     import numpy as np
     from conftest import rel_err

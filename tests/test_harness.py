@@ -181,7 +181,9 @@ def test_free_rider_registry_surface():
     """ids 6 / 22 / 26 reuse the RFDN / IMDN graphs with their own checkpoints (test_demo.py:66-72,175-181,203-209)."""
     from ntire2022_esr_amd import IMDN, RFDN
     from ntire2022_esr_amd.registry import load_checkpoint, supported_ids
-    assert supported_ids() == [-1, 0, 4, 6, 18, 22, 26]
-    for stem, m in (("team06_v1", RFDN(nf=50)), ("team22_rep_rfdn", RFDN(nf=40)), ("team26_imdn_nb7", IMDN(nb=7))):
+    assert supported_ids() == [-1, 0, 4, 6, 8, 18, 22, 26, 40]
+    for stem, m in (("team06_v1", RFDN(nf=50)), ("team22_rep_rfdn", RFDN(nf=40)), ("team26_imdn_nb7", IMDN(nb=7)),
+                    ("team40_rfdn_pruned", RFDN(nf=40, block_residual=False, esa_f=12)),          # near riders
+                    ("team08_sfdn", RFDN(block_residual=False, esa_conv_f=False))):
         missing, unexpected = m.load_state_dict(load_checkpoint(stem), strict=True)
         assert not missing and not unexpected

@@ -97,24 +97,50 @@ def load_reference_models():
 
 def load_free_riders():
     """Registry entries that reuse the in-scope graphs with their own checkpoints:
-    id 6 `v1` and id 22 `RFDN40` are the rfdn_baseline graph (nf=50 / nf=40), id 26 is IMDN with nb=7."""
+    id 6 `v1` and id 22 `RFDN40` are the rfdn_baseline graph (nf=50 / nf=40), id 26 is IMDN with nb=7; the near
+    riders id 40 (pruned RFDN: nf=40, no in-block residual, ESA width fixed at 12) and id 8 (SFDN: residual folded
+    into the checkpoint's weights, ESA without conv_f) are RFDN graphs with two switches."""
     from models.team06_v1 import v1
     from models.team22_rep_rfdn import RFDN40
     from models.imdn_baseline import IMDN
+    from models.team40_rfdn_pruned import RFDN as RFDNPrune
+    with contextlib.redirect_stdout(io.StringIO()):
+        from models.team08_sfdn import RFDN as SFDN
 
     def ld(name):
         return torch.load(os.path.join(REF, "model_zoo", name), map_location="cpu", weights_only=False)
 
     out = {}
-    for key, ctor, ck in (("team06_v1", lambda: v1(in_nc=3, nf=50, num_modules=4, out_nc=3, upscale=4), "team06_v1.pth"),
-                          ("team22_rep_rfdn", RFDN40, "team22_rep_rfdn.pth"),
-                          ("team26_imdn_nb7", lambda: IMDN(in_nc=3, out_nc=3, nc=64, nb=7, upscale=4, act_mode='L',
-                                                           upsample_mode='pixelshuffle'), "team26_imdn_nb7.pth")):
-        m = ctor()
+    for key, ctor, ck, dr in (("team06_v1", lambda: v1(in_nc=3, nf=50, num_modules=4, out_nc=3, upscale=4), "team06_v1.pth", 1.0),
+                              ("team22_rep_rfdn", RFDN40, "team22_rep_rfdn.pth", 1.0),
+                              ("team26_imdn_nb7", lambda: IMDN(in_nc=3, out_nc=3, nc=64, nb=7, upscale=4, act_mode='L',
+                                                               upsample_mode='pixelshuffle'), "team26_imdn_nb7.pth", 1.0),
+                              ("team40_rfdn_pruned", lambda: RFDNPrune(in_nc=3, nf=40, num_modules=4, out_nc=3, upscale=4),
+                               "team40_rfdn_pruned.pth", 255.0),                                   # test_demo.py:302-308
+                              ("team08_sfdn", SFDN, "team08_sfdn.pt", 1.0)):                         # test_demo.py:76-82
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = ctor()
         sd = ld(ck)
         m.load_state_dict(sd, strict=True)
-        out[key] = (m.eval(), sd, 1.0)
+        out[key] = (m.eval(), sd, dr)
     return out
+
+
+def write_riders(manifest):
+    """weights + one small seeded vector for each free rider"""
+    riders = load_free_riders()
+    with torch.no_grad():
+        for name, (m, sd, dr) in riders.items():
+            tensors = {k: v.detach().float().contiguous().clone() for k, v in sd.items()}
+            path = os.path.join(WDIR, name + ".safetensors")
+            save_file(tensors, path)
+            manifest[name] = {"file": name + ".safetensors", "sha256": sha256(path), "data_range": dr,
+                              "num_tensors": len(tensors),
+                              "num_elements": int(sum(v.numel() for v in tensors.values())),
+                              "keys": {k: list(v.shape) for k, v in tensors.items()}}
+            g = torch.Generator().manual_seed(2)
+            xb = torch.rand(2, 3, 20, 36, generator=g) * dr
+            np.savez(os.path.join(GOLD, f"e2e_{name}.npz"), xb=xb.numpy(), yb=m(xb).numpy(), data_range=np.float32(dr))
 
 
 def sha256(path):
@@ -151,19 +177,7 @@ def main():
         json.dump(manifest, f, indent=1)
 
     # ---- free riders: weights + one small seeded vector each -------------------
-    riders = load_free_riders()
-    with torch.no_grad():
-        for name, (m, sd, dr) in riders.items():
-            tensors = {k: v.detach().float().contiguous().clone() for k, v in sd.items()}
-            path = os.path.join(WDIR, name + ".safetensors")
-            save_file(tensors, path)
-            manifest[name] = {"file": name + ".safetensors", "sha256": sha256(path), "data_range": dr,
-                              "num_tensors": len(tensors),
-                              "num_elements": int(sum(v.numel() for v in tensors.values())),
-                              "keys": {k: list(v.shape) for k, v in tensors.items()}}
-            g = torch.Generator().manual_seed(2)
-            xb = torch.rand(2, 3, 20, 36, generator=g) * dr
-            np.savez(os.path.join(GOLD, f"e2e_{name}.npz"), xb=xb.numpy(), yb=m(xb).numpy(), data_range=np.float32(dr))
+    write_riders(manifest)
     with open(os.path.join(WDIR, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)
 
@@ -287,4 +301,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--riders-only" in sys.argv:           # refresh the free riders without touching the other fixtures
+        _stub_cv2_torchvision()
+        sys.path.insert(0, REF)
+        os.chdir(REF)
+        man = json.load(open(os.path.join(WDIR, "manifest.json")))
+        write_riders(man)
+        json.dump(man, open(os.path.join(WDIR, "manifest.json"), "w"), indent=1)
+    else:
+        main()

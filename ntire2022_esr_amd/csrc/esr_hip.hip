@@ -9,11 +9,12 @@
 //   MFMA D       lane l holds D[(l>>4)*4 + r][l&15], r=0..3  -> 4 CONSECUTIVE output channels of ONE
 //                pixel per lane: the NHWC store is one dwordx4, and with 16c+4i+j channel order the
 //                PixelShuffle(4) store is one dwordx4 of 4 horizontally adjacent HR pixels.
-//   block        256 threads = 4 waves, 16x16 output pixels x (NT*16) output channels;
-//                wave wv owns rows 4wv..4wv+3 (4 pixel tiles) x NT channel tiles -> 4*NT accumulators.
-//   K loop       input channels in chunks of 8: per chunk the (16+2)^2 halo tile (8 ch) and the
-//                chunk's weights for all taps/tiles are staged global->VGPR->LDS, double buffered,
-//                one barrier per chunk; 2 blocks/CU (57.6 KB LDS each) overlap each other's staging.
+//   block        NW waves (4 or 8), 16 x (4*NW) output pixels x (NT*16) output channels; wave wv owns rows
+//                4wv..4wv+3 (4 pixel tiles) x NT channel tiles -> 4*NT accumulators.  NW = 4: two blocks per CU;
+//                NW = 8 (large 3x3 launches): one block per CU, eight waves share one weight stage.
+//   K loop       input channels in chunks of 8, double-buffered LDS stages, one barrier per chunk: the chunk's
+//                weights go global->LDS by DMA (global_load_lds), the halo tile global->VGPR->LDS (zero fill,
+//                (pixel, half) scatter), requested two stages ahead; persistent blocks walk the tiles.
 //   LDS images   input  [half h][halo pixel][4 ch]   (h = channels 0-3 | 4-7 of the chunk)
 //                weight [tap][tile][lane][2]          (lane-linear: conflict-free ds_read_b64)
 //                a lane (p, kq) reads channels c0+2kq+{0,1}: k-slot kq of MFMA j <-> channel c0+2kq+j,
@@ -952,7 +953,7 @@ extern "C" {
 
 int esr_abi_version(void) { return ESR_ABI_VERSION; }
 const char* esr_last_hip_error(void) { return g_err; }
-const char* esr_build_info(void) { return "gfx950 f32:v_mfma_f32_16x16x4_f32 h16:v_mfma_f32_16x16x16_{bf16,f16} tile16x16 chunk8 persistent"; }
+const char* esr_build_info(void) { return "gfx950 f32:v_mfma_f32_16x16x4_f32 h16:v_mfma_f32_16x16x16_{bf16,f16} tiles 16x16/16x32 chunk8 persistent"; }
 
 size_t esr_packed_conv_bytes(int cin_phys, int cout, int ksize)
 {

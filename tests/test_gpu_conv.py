@@ -219,3 +219,36 @@ def test_fused_tail_argument_checks():
     w3, b3 = torch.randn(16, 48, 3, 3), torch.randn(16)
     with pytest.raises(L.EsrError):                                 # 1x1 with too few outputs for the 4-tile tail
         ops.conv2d(x, w3, b3, tail_weight=torch.randn(32, 64), tail_bias=torch.randn(32), tail_cat=cat)
+
+
+def test_conv_randomised_shapes():
+    """Seeded sweep over shapes / channel counts / epilogues, sized so that both block shapes (4-wave 16x16 tiles and
+    8-wave 16x32 tiles) and every edge-tile combination occur; each case against ATen."""
+    import random
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    rng = random.Random(1234)
+    seen = set()
+    for case in range(36):
+        n = rng.choice([1, 2, 3, 5, 8])
+        h, w = rng.randint(3, 300), rng.randint(3, 300)
+        if n * h * w > 400_000:
+            h, w = h // 2 + 2, w // 2 + 2
+        cin = rng.choice([8, 16, 24, 40, 48, 56, 64])
+        cout = rng.choice([16, 24, 48, 52, 64])
+        k = rng.choice([1, 3, 3, 3])
+        act, res_mode = rng.choice([0, 1, 2, 3]), rng.choice([0, 0, 1, 2])
+        seen.add(_block_waves(n, h, w, cin, cout, k))
+        g = torch.Generator().manual_seed(case)
+        x = torch.randn(n, cin, h, w, generator=g)
+        r = torch.randn(n, cout, h, w, generator=g)
+        wt = torch.randn(cout, cin, k, k, generator=g) * 0.1
+        b = torch.randn(cout, generator=g)
+        c = F.conv2d(x, wt, b, padding=k // 2)
+        ref = {0: ACTS[act](c), 1: ACTS[act](c + r), 2: ACTS[act](c) + r}[res_mode]
+        y = ops.conv2d(_nhwc(x).to(dev), wt, b, act=act, slope=0.05,
+                       res=_nhwc(r).to(dev) if res_mode else None, res_mode=res_mode)
+        y = y.cpu().permute(0, 3, 1, 2)[:, :cout]
+        err = float((y - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        assert err < 2e-5, (case, n, h, w, cin, cout, k, act, res_mode, err)
+    assert seen == {4, 8}

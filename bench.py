@@ -212,6 +212,18 @@ def main():
             "model_frac_of_mfma_peak": round(value * gflop_per_img / 1e3 / (peak * world), 4),
             "roofline": roofline,
         }
+        if world == 1:
+            # the reference's own semantics (test_demo.py:416-433: one image per forward), outside the timed region
+            with torch.no_grad():
+                x1 = x[:1].contiguous()
+                for _ in range(5):
+                    model(x1)
+                torch.cuda.synchronize(device)
+                t1 = time.perf_counter()
+                for _ in range(50):
+                    model(x1)
+                torch.cuda.synchronize(device)
+            out["b1_latency_ms"] = round((time.perf_counter() - t1) / 50 * 1e3, 3)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -103,6 +103,9 @@ def main():
                     help="MFMA operand format of the full-resolution 3x3 convs (storage/accumulate fp32); "
                          "the headline metric is f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--b1-latency", action="store_true",
+                    help="also report the latency of a single-image forward (extra launches after the timed region: "
+                         "keep it off when the run is profiled, the B=1 launches would enter the per-kernel averages)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not record per-kernel HIP events during the timed steps")
     args = ap.parse_args()
@@ -212,7 +215,7 @@ def main():
             "model_frac_of_mfma_peak": round(value * gflop_per_img / 1e3 / (peak * world), 4),
             "roofline": roofline,
         }
-        if world == 1:
+        if world == 1 and args.b1_latency:
             # the reference's own semantics (test_demo.py:416-433: one image per forward), outside the timed region
             with torch.no_grad():
                 x1 = x[:1].contiguous()

@@ -196,14 +196,41 @@ int esr_sqerr_u8(const uint8_t* a_hwc, const uint8_t* b_hwc, int h, int w, int c
  * The Python host builds the list once per (model, N, H, W) and replays it.
  */
 typedef enum esr_op_kind {
-    ESR_OP_CONV = 0, ESR_OP_CONV3X3S2 = 1, ESR_OP_MAXPOOL7S3 = 2, ESR_OP_ESA_APPLY = 3, ESR_OP_DWCONV = 4
+    ESR_OP_CONV = 0, ESR_OP_CONV3X3S2 = 1, ESR_OP_MAXPOOL7S3 = 2, ESR_OP_ESA_APPLY = 3, ESR_OP_DWCONV = 4,
+    ESR_OP_BSCONV = 5
 } esr_op_kind;
+
+/*
+ * esr_bsconv_f32 -- BSConvU (models/team18_bsrn.py:44-88) in one launch: y = act(dw3x3(pw1x1(x)) [+ res]), the
+ * pointwise result never reaches memory (the depthwise conv zero-pads it, so out-of-image halo positions are 0, not
+ * the pointwise bias).  Optionally the distillation 1x1 of the enclosing block (team18_bsrn.py:135-148: c{j}_d reads
+ * the same input as c{j}_r) is evaluated on the same input tile: d_out = d_act(W_d . x + b_d).
+ * pw_packed / d_packed = esr_pack_conv_f32(..., ksize = 1) blobs, dw_packed = esr_pack_dw_f32.  cin, c <= 64, d_cout <= 32.
+ */
+typedef struct esr_bsconv_desc {
+    int32_t n, h, w;
+    int32_t cin;                /* input channels of the pointwise conv */
+    int32_t c;                  /* pointwise outputs = depthwise channels */
+    int32_t act;                /* esr_act of the depthwise output */
+    float   slope;
+    int32_t res_mode;           /* esr_res, applied to the depthwise output */
+    esr_view in, res, out;
+    const void* pw_packed;
+    const void* dw_packed;
+    const void* d_packed;       /* NULL = no distillation conv */
+    int32_t d_cout;
+    int32_t d_act;
+    esr_view d_out;
+} esr_bsconv_desc;
+
+int esr_bsconv_f32(const esr_bsconv_desc* d, void* hip_stream);
 
 typedef struct esr_op {
     int32_t kind;               /* esr_op_kind */
     int32_t reserved;
     esr_conv_desc conv;         /* ESR_OP_CONV, ESR_OP_DWCONV */
     esr_esa_desc esa;           /* the three ESA kinds */
+    esr_bsconv_desc bs;         /* ESR_OP_BSCONV (ABI v3) */
 } esr_op;
 
 int esr_run_ops(const esr_op* ops, int n_ops, void* hip_stream);

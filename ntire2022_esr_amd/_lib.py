@@ -16,7 +16,7 @@ STATUS = {0: "ESR_OK", -1: "ESR_ERR_BAD_ARG", -2: "ESR_ERR_UNSUPPORTED", -3: "ES
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
 RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
 NHWC, NCHW_IN, NCHW_SHUFFLE4 = 0, 1, 2
-OP_CONV, OP_CONV3X3S2, OP_MAXPOOL7S3, OP_ESA_APPLY, OP_DWCONV = 0, 1, 2, 3, 4
+OP_CONV, OP_CONV3X3S2, OP_MAXPOOL7S3, OP_ESA_APPLY, OP_DWCONV, OP_BSCONV = 0, 1, 2, 3, 4, 5
 ESA_FP = 16
 COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2
 COMPUTE = {"f32": 0, "bf16": 1, "f16": 2}
@@ -52,8 +52,21 @@ class EsaDesc(ctypes.Structure):
     ]
 
 
+class BsDesc(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_int32), ("h", ctypes.c_int32), ("w", ctypes.c_int32),
+        ("cin", ctypes.c_int32), ("c", ctypes.c_int32), ("act", ctypes.c_int32), ("slope", ctypes.c_float),
+        ("res_mode", ctypes.c_int32),
+        ("inp", View), ("res", View), ("out", View),
+        ("pw_packed", ctypes.c_void_p), ("dw_packed", ctypes.c_void_p), ("d_packed", ctypes.c_void_p),
+        ("d_cout", ctypes.c_int32), ("d_act", ctypes.c_int32),
+        ("d_out", View),
+    ]
+
+
 class Op(ctypes.Structure):
-    _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("conv", ConvDesc), ("esa", EsaDesc)]
+    _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("conv", ConvDesc), ("esa", EsaDesc),
+                ("bs", BsDesc)]
 
 
 # every symbol include/esr_hip.h declares (tests check the .so exports all of them)
@@ -65,7 +78,7 @@ EXPORTS = [
     "esr_prof_create", "esr_run_ops_profiled", "esr_prof_collect", "esr_prof_destroy",
     "esr_packed_dense_bytes", "esr_pack_dense_f32",
     "esr_conv3x3s2_f32", "esr_maxpool7s3_f32", "esr_esa_apply_f32",
-    "esr_packed_dw_bytes", "esr_pack_dw_f32", "esr_dwconv3x3_f32",
+    "esr_packed_dw_bytes", "esr_pack_dw_f32", "esr_dwconv3x3_f32", "esr_bsconv_f32",
     "esr_tensor2uint_u8", "esr_sqerr_u8",
 ]
 
@@ -118,6 +131,8 @@ def lib():
     L.esr_pack_dw_f32.restype = ci
     L.esr_dwconv3x3_f32.argtypes = [ctypes.POINTER(ConvDesc), vp]
     L.esr_dwconv3x3_f32.restype = ci
+    L.esr_bsconv_f32.argtypes = [ctypes.POINTER(BsDesc), vp]
+    L.esr_bsconv_f32.restype = ci
     L.esr_tensor2uint_u8.argtypes = [vp, vp, ci, ci, ci, ctypes.c_float, vp]
     L.esr_tensor2uint_u8.restype = ci
     L.esr_sqerr_u8.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]

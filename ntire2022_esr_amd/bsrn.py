@@ -93,11 +93,11 @@ class BSRN(HipSRModel):
             b = f'B{k}.'
             src = cur
             for j, (rin, rout) in enumerate(((cur, r1), (r1, r2), (r2, r1)), start=1):
-                plan.conv(b + f'c{j}_d', rin, cat[(j - 1) * dc:j * dc], C, dc, k=1, counted=False, **g)
-                plan.conv(b + f'c{j}_r.pw', rin, t, C, C, k=1, counted=False)
-                plan.dwconv(b + f'c{j}_r.dw', t, rout, C, res=rin, res_mode=L.RES_PRE_ACT, **g)
-            plan.conv(b + 'c4.pw', r1, t[0:dc], C, dc, k=1, counted=False)
-            plan.dwconv(b + 'c4.dw', t[0:dc], cat[3 * dc:4 * dc], dc, **g)
+                # c{j}_d (Linear + GELU) and c{j}_r = BSConvU (+ input, GELU) read the same tensor: one launch, the
+                # pointwise result stays in LDS (team18_bsrn.py:150-163)
+                plan.bsconv(b + f'c{j}_r.pw', b + f'c{j}_r.dw', rin, rout, C, C, res=rin, res_mode=L.RES_PRE_ACT,
+                            distill=dict(w=b + f'c{j}_d', dst=cat[(j - 1) * dc:j * dc], cout=dc, act=L.ACT_GELU), **g)
+            plan.bsconv(b + 'c4.pw', b + 'c4.dw', r1, cat[3 * dc:4 * dc], C, dc, **g)
             plan.conv(b + 'c5', cat, v, 4 * dc, C, k=1, counted=False)
             plan.conv(b + 'esa.conv1', v, c1, C, f, k=1, counted=False)
             plan.conv3x3s2(b + 'esa.conv2', c1, lo2, f)
@@ -113,8 +113,7 @@ class BSRN(HipSRModel):
             plan.conv(b + 'conv_out', u, out, C, C, k=1, res=src, res_mode=L.RES_PRE_ACT, counted=False)
             cur = out
         plan.conv('c1', bcat, v, nb * C, C, k=1, counted=False, **g)
-        plan.conv('c2.pw', v, t, C, C, k=1, counted=False)
-        plan.dwconv('c2.dw', t, u, C, res=fea, res_mode=L.RES_PRE_ACT)
+        plan.bsconv('c2.pw', 'c2.dw', v, u, C, C, res=fea, res_mode=L.RES_PRE_ACT)
         plan.conv('upsampler.upsampleOneStep.0', u, OUTPUT, C, self.out_nc * 16)
 
     # -- complexity counters: what utils/model_summary.py reports for this graph -----------------------------
@@ -127,6 +126,9 @@ class BSRN(HipSRModel):
         h, w = (hw if hw else (plan.h, plan.w))
         if o["kind"] == "dw":
             return 9 * o["cin"] * plan.n * h * w, o["cout"] * plan.n * h * w, 1
+        if o["kind"] == "bs":                                             # depthwise Conv2d + 1 or 2 Linear calls in one launch
+            nlin = 1 + (o["distill"] is not None)
+            return 9 * o["cout"] * plan.n * h * w + nlin * plan.n * h * h, o["cout"] * plan.n * h * w, 1
         if o["kind"] == "conv" and not o.get("counted", True):
             return plan.n * h * h, 0, 0                                   # a Linear call
         if o["kind"] == "apply":

@@ -1,0 +1,275 @@
+// esr_bsconv.hip -- BSConvU (models/team18_bsrn.py:44-88) as ONE kernel: pointwise 1x1 (nn.Linear on NHWC) -> depthwise 3x3
+// (zero padding on the pointwise OUTPUT, bias) -> + residual -> activation, optionally with the block's distillation 1x1
+// (team18_bsrn.py:135-148: c{j}_d reads the same input as c{j}_r) riding along.  Separate kernels move the pointwise
+// result through HBM twice (write, then read by the depthwise conv) and read the input twice more; here the input tile
+// (16x16 pixels + halo) is read once, the pointwise result lives in LDS only.
+//   phase 1  pointwise GEMM on MFMA over the 18x18 halo pixel list (21 pixel tiles of 16): B fragments straight from global
+//            memory (lane (px, kq): the 16 bytes of channels 16C+4kq.. of its pixel, hardware zero fill outside the image),
+//            weights resident in LDS ([16-channel chunk][tile][lane][4]); the D fragment (4 channels of one pixel per lane)
+//            goes to the LDS tile [halo pixel][channel], zeroed where the pixel lies outside the image (the depthwise conv
+//            pads the pointwise output with zeros, not with its bias); distillation outputs go to global memory directly.
+//   phase 2  depthwise 3x3 on VALU: thread = (pixel, 4 channels), 9 float4 LDS reads, bias, residual, activation, one
+//            16-byte store; 192 contiguous bytes per pixel for 48 channels.
+// Memory-bound by design: per tile it reads 1.27x the input (halo) + the residual and writes the output once.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include "esr_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BT = 16;                 // output tile edge
+constexpr int BH = BT + 2;             // halo edge
+constexpr int BNPX = BH * BH;          // 324 halo pixels
+constexpr int BNPT = (BNPX + 15) / 16; // 21 pixel tiles of 16
+constexpr int BPTW = (BNPT + 3) / 4;   // pixel tiles per wave (6)
+constexpr int BMAXC16 = 4;             // cin <= 64
+constexpr unsigned BOOB = 0x80000000u;
+
+struct BsK {
+    const float* x; const float* res; float* y; float* dy;
+    const float* pw; const float* pwb; const float* dwp; const float* dpw; const float* dpb;
+    int N, H, W;
+    int nch8;             // 8-channel chunks of the packed 1x1 blobs
+    int cp;               // depthwise channels rounded up to 4
+    int d_cout4;
+    int x_pitch, x_coff, r_pitch, r_coff, y_pitch, y_coff, dy_pitch, dy_coff;
+    int act, res_mode, d_act;
+    float slope;
+    int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ float bs_act(float v, int act, float slope)
+{
+    if (act == ESR_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    if (act == ESR_ACT_LRELU) return fmaxf(v, v * slope);
+    if (act == ESR_ACT_RELU) return fmaxf(v, 0.f);
+    return v;
+}
+
+// esr_pack_conv_f32(ksize = 1) blob ([chunk of 8][tile][kq'*16+i][j'], channel = 8*chunk + 2kq' + j') -> LDS image
+// [chunk of 16][tile][lane = kq*16+i][j], channel = 16*chunk + 4kq + j; an odd chunk count leaves the upper half zero
+template <int NTL>
+__device__ __forceinline__ void build_image(float* img, const float* blob, int nch8, int tid)
+{
+    const int nc16 = (nch8 + 1) >> 1;
+    if (nch8 & 1)
+        for (int e = tid; e < NTL * 128; e += 256) {
+            const int tt = e >> 7, l = 32 + ((e >> 2) & 31), j = e & 3;
+            img[(((nc16 - 1) * NTL + tt) * 64 + l) * 4 + j] = 0.f;
+        }
+    for (int q = tid; q < nch8 * NTL * 32; q += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(blob + (size_t)q * 4);
+        const int ip = q & 7, kq8 = (q >> 3) & 3, ct = q >> 5;
+        const int tt = ct % NTL, chunk8 = ct / NTL;
+        const int ch16 = 8 * (chunk8 & 1) + 2 * kq8;
+        float* dst = img + (((chunk8 >> 1) * NTL + tt) * 64 + (ch16 >> 2) * 16 + 2 * ip) * 4 + (ch16 & 3);
+        dst[0] = v.x; dst[1] = v.y; dst[4] = v.z; dst[5] = v.w;
+    }
+}
+
+template <int NTP, int NTD>
+__global__ __launch_bounds__(256, 2) void bsconv_kernel(const BsK p)
+{
+    extern __shared__ __attribute__((aligned(16))) float bsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int px = lane & 15, kq = lane >> 4;
+    const int nc16 = (p.nch8 + 1) >> 1;
+    float* const tl = bsm;                                   // [BNPX][cp] pointwise result
+    float* const ipw = tl + BNPX * p.cp;                     // pointwise weight image
+    float* const idp = ipw + nc16 * NTP * 256;               // distillation weight image
+    float* const sdw = idp + nc16 * NTD * 256;               // depthwise [tap][cp] + bias[cp]
+    float* const sb = sdw + 10 * p.cp;                       // pointwise bias [NTP*16], distillation bias [NTD*16]
+    build_image<NTP>(ipw, p.pw, p.nch8, tid);
+    if (NTD) build_image<(NTD ? NTD : 1)>(idp, p.dpw, p.nch8, tid);
+    for (int i = tid; i < 10 * p.cp; i += 256) sdw[i] = p.dwp[i];
+    if (tid < NTP * 16) sb[tid] = p.pwb[tid];
+    if (NTD && tid < NTD * 16) sb[NTP * 16 + tid] = p.dpb[tid];
+    __syncthreads();
+
+    const int ntiles = p.N * p.tiles_y * p.tiles_x;
+    const size_t img_floats = (size_t)p.H * p.W * p.x_pitch;
+    const int cin_phys = p.nch8 * 8;
+    const int nq = p.cp >> 2;
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = t % p.tiles_x, tq = t / p.tiles_x;
+        const int ty = tq % p.tiles_y, n = tq / p.tiles_y;
+        const int x0 = tx * BT, y0 = ty * BT;
+        const __amdgpu_buffer_rsrc_t xr =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)n * img_floats), 0, (int)(img_floats * 4), 0x00020000);
+
+        // ---- phase 1: all B fragments of this wave's pixel tiles are requested before the first MFMA ----------------
+        f32x4 b[BPTW][BMAXC16];
+        bool valid[BPTW];
+        int gpix[BPTW];
+#pragma unroll
+        for (int s = 0; s < BPTW; ++s) {
+            const int pl = (wv + 4 * s) * 16 + px;
+            const int ly = pl / BH, lx = pl - ly * BH;
+            const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+            valid[s] = wv + 4 * s < BNPT && pl < BNPX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            gpix[s] = gy * p.W + gx;
+            const unsigned vo = valid[s] ? (unsigned)(gpix[s] * p.x_pitch + p.x_coff + 4 * kq) * 4u : BOOB;
+#pragma unroll
+            for (int C = 0; C < BMAXC16; ++C) {
+                const bool ok = C < nc16 && 16 * C + 4 * kq < cin_phys;
+                b[s][C] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? vo : BOOB, C * 64, 0));
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < BPTW; ++s) {
+            if (wv + 4 * s >= BNPT) break;
+            f32x4 acc[NTP], dacc[NTD ? NTD : 1];
+#pragma unroll
+            for (int tt = 0; tt < NTP; ++tt) acc[tt] = *reinterpret_cast<const f32x4*>(sb + tt * 16 + kq * 4);
+#pragma unroll
+            for (int td = 0; td < NTD; ++td) dacc[td] = *reinterpret_cast<const f32x4*>(sb + NTP * 16 + td * 16 + kq * 4);
+#pragma unroll
+            for (int C = 0; C < BMAXC16; ++C) {
+                if (C >= nc16) break;
+#pragma unroll
+                for (int tt = 0; tt < NTP; ++tt) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(ipw + ((C * NTP + tt) * 64 + lane) * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[s][C][j], acc[tt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int td = 0; td < NTD; ++td) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(idp + ((C * NTD + td) * 64 + lane) * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dacc[td] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[s][C][j], dacc[td], 0, 0, 0);
+                }
+            }
+            const int pl = (wv + 4 * s) * 16 + px;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            if (pl < BNPX) {
+#pragma unroll
+                for (int tt = 0; tt < NTP; ++tt)
+                    if (tt * 16 + kq * 4 < p.cp) *reinterpret_cast<f32x4*>(tl + pl * p.cp + tt * 16 + kq * 4) = valid[s] ? acc[tt] : zero;
+            }
+            if (NTD) {
+                const int ly = pl / BH, lx = pl - ly * BH;
+                if (valid[s] && ly >= 1 && ly <= BT && lx >= 1 && lx <= BT) {
+                    float* dst = p.dy + ((size_t)n * p.H * p.W + gpix[s]) * p.dy_pitch + p.dy_coff;
+#pragma unroll
+                    for (int td = 0; td < NTD; ++td) {
+                        if (td * 16 + kq * 4 >= p.d_cout4) continue;
+                        f32x4 v = dacc[td];
+                        v.x = bs_act(v.x, p.d_act, p.slope); v.y = bs_act(v.y, p.d_act, p.slope);
+                        v.z = bs_act(v.z, p.d_act, p.slope); v.w = bs_act(v.w, p.d_act, p.slope);
+                        *reinterpret_cast<f32x4*>(dst + td * 16 + kq * 4) = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: depthwise 3x3 + bias (+res) (+act) ---------------------------------------------------------------
+        for (int idx = tid; idx < BT * BT * nq; idx += 256) {
+            const int pixel = idx / nq, q = idx - pixel * nq;
+            const int oy = pixel >> 4, ox = pixel & 15;
+            const int gy = y0 + oy, gx = x0 + ox;
+            if (gy >= p.H || gx >= p.W) continue;
+            f32x4 a = *reinterpret_cast<const f32x4*>(sdw + 9 * p.cp + q * 4);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    a += *reinterpret_cast<const f32x4*>(tl + ((oy + ky) * BH + ox + kx) * p.cp + q * 4) *
+                         *reinterpret_cast<const f32x4*>(sdw + (ky * 3 + kx) * p.cp + q * 4);
+            const size_t gp = (size_t)n * p.H * p.W + (size_t)gy * p.W + gx;
+            f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+            if (p.res_mode != ESR_RES_NONE) rv = *reinterpret_cast<const f32x4*>(p.res + gp * p.r_pitch + p.r_coff + q * 4);
+            if (p.res_mode == ESR_RES_PRE_ACT) a += rv;
+            a.x = bs_act(a.x, p.act, p.slope); a.y = bs_act(a.y, p.act, p.slope);
+            a.z = bs_act(a.z, p.act, p.slope); a.w = bs_act(a.w, p.act, p.slope);
+            if (p.res_mode == ESR_RES_POST_ACT) a += rv;
+            *reinterpret_cast<f32x4*>(p.y + gp * p.y_pitch + p.y_coff + q * 4) = a;
+        }
+        __syncthreads();
+    }
+}
+
+template <int NTP, int NTD>
+int launch_bs(const BsK& k, size_t lds, hipStream_t st)
+{
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bsconv_kernel<NTP, NTD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    const int ntiles = k.N * k.tiles_x * k.tiles_y;
+    const int grid = ntiles < 512 ? ntiles : 512;
+    hipLaunchKernelGGL((bsconv_kernel<NTP, NTD>), dim3(grid), dim3(256), lds, st, k);
+    return esr_check_launch("bsconv_kernel launch");
+}
+
+template <int NTP>
+int launch_bs_d(int ntd, const BsK& k, size_t lds, hipStream_t st)
+{
+    switch (ntd) {
+        case 0: return launch_bs<NTP, 0>(k, lds, st);
+        case 1: return launch_bs<NTP, 1>(k, lds, st);
+        case 2: return launch_bs<NTP, 2>(k, lds, st);
+    }
+    return ESR_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int esr_bsconv_f32(const esr_bsconv_desc* d, void* hip_stream)
+{
+    if (!d || !d->in.ptr || !d->out.ptr || !d->pw_packed || !d->dw_packed) return ESR_ERR_BAD_ARG;
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->c <= 0) return ESR_ERR_BAD_ARG;
+    if (d->cin > 64 || d->c > 64) return ESR_ERR_UNSUPPORTED;
+    const int cin_phys = esr_round_up(d->cin, 8), cp = esr_round_up(d->c, 4);
+    if ((d->in.pitch & 3) || (d->in.coff & 3) || d->in.coff + cin_phys > d->in.pitch) return ESR_ERR_BAD_ARG;
+    if ((d->out.pitch & 3) || (d->out.coff & 3) || d->out.coff + cp > d->out.pitch) return ESR_ERR_BAD_ARG;
+    if (d->res_mode != ESR_RES_NONE && (!d->res.ptr || (d->res.pitch & 3) || (d->res.coff & 3) || d->res.coff + cp > d->res.pitch))
+        return ESR_ERR_BAD_ARG;
+    const int ntp = esr_round_up(d->c, 16) / 16;
+    int ntd = 0, dc4 = 0;
+    if (d->d_packed) {
+        if (d->d_cout <= 0 || d->d_cout > 32) return ESR_ERR_UNSUPPORTED;
+        dc4 = esr_round_up(d->d_cout, 4);
+        ntd = esr_round_up(d->d_cout, 16) / 16;
+        if (!d->d_out.ptr || (d->d_out.pitch & 3) || (d->d_out.coff & 3) || d->d_out.coff + dc4 > d->d_out.pitch) return ESR_ERR_BAD_ARG;
+    }
+    {
+        const double px_all = (double)d->n * d->h * d->w;
+        int maxpitch = d->in.pitch > d->out.pitch ? d->in.pitch : d->out.pitch;
+        if (d->res_mode != ESR_RES_NONE && d->res.pitch > maxpitch) maxpitch = d->res.pitch;
+        if (d->d_packed && d->d_out.pitch > maxpitch) maxpitch = d->d_out.pitch;
+        if (px_all * maxpitch >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
+        if ((double)d->h * d->w * d->in.pitch * 4.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
+    }
+    BsK k;
+    k.x = static_cast<const float*>(d->in.ptr); k.res = static_cast<const float*>(d->res.ptr);
+    k.y = static_cast<float*>(d->out.ptr); k.dy = static_cast<float*>(d->d_out.ptr);
+    k.nch8 = cin_phys / 8;
+    k.pw = static_cast<const float*>(d->pw_packed);
+    k.pwb = k.pw + (size_t)k.nch8 * ntp * 128;                  // esr_pack_conv_f32 layout: weights, then bias[nt*16]
+    k.dwp = static_cast<const float*>(d->dw_packed);
+    k.dpw = static_cast<const float*>(d->d_packed);
+    k.dpb = k.dpw ? k.dpw + (size_t)k.nch8 * ntd * 128 : nullptr;
+    k.N = d->n; k.H = d->h; k.W = d->w; k.cp = cp; k.d_cout4 = dc4;
+    k.x_pitch = d->in.pitch; k.x_coff = d->in.coff; k.r_pitch = d->res.pitch; k.r_coff = d->res.coff;
+    k.y_pitch = d->out.pitch; k.y_coff = d->out.coff; k.dy_pitch = d->d_out.pitch; k.dy_coff = d->d_out.coff;
+    k.act = d->act; k.res_mode = d->res_mode; k.d_act = d->d_act; k.slope = d->slope;
+    k.tiles_x = (d->w + BT - 1) / BT; k.tiles_y = (d->h + BT - 1) / BT;
+    const int nc16 = (k.nch8 + 1) / 2;
+    const size_t lds = ((size_t)BNPX * cp + (size_t)nc16 * (ntp + ntd) * 256 + 10 * cp + (ntp + ntd) * 16) * sizeof(float);
+    if (lds > 160 * 1024) return ESR_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    switch (ntp) {
+        case 1: return launch_bs_d<1>(ntd, k, lds, st);
+        case 2: return launch_bs_d<2>(ntd, k, lds, st);
+        case 3: return launch_bs_d<3>(ntd, k, lds, st);
+        case 4: return launch_bs_d<4>(ntd, k, lds, st);
+    }
+    return ESR_ERR_UNSUPPORTED;
+}

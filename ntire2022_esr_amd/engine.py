@@ -164,6 +164,12 @@ class Plan:
         self.ops.append(dict(kind="dw", w=wname, src=src, dst=dst, dst1=None, cin=c, cout=c, k=3, act=act, slope=slope,
                              res=res, res_mode=res_mode, split=0, hw=hw, counted=True))
 
+    def bsconv(self, pw, dw, src, dst, cin, c, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.RES_NONE, distill=None):
+        """BSConvU in one launch (esr_bsconv_f32): dst = act(dw3x3(pw1x1(src)) [+ res]).  distill = dict(w=<1x1 weight
+        name>, dst=<view>, cout, act): the enclosing block's distillation conv on the same input."""
+        self.ops.append(dict(kind="bs", pw=pw, dw=dw, w=dw, src=src, dst=dst, cin=cin, cout=c, k=3, act=act, slope=slope,
+                             res=res, res_mode=res_mode, distill=distill, hw=None, counted=True))
+
     def conv3x3s2(self, wname, src, dst, f):
         self.ops.append(dict(kind="s2", w=wname, src=src, dst=dst, f=f, cin=f, cout=f, k=3, act=L.ACT_NONE,
                              hw=(dst.h, dst.w), counted=True))
@@ -189,6 +195,22 @@ class Plan:
         base = workspace.data_ptr() if workspace is not None else 0
         for i, o in enumerate(self.ops):
             op = arr[i]
+            if o["kind"] == "bs":
+                op.kind = L.OP_BSCONV
+                d = op.bs
+                d.n, d.h, d.w, d.cin, d.c = self.n, self.h, self.w, o["cin"], o["cout"]
+                d.act, d.slope, d.res_mode = o["act"], o["slope"], o["res_mode"]
+                d.inp, d.out = self._view(o["src"], base), self._view(o["dst"], base)
+                if o["res"] is not None:
+                    d.res = self._view(o["res"], base)
+                d.pw_packed = ctypes.c_void_p(weights[o["pw"]].data_ptr())
+                d.dw_packed = ctypes.c_void_p(weights[o["dw"]].data_ptr())
+                t = o["distill"]
+                if t is not None:
+                    d.d_packed = ctypes.c_void_p(weights[t["w"]].data_ptr())
+                    d.d_cout, d.d_act = t["cout"], t.get("act", L.ACT_NONE)
+                    d.d_out = self._view(t["dst"], base)
+                continue
             if o["kind"] not in ("conv", "dw"):
                 e = op.esa
                 e.n = self.n
@@ -407,7 +429,7 @@ class HipSRModel(nn.Module):
             for i, o in enumerate(plan.ops):
                 if o["kind"] != "conv":
                     kern = {"s2": "conv3x3s2_kernel", "pool": "maxpool7s3_kernel", "apply": "esa_apply_kernel",
-                            "dw": "dwconv3x3_kernel"}[o["kind"]]
+                            "dw": "dwconv3x3_kernel", "bs": "bsconv_kernel"}[o["kind"]]
                     out.append(dict(name=o.get("w", o["kind"]), kernel=kern, cin=0, cout=0, k=0, flops=0.0,
                                     ms_sum=ms[i], passes=passes.value))
                     continue

@@ -169,26 +169,47 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(const BsK p)
         __syncthreads();
 
         // ---- phase 2: depthwise 3x3 + bias (+res) (+act) ---------------------------------------------------------------
-        for (int idx = tid; idx < BT * BT * nq; idx += 256) {
-            const int pixel = idx / nq, q = idx - pixel * nq;
-            const int oy = pixel >> 4, ox = pixel & 15;
-            const int gy = y0 + oy, gx = x0 + ox;
-            if (gy >= p.H || gx >= p.W) continue;
-            f32x4 a = *reinterpret_cast<const f32x4*>(sdw + 9 * p.cp + q * 4);
+        // thread = (channel quad q, pixel slot): its 9 weight vectors stay in registers, all residual loads of its pixels
+        // are requested before the first one is used
+        {
+            const int pp = 256 / nq;                              // pixels per pass
+            const int q = tid % nq, ps = tid / nq;
+            const bool worker = ps < pp;
+            f32x4 wreg[9], bias4;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int tp = 0; tp < 9; ++tp) wreg[tp] = *reinterpret_cast<const f32x4*>(sdw + tp * p.cp + q * 4);
+            bias4 = *reinterpret_cast<const f32x4*>(sdw + 9 * p.cp + q * 4);
+            const int npass = (BT * BT + pp - 1) / pp;
+            auto res_of = [&](int i) {
+                const int pixel = ps + pp * i;
+                const int gy = y0 + (pixel >> 4), gx = x0 + (pixel & 15);
+                f32x4 r = {0.f, 0.f, 0.f, 0.f};
+                if (p.res_mode != ESR_RES_NONE && worker && pixel < BT * BT && gy < p.H && gx < p.W)
+                    r = *reinterpret_cast<const f32x4*>(p.res + ((size_t)n * p.H * p.W + (size_t)gy * p.W + gx) * p.r_pitch + p.r_coff + q * 4);
+                return r;
+            };
+            f32x4 rv0 = res_of(0), rv1 = res_of(1);               // two passes ahead
+#pragma unroll 1
+            for (int i = 0; i < npass; ++i) {
+                const f32x4 rv = rv0;
+                rv0 = rv1;
+                rv1 = res_of(i + 2);
+                const int pixel = ps + pp * i;
+                const int oy = pixel >> 4, ox = pixel & 15;
+                const int gy = y0 + oy, gx = x0 + ox;
+                if (!(worker && pixel < BT * BT && gy < p.H && gx < p.W)) continue;
+                f32x4 a = bias4;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
-                    a += *reinterpret_cast<const f32x4*>(tl + ((oy + ky) * BH + ox + kx) * p.cp + q * 4) *
-                         *reinterpret_cast<const f32x4*>(sdw + (ky * 3 + kx) * p.cp + q * 4);
-            const size_t gp = (size_t)n * p.H * p.W + (size_t)gy * p.W + gx;
-            f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-            if (p.res_mode != ESR_RES_NONE) rv = *reinterpret_cast<const f32x4*>(p.res + gp * p.r_pitch + p.r_coff + q * 4);
-            if (p.res_mode == ESR_RES_PRE_ACT) a += rv;
-            a.x = bs_act(a.x, p.act, p.slope); a.y = bs_act(a.y, p.act, p.slope);
-            a.z = bs_act(a.z, p.act, p.slope); a.w = bs_act(a.w, p.act, p.slope);
-            if (p.res_mode == ESR_RES_POST_ACT) a += rv;
-            *reinterpret_cast<f32x4*>(p.y + gp * p.y_pitch + p.y_coff + q * 4) = a;
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+                        a += *reinterpret_cast<const f32x4*>(tl + ((oy + ky) * BH + ox + kx) * p.cp + q * 4) * wreg[ky * 3 + kx];
+                if (p.res_mode == ESR_RES_PRE_ACT) a += rv;
+                a.x = bs_act(a.x, p.act, p.slope); a.y = bs_act(a.y, p.act, p.slope);
+                a.z = bs_act(a.z, p.act, p.slope); a.w = bs_act(a.w, p.act, p.slope);
+                if (p.res_mode == ESR_RES_POST_ACT) a += rv;
+                *reinterpret_cast<f32x4*>(p.y + ((size_t)n * p.H * p.W + (size_t)gy * p.W + gx) * p.y_pitch + p.y_coff + q * 4) = a;
+            }
         }
         __syncthreads();
     }

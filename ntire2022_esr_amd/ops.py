@@ -110,3 +110,35 @@ def psnr_device(a_u8, b_u8, border=0):
     if se == 0:
         return float('inf')
     return 20 * math.log10(255.0 / math.sqrt(se / count))
+
+
+def bsconv(x, pw_weight, pw_bias, dw_weight, dw_bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.RES_NONE,
+           in_coff=0, cin=None, d_weight=None, d_bias=None, d_act=L.ACT_NONE):
+    """BSConvU in one launch (esr_bsconv_f32): act(dw3x3(pw1x1(x)) [+ res]); returns y, or (y, distilled) when the
+    distillation 1x1 `d_weight` [d_cout, cin] is given.  x: NHWC [N,H,W,pitch]; pw_weight [c, cin]; dw_weight [c,1,3,3]."""
+    from .engine import pack_dw
+    if not x.is_cuda:
+        raise L.EsrError("bsconv: tensors must live on the GPU; there is no CPU fallback")
+    lib = L.lib()
+    n, h, w, _ = x.shape
+    c, wcin = pw_weight.shape[0], pw_weight.shape[1]
+    cin = wcin if cin is None else cin
+    keep = [pack_conv(pw_weight.reshape(c, wcin, 1, 1), pw_bias).to(x.device), pack_dw(dw_weight, dw_bias).to(x.device)]
+    d = L.BsDesc()
+    d.n, d.h, d.w, d.cin, d.c = n, h, w, cin, c
+    d.act, d.slope, d.res_mode = act, slope, res_mode
+    d.inp = _view(x, in_coff)
+    y = torch.zeros((n, h, w, (c + 3) // 4 * 4), dtype=torch.float32, device=x.device)
+    d.out = _view(y)
+    if res is not None:
+        d.res = _view(res)
+    d.pw_packed, d.dw_packed = ctypes.c_void_p(keep[0].data_ptr()), ctypes.c_void_p(keep[1].data_ptr())
+    yd = None
+    if d_weight is not None:
+        dco = d_weight.shape[0]
+        keep.append(pack_conv(d_weight.reshape(dco, wcin, 1, 1), d_bias).to(x.device))
+        yd = torch.zeros((n, h, w, (dco + 3) // 4 * 4), dtype=torch.float32, device=x.device)
+        d.d_packed, d.d_cout, d.d_act, d.d_out = ctypes.c_void_p(keep[2].data_ptr()), dco, d_act, _view(yd)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    L.check(lib.esr_bsconv_f32(ctypes.byref(d), ctypes.c_void_p(stream)), "esr_bsconv_f32")
+    return y if yd is None else (y, yd)

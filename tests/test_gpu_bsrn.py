@@ -89,3 +89,36 @@ def test_bsrn_vs_oracle_and_config5_shape(model):
     xi = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float().div(255.0).unsqueeze(0)
     yi = model(xi.to(DEV)).cpu()
     assert rel_err(yi[0, :, ::5, ::5].numpy(), g["sr_sample"], 1.0) < TOL
+
+
+@pytest.mark.parametrize("cin,c,dco", [(48, 48, 24), (48, 24, 0), (48, 48, 0), (12, 12, 0), (64, 64, 32), (40, 56, 16)])
+@pytest.mark.parametrize("n,hw", [(1, (16, 16)), (2, (23, 37)), (3, (70, 45))])
+@pytest.mark.parametrize("act,res_mode", [(3, 1), (0, 0), (1, 2)])
+def test_fused_bsconv(cin, c, dco, n, hw, act, res_mode):
+    """esr_bsconv_f32 (pointwise -> depthwise 3x3 with zero padding of the pointwise OUTPUT -> +res -> act, plus the
+    distillation 1x1 on the same input) against nn.Linear / depthwise nn.Conv2d on the CPU."""
+    from ntire2022_esr_amd import ops
+    g = torch.Generator().manual_seed(cin + c + dco + n + hw[0] + act + res_mode)
+    x = torch.randn(n, cin, *hw, generator=g)
+    r = torch.randn(n, c, *hw, generator=g)
+    pw, pb = torch.randn(c, cin, generator=g) * 0.2, torch.randn(c, generator=g)
+    dw, db = torch.randn(c, 1, 3, 3, generator=g) * 0.3, torch.randn(c, generator=g)
+    a = {0: lambda v: v, 1: lambda v: F.leaky_relu(v, 0.05), 3: F.gelu}[act]
+    t = F.conv2d(x, pw[:, :, None, None], pb)
+    conv = F.conv2d(t, dw, db, padding=1, groups=c)
+    ref = {0: a(conv), 1: a(conv + r), 2: a(conv) + r}[res_mode]
+    pitch = (cin + 7) // 8 * 8 + 8
+    xg = torch.zeros(n, *hw, pitch)
+    xg[..., 8:8 + cin] = x.permute(0, 2, 3, 1)
+    rg = F.pad(r.permute(0, 2, 3, 1).contiguous(), (0, (-c) % 4))
+    kw = dict(act=act, slope=0.05, res=rg.to(DEV) if res_mode else None, res_mode=res_mode, in_coff=8, cin=cin)
+    if dco:
+        wd, bd = torch.randn(dco, cin, generator=g) * 0.2, torch.randn(dco, generator=g)
+        y, yd = ops.bsconv(xg.to(DEV), pw, pb, dw, db, d_weight=wd, d_bias=bd, d_act=3, **kw)
+        refd = F.gelu(F.conv2d(x, wd[:, :, None, None], bd))
+        yd = yd.cpu().permute(0, 3, 1, 2)[:, :dco]
+        assert float((yd - refd).abs().max()) / max(1.0, float(refd.abs().max())) < TOL
+    else:
+        y = ops.bsconv(xg.to(DEV), pw, pb, dw, db, **kw)
+    y = y.cpu().permute(0, 3, 1, 2)[:, :c]
+    assert float((y - ref).abs().max()) / max(1.0, float(ref.abs().max())) < TOL

@@ -1,5 +1,5 @@
 import sys, os, collections, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ntire2022_esr_amd.registry import select_model
 m, name, dr, _ = select_model(-1, torch.device("cuda:0"))
 x = torch.rand(1, 3, 256, 256, device="cuda:0")

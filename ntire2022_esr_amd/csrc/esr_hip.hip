@@ -187,8 +187,11 @@ __device__ __forceinline__ void epilogue_nhwc_fast(const ConvK& p, f32x4 (&acc)[
             if (!has_split) {
                 if (NT == 4 || to0) *reinterpret_cast<f32x4*>(p.y0 + pu * p.y0_pitch + off0) = o;
             } else {
-                if (to0) *reinterpret_cast<f32x4*>(p.y0 + pu * p.y0_pitch + off0) = o;
-                if (to1) *reinterpret_cast<f32x4*>(p.y1 + pu * p.y1_pitch + off1) = o;
+                // split store (IMDBlock: 16 channels to the concat slice, 48 to the next stage) as ONE instruction with
+                // per-lane 64-bit addresses: two lane-masked stores cost twice the issue time of this kernel's scarcest
+                // resource, the VMEM issue slot
+                float* const dst = to0 ? p.y0 + pu * p.y0_pitch + off0 : p.y1 + pu * p.y1_pitch + off1;
+                if (to0 || to1) *reinterpret_cast<f32x4*>(dst) = o;
             }
         }
     }

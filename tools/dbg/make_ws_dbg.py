@@ -55,5 +55,5 @@ open(src, 'w').write(s)
 csrc = os.path.join(R, 'ntire2022_esr_amd/csrc')
 subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-DESR_EXPERIMENTAL_WS',
                        '-I', os.path.join(R, 'include'), '-I', csrc, '-o', os.path.join(R, f'tools/dbg/libesr_dbg_ws{"" if VAR == "probe" else "_" + VAR}.so'),
-                       src, os.path.join(csrc, 'esr_esa.hip')])
+                       src, os.path.join(csrc, 'esr_esa.hip'), os.path.join(csrc, 'esr_bsconv.hip')])
 print('built', VAR)

@@ -65,6 +65,7 @@ struct ConvK {
     const float* cat;     // first `cat_chunks`*16 input channels of the 1x1
     int cat_pitch, cat_coff, cat_chunks;
     int mid_act;
+    int res_in;           // the (pre-activation) residual IS the conv input: taken from the staged tile, no residual loads
 #ifdef ESR_EXPERIMENTAL_WS
     int hand_rows;        // accumulator rows (of 4) finished by the loader partner
 #endif
@@ -502,6 +503,21 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
                 else if (has_next) load_input(nxt, 0);
             }
             const char* s = smem + sbuf * STAGE_BYTES;
+            if (KS == 3 && !IN_NCHW && TNT == 0 && p.res_in) {
+                // act(conv(x) + x) (RFDB, rfdn_baseline/block.py:151-157): the residual of output channels 8c..8c+7 is the
+                // centre pixel of input chunk c, which is in LDS right now in exactly the layout of the accumulator rows
+                // ([half][pixel][4 channels]); 4 ds_reads for half the lanes replace 16 global loads per tile in the epilogue
+                const int ttc = c >> 1;
+                if ((kq >> 1) == (c & 1)) {
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt)
+                        if (tt == ttc) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                acc[tt][r] += *reinterpret_cast<const f32x4*>(s + (kq & 1) * (NPX * 16) + ((wv * 4 + r + 1) * TH + px + 1) * 16);
+                        }
+                }
+            }
             // fragment reads run one tap ahead of the MFMAs that consume them
             f32x2 a[2][NT], b[2][4];
             auto load_frag = [&](int slot, int tap) {
@@ -1149,6 +1165,12 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
     k.cout_store = cout4;
     k.split = split;
     k.act = d->act; k.slope = d->slope; k.res_mode = d->res_mode;
+    k.res_in = 0;
+    if (!h16 && !tail && d->ksize == 3 && !in_nchw && d->res_mode == ESR_RES_PRE_ACT && d->cin == d->cout &&
+        d->res.ptr == d->in.ptr && d->res.pitch == d->in.pitch && d->res.coff == d->in.coff) {
+        k.res_in = 1;                               // residual == input: added from the staged input tile inside the K loop
+        k.res_mode = ESR_RES_NONE;
+    }
     k.out_layout = d->out_layout;
     k.tiles_x = (d->w + TILE - 1) / TILE;
     k.tiles_y = (d->h + TILE - 1) / TILE;

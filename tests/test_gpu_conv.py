@@ -252,3 +252,22 @@ def test_conv_randomised_shapes():
         err = float((y - ref).abs().max()) / max(1.0, float(ref.abs().max()))
         assert err < 2e-5, (case, n, h, w, cin, cout, k, act, res_mode, err)
     assert seen == {4, 8}
+
+
+@pytest.mark.parametrize("n,hw,c", [(1, (19, 23), 64), (2, (40, 56), 48), (4, (150, 140), 40), (6, (160, 144), 56)])
+@pytest.mark.parametrize("act", [1, 0])
+def test_conv_residual_is_the_input(n, hw, c, act):
+    """act(conv(x) + x) with the residual view identical to the input view (RFDB's refinement convs): the kernel takes
+    the residual from the staged input tile instead of loading it; both block shapes."""
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(n + hw[0] + c + act)
+    x = torch.randn(n, c, *hw, generator=g)
+    w = torch.randn(c, c, 3, 3, generator=g) * 0.1
+    b = torch.randn(c, generator=g)
+    ref = ACTS[act](F.conv2d(x, w, b, padding=1) + x)
+    xg = torch.zeros(n, *hw, (c + 7) // 8 * 8)
+    xg[..., :c] = x.permute(0, 2, 3, 1)
+    xg = xg.to(dev)
+    y = ops.conv2d(xg, w, b, act=act, slope=0.05, res=xg, res_mode=1, cin=c)
+    _check(y, ref)

@@ -107,6 +107,15 @@ typedef struct esr_conv_desc {
     int32_t tail_cout;
     int32_t tail_mid_act;       /* esr_act applied to the 3x3 result before the 1x1 (slope = `slope`) */
     int32_t reserved2;
+    /* ABI v3 -- optional "post" 1x1: besides its own output, the conv's ACTIVATED result x' feeds a 1x1 whose output goes to
+     * `post_out`:  post_out = post_act(W_p . x' + b_p).  RFDB: r_j = act(c{j}_r(..)), d_{j+1} = lrelu(c{j+1}_d(r_j))
+     * (models/rfdn_baseline/block.py:150-160) -- the distillation conv is evaluated by the kernel that produces its input.
+     * post_wpacked = esr_pack_conv_f32 of the 1x1 (cin = this conv's cout, ksize 1); NULL = none.  Supported: ksize 3, NHWC
+     * in/out, 48 < cout <= 64, post_cout <= 32, fp32, residual none or identical to the input (pre-activation). */
+    const void* post_wpacked;
+    esr_view post_out;
+    int32_t post_cout;
+    int32_t post_act;
 } esr_conv_desc;
 
 /* Host-side weight packer (the K10 "weight packer" of SURVEY 7.2): OIHW fp32 (the layout of every

@@ -39,6 +39,8 @@ class ConvDesc(ctypes.Structure):
         ("tail_wpacked", ctypes.c_void_p), ("tail_cat", View),
         ("tail_cat_c", ctypes.c_int32), ("tail_cout", ctypes.c_int32),
         ("tail_mid_act", ctypes.c_int32), ("reserved2", ctypes.c_int32),
+        ("post_wpacked", ctypes.c_void_p), ("post_out", View),
+        ("post_cout", ctypes.c_int32), ("post_act", ctypes.c_int32),
     ]
 
 

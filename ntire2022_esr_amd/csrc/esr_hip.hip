@@ -65,6 +65,9 @@ struct ConvK {
     const float* cat;     // first `cat_chunks`*16 input channels of the 1x1
     int cat_pitch, cat_coff, cat_chunks;
     int mid_act;
+    // post 1x1 (PNT > 0 kernels): see esr_conv_desc.post_*
+    const float* wp3; const float* bias3; float* y2;
+    int y2_pitch, y2_coff, y2_cout4, post_act, post_nch8;
     int res_in;           // the (pre-activation) residual IS the conv input: taken from the staged tile, no residual loads
 #ifdef ESR_EXPERIMENTAL_WS
     int hand_rows;        // accumulator rows (of 4) finished by the loader partner
@@ -263,9 +266,14 @@ __device__ __forceinline__ void epilogue_shuffle(const ConvK& p, f32x4 (&acc)[NT
 // life of the block ([16-channel chunk][tile][lane][4]) and its result takes the ordinary epilogue.
 constexpr int TAIL_C16 = 4;                           // K of the 1x1 <= 64
 
-template <int NT, int KS, bool IN_NCHW, int NW, int TNT = 0>
+// PNT > 0: "post" 1x1 -- the activated output tile of this conv (its D fragments, again B fragments of a 1x1 whose K chunks
+// are this conv's output-channel tiles) also feeds a second 1x1 whose result goes to another view: RFDB's distillation
+// conv c{j+1}_d = lrelu(W . r_j) is computed by the kernel that produces r_j (rfdn_baseline/block.py:150-160) instead of
+// by a launch of its own that reads r_j back.
+template <int NT, int KS, bool IN_NCHW, int NW, int TNT = 0, int PNT = 0>
 __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
 {
+    static_assert(PNT == 0 || (TNT == 0 && KS == 3 && !IN_NCHW && NW == 8), "post 1x1: 8-wave 3x3 NHWC kernels");
     static_assert(TNT == 0 || (NT == 1 && KS == 3 && !IN_NCHW && NW == 4), "tail: 3x3, <= 16 channels, 4-wave blocks");
     constexpr int THREADS = 64 * NW;                  // shadows the file-scope constant: NW waves of 4 rows each
     constexpr int TILE_H = 4 * NW;
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
     constexpr int W_ROUNDS = (W_ITEMS + THREADS - 1) / THREADS;
     constexpr unsigned OOB = 0x80000000u;             // > any per-image byte offset (host checks < 2 GiB)
 
-    constexpr int TAIL_FLOATS = TNT ? TAIL_C16 * TNT * 256 + TNT * 16 : 0;     // 1x1 weight image + bias
+    constexpr int TAIL_FLOATS = TNT ? TAIL_C16 * TNT * 256 + TNT * 16 : (PNT ? NT * PNT * 256 + PNT * 16 : 0);   // 1x1 weight image + bias
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + NW * EPI_WAVE_FLOATS * 4 + TAIL_FLOATS * 4];
 
     // Issue priority: everything that is not the MFMA stream (staging, barrier, epilogue: a handful of
@@ -439,6 +447,21 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
         }
         if (tid < TNT * 16) wl[TAIL_C16 * TNT * 256 + tid] = p.bias2[tid];
     }
+    if (PNT) {
+        // same blob -> image transform as the tail's; K chunks of 16 = this conv's NT output tiles
+        const int nch8 = p.post_nch8;                        // <= 2 * NT; the image beyond it stays zero
+        for (int e = tid; e < NT * PNT * 256; e += THREADS) wl[e] = 0.f;
+        __syncthreads();
+        for (int q = tid; q < nch8 * PNT * 32; q += THREADS) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.wp3 + (size_t)q * 4);
+            const int ip = q & 7, kq8 = (q >> 3) & 3, ct = q >> 5;
+            const int tt = ct % PNT, chunk8 = ct / PNT;
+            const int ch16 = 8 * (chunk8 & 1) + 2 * kq8;
+            float* dst = wl + (((chunk8 >> 1) * PNT + tt) * 64 + (ch16 >> 2) * 16 + 2 * ip) * 4 + (ch16 & 3);
+            dst[0] = v.x; dst[1] = v.y; dst[4] = v.z; dst[5] = v.w;
+        }
+        if (tid < PNT * 16) wl[NT * PNT * 256 + tid] = p.bias3[tid];
+    }
     const size_t cat_img_floats = (size_t)p.H * p.W * p.cat_pitch;
 
     setup_tile(t, cur);
@@ -592,6 +615,53 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
                 if (C < p.cat_chunks) tail_chunk(C, bc[C]);
             tail_chunk(p.cat_chunks, acc[0]);
             epilogue_nhwc<(TNT ? TNT : 1)>(p, acc2, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE_H);
+        } else if (PNT) {
+            // post GEMM from activated copies of the fragments (host: no residual left for the epilogue, so act(acc) IS the
+            // conv's output), then the ordinary epilogue of the main output
+            f32x4 accd[PNT ? PNT : 1][4];
+#pragma unroll
+            for (int td = 0; td < PNT; ++td)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accd[td][r] = *reinterpret_cast<const f32x4*>(wl + NT * PNT * 256 + td * 16 + kq * 4);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                f32x4 bv[4];                                  // activated copy: the B operand of the post GEMM
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f32x4 v = acc[tt][r];
+                    v.x = act_any(v.x, p.act, p.slope); v.y = act_any(v.y, p.act, p.slope);
+                    v.z = act_any(v.z, p.act, p.slope); v.w = act_any(v.w, p.act, p.slope);
+                    bv[r] = v;
+                }
+                f32x4 a3[PNT ? PNT : 1];
+#pragma unroll
+                for (int td = 0; td < PNT; ++td) a3[td] = *reinterpret_cast<const f32x4*>(wl + ((tt * PNT + td) * 64 + lane) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int td = 0; td < PNT; ++td)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            accd[td][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[td][j], bv[r][j], accd[td][r], 0, 0, 0);
+            }
+            {
+                const int gx = cur.x0 + px;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gy = cur.y0 + wv * 4 + r;
+                    if (gy >= p.H || gx >= p.W) continue;
+                    float* dst = p.y2 + ((size_t)(cur.n * p.H + gy) * p.W + gx) * p.y2_pitch + p.y2_coff;
+#pragma unroll
+                    for (int td = 0; td < PNT; ++td) {
+                        if (td * 16 + kq * 4 >= p.y2_cout4) continue;
+                        f32x4 v = accd[td][r];
+                        v.x = act_any(v.x, p.post_act, p.slope); v.y = act_any(v.y, p.post_act, p.slope);
+                        v.z = act_any(v.z, p.post_act, p.slope); v.w = act_any(v.w, p.post_act, p.slope);
+                        *reinterpret_cast<f32x4*>(dst + td * 16 + kq * 4) = v;
+                    }
+                }
+            }
+            epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE_H);
         } else if (p.out_layout == ESR_NCHW_SHUFFLE4) epilogue_shuffle<NT>(p, acc, cur.n, cur.x0, cur.y0, wv, lane);
         else epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE_H);
         if (!has_next) break;
@@ -830,7 +900,10 @@ int launch_conv(const ConvK& k, hipStream_t st)
         ConvK kk = k;
         kk.tiles_y = tall_y;
         const int grid = ntall < 256 ? ntall : 256;
-        hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, CAN_TALL ? 8 : 4>), dim3(grid), dim3(512), 0, st, kk);
+        if (NT == 4 && kk.wp3)
+            hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, CAN_TALL ? 8 : 4, 0, (CAN_TALL && NT == 4) ? 2 : 0>), dim3(grid), dim3(512), 0, st, kk);
+        else
+            hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, CAN_TALL ? 8 : 4>), dim3(grid), dim3(512), 0, st, kk);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             set_err("conv_f32_kernel (tall) launch", e);
@@ -1110,6 +1183,22 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
         if (!d->tail_cat.ptr || (d->tail_cat.pitch & 3) || (d->tail_cat.coff & 3) || d->tail_cat.coff + d->tail_cat_c > d->tail_cat.pitch)
             return ESR_ERR_BAD_ARG;
     }
+    const bool post = d->post_wpacked != nullptr;
+    if (post) {
+        if (tail || d->ksize != 3 || in_nchw || d->out_layout != ESR_NHWC || d->cout <= 48 || d->cout > 64 ||
+            d->compute != ESR_COMPUTE_F32 || d->post_cout <= 0 || d->post_cout > 32)
+            return ESR_ERR_UNSUPPORTED;
+        const bool res_is_in = d->res_mode == ESR_RES_PRE_ACT && d->cin == d->cout && d->res.ptr == d->in.ptr &&
+                               d->res.pitch == d->in.pitch && d->res.coff == d->in.coff;
+        if (d->res_mode != ESR_RES_NONE && !res_is_in) return ESR_ERR_UNSUPPORTED;
+        if (d->split > 0 && d->split < d->cout) return ESR_ERR_UNSUPPORTED;
+        const int pc4 = round_up(d->post_cout, 4);
+        if (!d->post_out.ptr || (d->post_out.pitch & 3) || (d->post_out.coff & 3) || d->post_out.coff + pc4 > d->post_out.pitch)
+            return ESR_ERR_BAD_ARG;
+        if ((double)d->n * d->h * d->w * d->post_out.pitch >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
+        // the 1x1 reads the conv's output as 8-channel chunks when it has to run as a launch of its own (small shapes)
+        if (d->out0.coff + round_up(d->cout, CHUNK) > d->out0.pitch) return ESR_ERR_BAD_ARG;
+    }
     const int ecout = tail ? d->tail_cout : d->cout;          // channels the epilogue stores
     const int cout4 = round_up(ecout, 4);
     int split = d->split <= 0 ? cout4 : d->split;
@@ -1175,6 +1264,30 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
     k.tiles_x = (d->w + TILE - 1) / TILE;
     k.tiles_y = (d->h + TILE - 1) / TILE;
     k.wp2 = nullptr; k.bias2 = nullptr; k.cat = nullptr; k.cat_pitch = k.cat_coff = k.cat_chunks = 0; k.mid_act = ESR_ACT_NONE;
+    k.wp3 = nullptr; k.bias3 = nullptr; k.y2 = nullptr; k.y2_pitch = k.y2_coff = k.y2_cout4 = 0; k.post_act = ESR_ACT_NONE; k.post_nch8 = 0;
+    if (post) {
+        if (conv_block_waves(3, false, nt, k.nchunks, d->n, d->h, d->w) != 8) {
+            // small launch (4-wave shape, no room for the 1x1's weights next to two blocks per CU): two launches
+            esr_conv_desc a = *d;
+            a.post_wpacked = nullptr;
+            const int rc = esr_conv2d_f32(&a, hip_stream);
+            if (rc != ESR_OK) return rc;
+            esr_conv_desc b;
+            memset(&b, 0, sizeof(b));
+            b.n = d->n; b.h = d->h; b.w = d->w; b.cin = d->cout; b.cout = d->post_cout; b.ksize = 1;
+            b.in_layout = ESR_NHWC; b.out_layout = ESR_NHWC; b.act = d->post_act; b.slope = d->slope;
+            b.in = d->out0; b.out0 = d->post_out; b.wpacked = d->post_wpacked; b.compute = ESR_COMPUTE_F32;
+            return esr_conv2d_f32(&b, hip_stream);
+        }
+        k.wp3 = static_cast<const float*>(d->post_wpacked);
+        const int pnt = round_up(d->post_cout, 16) / 16;
+        if (pnt != 2) return ESR_ERR_UNSUPPORTED;              // post_cout in (16, 32]
+        k.bias3 = k.wp3 + (size_t)(round_up(d->cout, CHUNK) / CHUNK) * pnt * 128;
+        k.y2 = static_cast<float*>(d->post_out.ptr);
+        k.y2_pitch = d->post_out.pitch; k.y2_coff = d->post_out.coff; k.y2_cout4 = round_up(d->post_cout, 4);
+        k.post_act = d->post_act;
+        k.post_nch8 = round_up(d->cout, CHUNK) / CHUNK;
+    }
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     if (tail) {
         k.wp2 = static_cast<const float*>(d->tail_wpacked);

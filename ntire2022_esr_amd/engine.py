@@ -151,13 +151,16 @@ class Plan:
         return b
 
     def conv(self, wname, src, dst, cin, cout, k=3, act=L.ACT_NONE, slope=0.05,
-             res=None, res_mode=L.RES_NONE, dst1=None, split=0, hw=None, counted=True, tail=None):
+             res=None, res_mode=L.RES_NONE, dst1=None, split=0, hw=None, counted=True, tail=None, post=None):
         """src/dst/res: INPUT | OUTPUT | Buffer | (Buffer, coff, channels).  hw: spatial dims if not full-res.
         counted=False marks launches that are not an nn.Conv2d call of the reference (complexity counters).
         tail = dict(w=<1x1 weight name>, cat=<view of its other input channels>, cat_c, cout, mid_act): the 3x3 result
-        (cout <= 16) feeds a fused 1x1 (esr_conv_desc.tail_*); dst/res/act/split then belong to the 1x1."""
+        (cout <= 16) feeds a fused 1x1 (esr_conv_desc.tail_*); dst/res/act/split then belong to the 1x1.
+        post = dict(w=<1x1 weight name>, dst=<view>, cout, act): a 1x1 of this conv's activated output, stored to `dst`
+        by the same launch (esr_conv_desc.post_*)."""
         self.ops.append(dict(kind="conv", w=wname, src=src, dst=dst, dst1=dst1, cin=cin, cout=cout, k=k, act=act,
-                             slope=slope, res=res, res_mode=res_mode, split=split, hw=hw, counted=counted, tail=tail))
+                             slope=slope, res=res, res_mode=res_mode, split=split, hw=hw, counted=counted, tail=tail,
+                             post=post))
 
     def dwconv(self, wname, src, dst, c, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.RES_NONE, hw=None):
         """depthwise 3x3 + bias (+res) (+act): the dw half of BSConvU."""
@@ -266,6 +269,11 @@ class Plan:
                 d.tail_wpacked = ctypes.c_void_p(weights[t["w"]].data_ptr())
                 d.tail_cat = self._view(t["cat"], base)
                 d.tail_cat_c, d.tail_cout, d.tail_mid_act = t["cat_c"], t["cout"], t.get("mid_act", L.ACT_NONE)
+            t = o.get("post")
+            if t is not None:
+                d.post_wpacked = ctypes.c_void_p(weights[t["w"]].data_ptr())
+                d.post_out = self._view(t["dst"], base)
+                d.post_cout, d.post_act = t["cout"], t.get("act", L.ACT_NONE)
         return arr, in_idx, out_idx
 
 
@@ -332,7 +340,7 @@ class HipSRModel(nn.Module):
 
     def _uses_h16(self, o):
         return (self.compute != "f32" and o["kind"] == "conv" and o["k"] == 3 and o["hw"] is None and o["src"] is not INPUT
-                and o.get("tail") is None)        # the fused 3x3 -> 1x1 kernel exists for fp32 MFMA operands only
+                and o.get("tail") is None and o.get("post") is None)   # the fused 1x1 paths exist for fp32 MFMA operands only
 
     # -- packing ------------------------------------------------------------------------------
     def _signature(self):
@@ -451,6 +459,12 @@ class HipSRModel(nn.Module):
                     rd = 4.0 * (npix * (o["cin"] + t["cat_c"] + (t["cout"] if o["res"] is not None else 0))
                                 + o["cin"] * o["cout"] * 9 + k1 * t["cout"])
                     wr = 4.0 * npix * t["cout"]
+                t = o.get("post")
+                if t is not None:                   # + the 1x1 of the activated output, stored by the same launch
+                    if nw == 8:
+                        kern = kern[:-1] + f",POST={(t['cout'] + 15) // 16}>"
+                    flops += 2.0 * npix * o["cout"] * t["cout"]
+                    wr += 4.0 * npix * t["cout"]
                 out.append(dict(name=o["w"], kernel=kern, cin=o["cin"], cout=o["cout"], k=o["k"], flops=flops,
                                 read_bytes=rd, write_bytes=wr, ms_sum=ms[i], passes=passes.value))
         return out
@@ -477,6 +491,9 @@ class HipSRModel(nn.Module):
             if t is not None:                       # two nn.Conv2d calls of the reference in one launch
                 return [(o["cin"], o["cout"], o["k"], npix, t.get("mid_act", L.ACT_NONE)),
                         (t["cat_c"] + o["cout"], t["cout"], 1, npix, o["act"])]
+            t = o.get("post")
+            if t is not None:
+                return [(o["cin"], o["cout"], o["k"], npix, o["act"]), (o["cout"], t["cout"], 1, npix, t.get("act", L.ACT_NONE))]
             return [(o["cin"], o["cout"], o["k"], npix, o["act"])]
         if o["kind"] == "s2":
             return [(o["f"], o["f"], 3, plan.n * o["dst"].h * o["dst"].w, L.ACT_NONE)]

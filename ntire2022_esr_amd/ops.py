@@ -17,11 +17,13 @@ def _view(t, coff=0):
 def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.RES_NONE,
            in_nchw=False, shuffle_out=False, out=None, out_coff=0, in_coff=0, cin=None,
            split=0, out1=None, out1_coff=0, res_coff=0, packed=None, cin_map=None, compute="f32",
-           tail_weight=None, tail_bias=None, tail_cat=None, tail_cat_coff=0, tail_mid_act=L.ACT_NONE):
+           tail_weight=None, tail_bias=None, tail_cat=None, tail_cat_coff=0, tail_mid_act=L.ACT_NONE,
+           post_weight=None, post_bias=None, post_act=L.ACT_NONE):
     """Fused conv (k=1|3, stride 1, same padding) on the current stream.
 
     x       NHWC [N,H,W,pitch] (channels [in_coff, in_coff+cin) are read) or NCHW if in_nchw
     returns NHWC [N,H,W,cout] (or `out`), or NCHW [N,cout/16,4H,4W] if shuffle_out
+    post_*  esr_conv_desc.post_*: post_weight [pc, cout(, 1, 1)] applied to this conv's activated output; returns (y, post)
     tail_*  fused 1x1 (esr_conv_desc.tail_*): tail_weight [cout1, cat_c + 16(, 1, 1)] over concat(tail_cat slice,
             mid_act(this 3x3 conv)); act / res / out then apply to the 1x1, whose output is returned
     """
@@ -71,9 +73,16 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
     if res is not None:
         d.res = _view(res, res_coff)
     d.wpacked = ctypes.c_void_p(packed.data_ptr())
+    yp = None
+    if post_weight is not None:
+        pw = post_weight if post_weight.dim() == 4 else post_weight[:, :, None, None]
+        keep2 = pack_conv(pw, post_bias).to(x.device)
+        yp = torch.zeros((n, h, w, (pw.shape[0] + 3) // 4 * 4), dtype=torch.float32, device=x.device)
+        d.post_wpacked, d.post_out = ctypes.c_void_p(keep2.data_ptr()), _view(yp)
+        d.post_cout, d.post_act = pw.shape[0], post_act
     stream = torch.cuda.current_stream(x.device).cuda_stream
     L.check(lib.esr_conv2d_f32(ctypes.byref(d), ctypes.c_void_p(stream)), "esr_conv2d_f32")
-    return y
+    return y if yp is None else (y, yp)
 
 
 def tensor2uint_device(img_sr, data_range):

@@ -84,10 +84,17 @@ class RFDN(HipSRModel):
         for k in range(1, 5):
             b = f'B{k}.'
             plan.conv(b + 'c1_d', cur, cat[0:DP], nf, dc, k=1, **act)
-            plan.conv(b + 'c1_r', cur, r1, nf, nf, **res(cur), **act)
-            plan.conv(b + 'c2_d', r1, cat[DP:2 * DP], nf, dc, k=1, **act)
-            plan.conv(b + 'c2_r', r1, r2, nf, nf, **res(r1), **act)
-            plan.conv(b + 'c3_d', r2, cat[2 * DP:3 * DP], nf, dc, k=1, **act)
+            if self.compute == 'f32' and 48 < nf <= 64 and 16 < dc <= 32:
+                # the distillation conv of r_j rides in the epilogue of the conv that produces r_j (block.py:150-160)
+                plan.conv(b + 'c1_r', cur, r1, nf, nf, **res(cur), **act,
+                          post=dict(w=b + 'c2_d', dst=cat[DP:2 * DP], cout=dc, act=L.ACT_LRELU))
+                plan.conv(b + 'c2_r', r1, r2, nf, nf, **res(r1), **act,
+                          post=dict(w=b + 'c3_d', dst=cat[2 * DP:3 * DP], cout=dc, act=L.ACT_LRELU))
+            else:
+                plan.conv(b + 'c1_r', cur, r1, nf, nf, **res(cur), **act)
+                plan.conv(b + 'c2_d', r1, cat[DP:2 * DP], nf, dc, k=1, **act)
+                plan.conv(b + 'c2_r', r1, r2, nf, nf, **res(r1), **act)
+                plan.conv(b + 'c3_d', r2, cat[2 * DP:3 * DP], nf, dc, k=1, **act)
             plan.conv(b + 'c3_r', r2, r1, nf, nf, **res(r2), **act)
             plan.conv(b + 'c4', r1, cat[3 * DP:4 * DP], nf, dc, **act)
             plan.conv(b + 'c5', cat, v, 4 * DP, nf, k=1)

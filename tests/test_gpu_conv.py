@@ -271,3 +271,29 @@ def test_conv_residual_is_the_input(n, hw, c, act):
     xg = xg.to(dev)
     y = ops.conv2d(xg, w, b, act=act, slope=0.05, res=xg, res_mode=1, cin=c)
     _check(y, ref)
+
+
+@pytest.mark.parametrize("n,hw", [(1, (20, 24)), (5, (200, 136)), (3, (250, 250))])
+@pytest.mark.parametrize("c,pc,res_in", [(50, 25, True), (64, 32, False), (56, 20, True)])
+def test_conv_with_post_1x1(n, hw, c, pc, res_in):
+    """esr_conv_desc.post_*: r = lrelu(conv3x3(x) [+ x]) stored, and d = lrelu(W_p . r + b_p) stored by the same launch
+    (RFDB: the next distillation conv rides in the producer's epilogue); small shapes take the two-launch fallback."""
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(n + hw[0] + c + pc)
+    x = torch.randn(n, c, *hw, generator=g)
+    w = torch.randn(c, c, 3, 3, generator=g) * 0.1
+    b = torch.randn(c, generator=g)
+    wp = torch.randn(pc, c, generator=g) * 0.2
+    bp = torch.randn(pc, generator=g)
+    r = F.leaky_relu(F.conv2d(x, w, b, padding=1) + (x if res_in else 0), 0.05)
+    dref = F.leaky_relu(F.conv2d(r, wp[:, :, None, None], bp), 0.05)
+    pitch = (c + 7) // 8 * 8
+    xg = torch.zeros(n, *hw, pitch)
+    xg[..., :c] = x.permute(0, 2, 3, 1)
+    xg = xg.to(dev)
+    out = torch.zeros(n, *hw, pitch, device=dev)
+    y, yd = ops.conv2d(xg, w, b, act=1, slope=0.05, cin=c, out=out, res=xg if res_in else None, res_mode=1 if res_in else 0,
+                       post_weight=wp, post_bias=bp, post_act=1)
+    _check(y, r)
+    _check(yd, dref)

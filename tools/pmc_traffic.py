@@ -25,11 +25,15 @@ def per_kernel(d, counter):
 
 
 def label(sym):
-    m = re.search(r"conv_f32_kernel<(\d+), (\d+), (true|false), (\d+), (\d+)>", sym)
+    m = re.search(r"conv_f32_kernel<(\d+), (\d+), (true|false), (\d+), (\d+), (\d+)>", sym)
     if not m:
         return None
     base = f"conv_f32_kernel<NT={m.group(1)},KS={m.group(2)},NCHW_IN={int(m.group(3) == 'true')},NW={m.group(4)}"
-    return base + (f",TAIL={m.group(5)}>" if m.group(5) != "0" else ">")
+    if m.group(5) != "0":
+        base += f",TAIL={m.group(5)}"
+    if m.group(6) != "0":
+        base += f",POST={m.group(6)}"
+    return base + ">"
 
 
 def main():

@@ -878,11 +878,11 @@ inline int round_up(int v, int m) { return esr_round_up(v, m); }
 
 // Which conv_f32_kernel variant a launch takes: 8-wave blocks on 16x32-pixel tiles (one per CU) for large 3x3 NHWC
 // launches, else 4-wave blocks on 16x16 tiles (two per CU).  The eight waves share one weight stage, so a SIMD issues a
-// third fewer staging instructions per MFMA (they, not the MFMA pipe, bound this kernel: DESIGN.md).  ESR_TALL_MIN
-// overrides the launch-size threshold (tuning only).
+// third fewer staging instructions per MFMA (they, not the MFMA pipe, bound this kernel: DESIGN.md).
+constexpr int TALL_MIN_TILES = 256;        // one 16x32 tile per CU: below that the 4-wave shape fills the chip better
 inline int conv_block_waves(int ksize, bool in_nchw, int nt, int nchunks, int n, int h, int w)
 {
-    static const int tall_min = getenv("ESR_TALL_MIN") ? atoi(getenv("ESR_TALL_MIN")) : 256;
+    const int tall_min = TALL_MIN_TILES;
     if (ksize != 3 || in_nchw || nt < 3 || nchunks < 2) return 4;
     const long ntall = (long)n * ((w + TILE - 1) / TILE) * ((h + 31) / 32);
     return ntall >= tall_min ? 8 : 4;

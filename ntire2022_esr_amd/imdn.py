@@ -27,8 +27,9 @@ class IMDN(HipSRModel):
             raise AssertionError('Examples of activation function: R, L, BR, BL, IR, IL')
         if upsample_mode != 'pixelshuffle':
             raise NotImplementedError('upsample mode [{:s}] is not found'.format(upsample_mode))
-        if upscale != 4 or nc % 16 or nc > 64 or in_nc > 4 or (out_nc * 16) > 64:
-            raise NotImplementedError('HIP IMDN supports upscale=4, nc in {16,32,48,64}, in_nc<=4, out_nc<=4')
+        if upscale != 4 or nc not in (32, 64) or in_nc > 4 or (out_nc * 16) > 64:
+            # r_nc = 3/4 nc must be a whole number of 8-channel K chunks (esr_conv2d_f32: in.coff + round_up(cin, 8) <= pitch)
+            raise NotImplementedError('HIP IMDN supports upscale=4, nc in {32, 64}, in_nc<=4, out_nc<=4')
         self.in_nc, self.out_nc, self.nc, self.nb, self.upscale = in_nc, out_nc, nc, nb, upscale
         self.act = L.ACT_LRELU if 'L' in act_mode else L.ACT_RELU
         self.slope = negative_slope

@@ -19,7 +19,7 @@ def _entries():
     return {
         -1: ("IMDN_baseline", "imdn_baseline", 1.0, None, lambda: IMDN(in_nc=3, out_nc=3, nc=64, nb=8, upscale=4)),
         0: ("RFDN_baseline", "rfdn_baseline", 255.0, None, lambda: RFDN()),                    # test_demo.py:24-30
-        4: ("ByteESR", "team04_rlfn", 255.0, None, lambda: RLFN_cut(in_nc=3, out_nc=3)),        # test_demo.py:52-58
+        4: ("RLFN", "team04_rlfn", 255.0, None, lambda: RLFN_cut(in_nc=3, out_nc=3)),        # test_demo.py:52-58
         # free riders: same graphs, own checkpoints (test_demo.py:66-72, 175-181, 203-209)
         6: ("V1", "team06_v1", 1.0, None, lambda: RFDN(in_nc=3, nf=50, num_modules=4, out_nc=3, upscale=4)),
         22: ("RFDN40", "team22_rep_rfdn", 1.0, None, lambda: RFDN(in_nc=3, nf=40, num_modules=4, out_nc=3, upscale=4)),
@@ -29,7 +29,7 @@ def _entries():
              lambda: RFDN(in_nc=3, nf=40, num_modules=4, out_nc=3, upscale=4, block_residual=False, esa_f=12)),
         26: ("IMDN", "team26_imdn_nb7", 1.0, None, lambda: IMDN(in_nc=3, out_nc=3, nc=64, nb=7, upscale=4, act_mode='L',
                                                                 upsample_mode='pixelshuffle')),
-        18: ("XPixel", "team18_bsrn", 1.0, None,                                                 # test_demo.py:150-157
+        18: ("RFDNFINALB5", "team18_bsrn", 1.0, None,                                                 # test_demo.py:150-157
              lambda: BSRN(num_in_ch=3, num_feat=48, num_block=5, num_out_ch=3, upscale=4, conv='BSConvU',
                           upsampler='pixelshuffledirect')),
     }
@@ -45,7 +45,7 @@ def load_checkpoint(stem, model_zoo=None):
         for ext in (".pth", ".pt"):
             p = os.path.join(model_zoo, stem + ext)
             if os.path.exists(p):
-                sd = torch.load(p, map_location="cpu", weights_only=False)   # imdn_baseline.pth holds CUDA storages
+                sd = torch.load(p, map_location="cpu", weights_only=True)    # plain tensors only: no pickle code execution
                 return sd["params"] if isinstance(sd, dict) and "params" in sd and len(sd) == 1 else sd
     from safetensors.torch import load_file
     return load_file(os.path.join(_REPO, "weights", stem + ".safetensors"))

@@ -121,14 +121,17 @@ def test_imdn_plan_shape():
     m._build_plan(plan, 3)
     assert len(plan.ops) == 3 + 4 * 8
     assert sum(o.get("tail") is not None for o in plan.ops) == 8
-    assert plan.total == 2 * 40 * 56 * (64 * 3 + 48 * 3)                      # fea, xa, xb | cat (d1 d2 d3), r1, r2
-    assert m.workspace_bytes(2, 40, 56) == plan.total * 4
+    assert plan.total == 4 * 2 * 40 * 56 * (64 * 3 + 48 * 3)                  # bytes: fea, xa, xb | cat (d1 d2 d3), r1, r2
+    assert m.workspace_bytes(2, 40, 56) == plan.total
     total_macs = sum(cin * cout * k * k for o in plan.ops for (cin, cout, k, _, _) in m._counted_convs(plan, o))
     assert total_macs == 891584                                                # MAC per LR pixel
-    m48 = IMDN(nc=48)                                                          # no 16-channel distillation: unfused
+    m32 = IMDN(nc=32)                                                          # no 16-channel distillation: unfused
     plan = Plan(1, 40, 56)
-    m48._build_plan(plan, 3)
+    m32._build_plan(plan, 3)
     assert len(plan.ops) == 3 + 5 * 8 and all(o.get("tail") is None for o in plan.ops)
+    for nc in (16, 48):                                                        # 3/4 nc is not a whole number of 8-channel chunks
+        with pytest.raises(NotImplementedError):
+            IMDN(nc=nc)
 
 
 def test_h16_packer_layout_and_rounding():

@@ -1,32 +1,42 @@
 #!/usr/bin/env python3
-"""bench.py -- images/s of the IMDN x4 fp32 forward (256x256 -> 1024x1024) on N MI355X.
+"""bench.py -- images/s of the x4 SR forward path on N MI355X (default: IMDN fp32, 32 x 256x256 -> 1024x1024).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1 works both ways: under `python -m torch.distributed.run ... bench.py --gpus N ...` (RANK / LOCAL_RANK /
+      WORLD_SIZE / MASTER_* from the environment) and as a plain `python bench.py --gpus N`, which re-executes itself
+      under torch.distributed.run on 127.0.0.1 with N ranks.
 
-A "step" is one pass of the hot path (test_demo.py forward(), :364-367) over one batch of
-synthetic LR tiles already resident in HBM.  Image-level data parallelism: every
-rank holds a full replica and its own batch, there is no collective inside the timed region
-("scaling": "weak"); the only communication is the MAX-reduction of the elapsed time.
+Workloads (BASELINE.json configs):
+  [1] headline          python bench.py                                         IMDN x4 fp32, 32 x 3x256x256 per GPU
+  [2] RFDN bf16 DIV2K   python bench.py --model rfdn_baseline --compute bf16 --sizes div2k      B = 1, DIV2K-val LR shapes
+  [3] RLFN bf16 DIV2K   python bench.py --model team04_rlfn  --compute bf16 --sizes div2k
+  [4] BSRN fp16 tiles   python bench.py --model team18_bsrn  --compute f16 --tile 270x480
+
+A "step" is one pass of the hot path (test_demo.py forward(), :364-367) over one batch of synthetic LR input already
+resident in HBM (`--sizes div2k`: one pass over a fixed list of 10 DIV2K-val-shaped LR images, one image per forward like
+the reference's loop, test_demo.py:416-433).  Image-level data parallelism: every rank holds a full replica
+and its own inputs, there is no collective inside the timed region ("scaling": "weak"); the only communication is the
+MAX-reduction of the elapsed time (and a gather of the ranks that took part).
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline      dominant kernel (3x3 conv, 64 output channels, fp32 MFMA): algorithmic FLOPs per
-                launch / average launch duration from HIP events recorded on the launch stream
-                during the timed steps, against the dense fp32 MFMA peak (157.3 TFLOP/s)
-  cpu_baseline  the reference's CPU path restated (oracle/torch_port.py: the same ATen op sequence)
-                timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+  roofline      the kernel symbol with the largest share of the timed kernel time: ALGORITHMIC flops and HBM bytes per
+                launch / average launch duration from HIP events recorded on the launch stream during the timed steps,
+                against the dense MFMA peak of its operand type and the 8 TB/s HBM peak; `bound` names the binding one
+  cpu_baseline  the reference's CPU path restated (oracle/torch_port.py: the same ATen op sequence) timed on this box's
+                host cores on a bounded sample (rank 0, N=1 only)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-import torch
-
-FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-in MFMA
+HBM_PEAK_GBS = 8000.0                  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (about 6.3 TB/s achievable)
 MODELS = {
     # name -> (registry id, data_range, algorithmic GFLOP per 256x256 image: BASELINE.md section 2)
     "imdn_baseline": (-1, 1.0, 116.86),       # BASELINE.json configs[1]: the headline workload
@@ -35,6 +45,9 @@ MODELS = {
     "team18_bsrn": (18, 1.0, 18.86),
 }
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2516.0, "f16": 2516.0}   # dense MFMA peaks, MI355X_MICROARCH.md
+# LR shapes (H, W) of a DIV2K-validation-like mix (x4 bicubic of 2040-wide / 2040-tall 2K photographs): mostly 339x510
+DIV2K_LR_SHAPES = [(339, 510), (339, 510), (384, 510), (339, 510), (510, 339), (294, 510), (339, 510), (345, 510),
+                   (510, 384), (339, 510)]
 
 
 def build_model(name, device, compute):
@@ -45,11 +58,13 @@ def build_model(name, device, compute):
     return m, "checkpoint"
 
 
-def cpu_baseline(name, budget_s=14.0):
-    """The reference's PyTorch CPU path, restated op for op (oracle/torch_port.py), batch 1, fp32,
-    1x3x256x256.  A thread-count sweep first (oneDNN over-threads badly on a
-    256x256 tile: all physical cores is NOT the fastest setting on a 2x64-core host), then the best
-    setting is timed for the rest of the budget; `cores` = the thread count of the reported number."""
+def cpu_baseline(name, shape, budget_s=16.0):
+    """The reference's PyTorch CPU path, restated op for op (oracle/torch_port.py), batch 1, fp32, one LR image of the
+    bench workload's shape.  SURVEY 8d asks for P = 1 and P = all physical cores; oneDNN
+    over-threads badly on one small image (all cores is NOT the fastest setting on a 2x64-core host), so a thread-count
+    sweep is timed as well and the reported `value` is the FASTEST setting (the strongest baseline), `cores` its thread
+    count; every point of the sweep is in `points_ms`."""
+    import torch
     from safetensors.torch import load_file
     from oracle import torch_port as TP
     try:
@@ -59,10 +74,11 @@ def cpu_baseline(name, budget_s=14.0):
         phys = os.cpu_count()
     sd = load_file(os.path.join(REPO, "weights", name + ".safetensors"))
     dr = MODELS[name][1]
-    x = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(0)) * dr
+    x = torch.rand(1, 3, shape[0], shape[1], generator=torch.Generator().manual_seed(0)) * dr
     fwd = TP.FORWARD[name]
     cands = sorted({c for c in (8, 16, 32, 64, phys) if c <= phys})
     sweep = {}
+    t_start = time.perf_counter()
     with torch.no_grad():
         for c in cands:
             torch.set_num_threads(c)
@@ -77,94 +93,162 @@ def cpu_baseline(name, budget_s=14.0):
         torch.set_num_threads(best)
         fwd(sd, x)
         times = []
-        t_end = time.perf_counter() + max(3.0, budget_s - 3.2 * sum(sweep.values()))
+        t_end = time.perf_counter() + max(3.0, budget_s * 0.6 - (time.perf_counter() - t_start))
         while (time.perf_counter() < t_end and len(times) < 200) or len(times) < 5:
             t0 = time.perf_counter()
             fwd(sd, x)
             times.append(time.perf_counter() - t0)
+        torch.set_num_threads(1)                      # the P = 1 point: one timed forward (seconds of scalar-core work)
+        t0 = time.perf_counter()
+        fwd(sd, x)
+        p1 = time.perf_counter() - t0
     times.sort()
     med = times[len(times) // 2]
+    pts = {"1": round(p1 * 1e3, 1)}
+    pts.update({str(c): round(v * 1e3, 1) for c, v in sweep.items()})
     return {"value": round(1.0 / med, 3), "unit": "images/s", "cores": int(best), "kind": "port",
-            "sample": f"{len(times)} forwards of 1x3x256x256 fp32 (median {med * 1e3:.1f} ms) with "
-                      f"torch.set_num_threads({best}) = best of sweep "
-                      + ", ".join(f"{c}t:{v * 1e3:.0f}ms" for c, v in sweep.items())
-                      + f"; host has {phys} physical cores; oracle/torch_port.py = the reference's ATen op "
-                        "sequence on oneDNN"}
+            "points_ms": pts, "physical_cores": int(phys),
+            "p1_images_per_s": round(1.0 / p1, 3), "pall_images_per_s": round(1.0 / sweep[max(sweep)], 3),
+            "sample": f"{len(times)} forwards of 1x3x{shape[0]}x{shape[1]} fp32 (median {med * 1e3:.1f} ms) with "
+                      f"torch.set_num_threads({best}) = fastest of the sweep in points_ms (1 = one core, {max(sweep)} = all "
+                      f"{phys} physical cores); oracle/torch_port.py = the reference's ATen op sequence on oneDNN"}
 
 
-def main():
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="LR tiles per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="LR tiles per GPU per step (default 32; 1 with --sizes div2k)")
     ap.add_argument("--model", default="imdn_baseline", choices=sorted(MODELS))
     ap.add_argument("--compute", default="f32", choices=["f32", "bf16", "f16"],
-                    help="MFMA operand format of the full-resolution 3x3 convs (storage/accumulate fp32); "
-                         "the headline metric is f32")
+                    help="f32 (headline) | bf16 | f16 arithmetic of the 16-bit configs (BASELINE.json configs [2]-[4])")
+    ap.add_argument("--tile", default="256x256", help="LR tile HxW (config [4]: 270x480)")
+    ap.add_argument("--sizes", default="tile", choices=["tile", "div2k"],
+                    help="div2k: one step = the 10 DIV2K-val-shaped LR images of DIV2K_LR_SHAPES, one image per forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--b1-latency", action="store_true",
                     help="also report the latency of a single-image forward (extra launches after the timed region: "
                          "keep it off when the run is profiled, the B=1 launches would enter the per-kernel averages)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not record per-kernel HIP events during the timed steps")
-    args = ap.parse_args()
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="rendezvous + timing reduction only (gloo on CPU, NO forward, not a measurement): lets the N > 1 "
+                         "launch logic be tested on a box without GPUs")
+    return ap.parse_args()
 
+
+def main():
+    args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; the engine has no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+
+    import torch
+    selftest = args.launcher_selftest
+    if not selftest:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X; the engine has no CPU fallback"
+        torch.cuda.set_device(local_rank)
+    device = torch.device("cpu") if selftest else torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-
-    _, dr, gflop_per_img = MODELS[args.model]
-    model, weights = build_model(args.model, device, args.compute)
-    peak = PEAK_TFLOPS[args.compute]
-    B = args.batch
-    x = (torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(rank)) * dr).to(device)
+        if selftest:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        if not selftest:
+            torch.cuda.synchronize(device)
+
+    def reduce_elapsed(elapsed):
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        seen = [rank]
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            r = torch.tensor([rank], dtype=torch.int64, device=device)
+            allr = [torch.zeros_like(r) for _ in range(world)]
+            dist.all_gather(allr, r)
+            seen = sorted(int(v.item()) for v in allr)
+        return float(t.item()), seen
+
+    if selftest:
+        barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        barrier()
+        elapsed, seen = reduce_elapsed(time.perf_counter() - t0)
+        if rank == 0:
+            print(json.dumps({"launcher_selftest": True, "n_gpus": world, "ranks_seen": seen,
+                              "max_elapsed_s": round(elapsed, 4), "note": "no forward was run; not a measurement"}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    _, dr, gflop256 = MODELS[args.model]
+    model, weights = build_model(args.model, device, args.compute)
+    peak = PEAK_TFLOPS[args.compute]
+    th, tw = (int(v) for v in args.tile.lower().split("x"))
+    if args.sizes == "div2k":
+        B = args.batch or 1
+        shapes = DIV2K_LR_SHAPES
+    else:
+        B = args.batch or 32
+        shapes = [(th, tw)]
+    gen = torch.Generator().manual_seed(rank)
+    xs = [(torch.rand(B, 3, h, w, generator=gen) * dr).to(device) for h, w in shapes]
+    imgs_per_step = B * len(xs)
+    gflop_per_step = sum(B * gflop256 * (h * w) / 65536.0 for h, w in shapes)
+
+    def step():
+        for x in xs:
+            y = model(x)
+        return y
 
     with torch.no_grad():
         for _ in range(args.warmup):
-            y = model(x)
+            y = step()
         if not args.no_kernel_events:
             model.enable_profiling(args.steps)
-            model(x)                       # creates the events outside the timed region
+            step()                         # creates the events outside the timed region
             torch.cuda.synchronize(device)
             model.collect_profile()        # discard
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            y = model(x)
+            y = step()
         barrier()
         elapsed = time.perf_counter() - t0
-    assert tuple(y.shape) == (B, 3, 1024, 1024)
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    assert tuple(y.shape) == (B, 3, 4 * shapes[-1][0], 4 * shapes[-1][1])
+    elapsed, seen = reduce_elapsed(elapsed)
 
     roofline = None
     if not args.no_kernel_events:
         prof = model.collect_profile()
         model.disable_profiling()
         # dominant kernel = the kernel symbol with the largest share of the timed kernel time
-        # (IMDN fp32: the 3x3 conv with 4 output-channel tiles, i.e. all 64-output-channel 3x3 convs)
         by_kernel = {}
         for o in prof:
             by_kernel[o["kernel"]] = by_kernel.get(o["kernel"], 0.0) + o["ms_sum"]
@@ -172,53 +256,71 @@ def main():
         dom = [o for o in prof if o["kernel"] == dom_name]
         launches = sum(o["passes"] for o in dom)
         ms = sum(o["ms_sum"] for o in dom)
-        flops = sum(o["flops"] * o["passes"] for o in dom)
+        flops = sum(o["flops"] * o["passes"] for o in dom) / launches
+        nbytes = sum((o["read_bytes"] + o["write_bytes"]) * o["passes"] for o in dom) / launches
         total_ms = sum(o["ms_sum"] for o in prof)
-        avg_ms = ms / launches
-        achieved = flops / launches / (avg_ms * 1e-3) / 1e12
-        traffic = None
+        avg_s = ms / launches * 1e-3
+        tflops, gbs = flops / avg_s / 1e12, nbytes / avg_s / 1e9
+        kpeak = peak if ("h16" in dom_name or "s16" in dom_name) else PEAK_TFLOPS["f32"]   # fp32-MFMA kernels in every mode
+        f_mfma, f_hbm = tflops / kpeak, gbs / HBM_PEAK_GBS
+        traffic, traffic_src = None, None
         tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.sizes == "tile" and (th, tw, B) == (256, 256, 32):
             try:
-                traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch") if args.batch == 32 else None
+                traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
+                traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command on an earlier run, NOT this run)"
             except Exception:
                 traffic = None
-        if args.compute == "f32" or not dom_name.startswith("conv_"):
-            roofline = {"bound": "mfma", "kernel": dom_name + " (3x3 conv, fp32 v_mfma_f32_16x16x4_f32)",
-                        "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(achieved / peak, 4), "traffic": traffic}
+        if f_mfma >= f_hbm:
+            roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(tflops, 2), "peak": kpeak, "unit": "TFLOP/s",
+                        "frac": round(f_mfma, 4), "traffic": traffic}
         else:
-            # 16-bit operands with fp32 storage: the conv is HBM-bound; algorithmic bytes per launch =
-            # input + output activations at 4 B (weights are KBs)
-            gb = sum((o["cin"] + o["cout"]) * 4.0 * B * 65536 * o["passes"] for o in dom) / launches / 1e9
-            roofline = {"bound": "hbm", "kernel": dom_name + " (3x3 conv, 16-bit MFMA operands, fp32 storage)",
-                        "achieved": round(gb / (avg_ms * 1e-3), 1), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(gb / (avg_ms * 1e-3) / 8000.0, 4), "traffic": None}
-        roofline.update({
-                    "launches": launches, "avg_launch_ms": round(avg_ms, 4),
-                    "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
-                    "share_of_kernel_time": round(ms / total_ms, 4)})
+            roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(f_hbm, 4), "traffic": traffic}
+        roofline.update({"traffic_source": traffic_src, "launches": launches, "avg_launch_ms": round(ms / launches, 4),
+                         "algorithmic_gflop_per_launch": round(flops / 1e9, 3),
+                         "algorithmic_mb_per_launch": round(nbytes / 1e6, 2),
+                         "frac_of_mfma_peak": round(f_mfma, 4), "frac_of_hbm_peak": round(f_hbm, 4),
+                         "share_of_kernel_time": round(ms / total_ms, 4)})
+        # every kernel symbol: share of the step, achieved TFLOP/s and GB/s on algorithmic work
+        table = []
+        for kn, kms in sorted(by_kernel.items(), key=lambda kv: -kv[1]):
+            ops = [o for o in prof if o["kernel"] == kn]
+            n = sum(o["passes"] for o in ops)
+            fl = sum(o["flops"] * o["passes"] for o in ops)
+            by = sum((o["read_bytes"] + o["write_bytes"]) * o["passes"] for o in ops)
+            table.append({"kernel": kn, "share": round(kms / total_ms, 4), "avg_ms": round(kms / n, 4),
+                          "tflops": round(fl / (kms * 1e-3) / 1e12, 2), "gbs": round(by / (kms * 1e-3) / 1e9, 1)})
+        roofline["kernels"] = table
 
     if rank == 0:
-        imgs = world * B * args.steps
+        imgs = world * imgs_per_step * args.steps
         value = imgs / elapsed
+        if args.sizes == "div2k":
+            wl = (f"{args.model} x4 {args.compute}, DIV2K-val-shaped LR images {sorted(set(shapes))} "
+                  f"({len(shapes)} per step, B = {B} per forward)")
+            metric = "images/sec (DIV2K-val-shaped LR ~339x510 -> x4)"
+        else:
+            wl = f"{args.model} x4 {args.compute}, {B}x3x{th}x{tw} LR batch per GPU -> {B}x3x{4 * th}x{4 * tw}"
+            metric = f"images/sec ({th}x{tw}->{4 * th}x{4 * tw} x4)"
+        model_tflops = world * gflop_per_step * args.steps / elapsed / 1e3
         out = {
-            "metric": "images/sec (256x256->1024x1024 x4)",
+            "metric": metric,
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.compute,
             "data": f"synthetic (uniform [0,{dr:g}) LR tiles resident in HBM; weights: {weights})",
-            "config": {"workload": f"{args.model} x4 {args.compute}, {B}x3x256x256 LR batch per GPU -> {B}x3x1024x1024",
-                       "batch_per_gpu": B, "parallelism": f"image-parallel replicas x{world}",
-                       "algorithmic_gflop_per_image": gflop_per_img},
-            "model_tflops": round(value * gflop_per_img / 1e3, 2),
-            "model_frac_of_mfma_peak": round(value * gflop_per_img / 1e3 / (peak * world), 4),
+            "config": {"workload": wl, "batch_per_gpu": B, "parallelism": f"image-parallel replicas x{world}",
+                       "algorithmic_gflop_per_step_per_gpu": round(gflop_per_step, 2)},
+            "ranks_seen": seen,
+            "model_tflops": round(model_tflops, 2),
+            "model_frac_of_mfma_peak": round(model_tflops / (peak * world), 4),
             "roofline": roofline,
         }
         if world == 1 and args.b1_latency:
             # the reference's own semantics (test_demo.py:416-433: one image per forward), outside the timed region
             with torch.no_grad():
-                x1 = x[:1].contiguous()
+                x1 = xs[0][:1].contiguous()
                 for _ in range(5):
                     model(x1)
                 torch.cuda.synchronize(device)
@@ -228,7 +330,7 @@ def main():
                 torch.cuda.synchronize(device)
             out["b1_latency_ms"] = round((time.perf_counter() - t1) / 50 * 1e3, 3)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.model)
+            out["cpu_baseline"] = cpu_baseline(args.model, shapes[0])
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if dist is not None:

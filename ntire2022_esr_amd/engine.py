@@ -166,16 +166,17 @@ class Plan:
         return b
 
     def conv(self, wname, src, dst, cin, cout, k=3, act=L.ACT_NONE, slope=0.05,
-             res=None, res_mode=L.RES_NONE, dst1=None, split=0, hw=None, counted=True, tail=None, post=None):
+             res=None, res_mode=L.RES_NONE, dst1=None, split=0, hw=None, counted=True, tail=None, post=None, cin_alg=None):
         """src/dst/res: INPUT | OUTPUT | Buffer | (Buffer, coff, channels).  hw: spatial dims if not full-res.
         counted=False marks launches that are not an nn.Conv2d call of the reference (complexity counters).
         tail = dict(w=<1x1 weight name>, cat=<view of its other input channels>, cat_c, cout, mid_act): the 3x3 result
         (cout <= 16) feeds a fused 1x1 (esr_conv_desc.tail_*); dst/res/act/split then belong to the 1x1.
         post = dict(w=<1x1 weight name>, dst=<view>, cout, act): a 1x1 of this conv's activated output, stored to `dst`
-        by the same launch (esr_conv_desc.post_*)."""
+        by the same launch (esr_conv_desc.post_*).  cin_alg: logical input channels when `cin` counts the pad slots of a
+        padded concat buffer (algorithmic flops / bytes)."""
         self.ops.append(dict(kind="conv", w=wname, src=src, dst=dst, dst1=dst1, cin=cin, cout=cout, k=k, act=act,
                              slope=slope, res=res, res_mode=res_mode, split=split, hw=hw, counted=counted, tail=tail,
-                             post=post))
+                             post=post, cin_alg=cin if cin_alg is None else cin_alg))
 
     def dwconv(self, wname, src, dst, c, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.RES_NONE, hw=None):
         """depthwise 3x3 + bias (+res) (+act): the dw half of BSConvU."""
@@ -508,52 +509,90 @@ class HipSRModel(nn.Module):
         self._profs = {}
         self._prof_passes = 0
 
-    def collect_profile(self):
-        """After a device synchronise: list of dicts {name, kernel, flops, ms_sum, passes} per op, summed
-        over the recorded passes of every cached shape."""
+    def op_costs(self, plan, arr=None):
+        """Per op of `plan`: device kernel symbol, ALGORITHMIC flops (2 x MACs of the matrix products the op stands
+        for) and ALGORITHMIC HBM bytes (every input slice / residual / weight read once, every output written once,
+        at the storage type of the buffer) -- the numerators of bench.py's roofline leg."""
+        es = plan.esize
         out = []
-        for key, prof in self._profs.items():
-            ent = self._plans.get(key)
-            if ent is None or ent.arr is None:
-                continue
-            arr, plan = ent.arr, ent.plan
-            n = len(arr)
-            ms = (ctypes.c_double * n)()
-            passes = ctypes.c_int(0)
-            L.check(L.lib().esr_prof_collect(prof, ms, n, ctypes.byref(passes)), "esr_prof_collect")
-            for i, o in enumerate(plan.ops):
-                if o["kind"] != "conv":
-                    kern = {"s2": "conv3x3s2_kernel", "pool": "maxpool7s3_kernel", "apply": "esa_apply_kernel",
-                            "dw": "dwconv3x3_kernel", "bs": "bsconv_kernel"}[o["kind"]]
-                    out.append(dict(name=o.get("w", o["kind"]), kernel=kern, cin=0, cout=0, k=0, flops=0.0,
-                                    ms_sum=ms[i], passes=passes.value))
-                    continue
+        for i, o in enumerate(plan.ops):
+            kind = o["kind"]
+            hw = o.get("hw")
+            npix = plan.npix if hw is None else plan.n * hw[0] * hw[1]
+            e_act = es if hw is None else 4                       # low-resolution maps are fp32
+            if kind == "conv":
                 nt = (o["cout"] + 15) // 16
-                nw = L.lib().esr_conv_block_waves(ctypes.byref(arr[i].conv))
+                nw = L.lib().esr_conv_block_waves(ctypes.byref(arr[i].conv)) if arr is not None else 0
                 kern = f"conv_f32_kernel<NT={nt},KS={o['k']},NCHW_IN={int(o['src'] is INPUT)},NW={nw}>"
                 if self._uses_h16(o):
                     kern = f"conv_h16_kernel<NT={nt},{self.compute}>"
-                npix = plan.npix if o["hw"] is None else plan.n * o["hw"][0] * o["hw"][1]
-                # algorithmic HBM bytes: input slice + residual + weights read once, output written once (fp32 storage)
-                rd = 4.0 * (npix * (o["cin"] + (o["cout"] if o["res"] is not None else 0)) + o["cin"] * o["cout"] * o["k"] ** 2)
-                flops = 2.0 * npix * o["cin"] * o["cout"] * o["k"] * o["k"]
-                wr = 4.0 * npix * o["cout"]
+                e_in = 4 if o["src"] is INPUT else e_act
+                e_out = 4 if o["dst"] is OUTPUT else e_act
+                ca = o["cin_alg"]
+                rd = npix * (ca * e_in + (o["cout"] * e_act if o["res"] is not None else 0)) + 4.0 * ca * o["cout"] * o["k"] ** 2
+                wr = float(npix * o["cout"] * e_out)
+                flops = 2.0 * npix * ca * o["cout"] * o["k"] * o["k"]
                 t = o.get("tail")
                 if t is not None:                   # 3x3 -> 1x1 in one kernel: both GEMMs' flops, the 1x1's traffic
                     kern = f"conv_f32_kernel<NT={nt},KS=3,NCHW_IN=0,NW=4,TAIL={(t['cout'] + 15) // 16}>"
                     k1 = t["cat_c"] + o["cout"]
                     flops += 2.0 * npix * k1 * t["cout"]
-                    rd = 4.0 * (npix * (o["cin"] + t["cat_c"] + (t["cout"] if o["res"] is not None else 0))
-                                + o["cin"] * o["cout"] * 9 + k1 * t["cout"])
-                    wr = 4.0 * npix * t["cout"]
+                    rd = npix * e_act * (o["cin"] + t["cat_c"] + (t["cout"] if o["res"] is not None else 0)) \
+                        + 4.0 * (o["cin"] * o["cout"] * 9 + k1 * t["cout"])
+                    wr = float(npix * e_act * t["cout"])
                 t = o.get("post")
                 if t is not None:                   # + the 1x1 of the activated output, stored by the same launch
                     if nw == 8:
                         kern = kern[:-1] + f",POST={(t['cout'] + 15) // 16}>"
                     flops += 2.0 * npix * o["cout"] * t["cout"]
-                    wr += 4.0 * npix * t["cout"]
-                out.append(dict(name=o["w"], kernel=kern, cin=o["cin"], cout=o["cout"], k=o["k"], flops=flops,
-                                read_bytes=rd, write_bytes=wr, ms_sum=ms[i], passes=passes.value))
+                    wr += npix * e_act * t["cout"]
+            elif kind == "bs":                      # pointwise (+ distillation) GEMM + depthwise, one launch
+                t = o["distill"]
+                dco = t["cout"] if t is not None else 0
+                kern = f"bsconv_kernel<NTP={(o['cout'] + 15) // 16},NTD={(dco + 15) // 16}>"
+                flops = 2.0 * npix * (o["cin"] * (o["cout"] + dco) + 9 * o["cout"])
+                rd = npix * e_act * (o["cin"] + (o["cout"] if o["res"] is not None else 0)) + 4.0 * (o["cin"] * (o["cout"] + dco) + 10 * o["cout"])
+                wr = float(npix * e_act * (o["cout"] + dco))
+            elif kind == "dw":
+                kern = "dwconv3x3_kernel"
+                flops = 2.0 * 9 * o["cout"] * npix
+                rd = float(npix * e_act * (o["cin"] + (o["cout"] if o["res"] is not None else 0)))
+                wr = float(npix * e_act * o["cout"])
+            elif kind == "s2":                      # reads the full-resolution conv1 map, writes the half-resolution one
+                kern = "conv3x3s2_kernel"
+                src = o["src"]
+                flops = 2.0 * 9 * o["f"] * o["f"] * npix
+                rd = float(plan.n * src.h * src.w * o["f"] * src.esize)
+                wr = float(npix * o["f"] * 4)
+            elif kind == "pool":
+                kern = "maxpool7s3_kernel"
+                flops = 0.0
+                rd = float(plan.n * o["src"].h * o["src"].w * 16 * 4)
+                wr = float(plan.n * o["dst"].h * o["dst"].w * 16 * 4)
+            else:                                   # apply: conv_f (f x f) + conv4 (f x c) per pixel, x read, y written
+                kern = "esa_apply_kernel"
+                flops = 2.0 * plan.npix * (o["f"] * o["f"] + o["f"] * o["c"])
+                rd = float(plan.npix * es * (o["c"] + o["f"]) + plan.n * o["c3"].h * o["c3"].w * o["f"] * 4)
+                wr = float(plan.npix * es * o["c"])
+            out.append(dict(name=o.get("w", kind), kernel=kern, cin=o.get("cin", 0), cout=o.get("cout", 0), k=o.get("k", 0),
+                            flops=flops, read_bytes=rd, write_bytes=wr))
+        return out
+
+    def collect_profile(self):
+        """After a device synchronise: list of dicts {name, kernel, flops, read_bytes, write_bytes, ms_sum, passes} per
+        op, summed over the recorded passes of every cached shape."""
+        out = []
+        for key, prof in self._profs.items():
+            ent = self._plans.get(key)
+            if ent is None or ent.arr is None:
+                continue
+            n = len(ent.arr)
+            ms = (ctypes.c_double * n)()
+            passes = ctypes.c_int(0)
+            L.check(L.lib().esr_prof_collect(prof, ms, n, ctypes.byref(passes)), "esr_prof_collect")
+            for i, c in enumerate(self.op_costs(ent.plan, ent.arr)):
+                c.update(ms_sum=ms[i], passes=passes.value, shape=key[:4])
+                out.append(c)
         return out
 
     def _complexity_terms(self, plan, o):

@@ -97,7 +97,7 @@ class RFDN(HipSRModel):
                 plan.conv(b + 'c3_d', r2, cat[2 * DP:3 * DP], nf, dc, k=1, **act)
             plan.conv(b + 'c3_r', r2, r1, nf, nf, **res(r2), **act)
             plan.conv(b + 'c4', r1, cat[3 * DP:4 * DP], nf, dc, **act)
-            plan.conv(b + 'c5', cat, v, 4 * DP, nf, k=1)
+            plan.conv(b + 'c5', cat, v, 4 * DP, nf, k=1, cin_alg=4 * dc)
             plan.conv(b + 'esa.conv1', v, c1, nf, f, k=1)
             plan.conv3x3s2(b + 'esa.conv2', c1, lo2, f)
             plan.maxpool7s3(lo2, la)
@@ -107,7 +107,7 @@ class RFDN(HipSRModel):
             out = bcat[(k - 1) * P:k * P]
             plan.esa_apply(b + 'esa.conv_f', b + 'esa.conv4', v, c1, lb, out, nf, f)
             cur = out
-        plan.conv('c.0', bcat, v, 4 * P, nf, k=1, **act)
+        plan.conv('c.0', bcat, v, 4 * P, nf, k=1, cin_alg=4 * nf, **act)
         plan.conv('LR_conv', v, r1, nf, nf, res=fea, res_mode=L.RES_PRE_ACT)
         plan.conv('upsampler.0', r1, OUTPUT, nf, self.out_nc * 16)
 

@@ -1,0 +1,131 @@
+"""-m gpu: BASELINE.json configs [2]-[4] at their STATED sizes against vectors produced by the real reference
+(tools/gen_golden_r2.py): a DIV2K-val-shaped 339x510 LR image and a 256x256 one for all four networks, the 270x480
+tile for BSRN / RLFN -- in fp32 (<= 2e-5 * data_range, uint8 flips <= 0.02 % all +-1, |dPSNR| <= 0.002 dB) and in
+the 16-bit modes, where the budget of BASELINE.md section 4 / SURVEY 8c is asserted against the REFERENCE's PSNR:
+bf16 <= 0.01 dB, fp16 <= 0.005 dB."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+IDS = {"imdn_baseline": -1, "rfdn_baseline": 0, "team04_rlfn": 4, "team18_bsrn": 18}
+BUDGET = {"f32": 0.002, "bf16": 0.01, "f16": 0.005}
+CASES = [("imdn_baseline", 339, 510), ("rfdn_baseline", 339, 510), ("team04_rlfn", 339, 510), ("team18_bsrn", 339, 510),
+         ("team18_bsrn", 270, 480), ("team04_rlfn", 270, 480),
+         ("imdn_baseline", 256, 256), ("rfdn_baseline", 256, 256), ("team04_rlfn", 256, 256), ("team18_bsrn", 256, 256)]
+
+_models = {}
+
+
+def _model(name, compute):
+    from ntire2022_esr_amd.registry import select_model
+    if name not in _models:
+        _models[name] = select_model(IDS[name], torch.device(DEV))
+    m, _, dr, _ = _models[name]
+    m.set_compute(compute)
+    return m, dr
+
+
+def _hr(h4, w4):
+    """what tools/gen_golden_r2.py used as ground truth: utils/test.bmp mirror-tiled"""
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(GOLD, "test.bmp")).convert("RGB"))
+    return np.pad(img, ((0, h4 - img.shape[0]), (0, w4 - img.shape[1]), (0, 0)), mode="symmetric")
+
+
+@pytest.mark.parametrize("name,h,w", CASES)
+def test_fp32_matches_reference_at_stated_size(name, h, w):
+    from ntire2022_esr_amd import image_util as util
+    g = np.load(os.path.join(GOLD, f"big_{name}_{h}x{w}.npz"))
+    m, dr = _model(name, "f32")
+    assert float(g["data_range"]) == dr and g["lr"].shape == (h, w, 3)
+    y = m(util.uint2tensor4(g["lr"], dr).to(DEV))
+    assert tuple(y.shape) == (1, 3, 4 * h, 4 * w)
+    err = float(np.abs(y[0, :, ::9, ::9].cpu().numpy().astype(np.float64) - g["sr_sample"]).max()) / dr
+    assert err < 2e-5, err
+    assert abs(float(y.double().mean()) - float(g["sr_mean"])) < 2e-6 * dr
+    y8 = util.tensor2uint(y, dr)
+    d = np.abs(y8[600:728, 700:828].astype(np.int32) - g["sr_u8_crop"].astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() <= 2e-4
+    psnr = util.calculate_psnr(y8, _hr(4 * h, 4 * w), border=4)
+    assert abs(psnr - float(g["psnr"])) <= BUDGET["f32"], (psnr, float(g["psnr"]))
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
+@pytest.mark.parametrize("name,h,w", CASES)
+def test_16bit_psnr_budget_at_stated_size(name, h, w, compute):
+    from ntire2022_esr_amd import image_util as util
+    g = np.load(os.path.join(GOLD, f"big_{name}_{h}x{w}.npz"))
+    m, dr = _model(name, compute)
+    try:
+        y = m(util.uint2tensor4(g["lr"], dr).to(DEV))
+        psnr = util.calculate_psnr(util.tensor2uint(y, dr), _hr(4 * h, 4 * w), border=4)
+        rel = float(np.abs(y[0, :, ::9, ::9].cpu().numpy() - g["sr_sample"]).max()) / dr
+    finally:
+        m.set_compute("f32")
+    print(f"{name} {h}x{w} {compute}: PSNR {psnr:.4f} vs reference {float(g['psnr']):.4f} dB "
+          f"(d = {psnr - float(g['psnr']):+.4f}), max|dy|/range = {rel:.2e}")
+    assert abs(psnr - float(g["psnr"])) <= BUDGET[compute]
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
+@pytest.mark.parametrize("name", sorted(IDS))
+def test_16bit_mean_psnr_shift_small_set(name, compute):
+    """mean |dPSNR| vs the reference over test.bmp at 256x256 LR + the three mini_div2k images (the set VERDICT r01 names)"""
+    from ntire2022_esr_amd import image_util as util
+    m, dr = _model(name, compute)
+    ref = json.load(open(os.path.join(GOLD, "mini_div2k", "reference_psnr.json")))[name]["valid_psnr"]
+    d = []
+    try:
+        g = np.load(os.path.join(GOLD, f"big_{name}_256x256.npz"))
+        y8 = util.tensor2uint(m(util.uint2tensor4(g["lr"], dr).to(DEV)), dr)
+        d.append(util.calculate_psnr(y8, _hr(1024, 1024), border=4) - float(g["psnr"]))
+        for i in range(3):
+            lr = util.imread_uint(os.path.join(GOLD, "mini_div2k", "DIV2K_valid_LR", f"{801 + i:04}x4.png"))
+            hr = util.modcrop(util.imread_uint(os.path.join(GOLD, "mini_div2k", "DIV2K_valid_HR", f"{801 + i:04}.png")), 4)
+            y8 = util.tensor2uint(m(util.uint2tensor4(lr, dr).to(DEV)), dr)
+            d.append(util.calculate_psnr(y8, hr, border=4) - ref[i])
+    finally:
+        m.set_compute("f32")
+    print(f"{name} {compute}: dPSNR per image {['%+.4f' % v for v in d]}, mean |d| = {np.mean(np.abs(d)):.4f} dB")
+    assert np.mean(np.abs(d)) <= BUDGET[compute]
+
+
+@pytest.mark.parametrize("name", ["imdn_baseline", "rfdn_baseline"])
+def test_tiled_forward_matches_reference(name):
+    """the overlap-tiled forward() (test_demo.py:368-389) against the reference's own tiled output"""
+    from ntire2022_esr_amd import harness as H
+    g = np.load(os.path.join(GOLD, f"tiled_{name}.npz"))
+    m, dr = _model(name, "f32")
+    y = H.forward(torch.from_numpy(g["x"]).to(DEV), m, tile=int(g["tile"]), tile_overlap=int(g["overlap"]))
+    err = float(np.abs(y[0, :, ::3, ::3].cpu().numpy().astype(np.float64) - g["y_sample"]).max()) / dr
+    assert err < 2e-5, err
+    assert abs(float(y.double().mean()) - float(g["y_mean"])) < 2e-6 * dr
+
+
+def test_hundred_shapes_one_workspace():
+    """DIV2K has ~100 distinct LR shapes: plans are cached (LRU), the workspace is ONE grow-only allocation that is
+    re-zeroed on a shape switch, and results do not depend on what ran before."""
+    m, dr = _model("team04_rlfn", "f32")
+    g = torch.Generator().manual_seed(0)
+    x0 = (torch.rand(1, 3, 40, 56, generator=g) * dr).to(DEV)
+    y0 = m(x0).clone()
+    shapes = [(24 + (i * 7) % 41, 20 + (i * 11) % 53) for i in range(100)]
+    big = max(m.workspace_bytes(1, h, w) for h, w in shapes)
+    for h, w in shapes:
+        m.prepare((1, 3, h, w), DEV)
+        m((torch.rand(1, 3, h, w, generator=g) * dr).to(DEV))
+    torch.cuda.synchronize()
+    assert len(m._plans) <= m.MAX_PLANS and m._ws.numel() >= big
+    base = m._ws.data_ptr()
+    for h, w in shapes[:20]:                                  # second pass: nothing is re-planned or re-allocated
+        ent = m._plans[(1, 3, h, w, torch.device(DEV))]
+        m((torch.rand(1, 3, h, w, generator=g) * dr).to(DEV))
+        assert m._plans[(1, 3, h, w, torch.device(DEV))] is ent and m._ws.data_ptr() == base
+    assert torch.equal(m(x0), y0)

@@ -44,12 +44,12 @@ def test_h16_rejects_unsupported():
                    packed=torch.zeros(4096, device=DEV), compute="bf16")            # 1x1 has no 16-bit path
 
 
-@pytest.mark.parametrize("mid,compute,max_dpsnr", [(-1, "f16", 0.002), (-1, "bf16", 0.03), (0, "bf16", 0.03), (4, "bf16", 0.03),
-                                                   (4, "f16", 0.002), (18, "f16", 0.002)])
+@pytest.mark.parametrize("mid,compute,max_dpsnr", [(-1, "f16", 0.005), (-1, "bf16", 0.01), (0, "bf16", 0.01), (4, "bf16", 0.01),
+                                                   (4, "f16", 0.005), (18, "f16", 0.005), (0, "f16", 0.005), (18, "bf16", 0.01)])
 def test_network_psnr_shift(mid, compute, max_dpsnr):
     """PSNR of the 16-bit-operand network vs the fp32 network's PSNR on the natural image (64x64 bicubic LR of
-    utils/test.bmp -> 256x256 vs the original): |dPSNR| budget per SURVEY 8c (fp16 <= 0.005, bf16 to be engineered
-    to <= 0.01 on DIV2K; here bounded at 0.03 on one image, the measured value is printed)."""
+    utils/test.bmp -> 256x256 vs the original): |dPSNR| budget per SURVEY 8c / BASELINE.md section 4: fp16 <= 0.005 dB,
+    bf16 <= 0.01 dB (the stated-size cases against the REFERENCE's PSNR are in test_gpu_big.py)."""
     from PIL import Image
     from ntire2022_esr_amd import image_util as util
     from ntire2022_esr_amd.registry import select_model

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESR_ABI_VERSION 3
+#define ESR_ABI_VERSION 4
 
 typedef enum esr_status {
     ESR_OK = 0,
@@ -47,11 +47,19 @@ typedef enum esr_act { ESR_ACT_NONE = 0, ESR_ACT_LRELU = 1, ESR_ACT_RELU = 2, ES
  *   POST: act(conv(x)) + r   RLFB  team04_rlfn.py:117-119 */
 typedef enum esr_res { ESR_RES_NONE = 0, ESR_RES_PRE_ACT = 1, ESR_RES_POST_ACT = 2 } esr_res;
 
-/* arithmetic of the matrix products (storage and accumulation are always fp32):
- *   F32   exact fp32 MFMA (v_mfma_f32_16x16x4_f32)
- *   BF16 / F16   operands rounded (RNE) to bf16 / fp16, v_mfma_f32_16x16x16_{bf16,f16}, fp32 accumulate;
- *                3x3 NHWC convolutions only; wpacked must come from esr_pack_conv_h16 */
+/* arithmetic of the matrix products (accumulation is always fp32):
+ *   F32          exact fp32 MFMA (v_mfma_f32_16x16x4_f32); storage must be ESR_STORE_F32 (or the NCHW head of a 16-bit network)
+ *   BF16 / F16   v_mfma_f32_16x16x32_{bf16,f16} on 16-bit operands; goes with the SAME 16-bit storage type (esr_storage):
+ *                the stored activation IS the MFMA operand, weights come from esr_pack_conv_s16 */
 typedef enum esr_compute { ESR_COMPUTE_F32 = 0, ESR_COMPUTE_BF16 = 1, ESR_COMPUTE_F16 = 2 } esr_compute;
+
+/* ABI v4 -- element type of the FULL-RESOLUTION NHWC activation views of an op (in, res, out0, out1, ESA x / y / c1,
+ * BSConvU in / res / out / d_out).  pitch / coff of those views count ELEMENTS.  16-bit storage halves the HBM traffic of
+ * the memory-bound layers (BASELINE.json configs [2]-[4]); arithmetic stays fp32-accumulate, values are rounded (RNE) once,
+ * when stored.  The network input / output (NCHW) and the ESA low-resolution maps (pitch ESR_ESA_FP) are always fp32.
+ * For esr_conv2d_f32 on NHWC input, storage BF16 / F16 requires compute BF16 / F16 and weights from esr_pack_conv_s16;
+ * views then need pitch and coff in multiples of 8 elements (16 bytes) and in.coff + round_up(cin, 16) <= in.pitch. */
+typedef enum esr_storage { ESR_STORE_F32 = 0, ESR_STORE_BF16 = 1, ESR_STORE_F16 = 2 } esr_storage;
 
 typedef enum esr_layout {
     ESR_NHWC = 0,            /* [n][h][w][pitch] fp32, channel slice [coff, coff+c) */
@@ -91,9 +99,9 @@ typedef struct esr_conv_desc {
     esr_view in;                /* pitch/coff ignored for ESR_NCHW_IN */
     esr_view res;               /* residual, NHWC, `cout` channels from coff; unused if ESR_RES_NONE */
     esr_view out0, out1;        /* out0.ptr is the NCHW tensor for ESR_NCHW_SHUFFLE4 */
-    const void* wpacked;        /* device pointer to esr_pack_conv_f32 (or esr_pack_conv_h16) output */
+    const void* wpacked;        /* device pointer to esr_pack_conv_f32 (16-bit storage: esr_pack_conv_s16) output */
     int32_t compute;            /* esr_compute; 0 = fp32 */
-    int32_t reserved;
+    int32_t storage;            /* esr_storage of the NHWC views (ABI v4; 0 = fp32) */
     /* ABI v3 -- optional fused 1x1 tail: the 3x3 result (cout <= 16, after `tail_mid_act`) never goes to memory; it is
      * the LAST 16 input channels of a 1x1 convolution whose first `tail_cat_c` input channels are read from `tail_cat`:
      *     y = W1x1 . concat(tail_cat[0:tail_cat_c), mid_act(conv3x3(in))) + b1x1
@@ -130,11 +138,16 @@ int    esr_pack_conv_f32(const float* w_oihw, const float* bias, int cin, int co
 int    esr_unpack_conv_f32(const void* packed, size_t bytes, int cin, int cout, int ksize,
                            const int32_t* cin_map, int cin_phys, float* w_oihw, float* bias);
 
-/* 16-bit-operand weights for ESR_COMPUTE_BF16 / ESR_COMPUTE_F16 (3x3 only): [cin chunk][tap pair][tile][lane][4]
- * 16-bit values (RNE from fp32) followed by the fp32 bias.  `compute` selects the operand format. */
-size_t esr_packed_conv_h16_bytes(int cin_phys, int cout);
-int    esr_pack_conv_h16(const float* w_oihw, const float* bias, int cin, int cout, const int32_t* cin_map,
+/* 16-bit-STORAGE weights (ESR_STORE_BF16 / ESR_STORE_F16 descriptors, ksize 1 or 3): K chunks of 16 input channels,
+ * [chunk][tap pair][16-cout tile][lane][8] 16-bit values for v_mfma_f32_16x16x32_{bf16,f16}, followed by the fp32 bias.
+ * 3x3: the 9 taps of every (cout, cin) filter are rounded with error diffusion (tap k absorbs the rounding error of tap
+ * k-1), so the filter's DC gain keeps fp32 accuracy; 1x1: the second tap slot carries the rounding residual (w = hi + lo).
+ * esr_unpack_conv_s16 returns the EFFECTIVE fp32 weights the kernel multiplies by (tests). */
+size_t esr_packed_conv_s16_bytes(int cin_phys, int cout, int ksize);
+int    esr_pack_conv_s16(const float* w_oihw, const float* bias, int cin, int cout, int ksize, const int32_t* cin_map,
                          int cin_phys, int compute, void* out, size_t out_bytes);
+int    esr_unpack_conv_s16(const void* packed, size_t bytes, int cin, int cout, int ksize, const int32_t* cin_map,
+                           int cin_phys, int compute, float* w_oihw, float* bias);
 
 int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream);
 /* Diagnostics: waves per block of the conv_f32_kernel variant esr_conv2d_f32 launches for `d` (4 = 16x16-pixel tiles,
@@ -164,7 +177,7 @@ typedef struct esr_esa_desc {
     int32_t c;                  /* n_feats (logical channels of x / y) */
     int32_t f;                  /* ESA width (<= 16) */
     int32_t h_lo, w_lo;         /* dims of the low-resolution map (source of the op) */
-    int32_t reserved;
+    int32_t storage;            /* esr_storage of the full-resolution views x / y / c1 (ABI v4; 0 = fp32) */
     esr_view x;                 /* apply: block input x ; conv3x3s2 / maxpool: source map (pitch 16) */
     esr_view y;                 /* destination */
     const void* c1;             /* apply: c1_ = conv1(x), [n*h*w][16] */
@@ -230,6 +243,8 @@ typedef struct esr_bsconv_desc {
     int32_t d_cout;
     int32_t d_act;
     esr_view d_out;
+    int32_t storage;            /* esr_storage of in / res / out / d_out (ABI v4; 0 = fp32) */
+    int32_t reserved;
 } esr_bsconv_desc;
 
 int esr_bsconv_f32(const esr_bsconv_desc* d, void* hip_stream);

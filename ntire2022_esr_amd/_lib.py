@@ -20,6 +20,7 @@ OP_CONV, OP_CONV3X3S2, OP_MAXPOOL7S3, OP_ESA_APPLY, OP_DWCONV, OP_BSCONV = 0, 1,
 ESA_FP = 16
 COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2
 COMPUTE = {"f32": 0, "bf16": 1, "f16": 2}
+STORE = {"f32": 0, "bf16": 1, "f16": 2}     # esr_storage: element type of the full-resolution NHWC views
 
 
 class View(ctypes.Structure):
@@ -35,7 +36,7 @@ class ConvDesc(ctypes.Structure):
         ("res_mode", ctypes.c_int32), ("split", ctypes.c_int32),
         ("inp", View), ("res", View), ("out0", View), ("out1", View),
         ("wpacked", ctypes.c_void_p),
-        ("compute", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("compute", ctypes.c_int32), ("storage", ctypes.c_int32),
         ("tail_wpacked", ctypes.c_void_p), ("tail_cat", View),
         ("tail_cat_c", ctypes.c_int32), ("tail_cout", ctypes.c_int32),
         ("tail_mid_act", ctypes.c_int32), ("reserved2", ctypes.c_int32),
@@ -48,7 +49,7 @@ class EsaDesc(ctypes.Structure):
     _fields_ = [
         ("n", ctypes.c_int32), ("h", ctypes.c_int32), ("w", ctypes.c_int32),
         ("c", ctypes.c_int32), ("f", ctypes.c_int32), ("h_lo", ctypes.c_int32), ("w_lo", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("storage", ctypes.c_int32),
         ("x", View), ("y", View),
         ("c1", ctypes.c_void_p), ("c3", ctypes.c_void_p), ("w0", ctypes.c_void_p), ("w1", ctypes.c_void_p),
     ]
@@ -63,6 +64,7 @@ class BsDesc(ctypes.Structure):
         ("pw_packed", ctypes.c_void_p), ("dw_packed", ctypes.c_void_p), ("d_packed", ctypes.c_void_p),
         ("d_cout", ctypes.c_int32), ("d_act", ctypes.c_int32),
         ("d_out", View),
+        ("storage", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
 
@@ -75,7 +77,7 @@ class Op(ctypes.Structure):
 EXPORTS = [
     "esr_abi_version", "esr_last_hip_error", "esr_build_info",
     "esr_packed_conv_bytes", "esr_pack_conv_f32", "esr_unpack_conv_f32",
-    "esr_packed_conv_h16_bytes", "esr_pack_conv_h16",
+    "esr_packed_conv_s16_bytes", "esr_pack_conv_s16", "esr_unpack_conv_s16",
     "esr_conv2d_f32", "esr_conv_block_waves", "esr_run_ops",
     "esr_prof_create", "esr_run_ops_profiled", "esr_prof_collect", "esr_prof_destroy",
     "esr_packed_dense_bytes", "esr_pack_dense_f32",
@@ -110,10 +112,12 @@ def lib():
     L.esr_pack_conv_f32.restype = ci
     L.esr_unpack_conv_f32.argtypes = [vp, sz, ci, ci, ci, vp, ci, vp, vp]
     L.esr_unpack_conv_f32.restype = ci
-    L.esr_packed_conv_h16_bytes.argtypes = [ci, ci]
-    L.esr_packed_conv_h16_bytes.restype = sz
-    L.esr_pack_conv_h16.argtypes = [vp, vp, ci, ci, vp, ci, ci, vp, sz]
-    L.esr_pack_conv_h16.restype = ci
+    L.esr_packed_conv_s16_bytes.argtypes = [ci, ci, ci]
+    L.esr_packed_conv_s16_bytes.restype = sz
+    L.esr_pack_conv_s16.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, vp, sz]
+    L.esr_pack_conv_s16.restype = ci
+    L.esr_unpack_conv_s16.argtypes = [vp, sz, ci, ci, ci, vp, ci, ci, vp, vp]
+    L.esr_unpack_conv_s16.restype = ci
     L.esr_conv2d_f32.argtypes = [ctypes.POINTER(ConvDesc), vp]
     L.esr_conv2d_f32.restype = ci
     L.esr_conv_block_waves.argtypes = [ctypes.POINTER(ConvDesc)]
@@ -147,7 +151,7 @@ def lib():
     L.esr_prof_collect.restype = ci
     L.esr_prof_destroy.argtypes = [vp]
     L.esr_prof_destroy.restype = None
-    if L.esr_abi_version() != 3:
+    if L.esr_abi_version() != 4:
         raise EsrError("libesr_hip.so ABI version mismatch")
     _lib = L
     return L

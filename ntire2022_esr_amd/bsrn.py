@@ -11,7 +11,7 @@ epilogue.  Two load-time folds, both exact up to one fp32 rounding:
 import torch
 
 from . import _lib as L
-from .engine import INPUT, OUTPUT, HipSRModel, pack_conv
+from .engine import INPUT, OUTPUT, HipSRModel, pack_conv, pack_conv_s16
 from .rlfn import FP, _lowres, _pad8
 
 
@@ -68,6 +68,8 @@ class BSRN(HipSRModel):
             co = self._leaf(f'B{k}.conv_out')
             cw = self._leaf(f'B{k}').cw.detach().float().reshape(1, C)
             packed[f'B{k}.conv_out'] = pack_conv(co.weight.detach().float() * cw, co.bias).to(device)
+            if self._store() != "f32":
+                packed[f'B{k}.conv_out#s16'] = pack_conv_s16(co.weight.detach().float() * cw, co.bias, self._store()).to(device)
 
     def _build_plan(self, plan, c):
         if c != self.in_nc:

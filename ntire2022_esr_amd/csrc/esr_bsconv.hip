@@ -18,6 +18,15 @@
 #include "esr_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// 16-bit storage (ST = ESR_STORE_BF16 / ESR_STORE_F16, BASELINE.json config [4]): the input / residual / outputs are
+// 16-bit in HBM (half the bytes of this memory-bound kernel); the pointwise GEMM runs on v_mfma_f32_16x16x32_{bf16,f16}
+// with the B fragment loaded straight from global memory as it is stored (16 bytes = 8 channels per lane) and the 1x1
+// weights as hi + lo 16-bit pairs (esr_pack_conv_s16 blobs: the blob IS the LDS image); the pointwise result stays fp32
+// in LDS, the depthwise conv / residual / GELU are fp32, results are rounded once when stored.
 
 namespace {
 
@@ -30,7 +39,7 @@ constexpr int BMAXC16 = 4;             // cin <= 64
 constexpr unsigned BOOB = 0x80000000u;
 
 struct BsK {
-    const float* x; const float* res; float* y; float* dy;
+    const void* x; const void* res; void* y; void* dy;
     const float* pw; const float* pwb; const float* dwp; const float* dpw; const float* dpb;
     int N, H, W;
     int nch8;             // 8-channel chunks of the packed 1x1 blobs
@@ -42,12 +51,69 @@ struct BsK {
     int tiles_x, tiles_y;
 };
 
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): one v_rcp, one v_exp, 6 FMAs instead of libm's branchy erff.
+// Used where the result is rounded to 16 bits anyway (relative 2^-9 / 2^-12): the approximation error is invisible there.
+__device__ __forceinline__ float fast_erf(float x)
+{
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    return copysignf(1.f - p * t * e, x);
+}
+
+template <int ST>
 __device__ __forceinline__ float bs_act(float v, int act, float slope)
 {
-    if (act == ESR_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    if (act == ESR_ACT_GELU) {
+        if (ST == ESR_STORE_F32) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        return 0.5f * v * (1.f + fast_erf(v * 0.70710678118654752440f));
+    }
     if (act == ESR_ACT_LRELU) return fmaxf(v, v * slope);
     if (act == ESR_ACT_RELU) return fmaxf(v, 0.f);
     return v;
+}
+
+template <int ST>
+__device__ __forceinline__ f32x4 ld4(const void* base, size_t idx)
+{
+    if (ST == ESR_STORE_F32) return *reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + idx);
+    const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(base) + idx);
+    f32x4 v;
+    if (ST == ESR_STORE_BF16) {
+        v.x = __builtin_bit_cast(float, u.x << 16); v.y = __builtin_bit_cast(float, u.x & 0xffff0000u);
+        v.z = __builtin_bit_cast(float, u.y << 16); v.w = __builtin_bit_cast(float, u.y & 0xffff0000u);
+    } else {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 a = __builtin_bit_cast(h2, u.x), b = __builtin_bit_cast(h2, u.y);
+        v.x = (float)a[0]; v.y = (float)a[1]; v.z = (float)b[0]; v.w = (float)b[1];
+    }
+    return v;
+}
+
+template <int ST>
+__device__ __forceinline__ void st4(void* base, size_t idx, f32x4 v)
+{
+    if (ST == ESR_STORE_F32) {
+        *reinterpret_cast<f32x4*>(static_cast<float*>(base) + idx) = v;
+        return;
+    }
+    uint2 u;
+    if (ST == ESR_STORE_BF16) {
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        b2 a, b;
+        a[0] = (__bf16)v.x; a[1] = (__bf16)v.y; b[0] = (__bf16)v.z; b[1] = (__bf16)v.w;
+        u.x = __builtin_bit_cast(unsigned, a); u.y = __builtin_bit_cast(unsigned, b);
+    } else {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 a, b;
+        a[0] = (_Float16)v.x; a[1] = (_Float16)v.y; b[0] = (_Float16)v.z; b[1] = (_Float16)v.w;
+        u.x = __builtin_bit_cast(unsigned, a); u.y = __builtin_bit_cast(unsigned, b);
+    }
+    *reinterpret_cast<uint2*>(static_cast<unsigned short*>(base) + idx) = u;
 }
 
 // esr_pack_conv_f32(ksize = 1) blob ([chunk of 8][tile][kq'*16+i][j'], channel = 8*chunk + 2kq' + j') -> LDS image
@@ -71,9 +137,18 @@ __device__ __forceinline__ void build_image(float* img, const float* blob, int n
     }
 }
 
-template <int NTP, int NTD>
+template <int ST>
+__device__ __forceinline__ f32x4 mfma16(f32x4 a, f32x4 b, f32x4 c)
+{
+    if (ST == ESR_STORE_BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int NTP, int NTD, int ST>
 __global__ __launch_bounds__(256, 2) void bsconv_kernel(const BsK p)
 {
+    constexpr bool S16 = ST != ESR_STORE_F32;
+    constexpr int ES = S16 ? 2 : 4;                          // bytes per stored element
     extern __shared__ __attribute__((aligned(16))) float bsm[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int px = lane & 15, kq = lane >> 4;
@@ -83,15 +158,21 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(const BsK p)
     float* const idp = ipw + nc16 * NTP * 256;               // distillation weight image
     float* const sdw = idp + nc16 * NTD * 256;               // depthwise [tap][cp] + bias[cp]
     float* const sb = sdw + 10 * p.cp;                       // pointwise bias [NTP*16], distillation bias [NTD*16]
-    build_image<NTP>(ipw, p.pw, p.nch8, tid);
-    if (NTD) build_image<(NTD ? NTD : 1)>(idp, p.dpw, p.nch8, tid);
+    if (S16) {
+        // esr_pack_conv_s16(ksize = 1) blobs are [16-channel chunk][tile][lane][8 x 16 bit]: already the lane-linear LDS image
+        for (int i = tid; i < nc16 * NTP * 256; i += 256) ipw[i] = p.pw[i];
+        if (NTD) for (int i = tid; i < nc16 * NTD * 256; i += 256) idp[i] = p.dpw[i];
+    } else {
+        build_image<NTP>(ipw, p.pw, p.nch8, tid);
+        if (NTD) build_image<(NTD ? NTD : 1)>(idp, p.dpw, p.nch8, tid);
+    }
     for (int i = tid; i < 10 * p.cp; i += 256) sdw[i] = p.dwp[i];
     if (tid < NTP * 16) sb[tid] = p.pwb[tid];
     if (NTD && tid < NTD * 16) sb[NTP * 16 + tid] = p.dpb[tid];
     __syncthreads();
 
     const int ntiles = p.N * p.tiles_y * p.tiles_x;
-    const size_t img_floats = (size_t)p.H * p.W * p.x_pitch;
+    const size_t img_elems = (size_t)p.H * p.W * p.x_pitch;
     const int cin_phys = p.nch8 * 8;
     const int nq = p.cp >> 2;
 
@@ -99,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(const BsK p)
         const int tx = t % p.tiles_x, tq = t / p.tiles_x;
         const int ty = tq % p.tiles_y, n = tq / p.tiles_y;
         const int x0 = tx * BT, y0 = ty * BT;
-        const __amdgpu_buffer_rsrc_t xr =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)n * img_floats), 0, (int)(img_floats * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(static_cast<const char*>(p.x) + (size_t)n * img_elems * ES), 0, (int)(img_elems * ES), 0x00020000);
 
         // ---- phase 1: all B fragments of this wave's pixel tiles are requested before the first MFMA ----------------
         f32x4 b[BPTW][BMAXC16];
@@ -113,11 +194,14 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(const BsK p)
             const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
             valid[s] = wv + 4 * s < BNPT && pl < BNPX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             gpix[s] = gy * p.W + gx;
-            const unsigned vo = valid[s] ? (unsigned)(gpix[s] * p.x_pitch + p.x_coff + 4 * kq) * 4u : BOOB;
+            // fp32: lane (px, kq) holds channels 16C + 4kq .. +3 (k slot of the 16x16x4 MFMAs); 16-bit: channels
+            // 16C + 8(kq & 1) .. +7 (16 bytes), lanes kq >= 2 read the same bytes again -- their weight slots carry the lo parts
+            const int chl = S16 ? 8 * (kq & 1) : 4 * kq;
+            const unsigned vo = valid[s] ? (unsigned)(gpix[s] * p.x_pitch + p.x_coff + chl) * (unsigned)ES : BOOB;
 #pragma unroll
             for (int C = 0; C < BMAXC16; ++C) {
-                const bool ok = C < nc16 && 16 * C + 4 * kq < cin_phys;
-                b[s][C] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? vo : BOOB, C * 64, 0));
+                const bool ok = C < nc16 && 16 * C + chl < cin_phys;
+                b[s][C] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? vo : BOOB, C * 16 * ES, 0));
             }
         }
 #pragma unroll
@@ -134,14 +218,20 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(const BsK p)
 #pragma unroll
                 for (int tt = 0; tt < NTP; ++tt) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(ipw + ((C * NTP + tt) * 64 + lane) * 4);
+                    if (S16) acc[tt] = mfma16<ST>(a, b[s][C], acc[tt]);
+                    else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[s][C][j], acc[tt], 0, 0, 0);
+                        for (int j = 0; j < 4; ++j) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[s][C][j], acc[tt], 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int td = 0; td < NTD; ++td) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(idp + ((C * NTD + td) * 64 + lane) * 4);
+                    if (S16) dacc[td] = mfma16<ST>(a, b[s][C], dacc[td]);
+                    else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) dacc[td] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[s][C][j], dacc[td], 0, 0, 0);
+                        for (int j = 0; j < 4; ++j) dacc[td] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[s][C][j], dacc[td], 0, 0, 0);
+                    }
                 }
             }
             const int pl = (wv + 4 * s) * 16 + px;
@@ -154,14 +244,14 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(const BsK p)
             if (NTD) {
                 const int ly = pl / BH, lx = pl - ly * BH;
                 if (valid[s] && ly >= 1 && ly <= BT && lx >= 1 && lx <= BT) {
-                    float* dst = p.dy + ((size_t)n * p.H * p.W + gpix[s]) * p.dy_pitch + p.dy_coff;
+                    const size_t dsti = ((size_t)n * p.H * p.W + gpix[s]) * p.dy_pitch + p.dy_coff;
 #pragma unroll
                     for (int td = 0; td < NTD; ++td) {
                         if (td * 16 + kq * 4 >= p.d_cout4) continue;
                         f32x4 v = dacc[td];
-                        v.x = bs_act(v.x, p.d_act, p.slope); v.y = bs_act(v.y, p.d_act, p.slope);
-                        v.z = bs_act(v.z, p.d_act, p.slope); v.w = bs_act(v.w, p.d_act, p.slope);
-                        *reinterpret_cast<f32x4*>(dst + td * 16 + kq * 4) = v;
+                        v.x = bs_act<ST>(v.x, p.d_act, p.slope); v.y = bs_act<ST>(v.y, p.d_act, p.slope);
+                        v.z = bs_act<ST>(v.z, p.d_act, p.slope); v.w = bs_act<ST>(v.w, p.d_act, p.slope);
+                        st4<ST>(p.dy, dsti + td * 16 + kq * 4, v);
                     }
                 }
             }
@@ -185,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(const BsK p)
                 const int gy = y0 + (pixel >> 4), gx = x0 + (pixel & 15);
                 f32x4 r = {0.f, 0.f, 0.f, 0.f};
                 if (p.res_mode != ESR_RES_NONE && worker && pixel < BT * BT && gy < p.H && gx < p.W)
-                    r = *reinterpret_cast<const f32x4*>(p.res + ((size_t)n * p.H * p.W + (size_t)gy * p.W + gx) * p.r_pitch + p.r_coff + q * 4);
+                    r = ld4<ST>(p.res, ((size_t)n * p.H * p.W + (size_t)gy * p.W + gx) * p.r_pitch + p.r_coff + q * 4);
                 return r;
             };
             f32x4 rv0 = res_of(0), rv1 = res_of(1);               // two passes ahead
@@ -205,37 +295,49 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(const BsK p)
                     for (int kx = 0; kx < 3; ++kx)
                         a += *reinterpret_cast<const f32x4*>(tl + ((oy + ky) * BH + ox + kx) * p.cp + q * 4) * wreg[ky * 3 + kx];
                 if (p.res_mode == ESR_RES_PRE_ACT) a += rv;
-                a.x = bs_act(a.x, p.act, p.slope); a.y = bs_act(a.y, p.act, p.slope);
-                a.z = bs_act(a.z, p.act, p.slope); a.w = bs_act(a.w, p.act, p.slope);
+                a.x = bs_act<ST>(a.x, p.act, p.slope); a.y = bs_act<ST>(a.y, p.act, p.slope);
+                a.z = bs_act<ST>(a.z, p.act, p.slope); a.w = bs_act<ST>(a.w, p.act, p.slope);
                 if (p.res_mode == ESR_RES_POST_ACT) a += rv;
-                *reinterpret_cast<f32x4*>(p.y + ((size_t)n * p.H * p.W + (size_t)gy * p.W + gx) * p.y_pitch + p.y_coff + q * 4) = a;
+                st4<ST>(p.y, ((size_t)n * p.H * p.W + (size_t)gy * p.W + gx) * p.y_pitch + p.y_coff + q * 4, a);
             }
         }
         __syncthreads();
     }
 }
 
-template <int NTP, int NTD>
+template <int NTP, int NTD, int ST>
 int launch_bs(const BsK& k, size_t lds, hipStream_t st)
 {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bsconv_kernel<NTP, NTD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bsconv_kernel<NTP, NTD, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int grid = ntiles < 512 ? ntiles : 512;
-    hipLaunchKernelGGL((bsconv_kernel<NTP, NTD>), dim3(grid), dim3(256), lds, st, k);
+    hipLaunchKernelGGL((bsconv_kernel<NTP, NTD, ST>), dim3(grid), dim3(256), lds, st, k);
     return esr_check_launch("bsconv_kernel launch");
 }
 
-template <int NTP>
+template <int NTP, int ST>
 int launch_bs_d(int ntd, const BsK& k, size_t lds, hipStream_t st)
 {
     switch (ntd) {
-        case 0: return launch_bs<NTP, 0>(k, lds, st);
-        case 1: return launch_bs<NTP, 1>(k, lds, st);
-        case 2: return launch_bs<NTP, 2>(k, lds, st);
+        case 0: return launch_bs<NTP, 0, ST>(k, lds, st);
+        case 1: return launch_bs<NTP, 1, ST>(k, lds, st);
+        case 2: return launch_bs<NTP, 2, ST>(k, lds, st);
+    }
+    return ESR_ERR_UNSUPPORTED;
+}
+
+template <int ST>
+int launch_bs_p(int ntp, int ntd, const BsK& k, size_t lds, hipStream_t st)
+{
+    switch (ntp) {
+        case 1: return launch_bs_d<1, ST>(ntd, k, lds, st);
+        case 2: return launch_bs_d<2, ST>(ntd, k, lds, st);
+        case 3: return launch_bs_d<3, ST>(ntd, k, lds, st);
+        case 4: return launch_bs_d<4, ST>(ntd, k, lds, st);
     }
     return ESR_ERR_UNSUPPORTED;
 }
@@ -247,8 +349,11 @@ extern "C" int esr_bsconv_f32(const esr_bsconv_desc* d, void* hip_stream)
     if (!d || !d->in.ptr || !d->out.ptr || !d->pw_packed || !d->dw_packed) return ESR_ERR_BAD_ARG;
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->c <= 0) return ESR_ERR_BAD_ARG;
     if (d->cin > 64 || d->c > 64) return ESR_ERR_UNSUPPORTED;
+    const bool s16 = d->storage == ESR_STORE_BF16 || d->storage == ESR_STORE_F16;
+    if (d->storage != ESR_STORE_F32 && !s16) return ESR_ERR_BAD_ARG;
     const int cin_phys = esr_round_up(d->cin, 8), cp = esr_round_up(d->c, 4);
     if ((d->in.pitch & 3) || (d->in.coff & 3) || d->in.coff + cin_phys > d->in.pitch) return ESR_ERR_BAD_ARG;
+    if (s16 && ((d->in.pitch & 7) || (d->in.coff & 7))) return ESR_ERR_BAD_ARG;          // 16-byte B fragments
     if ((d->out.pitch & 3) || (d->out.coff & 3) || d->out.coff + cp > d->out.pitch) return ESR_ERR_BAD_ARG;
     if (d->res_mode != ESR_RES_NONE && (!d->res.ptr || (d->res.pitch & 3) || (d->res.coff & 3) || d->res.coff + cp > d->res.pitch))
         return ESR_ERR_BAD_ARG;
@@ -269,14 +374,17 @@ extern "C" int esr_bsconv_f32(const esr_bsconv_desc* d, void* hip_stream)
         if ((double)d->h * d->w * d->in.pitch * 4.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
     }
     BsK k;
-    k.x = static_cast<const float*>(d->in.ptr); k.res = static_cast<const float*>(d->res.ptr);
-    k.y = static_cast<float*>(d->out.ptr); k.dy = static_cast<float*>(d->d_out.ptr);
+    k.x = d->in.ptr; k.res = d->res.ptr;
+    k.y = d->out.ptr; k.dy = d->d_out.ptr;
     k.nch8 = cin_phys / 8;
+    const int nc16w = (k.nch8 + 1) / 2;
     k.pw = static_cast<const float*>(d->pw_packed);
-    k.pwb = k.pw + (size_t)k.nch8 * ntp * 128;                  // esr_pack_conv_f32 layout: weights, then bias[nt*16]
+    // fp32: esr_pack_conv_f32 layout (chunks of 8: weights, then bias[nt*16]); 16-bit: esr_pack_conv_s16 (chunks of 16, 1 KB per
+    // chunk and tile = 256 floats, then the fp32 bias)
+    k.pwb = s16 ? k.pw + (size_t)nc16w * ntp * 256 : k.pw + (size_t)k.nch8 * ntp * 128;
     k.dwp = static_cast<const float*>(d->dw_packed);
     k.dpw = static_cast<const float*>(d->d_packed);
-    k.dpb = k.dpw ? k.dpw + (size_t)k.nch8 * ntd * 128 : nullptr;
+    k.dpb = k.dpw ? (s16 ? k.dpw + (size_t)nc16w * ntd * 256 : k.dpw + (size_t)k.nch8 * ntd * 128) : nullptr;
     k.N = d->n; k.H = d->h; k.W = d->w; k.cp = cp; k.d_cout4 = dc4;
     k.x_pitch = d->in.pitch; k.x_coff = d->in.coff; k.r_pitch = d->res.pitch; k.r_coff = d->res.coff;
     k.y_pitch = d->out.pitch; k.y_coff = d->out.coff; k.dy_pitch = d->d_out.pitch; k.dy_coff = d->d_out.coff;
@@ -286,11 +394,10 @@ extern "C" int esr_bsconv_f32(const esr_bsconv_desc* d, void* hip_stream)
     const size_t lds = ((size_t)BNPX * cp + (size_t)nc16 * (ntp + ntd) * 256 + 10 * cp + (ntp + ntd) * 16) * sizeof(float);
     if (lds > 160 * 1024) return ESR_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    switch (ntp) {
-        case 1: return launch_bs_d<1>(ntd, k, lds, st);
-        case 2: return launch_bs_d<2>(ntd, k, lds, st);
-        case 3: return launch_bs_d<3>(ntd, k, lds, st);
-        case 4: return launch_bs_d<4>(ntd, k, lds, st);
+    switch (d->storage) {
+        case ESR_STORE_F32: return launch_bs_p<ESR_STORE_F32>(ntp, ntd, k, lds, st);
+        case ESR_STORE_BF16: return launch_bs_p<ESR_STORE_BF16>(ntp, ntd, k, lds, st);
+        case ESR_STORE_F16: return launch_bs_p<ESR_STORE_F16>(ntp, ntd, k, lds, st);
     }
-    return ESR_ERR_UNSUPPORTED;
+    return ESR_ERR_BAD_ARG;
 }

@@ -20,9 +20,51 @@ namespace {
 
 constexpr int FP = ESR_ESA_FP;   // 16
 
+// Element access for the full-resolution views: ST = esr_storage (0 fp32, 1 bf16, 2 fp16); idx counts elements and is a
+// multiple of 4.  Arithmetic is fp32 in every case; a store rounds once (RNE).
+template <int ST>
+__device__ __forceinline__ f32x4 ld4(const void* base, size_t idx)
+{
+    if (ST == ESR_STORE_F32) return *reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + idx);
+    const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(base) + idx);
+    f32x4 v;
+    if (ST == ESR_STORE_BF16) {
+        v.x = __builtin_bit_cast(float, u.x << 16); v.y = __builtin_bit_cast(float, u.x & 0xffff0000u);
+        v.z = __builtin_bit_cast(float, u.y << 16); v.w = __builtin_bit_cast(float, u.y & 0xffff0000u);
+    } else {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 a = __builtin_bit_cast(h2, u.x), b = __builtin_bit_cast(h2, u.y);
+        v.x = (float)a[0]; v.y = (float)a[1]; v.z = (float)b[0]; v.w = (float)b[1];
+    }
+    return v;
+}
+
+template <int ST>
+__device__ __forceinline__ void st4(void* base, size_t idx, f32x4 v)
+{
+    if (ST == ESR_STORE_F32) {
+        *reinterpret_cast<f32x4*>(static_cast<float*>(base) + idx) = v;
+        return;
+    }
+    uint2 u;
+    if (ST == ESR_STORE_BF16) {
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        b2 a, b;
+        a[0] = (__bf16)v.x; a[1] = (__bf16)v.y; b[0] = (__bf16)v.z; b[1] = (__bf16)v.w;
+        u.x = __builtin_bit_cast(unsigned, a); u.y = __builtin_bit_cast(unsigned, b);
+    } else {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 a, b;
+        a[0] = (_Float16)v.x; a[1] = (_Float16)v.y; b[0] = (_Float16)v.z; b[1] = (_Float16)v.w;
+        u.x = __builtin_bit_cast(unsigned, a); u.y = __builtin_bit_cast(unsigned, b);
+    }
+    *reinterpret_cast<uint2*>(static_cast<unsigned short*>(base) + idx) = u;
+}
+
 // ---- 3x3 stride 2, no padding, FP -> FP --------------------------------------------------------
 // thread = (output pixel, quad of 4 output channels); weights [tap][cin][cout] in LDS.
-__global__ __launch_bounds__(256) void conv3x3s2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+template <int ST>
+__global__ __launch_bounds__(256) void conv3x3s2_kernel(const void* __restrict__ x, const float* __restrict__ wp,
                                                         float* __restrict__ y, int N, int H, int W, int Ho, int Wo)
 {
     __shared__ __attribute__((aligned(16))) float sw[9 * FP * FP + FP];
@@ -39,11 +81,11 @@ __global__ __launch_bounds__(256) void conv3x3s2_kernel(const float* __restrict_
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const float* xp = x + (((size_t)n * H + (oy * 2 + ky)) * W + (ox * 2 + kx)) * FP;
+            const size_t xi = (((size_t)n * H + (oy * 2 + ky)) * W + (ox * 2 + kx)) * FP;
             const float* wt = sw + (ky * 3 + kx) * FP * FP + q * 4;
 #pragma unroll
             for (int cq = 0; cq < FP / 4; ++cq) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + cq * 4);
+                const f32x4 xv = ld4<ST>(x, xi + cq * 4);
                 acc += xv.x * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 0) * FP);
                 acc += xv.y * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 1) * FP);
                 acc += xv.z * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 2) * FP);
@@ -81,12 +123,13 @@ __global__ __launch_bounds__(256) void maxpool7s3_kernel(const float* __restrict
 // of LDS, then lane g produces output channels 4g..4g+3 (16 x 4 FMAs, sigmoid, multiply).  x is read once and
 // y written once, both as contiguous float4 per lane.
 struct EsaK {
-    const float* x; const float* c1; const float* c3; const float* wf; const float* w4; float* y;
+    const void* x; const void* c1; const float* c3; const float* wf; const float* w4; void* y;
     int x_pitch, x_coff, y_pitch, y_coff;
     int N, H, W, Cp4, cp, h3, w3;
     float sh, sw;
 };
 
+template <int ST>
 __global__ __launch_bounds__(256) void esa_apply_kernel(const EsaK p)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];      // wf: FP*FP + FP ; w4: FP*cp + cp ; s: 16*FP
@@ -122,10 +165,9 @@ __global__ __launch_bounds__(256) void esa_apply_kernel(const EsaK p)
     const float c = cb[((size_t)y1 * p.w3 + x0) * FP], d = cb[((size_t)y1 * p.w3 + x1) * FP];
     float sg = hy * (hx * a + lx * b) + ly * (hx * c + lx * d) + sm[FP * FP + g];
     // + conv_f(c1_)[g] = sum_i c1[i] * Wf[i][g]
-    const float* c1p = p.c1 + (size_t)pix * FP;
 #pragma unroll
     for (int iq = 0; iq < FP / 4; ++iq) {
-        const f32x4 cv = *reinterpret_cast<const f32x4*>(c1p + iq * 4);
+        const f32x4 cv = ld4<ST>(p.c1, (size_t)pix * FP + iq * 4);
         sg = fmaf(cv.x, sm[(iq * 4 + 0) * FP + g], sg);
         sg = fmaf(cv.y, sm[(iq * 4 + 1) * FP + g], sg);
         sg = fmaf(cv.z, sm[(iq * 4 + 2) * FP + g], sg);
@@ -148,13 +190,13 @@ __global__ __launch_bounds__(256) void esa_apply_kernel(const EsaK p)
         m += sv.z * *reinterpret_cast<const f32x4*>(w4 + (iq * 4 + 2) * p.cp + g * 4);
         m += sv.w * *reinterpret_cast<const f32x4*>(w4 + (iq * 4 + 3) * p.cp + g * 4);
     }
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + (size_t)pix * p.x_pitch + p.x_coff + g * 4);
+    const f32x4 xv = ld4<ST>(p.x, (size_t)pix * p.x_pitch + p.x_coff + g * 4);
     f32x4 o;
     o.x = xv.x * (1.f / (1.f + expf(-m.x)));
     o.y = xv.y * (1.f / (1.f + expf(-m.y)));
     o.z = xv.z * (1.f / (1.f + expf(-m.z)));
     o.w = xv.w * (1.f / (1.f + expf(-m.w)));
-    *reinterpret_cast<f32x4*>(p.y + (size_t)pix * p.y_pitch + p.y_coff + g * 4) = o;
+    st4<ST>(p.y, (size_t)pix * p.y_pitch + p.y_coff + g * 4, o);
     }
 }
 
@@ -162,7 +204,7 @@ __global__ __launch_bounds__(256) void esa_apply_kernel(const EsaK p)
 // thread = (pixel, quad of 4 channels); weights [tap][cp] + bias[cp] in LDS.  Memory-bound: the 9 taps of a
 // pixel are served from L1/L2 (each input float4 is read by 9 neighbouring threads).
 struct DwK {
-    const float* x; const float* wp; const float* res; float* y;
+    const void* x; const float* wp; const void* res; void* y;
     int N, H, W, cp, nq;
     int x_pitch, x_coff, r_pitch, r_coff, y_pitch, y_coff;
     int act, res_mode;
@@ -177,6 +219,7 @@ __device__ __forceinline__ float dw_act(float v, int act, float slope)
     return v;
 }
 
+template <int ST>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const DwK p)
 {
     extern __shared__ __attribute__((aligned(16))) float sdw[];          // 10 * cp floats
@@ -197,18 +240,17 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const DwK p)
         for (int kx = 0; kx < 3; ++kx) {
             const int ix = ox + kx - 1;
             if (ix < 0 || ix >= p.W) continue;
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(
-                p.x + (size_t)(pix + (long long)(ky - 1) * p.W + (kx - 1)) * p.x_pitch + p.x_coff + q * 4);
+            const f32x4 xv = ld4<ST>(p.x, (size_t)(pix + (long long)(ky - 1) * p.W + (kx - 1)) * p.x_pitch + p.x_coff + q * 4);
             acc += xv * *reinterpret_cast<const f32x4*>(sdw + (ky * 3 + kx) * p.cp + q * 4);
         }
     }
     f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-    if (p.res_mode != ESR_RES_NONE) rv = *reinterpret_cast<const f32x4*>(p.res + (size_t)pix * p.r_pitch + p.r_coff + q * 4);
+    if (p.res_mode != ESR_RES_NONE) rv = ld4<ST>(p.res, (size_t)pix * p.r_pitch + p.r_coff + q * 4);
     if (p.res_mode == ESR_RES_PRE_ACT) acc += rv;
     acc.x = dw_act(acc.x, p.act, p.slope); acc.y = dw_act(acc.y, p.act, p.slope);
     acc.z = dw_act(acc.z, p.act, p.slope); acc.w = dw_act(acc.w, p.act, p.slope);
     if (p.res_mode == ESR_RES_POST_ACT) acc += rv;
-    *reinterpret_cast<f32x4*>(p.y + (size_t)pix * p.y_pitch + p.y_coff + q * 4) = acc;
+    st4<ST>(p.y, (size_t)pix * p.y_pitch + p.y_coff + q * 4, acc);
 }
 
 // ---- post-processing: tensor2uint and squared error on uint8 ----------------------------------------
@@ -296,15 +338,22 @@ int esr_dwconv3x3_f32(const esr_conv_desc* d, void* hip_stream)
         (!d->res.ptr || (d->res.pitch & 3) || (d->res.coff & 3) || d->res.coff + cp > d->res.pitch))
         return ESR_ERR_BAD_ARG;
     DwK k;
-    k.x = static_cast<const float*>(d->in.ptr); k.wp = static_cast<const float*>(d->wpacked);
-    k.res = static_cast<const float*>(d->res.ptr); k.y = static_cast<float*>(d->out0.ptr);
+    k.x = d->in.ptr; k.wp = static_cast<const float*>(d->wpacked);
+    k.res = d->res.ptr; k.y = d->out0.ptr;
     k.N = d->n; k.H = d->h; k.W = d->w; k.cp = cp; k.nq = cp / 4;
     k.x_pitch = d->in.pitch; k.x_coff = d->in.coff; k.r_pitch = d->res.pitch; k.r_coff = d->res.coff;
     k.y_pitch = d->out0.pitch; k.y_coff = d->out0.coff;
     k.act = d->act; k.res_mode = d->res_mode; k.slope = d->slope;
     const long long nthreads = (long long)d->n * d->h * d->w * k.nq;
-    hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), (size_t)10 * cp * sizeof(float),
-                       static_cast<hipStream_t>(hip_stream), k);
+    const dim3 grid((unsigned)((nthreads + 255) / 256));
+    const size_t lds = (size_t)10 * cp * sizeof(float);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    switch (d->storage) {
+        case ESR_STORE_F32: hipLaunchKernelGGL(dwconv3x3_kernel<ESR_STORE_F32>, grid, dim3(256), lds, st, k); break;
+        case ESR_STORE_BF16: hipLaunchKernelGGL(dwconv3x3_kernel<ESR_STORE_BF16>, grid, dim3(256), lds, st, k); break;
+        case ESR_STORE_F16: hipLaunchKernelGGL(dwconv3x3_kernel<ESR_STORE_F16>, grid, dim3(256), lds, st, k); break;
+        default: return ESR_ERR_BAD_ARG;
+    }
     return esr_check_launch("dwconv3x3_kernel launch");
 }
 
@@ -349,9 +398,16 @@ int esr_conv3x3s2_f32(const esr_esa_desc* d, void* hip_stream)
     const int Ho = (d->h - 3) / 2 + 1, Wo = (d->w - 3) / 2 + 1;
     if (d->h_lo != Ho || d->w_lo != Wo) return ESR_ERR_BAD_ARG;
     const long long npix = (long long)d->n * Ho * Wo;
-    hipLaunchKernelGGL(conv3x3s2_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
-                       static_cast<const float*>(d->x.ptr), static_cast<const float*>(d->w0), static_cast<float*>(d->y.ptr),
-                       d->n, d->h, d->w, Ho, Wo);
+    const dim3 grid((unsigned)((npix + 63) / 64));
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const float* w0 = static_cast<const float*>(d->w0);
+    float* y = static_cast<float*>(d->y.ptr);                 // the half-resolution map is fp32 in every storage mode
+    switch (d->storage) {
+        case ESR_STORE_F32: hipLaunchKernelGGL(conv3x3s2_kernel<ESR_STORE_F32>, grid, dim3(256), 0, st, d->x.ptr, w0, y, d->n, d->h, d->w, Ho, Wo); break;
+        case ESR_STORE_BF16: hipLaunchKernelGGL(conv3x3s2_kernel<ESR_STORE_BF16>, grid, dim3(256), 0, st, d->x.ptr, w0, y, d->n, d->h, d->w, Ho, Wo); break;
+        case ESR_STORE_F16: hipLaunchKernelGGL(conv3x3s2_kernel<ESR_STORE_F16>, grid, dim3(256), 0, st, d->x.ptr, w0, y, d->n, d->h, d->w, Ho, Wo); break;
+        default: return ESR_ERR_BAD_ARG;
+    }
     return esr_check_launch("conv3x3s2_kernel launch");
 }
 
@@ -360,6 +416,7 @@ int esr_maxpool7s3_f32(const esr_esa_desc* d, void* hip_stream)
     int rc = lowres_args_ok(d);
     if (rc != ESR_OK) return rc;
     if (d->h < 7 || d->w < 7) return ESR_ERR_TOO_SMALL;
+    if (d->storage != ESR_STORE_F32) return ESR_ERR_BAD_ARG;          // low-resolution maps are always fp32
     const int Ho = (d->h - 7) / 3 + 1, Wo = (d->w - 7) / 3 + 1;
     if (d->h_lo != Ho || d->w_lo != Wo) return ESR_ERR_BAD_ARG;
     const long long npix = (long long)d->n * Ho * Wo;
@@ -377,9 +434,9 @@ int esr_esa_apply_f32(const esr_esa_desc* d, void* hip_stream)
     if ((d->x.pitch & 3) || (d->x.coff & 3) || d->x.coff + cp4 > d->x.pitch) return ESR_ERR_BAD_ARG;
     if ((d->y.pitch & 3) || (d->y.coff & 3) || d->y.coff + cp4 > d->y.pitch) return ESR_ERR_BAD_ARG;
     EsaK k;
-    k.x = static_cast<const float*>(d->x.ptr); k.c1 = static_cast<const float*>(d->c1);
+    k.x = d->x.ptr; k.c1 = d->c1;
     k.c3 = static_cast<const float*>(d->c3); k.wf = static_cast<const float*>(d->w0);
-    k.w4 = static_cast<const float*>(d->w1); k.y = static_cast<float*>(d->y.ptr);
+    k.w4 = static_cast<const float*>(d->w1); k.y = d->y.ptr;
     k.x_pitch = d->x.pitch; k.x_coff = d->x.coff; k.y_pitch = d->y.pitch; k.y_coff = d->y.coff;
     k.N = d->n; k.H = d->h; k.W = d->w; k.Cp4 = cp4; k.cp = cp4; k.h3 = d->h_lo; k.w3 = d->w_lo;
     k.sh = (float)d->h_lo / (float)d->h;      // ATen area_pixel_compute_scale: float(in) / out
@@ -388,7 +445,13 @@ int esr_esa_apply_f32(const esr_esa_desc* d, void* hip_stream)
     const size_t lds = ((size_t)FP * FP + FP + (((size_t)FP * cp4 + cp4 + 3) & ~(size_t)3) + 16 * FP) * sizeof(float);
     const long long ngroups = (npix + 15) / 16;
     const unsigned grid = (unsigned)(ngroups < 8192 ? ngroups : 8192);        // 256 CUs x 8 blocks x 4 rounds
-    hipLaunchKernelGGL(esa_apply_kernel, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(hip_stream), k);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    switch (d->storage) {
+        case ESR_STORE_F32: hipLaunchKernelGGL(esa_apply_kernel<ESR_STORE_F32>, dim3(grid), dim3(256), lds, st, k); break;
+        case ESR_STORE_BF16: hipLaunchKernelGGL(esa_apply_kernel<ESR_STORE_BF16>, dim3(grid), dim3(256), lds, st, k); break;
+        case ESR_STORE_F16: hipLaunchKernelGGL(esa_apply_kernel<ESR_STORE_F16>, dim3(grid), dim3(256), lds, st, k); break;
+        default: return ESR_ERR_BAD_ARG;
+    }
     return esr_check_launch("esa_apply_kernel launch");
 }
 

@@ -69,6 +69,7 @@ struct ConvK {
     const float* wp3; const float* bias3; float* y2;
     int y2_pitch, y2_coff, y2_cout4, post_act, post_nch8;
     int res_in;           // the (pre-activation) residual IS the conv input: taken from the staged tile, no residual loads
+    int out16;            // NCHW head only: the NHWC output is stored as bf16 (1) / fp16 (2) (esr_storage), 0 = fp32
 #ifdef ESR_EXPERIMENTAL_WS
     int hand_rows;        // accumulator rows (of 4) finished by the loader partner
 #endif
@@ -220,6 +221,47 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvK& p, f32x4 (&acc)[NT][4
     else if (inside && p.act == ESR_ACT_GELU && p.res_mode == ESR_RES_NONE)
         epilogue_nhwc_fast<ESR_ACT_GELU, ESR_RES_NONE, NT>(p, acc, scr, n, x0, y0, wv, lane);
     else epilogue_nhwc_checked<NT>(p, acc, scr, n, x0, y0, wv, lane);
+}
+
+// NCHW head of a 16-bit-storage network: the native fragment (4 channels of one pixel per lane) goes out as 8 bytes per lane.
+// HBM-write-bound and 1 % of a forward: no transposition.
+template <int NT>
+__device__ __forceinline__ void epilogue_nhwc_store16(const ConvK& p, f32x4 (&acc)[NT][4], int n, int x0, int y0, int wv, int lane)
+{
+    const int px = lane & 15, kq = lane >> 4;
+    const int gx = x0 + px;
+    if (gx >= p.W) return;
+    const int c8 = (p.cout_store + 7) & ~7;                  // pad channels up to the 16-byte granule are written as act(0 + bias 0) = 0
+    unsigned short* const y = reinterpret_cast<unsigned short*>(p.y0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gy = y0 + wv * 4 + r;
+        if (gy >= p.H) continue;
+        const size_t pix = ((size_t)n * p.H + gy) * p.W + gx;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int cb = t * 16 + kq * 4;
+            if (cb >= c8) continue;
+            f32x4 v = acc[t][r];
+            v.x = act_any(v.x, p.act, p.slope); v.y = act_any(v.y, p.act, p.slope);
+            v.z = act_any(v.z, p.act, p.slope); v.w = act_any(v.w, p.act, p.slope);
+            unsigned lo, hi;
+            if (p.out16 == ESR_STORE_BF16) {
+                typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+                b2 a, b;
+                a[0] = (__bf16)v.x; a[1] = (__bf16)v.y; b[0] = (__bf16)v.z; b[1] = (__bf16)v.w;
+                lo = __builtin_bit_cast(unsigned, a); hi = __builtin_bit_cast(unsigned, b);
+            } else {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                h2 a, b;
+                a[0] = (_Float16)v.x; a[1] = (_Float16)v.y; b[0] = (_Float16)v.z; b[1] = (_Float16)v.w;
+                lo = __builtin_bit_cast(unsigned, a); hi = __builtin_bit_cast(unsigned, b);
+            }
+            uint2 o;
+            o.x = lo; o.y = hi;
+            *reinterpret_cast<uint2*>(y + pix * p.y0_pitch + p.y0_coff + cb) = o;
+        }
+    }
 }
 
 template <int NT>
@@ -663,6 +705,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
             }
             epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE_H);
         } else if (p.out_layout == ESR_NCHW_SHUFFLE4) epilogue_shuffle<NT>(p, acc, cur.n, cur.x0, cur.y0, wv, lane);
+        else if (IN_NCHW && p.out16) epilogue_nhwc_store16<NT>(p, acc, cur.n, cur.x0, cur.y0, wv, lane);
         else epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE_H);
         if (!has_next) break;
         cur = nxt;
@@ -675,201 +718,6 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
 #ifdef ESR_EXPERIMENTAL_WS
 #include "experimental/conv_ws.inc"        // wave-specialised research variant (tools/dbg builds only)
 #endif
-
-// ---- 16-bit-operand variant (bf16 or fp16 MFMA operands, fp32 accumulate, fp32 storage) ----------------
-// Same persistent structure as conv_f32_kernel, KS = 3 and NHWC input only.  Activations stay fp32 in HBM and
-// are rounded (RNE) to bf16/fp16 while they are staged into LDS; weights are pre-rounded by esr_pack_conv_h16.
-// K slots of v_mfma_f32_16x16x16_{bf16,f16}: lane (i, kq) holds 4 consecutive k; here k-slot kq carries
-// tap 2*pair + (kq >> 1), channels c0 + 4*(kq & 1) + 0..3 -- one MFMA covers TWO taps x 8 channels, so the 9
-// taps of a chunk take 5 MFMAs (the 10th tap has zero weights) instead of 18 fp32 ones, at 16x the rate:
-// the layer becomes HBM/LDS-bound.  D fragment and epilogues are identical to the fp32 kernel.
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
-constexpr int H16_PAIRS = 5;
-
-template <bool BF16>
-__device__ __forceinline__ unsigned long long cvt4(f32x4 v)
-{
-    if (BF16) {
-        b16x4 b;
-        b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
-        return __builtin_bit_cast(unsigned long long, b);
-    } else {
-        h16x4 h;
-        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-        return __builtin_bit_cast(unsigned long long, h);
-    }
-}
-
-template <bool BF16>
-__device__ __forceinline__ f32x4 mfma16(unsigned long long a, unsigned long long b, f32x4 c)
-{
-    if (BF16) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
-}
-
-template <int NT, bool BF16>
-__global__ __launch_bounds__(THREADS, 2) void conv_h16_kernel(const ConvK p)
-{
-    constexpr int TH = TILE + 2;
-    constexpr int NPX = TH * TH;
-    constexpr int IN_ITEMS = 2 * NPX;                 // (pixel, half) items: 16 B fp32 in HBM -> 8 B in LDS
-    constexpr int IN_BYTES = IN_ITEMS * 8;
-    constexpr int W_ITEMS = H16_PAIRS * NT * 32;      // 16-byte items per stage (weights, 16-bit)
-    constexpr int W_BYTES = W_ITEMS * 16;
-    constexpr int STAGE_BYTES = IN_BYTES + W_BYTES;
-    constexpr int IN_ROUNDS = (IN_ITEMS + THREADS - 1) / THREADS;
-    constexpr int W_ROUNDS = (W_ITEMS + THREADS - 1) / THREADS;
-    constexpr unsigned OOB = 0x80000000u;
-
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + 4 * EPI_WAVE_FLOATS * 4];
-
-    __builtin_amdgcn_s_setprio(3);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = tid >> 6;
-    const int px = lane & 15;
-    const int kq = lane >> 4;
-    float* const scr = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES) + wv * EPI_WAVE_FLOATS;
-
-    const int ntiles = p.N * p.tiles_y * p.tiles_x;
-    const int G = gridDim.x;
-    auto tile_index = [&](int k) -> int {
-        const int base = k * G;
-        if (base >= ntiles) return -1;
-        int off = blockIdx.x;
-        if ((G & 7) == 0 && base + G <= ntiles) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-        const int t = base + off;
-        return t < ntiles ? t : -1;
-    };
-    struct TileCtx { int n, x0, y0; unsigned voff[IN_ROUNDS]; };
-    auto setup_tile = [&](int t, TileCtx& c) {
-        const int tx = t % p.tiles_x;
-        const int tq = t / p.tiles_x;
-        const int ty = tq % p.tiles_y;
-        c.n = tq / p.tiles_y;
-        c.x0 = tx * TILE;
-        c.y0 = ty * TILE;
-#pragma unroll
-        for (int r = 0; r < IN_ROUNDS; ++r) {
-            const int idx = tid + r * THREADS;
-            const int half = idx & 1;
-            const int pl = idx >> 1;
-            const int ly = pl / TH, lx = pl - ly * TH;
-            const int gy = c.y0 - 1 + ly, gx = c.x0 - 1 + lx;
-            const bool ok = idx < IN_ITEMS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            c.voff[r] = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff + 4 * half) * 4u : OOB;
-        }
-    };
-    const size_t img_floats = (size_t)p.H * p.W * p.in_pitch;
-    auto image_rsrc = [&](int n) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)n * img_floats), 0, (int)(img_floats * 4), 0x00020000);
-    };
-    const __amdgpu_buffer_rsrc_t wrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, p.nchunks * W_BYTES, 0x00020000);
-
-    f32x4 in_reg[IN_ROUNDS];
-    f32x4 w_reg[W_ROUNDS];
-    auto load_stage = [&](const TileCtx& tc, int c) {
-        const __amdgpu_buffer_rsrc_t xrsrc = image_rsrc(tc.n);
-#pragma unroll
-        for (int r = 0; r < IN_ROUNDS; ++r)
-            in_reg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, tc.voff[r], c * (CHUNK * 4), 0));
-#pragma unroll
-        for (int r = 0; r < W_ROUNDS; ++r) {
-            const unsigned voff = (unsigned)min(tid + r * THREADS, W_ITEMS - 1) * 16u;
-            w_reg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, c * W_BYTES, 0));
-        }
-    };
-    auto store_stage = [&](int buf) {
-        char* s = smem + buf * STAGE_BYTES;
-#pragma unroll
-        for (int r = 0; r < IN_ROUNDS; ++r) {
-            const int idx = tid + r * THREADS;
-            if (IN_ITEMS % THREADS == 0 || idx < IN_ITEMS)
-                *reinterpret_cast<unsigned long long*>(s + (idx & 1) * (NPX * 8) + (idx >> 1) * 8) = cvt4<BF16>(in_reg[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < W_ROUNDS; ++r) {
-            const int idx = tid + r * THREADS;
-            if (W_ITEMS % THREADS == 0 || idx < W_ITEMS)
-                *reinterpret_cast<f32x4*>(s + IN_BYTES + idx * 16) = w_reg[r];
-        }
-    };
-
-    // lane-constant LDS byte offsets: B operand of pair q reads tap min(2q + (kq >> 1), 8), channel half kq & 1
-    const int b_lane = (kq & 1) * (NPX * 8) + ((wv * 4) * TH + px) * 8;
-    int b_pair[H16_PAIRS];
-#pragma unroll
-    for (int q = 0; q < H16_PAIRS; ++q) {
-        const int tap = min(2 * q + (kq >> 1), 8);
-        b_pair[q] = b_lane + ((tap / 3) * TH + (tap % 3)) * 8;
-    }
-    const int a_base = IN_BYTES + lane * 8;
-
-    int k = 0;
-    int t = tile_index(0);
-    if (t < 0) return;
-    TileCtx cur, nxt;
-    setup_tile(t, cur);
-    load_stage(cur, 0);
-    store_stage(0);
-    __syncthreads();
-    int sbuf = 0;
-
-    for (;;) {
-        const int tn = tile_index(k + 1);
-        const bool has_next = tn >= 0;
-        f32x4 acc[NT][4];
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + tt * 16 + kq * 4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[tt][r] = bv;
-        }
-        for (int c = 0; c < p.nchunks; ++c) {
-            const bool more = c + 1 < p.nchunks;
-            if (more) {
-                load_stage(cur, c + 1);
-            } else if (has_next) {
-                setup_tile(tn, nxt);
-                load_stage(nxt, 0);
-            }
-            const char* s = smem + sbuf * STAGE_BYTES;
-            unsigned long long a[2][NT], b[2][4];
-            auto load_frag = [&](int slot, int q) {
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-                    a[slot][tt] = *reinterpret_cast<const unsigned long long*>(s + a_base + (q * NT + tt) * 512);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    b[slot][r] = *reinterpret_cast<const unsigned long long*>(s + b_pair[q] + r * (TH * 8));
-            };
-            load_frag(0, 0);
-            __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-            for (int q = 0; q < H16_PAIRS; ++q) {
-                const int cs = q & 1;
-                if (q + 1 < H16_PAIRS) load_frag(cs ^ 1, q + 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[tt][r] = mfma16<BF16>(a[cs][tt], b[cs][r], acc[tt][r]);
-            }
-            __builtin_amdgcn_s_setprio(3);
-            if (more || has_next) store_stage(sbuf ^ 1);
-            __syncthreads();
-            sbuf ^= 1;
-        }
-        if (p.out_layout == ESR_NCHW_SHUFFLE4) epilogue_shuffle<NT>(p, acc, cur.n, cur.x0, cur.y0, wv, lane);
-        else epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane);
-        if (!has_next) break;
-        cur = nxt;
-        ++k;
-    }
-}
 
 thread_local char g_err[256] = "";
 
@@ -978,49 +826,6 @@ int launch_conv_nt(int nt, const ConvK& k, hipStream_t st)
     return ESR_ERR_UNSUPPORTED;
 }
 
-template <int NT, bool BF16>
-int launch_h16(const ConvK& k, hipStream_t st)
-{
-    const int ntiles = k.N * k.tiles_x * k.tiles_y;
-    const int grid = ntiles < MAX_RESIDENT_BLOCKS ? ntiles : MAX_RESIDENT_BLOCKS;
-    hipLaunchKernelGGL((conv_h16_kernel<NT, BF16>), dim3(grid), dim3(THREADS), 0, st, k);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        set_err("conv_h16_kernel launch", e);
-        return ESR_ERR_LAUNCH;
-    }
-    return ESR_OK;
-}
-
-template <bool BF16>
-int launch_h16_nt(int nt, const ConvK& k, hipStream_t st)
-{
-    switch (nt) {
-        case 1: return launch_h16<1, BF16>(k, st);
-        case 2: return launch_h16<2, BF16>(k, st);
-        case 3: return launch_h16<3, BF16>(k, st);
-        case 4: return launch_h16<4, BF16>(k, st);
-    }
-    return ESR_ERR_UNSUPPORTED;
-}
-
-// host-side RNE conversions for the weight packer
-inline uint16_t f32_to_bf16(float f)
-{
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);       // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-inline uint16_t f32_to_f16(float f)
-{
-    const _Float16 h = (_Float16)f;        // host compiler: IEEE RNE
-    uint16_t r;
-    memcpy(&r, &h, 2);
-    return r;
-}
-
 }  // namespace
 
 void esr_set_err(const char* what, hipError_t e)
@@ -1045,7 +850,7 @@ extern "C" {
 
 int esr_abi_version(void) { return ESR_ABI_VERSION; }
 const char* esr_last_hip_error(void) { return g_err; }
-const char* esr_build_info(void) { return "gfx950 f32:v_mfma_f32_16x16x4_f32 h16:v_mfma_f32_16x16x16_{bf16,f16} tiles 16x16/16x32 chunk8 persistent"; }
+const char* esr_build_info(void) { return "gfx950 f32:v_mfma_f32_16x16x4_f32 (tiles 16x16/16x32, chunk 8) s16:v_mfma_f32_16x16x32_{bf16,f16} (16-bit storage, LDS-DMA ring, chunk 16) persistent"; }
 
 size_t esr_packed_conv_bytes(int cin_phys, int cout, int ksize)
 {
@@ -1114,49 +919,10 @@ int esr_unpack_conv_f32(const void* packed, size_t bytes, int cin, int cout, int
     return ESR_OK;
 }
 
-size_t esr_packed_conv_h16_bytes(int cin_phys, int cout)
-{
-    if (cin_phys <= 0 || cout <= 0) return 0;
-    const size_t nt = (size_t)round_up(cout, 16) / 16;
-    const size_t nchunks = (size_t)round_up(cin_phys, CHUNK) / CHUNK;
-    return nchunks * H16_PAIRS * nt * 512 + nt * 16 * sizeof(float);
-}
-
-int esr_pack_conv_h16(const float* w, const float* bias, int cin, int cout, const int32_t* cin_map, int cin_phys,
-                      int compute, void* out, size_t out_bytes)
-{
-    if (!w || !out || cin <= 0 || cout <= 0) return ESR_ERR_BAD_ARG;
-    if (compute != ESR_COMPUTE_BF16 && compute != ESR_COMPUTE_F16) return ESR_ERR_BAD_ARG;
-    if (!cin_map && cin_phys < cin) return ESR_ERR_BAD_ARG;
-    const size_t need = esr_packed_conv_h16_bytes(cin_phys, cout);
-    if (need == 0 || out_bytes < need) return ESR_ERR_BAD_ARG;
-    const int nt = round_up(cout, 16) / 16;
-    const int nchunks = round_up(cin_phys, CHUNK) / CHUNK;
-    memset(out, 0, need);
-    uint16_t* o = static_cast<uint16_t*>(out);
-    for (int s = 0; s < cin_phys; ++s) {
-        const int c = cin_map ? cin_map[s] : (s < cin ? s : -1);
-        if (c < 0) continue;
-        if (c >= cin) return ESR_ERR_BAD_ARG;
-        const int chunk = s / CHUNK, within = s % CHUNK;      // within = 4*(kq & 1) + j
-        for (int oc = 0; oc < cout; ++oc)
-            for (int tap = 0; tap < 9; ++tap) {
-                const int q = tap / 2, kq = (tap & 1) * 2 + within / 4, j = within % 4;
-                const size_t idx = ((((size_t)chunk * H16_PAIRS + q) * nt + oc / 16) * 64 + kq * 16 + oc % 16) * 4 + j;
-                const float v = w[((size_t)oc * cin + c) * 9 + tap];
-                o[idx] = compute == ESR_COMPUTE_BF16 ? f32_to_bf16(v) : f32_to_f16(v);
-            }
-    }
-    float* bo = reinterpret_cast<float*>(static_cast<char*>(out) + (size_t)nchunks * H16_PAIRS * nt * 512);
-    if (bias)
-        for (int oc = 0; oc < cout; ++oc) bo[oc] = bias[oc];
-    return ESR_OK;
-}
-
 int esr_conv_block_waves(const esr_conv_desc* d)
 {
     if (!d || d->cin <= 0 || d->cout <= 0) return 0;
-    if (d->compute != ESR_COMPUTE_F32) return 4;
+    if (d->storage != ESR_STORE_F32 && d->in_layout == ESR_NHWC) return 8;      // conv_s16_kernel: 8-wave blocks
     const bool in_nchw = d->in_layout == ESR_NCHW_IN;
     const int cin_phys = in_nchw ? CHUNK : round_up(d->cin, CHUNK);
     return conv_block_waves(d->ksize, in_nchw, round_up(d->cout, 16) / 16, cin_phys / CHUNK, d->n, d->h, d->w);
@@ -1171,13 +937,23 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
     const bool in_nchw = d->in_layout == ESR_NCHW_IN;
     if (in_nchw && (d->cin > 4 || d->ksize != 3)) return ESR_ERR_UNSUPPORTED;
     if (!in_nchw && d->in_layout != ESR_NHWC) return ESR_ERR_BAD_ARG;
+    const bool store16 = d->storage == ESR_STORE_BF16 || d->storage == ESR_STORE_F16;
+    if (d->storage != ESR_STORE_F32 && !store16) return ESR_ERR_BAD_ARG;
+    if (store16 && !in_nchw) return esr_conv2d_s16(d, hip_stream);         // 16-bit storage: esr_s16.hip
+    if (d->compute != ESR_COMPUTE_F32) return ESR_ERR_BAD_ARG;              // fp32 MFMA from here on (incl. the NCHW head)
+    if (store16) {
+        // the network head with 16-bit activations downstream: fp32 NCHW input (exact), fp32 MFMA, 16-bit NHWC store
+        if (d->out_layout != ESR_NHWC || d->res_mode != ESR_RES_NONE || d->tail_wpacked || d->post_wpacked) return ESR_ERR_UNSUPPORTED;
+        if (d->split > 0 && d->split < d->cout) return ESR_ERR_UNSUPPORTED;
+        if ((d->out0.pitch & 7) || (d->out0.coff & 7) || d->out0.coff + round_up(d->cout, 8) > d->out0.pitch) return ESR_ERR_BAD_ARG;
+    }
     if (!in_nchw && ((d->in.pitch & 3) || (d->in.coff & 3))) return ESR_ERR_BAD_ARG;
     const int cin_phys = in_nchw ? CHUNK : round_up(d->cin, CHUNK);
     if (!in_nchw && d->in.coff + cin_phys > d->in.pitch) return ESR_ERR_BAD_ARG;   // chunk reads stay inside the pixel
     // fused 1x1 tail: the epilogue fields describe the 1x1's output
     const bool tail = d->tail_wpacked != nullptr;
     if (tail) {
-        if (d->ksize != 3 || in_nchw || d->out_layout != ESR_NHWC || d->cout > 16 || d->compute != ESR_COMPUTE_F32) return ESR_ERR_UNSUPPORTED;
+        if (d->ksize != 3 || in_nchw || d->out_layout != ESR_NHWC || d->cout > 16) return ESR_ERR_UNSUPPORTED;
         if (d->tail_cat_c <= 0 || (d->tail_cat_c & 15) || d->tail_cat_c + 16 > 16 * TAIL_C16) return ESR_ERR_UNSUPPORTED;
         if (d->tail_cout <= 48 || d->tail_cout > 64) return ESR_ERR_UNSUPPORTED;
         if (!d->tail_cat.ptr || (d->tail_cat.pitch & 3) || (d->tail_cat.coff & 3) || d->tail_cat.coff + d->tail_cat_c > d->tail_cat.pitch)
@@ -1186,7 +962,7 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
     const bool post = d->post_wpacked != nullptr;
     if (post) {
         if (tail || d->ksize != 3 || in_nchw || d->out_layout != ESR_NHWC || d->cout <= 48 || d->cout > 64 ||
-            d->compute != ESR_COMPUTE_F32 || d->post_cout <= 0 || d->post_cout > 32)
+            d->post_cout <= 0 || d->post_cout > 32)
             return ESR_ERR_UNSUPPORTED;
         const bool res_is_in = d->res_mode == ESR_RES_PRE_ACT && d->cin == d->cout && d->res.ptr == d->in.ptr &&
                                d->res.pitch == d->in.pitch && d->res.coff == d->in.coff;
@@ -1233,15 +1009,12 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
 
     const int nt = round_up(d->cout, 16) / 16;
     const int taps = d->ksize * d->ksize;
-    const bool h16 = d->compute == ESR_COMPUTE_BF16 || d->compute == ESR_COMPUTE_F16;
-    if (d->compute != ESR_COMPUTE_F32 && !h16) return ESR_ERR_BAD_ARG;
-    if (h16 && (d->ksize != 3 || in_nchw)) return ESR_ERR_UNSUPPORTED;     // 16-bit operands: full 3x3 NHWC convs only
     ConvK k;
+    k.out16 = store16 ? d->storage : 0;
     k.x = static_cast<const float*>(d->in.ptr);
     k.wp = static_cast<const float*>(d->wpacked);
     k.nchunks = cin_phys / CHUNK;
-    k.bias = h16 ? reinterpret_cast<const float*>(static_cast<const char*>(d->wpacked) + (size_t)k.nchunks * H16_PAIRS * nt * 512)
-                 : k.wp + (size_t)k.nchunks * taps * nt * 128;
+    k.bias = k.wp + (size_t)k.nchunks * taps * nt * 128;
     k.res = static_cast<const float*>(d->res.ptr);
     k.y0 = static_cast<float*>(d->out0.ptr);
     k.y1 = static_cast<float*>(d->out1.ptr);
@@ -1255,7 +1028,7 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
     k.split = split;
     k.act = d->act; k.slope = d->slope; k.res_mode = d->res_mode;
     k.res_in = 0;
-    if (!h16 && !tail && d->ksize == 3 && !in_nchw && d->res_mode == ESR_RES_PRE_ACT && d->cin == d->cout &&
+    if (!tail && d->ksize == 3 && !in_nchw && d->res_mode == ESR_RES_PRE_ACT && d->cin == d->cout &&
         d->res.ptr == d->in.ptr && d->res.pitch == d->in.pitch && d->res.coff == d->in.coff) {
         k.res_in = 1;                               // residual == input: added from the staged input tile inside the K loop
         k.res_mode = ESR_RES_NONE;
@@ -1302,7 +1075,6 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
         }
         return launch_conv_tail(k, st);
     }
-    if (h16) return d->compute == ESR_COMPUTE_BF16 ? launch_h16_nt<true>(nt, k, st) : launch_h16_nt<false>(nt, k, st);
     if (in_nchw) return launch_conv_nt<3, true>(nt, k, st);
     if (d->ksize == 3) return launch_conv_nt<3, false>(nt, k, st);
     return launch_conv_nt<1, false>(nt, k, st);

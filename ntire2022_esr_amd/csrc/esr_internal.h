@@ -6,3 +6,6 @@
 void esr_set_err(const char* what, hipError_t e);
 int esr_check_launch(const char* what);
 static inline int esr_round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// esr_s16.hip: NHWC convolution on 16-bit storage (called by esr_conv2d_f32 when d->storage != ESR_STORE_F32)
+int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream);

@@ -50,12 +50,15 @@ def pack_conv(weight, bias, cin_map=None, cin_phys=None):
     return out
 
 
-def pack_conv_h16(weight, bias, compute, cin_map=None, cin_phys=None):
-    """3x3 OIHW fp32 weights -> 16-bit-operand blob (bf16 or fp16, RNE) + fp32 bias (esr_pack_conv_h16)."""
+def pack_conv_s16(weight, bias, compute, cin_map=None, cin_phys=None):
+    """OIHW (or [out,in]) fp32 weights -> the 16-bit-storage blob of esr_pack_conv_s16 (bf16 or fp16; 3x3 taps rounded
+    with error diffusion, 1x1 as hi + lo) + fp32 bias."""
     lib = L.lib()
     w = weight.detach().to("cpu", torch.float32).contiguous()
+    if w.dim() == 2:
+        w = w[:, :, None, None].contiguous()
     cout, cin, k, _ = w.shape
-    assert k == 3
+    assert k in (1, 3)
     b = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
     if cin_map is not None:
         cm = np.ascontiguousarray(np.asarray(cin_map, dtype=np.int32))
@@ -63,12 +66,30 @@ def pack_conv_h16(weight, bias, compute, cin_map=None, cin_phys=None):
     else:
         cm_p = None
         cin_phys = cin if cin_phys is None else cin_phys
-    nbytes = lib.esr_packed_conv_h16_bytes(cin_phys, cout)
+    nbytes = lib.esr_packed_conv_s16_bytes(cin_phys, cout, k)
     out = torch.empty((nbytes + 3) // 4, dtype=torch.float32)
-    L.check(lib.esr_pack_conv_h16(_ptr(w), _ptr(b) if b is not None else None, cin, cout, cm_p, cin_phys,
+    L.check(lib.esr_pack_conv_s16(_ptr(w), _ptr(b) if b is not None else None, cin, cout, k, cm_p, cin_phys,
                                   L.COMPUTE[compute] if isinstance(compute, str) else compute, _ptr(out), nbytes),
-            "esr_pack_conv_h16")
+            "esr_pack_conv_s16")
     return out
+
+
+def unpack_conv_s16(blob, cin, cout, k, compute, cin_map=None, cin_phys=None):
+    """EFFECTIVE fp32 weights (what the 16-bit kernel multiplies by) + bias of a pack_conv_s16 blob."""
+    lib = L.lib()
+    blob = blob.detach().to("cpu").contiguous()
+    if cin_map is not None:
+        cm = np.ascontiguousarray(np.asarray(cin_map, dtype=np.int32))
+        cin_phys, cm_p = len(cm), cm.ctypes.data_as(ctypes.c_void_p)
+    else:
+        cm_p = None
+        cin_phys = cin if cin_phys is None else cin_phys
+    w = torch.empty(cout, cin, k, k)
+    b = torch.empty(cout)
+    L.check(lib.esr_unpack_conv_s16(_ptr(blob), blob.numel() * blob.element_size(), cin, cout, k, cm_p, cin_phys,
+                                    L.COMPUTE[compute] if isinstance(compute, str) else compute, _ptr(w), _ptr(b)),
+            "esr_unpack_conv_s16")
+    return w, b
 
 
 def pack_dense(weight, bias, cin_p, cout_p):
@@ -207,8 +228,10 @@ class Plan:
         buf, coff, _ = v
         return L.View(ctypes.c_void_p(base_ptr + buf.offset), buf.pitch, coff)
 
-    def finalize(self, workspace, weights, h16=None, compute=0):
-        """weights: name -> device blob tensor.  Returns (Op array, input op indices, output op indices)."""
+    def finalize(self, workspace, weights):
+        """weights: name -> device blob tensor (16-bit-storage plans: `name#s16` for the NHWC convs).  Returns
+        (Op array, input op indices, output op indices)."""
+        st = L.STORE[self.store]
         arr = (L.Op * len(self.ops))()
         in_idx, out_idx = [], []
         base = workspace if isinstance(workspace, int) else (workspace.data_ptr() if workspace is not None else 0)
@@ -217,16 +240,18 @@ class Plan:
             if o["kind"] == "bs":
                 op.kind = L.OP_BSCONV
                 d = op.bs
+                d.storage = st
                 d.n, d.h, d.w, d.cin, d.c = self.n, self.h, self.w, o["cin"], o["cout"]
                 d.act, d.slope, d.res_mode = o["act"], o["slope"], o["res_mode"]
                 d.inp, d.out = self._view(o["src"], base), self._view(o["dst"], base)
                 if o["res"] is not None:
                     d.res = self._view(o["res"], base)
-                d.pw_packed = ctypes.c_void_p(weights[o["pw"]].data_ptr())
+                sfx = "#s16" if st else ""                        # 16-bit storage: hi + lo 1x1 blobs (esr_pack_conv_s16)
+                d.pw_packed = ctypes.c_void_p(weights[o["pw"] + sfx].data_ptr())
                 d.dw_packed = ctypes.c_void_p(weights[o["dw"]].data_ptr())
                 t = o["distill"]
                 if t is not None:
-                    d.d_packed = ctypes.c_void_p(weights[t["w"]].data_ptr())
+                    d.d_packed = ctypes.c_void_p(weights[t["w"] + sfx].data_ptr())
                     d.d_cout, d.d_act = t["cout"], t.get("act", L.ACT_NONE)
                     d.d_out = self._view(t["dst"], base)
                 continue
@@ -235,6 +260,7 @@ class Plan:
                 e.n = self.n
                 if o["kind"] == "apply":
                     op.kind = L.OP_ESA_APPLY
+                    e.storage = st
                     e.h, e.w, e.c, e.f = self.h, self.w, o["c"], o["f"]
                     e.h_lo, e.w_lo = o["c3"].h, o["c3"].w
                     e.x, e.y = self._view(o["x"], base), self._view(o["dst"], base)
@@ -248,6 +274,7 @@ class Plan:
                     e.h_lo, e.w_lo = o["dst"].h, o["dst"].w
                     e.x, e.y = self._view(o["src"], base), self._view(o["dst"], base)
                     if o["kind"] == "s2":
+                        e.storage = st                           # reads the full-resolution conv1 map
                         e.f = o["f"]
                         e.w0 = ctypes.c_void_p(weights[o["w"]].data_ptr())
                 continue
@@ -275,9 +302,11 @@ class Plan:
                 d.out1 = self._view(o["dst1"], base)
             if o["res"] is not None:
                 d.res = self._view(o["res"], base)
-            if h16 is not None and h16(o):
-                d.wpacked = ctypes.c_void_p(weights[o["w"] + "#h16"].data_ptr())
-                d.compute = compute
+            lowres = o["hw"] is not None
+            d.storage = 0 if lowres else st                       # ESA low-resolution maps: fp32
+            if st and not lowres and o["kind"] == "conv" and o["src"] is not INPUT:
+                d.wpacked = ctypes.c_void_p(weights[o["w"] + "#s16"].data_ptr())     # conv_s16_kernel
+                d.compute = st
             else:
                 d.wpacked = ctypes.c_void_p(weights[o["w"]].data_ptr())
             t = o.get("tail")
@@ -357,8 +386,10 @@ class HipSRModel(nn.Module):
         return mod
 
     def set_compute(self, mode):
-        """Operand format of the matrix products in the full-resolution 3x3 convolutions (storage and
-        accumulation stay fp32): 'f32' exact, 'bf16' / 'f16' = 16-bit MFMA operands (BASELINE configs 3-5)."""
+        """'f32': exact fp32 MFMA, fp32 activations.  'bf16' / 'f16' (BASELINE.json configs [2]-[4]): the full-resolution
+        activations are STORED in that type and are the MFMA operands as they are (v_mfma_f32_16x16x32), accumulation,
+        bias, residual and activation stay fp32, one rounding per stored value; the NCHW input / output and the ESA
+        low-resolution branch stay fp32."""
         if mode not in L.COMPUTE:
             raise ValueError(f"compute must be one of {sorted(L.COMPUTE)}")
         if mode != self.compute:
@@ -366,9 +397,21 @@ class HipSRModel(nn.Module):
             self._dirty = True
         return self
 
-    def _uses_h16(self, o):
-        return (self.compute != "f32" and o["kind"] == "conv" and o["k"] == 3 and o["hw"] is None and o["src"] is not INPUT
-                and o.get("tail") is None and o.get("post") is None)   # the fused 1x1 paths exist for fp32 MFMA operands only
+    def _store(self):
+        """storage type of the full-resolution activations for the current compute mode"""
+        return self.compute
+
+    def _s16_convs(self):
+        """paths of the convolutions conv_s16_kernel runs in the 16-bit modes: every full-resolution NHWC conv"""
+        plan = Plan(1, 32, 32, self._store())
+        self._build_plan(plan, self.in_nc)
+        paths = {o["w"] for o in plan.ops if o["kind"] == "conv" and o["hw"] is None and o["src"] is not INPUT}
+        for o in plan.ops:
+            if o["kind"] == "bs":                        # BSConvU: pointwise + distillation 1x1 weights as hi + lo blobs
+                paths.add(o["pw"])
+                if o["distill"] is not None:
+                    paths.add(o["distill"]["w"])
+        return paths
 
     # -- packing ------------------------------------------------------------------------------
     MAX_PLANS = 128                # DIV2K has ~100 distinct LR shapes; a plan is a few tens of KB of host memory
@@ -390,13 +433,20 @@ class HipSRModel(nn.Module):
         self._plans.clear()
         self._ws_owner = None
 
+    def _cin_map(self, path, cin_map, store):
+        """physical-slot -> logical-channel map of a conv reading a padded concat buffer; networks whose slice padding
+        depends on the storage type override this"""
+        return cin_map
+
     def repack(self, device):
         packed = {}
+        s16 = self._s16_convs() if self._store() != "f32" else set()
         for path, (cin, cout, k, cin_map) in self._conv_specs.items():
             leaf = self._leaf(path)
-            packed[path] = pack_conv(leaf.weight, leaf.bias, cin_map=cin_map).to(device)
-            if self.compute != "f32" and k == 3:
-                packed[path + "#h16"] = pack_conv_h16(leaf.weight, leaf.bias, self.compute, cin_map=cin_map).to(device)
+            packed[path] = pack_conv(leaf.weight, leaf.bias, cin_map=self._cin_map(path, cin_map, "f32")).to(device)
+            if path in s16:
+                packed[path + "#s16"] = pack_conv_s16(leaf.weight, leaf.bias, self._store(),
+                                                      cin_map=self._cin_map(path, cin_map, self._store())).to(device)
         for path, (cin_p, cout_p) in self._dense_specs.items():
             leaf = self._leaf(path)
             packed[path] = pack_dense(leaf.weight, leaf.bias, cin_p, cout_p).to(device)
@@ -427,7 +477,7 @@ class HipSRModel(nn.Module):
         n, c, h, w, device = key
         ent = self._plans.get(key)
         if ent is None:
-            plan = Plan(n, h, w)
+            plan = Plan(n, h, w, self._store())
             self._build_plan(plan, c)
             ent = _Entry(plan)
             self._plans[key] = ent
@@ -444,8 +494,7 @@ class HipSRModel(nn.Module):
             self._ws = torch.zeros(need, dtype=torch.uint8, device=device)
             self._ws_owner = key                                        # fresh zeros: this plan's pad channels are 0
         if ent.base != self._ws.data_ptr():
-            ent.arr, ent.in_idx, ent.out_idx = ent.plan.finalize(self._ws.data_ptr(), self._packed, self._uses_h16,
-                                                                 L.COMPUTE[self.compute])
+            ent.arr, ent.in_idx, ent.out_idx = ent.plan.finalize(self._ws.data_ptr(), self._packed)
             ent.base = self._ws.data_ptr()
         if self._ws_owner != key:
             # another shape's activations are lying where this plan keeps its zero pad channels
@@ -524,8 +573,8 @@ class HipSRModel(nn.Module):
                 nt = (o["cout"] + 15) // 16
                 nw = L.lib().esr_conv_block_waves(ctypes.byref(arr[i].conv)) if arr is not None else 0
                 kern = f"conv_f32_kernel<NT={nt},KS={o['k']},NCHW_IN={int(o['src'] is INPUT)},NW={nw}>"
-                if self._uses_h16(o):
-                    kern = f"conv_h16_kernel<NT={nt},{self.compute}>"
+                if plan.esize == 2 and hw is None and o["src"] is not INPUT:
+                    kern = f"conv_s16_kernel<NT={nt},KS={o['k']},NW=8,{plan.store}>"
                 e_in = 4 if o["src"] is INPUT else e_act
                 e_out = 4 if o["dst"] is OUTPUT else e_act
                 ca = o["cin_alg"]
@@ -628,6 +677,6 @@ class HipSRModel(nn.Module):
         return []
 
     def workspace_bytes(self, n, h, w, c=3):
-        plan = Plan(n, h, w)
+        plan = Plan(n, h, w, self._store())
         self._build_plan(plan, c)
         return plan.total

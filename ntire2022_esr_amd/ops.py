@@ -6,7 +6,7 @@ import ctypes
 import torch
 
 from . import _lib as L
-from .engine import pack_conv, pack_conv_h16
+from .engine import pack_conv, pack_conv_s16
 
 
 def _view(t, coff=0):
@@ -14,15 +14,21 @@ def _view(t, coff=0):
     return L.View(ctypes.c_void_p(t.data_ptr()), t.shape[-1], coff)
 
 
+_STORE_OF = {torch.float32: "f32", torch.bfloat16: "bf16", torch.float16: "f16"}
+
+
 def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.RES_NONE,
            in_nchw=False, shuffle_out=False, out=None, out_coff=0, in_coff=0, cin=None,
-           split=0, out1=None, out1_coff=0, res_coff=0, packed=None, cin_map=None, compute="f32",
+           split=0, out1=None, out1_coff=0, res_coff=0, packed=None, cin_map=None, store=None,
            tail_weight=None, tail_bias=None, tail_cat=None, tail_cat_coff=0, tail_mid_act=L.ACT_NONE,
            post_weight=None, post_bias=None, post_act=L.ACT_NONE):
     """Fused conv (k=1|3, stride 1, same padding) on the current stream.
 
-    x       NHWC [N,H,W,pitch] (channels [in_coff, in_coff+cin) are read) or NCHW if in_nchw
-    returns NHWC [N,H,W,cout] (or `out`), or NCHW [N,cout/16,4H,4W] if shuffle_out
+    x       NHWC [N,H,W,pitch] (channels [in_coff, in_coff+cin) are read) or NCHW fp32 if in_nchw.  The dtype of an NHWC
+            x is the storage type of the op: float32 -> exact fp32 MFMA; bfloat16 / float16 -> conv_s16_kernel (16-bit
+            operands as stored, fp32 accumulate, one rounding at the store); res / out / out1 have the same dtype.
+    store   NCHW input only: "bf16" | "f16" makes the NHWC output 16-bit (the head of a 16-bit network)
+    returns NHWC [N,H,W,cout] (or `out`), or NCHW fp32 [N,cout/16,4H,4W] if shuffle_out
     post_*  esr_conv_desc.post_*: post_weight [pc, cout(, 1, 1)] applied to this conv's activated output; returns (y, post)
     tail_*  fused 1x1 (esr_conv_desc.tail_*): tail_weight [cout1, cat_c + 16(, 1, 1)] over concat(tail_cat slice,
             mid_act(this 3x3 conv)); act / res / out then apply to the 1x1, whose output is returned
@@ -32,10 +38,15 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
     lib = L.lib()
     w4 = weight if weight.dim() == 4 else weight[:, :, None, None]
     cout, wcin, k, _ = w4.shape
+    st = _STORE_OF[x.dtype] if not in_nchw else (store or "f32")
+    s16 = st != "f32" and not in_nchw
     if packed is None:
-        packed = (pack_conv(weight, bias, cin_map=cin_map) if compute == "f32"
-                  else pack_conv_h16(weight, bias, compute, cin_map=cin_map)).to(x.device)
+        packed = (pack_conv_s16(weight, bias, st, cin_map=cin_map) if s16 else pack_conv(weight, bias, cin_map=cin_map)).to(x.device)
+    odt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[st]
+    gran = 4 if st == "f32" else 8
     d = L.ConvDesc()
+    d.storage = L.STORE[st]
+    d.compute = L.COMPUTE[st] if s16 else 0
     if in_nchw:
         n, c, h, w = x.shape
         d.in_layout, cin = L.NCHW_IN, c
@@ -55,7 +66,6 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
         d.tail_cat_c, d.tail_cout, d.tail_mid_act = tw.shape[1] - 16, tw.shape[0], tail_mid_act
         cout = tw.shape[0]                      # what the epilogue stores
     d.act, d.slope, d.res_mode, d.split = act, slope, res_mode, split
-    d.compute = L.COMPUTE[compute]
     if shuffle_out:
         y = torch.empty((n, cout // 16, 4 * h, 4 * w), dtype=torch.float32, device=x.device) if out is None else out
         d.out_layout = L.NCHW_SHUFFLE4
@@ -63,7 +73,7 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
     else:
         if out is None:
             c_store = (min(split, cout) if split else cout)
-            y = torch.zeros((n, h, w, (c_store + 3) // 4 * 4), dtype=torch.float32, device=x.device)
+            y = torch.zeros((n, h, w, (c_store + gran - 1) // gran * gran), dtype=odt, device=x.device)
         else:
             y = out
         d.out_layout = L.NHWC
@@ -124,20 +134,28 @@ def psnr_device(a_u8, b_u8, border=0):
 def bsconv(x, pw_weight, pw_bias, dw_weight, dw_bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.RES_NONE,
            in_coff=0, cin=None, d_weight=None, d_bias=None, d_act=L.ACT_NONE):
     """BSConvU in one launch (esr_bsconv_f32): act(dw3x3(pw1x1(x)) [+ res]); returns y, or (y, distilled) when the
-    distillation 1x1 `d_weight` [d_cout, cin] is given.  x: NHWC [N,H,W,pitch]; pw_weight [c, cin]; dw_weight [c,1,3,3]."""
+    distillation 1x1 `d_weight` [d_cout, cin] is given.  x: NHWC [N,H,W,pitch] fp32 / bfloat16 / float16 (the storage
+    type of the op: res and the outputs have the same dtype); pw_weight [c, cin]; dw_weight [c,1,3,3]."""
     from .engine import pack_dw
     if not x.is_cuda:
         raise L.EsrError("bsconv: tensors must live on the GPU; there is no CPU fallback")
     lib = L.lib()
+    st = _STORE_OF[x.dtype]
     n, h, w, _ = x.shape
     c, wcin = pw_weight.shape[0], pw_weight.shape[1]
     cin = wcin if cin is None else cin
-    keep = [pack_conv(pw_weight.reshape(c, wcin, 1, 1), pw_bias).to(x.device), pack_dw(dw_weight, dw_bias).to(x.device)]
+
+    def pk(wt, b):
+        w4 = wt.reshape(wt.shape[0], wcin, 1, 1)
+        return (pack_conv(w4, b) if st == "f32" else pack_conv_s16(w4, b, st)).to(x.device)
+
+    keep = [pk(pw_weight, pw_bias), pack_dw(dw_weight, dw_bias).to(x.device)]
     d = L.BsDesc()
+    d.storage = L.STORE[st]
     d.n, d.h, d.w, d.cin, d.c = n, h, w, cin, c
     d.act, d.slope, d.res_mode = act, slope, res_mode
     d.inp = _view(x, in_coff)
-    y = torch.zeros((n, h, w, (c + 3) // 4 * 4), dtype=torch.float32, device=x.device)
+    y = torch.zeros((n, h, w, (c + 3) // 4 * 4), dtype=x.dtype, device=x.device)
     d.out = _view(y)
     if res is not None:
         d.res = _view(res)
@@ -145,8 +163,8 @@ def bsconv(x, pw_weight, pw_bias, dw_weight, dw_bias, *, act=L.ACT_NONE, slope=0
     yd = None
     if d_weight is not None:
         dco = d_weight.shape[0]
-        keep.append(pack_conv(d_weight.reshape(dco, wcin, 1, 1), d_bias).to(x.device))
-        yd = torch.zeros((n, h, w, (dco + 3) // 4 * 4), dtype=torch.float32, device=x.device)
+        keep.append(pk(d_weight, d_bias))
+        yd = torch.zeros((n, h, w, (dco + 3) // 4 * 4), dtype=x.dtype, device=x.device)
         d.d_packed, d.d_cout, d.d_act, d.d_out = ctypes.c_void_p(keep[2].data_ptr()), dco, d_act, _view(yd)
     stream = torch.cuda.current_stream(x.device).cuda_stream
     L.check(lib.esr_bsconv_f32(ctypes.byref(d), ctypes.c_void_p(stream)), "esr_bsconv_f32")

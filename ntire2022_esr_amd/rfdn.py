@@ -36,7 +36,7 @@ class RFDN(HipSRModel):
         nf, dc, f = self.nf, self.dc, self.f
         # distilled slices are padded to whole 128-byte lines: a 1x1 writing a 112-byte slice of every 448 bytes costs
         # 17 % more time than one writing 128 of every 512 (partial-line writes), the wider c5 read costs 5 %
-        self.P, self.DP = _pad8(nf), (dc + 31) // 32 * 32
+        self.DP = (dc + 31) // 32 * 32
         cp4 = (nf + 3) // 4 * 4
         self._add_conv('fea_conv', in_nc, nf, 3)
         for k in range(1, 5):
@@ -54,7 +54,7 @@ class RFDN(HipSRModel):
             self._add_conv(b + 'esa.conv3', f, f, 3)
             self._add_conv(b + 'esa.conv3_', f, f, 3)
             self._add_conv(b + 'esa.conv4', f, nf, 1, dense=(FP, cp4))
-        self._add_conv('c.0', nf * num_modules, nf, 1, cin_map=_slice_map(num_modules, nf, self.P))
+        self._add_conv('c.0', nf * num_modules, nf, 1, cin_map=_slice_map(num_modules, nf, _pad8(nf)))
         self._add_conv('LR_conv', nf, nf, 3)
         self._add_conv('upsampler.0', nf, out_nc * upscale * upscale, 3)
 
@@ -66,7 +66,8 @@ class RFDN(HipSRModel):
             raise L.EsrError(f'RFDN expects {self.in_nc} input channels, got {c}')
         if plan.h < 15 or plan.w < 15:
             raise L.EsrError('ESA needs H, W >= 15 (3x3/s2 then 7x7/s3 pooling)')
-        nf, dc, f, P, DP = self.nf, self.dc, self.f, self.P, self.DP
+        nf, dc, f, DP = self.nf, self.dc, self.f, self.DP
+        P = plan.cpad(nf)                                 # 56 fp32 channels / 64 16-bit channels: whole K chunks
         h2, w2, h3, w3 = _lowres(plan.h, plan.w)
         fea = plan.buffer('fea', P)
         bcat = plan.buffer('bcat', 4 * P)                 # the four block outputs, RFDN.py:36
@@ -110,6 +111,11 @@ class RFDN(HipSRModel):
         plan.conv('c.0', bcat, v, 4 * P, nf, k=1, cin_alg=4 * nf, **act)
         plan.conv('LR_conv', v, r1, nf, nf, res=fea, res_mode=L.RES_PRE_ACT)
         plan.conv('upsampler.0', r1, OUTPUT, nf, self.out_nc * 16)
+
+    def _cin_map(self, path, cin_map, store):
+        if path == 'c.0':                                 # the block-output slices are as wide as the storage type's K chunks
+            return _slice_map(self.num_modules, self.nf, _pad8(self.nf) if store == "f32" else (self.nf + 15) // 16 * 16)
+        return cin_map
 
     def _extra_pack(self, packed, device):
         if not self.esa_conv_f:                  # SFDN: c3 + c1_  ==  c3 + conv_f(c1_) with conv_f = identity

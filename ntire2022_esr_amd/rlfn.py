@@ -55,7 +55,7 @@ class RLFN_cut(HipSRModel):
         if plan.h < 15 or plan.w < 15:
             raise L.EsrError('ESA needs H, W >= 15 (3x3/s2 then 7x7/s3 pooling)')
         nf, mf, f = self.nf, self.mf, self.esa_channels
-        P, M = _pad8(nf), _pad8(mf)
+        P, M = plan.cpad(nf), plan.cpad(mf)
         h2, w2, h3, w3 = _lowres(plan.h, plan.w)
         fea = plan.buffer('fea', P)
         xa, xb = plan.buffer('xa', P), plan.buffer('xb', P)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libesr_hip.so does not export {s}"
     assert set(L.EXPORTS) == set(syms), (set(L.EXPORTS) ^ set(syms))
-    assert lib.esr_abi_version() == 3
+    assert lib.esr_abi_version() == 4
     assert b"gfx950" in lib.esr_build_info()
 
 
@@ -134,23 +134,45 @@ def test_imdn_plan_shape():
             IMDN(nc=nc)
 
 
-def test_h16_packer_layout_and_rounding():
-    """esr_pack_conv_h16: RNE to bf16 / fp16, tap-pair layout, zero 10th tap and pad channels, fp32 bias tail."""
-    from ntire2022_esr_amd.engine import pack_conv_h16
+def test_s16_packer_layout_diffusion_and_split():
+    """esr_pack_conv_s16: [chunk of 16][tap pair][tile][lane][8] 16-bit image + fp32 bias; 3x3 taps rounded with error
+    diffusion (the filter's tap SUM stays exact to one rounding), 1x1 stored as hi + lo in the two tap slots of the pair."""
+    from ntire2022_esr_amd.engine import pack_conv_s16, unpack_conv_s16
     g = torch.Generator().manual_seed(3)
-    w, b = torch.randn(16, 8, 3, 3, generator=g), torch.randn(16, generator=g)
-    for mode, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
-        blob = pack_conv_h16(w, b, mode)
+    w, b = torch.randn(16, 16, 3, 3, generator=g), torch.randn(16, generator=g)
+    for mode, dt, eps in (("bf16", torch.bfloat16, 2.0 ** -8), ("f16", torch.float16, 2.0 ** -11)):
+        blob = pack_conv_s16(w, b, mode)
         raw = blob.numpy().view(np.uint16)
-        nw = 1 * 5 * 1 * 64 * 4                                 # chunks x pairs x tiles x lanes x 4
-        vals = torch.from_numpy(raw[:nw].astype(np.int16)).view(dt).float().reshape(5, 64, 4)
-        ref = w.to(dt).float()
+        nw = 1 * 5 * 1 * 64 * 8                                 # chunks x pairs x tiles x lanes x 8
+        vals = torch.from_numpy(raw[:nw].astype(np.int16)).view(dt).float().reshape(5, 64, 8)
+        weff, beff = unpack_conv_s16(blob, 16, 16, 3, mode)
+        assert torch.equal(beff, b)
         for tap in range(9):
             q, hk = tap // 2, tap % 2
             for half in range(2):
                 kq = hk * 2 + half
-                got = vals[q, kq * 16:(kq + 1) * 16, :]          # [cout i][j]
-                assert torch.equal(got, ref[:, 4 * half:4 * half + 4, tap // 3, tap % 3]), (mode, tap, half)
+                got = vals[q, kq * 16:(kq + 1) * 16, :]          # [cout i][j]: channels 8*half + j of tap `tap`
+                assert torch.equal(got, weff[:, 8 * half:8 * half + 8, tap // 3, tap % 3]), (mode, tap, half)
         assert torch.all(vals[4, 32:, :] == 0)                   # the padding 10th tap
+        # every effective weight is a 16-bit value; diffusion moves a tap by at most the rounding errors of its neighbours,
+        # i.e. by less than an ulp of the filter's largest tap ...
+        assert torch.equal(weff, weff.to(dt).float())
+        assert float(((weff - w).abs() / w.abs().amax(dim=(2, 3), keepdim=True)).max()) < 2 * eps
+        # ... and the tap sum of every (cout, cin) filter is far closer to the fp32 sum than independent rounding gets
+        e_diff = (weff.sum(dim=(2, 3)) - w.sum(dim=(2, 3))).abs()
+        e_rne = (w.to(dt).float().sum(dim=(2, 3)) - w.sum(dim=(2, 3))).abs()
+        assert float(e_diff.mean()) < 0.5 * float(e_rne.mean())
         bias = torch.from_numpy(blob.numpy().view(np.uint8)[nw * 2:nw * 2 + 64].copy()).view(torch.float32)
         assert torch.equal(bias, b)
+        # 1x1: hi + lo reproduces the fp32 weight to ~2^-16 (bf16) relative
+        w1 = torch.randn(24, 40, generator=g)
+        m = [i if i % 8 < 5 else -1 for i in range(64)]          # a padded concat layout: 8 slices of 5 channels in 8 slots
+        m = [(s // 8) * 5 + s % 8 if s % 8 < 5 else -1 for s in range(64)]
+        blob1 = pack_conv_s16(w1, None, mode, cin_map=m)
+        w1e, b1e = unpack_conv_s16(blob1, 40, 24, 1, mode, cin_map=m)
+        assert bool(((w1e[:, :, 0, 0] - w1).abs() <= (w1.abs() * eps * eps * 8).clamp_min(6.0e-8)).all())   # fp16 lo: subnormal floor
+        assert torch.all(b1e == 0)
+    lib = __import__("ntire2022_esr_amd._lib", fromlist=["lib"]).lib()
+    assert lib.esr_packed_conv_s16_bytes(64, 64, 3) == 4 * 5 * 4 * 1024 + 256
+    assert lib.esr_packed_conv_s16_bytes(256, 50, 1) == 16 * 1 * 4 * 1024 + 256
+    assert lib.esr_packed_conv_s16_bytes(64, 64, 2) == 0

@@ -51,6 +51,42 @@ def test_dwconv(c, hw, act, res_mode):
     assert torch.all(yc[..., (c + 3) // 4 * 4:] == 3.0)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,c,dco,hw,act,res_mode", [(48, 48, 24, (23, 31), 3, 1), (48, 24, 0, (16, 16), 3, 0),
+                                                       (48, 48, 0, (40, 19), 0, 1), (32, 16, 8, (17, 33), 1, 2)])
+def test_bsconv_16bit_storage(dt, cin, c, dco, hw, act, res_mode):
+    """fused BSConvU on 16-bit storage: 16-bit inputs (exact), hi + lo pointwise weights (fp32-accurate), fp32 depthwise /
+    residual / activation, ONE rounding at the store -- against fp64 ATen on the same inputs"""
+    from ntire2022_esr_amd import ops
+    g = torch.Generator().manual_seed(cin + c + hw[0] + act)
+    x = torch.randn(2, cin, *hw, generator=g).to(dt)
+    r = torch.randn(2, c, *hw, generator=g).to(dt)
+    pw, pb = torch.randn(c, cin, generator=g) * 0.2, torch.randn(c, generator=g)
+    dw, db = torch.randn(c, 1, 3, 3, generator=g) * 0.3, torch.randn(c, generator=g)
+    a = {0: lambda v: v, 1: lambda v: F.leaky_relu(v, 0.05), 3: F.gelu}[act]
+    t = F.conv2d(x.double(), pw.double()[:, :, None, None], pb.double())
+    conv = F.conv2d(t, dw.double(), db.double(), padding=1, groups=c)
+    ref = {0: a(conv), 1: a(conv + r.double()), 2: a(conv) + r.double()}[res_mode]
+    kw = {}
+    if dco:
+        d_w, d_b = torch.randn(dco, cin, generator=g) * 0.2, torch.randn(dco, generator=g)
+        kw = dict(d_weight=d_w, d_bias=d_b, d_act=3)
+        dref = F.gelu(F.conv2d(x.double(), d_w.double()[:, :, None, None], d_b.double()))
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    rg = F.pad(r.permute(0, 2, 3, 1).contiguous(), (0, (-c) % 8)).to(DEV) if res_mode else None
+    out = ops.bsconv(xg, pw, pb, dw, db, act=act, res=rg, res_mode=res_mode, **kw)
+    y = out[0] if dco else out
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+
+    def close(got, want):
+        tol = want.abs() * eps * 1.01 + 2e-4 * max(1.0, float(want.abs().max()))       # + the hi/lo weight residual
+        return bool(((got.double() - want).abs() <= tol).all())
+
+    assert y.dtype == dt and close(y.float().cpu().permute(0, 3, 1, 2)[:, :c], ref)
+    if dco:
+        assert close(out[1].float().cpu().permute(0, 3, 1, 2)[:, :dco], dref)
+
+
 @pytest.fixture(scope="module")
 def model():
     from ntire2022_esr_amd import BSRN

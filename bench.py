@@ -261,7 +261,9 @@ def main():
         total_ms = sum(o["ms_sum"] for o in prof)
         avg_s = ms / launches * 1e-3
         tflops, gbs = flops / avg_s / 1e12, nbytes / avg_s / 1e9
-        kpeak = peak if ("h16" in dom_name or "s16" in dom_name) else PEAK_TFLOPS["f32"]   # fp32-MFMA kernels in every mode
+        # 16-bit modes: conv_s16 / bsconv / esa kernels multiply on v_mfma_f32_16x16x32; the NCHW head and the ESA low-resolution
+        # convs (conv_f32_kernel) stay on the fp32 MFMA in every mode
+        kpeak = peak if not dom_name.startswith("conv_f32") else PEAK_TFLOPS["f32"]
         f_mfma, f_hbm = tflops / kpeak, gbs / HBM_PEAK_GBS
         traffic, traffic_src = None, None
         tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")

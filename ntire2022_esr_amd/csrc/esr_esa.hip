@@ -200,6 +200,153 @@ __global__ __launch_bounds__(256) void esa_apply_kernel(const EsaK p)
     }
 }
 
+// ---- fused ESA tail on 16-bit storage: the two 1x1 convolutions on the matrix cores ------------------------------------
+// One wave = 16 pixels per step.  S = Wf^T . c1 + bf + bilinear(c3) is ONE v_mfma_f32_16x16x32 (B operand = the 16 bytes of
+// c1 as stored; the upper 16 k slots carry the low parts of Wf: w = hi + lo), its D fragment -- lane (px, kq): s[4kq .. 4kq+3]
+// of pixel px, fp32 -- becomes the B operand of conv4 WITHOUT leaving the lane: k slots (kq, 0..3) = the 16-bit high parts
+// of those four values, (kq, 4..7) = their low parts (s = hi + lo keeps fp32 accuracy); per 16-channel output tile two
+// MFMAs (W4 high parts x s, W4 low parts x s_hi).  x is read and y written in the D layout (8 bytes per lane).
+// The VALU version above spends its time on LDS weight reads (0.31 ms per launch at batch 32 against 0.12 ms of memory time).
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+template <int ST>
+__device__ __forceinline__ unsigned short to16(float v)
+{
+    if (ST == ESR_STORE_BF16) return __builtin_bit_cast(unsigned short, (__bf16)v);
+    return __builtin_bit_cast(unsigned short, (_Float16)v);
+}
+template <int ST>
+__device__ __forceinline__ float from16(unsigned short h)
+{
+    if (ST == ESR_STORE_BF16) return __builtin_bit_cast(float, (unsigned)h << 16);
+    return (float)__builtin_bit_cast(_Float16, h);
+}
+template <int ST>
+__device__ __forceinline__ f32x4 mfma_k32(i32x4_t a, i32x4_t b, f32x4 c)
+{
+    if (ST == ESR_STORE_BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+template <int ST, int NT>
+__global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
+{
+    // LDS: A images, lane-linear 16 bytes per lane: [Wf][W4 hi x NT][W4 lo x NT], then bf[16] and b4[NT*16] as floats
+    __shared__ __attribute__((aligned(16))) unsigned short simg[(1 + 2 * NT) * 64 * 8];
+    __shared__ float sbias[16 + NT * 16];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < (1 + 2 * NT) * 512; e += 256) {
+        const int img = e >> 9, l = (e >> 3) & 63, j = e & 7;
+        const int i = l & 15, kq = l >> 4;
+        float v = 0.f;
+        if (img == 0) {
+            // conv_f: k slot (kq, j) = input channel 8 (kq & 1) + j, high part for kq < 2, low part for kq >= 2
+            const float w = p.wf[(8 * (kq & 1) + j) * FP + i];
+            const float hi = from16<ST>(to16<ST>(w));
+            v = kq < 2 ? hi : w - hi;
+        } else {
+            const int t = (img - 1) % NT, lo = (img - 1) / NT;
+            const int oc = 16 * t + i;
+            const float w = oc < p.cp ? p.w4[(4 * kq + (j & 3)) * p.cp + oc] : 0.f;
+            const float hi = from16<ST>(to16<ST>(w));
+            v = lo ? (j < 4 ? w - hi : 0.f) : hi;           // hi image: against s_hi (j < 4) and s_lo (j >= 4); lo image: against s_hi only
+        }
+        simg[e] = to16<ST>(v);
+    }
+    if (tid < 16) sbias[tid] = p.wf[FP * FP + tid];
+    for (int e = tid; e < NT * 16; e += 256) sbias[16 + e] = e < p.cp ? p.w4[FP * p.cp + e] : 0.f;
+    __syncthreads();
+
+    const int lane = tid & 63, wv = tid >> 6;
+    const int px = lane & 15, kq = lane >> 4;
+    const i32x4_t a_f = *reinterpret_cast<const i32x4_t*>(simg + lane * 8);
+    i32x4_t a_hi[NT], a_lo[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        a_hi[t] = *reinterpret_cast<const i32x4_t*>(simg + ((1 + t) * 64 + lane) * 8);
+        a_lo[t] = *reinterpret_cast<const i32x4_t*>(simg + ((1 + NT + t) * 64 + lane) * 8);
+    }
+    const f32x4 bf4 = *reinterpret_cast<const f32x4*>(sbias + kq * 4);
+    const long long npix = (long long)p.N * p.H * p.W;
+    const long long ngroups = (npix + 15) / 16;
+    const unsigned short* c1 = static_cast<const unsigned short*>(p.c1);
+    for (long long grp = (long long)blockIdx.x * 4 + wv; grp < ngroups; grp += (long long)gridDim.x * 4) {
+        const long long pixr = grp * 16 + px;
+        const bool live = pixr < npix;
+        const long long pix = live ? pixr : npix - 1;
+        const int ox = (int)(pix % p.W);
+        const int oy = (int)((pix / p.W) % p.H);
+        const int n = (int)(pix / ((long long)p.W * p.H));
+        // B operand of conv_f straight from memory: 8 channels (16 bytes) of c1, lanes kq >= 2 read the same bytes again
+        const i32x4_t bc1 = *reinterpret_cast<const i32x4_t*>(c1 + (size_t)pix * FP + 8 * (kq & 1));
+        // x in the D layout, requested before the arithmetic
+        f32x4 xv[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            xv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (16 * t + 4 * kq < p.Cp4) xv[t] = ld4<ST>(p.x, (size_t)pix * p.x_pitch + p.x_coff + 16 * t + 4 * kq);
+        }
+        // bilinear source coordinates: ATen area_pixel_compute_source_index, fused multiply-add (see oracle)
+        float fy = fmaf((float)oy + 0.5f, p.sh, -0.5f);
+        fy = fy < 0.f ? 0.f : fy;
+        const int y0 = (int)fy, y1 = y0 + (y0 < p.h3 - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, hy = 1.f - ly;
+        float fx = fmaf((float)ox + 0.5f, p.sw, -0.5f);
+        fx = fx < 0.f ? 0.f : fx;
+        const int x0 = (int)fx, x1 = x0 + (x0 < p.w3 - 1 ? 1 : 0);
+        const float lx = fx - (float)x0, hx = 1.f - lx;
+        const float* cb = p.c3 + (size_t)n * p.h3 * p.w3 * FP + kq * 4;
+        const f32x4 ta = *reinterpret_cast<const f32x4*>(cb + ((size_t)y0 * p.w3 + x0) * FP);
+        const f32x4 tb = *reinterpret_cast<const f32x4*>(cb + ((size_t)y0 * p.w3 + x1) * FP);
+        const f32x4 tc = *reinterpret_cast<const f32x4*>(cb + ((size_t)y1 * p.w3 + x0) * FP);
+        const f32x4 td = *reinterpret_cast<const f32x4*>(cb + ((size_t)y1 * p.w3 + x1) * FP);
+        f32x4 sacc = hy * (hx * ta + lx * tb) + ly * (hx * tc + lx * td) + bf4;      // same evaluation order as the VALU kernel
+        sacc = mfma_k32<ST>(a_f, bc1, sacc);
+        // s -> B operand of conv4: high parts in k slots 0..3, low parts in 4..7
+        unsigned short h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = to16<ST>(sacc[j]);
+            l[j] = to16<ST>(sacc[j] - from16<ST>(h[j]));
+        }
+        i32x4_t bs;
+        bs.x = (int)((unsigned)h[0] | ((unsigned)h[1] << 16)); bs.y = (int)((unsigned)h[2] | ((unsigned)h[3] << 16));
+        bs.z = (int)((unsigned)l[0] | ((unsigned)l[1] << 16)); bs.w = (int)((unsigned)l[2] | ((unsigned)l[3] << 16));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 m = *reinterpret_cast<const f32x4*>(sbias + 16 + t * 16 + kq * 4);
+            m = mfma_k32<ST>(a_hi[t], bs, m);
+            m = mfma_k32<ST>(a_lo[t], bs, m);
+            f32x4 o;
+            o.x = xv[t].x * (1.f / (1.f + expf(-m.x)));
+            o.y = xv[t].y * (1.f / (1.f + expf(-m.y)));
+            o.z = xv[t].z * (1.f / (1.f + expf(-m.z)));
+            o.w = xv[t].w * (1.f / (1.f + expf(-m.w)));
+            // only the store is predicated: the MFMAs above must run with every lane active (a lane supplies A / B operands)
+            if (live && 16 * t + 4 * kq < p.Cp4) st4<ST>(p.y, (size_t)pix * p.y_pitch + p.y_coff + 16 * t + 4 * kq, o);
+        }
+    }
+}
+
+template <int ST>
+int launch_esa_mfma(const EsaK& k, hipStream_t st)
+{
+    const long long npix = (long long)k.N * k.H * k.W;
+    const long long nwg = ((npix + 15) / 16 + 3) / 4;
+    const unsigned grid = (unsigned)(nwg < 4096 ? nwg : 4096);
+    const int nt = (k.Cp4 + 15) / 16;
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 1>), dim3(grid), dim3(256), 0, st, k); break;
+        case 2: hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 2>), dim3(grid), dim3(256), 0, st, k); break;
+        case 3: hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 3>), dim3(grid), dim3(256), 0, st, k); break;
+        case 4: hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 4>), dim3(grid), dim3(256), 0, st, k); break;
+        default: return ESR_ERR_UNSUPPORTED;
+    }
+    return esr_check_launch("esa_apply_mfma_kernel launch");
+}
+
 // ---- depthwise 3x3, zero padding, fused residual / activation -------------------------------------
 // thread = (pixel, quad of 4 channels); weights [tap][cp] + bias[cp] in LDS.  Memory-bound: the 9 taps of a
 // pixel are served from L1/L2 (each input float4 is read by 9 neighbouring threads).
@@ -448,8 +595,8 @@ int esr_esa_apply_f32(const esr_esa_desc* d, void* hip_stream)
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     switch (d->storage) {
         case ESR_STORE_F32: hipLaunchKernelGGL(esa_apply_kernel<ESR_STORE_F32>, dim3(grid), dim3(256), lds, st, k); break;
-        case ESR_STORE_BF16: hipLaunchKernelGGL(esa_apply_kernel<ESR_STORE_BF16>, dim3(grid), dim3(256), lds, st, k); break;
-        case ESR_STORE_F16: hipLaunchKernelGGL(esa_apply_kernel<ESR_STORE_F16>, dim3(grid), dim3(256), lds, st, k); break;
+        case ESR_STORE_BF16: return launch_esa_mfma<ESR_STORE_BF16>(k, st);
+        case ESR_STORE_F16: return launch_esa_mfma<ESR_STORE_F16>(k, st);
         default: return ESR_ERR_BAD_ARG;
     }
     return esr_check_launch("esa_apply_kernel launch");

@@ -7,12 +7,12 @@
 //   * the input halo tile goes global -> LDS by DMA (`buffer_load_dwordx4 ... lds`): no staging VGPRs, no ds_write, no
 //     conversion (the storage type IS the operand type); out-of-image halo pixels use an out-of-range buffer offset and
 //     the hardware writes zeros (the convolution's zero padding);
-//   * a ring of three K stages (16 channels = 32 bytes per pixel each): while stage g is multiplied, g+1 and g+2 are in
-//     flight, across tile boundaries of the persistent block, so ~40 KB per CU are always on the way from HBM;
+//   * a ring of R = 3..8 K stages (16 channels = 32 bytes per pixel each, as many as fit next to the weights): while
+//     stage s is multiplied, s+1 .. s+R-1 are in flight, across tile boundaries of the persistent block;
 //   * the layer's whole weight set is resident in LDS for the life of the block (<= 80 KB: 64 -> 64 channels, 3x3);
-//   * one barrier per stage, counted `s_waitcnt vmcnt` (loads return in order: the older stage has landed while the
-//     newer stays in flight); the epilogue runs AFTER that barrier so its stores get a whole stage to drain before the
-//     next counted wait has to look past them.
+//   * one barrier per stage with an EXACT `s_waitcnt vmcnt(N)`: N counts every vector-memory instruction the wave issued
+//     after the DMA of the stage it needs (younger stages, the previous tile's stores, residual loads), so nothing but
+//     the needed stage is waited for; the previous tile's epilogue runs behind the DMA issue of the next tile's stage.
 // GEMM view and fragment maps: D[cout][pixel], A = weights, B = 16 consecutive pixels of one image row, D gives lane
 // (px, kq) 4 consecutive output channels of one pixel -- exactly as conv_f32_kernel (esr_hip.hip).  K slots of one MFMA:
 // lane (i, kq) holds 8 consecutive k = 8 channels (16 bytes) of ONE tap: kq & 1 selects the channel half of the chunk,
@@ -25,6 +25,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#include <type_traits>
 
 #include "esr_internal.h"
 
@@ -38,9 +39,10 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int TILE = 16;            // output tile width (pixels) = one MFMA's pixel dimension
-constexpr int RING = 3;             // input stages in LDS
-constexpr int EPI_PITCH = 68;       // floats per scratch pixel row (64 + 4 pad)
-constexpr int EPI_PIX = 8;          // pixels per transposed half row
+constexpr int RING_MIN = 3, RING_MAX = 8;   // input stages in LDS (as many as fit next to the resident weights)
+constexpr int SCR_ROW = 144;        // bytes per scratch pixel row: 64 channels x 2 B + 16 pad
+constexpr int SCR_PIX = 8;          // pixels per transposed half row
+constexpr int SCR_WAVE = SCR_PIX * SCR_ROW;
 constexpr unsigned OOB = 0x80000000u;
 constexpr int LDS_LIMIT = 160 * 1024;
 
@@ -53,6 +55,7 @@ struct S16K {
     char* y1;
     int N, H, W;
     int nchunks;          // ceil(cin_phys / 16)
+    int ring;             // input stages in LDS
     int in_pitch, in_coff;
     int res_pitch, res_coff;
     int y0_pitch, y0_coff, y1_pitch, y1_coff;
@@ -60,7 +63,8 @@ struct S16K {
     int split;
     int act;
     float slope;          // LeakyReLU slope; the kernel evaluates max(v, slope * v): 1 = identity, 0 = ReLU
-    int res_mode;
+    int res_mode;         // residual read from HBM (0 = none)
+    int res_in;           // pre-activation residual == the conv input: added from the staged tile in LDS, no loads
     int out_layout;
     int tiles_x, tiles_y;
 };
@@ -98,10 +102,35 @@ __device__ __forceinline__ void unpack2(unsigned u, float& a, float& b)
     }
 }
 
-__device__ __forceinline__ float act1(float v, int act, float slope)
+template <bool BF16>
+__device__ __forceinline__ f32x4 unpack4(uint2 u)
 {
-    // slope carries none (1) / LeakyReLU (s) / ReLU (0); GELU is the only other activation on the path (BSRN)
-    if (act == ESR_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    float a, b, c, d;
+    unpack2<BF16>(u.x, a, b);
+    unpack2<BF16>(u.y, c, d);
+    return f32x4{a, b, c, d};
+}
+
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7), invisible under the 16-bit rounding of the stored result
+__device__ __forceinline__ float fast_erf(float x)
+{
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+    float q = fmaf(1.061405429f, t, -1.453152027f);
+    q = fmaf(q, t, 1.421413741f);
+    q = fmaf(q, t, -0.284496736f);
+    q = fmaf(q, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    return copysignf(1.f - q * t * e, x);
+}
+
+// GELU is a compile-time branch of the epilogue body (one uniform branch per tile selects the body): a per-element runtime
+// test made hipcc emit three scalar branches per VALUE, and the branchy code -- not memory -- was 75 % of the kernel.
+// Everything else is max(v, slope * v): slope carries none (1) / LeakyReLU (s) / ReLU (0).
+template <bool GELU>
+__device__ __forceinline__ float act1(float v, float slope)
+{
+    if (GELU) return 0.5f * v * (1.f + fast_erf(v * 0.70710678118654752440f));
     return fmaxf(v, slope * v);
 }
 
@@ -110,6 +139,11 @@ __device__ __forceinline__ float act1(float v, int act, float slope)
 // which LDS bytes the DMA touches); completion is tracked by the counted waits of the stage loop.
 __device__ __forceinline__ void dma_buf16(unsigned lds_dst, unsigned voff, i32x4 rsrc, unsigned soff)
 {
+    // wave-uniform by construction; readfirstlane pins them to SGPRs where hipcc's uniformity analysis gives up
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    rsrc.x = __builtin_amdgcn_readfirstlane(rsrc.x); rsrc.y = __builtin_amdgcn_readfirstlane(rsrc.y);
+    rsrc.z = __builtin_amdgcn_readfirstlane(rsrc.z); rsrc.w = __builtin_amdgcn_readfirstlane(rsrc.w);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
@@ -117,21 +151,52 @@ __device__ __forceinline__ void dma_buf16(unsigned lds_dst, unsigned voff, i32x4
 
 __device__ __forceinline__ void dma_glb16(unsigned lds_dst, const void* g)
 {
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_dst), "v"(g) : "memory");
 }
 
-template <int N>
-__device__ __forceinline__ void wait_vm()
+// s_waitcnt vmcnt(cnt) for a wave-uniform runtime cnt (the immediate has to be a constant): a branch tree over the values
+// the stage loop produces; rounding DOWN is always safe (waits for more).
+__device__ __forceinline__ void wait_vm_dyn(int cnt)
 {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#define ESR_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (cnt < 0 ? 0 : (cnt > 47 ? 47 : cnt)) {
+        ESR_W(0) ESR_W(1) ESR_W(2) ESR_W(3) ESR_W(4) ESR_W(5) ESR_W(6) ESR_W(7) ESR_W(8) ESR_W(9) ESR_W(10) ESR_W(11)
+        ESR_W(12) ESR_W(13) ESR_W(14) ESR_W(15) ESR_W(16) ESR_W(17) ESR_W(18) ESR_W(19) ESR_W(20) ESR_W(21) ESR_W(22) ESR_W(23)
+        ESR_W(24) ESR_W(25) ESR_W(26) ESR_W(27) ESR_W(28) ESR_W(29) ESR_W(30) ESR_W(31) ESR_W(32) ESR_W(33) ESR_W(34) ESR_W(35)
+        ESR_W(36) ESR_W(37) ESR_W(38) ESR_W(39) ESR_W(40) ESR_W(41) ESR_W(42) ESR_W(43) ESR_W(44) ESR_W(45) ESR_W(46) ESR_W(47)
+    }
+#undef ESR_W
 }
 
-template <int NT, int KS, int NW, bool BF16>
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, size_t bytes)
+{
+    i32x4 r;
+    r.x = (int)(size_t)base;
+    r.y = (int)(((size_t)base >> 32) & 0xffff);
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+
+// Pipeline (per block, stages s = (tile, 16-channel chunk) in order; R = ring slots):
+//   top of stage s   stage s has landed (previous sync).  DMA of stage s+R-1 into the slot stage s-1 just released; then the
+//                    EPILOGUE of the previous tile if s is a tile's first stage (its stores are issued behind the DMA, so the
+//                    memory pipe never waits for them); then, if s is the tile's last stage, the residual loads of THIS tile
+//   compute(s)       5 tap-pair MFMA groups per chunk (1 for 1x1) from ring slot s % R and the resident weights
+//   sync             s_waitcnt vmcnt(N) + s_barrier with N = the exact number of vector-memory instructions this wave has
+//                    issued AFTER the DMA of stage s+1 (younger stages, epilogue stores, residual loads): loads and stores
+//                    retire in issue order, so stage s+1 has landed while everything younger stays in flight -- R-1 stages
+//                    (20 KB each for a 3x3 on 16x32 tiles) are on their way from HBM at any time.
+// Every vector-memory instruction is issued unconditionally (invalid lanes use out-of-range buffer offsets: loads return
+// zero, stores are dropped), which is what makes the count exact.
+// GRES: the launch reads a residual from HBM (its 8 NT registers exist only in these variants, which in exchange keep a
+// single set of MFMA operand fragments: they are memory-bound twice over).
+template <int NT, int KS, int NW, bool BF16, bool GRES>
 __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
 {
-    constexpr int THREADS = 64 * NW;
     constexpr int HALO = KS / 2;
     constexpr int TH = TILE + 2 * HALO;          // halo tile width = LDS row pitch in pixels
     constexpr int TILE_H = 4 * NW;               // wave wv owns rows 4wv .. 4wv+3
@@ -145,6 +210,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     constexpr int TAPS = KS * KS;
     constexpr int PAIRS = (TAPS + 1) / 2;
     constexpr int W_CHUNK_BYTES = PAIRS * NT * 1024;   // [pair][tile][lane][16 B]
+    constexpr int RES_LOADS = NT * 4;            // residual loads per wave and tile (8 bytes per lane each)
 
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
@@ -152,9 +218,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15;
     const int kq = lane >> 4;
+    const int R = p.ring;
     const int w_bytes = p.nchunks * W_CHUNK_BYTES;
     char* const ring = smem + w_bytes;
-    float* const scr = reinterpret_cast<float*>(ring + RING * STAGE_BYTES) + wv * (EPI_PIX * EPI_PITCH);
+    char* const scr = ring + R * STAGE_BYTES + wv * SCR_WAVE;
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned ring_lds = smem_lds + (unsigned)w_bytes;
 
@@ -185,20 +252,17 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     int lk = 0;                   // tile iteration of the cursor
     int lc = 0;                   // chunk of the cursor
     int lslot = 0;
+    int issued = 0;               // stages requested so far
     bool lvalid;
     unsigned lvoff[PPW];
     i32x4 lrsrc;
-    auto cursor_tile = [&]() {
+    auto cursor_tile = [&]() __attribute__((always_inline)) {
         const int t = tile_index(lk);
         lvalid = t >= 0;
         if (!lvalid) return;
         int n, x0, y0;
         tile_coords(t, n, x0, y0);
-        const char* base = p.x + (size_t)n * img_bytes;
-        lrsrc.x = (int)(size_t)base;
-        lrsrc.y = (int)(((size_t)base >> 32) & 0xffff);
-        lrsrc.z = (int)img_bytes;
-        lrsrc.w = 0x00020000;
+        lrsrc = make_rsrc(p.x + (size_t)n * img_bytes, img_bytes);
 #pragma unroll
         for (int r = 0; r < PPW; ++r) {
             const int pc = wv + NW * r;
@@ -210,7 +274,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
             lvoff[r] = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff + 8 * plane) * 2u : OOB;
         }
     };
-    auto issue_stage = [&]() {          // DMA of the cursor's stage into ring slot lslot, then advance the cursor
+    auto issue_stage = [&]() __attribute__((always_inline)) {          // DMA of the cursor's stage into ring slot lslot, then advance the cursor
         const unsigned dst0 = ring_lds + (unsigned)(lslot * STAGE_BYTES);
         const unsigned soff = (unsigned)lc * 32u;
 #pragma unroll
@@ -219,23 +283,16 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
             if (NPIECES % NW == 0 || r < PPW - 1 || pc < NPIECES)       // wave-uniform
                 dma_buf16(dst0 + (unsigned)pc * 1024u, lvoff[r], lrsrc, soff);
         }
-        lslot = lslot == RING - 1 ? 0 : lslot + 1;
+        ++issued;
+        lslot = lslot == R - 1 ? 0 : lslot + 1;
         if (++lc == p.nchunks) {
             lc = 0;
             ++lk;
             cursor_tile();
         }
     };
-    // counted wait + barrier: the OLDEST outstanding stage has landed in every wave's view; `newer` = a younger stage
-    // of this wave is still in flight and stays so
-    auto stage_sync = [&](bool newer) {
-        if (!newer) wait_vm<0>();
-        else if (n_my == PPW) wait_vm<PPW>();
-        else wait_vm<(PPW > 1 ? PPW - 1 : 0)>();
-        __builtin_amdgcn_s_barrier();
-    };
 
-    // ---- prologue: weights (resident), stages 0 and 1 ---------------------------------------------------------------
+    // ---- prologue: weights (resident), the first R-1 stages ---------------------------------------------------------
     {
         const int wpieces = w_bytes / 1024;
         for (int pc = wv; pc < wpieces; pc += NW)
@@ -243,10 +300,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     }
     cursor_tile();
     if (!lvalid) return;                 // block without tiles (grid <= ntiles: does not happen)
-    issue_stage();
-    bool ahead = lvalid;
-    if (ahead) issue_stage();
-    stage_sync(ahead);
+    for (int i = 0; i < R - 1 && lvalid; ++i) issue_stage();
+    wait_vm_dyn((issued - 1) * n_my);    // the weights and stage 0 have landed
+    __builtin_amdgcn_s_barrier();
 
     f32x4 biasv[NT];
 #pragma unroll
@@ -260,162 +316,253 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         b_off[q] = (kq & 1) * PLANE_BYTES + (((wv * 4) + tap / KS) * TH + px + tap % KS) * 16;
     }
     const int a_off = lane * 16;
+    // the centre pixel of this lane's accumulator rows in the staged tile: channels 16c + 4kq .. +3 of chunk c
+    const int c_off = (kq >> 1) * PLANE_BYTES + ((wv * 4 + HALO) * TH + px + HALO) * 16 + (kq & 1) * 8;
+
+    const bool shuffle = p.out_layout == ESR_NCHW_SHUFFLE4;
+    const bool has_split = !shuffle && p.split < p.cout_store;
+    constexpr bool gres = GRES;
+    const int epi_stores = shuffle ? 4 * NT : (has_split ? 16 : 8);     // store instructions per wave and tile
+    const unsigned hmask = (1u << (R - 1)) - 1u;
+    unsigned hist_st = 0, hist_rs = 0;   // bit i: an epilogue's stores / a tile's residual loads were issued at the top of stage s - i
+    const size_t res_img = (size_t)p.H * p.W * p.res_pitch * 2;
+    const size_t y0_img = shuffle ? (size_t)p.cout_store * p.H * p.W * 4 : (size_t)p.H * p.W * p.y0_pitch * 2;   // NCHW fp32: cout/16 planes of 4H x 4W
+    const size_t y1_img = (size_t)p.H * p.W * p.y1_pitch * 2;
+
+    f32x4 acc[NT][4];
+    uint2 rv[GRES ? NT : 1][4];          // residual of the current tile in D-fragment layout (hidden asm loads)
+#pragma unroll
+    for (int tt = 0; tt < (GRES ? NT : 1); ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[tt][r] = uint2{0u, 0u};
+
+    auto load_residual = [&](int n, int x0, int y0) __attribute__((always_inline)) {
+        if (!GRES) return;
+        const i32x4 rr = make_rsrc(p.res + (size_t)n * res_img, res_img);
+        i32x4 rru;
+        rru.x = __builtin_amdgcn_readfirstlane(rr.x); rru.y = __builtin_amdgcn_readfirstlane(rr.y);
+        rru.z = __builtin_amdgcn_readfirstlane(rr.z); rru.w = __builtin_amdgcn_readfirstlane(rr.w);
+        const int gx = x0 + px;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gy = y0 + wv * 4 + r;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                const int cb = tt * 16 + kq * 4;
+                const bool ok = gy < p.H && gx < p.W && cb < p.cout_store;
+                const unsigned vo = ok ? (unsigned)((gy * p.W + gx) * p.res_pitch + p.res_coff + cb) * 2u : OOB;
+                asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(rv[GRES ? tt : 0][r]) : "v"(vo), "s"(rru) : "memory");
+            }
+        }
+    };
+
+    auto epilogue_body = [&](auto gelu_tag, int n, int x0, int y0, int younger_dma) __attribute__((always_inline)) {
+        constexpr bool GELU = decltype(gelu_tag)::value;
+        if (gres) {
+            // the residual loads were issued one whole stage ago, behind them only this top's DMA
+            wait_vm_dyn(younger_dma);
+#pragma unroll
+            for (int tt = 0; tt < (GRES ? NT : 1); ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(rv[tt][r]));      // uses below stay behind the wait
+        }
+        if (shuffle) {
+            // out[n, t, 4gy + kq, 4gx + 0..3] = channel 16t + 4kq + j: the D fragment is one dwordx4 of 4 adjacent HR pixels
+            const int gx = x0 + px;
+            const unsigned W4 = (unsigned)p.W * 4u, H4 = (unsigned)p.H * 4u;
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)n * y0_img, 0, (int)y0_img, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gy = y0 + wv * 4 + r;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    const bool ok = gy < p.H && gx < p.W && tt * 16 + kq * 4 < p.cout_store;
+                    f32x4 v = acc[tt][r];
+                    v.x = act1<GELU>(v.x, p.slope); v.y = act1<GELU>(v.y, p.slope);
+                    v.z = act1<GELU>(v.z, p.slope); v.w = act1<GELU>(v.w, p.slope);
+                    const unsigned vo = ok ? (((unsigned)tt * H4 + (unsigned)gy * 4u + (unsigned)kq) * W4 + (unsigned)gx * 4u) * 4u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yr, vo, 0, 0);
+                }
+            }
+            return;
+        }
+        // NHWC 16-bit: residual / activation / rounding in the fragment layout, then each wave transposes half a pixel row
+        // at a time through its private scratch: lane (p8, cg) owns the 8 channels 8cg.. of pixel p8 -- one 16-byte store per
+        // lane, 128 contiguous bytes per pixel, 1 KB per instruction
+        const int p8 = lane >> 3, cg = lane & 7;
+        const int cb = cg * 8;
+        const bool ch0 = cb < p.split;                       // goes to out0
+        const bool ch1 = !ch0 && cb < p.cout_store;          // goes to out1 (split store)
+        const __amdgpu_buffer_rsrc_t yr0 = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)n * y0_img, 0, (int)y0_img, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yr1 = __builtin_amdgcn_make_buffer_rsrc(p.y1 + (size_t)n * y1_img, 0, (int)y1_img, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gy = y0 + wv * 4 + r;
+            uint2 pk[NT];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                f32x4 v = acc[tt][r];
+                f32x4 rf = {0.f, 0.f, 0.f, 0.f};
+                if (GRES) rf = unpack4<BF16>(rv[GRES ? tt : 0][r]);
+                if (GRES && p.res_mode == ESR_RES_PRE_ACT) v += rf;
+                v.x = act1<GELU>(v.x, p.slope); v.y = act1<GELU>(v.y, p.slope);
+                v.z = act1<GELU>(v.z, p.slope); v.w = act1<GELU>(v.w, p.slope);
+                if (GRES && p.res_mode == ESR_RES_POST_ACT) v += rf;
+                pk[tt].x = pack2<BF16>(v.x, v.y);
+                pk[tt].y = pack2<BF16>(v.z, v.w);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                __builtin_amdgcn_wave_barrier();
+                if ((px >> 3) == h) {
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) *reinterpret_cast<uint2*>(scr + (px & 7) * SCR_ROW + (tt * 16 + kq * 4) * 2) = pk[tt];
+                }
+                __builtin_amdgcn_wave_barrier();
+                const i32x4 o = *reinterpret_cast<const i32x4*>(scr + p8 * SCR_ROW + min(cb, NT * 16 - 8) * 2);
+                const int gx = x0 + 8 * h + p8;
+                const bool in = gy < p.H && gx < p.W;
+                const unsigned pix = (unsigned)(gy * p.W + gx);
+                const unsigned vo0 = (in && ch0) ? (pix * (unsigned)p.y0_pitch + (unsigned)(p.y0_coff + cb)) * 2u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(o, yr0, vo0, 0, 0);
+                if (has_split) {
+                    const unsigned vo1 = (in && ch1) ? (pix * (unsigned)p.y1_pitch + (unsigned)(p.y1_coff + cb - p.split)) * 2u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(o, yr1, vo1, 0, 0);
+                }
+            }
+        }
+    };
+
+    auto epilogue = [&](int n, int x0, int y0, int younger_dma) __attribute__((always_inline)) {
+        if (p.act == ESR_ACT_GELU) epilogue_body(std::true_type{}, n, x0, y0, younger_dma);
+        else epilogue_body(std::false_type{}, n, x0, y0, younger_dma);
+    };
 
     int slot = 0;
+    int s = 0;                           // stage index
+    bool pend = false;                   // a finished tile waits for its epilogue
+    int pn = 0, px0 = 0, py0 = 0;
     for (int k = 0;; ++k) {
         const int t = tile_index(k);
         if (t < 0) break;
         int n, x0, y0;
         tile_coords(t, n, x0, y0);
-        f32x4 acc[NT][4];
+        for (int c = 0; c < p.nchunks; ++c, ++s) {
+            // ---- top of stage s -----------------------------------------------------------------------------------
+            int dma_now = 0;
+            if (lvalid) {
+                issue_stage();
+                dma_now = n_my;
+            }
+            hist_st <<= 1;
+            hist_rs <<= 1;
+            if (c == 0) {
+                if (pend) {
+                    epilogue(pn, px0, py0, dma_now);
+                    hist_st |= 1u;
+                    pend = false;
+                }
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
+                for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[tt][r] = biasv[tt];
-
-        for (int c = 0; c < p.nchunks; ++c) {
-            // request the stage after next: its slot was last read two stages ago, every wave is past that barrier
-            ahead = lvalid;
-            if (ahead) issue_stage();
-            const char* s = ring + slot * STAGE_BYTES;
+                    for (int r = 0; r < 4; ++r) acc[tt][r] = biasv[tt];
+            }
+            if (gres && c == p.nchunks - 1) {
+                load_residual(n, x0, y0);
+                hist_rs |= 1u;
+            }
+            // ---- compute -------------------------------------------------------------------------------------------
+            const char* sb = ring + slot * STAGE_BYTES;
             const char* wc = smem + c * W_CHUNK_BYTES + a_off;
-            i32x4 a[2][NT], b[2][4];
+            if (KS == 3 && p.res_in) {
+                // act(conv(x) + x): the residual of output channels 16c .. 16c+15 is the centre pixel of input chunk c
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+                    if (tt == c) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[tt][r] += unpack4<BF16>(*reinterpret_cast<const uint2*>(sb + c_off + r * (TH * 16)));
+                    }
+            }
+            constexpr int NBUF = GRES ? 1 : 2;               // fragment sets: the read of pair q+1 runs under the MFMAs of pair q
+            i32x4 a[NBUF][NT], b[NBUF][4];
             auto load_frag = [&](int buf, int q) {
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) a[buf][tt] = *reinterpret_cast<const i32x4*>(wc + (q * NT + tt) * 1024);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) b[buf][r] = *reinterpret_cast<const i32x4*>(s + b_off[q] + r * (TH * 16));
+                for (int r = 0; r < 4; ++r) b[buf][r] = *reinterpret_cast<const i32x4*>(sb + b_off[q] + r * (TH * 16));
             };
-            load_frag(0, 0);
+            if (NBUF == 2) load_frag(0, 0);
 #pragma unroll
             for (int q = 0; q < PAIRS; ++q) {
-                const int cs = q & 1;
-                if (q + 1 < PAIRS) load_frag(cs ^ 1, q + 1);
-                __builtin_amdgcn_sched_barrier(0);          // keep the prefetch above this pair's MFMAs
+                const int cs = NBUF == 2 ? (q & 1) : 0;
+                if (NBUF == 2) {
+                    if (q + 1 < PAIRS) load_frag(cs ^ 1, q + 1);
+                    __builtin_amdgcn_sched_barrier(0);      // keep the prefetch above this pair's MFMAs
+                } else {
+                    load_frag(0, q);
+                }
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], acc[tt][r]);
             }
-            // the next stage (requested one stage ago) has landed once at most the newest request is outstanding
-            stage_sync(ahead);
-            slot = slot == RING - 1 ? 0 : slot + 1;
-        }
-
-        // ---- epilogue (after the barrier: the other waves are already multiplying the next tile) --------------------
-        if (p.out_layout == ESR_NCHW_SHUFFLE4) {
-            // out[n, t, 4gy + kq, 4gx + 0..3] = channel 16t + 4kq + j: the D fragment is one dwordx4 of 4 adjacent HR pixels
-            const int gx = x0 + px;
-            const size_t W4 = (size_t)p.W * 4, H4 = (size_t)p.H * 4;
-            const int nco = p.cout_store / 16;
-            float* const yo = reinterpret_cast<float*>(p.y0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gy = y0 + wv * 4 + r;
-                if (gy >= p.H || gx >= p.W) continue;
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) {
-                    if (tt * 16 + kq * 4 >= p.cout_store) continue;
-                    f32x4 v = acc[tt][r];
-                    v.x = act1(v.x, p.act, p.slope); v.y = act1(v.y, p.act, p.slope);
-                    v.z = act1(v.z, p.act, p.slope); v.w = act1(v.w, p.act, p.slope);
-                    *reinterpret_cast<f32x4*>(yo + (((size_t)n * nco + tt) * H4 + (size_t)gy * 4 + kq) * W4 + (size_t)gx * 4) = v;
-                }
+            // ---- sync: stage s+1 has landed; everything issued after its DMA may stay in flight -------------------------
+            {
+                const int younger = issued - (s + 2);        // stages requested behind stage s+1
+                const int cnt = younger * n_my + epi_stores * __builtin_popcount(hist_st & hmask) +
+                                RES_LOADS * __builtin_popcount(hist_rs & hmask);
+                wait_vm_dyn(younger < 0 ? 0 : cnt);
+                __builtin_amdgcn_s_barrier();
             }
-        } else {
-            // each wave transposes half a pixel row at a time through its private scratch: lane (p8, cg) then owns the 8
-            // channels 8cg.. of pixel p8 -- one 16-byte residual load and one 16-byte store per lane, 128 contiguous
-            // bytes per pixel, 1 KB per instruction
-            const int p8 = lane >> 3, cg = lane & 7;
-            const int cb = cg * 8;
-            const bool ch_ok = cb < p.cout_store;
-            const bool to0 = cb < p.split;
-            const int rdc = (NT == 4) ? cb : min(cb, NT * 16 - 8);
-            char* const ybase = to0 ? p.y0 + (size_t)(p.y0_coff + cb) * 2 : p.y1 + (size_t)(p.y1_coff + cb - p.split) * 2;
-            const int ypitch2 = (to0 ? p.y0_pitch : p.y1_pitch) * 2;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gy = y0 + wv * 4 + r;
-                i32x4 rv[2];
-                bool ok[2];
-                size_t pix[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int gx = x0 + 8 * h + p8;
-                    ok[h] = ch_ok && gy < p.H && gx < p.W;
-                    pix[h] = ((size_t)n * p.H + gy) * p.W + gx;
-                    rv[h] = i32x4{0, 0, 0, 0};
-                    if (p.res_mode != ESR_RES_NONE && ok[h])
-                        rv[h] = *reinterpret_cast<const i32x4*>(p.res + (pix[h] * p.res_pitch + p.res_coff + cb) * 2);
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    __builtin_amdgcn_wave_barrier();
-                    if ((px >> 3) == h) {
-#pragma unroll
-                        for (int tt = 0; tt < NT; ++tt) *reinterpret_cast<f32x4*>(scr + (px & 7) * EPI_PITCH + tt * 16 + kq * 4) = acc[tt][r];
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(scr + p8 * EPI_PITCH + rdc);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(scr + p8 * EPI_PITCH + rdc + 4);
-                    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                    float rr[8];
-                    unpack2<BF16>((unsigned)rv[h].x, rr[0], rr[1]); unpack2<BF16>((unsigned)rv[h].y, rr[2], rr[3]);
-                    unpack2<BF16>((unsigned)rv[h].z, rr[4], rr[5]); unpack2<BF16>((unsigned)rv[h].w, rr[6], rr[7]);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float o = v[j];
-                        if (p.res_mode == ESR_RES_PRE_ACT) o += rr[j];
-                        o = act1(o, p.act, p.slope);
-                        if (p.res_mode == ESR_RES_POST_ACT) o += rr[j];
-                        v[j] = o;
-                    }
-                    if (ok[h]) {
-                        i32x4 o;
-                        o.x = (int)pack2<BF16>(v[0], v[1]); o.y = (int)pack2<BF16>(v[2], v[3]);
-                        o.z = (int)pack2<BF16>(v[4], v[5]); o.w = (int)pack2<BF16>(v[6], v[7]);
-                        *reinterpret_cast<i32x4*>(ybase + pix[h] * ypitch2) = o;
-                    }
-                }
-            }
+            slot = slot == R - 1 ? 0 : slot + 1;
         }
+        pend = true;
+        pn = n; px0 = x0; py0 = y0;
     }
+    if (pend) epilogue(pn, px0, py0, 0);
 }
 
-template <int NT, int KS, int NW, bool BF16>
+template <int NT, int KS, int NW, bool BF16, bool GRES>
 int launch_s16(const S16K& k, size_t lds, hipStream_t st)
 {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<NT, KS, NW, BF16>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<NT, KS, NW, BF16, GRES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
         attr = true;
     }
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int grid = ntiles < 256 ? ntiles : 256;          // one block per CU (LDS), persistent over the tiles
-    hipLaunchKernelGGL((conv_s16_kernel<NT, KS, NW, BF16>), dim3(grid), dim3(64 * NW), lds, st, k);
+    hipLaunchKernelGGL((conv_s16_kernel<NT, KS, NW, BF16, GRES>), dim3(grid), dim3(64 * NW), lds, st, k);
     return esr_check_launch("conv_s16_kernel launch");
 }
 
-template <int KS, bool BF16>
+template <int KS, bool BF16, bool GRES>
 int launch_s16_nt(int nt, const S16K& k, size_t lds, hipStream_t st)
 {
     switch (nt) {
-        case 1: return launch_s16<1, KS, 8, BF16>(k, lds, st);
-        case 2: return launch_s16<2, KS, 8, BF16>(k, lds, st);
-        case 3: return launch_s16<3, KS, 8, BF16>(k, lds, st);
-        case 4: return launch_s16<4, KS, 8, BF16>(k, lds, st);
+        case 1: return launch_s16<1, KS, 8, BF16, GRES>(k, lds, st);
+        case 2: return launch_s16<2, KS, 8, BF16, GRES>(k, lds, st);
+        case 3: return launch_s16<3, KS, 8, BF16, GRES>(k, lds, st);
+        case 4: return launch_s16<4, KS, 8, BF16, GRES>(k, lds, st);
     }
     return ESR_ERR_UNSUPPORTED;
 }
 
-// LDS bytes of a launch: resident weights + input ring + epilogue scratch
-size_t s16_lds_bytes(int nchunks, int nt, int ksize, int nw)
+template <int KS, bool BF16>
+int launch_s16_res(int nt, const S16K& k, size_t lds, hipStream_t st)
+{
+    return k.res_mode != ESR_RES_NONE ? launch_s16_nt<KS, BF16, true>(nt, k, lds, st) : launch_s16_nt<KS, BF16, false>(nt, k, lds, st);
+}
+
+// LDS bytes of a launch: resident weights + `ring` input stages + epilogue scratch
+size_t s16_lds_bytes(int nchunks, int nt, int ksize, int nw, int ring)
 {
     const int halo = ksize / 2, th = TILE + 2 * halo, thy = 4 * nw + 2 * halo;
     const int ppp = (th * thy + 63) / 64;
     const int pairs = (ksize * ksize + 1) / 2;
-    return (size_t)nchunks * pairs * nt * 1024 + (size_t)RING * 2 * ppp * 1024 + (size_t)nw * EPI_PIX * EPI_PITCH * 4;
+    return (size_t)nchunks * pairs * nt * 1024 + (size_t)ring * 2 * ppp * 1024 + (size_t)nw * SCR_WAVE;
 }
 
 inline uint16_t f32_to_bf16(float f)
@@ -572,8 +719,17 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         return ESR_ERR_BAD_ARG;
     if ((double)d->h * d->w * d->in.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;   // per-image raw buffer < 2 GiB
     const int nchunks = cin_phys / 16;
-    const size_t lds = s16_lds_bytes(nchunks, nt, d->ksize, 8);
+    int ring = RING_MAX;                                     // as many input stages as fit next to the resident weights
+    while (ring > RING_MIN && s16_lds_bytes(nchunks, nt, d->ksize, 8, ring) > (size_t)LDS_LIMIT) --ring;
+    const size_t lds = s16_lds_bytes(nchunks, nt, d->ksize, 8, ring);
     if (lds > (size_t)LDS_LIMIT) return ESR_ERR_UNSUPPORTED;                                     // weight set too large to stay resident
+    if (!shuffle) {
+        if ((double)d->h * d->w * d->out0.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
+        if (split < cout8 && (double)d->h * d->w * d->out1.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
+    } else if ((double)d->cout * d->h * d->w * 4.0 >= 2147483647.0) {
+        return ESR_ERR_UNSUPPORTED;                          // per-image raw buffers < 2 GiB (out-of-range offset 0x80000000)
+    }
+    if (d->res_mode != ESR_RES_NONE && (double)d->h * d->w * d->res.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
     const int pairs = (d->ksize * d->ksize + 1) / 2;
 
     S16K k;
@@ -585,6 +741,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     k.y1 = static_cast<char*>(d->out1.ptr);
     k.N = d->n; k.H = d->h; k.W = d->w;
     k.nchunks = nchunks;
+    k.ring = ring;
     k.in_pitch = d->in.pitch; k.in_coff = d->in.coff;
     k.res_pitch = d->res.pitch; k.res_coff = d->res.coff;
     k.y0_pitch = d->out0.pitch; k.y0_coff = d->out0.coff;
@@ -594,10 +751,16 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     k.act = d->act;
     k.slope = d->act == ESR_ACT_LRELU ? d->slope : (d->act == ESR_ACT_RELU ? 0.f : 1.f);
     k.res_mode = d->res_mode;
+    k.res_in = 0;
+    if (d->ksize == 3 && d->res_mode == ESR_RES_PRE_ACT && d->cin == d->cout && d->res.ptr == d->in.ptr &&
+        d->res.pitch == d->in.pitch && d->res.coff == d->in.coff) {
+        k.res_in = 1;                               // residual == input: added from the staged tile, no residual loads
+        k.res_mode = ESR_RES_NONE;
+    }
     k.out_layout = d->out_layout;
     k.tiles_x = (d->w + TILE - 1) / TILE;
     k.tiles_y = (d->h + 31) / 32;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    if (d->ksize == 3) return bf16 ? launch_s16_nt<3, true>(nt, k, lds, st) : launch_s16_nt<3, false>(nt, k, lds, st);
-    return bf16 ? launch_s16_nt<1, true>(nt, k, lds, st) : launch_s16_nt<1, false>(nt, k, lds, st);
+    if (d->ksize == 3) return bf16 ? launch_s16_res<3, true>(nt, k, lds, st) : launch_s16_res<3, false>(nt, k, lds, st);
+    return bf16 ? launch_s16_res<1, true>(nt, k, lds, st) : launch_s16_res<1, false>(nt, k, lds, st);
 }

@@ -9,6 +9,7 @@ and the stream handle.
 """
 import collections
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -322,6 +323,32 @@ class Plan:
         return arr, in_idx, out_idx
 
 
+# ---- torch.library custom op -------------------------------------------------------------------------------------------
+# `model(x)` goes through ONE registered operator, esr::sr_forward(x, handle) -> y, so that graph capture / FakeTensor
+# tracing / torch.compile see an opaque op with a shape function instead of ctypes calls: the "thin PyTorch-ROCm custom-op
+# layer" the drop-in modules sit on.  The real implementation replays the fused op list through the C ABI; the fake (meta)
+# implementation only computes the output shape.  `handle` identifies the live module (weak reference, id-keyed).
+_LIVE = weakref.WeakValueDictionary()
+
+
+@torch.library.custom_op("esr::sr_forward", mutates_args=())
+def sr_forward(x: torch.Tensor, handle: int) -> torch.Tensor:
+    m = _LIVE.get(handle)
+    if m is None:
+        raise L.EsrError(f"esr::sr_forward: no live model with handle {handle}")
+    return m._forward_impl(x)
+
+
+@sr_forward.register_fake
+def _sr_forward_fake(x, handle):
+    m = _LIVE.get(handle)
+    if m is None:
+        raise L.EsrError(f"esr::sr_forward: no live model with handle {handle}")
+    if x.dim() != 4:
+        raise L.EsrError("expected a 4-D float32 NCHW tensor (uint2tensor4 output)")
+    return x.new_empty((x.shape[0], m.out_nc, x.shape[2] * m.upscale, x.shape[3] * m.upscale), dtype=torch.float32)
+
+
 class _Entry:
     """One cached shape: the Plan, and its esr_op array finalized against workspace base `base`."""
     __slots__ = ("plan", "arr", "in_idx", "out_idx", "base")
@@ -517,6 +544,11 @@ class HipSRModel(nn.Module):
         return self._entry((n, c, h, w, device))
 
     def forward(self, x):
+        """NCHW fp32 [N, in_nc, H, W] on the GPU -> NCHW fp32 [N, out_nc, 4H, 4W]: one esr::sr_forward call."""
+        _LIVE[id(self)] = self
+        return torch.ops.esr.sr_forward(x, id(self))
+
+    def _forward_impl(self, x):
         if not x.is_cuda:
             raise L.EsrError(f"{type(self).__name__}: input is on {x.device}; this engine only runs on an "
                              "MI355X through libesr_hip.so and has no CPU fallback (use oracle/ for CPU checks)")

@@ -249,6 +249,31 @@ typedef struct esr_bsconv_desc {
 
 int esr_bsconv_f32(const esr_bsconv_desc* d, void* hip_stream);
 
+/*
+ * esr_channel_attention_f32 -- CALayer (models/basicblock.py:333-348) and the contrast-aware CCALayer
+ * (models/team05_efdn/plainblock.py:106-122):
+ *     y = x * sigmoid(W2 . relu(W1 . s + b1) + b2),   s[c] = mean_hw(x[c])            (contrast = 0, CA)
+ *                                                     s[c] = std_hw(x[c]) + mean_hw(x[c])  (contrast = 1, CCA; population std)
+ * One reduction pass (fp64 sums of x and x^2 per image and channel) and one scaling pass.  `layout` ESR_NHWC: x / y are NHWC
+ * views (any esr_storage); ESR_NCHW_IN: x / y are plain NCHW fp32 tensors (pitch / coff ignored).  w1 / w2 are
+ * esr_pack_dense_f32 blobs of the two 1x1 convolutions: w1 (cin = c, cout = cr, cin_p = c, cout_p = cr), w2 (cin = cr,
+ * cout = c, cin_p = cr, cout_p = round_up(c, 4)).  `stats` is caller-provided scratch of n * 2 * round_up(c, 4) doubles
+ * (the call zeroes it on the stream).  c <= 64, cr <= 16.
+ */
+typedef struct esr_ca_desc {
+    int32_t n, h, w, c;
+    int32_t cr;                 /* channel / reduction */
+    int32_t contrast;           /* 0 = CALayer, 1 = CCALayer */
+    int32_t layout;             /* ESR_NHWC | ESR_NCHW_IN */
+    int32_t storage;            /* esr_storage of the NHWC views */
+    esr_view x, y;
+    const void* w1;
+    const void* w2;
+    void* stats;
+} esr_ca_desc;
+
+int esr_channel_attention_f32(const esr_ca_desc* d, void* hip_stream);
+
 typedef struct esr_op {
     int32_t kind;               /* esr_op_kind */
     int32_t reserved;

@@ -68,6 +68,15 @@ class BsDesc(ctypes.Structure):
     ]
 
 
+class CaDesc(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_int32), ("h", ctypes.c_int32), ("w", ctypes.c_int32), ("c", ctypes.c_int32),
+        ("cr", ctypes.c_int32), ("contrast", ctypes.c_int32), ("layout", ctypes.c_int32), ("storage", ctypes.c_int32),
+        ("x", View), ("y", View),
+        ("w1", ctypes.c_void_p), ("w2", ctypes.c_void_p), ("stats", ctypes.c_void_p),
+    ]
+
+
 class Op(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("conv", ConvDesc), ("esa", EsaDesc),
                 ("bs", BsDesc)]
@@ -83,7 +92,7 @@ EXPORTS = [
     "esr_packed_dense_bytes", "esr_pack_dense_f32",
     "esr_conv3x3s2_f32", "esr_maxpool7s3_f32", "esr_esa_apply_f32",
     "esr_packed_dw_bytes", "esr_pack_dw_f32", "esr_dwconv3x3_f32", "esr_bsconv_f32",
-    "esr_tensor2uint_u8", "esr_sqerr_u8",
+    "esr_tensor2uint_u8", "esr_sqerr_u8", "esr_channel_attention_f32",
 ]
 
 _lib = None
@@ -139,6 +148,8 @@ def lib():
     L.esr_dwconv3x3_f32.restype = ci
     L.esr_bsconv_f32.argtypes = [ctypes.POINTER(BsDesc), vp]
     L.esr_bsconv_f32.restype = ci
+    L.esr_channel_attention_f32.argtypes = [ctypes.POINTER(CaDesc), vp]
+    L.esr_channel_attention_f32.restype = ci
     L.esr_tensor2uint_u8.argtypes = [vp, vp, ci, ci, ci, ctypes.c_float, vp]
     L.esr_tensor2uint_u8.restype = ci
     L.esr_sqerr_u8.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]

@@ -10,6 +10,7 @@ torch.distributed.run) and a `--synthetic N` mode for data-free boxes.
 import argparse
 import json
 import logging
+import math
 import os
 import sys
 
@@ -28,6 +29,33 @@ def select_dataset(data_dir, mode):
                  os.path.join(data_dir, f"DIV2K_test_HR/{i:04}.png")) for i in range(901, 1001)]
     return [(os.path.join(data_dir, f"DIV2K_valid_LR/{i:04}x4.png"),
              os.path.join(data_dir, f"DIV2K_valid_HR/{i:04}.png")) for i in range(801, 901)]
+
+
+def make_synthetic_dataset(root, n, seed_image=None):
+    """`--synthetic N`: N DIV2K-validation-shaped LR / HR PNG pairs for data-free boxes, laid out like select_dataset()
+    expects (DIV2K_valid_LR/08xxx4.png, DIV2K_valid_HR/08xx.png).  HR = a natural image (tests/golden/test.bmp by default)
+    mirror-tiled to 4H x 4W and rolled per index, LR = its PIL-bicubic x4 reduction: natural statistics, so the PNG codec
+    works as hard as on DIV2K.  PSNR values on it mean nothing; wall-clock images/s of the pipeline does."""
+    from PIL import Image
+    shapes = [(339, 510), (339, 510), (384, 510), (339, 510), (510, 339), (294, 510), (339, 510), (345, 510), (510, 384), (339, 510)]
+    if seed_image is None:
+        seed_image = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "test.bmp")
+    base = np.array(Image.open(seed_image).convert("RGB"))
+    os.makedirs(os.path.join(root, "DIV2K_valid_LR"), exist_ok=True)
+    os.makedirs(os.path.join(root, "DIV2K_valid_HR"), exist_ok=True)
+    pairs = []
+    for i in range(n):
+        h, w = shapes[i % len(shapes)]
+        hr = np.pad(base, ((0, 4 * h - base.shape[0]), (0, 4 * w - base.shape[1]), (0, 0)), mode="symmetric")
+        hr = np.ascontiguousarray(np.roll(hr, (37 * i, 91 * i), axis=(0, 1)))
+        lr = np.array(Image.fromarray(hr).resize((w, h), Image.BICUBIC))
+        lp = os.path.join(root, f"DIV2K_valid_LR/{801 + i:04}x4.png")
+        hp = os.path.join(root, f"DIV2K_valid_HR/{801 + i:04}.png")
+        if not (os.path.exists(lp) and os.path.exists(hp)):
+            Image.fromarray(lr).save(lp)
+            Image.fromarray(hr).save(hp)
+        pairs.append((lp, hp))
+    return pairs
 
 
 def forward(img_lq, model, tile=None, tile_overlap=32, scale=4):
@@ -51,7 +79,17 @@ def forward(img_lq, model, tile=None, tile_overlap=32, scale=4):
 
 def run(model, model_name, data_range, tile, logger, device, args, mode="test", pairs=None, timer=None):
     """Per-image loop (test_demo.py:416-465) over this rank's shard; returns the reference's result dict on
-    every rank (lists in image order, averages in index order)."""
+    every rank (lists in image order, averages in index order).
+
+    On the GPU the loop is a three-stage pipeline -- the reference's loop is strictly serial and on DIV2K
+    its PNG decode / encode (2040x1356 HR) dwarfs a few-ms forward:
+      readers   a thread pool decodes the LR / HR PNGs of the next images while the GPU works (PIL's inflate drops the GIL)
+      GPU       H2D of the LR (and HR, uint8), prepare(), event-bracketed forward(), tensor2uint + squared error on the
+                device, asynchronous D2H of the uint8 SR image into pinned memory; nothing here waits for the host
+      writers   a thread pool encodes / writes the SR PNGs
+    Images retire IN ORDER from a small in-flight window, so the log lines, result lists and files are those of the serial
+    loop, bit for bit; each image's runtime is its own event pair around forward(), as in the reference."""
+    import time
     sf = 4
     border = sf
     rank, world = getattr(args, "rank", 0), getattr(args, "world", 1)
@@ -59,50 +97,114 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
     save_path = os.path.join(args.save_dir, model_name, "test" if mode == "test" else "valid")
     os.makedirs(save_path, exist_ok=True)
     use_cuda = device.type == "cuda"
-    if use_cuda:
-        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.reset_peak_memory_stats(device)
+    want_ssim = getattr(args, "ssim", False)
+    mine = D.shard(len(data_path), rank, world)
     rows = []
-    for i in D.shard(len(data_path), rank, world):
+    t_wall = time.perf_counter()
+
+    def load_pair(i):
         lr_path, hr_path = data_path[i]
-        img_name, ext = os.path.splitext(os.path.basename(hr_path))
-        img_lr = util.uint2tensor4(util.imread_uint(lr_path, n_channels=3), data_range).to(device)
+        return util.imread_uint(lr_path, n_channels=3), util.modcrop(util.imread_uint(hr_path, n_channels=3).squeeze(), sf)
+
+    def log_row(i, ms, psnr, img_sr_u8, img_hr):
+        img_name, ext = os.path.splitext(os.path.basename(data_path[i][1]))
+        if want_ssim:
+            ssim = util.calculate_ssim(img_sr_u8, img_hr, border=border)
+            logger.info("{:s} - PSNR: {:.2f} dB; SSIM: {:.4f}.".format(img_name + ext, psnr, ssim))
+        else:
+            ssim = float("nan")
+            logger.info("{:s} - PSNR: {:.2f} dB".format(img_name + ext, psnr))
+        rows.append((i, ms, psnr, ssim))
+        return os.path.join(save_path, img_name[:4] + ext)
+
+    if not use_cuda or not getattr(args, "device_metrics", True):
+        # serial reference loop (CPU stand-in models in the tests; device_metrics=False keeps the host metric path testable)
         if use_cuda:
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.reset_peak_memory_stats(device)
+        for i in mine:
+            lr, img_hr = load_pair(i)
+            img_lr = util.uint2tensor4(lr, data_range).to(device)
+            if use_cuda:
+                if hasattr(model, "prepare"):
+                    b, c, h, w = img_lr.shape
+                    t = None if tile is None else min(tile, h, w)
+                    model.prepare((b, c, h, w) if t is None else (b, c, t, t), device)
+                start.record()
+                img_sr = forward(img_lr, model, tile)
+                end.record()
+                torch.cuda.synchronize()
+                ms = start.elapsed_time(end)
+            else:
+                t0 = time.perf_counter()
+                img_sr = forward(img_lr, model, tile)
+                ms = (time.perf_counter() - t0) * 1e3
+            img_sr = util.tensor2uint(img_sr, data_range)
+            psnr = util.calculate_psnr(img_sr, img_hr, border=border)
+            util.imsave(img_sr, log_row(i, ms, psnr, img_sr, img_hr))
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        from . import ops
+        torch.cuda.reset_peak_memory_stats(device)
+        nio = max(1, int(getattr(args, "io_workers", 4)))
+        window = max(1, int(getattr(args, "inflight", 3)))
+        readers, writers = ThreadPoolExecutor(nio), ThreadPoolExecutor(nio)
+        copy_stream = torch.cuda.Stream(device)
+        ahead = [readers.submit(load_pair, i) for i in mine[:nio + window]]
+        nxt = len(ahead)
+        inflight, writes = [], []
+
+        def retire():
+            i, start, end, done, sr_host, se_dev, count, img_hr = inflight.pop(0)
+            done.synchronize()                                   # this image's D2H (and everything before it) has finished
+            ms = start.elapsed_time(end)
+            se = int(se_dev.item())
+            psnr = float("inf") if se == 0 else 20 * math.log10(255.0 / math.sqrt(se / count))
+            img_sr = sr_host.numpy()
+            writes.append(writers.submit(util.imsave, img_sr, log_row(i, ms, psnr, img_sr, img_hr)))
+
+        for k, i in enumerate(mine):
+            lr, img_hr = ahead[k].result()
+            ahead[k] = None
+            if nxt < len(mine):
+                ahead.append(readers.submit(load_pair, mine[nxt]))
+                nxt += 1
+            img_lr = util.uint2tensor4(lr, data_range).to(device, non_blocking=True)
+            hr_dev = torch.from_numpy(np.ascontiguousarray(img_hr)).to(device, non_blocking=True)
             if hasattr(model, "prepare"):
                 # plan construction / workspace zero fill are not part of the forward the reference times
                 # (test_demo.py:429-432 brackets model(img_lq) only); whole-image and tiled shapes alike
                 b, c, h, w = img_lr.shape
                 t = None if tile is None else min(tile, h, w)
                 model.prepare((b, c, h, w) if t is None else (b, c, t, t), device)
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             start.record()
             img_sr = forward(img_lr, model, tile)
             end.record()
-            torch.cuda.synchronize()
-            ms = start.elapsed_time(end)
-        else:
-            import time
-            t0 = time.perf_counter()
-            img_sr = forward(img_lr, model, tile)
-            ms = (time.perf_counter() - t0) * 1e3
-        img_hr = util.modcrop(util.imread_uint(hr_path, n_channels=3).squeeze(), sf)
-        if use_cuda and getattr(args, "device_metrics", True):
-            # uint8 conversion and the squared-error sum run on the GPU: the SR image crosses PCIe once as uint8
-            # (needed for imsave) and the PSNR as one integer
-            from . import ops
             sr_dev = ops.tensor2uint_device(img_sr, data_range)
-            psnr = ops.psnr_device(sr_dev, torch.from_numpy(np.ascontiguousarray(img_hr)).to(device), border=border)
-            img_sr = sr_dev.cpu().numpy()
-        else:
-            img_sr = util.tensor2uint(img_sr, data_range)
-            psnr = util.calculate_psnr(img_sr, img_hr, border=border)
-        if getattr(args, "ssim", False):
-            ssim = util.calculate_ssim(img_sr, img_hr, border=border)
-            logger.info("{:s} - PSNR: {:.2f} dB; SSIM: {:.4f}.".format(img_name + ext, psnr, ssim))
-        else:
-            ssim = float("nan")
-            logger.info("{:s} - PSNR: {:.2f} dB".format(img_name + ext, psnr))
-        rows.append((i, ms, psnr, ssim))
-        util.imsave(img_sr, os.path.join(save_path, img_name[:4] + ext))
+            if sr_dev.shape != hr_dev.shape:
+                raise ValueError('Input images must have the same dimensions.')
+            se_dev = ops.sqerr_device(sr_dev, hr_dev, border=border)
+            ready = torch.cuda.Event()
+            ready.record()
+            sr_host = torch.empty(sr_dev.shape, dtype=torch.uint8, pin_memory=True)
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ready)
+                sr_host.copy_(sr_dev, non_blocking=True)
+                sr_dev.record_stream(copy_stream)
+                done = torch.cuda.Event()
+                done.record()
+            hh, ww = sr_dev.shape[:2]
+            inflight.append((i, start, end, done, sr_host, se_dev, (hh - 2 * border) * (ww - 2 * border) * sr_dev.shape[2], img_hr))
+            if len(inflight) > window:
+                retire()
+        while inflight:
+            retire()
+        for w_ in writes:
+            w_.result()
+        readers.shutdown()
+        writers.shutdown()
+    wall = time.perf_counter() - t_wall
     allrows = D.gather_rows(rows, len(data_path), rank, world, device)
     results = {f"{mode}_runtime": [float(v) for v in allrows[:, 1]],
                f"{mode}_psnr": [float(v) for v in allrows[:, 2]]}
@@ -121,6 +223,14 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
     logger.info("{:>16s} : {:<.3f} [M]".format("Max Memery", results[f"{mode}_memory"]))
     logger.info("------> Average runtime of ({}) is : {:.6f} seconds".format(
         "test" if mode == "test" else "valid", results[f"{mode}_ave_runtime"]))
+    # wall clock of this rank's loop (decode + forward + metrics + encode): what the pipeline is for.  Not a key of the
+    # reference's result dict, so it travels on `args.pipeline` (main() writes it to pipeline.json) and in the log
+    ips = len(mine) * world / wall if wall > 0 else 0.0
+    if not hasattr(args, "pipeline"):
+        args.pipeline = {}
+    args.pipeline[mode] = {"wall_seconds": wall, "images": len(data_path), "ranks": world, "images_per_s": ips}
+    logger.info("{:>16s} : {:.2f} images/s wall clock ({} images on {} rank(s), PNG decode / encode included)".format(
+        "Pipeline", ips, len(data_path), world))
     return results
 
 
@@ -167,7 +277,15 @@ def main(args):
     results = json.load(open(json_path)) if os.path.exists(json_path) else dict()
     model, model_name, data_range, tile = select_model(args.model_id, device, getattr(args, "model_zoo", None))
     logger.info(model_name)
-    results[model_name] = run(model, model_name, data_range, tile, logger, device, args, mode="valid")
+    pairs = None
+    if getattr(args, "synthetic", 0):
+        if rank == 0:
+            make_synthetic_dataset(os.path.join(args.save_dir, "_synthetic"), args.synthetic)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        pairs = make_synthetic_dataset(os.path.join(args.save_dir, "_synthetic"), args.synthetic)   # paths only: files exist
+    results[model_name] = run(model, model_name, data_range, tile, logger, device, args, mode="valid", pairs=pairs)
     if args.include_test:
         results[model_name].update(run(model, model_name, data_range, tile, logger, device, args, mode="test"))
     c = model_complexity(model, (3, 256, 256))
@@ -179,6 +297,7 @@ def main(args):
     results[model_name].update({"activations": activations, "num_conv": c["num_conv"], "flops": flops,
                                 "num_parameters": num_parameters})
     if rank == 0:
+        json.dump(getattr(args, "pipeline", {}), open(os.path.join(os.getcwd(), "pipeline.json"), "w"))
         json.dump(results, open(json_path, "w"))
         open(os.path.join(os.getcwd(), "results.txt"), "w").write(results_table(results, args.include_test))
     if world > 1:
@@ -196,6 +315,10 @@ def build_parser():
     p.add_argument("--include_test", action="store_true", help="Inference on the DIV2K test set")
     p.add_argument("--ssim", action="store_true", help="Calculate SSIM")
     p.add_argument("--model_zoo", default=None, type=str, help="directory holding the reference's .pth checkpoints")
+    p.add_argument("--synthetic", default=0, type=int, metavar="N",
+                   help="run on N generated DIV2K-val-shaped PNG pairs under save_dir/_synthetic instead of data_dir")
+    p.add_argument("--io_workers", default=4, type=int, help="PNG decode / encode threads per rank")
+    p.add_argument("--inflight", default=3, type=int, help="images in flight between the GPU and the writers")
     return p
 
 

@@ -112,6 +112,19 @@ def tensor2uint_device(img_sr, data_range):
     return out
 
 
+def sqerr_device(a_u8, b_u8, border=0):
+    """sum over the border-cropped region of (a - b)^2 for two HWC uint8 CUDA tensors as a 1-element int64 DEVICE tensor:
+    no host synchronisation (the harness pipeline reads it when the image retires)."""
+    a, b = a_u8.contiguous(), b_u8.contiguous()
+    h, w = a.shape[:2]
+    c = a.shape[2] if a.dim() == 3 else 1
+    acc = torch.empty(1, dtype=torch.int64, device=a.device)
+    stream = torch.cuda.current_stream(a.device).cuda_stream
+    L.check(L.lib().esr_sqerr_u8(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), h, w, c, border,
+                                 ctypes.c_void_p(acc.data_ptr()), ctypes.c_void_p(stream)), "esr_sqerr_u8")
+    return acc
+
+
 def psnr_device(a_u8, b_u8, border=0):
     """calculate_psnr for two HWC uint8 CUDA tensors: exact integer squared-error sum on the device, one scalar D2H."""
     import math
@@ -169,3 +182,31 @@ def bsconv(x, pw_weight, pw_bias, dw_weight, dw_bias, *, act=L.ACT_NONE, slope=0
     stream = torch.cuda.current_stream(x.device).cuda_stream
     L.check(lib.esr_bsconv_f32(ctypes.byref(d), ctypes.c_void_p(stream)), "esr_bsconv_f32")
     return y if yd is None else (y, yd)
+
+
+def channel_attention(x, w1, b1, w2, b2, *, contrast=False, nchw=False, out=None):
+    """CALayer / CCALayer (esr_channel_attention_f32): y = x * sigmoid(W2 . relu(W1 . s + b1) + b2) with s = mean over H, W
+    (contrast=False, models/basicblock.py:333-348) or std + mean (contrast=True, models/team05_efdn/plainblock.py:106-122).
+    x: NHWC [N,H,W,pitch] (fp32 / bf16 / fp16) or, with nchw=True, NCHW fp32 [N,C,H,W]; w1 [cr, c(,1,1)], w2 [c, cr(,1,1)]."""
+    from .engine import pack_dense
+    if not x.is_cuda:
+        raise L.EsrError("channel_attention: tensors must live on the GPU; there is no CPU fallback")
+    cr, c = w1.shape[0], w1.shape[1]
+    c4 = (c + 3) // 4 * 4
+    if nchw:
+        n, _, h, w = x.shape
+    else:
+        n, h, w, _ = x.shape
+    keep = [pack_dense(w1.reshape(cr, c, 1, 1), b1, c, cr).to(x.device), pack_dense(w2.reshape(c, cr, 1, 1), b2, cr, c4).to(x.device)]
+    y = torch.zeros_like(x) if out is None else out
+    stats = torch.empty(n * 2 * c4, dtype=torch.float64, device=x.device)
+    d = L.CaDesc()
+    d.n, d.h, d.w, d.c, d.cr, d.contrast = n, h, w, c, cr, int(contrast)
+    d.layout = L.NCHW_IN if nchw else L.NHWC
+    d.storage = L.STORE[_STORE_OF[x.dtype]]
+    d.x = L.View(ctypes.c_void_p(x.data_ptr()), 0 if nchw else x.shape[-1], 0)
+    d.y = L.View(ctypes.c_void_p(y.data_ptr()), 0 if nchw else y.shape[-1], 0)
+    d.w1, d.w2, d.stats = keep[0].data_ptr(), keep[1].data_ptr(), stats.data_ptr()
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    L.check(L.lib().esr_channel_attention_f32(ctypes.byref(d), ctypes.c_void_p(stream)), "esr_channel_attention_f32")
+    return y

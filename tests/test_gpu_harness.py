@@ -101,3 +101,30 @@ def test_device_tensor2uint_and_psnr_match_host():
     big2 = (big.int() + torch.randint(-5, 6, big.shape, generator=g)).clamp(0, 255).to(torch.uint8)
     assert ops.psnr_device(big.to("cuda:0"), big2.to("cuda:0"), 4) == pytest.approx(
         util.calculate_psnr(big.numpy(), big2.numpy(), 4), abs=1e-10)
+
+
+def test_pipeline_equals_serial_loop(tmp_path):
+    """the 3-stage host pipeline (decode-ahead readers, in-flight window, async D2H, writer pool) produces the serial loop's
+    results bit for bit: per-image PSNRs, SR PNGs, averages -- on the committed set and on a generated DIV2K-shaped one"""
+    import numpy as np
+    from ntire2022_esr_amd import harness as H
+    from ntire2022_esr_amd import image_util as util
+    from ntire2022_esr_amd.registry import select_model
+    dev = torch.device("cuda:0")
+    model, name, data_range, tile = select_model(4, dev)
+    pairs = H.select_dataset(os.path.join(GOLD, "mini_div2k"), "valid")[:3]
+    pairs += H.make_synthetic_dataset(str(tmp_path / "syn"), 3)
+    log = logging.getLogger("gpu")
+    a1 = types.SimpleNamespace(save_dir=str(tmp_path / "pipe"), rank=0, world=1, io_workers=3, inflight=2)
+    a2 = types.SimpleNamespace(save_dir=str(tmp_path / "serial"), rank=0, world=1, device_metrics=False)
+    r1 = H.run(model, name, data_range, tile, log, dev, a1, mode="valid", pairs=pairs)
+    r2 = H.run(model, name, data_range, tile, log, dev, a2, mode="valid", pairs=pairs)
+    assert r1["valid_psnr"] == r2["valid_psnr"] and r1["valid_ave_psnr"] == r2["valid_ave_psnr"]
+    assert set(r1) == set(r2) and all(t > 0 for t in r1["valid_runtime"])
+    for f in sorted(os.listdir(str(tmp_path / "serial" / name / "valid"))):
+        x = util.imread_uint(str(tmp_path / "pipe" / name / "valid" / f))
+        y = util.imread_uint(str(tmp_path / "serial" / name / "valid" / f))
+        assert np.array_equal(x, y), f
+    assert a1.pipeline["valid"]["images"] == 6 and a1.pipeline["valid"]["images_per_s"] > 0
+    # the big generated images are DIV2K-shaped: 4 x (339 x 510) etc.
+    assert util.imread_uint(pairs[3][1]).shape == (1356, 2040, 3) and util.imread_uint(pairs[3][0]).shape == (339, 510, 3)

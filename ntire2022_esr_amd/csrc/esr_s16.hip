@@ -67,6 +67,7 @@ struct S16K {
     int res_in;           // pre-activation residual == the conv input: added from the staged tile in LDS, no loads
     int out_layout;
     int tiles_x, tiles_y;
+    unsigned magic_x, magic_y;   // ceil(2^32 / tiles): t / tiles == umulhi(t, magic) for t * tiles < 2^32 (0: tiles == 1)
 };
 
 template <bool BF16>
@@ -218,6 +219,17 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15;
     const int kq = lane >> 4;
+    // The launch parameters are re-read from the kernarg segment where they are used (tile set-up, epilogue) instead of living
+    // in SGPRs across the stage loop: with ~40 parameters + loop state hipcc spilled 70-160 SGPRs to VGPR lanes and the
+    // v_readlane / v_writelane traffic was a third of the kernel's VALU instructions.  The asm makes the pointer opaque, so the
+    // scalar loads (a few s_load_dwordx8 per tile) cannot be hoisted back out of the loop.
+    typedef const __attribute__((address_space(4))) S16K* kparg_t;
+    const kparg_t kp0 = (kparg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    auto KP = [&]() __attribute__((always_inline)) -> kparg_t {
+        kparg_t q = kp0;
+        asm volatile("" : "+s"(q));
+        return q;
+    };
     const int R = p.ring;
     const int w_bytes = p.nchunks * W_CHUNK_BYTES;
     char* const ring = smem + w_bytes;
@@ -236,11 +248,14 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         const int t = base + off;
         return t < ntiles ? t : -1;
     };
-    auto tile_coords = [&](int t, int& n, int& x0, int& y0) {
-        const int tx = t % p.tiles_x;
-        const int tq = t / p.tiles_x;
-        const int ty = tq % p.tiles_y;
-        n = tq / p.tiles_y;
+    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) {
+        const kparg_t q = KP();
+        const unsigned mx = q->magic_x, my = q->magic_y;
+        const int tsx = q->tiles_x, tsy = q->tiles_y;
+        const int tq = mx ? (int)__umulhi((unsigned)t, mx) : t;          // t / tiles_x without the 25-instruction division
+        const int tx = t - tq * tsx;
+        n = my ? (int)__umulhi((unsigned)tq, my) : tq;
+        const int ty = tq - n * tsy;
         x0 = tx * TILE;
         y0 = ty * TILE_H;
     };
@@ -248,7 +263,6 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     // ---- load cursor: the (tile, chunk) stage requested next ---------------------------------------------------------
     // piece pc = wv + NW * r of a stage: plane pc / PPP, items (pc % PPP) * 64 + lane of that plane
     const int n_my = (NPIECES % NW == 0 || wv < NPIECES % NW) ? PPW : PPW - 1;     // wave-uniform
-    const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 2;
     int lk = 0;                   // tile iteration of the cursor
     int lc = 0;                   // chunk of the cursor
     int lslot = 0;
@@ -262,7 +276,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         if (!lvalid) return;
         int n, x0, y0;
         tile_coords(t, n, x0, y0);
-        lrsrc = make_rsrc(p.x + (size_t)n * img_bytes, img_bytes);
+        const kparg_t q = KP();
+        const int qH = q->H, qW = q->W, qpitch = q->in_pitch, qcoff = q->in_coff;
+        const size_t img_bytes = (size_t)qH * qW * qpitch * 2;
+        lrsrc = make_rsrc(q->x + (size_t)n * img_bytes, img_bytes);
 #pragma unroll
         for (int r = 0; r < PPW; ++r) {
             const int pc = wv + NW * r;
@@ -270,8 +287,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
             const int pl = (pc - plane * PPP) * 64 + lane;
             const int ly = pl / TH, lx = pl - ly * TH;
             const int gy = y0 - HALO + ly, gx = x0 - HALO + lx;
-            const bool ok = pc < NPIECES && pl < NPX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            lvoff[r] = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff + 8 * plane) * 2u : OOB;
+            const bool ok = pc < NPIECES && pl < NPX && (unsigned)gy < (unsigned)qH && (unsigned)gx < (unsigned)qW;
+            lvoff[r] = ok ? (unsigned)((gy * qW + gx) * qpitch + qcoff + 8 * plane) * 2u : OOB;
         }
     };
     auto issue_stage = [&]() __attribute__((always_inline)) {          // DMA of the cursor's stage into ring slot lslot, then advance the cursor
@@ -319,15 +336,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     // the centre pixel of this lane's accumulator rows in the staged tile: channels 16c + 4kq .. +3 of chunk c
     const int c_off = (kq >> 1) * PLANE_BYTES + ((wv * 4 + HALO) * TH + px + HALO) * 16 + (kq & 1) * 8;
 
-    const bool shuffle = p.out_layout == ESR_NCHW_SHUFFLE4;
-    const bool has_split = !shuffle && p.split < p.cout_store;
     constexpr bool gres = GRES;
-    const int epi_stores = shuffle ? 4 * NT : (has_split ? 16 : 8);     // store instructions per wave and tile
+    const int epi_stores = p.out_layout == ESR_NCHW_SHUFFLE4 ? 4 * NT : (p.split < p.cout_store ? 16 : 8);   // stores per wave and tile
     const unsigned hmask = (1u << (R - 1)) - 1u;
     unsigned hist_st = 0, hist_rs = 0;   // bit i: an epilogue's stores / a tile's residual loads were issued at the top of stage s - i
-    const size_t res_img = (size_t)p.H * p.W * p.res_pitch * 2;
-    const size_t y0_img = shuffle ? (size_t)p.cout_store * p.H * p.W * 4 : (size_t)p.H * p.W * p.y0_pitch * 2;   // NCHW fp32: cout/16 planes of 4H x 4W
-    const size_t y1_img = (size_t)p.H * p.W * p.y1_pitch * 2;
 
     f32x4 acc[NT][4];
     uint2 rv[GRES ? NT : 1][4];          // residual of the current tile in D-fragment layout (hidden asm loads)
@@ -338,7 +350,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
 
     auto load_residual = [&](int n, int x0, int y0) __attribute__((always_inline)) {
         if (!GRES) return;
-        const i32x4 rr = make_rsrc(p.res + (size_t)n * res_img, res_img);
+        const kparg_t q = KP();
+        const int qH = q->H, qW = q->W, qrp = q->res_pitch, qrc = q->res_coff, qcs = q->cout_store;
+        const size_t res_img = (size_t)qH * qW * qrp * 2;
+        const i32x4 rr = make_rsrc(q->res + (size_t)n * res_img, res_img);
         i32x4 rru;
         rru.x = __builtin_amdgcn_readfirstlane(rr.x); rru.y = __builtin_amdgcn_readfirstlane(rr.y);
         rru.z = __builtin_amdgcn_readfirstlane(rr.z); rru.w = __builtin_amdgcn_readfirstlane(rr.w);
@@ -349,8 +364,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
                 const int cb = tt * 16 + kq * 4;
-                const bool ok = gy < p.H && gx < p.W && cb < p.cout_store;
-                const unsigned vo = ok ? (unsigned)((gy * p.W + gx) * p.res_pitch + p.res_coff + cb) * 2u : OOB;
+                const bool ok = gy < qH && gx < qW && cb < qcs;
+                const unsigned vo = ok ? (unsigned)((gy * qW + gx) * qrp + qrc + cb) * 2u : OOB;
                 asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(rv[GRES ? tt : 0][r]) : "v"(vo), "s"(rru) : "memory");
             }
         }
@@ -358,6 +373,11 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
 
     auto epilogue_body = [&](auto gelu_tag, int n, int x0, int y0, int younger_dma) __attribute__((always_inline)) {
         constexpr bool GELU = decltype(gelu_tag)::value;
+        const kparg_t q = KP();
+        const int qH = q->H, qW = q->W, qcs = q->cout_store, qsplit = q->split, qres_mode = q->res_mode;
+        const float qslope = q->slope;
+        const bool shuffle = q->out_layout == ESR_NCHW_SHUFFLE4;
+        const bool has_split = !shuffle && qsplit < qcs;
         if (gres) {
             // the residual loads were issued one whole stage ago, behind them only this top's DMA
             wait_vm_dyn(younger_dma);
@@ -369,17 +389,18 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         if (shuffle) {
             // out[n, t, 4gy + kq, 4gx + 0..3] = channel 16t + 4kq + j: the D fragment is one dwordx4 of 4 adjacent HR pixels
             const int gx = x0 + px;
-            const unsigned W4 = (unsigned)p.W * 4u, H4 = (unsigned)p.H * 4u;
-            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)n * y0_img, 0, (int)y0_img, 0x00020000);
+            const unsigned W4 = (unsigned)qW * 4u, H4 = (unsigned)qH * 4u;
+            const size_t y0_img = (size_t)qcs * qH * qW * 4;                 // NCHW fp32: cout / 16 planes of 4H x 4W
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(q->y0 + (size_t)n * y0_img, 0, (int)y0_img, 0x00020000);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gy = y0 + wv * 4 + r;
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
-                    const bool ok = gy < p.H && gx < p.W && tt * 16 + kq * 4 < p.cout_store;
+                    const bool ok = gy < qH && gx < qW && tt * 16 + kq * 4 < qcs;
                     f32x4 v = acc[tt][r];
-                    v.x = act1<GELU>(v.x, p.slope); v.y = act1<GELU>(v.y, p.slope);
-                    v.z = act1<GELU>(v.z, p.slope); v.w = act1<GELU>(v.w, p.slope);
+                    v.x = act1<GELU>(v.x, qslope); v.y = act1<GELU>(v.y, qslope);
+                    v.z = act1<GELU>(v.z, qslope); v.w = act1<GELU>(v.w, qslope);
                     const unsigned vo = ok ? (((unsigned)tt * H4 + (unsigned)gy * 4u + (unsigned)kq) * W4 + (unsigned)gx * 4u) * 4u : OOB;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yr, vo, 0, 0);
                 }
@@ -391,10 +412,12 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         // lane, 128 contiguous bytes per pixel, 1 KB per instruction
         const int p8 = lane >> 3, cg = lane & 7;
         const int cb = cg * 8;
-        const bool ch0 = cb < p.split;                       // goes to out0
-        const bool ch1 = !ch0 && cb < p.cout_store;          // goes to out1 (split store)
-        const __amdgpu_buffer_rsrc_t yr0 = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)n * y0_img, 0, (int)y0_img, 0x00020000);
-        const __amdgpu_buffer_rsrc_t yr1 = __builtin_amdgcn_make_buffer_rsrc(p.y1 + (size_t)n * y1_img, 0, (int)y1_img, 0x00020000);
+        const bool ch0 = cb < qsplit;                        // goes to out0
+        const bool ch1 = !ch0 && cb < qcs;                   // goes to out1 (split store)
+        const int qy0p = q->y0_pitch, qy0c = q->y0_coff, qy1p = q->y1_pitch, qy1c = q->y1_coff;
+        const size_t y0_img = (size_t)qH * qW * qy0p * 2, y1_img = (size_t)qH * qW * qy1p * 2;
+        const __amdgpu_buffer_rsrc_t yr0 = __builtin_amdgcn_make_buffer_rsrc(q->y0 + (size_t)n * y0_img, 0, (int)y0_img, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yr1 = __builtin_amdgcn_make_buffer_rsrc(q->y1 + (size_t)n * y1_img, 0, (int)y1_img, 0x00020000);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gy = y0 + wv * 4 + r;
@@ -404,10 +427,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                 f32x4 v = acc[tt][r];
                 f32x4 rf = {0.f, 0.f, 0.f, 0.f};
                 if (GRES) rf = unpack4<BF16>(rv[GRES ? tt : 0][r]);
-                if (GRES && p.res_mode == ESR_RES_PRE_ACT) v += rf;
-                v.x = act1<GELU>(v.x, p.slope); v.y = act1<GELU>(v.y, p.slope);
-                v.z = act1<GELU>(v.z, p.slope); v.w = act1<GELU>(v.w, p.slope);
-                if (GRES && p.res_mode == ESR_RES_POST_ACT) v += rf;
+                if (GRES && qres_mode == ESR_RES_PRE_ACT) v += rf;
+                v.x = act1<GELU>(v.x, qslope); v.y = act1<GELU>(v.y, qslope);
+                v.z = act1<GELU>(v.z, qslope); v.w = act1<GELU>(v.w, qslope);
+                if (GRES && qres_mode == ESR_RES_POST_ACT) v += rf;
                 pk[tt].x = pack2<BF16>(v.x, v.y);
                 pk[tt].y = pack2<BF16>(v.z, v.w);
             }
@@ -421,12 +444,12 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                 __builtin_amdgcn_wave_barrier();
                 const i32x4 o = *reinterpret_cast<const i32x4*>(scr + p8 * SCR_ROW + min(cb, NT * 16 - 8) * 2);
                 const int gx = x0 + 8 * h + p8;
-                const bool in = gy < p.H && gx < p.W;
-                const unsigned pix = (unsigned)(gy * p.W + gx);
-                const unsigned vo0 = (in && ch0) ? (pix * (unsigned)p.y0_pitch + (unsigned)(p.y0_coff + cb)) * 2u : OOB;
+                const bool in = gy < qH && gx < qW;
+                const unsigned pix = (unsigned)(gy * qW + gx);
+                const unsigned vo0 = (in && ch0) ? (pix * (unsigned)qy0p + (unsigned)(qy0c + cb)) * 2u : OOB;
                 __builtin_amdgcn_raw_buffer_store_b128(o, yr0, vo0, 0, 0);
                 if (has_split) {
-                    const unsigned vo1 = (in && ch1) ? (pix * (unsigned)p.y1_pitch + (unsigned)(p.y1_coff + cb - p.split)) * 2u : OOB;
+                    const unsigned vo1 = (in && ch1) ? (pix * (unsigned)qy1p + (unsigned)(qy1c + cb - qsplit)) * 2u : OOB;
                     __builtin_amdgcn_raw_buffer_store_b128(o, yr1, vo1, 0, 0);
                 }
             }
@@ -434,7 +457,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     };
 
     auto epilogue = [&](int n, int x0, int y0, int younger_dma) __attribute__((always_inline)) {
-        if (p.act == ESR_ACT_GELU) epilogue_body(std::true_type{}, n, x0, y0, younger_dma);
+        if (KP()->act == ESR_ACT_GELU) epilogue_body(std::true_type{}, n, x0, y0, younger_dma);
         else epilogue_body(std::false_type{}, n, x0, y0, younger_dma);
     };
 
@@ -462,10 +485,6 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                     hist_st |= 1u;
                     pend = false;
                 }
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[tt][r] = biasv[tt];
             }
             if (gres && c == p.nchunks - 1) {
                 load_residual(n, x0, y0);
@@ -474,16 +493,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
             // ---- compute -------------------------------------------------------------------------------------------
             const char* sb = ring + slot * STAGE_BYTES;
             const char* wc = smem + c * W_CHUNK_BYTES + a_off;
-            if (KS == 3 && p.res_in) {
-                // act(conv(x) + x): the residual of output channels 16c .. 16c+15 is the centre pixel of input chunk c
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-                    if (tt == c) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            acc[tt][r] += unpack4<BF16>(*reinterpret_cast<const uint2*>(sb + c_off + r * (TH * 16)));
-                    }
-            }
+
             constexpr int NBUF = GRES ? 1 : 2;               // fragment sets: the read of pair q+1 runs under the MFMAs of pair q
             i32x4 a[NBUF][NT], b[NBUF][4];
             auto load_frag = [&](int buf, int q) {
@@ -502,10 +512,30 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                 } else {
                     load_frag(0, q);
                 }
+                if (q == 0 && c == 0) {
+                    // first MFMA group of a tile: the accumulator input is the bias
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], biasv[tt]);
+                } else {
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], acc[tt][r]);
+                }
+            }
+            if (KS == 3 && p.res_in) {
+                // act(conv(x) + x): the residual of output channels 16c .. 16c+15 is the centre pixel of input chunk c, still in
+                // this stage's ring slot (read behind the MFMAs: nothing waits for it)
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
+                    if (tt == c) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], acc[tt][r]);
+                        for (int r = 0; r < 4; ++r)
+                            acc[tt][r] += unpack4<BF16>(*reinterpret_cast<const uint2*>(sb + c_off + r * (TH * 16)));
+                    }
             }
             // ---- sync: stage s+1 has landed; everything issued after its DMA may stay in flight -------------------------
             {
@@ -760,6 +790,12 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     k.out_layout = d->out_layout;
     k.tiles_x = (d->w + TILE - 1) / TILE;
     k.tiles_y = (d->h + 31) / 32;
+    k.magic_x = k.tiles_x > 1 ? (unsigned)((0x100000000ull + k.tiles_x - 1) / k.tiles_x) : 0u;
+    k.magic_y = k.tiles_y > 1 ? (unsigned)((0x100000000ull + k.tiles_y - 1) / k.tiles_y) : 0u;
+    {
+        const double nt_all = (double)d->n * k.tiles_x * k.tiles_y;
+        if (nt_all * (k.tiles_x > k.tiles_y ? k.tiles_x : k.tiles_y) >= 4294967296.0) return ESR_ERR_UNSUPPORTED;   // magic division range
+    }
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     if (d->ksize == 3) return bf16 ? launch_s16_res<3, true>(nt, k, lds, st) : launch_s16_res<3, false>(nt, k, lds, st);
     return bf16 ? launch_s16_res<1, true>(nt, k, lds, st) : launch_s16_res<1, false>(nt, k, lds, st);

@@ -146,7 +146,7 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
         from concurrent.futures import ThreadPoolExecutor
         from . import ops
         torch.cuda.reset_peak_memory_stats(device)
-        nio = max(1, int(getattr(args, "io_workers", 4)))
+        nio = max(1, int(getattr(args, "io_workers", 8)))
         window = max(1, int(getattr(args, "inflight", 3)))
         readers, writers = ThreadPoolExecutor(nio), ThreadPoolExecutor(nio)
         copy_stream = torch.cuda.Stream(device)
@@ -317,7 +317,7 @@ def build_parser():
     p.add_argument("--model_zoo", default=None, type=str, help="directory holding the reference's .pth checkpoints")
     p.add_argument("--synthetic", default=0, type=int, metavar="N",
                    help="run on N generated DIV2K-val-shaped PNG pairs under save_dir/_synthetic instead of data_dir")
-    p.add_argument("--io_workers", default=4, type=int, help="PNG decode / encode threads per rank")
+    p.add_argument("--io_workers", default=8, type=int, help="PNG decode / encode threads per rank")
     p.add_argument("--inflight", default=3, type=int, help="images in flight between the GPU and the writers")
     return p
 

@@ -30,7 +30,12 @@ def imread_uint(path, n_channels=3):
 def imsave(img, img_path):
     img = np.squeeze(img)
     os.makedirs(os.path.dirname(os.path.abspath(img_path)), exist_ok=True)
-    Image.fromarray(img).save(img_path)
+    if str(img_path).lower().endswith(".png"):
+        # cv2.imwrite's default PNG setting is compression level 1 (IMWRITE_PNG_COMPRESSION, "best speed"); PIL's default is 6
+        # and 3x slower on a 2040x1356 image.  Lossless either way: the decoded array is identical.
+        Image.fromarray(img).save(img_path, compress_level=1)
+    else:
+        Image.fromarray(img).save(img_path)
 
 
 def uint2tensor4(img, data_range):

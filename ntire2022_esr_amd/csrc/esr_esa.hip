@@ -147,9 +147,19 @@ __global__ __launch_bounds__(256) void esa_apply_kernel(const EsaK p)
     for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const long long pix = min(grp * 16 + pl, npix - 1);                         // clamp: every lane takes part in the exchange
     const bool live = grp * 16 + pl < npix && g * 4 < p.Cp4;
-    const int ox = (int)(pix % p.W);
-    const int oy = (int)((pix / p.W) % p.H);
-    const int n = (int)(pix / ((long long)p.W * p.H));
+    // block-uniform 32-bit division of the group's first pixel (scalar unit), a carry per lane (see esa_apply_mfma_kernel)
+    const unsigned pix0 = (unsigned)grp * 16u;
+    const unsigned row0 = pix0 / (unsigned)p.W;
+    const unsigned n0 = row0 / (unsigned)p.H;
+    int ox = (int)(pix0 - row0 * (unsigned)p.W) + pl;
+    int oy = (int)(row0 - n0 * (unsigned)p.H);
+    int n = (int)n0;
+    for (int wrap = 0; wrap < 2; ++wrap)
+        if (ox >= p.W) {
+            ox -= p.W;
+            if (++oy == p.H) { oy = 0; ++n; }
+        }
+    if (grp * 16 + pl >= npix) { ox = p.W - 1; oy = p.H - 1; n = p.N - 1; }
 
     // bilinear source coordinates: ATen area_pixel_compute_source_index, fused multiply-add (see oracle)
     float fy = fmaf((float)oy + 0.5f, p.sh, -0.5f);
@@ -230,12 +240,16 @@ __device__ __forceinline__ f32x4 mfma_k32(i32x4_t a, i32x4_t b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 
-template <int ST, int NT>
+// Channel <-> MFMA row map of conv4: tile t, row i (= 4 kq + r) computes channel 32 (t >> 1) + 8 kq + 4 (t & 1) + r, so a lane's
+// results of a tile PAIR are 8 CONSECUTIVE channels: x is read and y written as 16 bytes per lane, 64 contiguous bytes per
+// pixel and instruction (the natural 16 t + 4 kq + r map gives 8-byte pieces, 32 bytes per pixel: twice the requests).
+template <int ST, int NP>                         // NP = channel pairs of tiles = ceil(C / 32)
 __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
 {
+    constexpr int NT = 2 * NP;
     // LDS: A images, lane-linear 16 bytes per lane: [Wf][W4 hi x NT][W4 lo x NT], then bf[16] and b4[NT*16] as floats
     __shared__ __attribute__((aligned(16))) unsigned short simg[(1 + 2 * NT) * 64 * 8];
-    __shared__ float sbias[16 + NT * 16];
+    __shared__ __attribute__((aligned(16))) float sbias[16 + NT * 16];
     const int tid = threadIdx.x;
     for (int e = tid; e < (1 + 2 * NT) * 512; e += 256) {
         const int img = e >> 9, l = (e >> 3) & 63, j = e & 7;
@@ -248,7 +262,7 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
             v = kq < 2 ? hi : w - hi;
         } else {
             const int t = (img - 1) % NT, lo = (img - 1) / NT;
-            const int oc = 16 * t + i;
+            const int oc = 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3);
             const float w = oc < p.cp ? p.w4[(4 * kq + (j & 3)) * p.cp + oc] : 0.f;
             const float hi = from16<ST>(to16<ST>(w));
             v = lo ? (j < 4 ? w - hi : 0.f) : hi;           // hi image: against s_hi (j < 4) and s_lo (j >= 4); lo image: against s_hi only
@@ -256,7 +270,11 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
         simg[e] = to16<ST>(v);
     }
     if (tid < 16) sbias[tid] = p.wf[FP * FP + tid];
-    for (int e = tid; e < NT * 16; e += 256) sbias[16 + e] = e < p.cp ? p.w4[FP * p.cp + e] : 0.f;
+    for (int e = tid; e < NT * 16; e += 256) {
+        const int t = e >> 4, i = e & 15;
+        const int oc = 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3);
+        sbias[16 + e] = oc < p.cp ? p.w4[FP * p.cp + oc] : 0.f;
+    }
     __syncthreads();
 
     const int lane = tid & 63, wv = tid >> 6;
@@ -272,38 +290,72 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
     const long long npix = (long long)p.N * p.H * p.W;
     const long long ngroups = (npix + 15) / 16;
     const unsigned short* c1 = static_cast<const unsigned short*>(p.c1);
-    for (long long grp = (long long)blockIdx.x * 4 + wv; grp < ngroups; grp += (long long)gridDim.x * 4) {
-        const long long pixr = grp * 16 + px;
-        const bool live = pixr < npix;
-        const long long pix = live ? pixr : npix - 1;
-        const int ox = (int)(pix % p.W);
-        const int oy = (int)((pix / p.W) % p.H);
-        const int n = (int)(pix / ((long long)p.W * p.H));
-        // B operand of conv_f straight from memory: 8 channels (16 bytes) of c1, lanes kq >= 2 read the same bytes again
-        const i32x4_t bc1 = *reinterpret_cast<const i32x4_t*>(c1 + (size_t)pix * FP + 8 * (kq & 1));
-        // x in the D layout, requested before the arithmetic
-        f32x4 xv[NT];
+    const unsigned short* xs = static_cast<const unsigned short*>(p.x);
+    unsigned short* ys = static_cast<unsigned short*>(p.y);
+    const long long gstep = (long long)gridDim.x * 4;
+    bool chan_ok[NP];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            xv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (16 * t + 4 * kq < p.Cp4) xv[t] = ld4<ST>(p.x, (size_t)pix * p.x_pitch + p.x_coff + 16 * t + 4 * kq);
+    for (int q = 0; q < NP; ++q) chan_ok[q] = 32 * q + 8 * kq < p.Cp4;
+
+    // everything a group reads, requested one group ahead of its arithmetic
+    struct Grp {
+        long long pix;
+        bool live;
+        i32x4_t bc1;
+        i32x4_t xv[NP];
+        f32x4 ta, tb, tc, td;
+        float ly, lx;
+    };
+    auto fetch = [&](long long grp, Grp& g) __attribute__((always_inline)) {
+        // the 16 pixels of a group are consecutive: ONE wave-uniform 32-bit division chain per group (scalar unit), a carry per lane
+        const unsigned pix0 = (unsigned)grp * 16u;                       // npix < 2^31 (host)
+        const unsigned row0 = pix0 / (unsigned)p.W;
+        const unsigned n0 = row0 / (unsigned)p.H;
+        int ox = (int)(pix0 - row0 * (unsigned)p.W) + px;
+        int oy = (int)(row0 - n0 * (unsigned)p.H);
+        int n = (int)n0;
+        if (ox >= p.W) {                                                 // W >= 15 here: at most two wraps
+            ox -= p.W;
+            if (++oy == p.H) { oy = 0; ++n; }
+        }
+        if (ox >= p.W) {
+            ox -= p.W;
+            if (++oy == p.H) { oy = 0; ++n; }
+        }
+        const long long pixr = (long long)pix0 + px;
+        g.live = pixr < npix;
+        g.pix = pixr;
+        if (!g.live) { g.pix = npix - 1; ox = p.W - 1; oy = p.H - 1; n = p.N - 1; }
+        // B operand of conv_f straight from memory: 8 channels (16 bytes) of c1, lanes kq >= 2 read the same bytes again
+        g.bc1 = *reinterpret_cast<const i32x4_t*>(c1 + (size_t)g.pix * FP + 8 * (kq & 1));
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            g.xv[q] = i32x4_t{0, 0, 0, 0};
+            if (chan_ok[q]) g.xv[q] = *reinterpret_cast<const i32x4_t*>(xs + (size_t)g.pix * p.x_pitch + p.x_coff + 32 * q + 8 * kq);
         }
         // bilinear source coordinates: ATen area_pixel_compute_source_index, fused multiply-add (see oracle)
         float fy = fmaf((float)oy + 0.5f, p.sh, -0.5f);
         fy = fy < 0.f ? 0.f : fy;
         const int y0 = (int)fy, y1 = y0 + (y0 < p.h3 - 1 ? 1 : 0);
-        const float ly = fy - (float)y0, hy = 1.f - ly;
+        g.ly = fy - (float)y0;
         float fx = fmaf((float)ox + 0.5f, p.sw, -0.5f);
         fx = fx < 0.f ? 0.f : fx;
         const int x0 = (int)fx, x1 = x0 + (x0 < p.w3 - 1 ? 1 : 0);
-        const float lx = fx - (float)x0, hx = 1.f - lx;
+        g.lx = fx - (float)x0;
         const float* cb = p.c3 + (size_t)n * p.h3 * p.w3 * FP + kq * 4;
-        const f32x4 ta = *reinterpret_cast<const f32x4*>(cb + ((size_t)y0 * p.w3 + x0) * FP);
-        const f32x4 tb = *reinterpret_cast<const f32x4*>(cb + ((size_t)y0 * p.w3 + x1) * FP);
-        const f32x4 tc = *reinterpret_cast<const f32x4*>(cb + ((size_t)y1 * p.w3 + x0) * FP);
-        const f32x4 td = *reinterpret_cast<const f32x4*>(cb + ((size_t)y1 * p.w3 + x1) * FP);
-        f32x4 sacc = hy * (hx * ta + lx * tb) + ly * (hx * tc + lx * td) + bf4;      // same evaluation order as the VALU kernel
-        sacc = mfma_k32<ST>(a_f, bc1, sacc);
+        g.ta = *reinterpret_cast<const f32x4*>(cb + ((size_t)y0 * p.w3 + x0) * FP);
+        g.tb = *reinterpret_cast<const f32x4*>(cb + ((size_t)y0 * p.w3 + x1) * FP);
+        g.tc = *reinterpret_cast<const f32x4*>(cb + ((size_t)y1 * p.w3 + x0) * FP);
+        g.td = *reinterpret_cast<const f32x4*>(cb + ((size_t)y1 * p.w3 + x1) * FP);
+    };
+    auto sigmoid = [](float m) __attribute__((always_inline)) {
+        // 1 / (1 + 2^(-m log2 e)) on v_exp_f32 / v_rcp_f32: ~1 ulp, far below the 16-bit rounding of the stored product
+        return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * m));
+    };
+    auto finish = [&](const Grp& g) __attribute__((always_inline)) {
+        const float hy = 1.f - g.ly, hx = 1.f - g.lx;
+        f32x4 sacc = hy * (hx * g.ta + g.lx * g.tb) + g.ly * (hx * g.tc + g.lx * g.td) + bf4;      // same evaluation order as the VALU kernel
+        sacc = mfma_k32<ST>(a_f, g.bc1, sacc);
         // s -> B operand of conv4: high parts in k slots 0..3, low parts in 4..7
         unsigned short h[4], l[4];
 #pragma unroll
@@ -315,18 +367,39 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
         bs.x = (int)((unsigned)h[0] | ((unsigned)h[1] << 16)); bs.y = (int)((unsigned)h[2] | ((unsigned)h[3] << 16));
         bs.z = (int)((unsigned)l[0] | ((unsigned)l[1] << 16)); bs.w = (int)((unsigned)l[2] | ((unsigned)l[3] << 16));
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            f32x4 m = *reinterpret_cast<const f32x4*>(sbias + 16 + t * 16 + kq * 4);
-            m = mfma_k32<ST>(a_hi[t], bs, m);
-            m = mfma_k32<ST>(a_lo[t], bs, m);
-            f32x4 o;
-            o.x = xv[t].x * (1.f / (1.f + expf(-m.x)));
-            o.y = xv[t].y * (1.f / (1.f + expf(-m.y)));
-            o.z = xv[t].z * (1.f / (1.f + expf(-m.z)));
-            o.w = xv[t].w * (1.f / (1.f + expf(-m.w)));
+        for (int q = 0; q < NP; ++q) {
+            f32x4 m0 = *reinterpret_cast<const f32x4*>(sbias + 16 + (2 * q) * 16 + kq * 4);
+            f32x4 m1 = *reinterpret_cast<const f32x4*>(sbias + 16 + (2 * q + 1) * 16 + kq * 4);
+            m0 = mfma_k32<ST>(a_hi[2 * q], bs, m0);
+            m1 = mfma_k32<ST>(a_hi[2 * q + 1], bs, m1);
+            m0 = mfma_k32<ST>(a_lo[2 * q], bs, m0);
+            m1 = mfma_k32<ST>(a_lo[2 * q + 1], bs, m1);
+            const unsigned xw[4] = {(unsigned)g.xv[q].x, (unsigned)g.xv[q].y, (unsigned)g.xv[q].z, (unsigned)g.xv[q].w};
+            const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+            unsigned ow[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const float xa = from16<ST>((unsigned short)(xw[d] & 0xffffu)), xb = from16<ST>((unsigned short)(xw[d] >> 16));
+                ow[d] = (unsigned)to16<ST>(xa * sigmoid(mm[2 * d])) | ((unsigned)to16<ST>(xb * sigmoid(mm[2 * d + 1])) << 16);
+            }
             // only the store is predicated: the MFMAs above must run with every lane active (a lane supplies A / B operands)
-            if (live && 16 * t + 4 * kq < p.Cp4) st4<ST>(p.y, (size_t)pix * p.y_pitch + p.y_coff + 16 * t + 4 * kq, o);
+            if (g.live && chan_ok[q])
+                *reinterpret_cast<i32x4_t*>(ys + (size_t)g.pix * p.y_pitch + p.y_coff + 32 * q + 8 * kq) =
+                    i32x4_t{(int)ow[0], (int)ow[1], (int)ow[2], (int)ow[3]};
         }
+    };
+    long long grp = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wv);
+    if (grp >= ngroups) return;
+    Grp cur, nxt;
+    fetch(grp, cur);
+    for (;;) {
+        const long long gn = grp + gstep;
+        const bool more = gn < ngroups;                          // wave-uniform
+        if (more) fetch(gn, nxt);
+        finish(cur);
+        if (!more) break;
+        cur = nxt;
+        grp = gn;
     }
 }
 
@@ -336,12 +409,10 @@ int launch_esa_mfma(const EsaK& k, hipStream_t st)
     const long long npix = (long long)k.N * k.H * k.W;
     const long long nwg = ((npix + 15) / 16 + 3) / 4;
     const unsigned grid = (unsigned)(nwg < 4096 ? nwg : 4096);
-    const int nt = (k.Cp4 + 15) / 16;
-    switch (nt) {
+    const int np = (k.Cp4 + 31) / 32;
+    switch (np) {
         case 1: hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 1>), dim3(grid), dim3(256), 0, st, k); break;
         case 2: hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 2>), dim3(grid), dim3(256), 0, st, k); break;
-        case 3: hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 3>), dim3(grid), dim3(256), 0, st, k); break;
-        case 4: hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 4>), dim3(grid), dim3(256), 0, st, k); break;
         default: return ESR_ERR_UNSUPPORTED;
     }
     return esr_check_launch("esa_apply_mfma_kernel launch");
@@ -580,6 +651,12 @@ int esr_esa_apply_f32(const esr_esa_desc* d, void* hip_stream)
     const int cp4 = esr_round_up(d->c, 4);
     if ((d->x.pitch & 3) || (d->x.coff & 3) || d->x.coff + cp4 > d->x.pitch) return ESR_ERR_BAD_ARG;
     if ((d->y.pitch & 3) || (d->y.coff & 3) || d->y.coff + cp4 > d->y.pitch) return ESR_ERR_BAD_ARG;
+    if (d->storage != ESR_STORE_F32) {
+        // 16-bit storage moves 8 channels (16 bytes) per lane: granules of 8, padded channels are read and written as zeros
+        const int cp8 = esr_round_up(d->c, 8);
+        if ((d->x.pitch & 7) || (d->x.coff & 7) || d->x.coff + cp8 > d->x.pitch) return ESR_ERR_BAD_ARG;
+        if ((d->y.pitch & 7) || (d->y.coff & 7) || d->y.coff + cp8 > d->y.pitch) return ESR_ERR_BAD_ARG;
+    }
     EsaK k;
     k.x = d->x.ptr; k.c1 = d->c1;
     k.c3 = static_cast<const float*>(d->c3); k.wf = static_cast<const float*>(d->w0);
@@ -589,6 +666,7 @@ int esr_esa_apply_f32(const esr_esa_desc* d, void* hip_stream)
     k.sh = (float)d->h_lo / (float)d->h;      // ATen area_pixel_compute_scale: float(in) / out
     k.sw = (float)d->w_lo / (float)d->w;
     const long long npix = (long long)d->n * d->h * d->w;
+    if (npix >= 2147483647LL) return ESR_ERR_UNSUPPORTED;                 // 32-bit pixel indices inside the kernels
     const size_t lds = ((size_t)FP * FP + FP + (((size_t)FP * cp4 + cp4 + 3) & ~(size_t)3) + 16 * FP) * sizeof(float);
     const long long ngroups = (npix + 15) / 16;
     const unsigned grid = (unsigned)(ngroups < 8192 ? ngroups : 8192);        // 256 CUs x 8 blocks x 4 rounds

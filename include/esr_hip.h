@@ -124,6 +124,16 @@ typedef struct esr_conv_desc {
     esr_view post_out;
     int32_t post_cout;
     int32_t post_act;
+    /* ABI v4 -- 16-bit storage: the post 1x1 is applied to the conv's FINISHED result (activation and residual included, fp32,
+     * not rounded), post_wpacked comes from esr_pack_post_s16, out0.ptr == NULL means the conv's own result is not stored (only
+     * the chain consumes it), and a second 1x1 can be chained on the first one's result (no activation):
+     *     x' = epilogue(conv(in));  post_out = post_act(W_p . x' + b_p);  post2_out = W_q . post_out_fp32 + b_q
+     * RLFB: c3_r -> c5 -> esa.conv1 (models/team04_rlfn.py:117-121, 76).  esr_conv_post_supported() tells whether a descriptor's
+     * chain runs fused (shape variants exist for the in-scope networks); otherwise build separate ops. */
+    const void* post2_wpacked;
+    esr_view post2_out;
+    int32_t post2_cout;
+    int32_t reserved3;
 } esr_conv_desc;
 
 /* Host-side weight packer (the K10 "weight packer" of SURVEY 7.2): OIHW fp32 (the layout of every
@@ -148,6 +158,12 @@ int    esr_pack_conv_s16(const float* w_oihw, const float* bias, int cin, int co
                          int cin_phys, int compute, void* out, size_t out_bytes);
 int    esr_unpack_conv_s16(const void* packed, size_t bytes, int cin, int cout, int ksize, const int32_t* cin_map,
                            int cin_phys, int compute, float* w_oihw, float* bias);
+
+/* post-chain 1x1 weights for 16-bit storage (esr_conv_desc.post_wpacked / post2_wpacked): [cout][cin] fp32 -> MFMA images of the
+ * high and low 16-bit parts + fp32 bias */
+size_t esr_packed_post_s16_bytes(int cin, int cout);
+int    esr_pack_post_s16(const float* w_oi, const float* bias, int cin, int cout, int compute, void* out, size_t out_bytes);
+int    esr_conv_post_supported(const esr_conv_desc* d);   /* 1: the descriptor's post chain has a fused kernel that fits */
 
 int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream);
 /* Diagnostics: waves per block of the conv_f32_kernel variant esr_conv2d_f32 launches for `d` (4 = 16x16-pixel tiles,

@@ -42,6 +42,8 @@ class ConvDesc(ctypes.Structure):
         ("tail_mid_act", ctypes.c_int32), ("reserved2", ctypes.c_int32),
         ("post_wpacked", ctypes.c_void_p), ("post_out", View),
         ("post_cout", ctypes.c_int32), ("post_act", ctypes.c_int32),
+        ("post2_wpacked", ctypes.c_void_p), ("post2_out", View),
+        ("post2_cout", ctypes.c_int32), ("reserved3", ctypes.c_int32),
     ]
 
 
@@ -87,6 +89,7 @@ EXPORTS = [
     "esr_abi_version", "esr_last_hip_error", "esr_build_info",
     "esr_packed_conv_bytes", "esr_pack_conv_f32", "esr_unpack_conv_f32",
     "esr_packed_conv_s16_bytes", "esr_pack_conv_s16", "esr_unpack_conv_s16",
+    "esr_packed_post_s16_bytes", "esr_pack_post_s16", "esr_conv_post_supported",
     "esr_conv2d_f32", "esr_conv_block_waves", "esr_run_ops",
     "esr_prof_create", "esr_run_ops_profiled", "esr_prof_collect", "esr_prof_destroy",
     "esr_packed_dense_bytes", "esr_pack_dense_f32",
@@ -127,6 +130,12 @@ def lib():
     L.esr_pack_conv_s16.restype = ci
     L.esr_unpack_conv_s16.argtypes = [vp, sz, ci, ci, ci, vp, ci, ci, vp, vp]
     L.esr_unpack_conv_s16.restype = ci
+    L.esr_packed_post_s16_bytes.argtypes = [ci, ci]
+    L.esr_packed_post_s16_bytes.restype = sz
+    L.esr_pack_post_s16.argtypes = [vp, vp, ci, ci, ci, vp, sz]
+    L.esr_pack_post_s16.restype = ci
+    L.esr_conv_post_supported.argtypes = [ctypes.POINTER(ConvDesc)]
+    L.esr_conv_post_supported.restype = ci
     L.esr_conv2d_f32.argtypes = [ctypes.POINTER(ConvDesc), vp]
     L.esr_conv2d_f32.restype = ci
     L.esr_conv_block_waves.argtypes = [ctypes.POINTER(ConvDesc)]

@@ -930,7 +930,8 @@ int esr_conv_block_waves(const esr_conv_desc* d)
 
 int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
 {
-    if (!d || !d->in.ptr || !d->out0.ptr || !d->wpacked) return ESR_ERR_BAD_ARG;
+    if (!d || !d->in.ptr || !d->wpacked) return ESR_ERR_BAD_ARG;
+    if (!d->out0.ptr && !(d->post_wpacked && d->storage != ESR_STORE_F32)) return ESR_ERR_BAD_ARG;   // 16-bit post chain may consume the result alone
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->cout <= 0) return ESR_ERR_BAD_ARG;
     if (d->ksize != 1 && d->ksize != 3) return ESR_ERR_UNSUPPORTED;
     if (d->cout > 64) return ESR_ERR_UNSUPPORTED;

@@ -68,6 +68,14 @@ struct S16K {
     int out_layout;
     int tiles_x, tiles_y;
     unsigned magic_x, magic_y;   // ceil(2^32 / tiles): t / tiles == umulhi(t, magic) for t * tiles < 2^32 (0: tiles == 1)
+    // post chain (PNT1 > 0 kernels): 1x1 convolution(s) of the epilogue result, evaluated in the epilogue (esr_conv_desc.post_*)
+    const char* pw1; const char* pw2;      // esr_pack_post_s16 blobs: hi images, lo images, fp32 bias
+    char* py1; char* py2;
+    int py1_pitch, py1_coff, py2_pitch, py2_coff;
+    int p1_cout8, p2_cout8;                // channels stored (multiples of 8 / 4)
+    float p1_slope;                        // activation of post 1 as max(v, slope v)
+    int post_lo;                           // the low-part weight images are resident too (w = hi + lo)
+    int store_main;                        // 0: the conv's own result is consumed by the post chain only
 };
 
 template <bool BF16>
@@ -195,9 +203,16 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, size_t bytes)
 // zero, stores are dropped), which is what makes the count exact.
 // GRES: the launch reads a residual from HBM (its 8 NT registers exist only in these variants, which in exchange keep a
 // single set of MFMA operand fragments: they are memory-bound twice over).
-template <int NT, int KS, int NW, bool BF16, bool GRES>
+// PNT1 / PNT2: output tiles of a chain of 1x1 convolutions evaluated in the epilogue on the fp32 result tile (RLFB: c3_r -> c5 ->
+// esa.conv1, team04_rlfn.py:117-121 / :76; RFDB: c{j}_r -> c{j+1}_d, rfdn_baseline/block.py:150-160).  The D fragment of the
+// producing GEMM (lane (px, kq): 4 channels of one pixel, fp32) becomes the B operand of the next WITHOUT leaving the lane and
+// without being rounded: k slots (kq, 0..3) carry the 16-bit high parts of the four values, (kq, 4..7) their low parts, so the
+// intermediate tensor (RLFB's u, which nothing else reads) is neither stored nor quantised.
+template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 = 0>
 __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
 {
+    static_assert(PNT1 == 0 || KS == 3, "post chain: 3x3 convolutions");
+    static_assert(PNT2 == 0 || PNT1 > 0, "post 2 needs post 1");
     constexpr int HALO = KS / 2;
     constexpr int TH = TILE + 2 * HALO;          // halo tile width = LDS row pitch in pixels
     constexpr int TILE_H = 4 * NW;               // wave wv owns rows 4wv .. 4wv+3
@@ -231,7 +246,14 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         return q;
     };
     const int R = p.ring;
-    const int w_bytes = p.nchunks * W_CHUNK_BYTES;
+    const int w_main = p.nchunks * W_CHUNK_BYTES;
+    // post images: [post 1: NT k-tiles x PNT1 tiles, hi (then lo)][post 2: PNT1 k-tiles x PNT2 tiles, hi (then lo)][biases, 1 KB]
+    constexpr int P1_IMG = NT * PNT1 * 1024, P2_IMG = PNT1 * PNT2 * 1024;
+    const int plo = (PNT1 > 0 && p.post_lo) ? 2 : 1;
+    const int w_bytes = w_main + (PNT1 > 0 ? plo * (P1_IMG + P2_IMG) + 1024 : 0);
+    const char* const pimg1 = smem + w_main;
+    const char* const pimg2 = pimg1 + plo * P1_IMG;
+    float* const pbias = reinterpret_cast<float*>(smem + w_main + plo * (P1_IMG + P2_IMG));
     char* const ring = smem + w_bytes;
     char* const scr = ring + R * STAGE_BYTES + wv * SCR_WAVE;
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -311,14 +333,25 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
 
     // ---- prologue: weights (resident), the first R-1 stages ---------------------------------------------------------
     {
-        const int wpieces = w_bytes / 1024;
+        const int wpieces = w_main / 1024;
         for (int pc = wv; pc < wpieces; pc += NW)
             dma_glb16(smem_lds + (unsigned)pc * 1024u, p.wp + (size_t)pc * 1024 + lane * 16);
+        if (PNT1 > 0) {
+            // blob: hi images, lo images, bias; resident: hi (then lo when post_lo)
+            const int n1 = plo * P1_IMG / 1024, n2 = plo * P2_IMG / 1024;
+            for (int pc = wv; pc < n1; pc += NW)
+                dma_glb16(smem_lds + (unsigned)(w_main + pc * 1024), p.pw1 + (size_t)pc * 1024 + lane * 16);
+            for (int pc = wv; pc < n2; pc += NW)
+                dma_glb16(smem_lds + (unsigned)(w_main + plo * P1_IMG + pc * 1024), p.pw2 + (size_t)pc * 1024 + lane * 16);
+            if (tid < PNT1 * 16) pbias[tid] = reinterpret_cast<const float*>(p.pw1 + 2 * P1_IMG)[tid];
+            if (PNT2 > 0 && tid < PNT2 * 16) pbias[PNT1 * 16 + tid] = reinterpret_cast<const float*>(p.pw2 + 2 * P2_IMG)[tid];
+        }
     }
     cursor_tile();
     if (!lvalid) return;                 // block without tiles (grid <= ntiles: does not happen)
     for (int i = 0; i < R - 1 && lvalid; ++i) issue_stage();
     wait_vm_dyn((issued - 1) * n_my);    // the weights and stage 0 have landed
+    if (PNT1 > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the post biases written above
     __builtin_amdgcn_s_barrier();
 
     f32x4 biasv[NT];
@@ -337,7 +370,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     const int c_off = (kq >> 1) * PLANE_BYTES + ((wv * 4 + HALO) * TH + px + HALO) * 16 + (kq & 1) * 8;
 
     constexpr bool gres = GRES;
-    const int epi_stores = p.out_layout == ESR_NCHW_SHUFFLE4 ? 4 * NT : (p.split < p.cout_store ? 16 : 8);   // stores per wave and tile
+    const int epi_stores = PNT1 > 0 ? (p.store_main ? 8 : 0) + 8 + (PNT2 > 0 ? 4 : 0)
+                                    : (p.out_layout == ESR_NCHW_SHUFFLE4 ? 4 * NT : (p.split < p.cout_store ? 16 : 8));   // stores per wave and tile
     const unsigned hmask = (1u << (R - 1)) - 1u;
     unsigned hist_st = 0, hist_rs = 0;   // bit i: an epilogue's stores / a tile's residual loads were issued at the top of stage s - i
 
@@ -422,6 +456,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         for (int r = 0; r < 4; ++r) {
             const int gy = y0 + wv * 4 + r;
             uint2 pk[NT];
+            f32x4 u[PNT1 > 0 ? NT : 1];
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
                 f32x4 v = acc[tt][r];
@@ -433,6 +468,79 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                 if (GRES && qres_mode == ESR_RES_POST_ACT) v += rf;
                 pk[tt].x = pack2<BF16>(v.x, v.y);
                 pk[tt].y = pack2<BF16>(v.z, v.w);
+                if (PNT1 > 0) u[tt] = v;
+            }
+            if (PNT1 > 0) {
+                // ---- post chain on the fp32 result ---------------------------------------------------------------------
+                auto hilo = [&](f32x4 v) __attribute__((always_inline)) -> i32x4 {
+                    const unsigned h0 = pack2<BF16>(v.x, v.y), h1 = pack2<BF16>(v.z, v.w);
+                    float a, b, c, d;
+                    unpack2<BF16>(h0, a, b);
+                    unpack2<BF16>(h1, c, d);
+                    return i32x4{(int)h0, (int)h1, (int)pack2<BF16>(v.x - a, v.y - b), (int)pack2<BF16>(v.z - c, v.w - d)};
+                };
+                f32x4 d1[PNT1 > 0 ? PNT1 : 1];
+#pragma unroll
+                for (int ot = 0; ot < PNT1; ++ot) d1[ot] = *reinterpret_cast<const f32x4*>(pbias + ot * 16 + kq * 4);
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    const i32x4 bsv = hilo(u[kt]);
+#pragma unroll
+                    for (int ot = 0; ot < PNT1; ++ot) {
+                        d1[ot] = mfma32<BF16>(*reinterpret_cast<const i32x4*>(pimg1 + (kt * PNT1 + ot) * 1024 + a_off), bsv, d1[ot]);
+                        if (plo == 2)
+                            d1[ot] = mfma32<BF16>(*reinterpret_cast<const i32x4*>(pimg1 + P1_IMG + (kt * PNT1 + ot) * 1024 + a_off), bsv, d1[ot]);
+                    }
+                }
+                const float s1 = q->p1_slope;
+                uint2 pk1[PNT1 > 0 ? PNT1 : 1];
+#pragma unroll
+                for (int ot = 0; ot < PNT1; ++ot) {
+                    f32x4 v = d1[ot];
+                    v.x = fmaxf(v.x, s1 * v.x); v.y = fmaxf(v.y, s1 * v.y); v.z = fmaxf(v.z, s1 * v.z); v.w = fmaxf(v.w, s1 * v.w);
+                    d1[ot] = v;
+                    pk1[ot].x = pack2<BF16>(v.x, v.y);
+                    pk1[ot].y = pack2<BF16>(v.z, v.w);
+                }
+                // post 1 result: transposed 16-byte stores like the main output
+                {
+                    const int qp1p = q->py1_pitch, qp1c = q->py1_coff, qp1n = q->p1_cout8;
+                    const size_t p1_img = (size_t)qH * qW * qp1p * 2;
+                    const __amdgpu_buffer_rsrc_t pr1 = __builtin_amdgcn_make_buffer_rsrc(q->py1 + (size_t)n * p1_img, 0, (int)p1_img, 0x00020000);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        __builtin_amdgcn_wave_barrier();
+                        if ((px >> 3) == h) {
+#pragma unroll
+                            for (int ot = 0; ot < PNT1; ++ot) *reinterpret_cast<uint2*>(scr + (px & 7) * SCR_ROW + (ot * 16 + kq * 4) * 2) = pk1[ot];
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        const i32x4 o = *reinterpret_cast<const i32x4*>(scr + p8 * SCR_ROW + min(cb, PNT1 * 16 - 8) * 2);
+                        const int gx = x0 + 8 * h + p8;
+                        const bool in = gy < qH && gx < qW && cb < qp1n;
+                        const unsigned vo = in ? ((unsigned)(gy * qW + gx) * (unsigned)qp1p + (unsigned)(qp1c + cb)) * 2u : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b128(o, pr1, vo, 0, 0);
+                    }
+                }
+                if (PNT2 > 0) {
+                    f32x4 d2 = *reinterpret_cast<const f32x4*>(pbias + PNT1 * 16 + kq * 4);
+#pragma unroll
+                    for (int kt = 0; kt < PNT1; ++kt) {
+                        const i32x4 bsv = hilo(d1[kt]);
+                        d2 = mfma32<BF16>(*reinterpret_cast<const i32x4*>(pimg2 + kt * PNT2 * 1024 + a_off), bsv, d2);
+                        if (plo == 2) d2 = mfma32<BF16>(*reinterpret_cast<const i32x4*>(pimg2 + P2_IMG + kt * PNT2 * 1024 + a_off), bsv, d2);
+                    }
+                    // 16 channels: the D fragment as it is, 8 bytes per lane (4 channels of pixel px)
+                    const int qp2p = q->py2_pitch, qp2c = q->py2_coff, qp2n = q->p2_cout8;
+                    const size_t p2_img = (size_t)qH * qW * qp2p * 2;
+                    const __amdgpu_buffer_rsrc_t pr2 = __builtin_amdgcn_make_buffer_rsrc(q->py2 + (size_t)n * p2_img, 0, (int)p2_img, 0x00020000);
+                    const int gx = x0 + px;
+                    const bool in = gy < qH && gx < qW && kq * 4 < qp2n;
+                    const unsigned vo = in ? ((unsigned)(gy * qW + gx) * (unsigned)qp2p + (unsigned)(qp2c + kq * 4)) * 2u : OOB;
+                    typedef int i32x2 __attribute__((ext_vector_type(2)));
+                    __builtin_amdgcn_raw_buffer_store_b64(i32x2{(int)pack2<BF16>(d2.x, d2.y), (int)pack2<BF16>(d2.z, d2.w)}, pr2, vo, 0, 0);
+                }
+                if (!q->store_main) continue;
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -553,18 +661,18 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     if (pend) epilogue(pn, px0, py0, 0);
 }
 
-template <int NT, int KS, int NW, bool BF16, bool GRES>
+template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 = 0>
 int launch_s16(const S16K& k, size_t lds, hipStream_t st)
 {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<NT, KS, NW, BF16, GRES>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<NT, KS, NW, BF16, GRES, PNT1, PNT2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
         attr = true;
     }
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int grid = ntiles < 256 ? ntiles : 256;          // one block per CU (LDS), persistent over the tiles
-    hipLaunchKernelGGL((conv_s16_kernel<NT, KS, NW, BF16, GRES>), dim3(grid), dim3(64 * NW), lds, st, k);
+    hipLaunchKernelGGL((conv_s16_kernel<NT, KS, NW, BF16, GRES, PNT1, PNT2>), dim3(grid), dim3(64 * NW), lds, st, k);
     return esr_check_launch("conv_s16_kernel launch");
 }
 
@@ -586,13 +694,57 @@ int launch_s16_res(int nt, const S16K& k, size_t lds, hipStream_t st)
     return k.res_mode != ESR_RES_NONE ? launch_s16_nt<KS, BF16, true>(nt, k, lds, st) : launch_s16_nt<KS, BF16, false>(nt, k, lds, st);
 }
 
+// the post-chain variants that exist: (main tiles, residual from HBM, post-1 tiles, post-2 tiles)
+//   (3, yes, 3, 1)  RLFB  c3_r (+ block input, after the activation) -> c5 -> esa.conv1     nf = 46
+//   (4, no,  2, 0)  RFDB  c{j}_r (residual = its input, from LDS) -> c{j+1}_d               nf = 50
+//   (3, no,  2, 0)  RFDB                                                                   nf = 40
+inline bool post_variant_exists(int nt, bool gres, int pnt1, int pnt2)
+{
+    return (nt == 3 && gres && pnt1 == 3 && pnt2 == 1) || (nt == 4 && !gres && pnt1 == 2 && pnt2 == 0) ||
+           (nt == 3 && !gres && pnt1 == 2 && pnt2 == 0);
+}
+
+template <bool BF16>
+int launch_s16_post(int nt, bool gres, int pnt1, int pnt2, const S16K& k, size_t lds, hipStream_t st)
+{
+    if (nt == 3 && gres && pnt1 == 3 && pnt2 == 1) return launch_s16<3, 3, 8, BF16, true, 3, 1>(k, lds, st);
+    if (nt == 4 && !gres && pnt1 == 2 && pnt2 == 0) return launch_s16<4, 3, 8, BF16, false, 2, 0>(k, lds, st);
+    if (nt == 3 && !gres && pnt1 == 2 && pnt2 == 0) return launch_s16<3, 3, 8, BF16, false, 2, 0>(k, lds, st);
+    return ESR_ERR_UNSUPPORTED;
+}
+
 // LDS bytes of a launch: resident weights + `ring` input stages + epilogue scratch
-size_t s16_lds_bytes(int nchunks, int nt, int ksize, int nw, int ring)
+size_t s16_lds_bytes(int nchunks, int nt, int ksize, int nw, int ring, size_t post_bytes = 0)
 {
     const int halo = ksize / 2, th = TILE + 2 * halo, thy = 4 * nw + 2 * halo;
     const int ppp = (th * thy + 63) / 64;
     const int pairs = (ksize * ksize + 1) / 2;
-    return (size_t)nchunks * pairs * nt * 1024 + (size_t)ring * 2 * ppp * 1024 + (size_t)nw * SCR_WAVE;
+    return (size_t)nchunks * pairs * nt * 1024 + post_bytes + (size_t)ring * 2 * ppp * 1024 + (size_t)nw * SCR_WAVE;
+}
+
+// decides how a descriptor with a post chain runs: fills the tile counts and whether the low-part images are resident;
+// returns ESR_OK if a fused variant exists and fits the LDS
+int s16_post_plan(const esr_conv_desc* d, int nt, int nchunks, int* pnt1, int* pnt2, int* post_lo, int* ring, size_t* lds)
+{
+    if (d->ksize != 3 || d->out_layout != ESR_NHWC || (d->split > 0 && d->split < d->cout)) return ESR_ERR_UNSUPPORTED;
+    if (d->post_cout <= 0 || d->post_cout > 48) return ESR_ERR_UNSUPPORTED;
+    *pnt1 = esr_round_up(d->post_cout, 16) / 16;
+    *pnt2 = d->post2_wpacked ? 1 : 0;
+    if (*pnt2 && (d->post2_cout <= 0 || d->post2_cout > 16)) return ESR_ERR_UNSUPPORTED;
+    const bool res_is_in = d->res_mode == ESR_RES_PRE_ACT && d->cin == d->cout && d->res.ptr == d->in.ptr &&
+                           d->res.pitch == d->in.pitch && d->res.coff == d->in.coff;
+    const bool gres = d->res_mode != ESR_RES_NONE && !res_is_in;
+    if (!post_variant_exists(nt, gres, *pnt1, *pnt2)) return ESR_ERR_UNSUPPORTED;
+    for (int lo = 1; lo >= 0; --lo) {
+        const size_t pb = (size_t)(lo + 1) * (nt * *pnt1 + *pnt1 * *pnt2) * 1024 + 1024;
+        int r = RING_MAX;
+        while (r > RING_MIN && s16_lds_bytes(nchunks, nt, 3, 8, r, pb) > (size_t)LDS_LIMIT) --r;
+        if (s16_lds_bytes(nchunks, nt, 3, 8, r, pb) <= (size_t)LDS_LIMIT) {
+            *post_lo = lo; *ring = r; *lds = s16_lds_bytes(nchunks, nt, 3, 8, r, pb);
+            return ESR_OK;
+        }
+    }
+    return ESR_ERR_UNSUPPORTED;
 }
 
 inline uint16_t f32_to_bf16(float f)
@@ -690,6 +842,50 @@ int esr_pack_conv_s16(const float* w, const float* bias, int cin, int cout, int 
     return ESR_OK;
 }
 
+size_t esr_packed_post_s16_bytes(int cin, int cout)
+{
+    if (cin <= 0 || cout <= 0) return 0;
+    const size_t kt = (size_t)esr_round_up(cin, 16) / 16, ot = (size_t)esr_round_up(cout, 16) / 16;
+    return 2 * kt * ot * 1024 + ot * 16 * sizeof(float);
+}
+
+int esr_pack_post_s16(const float* w, const float* bias, int cin, int cout, int compute, void* out, size_t out_bytes)
+{
+    if (!w || !out || cin <= 0 || cout <= 0) return ESR_ERR_BAD_ARG;
+    if (compute != ESR_COMPUTE_BF16 && compute != ESR_COMPUTE_F16) return ESR_ERR_BAD_ARG;
+    const size_t need = esr_packed_post_s16_bytes(cin, cout);
+    if (out_bytes < need) return ESR_ERR_BAD_ARG;
+    const int kt = esr_round_up(cin, 16) / 16, ot = esr_round_up(cout, 16) / 16;
+    memset(out, 0, need);
+    uint16_t* hi = static_cast<uint16_t*>(out);
+    uint16_t* lo = hi + (size_t)kt * ot * 512;
+    // image [k tile][out tile][lane = kq * 16 + i][j]: input channel 16 kt + 4 kq + (j & 3) for output channel 16 ot + i; the
+    // B operand carries the high parts of the four fp32 inputs in slots 0..3 and their low parts in 4..7, so the hi image has
+    // the weight's high part in all eight slots, the lo image its low part in slots 0..3 only (lo x lo is dropped)
+    for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c) {
+            const float wv = w[(size_t)o * cin + c];
+            const uint16_t h = to16(wv, compute);
+            const uint16_t l = to16((double)wv - from16(h, compute), compute);
+            const size_t base = ((((size_t)(c / 16) * ot + o / 16) * 64 + ((c % 16) / 4) * 16 + o % 16) * 8) + (c % 4);
+            hi[base] = h;
+            hi[base + 4] = h;
+            lo[base] = l;
+        }
+    float* bo = reinterpret_cast<float*>(static_cast<char*>(out) + 2 * (size_t)kt * ot * 1024);
+    if (bias)
+        for (int o = 0; o < cout; ++o) bo[o] = bias[o];
+    return ESR_OK;
+}
+
+int esr_conv_post_supported(const esr_conv_desc* d)
+{
+    if (!d || !d->post_wpacked || (d->storage != ESR_STORE_BF16 && d->storage != ESR_STORE_F16)) return 0;
+    int a, b, c, r;
+    size_t l;
+    return s16_post_plan(d, esr_round_up(d->cout, 16) / 16, esr_round_up(d->cin, 16) / 16, &a, &b, &c, &r, &l) == ESR_OK;
+}
+
 int esr_unpack_conv_s16(const void* packed, size_t bytes, int cin, int cout, int ksize, const int32_t* cin_map, int cin_phys,
                         int compute, float* w, float* bias)
 {
@@ -726,7 +922,9 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     if (d->storage != ESR_STORE_BF16 && d->storage != ESR_STORE_F16) return ESR_ERR_BAD_ARG;
     if (d->compute != (bf16 ? ESR_COMPUTE_BF16 : ESR_COMPUTE_F16)) return ESR_ERR_BAD_ARG;   // operand type = storage type
     if (d->in_layout != ESR_NHWC) return ESR_ERR_UNSUPPORTED;                                  // the NCHW head runs on conv_f32_kernel
-    if (d->tail_wpacked || d->post_wpacked) return ESR_ERR_UNSUPPORTED;
+    if (d->tail_wpacked) return ESR_ERR_UNSUPPORTED;
+    const bool post = d->post_wpacked != nullptr;
+    if (!post && d->post2_wpacked) return ESR_ERR_BAD_ARG;
     if ((d->in.pitch & 7) || (d->in.coff & 7)) return ESR_ERR_BAD_ARG;                         // 16-byte granules
     const int cin_phys = esr_round_up(d->cin, 16);
     if (d->in.coff + cin_phys > d->in.pitch) return ESR_ERR_BAD_ARG;                           // chunk reads stay inside the pixel
@@ -738,7 +936,10 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     if (split & 7) return ESR_ERR_BAD_ARG;
     if (shuffle) {
         if (d->cout % 16 || d->res_mode != ESR_RES_NONE) return ESR_ERR_UNSUPPORTED;
+    } else if (d->out_layout == ESR_NHWC && post && !d->out0.ptr) {
+        // the conv's own result feeds the post chain only
     } else if (d->out_layout == ESR_NHWC) {
+        if (!d->out0.ptr) return ESR_ERR_BAD_ARG;
         if ((d->out0.pitch & 7) || (d->out0.coff & 7) || d->out0.coff + split > d->out0.pitch) return ESR_ERR_BAD_ARG;
         if (split < cout8 && (!d->out1.ptr || (d->out1.pitch & 7) || (d->out1.coff & 7) || d->out1.coff + (cout8 - split) > d->out1.pitch))
             return ESR_ERR_BAD_ARG;
@@ -750,13 +951,29 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     if ((double)d->h * d->w * d->in.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;   // per-image raw buffer < 2 GiB
     const int nchunks = cin_phys / 16;
     int ring = RING_MAX;                                     // as many input stages as fit next to the resident weights
-    while (ring > RING_MIN && s16_lds_bytes(nchunks, nt, d->ksize, 8, ring) > (size_t)LDS_LIMIT) --ring;
-    const size_t lds = s16_lds_bytes(nchunks, nt, d->ksize, 8, ring);
+    size_t lds = 0;
+    int pnt1 = 0, pnt2 = 0, post_lo = 0;
+    if (post) {
+        const int rc = s16_post_plan(d, nt, nchunks, &pnt1, &pnt2, &post_lo, &ring, &lds);
+        if (rc != ESR_OK) return rc;
+        const int p1c8 = esr_round_up(d->post_cout, 8);
+        if (!d->post_out.ptr || (d->post_out.pitch & 7) || (d->post_out.coff & 7) || d->post_out.coff + p1c8 > d->post_out.pitch) return ESR_ERR_BAD_ARG;
+        if ((double)d->h * d->w * d->post_out.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
+        if (pnt2) {
+            const int p2c4 = esr_round_up(d->post2_cout, 4);
+            if (!d->post2_out.ptr || (d->post2_out.pitch & 3) || (d->post2_out.coff & 3) || d->post2_out.coff + p2c4 > d->post2_out.pitch) return ESR_ERR_BAD_ARG;
+            if ((double)d->h * d->w * d->post2_out.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
+        }
+        if (d->post_act != ESR_ACT_NONE && d->post_act != ESR_ACT_LRELU && d->post_act != ESR_ACT_RELU) return ESR_ERR_UNSUPPORTED;
+    } else {
+        while (ring > RING_MIN && s16_lds_bytes(nchunks, nt, d->ksize, 8, ring) > (size_t)LDS_LIMIT) --ring;
+        lds = s16_lds_bytes(nchunks, nt, d->ksize, 8, ring);
+    }
     if (lds > (size_t)LDS_LIMIT) return ESR_ERR_UNSUPPORTED;                                     // weight set too large to stay resident
-    if (!shuffle) {
+    if (!shuffle && d->out0.ptr) {
         if ((double)d->h * d->w * d->out0.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
         if (split < cout8 && (double)d->h * d->w * d->out1.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
-    } else if ((double)d->cout * d->h * d->w * 4.0 >= 2147483647.0) {
+    } else if (shuffle && (double)d->cout * d->h * d->w * 4.0 >= 2147483647.0) {
         return ESR_ERR_UNSUPPORTED;                          // per-image raw buffers < 2 GiB (out-of-range offset 0x80000000)
     }
     if (d->res_mode != ESR_RES_NONE && (double)d->h * d->w * d->res.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
@@ -796,7 +1013,18 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         const double nt_all = (double)d->n * k.tiles_x * k.tiles_y;
         if (nt_all * (k.tiles_x > k.tiles_y ? k.tiles_x : k.tiles_y) >= 4294967296.0) return ESR_ERR_UNSUPPORTED;   // magic division range
     }
+    k.pw1 = static_cast<const char*>(d->post_wpacked); k.pw2 = static_cast<const char*>(d->post2_wpacked);
+    k.py1 = static_cast<char*>(d->post_out.ptr); k.py2 = static_cast<char*>(d->post2_out.ptr);
+    k.py1_pitch = d->post_out.pitch; k.py1_coff = d->post_out.coff; k.py2_pitch = d->post2_out.pitch; k.py2_coff = d->post2_out.coff;
+    k.p1_cout8 = esr_round_up(d->post_cout > 0 ? d->post_cout : 1, 8); k.p2_cout8 = esr_round_up(d->post2_cout > 0 ? d->post2_cout : 1, 4);
+    k.p1_slope = d->post_act == ESR_ACT_LRELU ? d->slope : (d->post_act == ESR_ACT_RELU ? 0.f : 1.f);
+    k.post_lo = post_lo;
+    k.store_main = d->out0.ptr ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (post) {
+        const bool gres = k.res_mode != ESR_RES_NONE;
+        return bf16 ? launch_s16_post<true>(nt, gres, pnt1, pnt2, k, lds, st) : launch_s16_post<false>(nt, gres, pnt1, pnt2, k, lds, st);
+    }
     if (d->ksize == 3) return bf16 ? launch_s16_res<3, true>(nt, k, lds, st) : launch_s16_res<3, false>(nt, k, lds, st);
     return bf16 ? launch_s16_res<1, true>(nt, k, lds, st) : launch_s16_res<1, false>(nt, k, lds, st);
 }

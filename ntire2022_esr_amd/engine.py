@@ -75,6 +75,20 @@ def pack_conv_s16(weight, bias, compute, cin_map=None, cin_phys=None):
     return out
 
 
+def pack_post_s16(weight, bias, compute):
+    """[cout, cin(, 1, 1)] fp32 weights of a 1x1 evaluated in a 16-bit conv's epilogue (esr_conv_desc.post_* / post2_*) ->
+    esr_pack_post_s16 blob (MFMA images of the weights' 16-bit high and low parts + fp32 bias)."""
+    lib = L.lib()
+    w = weight.detach().to("cpu", torch.float32).reshape(weight.shape[0], -1).contiguous()
+    cout, cin = w.shape
+    b = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
+    nbytes = lib.esr_packed_post_s16_bytes(cin, cout)
+    out = torch.empty((nbytes + 3) // 4, dtype=torch.float32)
+    L.check(lib.esr_pack_post_s16(_ptr(w), _ptr(b) if b is not None else None, cin, cout,
+                                  L.COMPUTE[compute] if isinstance(compute, str) else compute, _ptr(out), nbytes), "esr_pack_post_s16")
+    return out
+
+
 def unpack_conv_s16(blob, cin, cout, k, compute, cin_map=None, cin_phys=None):
     """EFFECTIVE fp32 weights (what the 16-bit kernel multiplies by) + bias of a pack_conv_s16 blob."""
     lib = L.lib()
@@ -296,6 +310,8 @@ class Plan:
             if o["dst"] is OUTPUT:
                 d.out_layout = L.NCHW_SHUFFLE4
                 out_idx.append(i)
+            elif o["dst"] is None:                                # consumed by the post chain only (out0.ptr == NULL)
+                d.out_layout = L.NHWC
             else:
                 d.out_layout = L.NHWC
                 d.out0 = self._view(o["dst"], base)
@@ -317,9 +333,17 @@ class Plan:
                 d.tail_cat_c, d.tail_cout, d.tail_mid_act = t["cat_c"], t["cout"], t.get("mid_act", L.ACT_NONE)
             t = o.get("post")
             if t is not None:
-                d.post_wpacked = ctypes.c_void_p(weights[t["w"]].data_ptr())
+                psfx = "#post" if (st and not lowres) else ""     # 16-bit storage: esr_pack_post_s16 images
+                d.post_wpacked = ctypes.c_void_p(weights[t["w"] + psfx].data_ptr())
                 d.post_out = self._view(t["dst"], base)
                 d.post_cout, d.post_act = t["cout"], t.get("act", L.ACT_NONE)
+                t2 = t.get("post2")
+                if t2 is not None:
+                    d.post2_wpacked = ctypes.c_void_p(weights[t2["w"] + psfx].data_ptr())
+                    d.post2_out = self._view(t2["dst"], base)
+                    d.post2_cout = t2["cout"]
+                if psfx and not L.lib().esr_conv_post_supported(ctypes.byref(d)):
+                    raise L.EsrError(f"{o['w']}: no fused post-chain kernel for this shape (the plan should have built separate ops)")
         return arr, in_idx, out_idx
 
 
@@ -460,6 +484,19 @@ class HipSRModel(nn.Module):
         self._plans.clear()
         self._ws_owner = None
 
+    def _post_convs(self):
+        """paths of the 1x1 convolutions evaluated in a 16-bit conv's epilogue (post / post2) in the current mode"""
+        plan = Plan(1, 32, 32, self._store())
+        self._build_plan(plan, self.in_nc)
+        out = set()
+        for o in plan.ops:
+            t = o.get("post") if o["kind"] == "conv" else None
+            if t is not None:
+                out.add(t["w"])
+                if t.get("post2") is not None:
+                    out.add(t["post2"]["w"])
+        return out
+
     def _cin_map(self, path, cin_map, store):
         """physical-slot -> logical-channel map of a conv reading a padded concat buffer; networks whose slice padding
         depends on the storage type override this"""
@@ -474,6 +511,9 @@ class HipSRModel(nn.Module):
             if path in s16:
                 packed[path + "#s16"] = pack_conv_s16(leaf.weight, leaf.bias, self._store(),
                                                       cin_map=self._cin_map(path, cin_map, self._store())).to(device)
+        for path in sorted(self._post_convs()) if self._store() != "f32" else ():
+            leaf = self._leaf(path)
+            packed[path + "#post"] = pack_post_s16(leaf.weight, leaf.bias, self._store()).to(device)
         for path, (cin_p, cout_p) in self._dense_specs.items():
             leaf = self._leaf(path)
             packed[path] = pack_dense(leaf.weight, leaf.bias, cin_p, cout_p).to(device)
@@ -611,7 +651,7 @@ class HipSRModel(nn.Module):
                 e_out = 4 if o["dst"] is OUTPUT else e_act
                 ca = o["cin_alg"]
                 rd = npix * (ca * e_in + (o["cout"] * e_act if o["res"] is not None else 0)) + 4.0 * ca * o["cout"] * o["k"] ** 2
-                wr = float(npix * o["cout"] * e_out)
+                wr = float(npix * o["cout"] * e_out) if o["dst"] is not None else 0.0
                 flops = 2.0 * npix * ca * o["cout"] * o["k"] * o["k"]
                 t = o.get("tail")
                 if t is not None:                   # 3x3 -> 1x1 in one kernel: both GEMMs' flops, the 1x1's traffic
@@ -627,6 +667,11 @@ class HipSRModel(nn.Module):
                         kern = kern[:-1] + f",POST={(t['cout'] + 15) // 16}>"
                     flops += 2.0 * npix * o["cout"] * t["cout"]
                     wr += npix * e_act * t["cout"]
+                    t2 = t.get("post2")
+                    if t2 is not None:
+                        kern = kern[:-1] + f"+{(t2['cout'] + 15) // 16}>"
+                        flops += 2.0 * npix * t["cout"] * t2["cout"]
+                        wr += npix * e_act * t2["cout"]
             elif kind == "bs":                      # pointwise (+ distillation) GEMM + depthwise, one launch
                 t = o["distill"]
                 dco = t["cout"] if t is not None else 0
@@ -700,7 +745,10 @@ class HipSRModel(nn.Module):
                         (t["cat_c"] + o["cout"], t["cout"], 1, npix, o["act"])]
             t = o.get("post")
             if t is not None:
-                return [(o["cin"], o["cout"], o["k"], npix, o["act"]), (o["cout"], t["cout"], 1, npix, t.get("act", L.ACT_NONE))]
+                r = [(o["cin"], o["cout"], o["k"], npix, o["act"]), (o["cout"], t["cout"], 1, npix, t.get("act", L.ACT_NONE))]
+                if t.get("post2") is not None:
+                    r.append((t["cout"], t["post2"]["cout"], 1, npix, L.ACT_NONE))
+                return r
             return [(o["cin"], o["cout"], o["k"], npix, o["act"])]
         if o["kind"] == "s2":
             return [(o["f"], o["f"], 3, plan.n * o["dst"].h * o["dst"].w, L.ACT_NONE)]

@@ -6,7 +6,7 @@ import ctypes
 import torch
 
 from . import _lib as L
-from .engine import pack_conv, pack_conv_s16
+from .engine import pack_conv, pack_conv_s16, pack_post_s16
 
 
 def _view(t, coff=0):
@@ -21,7 +21,7 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
            in_nchw=False, shuffle_out=False, out=None, out_coff=0, in_coff=0, cin=None,
            split=0, out1=None, out1_coff=0, res_coff=0, packed=None, cin_map=None, store=None,
            tail_weight=None, tail_bias=None, tail_cat=None, tail_cat_coff=0, tail_mid_act=L.ACT_NONE,
-           post_weight=None, post_bias=None, post_act=L.ACT_NONE):
+           post_weight=None, post_bias=None, post_act=L.ACT_NONE, post2_weight=None, post2_bias=None, store_main=True):
     """Fused conv (k=1|3, stride 1, same padding) on the current stream.
 
     x       NHWC [N,H,W,pitch] (channels [in_coff, in_coff+cin) are read) or NCHW fp32 if in_nchw.  The dtype of an NHWC
@@ -29,7 +29,9 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
             operands as stored, fp32 accumulate, one rounding at the store); res / out / out1 have the same dtype.
     store   NCHW input only: "bf16" | "f16" makes the NHWC output 16-bit (the head of a 16-bit network)
     returns NHWC [N,H,W,cout] (or `out`), or NCHW fp32 [N,cout/16,4H,4W] if shuffle_out
-    post_*  esr_conv_desc.post_*: post_weight [pc, cout(, 1, 1)] applied to this conv's activated output; returns (y, post)
+    post_*  esr_conv_desc.post_*: post_weight [pc, cout(, 1, 1)] applied to this conv's activated output; returns (y, post).
+            16-bit storage: applied to the finished fp32 result (residual included); post2_weight [pc2, pc] chains a second 1x1
+            on the first (returns (y, post, post2)); store_main=False does not store y (returns None in its place)
     tail_*  fused 1x1 (esr_conv_desc.tail_*): tail_weight [cout1, cat_c + 16(, 1, 1)] over concat(tail_cat slice,
             mid_act(this 3x3 conv)); act / res / out then apply to the 1x1, whose output is returned
     """
@@ -71,28 +73,37 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
         d.out_layout = L.NCHW_SHUFFLE4
         d.out0 = L.View(ctypes.c_void_p(y.data_ptr()), 0, 0)
     else:
-        if out is None:
-            c_store = (min(split, cout) if split else cout)
-            y = torch.zeros((n, h, w, (c_store + gran - 1) // gran * gran), dtype=odt, device=x.device)
-        else:
-            y = out
         d.out_layout = L.NHWC
-        d.out0 = _view(y, out_coff)
+        if not store_main:
+            y = None
+        else:
+            if out is None:
+                c_store = (min(split, cout) if split else cout)
+                y = torch.zeros((n, h, w, (c_store + gran - 1) // gran * gran), dtype=odt, device=x.device)
+            else:
+                y = out
+            d.out0 = _view(y, out_coff)
         if out1 is not None:
             d.out1 = _view(out1, out1_coff)
     if res is not None:
         d.res = _view(res, res_coff)
     d.wpacked = ctypes.c_void_p(packed.data_ptr())
-    yp = None
+    yp = yp2 = None
     if post_weight is not None:
         pw = post_weight if post_weight.dim() == 4 else post_weight[:, :, None, None]
-        keep2 = pack_conv(pw, post_bias).to(x.device)
-        yp = torch.zeros((n, h, w, (pw.shape[0] + 3) // 4 * 4), dtype=torch.float32, device=x.device)
+        keep2 = (pack_post_s16(pw, post_bias, st) if s16 else pack_conv(pw, post_bias)).to(x.device)
+        yp = torch.zeros((n, h, w, (pw.shape[0] + gran - 1) // gran * gran), dtype=odt, device=x.device)
         d.post_wpacked, d.post_out = ctypes.c_void_p(keep2.data_ptr()), _view(yp)
         d.post_cout, d.post_act = pw.shape[0], post_act
+        if post2_weight is not None:
+            keep3 = pack_post_s16(post2_weight, post2_bias, st).to(x.device)
+            yp2 = torch.zeros((n, h, w, (post2_weight.shape[0] + 7) // 8 * 8), dtype=odt, device=x.device)
+            d.post2_wpacked, d.post2_out, d.post2_cout = ctypes.c_void_p(keep3.data_ptr()), _view(yp2), post2_weight.shape[0]
     stream = torch.cuda.current_stream(x.device).cuda_stream
     L.check(lib.esr_conv2d_f32(ctypes.byref(d), ctypes.c_void_p(stream)), "esr_conv2d_f32")
-    return y if yp is None else (y, yp)
+    if yp is None:
+        return y
+    return (y, yp) if yp2 is None else (y, yp, yp2)
 
 
 def tensor2uint_device(img_sr, data_range):

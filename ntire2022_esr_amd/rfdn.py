@@ -85,7 +85,8 @@ class RFDN(HipSRModel):
         for k in range(1, 5):
             b = f'B{k}.'
             plan.conv(b + 'c1_d', cur, cat[0:DP], nf, dc, k=1, **act)
-            if self.compute == 'f32' and 48 < nf <= 64 and 16 < dc <= 32:
+            fused_post = (48 < nf <= 64 and 16 < dc <= 32) if plan.esize == 4 else ((nf + 15) // 16 in (3, 4) and 16 < dc <= 32)
+            if fused_post:
                 # the distillation conv of r_j rides in the epilogue of the conv that produces r_j (block.py:150-160)
                 plan.conv(b + 'c1_r', cur, r1, nf, nf, **res(cur), **act,
                           post=dict(w=b + 'c2_d', dst=cat[DP:2 * DP], cout=dc, act=L.ACT_LRELU))

@@ -72,9 +72,17 @@ class RLFN_cut(HipSRModel):
             b = f'B{k}.'
             plan.conv(b + 'c1_r', cur, t1, nf, mf, **act)
             plan.conv(b + 'c2_r', t1, t2, mf, mf, **act)
-            plan.conv(b + 'c3_r', t2, u, mf, nf, res=cur, res_mode=L.RES_POST_ACT, **act)
-            plan.conv(b + 'c5', u, v, nf, nf, k=1)
-            plan.conv(b + 'esa.conv1', v, c1, nf, f, k=1)
+            if plan.esize == 2 and (nf + 15) // 16 == 3 and f <= 16:
+                # 16-bit storage: c5 and esa.conv1 are evaluated in c3_r's epilogue on the fp32 tile (esr_conv_desc.post_* /
+                # post2_*): u = lrelu(c3_r(..)) + x (team04_rlfn.py:117-119) is never stored, never rounded -- two launches
+                # and three tensor passes less per block, and the rounding that cost RLFN bf16 most of its PSNR budget is gone
+                plan.conv(b + 'c3_r', t2, None, mf, nf, res=cur, res_mode=L.RES_POST_ACT, **act,
+                          post=dict(w=b + 'c5', dst=v, cout=nf, act=L.ACT_NONE,
+                                    post2=dict(w=b + 'esa.conv1', dst=c1, cout=f)))
+            else:
+                plan.conv(b + 'c3_r', t2, u, mf, nf, res=cur, res_mode=L.RES_POST_ACT, **act)
+                plan.conv(b + 'c5', u, v, nf, nf, k=1)
+                plan.conv(b + 'esa.conv1', v, c1, nf, f, k=1)
             plan.conv3x3s2(b + 'esa.conv2', c1, lo2, f)
             plan.maxpool7s3(lo2, lo3)
             plan.conv(b + 'esa.conv3', lo3, lo4, f, f, hw=(h3, w3))

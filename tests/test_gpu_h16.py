@@ -111,6 +111,70 @@ def test_s16_head_from_nchw_fp32(compute):
     assert torch.all(y[..., 46:] == 0)
 
 
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
+def test_s16_post_chain_rlfb(compute):
+    """RLFB tail in one launch: u = lrelu(c3_r(x)) + r (never stored), v = c5(u), c1 = esa.conv1(v): the 1x1s run on the fp32
+    tile (hi + lo operands), only v and c1 are rounded -- against fp64 with the blob's effective 3x3 weights"""
+    from ntire2022_esr_amd import ops
+    from ntire2022_esr_amd.engine import pack_conv_s16, unpack_conv_s16
+    dt = DT[compute]
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 48, 37, 29, generator=g).to(dt)
+    r = torch.randn(2, 46, 37, 29, generator=g).to(dt)
+    w, b = torch.randn(46, 48, 3, 3, generator=g) * 0.1, torch.randn(46, generator=g)
+    w5, b5 = torch.randn(46, 46, generator=g) * 0.2, torch.randn(46, generator=g)
+    w1, b1 = torch.randn(16, 46, generator=g) * 0.2, torch.randn(16, generator=g)
+    weff, _ = unpack_conv_s16(pack_conv_s16(w, b, compute), 48, 46, 3, compute)
+    u = F.leaky_relu(F.conv2d(x.double(), weff.double(), b.double(), padding=1), 0.05) + r.double()
+    v = F.conv2d(u, w5.double()[:, :, None, None], b5.double())
+    c1 = F.conv2d(v, w1.double()[:, :, None, None], b1.double())
+    rp = F.pad(_nhwc(r), (0, 2)).to(DEV)
+    y, yv, yc = ops.conv2d(_nhwc(x).to(DEV), w, b, act=1, res=rp, res_mode=2, post_weight=w5, post_bias=b5,
+                           post2_weight=w1, post2_bias=b1, store_main=False)
+    assert y is None and yv.dtype == dt and yv.shape[-1] == 48 and yc.shape[-1] == 16
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+
+    def close(got, want):
+        # one rounding of the stored value + the dropped lo x lo terms of the hi/lo split (2^-16 bf16 / 2^-22 fp16 relative)
+        tol = want.abs() * eps * 1.01 + 1e-3 * eps * 32 * max(1.0, float(want.abs().max()))
+        return bool(((got.double() - want).abs() <= tol).all())
+
+    assert close(yv.float().cpu().permute(0, 3, 1, 2)[:, :46], v)
+    assert close(yc.float().cpu().permute(0, 3, 1, 2)[:, :16], c1)
+    assert torch.all(yv[..., 46:] == 0)
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
+@pytest.mark.parametrize("nf", [50, 40])
+def test_s16_post_rfdb(compute, nf):
+    """RFDB: r = lrelu(c_r(x) + x) stored, d = lrelu(c_d(r)) from the same launch (rfdn_baseline/block.py:150-160)"""
+    from ntire2022_esr_amd import ops
+    from ntire2022_esr_amd.engine import pack_conv_s16, unpack_conv_s16
+    dt = DT[compute]
+    dc = nf // 2
+    g = torch.Generator().manual_seed(nf)
+    P = (nf + 15) // 16 * 16
+    x = torch.randn(1, nf, 45, 33, generator=g).to(dt)
+    w, b = torch.randn(nf, nf, 3, 3, generator=g) * 0.08, torch.randn(nf, generator=g)
+    wd, bd = torch.randn(dc, nf, generator=g) * 0.2, torch.randn(dc, generator=g)
+    weff, _ = unpack_conv_s16(pack_conv_s16(w, b, compute, cin_phys=P), nf, nf, 3, compute, cin_phys=P)
+    rr = F.leaky_relu(F.conv2d(x.double(), weff.double(), b.double(), padding=1) + x.double(), 0.05)
+    # nf = 50: four main tiles = 80 KB of resident 3x3 weights, the post weights' low-part images do not fit the LDS next to a
+    # three-stage ring, so the 1x1 multiplies by the 16-bit high parts only (esr_conv2d_s16: post_lo); nf = 40 keeps hi + lo
+    wd_eff = wd.to(dt).double() if nf > 48 else wd.double()
+    dd = F.leaky_relu(F.conv2d(rr, wd_eff[:, :, None, None], bd.double()), 0.05)
+    xin = F.pad(_nhwc(x), (0, P - nf)).to(DEV)
+    y, yd = ops.conv2d(xin, w, b, act=1, res=xin, res_mode=1, cin=nf, post_weight=wd, post_bias=bd, post_act=1)
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+
+    def close(got, want):
+        tol = want.abs() * eps * 1.01 + 2e-2 * eps * max(1.0, float(want.abs().max()))
+        return bool(((got.double() - want).abs() <= tol).all())
+
+    assert close(y.float().cpu().permute(0, 3, 1, 2)[:, :nf], rr)
+    assert close(yd.float().cpu().permute(0, 3, 1, 2)[:, :dc], dd)
+
+
 def test_s16_rejects_bad_descriptors():
     from ntire2022_esr_amd import _lib as L, ops
     x = torch.zeros(1, 8, 8, 24, dtype=torch.bfloat16, device=DEV)            # pitch 24 < round_up(cin, 16) = 32

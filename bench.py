@@ -267,10 +267,13 @@ def main():
         f_mfma, f_hbm = tflops / kpeak, gbs / HBM_PEAK_GBS
         traffic, traffic_src = None, None
         tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and args.sizes == "tile" and (th, tw, B) == (256, 256, 32):
+        if os.path.exists(tpath) and args.sizes == "tile":
             try:
-                traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
-                traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command on an earlier run, NOT this run)"
+                ent = json.load(open(tpath)).get(f"{args.model}:{args.compute}:{B}x{th}x{tw}", {})
+                traffic = ent.get(dom_name, {}).get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic_src = (f"profiles/pmc_traffic.json, {ent.get('_round', '?')}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                   "passes of this command on an EARLIER run (tools/pmc_traffic.py), not measured in this run")
             except Exception:
                 traffic = None
         if f_mfma >= f_hbm:

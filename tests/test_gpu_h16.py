@@ -56,8 +56,11 @@ def test_s16_conv_matches_fp64_reference(compute, cin, cout, k, hw, act, res_mod
     y = ops.conv2d(xin, w, b, act=act, res=rp, res_mode=res_mode, cin=cin, packed=blob.to(DEV))
     assert y.dtype == dt and y.shape[-1] == (cout + 7) // 8 * 8
     got = y.float().cpu().permute(0, 3, 1, 2)
-    ok, worst = _ulp_ok(got[:, :cout], ref, dt)
-    assert ok, worst
+    if act == 3:            # GELU in the 16-bit modes is gelu16(): |error| <= 1.3e-4 (tools/fit_gelu.py) on top of the rounding
+        assert bool(((got[:, :cout].double() - ref).abs() <= ref.abs() * 2.0 ** (-8 if dt == torch.bfloat16 else -11) * 1.01 + 2.5e-4).all())
+    else:
+        ok, worst = _ulp_ok(got[:, :cout], ref, dt)
+        assert ok, worst
     assert torch.all(got[:, cout:] == 0)                    # pad channels of the 16-byte granule are written as zeros
 
 

@@ -100,8 +100,13 @@ class BSRN(HipSRModel):
                 plan.bsconv(b + f'c{j}_r.pw', b + f'c{j}_r.dw', rin, rout, C, C, res=rin, res_mode=L.RES_PRE_ACT,
                             distill=dict(w=b + f'c{j}_d', dst=cat[(j - 1) * dc:j * dc], cout=dc, act=L.ACT_GELU), **g)
             plan.bsconv(b + 'c4.pw', b + 'c4.dw', r1, cat[3 * dc:4 * dc], C, dc, **g)
-            plan.conv(b + 'c5', cat, v, 4 * dc, C, k=1, counted=False)
-            plan.conv(b + 'esa.conv1', v, c1, C, f, k=1, counted=False)
+            if plan.esize == 2 and (C + 15) // 16 in (3, 4) and f <= 16:
+                # 16-bit storage: esa.conv1 rides in c5's epilogue on the fp32 tile (one launch less per block)
+                plan.conv(b + 'c5', cat, v, 4 * dc, C, k=1, counted=False,
+                          post=dict(w=b + 'esa.conv1', dst=c1, cout=f, act=L.ACT_NONE))
+            else:
+                plan.conv(b + 'c5', cat, v, 4 * dc, C, k=1, counted=False)
+                plan.conv(b + 'esa.conv1', v, c1, C, f, k=1, counted=False)
             plan.conv3x3s2(b + 'esa.conv2', c1, lo2, f)
             plan.maxpool7s3(lo2, la)
             plan.conv(b + 'esa.conv_max.pw', la, lt, f, f, k=1, hw=lo, counted=False)

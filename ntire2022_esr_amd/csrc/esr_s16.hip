@@ -218,7 +218,6 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, size_t bytes)
 template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 = 0>
 __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
 {
-    static_assert(PNT1 == 0 || KS == 3, "post chain: 3x3 convolutions");
     static_assert(PNT2 == 0 || PNT1 > 0, "post 2 needs post 1");
     constexpr int HALO = KS / 2;
     constexpr int TH = TILE + 2 * HALO;          // halo tile width = LDS row pitch in pixels
@@ -701,19 +700,27 @@ int launch_s16_res(int nt, const S16K& k, size_t lds, hipStream_t st)
     return k.res_mode != ESR_RES_NONE ? launch_s16_nt<KS, BF16, true>(nt, k, lds, st) : launch_s16_nt<KS, BF16, false>(nt, k, lds, st);
 }
 
-// the post-chain variants that exist: (main tiles, residual from HBM, post-1 tiles, post-2 tiles)
-//   (3, yes, 3, 1)  RLFB  c3_r (+ block input, after the activation) -> c5 -> esa.conv1     nf = 46
-//   (4, no,  2, 0)  RFDB  c{j}_r (residual = its input, from LDS) -> c{j+1}_d               nf = 50
-//   (3, no,  2, 0)  RFDB                                                                   nf = 40
-inline bool post_variant_exists(int nt, bool gres, int pnt1, int pnt2)
+// the post-chain variants that exist: (kernel size, main tiles, residual from HBM, post-1 tiles, post-2 tiles)
+//   (3, 3, yes, 3, 1)  RLFB  c3_r (+ block input, after the activation) -> c5 -> esa.conv1     nf = 46
+//   (3, 4, no,  2, 0)  RFDB  c{j}_r (residual = its input, from LDS) -> c{j+1}_d               nf = 50
+//   (3, 3, no,  2, 0)  RFDB                                                                   nf = 40
+//   (1, 3 | 4, no, 1, 0)  c5 (the 1x1 over the distillation concat) -> esa.conv1: BSRN / RFDN (team18_bsrn.py:167,110;
+//                         rfdn_baseline/block.py:164,118)
+inline bool post_variant_exists(int ks, int nt, bool gres, int pnt1, int pnt2)
 {
+    if (ks == 1) return (nt == 3 || nt == 4) && !gres && pnt1 == 1 && pnt2 == 0;
     return (nt == 3 && gres && pnt1 == 3 && pnt2 == 1) || (nt == 4 && !gres && pnt1 == 2 && pnt2 == 0) ||
            (nt == 3 && !gres && pnt1 == 2 && pnt2 == 0);
 }
 
 template <bool BF16>
-int launch_s16_post(int nt, bool gres, int pnt1, int pnt2, const S16K& k, size_t lds, hipStream_t st)
+int launch_s16_post(int ks, int nt, bool gres, int pnt1, int pnt2, const S16K& k, size_t lds, hipStream_t st)
 {
+    if (ks == 1) {
+        if (nt == 3 && !gres && pnt1 == 1 && pnt2 == 0) return launch_s16<3, 1, 8, BF16, false, 1, 0>(k, lds, st);
+        if (nt == 4 && !gres && pnt1 == 1 && pnt2 == 0) return launch_s16<4, 1, 8, BF16, false, 1, 0>(k, lds, st);
+        return ESR_ERR_UNSUPPORTED;
+    }
     if (nt == 3 && gres && pnt1 == 3 && pnt2 == 1) return launch_s16<3, 3, 8, BF16, true, 3, 1>(k, lds, st);
     if (nt == 4 && !gres && pnt1 == 2 && pnt2 == 0) return launch_s16<4, 3, 8, BF16, false, 2, 0>(k, lds, st);
     if (nt == 3 && !gres && pnt1 == 2 && pnt2 == 0) return launch_s16<3, 3, 8, BF16, false, 2, 0>(k, lds, st);
@@ -733,7 +740,7 @@ size_t s16_lds_bytes(int nchunks, int nt, int ksize, int nw, int ring, size_t po
 // returns ESR_OK if a fused variant exists and fits the LDS
 int s16_post_plan(const esr_conv_desc* d, int nt, int nchunks, int* pnt1, int* pnt2, int* post_lo, int* ring, size_t* lds)
 {
-    if (d->ksize != 3 || d->out_layout != ESR_NHWC || (d->split > 0 && d->split < d->cout)) return ESR_ERR_UNSUPPORTED;
+    if (d->out_layout != ESR_NHWC || (d->split > 0 && d->split < d->cout)) return ESR_ERR_UNSUPPORTED;
     if (d->post_cout <= 0 || d->post_cout > 48) return ESR_ERR_UNSUPPORTED;
     *pnt1 = esr_round_up(d->post_cout, 16) / 16;
     *pnt2 = d->post2_wpacked ? 1 : 0;
@@ -741,13 +748,13 @@ int s16_post_plan(const esr_conv_desc* d, int nt, int nchunks, int* pnt1, int* p
     const bool res_is_in = d->res_mode == ESR_RES_PRE_ACT && d->cin == d->cout && d->res.ptr == d->in.ptr &&
                            d->res.pitch == d->in.pitch && d->res.coff == d->in.coff;
     const bool gres = d->res_mode != ESR_RES_NONE && !res_is_in;
-    if (!post_variant_exists(nt, gres, *pnt1, *pnt2)) return ESR_ERR_UNSUPPORTED;
+    if (!post_variant_exists(d->ksize, nt, gres, *pnt1, *pnt2)) return ESR_ERR_UNSUPPORTED;
     for (int lo = 1; lo >= 0; --lo) {
         const size_t pb = (size_t)(lo + 1) * (nt * *pnt1 + *pnt1 * *pnt2) * 1024 + 1024;
         int r = RING_MAX;
-        while (r > RING_MIN && s16_lds_bytes(nchunks, nt, 3, 8, r, pb) > (size_t)LDS_LIMIT) --r;
-        if (s16_lds_bytes(nchunks, nt, 3, 8, r, pb) <= (size_t)LDS_LIMIT) {
-            *post_lo = lo; *ring = r; *lds = s16_lds_bytes(nchunks, nt, 3, 8, r, pb);
+        while (r > RING_MIN && s16_lds_bytes(nchunks, nt, d->ksize, 8, r, pb) > (size_t)LDS_LIMIT) --r;
+        if (s16_lds_bytes(nchunks, nt, d->ksize, 8, r, pb) <= (size_t)LDS_LIMIT) {
+            *post_lo = lo; *ring = r; *lds = s16_lds_bytes(nchunks, nt, d->ksize, 8, r, pb);
             return ESR_OK;
         }
     }
@@ -1030,7 +1037,8 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     if (post) {
         const bool gres = k.res_mode != ESR_RES_NONE;
-        return bf16 ? launch_s16_post<true>(nt, gres, pnt1, pnt2, k, lds, st) : launch_s16_post<false>(nt, gres, pnt1, pnt2, k, lds, st);
+        return bf16 ? launch_s16_post<true>(d->ksize, nt, gres, pnt1, pnt2, k, lds, st)
+                    : launch_s16_post<false>(d->ksize, nt, gres, pnt1, pnt2, k, lds, st);
     }
     if (d->ksize == 3) return bf16 ? launch_s16_res<3, true>(nt, k, lds, st) : launch_s16_res<3, false>(nt, k, lds, st);
     return bf16 ? launch_s16_res<1, true>(nt, k, lds, st) : launch_s16_res<1, false>(nt, k, lds, st);

@@ -99,8 +99,12 @@ class RFDN(HipSRModel):
                 plan.conv(b + 'c3_d', r2, cat[2 * DP:3 * DP], nf, dc, k=1, **act)
             plan.conv(b + 'c3_r', r2, r1, nf, nf, **res(r2), **act)
             plan.conv(b + 'c4', r1, cat[3 * DP:4 * DP], nf, dc, **act)
-            plan.conv(b + 'c5', cat, v, 4 * DP, nf, k=1, cin_alg=4 * dc)
-            plan.conv(b + 'esa.conv1', v, c1, nf, f, k=1)
+            if plan.esize == 2 and (nf + 15) // 16 in (3, 4) and f <= 16:
+                # 16-bit storage: esa.conv1 rides in c5's epilogue on the fp32 tile (one launch less per block)
+                plan.conv(b + 'c5', cat, v, 4 * DP, nf, k=1, cin_alg=4 * dc, post=dict(w=b + 'esa.conv1', dst=c1, cout=f, act=L.ACT_NONE))
+            else:
+                plan.conv(b + 'c5', cat, v, 4 * DP, nf, k=1, cin_alg=4 * dc)
+                plan.conv(b + 'esa.conv1', v, c1, nf, f, k=1)
             plan.conv3x3s2(b + 'esa.conv2', c1, lo2, f)
             plan.maxpool7s3(lo2, la)
             plan.conv(b + 'esa.conv_max', la, lb, f, f, act=L.ACT_RELU, **lo)

@@ -407,8 +407,11 @@ template <int ST>
 int launch_esa_mfma(const EsaK& k, hipStream_t st)
 {
     const long long npix = (long long)k.N * k.H * k.W;
-    const long long nwg = ((npix + 15) / 16 + 3) / 4;
-    const unsigned grid = (unsigned)(nwg < 4096 ? nwg : 4096);
+    // every block first builds the MFMA weight images (~2 us): give each wave at least ~4 pixel groups of work
+    const long long ngroups = (npix + 15) / 16;
+    long long nwg = (ngroups + 15) / 16;
+    nwg = nwg < 1 ? 1 : (nwg > 4096 ? 4096 : nwg);
+    const unsigned grid = (unsigned)nwg;
     const int np = (k.Cp4 + 31) / 32;
     switch (np) {
         case 1: hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 1>), dim3(grid), dim3(256), 0, st, k); break;

@@ -45,6 +45,10 @@ constexpr int SCR_PIX = 8;          // pixels per transposed half row
 constexpr int SCR_WAVE = SCR_PIX * SCR_ROW;
 constexpr unsigned OOB = 0x80000000u;
 constexpr int LDS_LIMIT = 160 * 1024;
+#ifndef ESR_S16_NW
+#define ESR_S16_NW 8
+#endif
+constexpr int S16_NW = ESR_S16_NW;     // waves per tile
 
 struct S16K {
     const char* x;        // NHWC 16-bit input
@@ -147,7 +151,11 @@ template <bool GELU>
 __device__ __forceinline__ float act1(float v, float slope)
 {
     if (GELU) return gelu16(v);
-    return fmaxf(v, slope * v);
+    // asm: fmaxf() on an MFMA result costs a second v_max (hipcc canonicalises the operand first)
+    float r;
+    const float sv = slope * v;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(sv));
+    return r;
 }
 
 // LDS-DMA: every lane moves 16 bytes from (buffer base + voff + soff) to LDS byte (lds_dst + lane * 16); an out-of-range
@@ -221,18 +229,18 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     static_assert(PNT2 == 0 || PNT1 > 0, "post 2 needs post 1");
     constexpr int HALO = KS / 2;
     constexpr int TH = TILE + 2 * HALO;          // halo tile width = LDS row pitch in pixels
-    constexpr int TILE_H = 4 * NW;               // wave wv owns rows 4wv .. 4wv+3
+    constexpr int TILE_H = 32;                   // tile height; wave wv owns rows RW wv .. RW wv + RW-1
+    constexpr int RW = TILE_H / NW;              // rows per wave: 4 (8 waves) or 2 (16 waves: 4 per SIMD hide each other's LDS / issue stalls)
+    static_assert(NW == 8 || NW == 16, "8 or 16 waves per tile");
     constexpr int THY = TILE_H + 2 * HALO;
     constexpr int NPX = TH * THY;
-    constexpr int PPP = (NPX + 63) / 64;         // 1 KB DMA pieces per channel-half plane
-    constexpr int PLANE_BYTES = PPP * 1024;      // multiple of 256: a tap shift moves all lanes of a ds_read_b128 alike
-    constexpr int STAGE_BYTES = 2 * PLANE_BYTES; // [half][halo pixel][8 channels]
-    constexpr int NPIECES = 2 * PPP;
+    constexpr int NPIECES = (NPX + 31) / 32;     // 1 KB DMA pieces: 32 halo pixels x 32 bytes (lane pair = the 16 channels of a pixel)
+    constexpr int STAGE_BYTES = NPIECES * 1024;  // [halo pixel][half][8 channels]
     constexpr int PPW = (NPIECES + NW - 1) / NW; // pieces per wave and stage (waves >= NPIECES % NW: one fewer)
     constexpr int TAPS = KS * KS;
     constexpr int PAIRS = (TAPS + 1) / 2;
     constexpr int W_CHUNK_BYTES = PAIRS * NT * 1024;   // [pair][tile][lane][16 B]
-    constexpr int RES_LOADS = NT * 4;            // residual loads per wave and tile (8 bytes per lane each)
+    constexpr int RES_LOADS = NT * RW;           // residual loads per wave and tile (8 bytes per lane each)
 
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
@@ -289,7 +297,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     };
 
     // ---- load cursor: the (tile, chunk) stage requested next ---------------------------------------------------------
-    // piece pc = wv + NW * r of a stage: plane pc / PPP, items (pc % PPP) * 64 + lane of that plane
+    // piece pc = wv + NW * r of a stage: halo pixels 32 pc + (lane >> 1), channel half lane & 1 -- a lane PAIR reads the 32
+    // contiguous bytes of a pixel's chunk (32-byte runs cost the memory pipe 12 % less than 16-byte ones: tools/abl nomfma_r*)
     const int n_my = (NPIECES % NW == 0 || wv < NPIECES % NW) ? PPW : PPW - 1;     // wave-uniform
     int lk = 0;                   // tile iteration of the cursor
     int lc = 0;                   // chunk of the cursor
@@ -311,8 +320,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
 #pragma unroll
         for (int r = 0; r < PPW; ++r) {
             const int pc = wv + NW * r;
-            const int plane = pc / PPP;
-            const int pl = (pc - plane * PPP) * 64 + lane;
+            const int plane = lane & 1;                       // channel half
+            const int pl = pc * 32 + (lane >> 1);
             const int ly = pl / TH, lx = pl - ly * TH;
             const int gy = y0 - HALO + ly, gx = x0 - HALO + lx;
             const bool ok = pc < NPIECES && pl < NPX && (unsigned)gy < (unsigned)qH && (unsigned)gx < (unsigned)qW;
@@ -369,24 +378,24 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
 #pragma unroll
     for (int q = 0; q < PAIRS; ++q) {
         const int tap = min(2 * q + (kq >> 1), TAPS - 1);
-        b_off[q] = (kq & 1) * PLANE_BYTES + (((wv * 4) + tap / KS) * TH + px + tap % KS) * 16;
+        b_off[q] = (((wv * RW) + tap / KS) * TH + px + tap % KS) * 32 + (kq & 1) * 16;
     }
     const int a_off = lane * 16;
     // the centre pixel of this lane's accumulator rows in the staged tile: channels 16c + 4kq .. +3 of chunk c
-    const int c_off = (kq >> 1) * PLANE_BYTES + ((wv * 4 + HALO) * TH + px + HALO) * 16 + (kq & 1) * 8;
+    const int c_off = ((wv * RW + HALO) * TH + px + HALO) * 32 + (kq >> 1) * 16 + (kq & 1) * 8;
 
     constexpr bool gres = GRES;
-    const int epi_stores = PNT1 > 0 ? (p.store_main ? 8 : 0) + 8 + (PNT2 > 0 ? 4 : 0)
-                                    : (p.out_layout == ESR_NCHW_SHUFFLE4 ? 4 * NT : (p.split < p.cout_store ? 16 : 8));   // stores per wave and tile
+    const int epi_stores = PNT1 > 0 ? (p.store_main ? 2 * RW : 0) + 2 * RW + (PNT2 > 0 ? RW : 0)
+                                    : (p.out_layout == ESR_NCHW_SHUFFLE4 ? RW * NT : (p.split < p.cout_store ? 4 * RW : 2 * RW));   // stores per wave and tile
     const unsigned hmask = (1u << (R - 1)) - 1u;
     unsigned hist_st = 0, hist_rs = 0;   // bit i: an epilogue's stores / a tile's residual loads were issued at the top of stage s - i
 
-    f32x4 acc[NT][4];
-    uint2 rv[GRES ? NT : 1][4];          // residual of the current tile in D-fragment layout (hidden asm loads)
+    f32x4 acc[NT][RW];
+    uint2 rv[GRES ? NT : 1][RW];         // residual of the current tile in D-fragment layout (hidden asm loads)
 #pragma unroll
     for (int tt = 0; tt < (GRES ? NT : 1); ++tt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rv[tt][r] = uint2{0u, 0u};
+        for (int r = 0; r < RW; ++r) rv[tt][r] = uint2{0u, 0u};
 
     auto load_residual = [&](int n, int x0, int y0) __attribute__((always_inline)) {
         if (!GRES) return;
@@ -397,15 +406,16 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         i32x4 rru;
         rru.x = __builtin_amdgcn_readfirstlane(rr.x); rru.y = __builtin_amdgcn_readfirstlane(rr.y);
         rru.z = __builtin_amdgcn_readfirstlane(rr.z); rru.w = __builtin_amdgcn_readfirstlane(rr.w);
-        const int gx = x0 + px;
+        // rows below the image fall past num_records and read zeros; one add per row, one per channel tile
+        const unsigned rbase = (unsigned)((y0 + wv * RW) * qW + x0) * (unsigned)qrp * 2u + (__umul24(px, qrp) + (unsigned)(qrc + kq * 4)) * 2u;
+        const unsigned rowb = (unsigned)qW * (unsigned)qrp * 2u;
+        const bool inx = x0 + px < qW;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gy = y0 + wv * 4 + r;
+        for (int r = 0; r < RW; ++r) {
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
                 const int cb = tt * 16 + kq * 4;
-                const bool ok = gy < qH && gx < qW && cb < qcs;
-                const unsigned vo = ok ? (unsigned)((gy * qW + gx) * qrp + qrc + cb) * 2u : OOB;
+                const unsigned vo = (inx && cb < qcs) ? rbase + (unsigned)r * rowb + (unsigned)tt * 32u : OOB;
                 asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(rv[GRES ? tt : 0][r]) : "v"(vo), "s"(rru) : "memory");
             }
         }
@@ -424,7 +434,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
 #pragma unroll
             for (int tt = 0; tt < (GRES ? NT : 1); ++tt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(rv[tt][r]));      // uses below stay behind the wait
+                for (int r = 0; r < RW; ++r) asm volatile("" : "+v"(rv[tt][r]));      // uses below stay behind the wait
         }
         if (shuffle) {
             // out[n, t, 4gy + kq, 4gx + 0..3] = channel 16t + 4kq + j: the D fragment is one dwordx4 of 4 adjacent HR pixels
@@ -433,8 +443,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
             const size_t y0_img = (size_t)qcs * qH * qW * 4;                 // NCHW fp32: cout / 16 planes of 4H x 4W
             const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(q->y0 + (size_t)n * y0_img, 0, (int)y0_img, 0x00020000);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gy = y0 + wv * 4 + r;
+            for (int r = 0; r < RW; ++r) {
+                const int gy = y0 + wv * RW + r;
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
                     const bool ok = gy < qH && gx < qW && tt * 16 + kq * 4 < qcs;
@@ -458,9 +468,20 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         const size_t y0_img = (size_t)qH * qW * qy0p * 2, y1_img = (size_t)qH * qW * qy1p * 2;
         const __amdgpu_buffer_rsrc_t yr0 = __builtin_amdgcn_make_buffer_rsrc(q->y0 + (size_t)n * y0_img, 0, (int)y0_img, 0x00020000);
         const __amdgpu_buffer_rsrc_t yr1 = __builtin_amdgcn_make_buffer_rsrc(q->y1 + (size_t)n * y1_img, 0, (int)y1_img, 0x00020000);
+        // store addressing: one lane-constant byte offset per half row h (lanes right of the image or beyond the stored channels:
+        // OOB); a row step is ONE add, and rows below the image fall past num_records (= the image's bytes), so the hardware
+        // drops them -- no per-store multiply / compare / select (they were a third of the epilogue's VALU work)
+        const unsigned srow = (unsigned)((y0 + wv * RW) * qW + x0);              // wave-uniform: pixel of (r = 0, h = 0, p8 = 0)
+        const unsigned rowb0 = (unsigned)qW * (unsigned)qy0p * 2u, rowb1 = (unsigned)qW * (unsigned)qy1p * 2u;
+        unsigned vb0[2], vb1[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gy = y0 + wv * 4 + r;
+        for (int h = 0; h < 2; ++h) {
+            const bool inx = x0 + 8 * h + p8 < qW;
+            vb0[h] = (inx && ch0) ? (srow + 8u * h) * (unsigned)qy0p * 2u + (__umul24(p8, qy0p) + (unsigned)(qy0c + cb)) * 2u : OOB;
+            vb1[h] = (has_split && inx && ch1) ? (srow + 8u * h) * (unsigned)qy1p * 2u + (__umul24(p8, qy1p) + (unsigned)(qy1c + cb - qsplit)) * 2u : OOB;
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
             uint2 pk[NT];
             f32x4 u[PNT1 > 0 ? NT : 1];
 #pragma unroll
@@ -513,6 +534,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                     const int qp1p = q->py1_pitch, qp1c = q->py1_coff, qp1n = q->p1_cout8;
                     const size_t p1_img = (size_t)qH * qW * qp1p * 2;
                     const __amdgpu_buffer_rsrc_t pr1 = __builtin_amdgcn_make_buffer_rsrc(q->py1 + (size_t)n * p1_img, 0, (int)p1_img, 0x00020000);
+                    const unsigned rowbp = (unsigned)qW * (unsigned)qp1p * 2u;
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         __builtin_amdgcn_wave_barrier();
@@ -522,9 +544,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                         }
                         __builtin_amdgcn_wave_barrier();
                         const i32x4 o = *reinterpret_cast<const i32x4*>(scr + p8 * SCR_ROW + min(cb, PNT1 * 16 - 8) * 2);
-                        const int gx = x0 + 8 * h + p8;
-                        const bool in = gy < qH && gx < qW && cb < qp1n;
-                        const unsigned vo = in ? ((unsigned)(gy * qW + gx) * (unsigned)qp1p + (unsigned)(qp1c + cb)) * 2u : OOB;
+                        const bool in = x0 + 8 * h + p8 < qW && cb < qp1n;
+                        const unsigned vo = in ? (srow + 8u * h) * (unsigned)qp1p * 2u + (__umul24(p8, qp1p) + (unsigned)(qp1c + cb)) * 2u +
+                                                     (unsigned)r * rowbp : OOB;
                         __builtin_amdgcn_raw_buffer_store_b128(o, pr1, vo, 0, 0);
                     }
                 }
@@ -540,9 +562,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                     const int qp2p = q->py2_pitch, qp2c = q->py2_coff, qp2n = q->p2_cout8;
                     const size_t p2_img = (size_t)qH * qW * qp2p * 2;
                     const __amdgpu_buffer_rsrc_t pr2 = __builtin_amdgcn_make_buffer_rsrc(q->py2 + (size_t)n * p2_img, 0, (int)p2_img, 0x00020000);
-                    const int gx = x0 + px;
-                    const bool in = gy < qH && gx < qW && kq * 4 < qp2n;
-                    const unsigned vo = in ? ((unsigned)(gy * qW + gx) * (unsigned)qp2p + (unsigned)(qp2c + kq * 4)) * 2u : OOB;
+                    const bool in = x0 + px < qW && kq * 4 < qp2n;
+                    const unsigned vo = in ? (srow + (unsigned)r * (unsigned)qW) * (unsigned)qp2p * 2u + (__umul24(px, qp2p) + (unsigned)(qp2c + kq * 4)) * 2u : OOB;
                     typedef int i32x2 __attribute__((ext_vector_type(2)));
                     __builtin_amdgcn_raw_buffer_store_b64(i32x2{(int)pack2<BF16>(d2.x, d2.y), (int)pack2<BF16>(d2.z, d2.w)}, pr2, vo, 0, 0);
                 }
@@ -557,15 +578,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                 }
                 __builtin_amdgcn_wave_barrier();
                 const i32x4 o = *reinterpret_cast<const i32x4*>(scr + p8 * SCR_ROW + min(cb, NT * 16 - 8) * 2);
-                const int gx = x0 + 8 * h + p8;
-                const bool in = gy < qH && gx < qW;
-                const unsigned pix = (unsigned)(gy * qW + gx);
-                const unsigned vo0 = (in && ch0) ? (pix * (unsigned)qy0p + (unsigned)(qy0c + cb)) * 2u : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(o, yr0, vo0, 0, 0);
-                if (has_split) {
-                    const unsigned vo1 = (in && ch1) ? (pix * (unsigned)qy1p + (unsigned)(qy1c + cb - qsplit)) * 2u : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(o, yr1, vo1, 0, 0);
-                }
+                __builtin_amdgcn_raw_buffer_store_b128(o, yr0, vb0[h] + (unsigned)r * rowb0, 0, 0);
+                if (has_split) __builtin_amdgcn_raw_buffer_store_b128(o, yr1, vb1[h] + (unsigned)r * rowb1, 0, 0);
             }
         }
     };
@@ -580,11 +594,15 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     bool pend = false;                   // a finished tile waits for its epilogue
     int pn = 0, px0 = 0, py0 = 0;
     for (int k = 0;; ++k) {
+        // the iteration behind the block's last tile only drains the pending epilogue: ONE copy of the epilogue in the
+        // code (a second call site behind the loop was 7 KB of cold instruction fetches at the end of every block)
         const int t = tile_index(k);
-        if (t < 0) break;
-        int n, x0, y0;
-        tile_coords(t, n, x0, y0);
-        for (int c = 0; c < p.nchunks; ++c, ++s) {
+        const bool have = t >= 0;
+        if (!have && !pend) break;
+        int n = 0, x0 = 0, y0 = 0;
+        if (have) tile_coords(t, n, x0, y0);
+        const int nst = have ? p.nchunks : 1;
+        for (int c = 0; c < nst; ++c, ++s) {
             // ---- top of stage s -----------------------------------------------------------------------------------
             int dma_now = 0;
             if (lvalid) {
@@ -600,6 +618,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                     pend = false;
                 }
             }
+            if (!have) break;
             if (gres && c == p.nchunks - 1) {
                 load_residual(n, x0, y0);
                 hist_rs |= 1u;
@@ -608,13 +627,13 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
             const char* sb = ring + slot * STAGE_BYTES;
             const char* wc = smem + c * W_CHUNK_BYTES + a_off;
 
-            constexpr int NBUF = GRES ? 1 : 2;               // fragment sets: the read of pair q+1 runs under the MFMAs of pair q
-            i32x4 a[NBUF][NT], b[NBUF][4];
+            constexpr int NBUF = (GRES || NW == 16) ? 1 : 2;               // fragment sets: the read of pair q+1 runs under the MFMAs of pair q
+            i32x4 a[NBUF][NT], b[NBUF][RW];
             auto load_frag = [&](int buf, int q) {
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) a[buf][tt] = *reinterpret_cast<const i32x4*>(wc + (q * NT + tt) * 1024);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) b[buf][r] = *reinterpret_cast<const i32x4*>(sb + b_off[q] + r * (TH * 16));
+                for (int r = 0; r < RW; ++r) b[buf][r] = *reinterpret_cast<const i32x4*>(sb + b_off[q] + r * (TH * 32));
             };
             if (NBUF == 2) load_frag(0, 0);
 #pragma unroll
@@ -631,13 +650,13 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
+                        for (int r = 0; r < RW; ++r)
                             acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], biasv[tt]);
                 } else {
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], acc[tt][r]);
+                        for (int r = 0; r < RW; ++r) acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], acc[tt][r]);
                 }
             }
             if (KS == 3 && p.res_in) {
@@ -647,8 +666,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                 for (int tt = 0; tt < NT; ++tt)
                     if (tt == c) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            acc[tt][r] += unpack4<BF16>(*reinterpret_cast<const uint2*>(sb + c_off + r * (TH * 16)));
+                        for (int r = 0; r < RW; ++r)
+                            acc[tt][r] += unpack4<BF16>(*reinterpret_cast<const uint2*>(sb + c_off + r * (TH * 32)));
                     }
             }
             // ---- sync: stage s+1 has landed; everything issued after its DMA may stay in flight -------------------------
@@ -661,10 +680,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
             }
             slot = slot == R - 1 ? 0 : slot + 1;
         }
+        if (!have) break;
         pend = true;
         pn = n; px0 = x0; py0 = y0;
     }
-    if (pend) epilogue(pn, px0, py0, 0);
 }
 
 template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 = 0>
@@ -686,10 +705,10 @@ template <int KS, bool BF16, bool GRES>
 int launch_s16_nt(int nt, const S16K& k, size_t lds, hipStream_t st)
 {
     switch (nt) {
-        case 1: return launch_s16<1, KS, 8, BF16, GRES>(k, lds, st);
-        case 2: return launch_s16<2, KS, 8, BF16, GRES>(k, lds, st);
-        case 3: return launch_s16<3, KS, 8, BF16, GRES>(k, lds, st);
-        case 4: return launch_s16<4, KS, 8, BF16, GRES>(k, lds, st);
+        case 1: return launch_s16<1, KS, S16_NW, BF16, GRES>(k, lds, st);
+        case 2: return launch_s16<2, KS, S16_NW, BF16, GRES>(k, lds, st);
+        case 3: return launch_s16<3, KS, S16_NW, BF16, GRES>(k, lds, st);
+        case 4: return launch_s16<4, KS, S16_NW, BF16, GRES>(k, lds, st);
     }
     return ESR_ERR_UNSUPPORTED;
 }
@@ -717,23 +736,23 @@ template <bool BF16>
 int launch_s16_post(int ks, int nt, bool gres, int pnt1, int pnt2, const S16K& k, size_t lds, hipStream_t st)
 {
     if (ks == 1) {
-        if (nt == 3 && !gres && pnt1 == 1 && pnt2 == 0) return launch_s16<3, 1, 8, BF16, false, 1, 0>(k, lds, st);
-        if (nt == 4 && !gres && pnt1 == 1 && pnt2 == 0) return launch_s16<4, 1, 8, BF16, false, 1, 0>(k, lds, st);
+        if (nt == 3 && !gres && pnt1 == 1 && pnt2 == 0) return launch_s16<3, 1, S16_NW, BF16, false, 1, 0>(k, lds, st);
+        if (nt == 4 && !gres && pnt1 == 1 && pnt2 == 0) return launch_s16<4, 1, S16_NW, BF16, false, 1, 0>(k, lds, st);
         return ESR_ERR_UNSUPPORTED;
     }
-    if (nt == 3 && gres && pnt1 == 3 && pnt2 == 1) return launch_s16<3, 3, 8, BF16, true, 3, 1>(k, lds, st);
-    if (nt == 4 && !gres && pnt1 == 2 && pnt2 == 0) return launch_s16<4, 3, 8, BF16, false, 2, 0>(k, lds, st);
-    if (nt == 3 && !gres && pnt1 == 2 && pnt2 == 0) return launch_s16<3, 3, 8, BF16, false, 2, 0>(k, lds, st);
+    if (nt == 3 && gres && pnt1 == 3 && pnt2 == 1) return launch_s16<3, 3, S16_NW, BF16, true, 3, 1>(k, lds, st);
+    if (nt == 4 && !gres && pnt1 == 2 && pnt2 == 0) return launch_s16<4, 3, S16_NW, BF16, false, 2, 0>(k, lds, st);
+    if (nt == 3 && !gres && pnt1 == 2 && pnt2 == 0) return launch_s16<3, 3, S16_NW, BF16, false, 2, 0>(k, lds, st);
     return ESR_ERR_UNSUPPORTED;
 }
 
 // LDS bytes of a launch: resident weights + `ring` input stages + epilogue scratch
 size_t s16_lds_bytes(int nchunks, int nt, int ksize, int nw, int ring, size_t post_bytes = 0)
 {
-    const int halo = ksize / 2, th = TILE + 2 * halo, thy = 4 * nw + 2 * halo;
-    const int ppp = (th * thy + 63) / 64;
+    const int halo = ksize / 2, th = TILE + 2 * halo, thy = 32 + 2 * halo;
+    const int npieces = (th * thy + 31) / 32;
     const int pairs = (ksize * ksize + 1) / 2;
-    return (size_t)nchunks * pairs * nt * 1024 + post_bytes + (size_t)ring * 2 * ppp * 1024 + (size_t)nw * SCR_WAVE;
+    return (size_t)nchunks * pairs * nt * 1024 + post_bytes + (size_t)ring * npieces * 1024 + (size_t)nw * SCR_WAVE;
 }
 
 // decides how a descriptor with a post chain runs: fills the tile counts and whether the low-part images are resident;
@@ -752,9 +771,9 @@ int s16_post_plan(const esr_conv_desc* d, int nt, int nchunks, int* pnt1, int* p
     for (int lo = 1; lo >= 0; --lo) {
         const size_t pb = (size_t)(lo + 1) * (nt * *pnt1 + *pnt1 * *pnt2) * 1024 + 1024;
         int r = RING_MAX;
-        while (r > RING_MIN && s16_lds_bytes(nchunks, nt, d->ksize, 8, r, pb) > (size_t)LDS_LIMIT) --r;
-        if (s16_lds_bytes(nchunks, nt, d->ksize, 8, r, pb) <= (size_t)LDS_LIMIT) {
-            *post_lo = lo; *ring = r; *lds = s16_lds_bytes(nchunks, nt, d->ksize, 8, r, pb);
+        while (r > RING_MIN && s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, r, pb) > (size_t)LDS_LIMIT) --r;
+        if (s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, r, pb) <= (size_t)LDS_LIMIT) {
+            *post_lo = lo; *ring = r; *lds = s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, r, pb);
             return ESR_OK;
         }
     }
@@ -980,8 +999,8 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         }
         if (d->post_act != ESR_ACT_NONE && d->post_act != ESR_ACT_LRELU && d->post_act != ESR_ACT_RELU) return ESR_ERR_UNSUPPORTED;
     } else {
-        while (ring > RING_MIN && s16_lds_bytes(nchunks, nt, d->ksize, 8, ring) > (size_t)LDS_LIMIT) --ring;
-        lds = s16_lds_bytes(nchunks, nt, d->ksize, 8, ring);
+        while (ring > RING_MIN && s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, ring) > (size_t)LDS_LIMIT) --ring;
+        lds = s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, ring);
     }
     if (lds > (size_t)LDS_LIMIT) return ESR_ERR_UNSUPPORTED;                                     // weight set too large to stay resident
     if (!shuffle && d->out0.ptr) {

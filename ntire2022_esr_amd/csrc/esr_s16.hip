@@ -144,14 +144,12 @@ __device__ __forceinline__ float gelu16(float x)
     return fmaxf(x, -4.f) * fmaf(xc, p, 0.5f);
 }
 
-// GELU is a compile-time branch of the epilogue body (one uniform branch per tile selects the body): a per-element runtime
-// test made hipcc emit three scalar branches per VALUE, and the branchy code -- not memory -- was 75 % of the kernel.
-// Everything else is max(v, slope * v): slope carries none (1) / LeakyReLU (s) / ReLU (0).
-template <bool GELU>
+// Epilogue activation: max(v, slope * v); slope carries none (1) / LeakyReLU (s) / ReLU (0).  GELU is applied IN PLACE to the
+// accumulators at the end of a tile's last stage (gelu_inplace below), after which the epilogue runs with slope = 1: as a
+// second body of the epilogue its polynomials cost every variant ~50 VGPRs (or spills) for an activation only a few
+// launches use.  asm: fmaxf() on an MFMA result costs a second v_max (hipcc canonicalises the operand first).
 __device__ __forceinline__ float act1(float v, float slope)
 {
-    if (GELU) return gelu16(v);
-    // asm: fmaxf() on an MFMA result costs a second v_max (hipcc canonicalises the operand first)
     float r;
     const float sv = slope * v;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(sv));
@@ -297,20 +295,25 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     };
 
     // ---- load cursor: the (tile, chunk) stage requested next ---------------------------------------------------------
-    // piece pc = wv + NW * r of a stage: halo pixels 32 pc + (lane >> 1), channel half lane & 1 -- a lane PAIR reads the 32
-    // contiguous bytes of a pixel's chunk (32-byte runs cost the memory pipe 12 % less than 16-byte ones: tools/abl nomfma_r*)
+    // piece pc = wv + NW * i of a stage: halo pixels 32 pc + (lane >> 1), channel half lane & 1 -- a lane PAIR reads the 32
+    // contiguous bytes of a pixel's chunk (32-byte runs cost the memory pipe 12 % less than 16-byte ones: tools/abl nomfma_r*).
+    // Behind the block's last tile the cursor keeps issuing (out-of-range offsets: zeros into a ring slot nobody reads), so
+    // every stage carries the same number of DMA instructions and the vmcnt arithmetic has no special cases.
     const int n_my = (NPIECES % NW == 0 || wv < NPIECES % NW) ? PPW : PPW - 1;     // wave-uniform
     int lk = 0;                   // tile iteration of the cursor
     int lc = 0;                   // chunk of the cursor
     int lslot = 0;
-    int issued = 0;               // stages requested so far
     bool lvalid;
     unsigned lvoff[PPW];
     i32x4 lrsrc;
     auto cursor_tile = [&]() __attribute__((always_inline)) {
         const int t = tile_index(lk);
         lvalid = t >= 0;
-        if (!lvalid) return;
+        if (!lvalid) {
+#pragma unroll
+            for (int r = 0; r < PPW; ++r) lvoff[r] = OOB;
+            return;
+        }
         int n, x0, y0;
         tile_coords(t, n, x0, y0);
         const kparg_t q = KP();
@@ -328,16 +331,12 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
             lvoff[r] = ok ? (unsigned)((gy * qW + gx) * qpitch + qcoff + 8 * plane) * 2u : OOB;
         }
     };
-    auto issue_stage = [&]() __attribute__((always_inline)) {          // DMA of the cursor's stage into ring slot lslot, then advance the cursor
-        const unsigned dst0 = ring_lds + (unsigned)(lslot * STAGE_BYTES);
-        const unsigned soff = (unsigned)lc * 32u;
-#pragma unroll
-        for (int r = 0; r < PPW; ++r) {
-            const int pc = wv + NW * r;
-            if (NPIECES % NW == 0 || r < PPW - 1 || pc < NPIECES)       // wave-uniform
-                dma_buf16(dst0 + (unsigned)pc * 1024u, lvoff[r], lrsrc, soff);
-        }
-        ++issued;
+    auto dma_piece = [&](int i) __attribute__((always_inline)) {       // piece i of this wave of the cursor's stage, into ring slot lslot
+        const int pc = wv + NW * i;
+        if (NPIECES % NW == 0 || i < PPW - 1 || pc < NPIECES)           // wave-uniform
+            dma_buf16(ring_lds + (unsigned)(lslot * STAGE_BYTES) + (unsigned)pc * 1024u, lvoff[i], lrsrc, (unsigned)lc * 32u);
+    };
+    auto cursor_advance = [&]() __attribute__((always_inline)) {
         lslot = lslot == R - 1 ? 0 : lslot + 1;
         if (++lc == p.nchunks) {
             lc = 0;
@@ -364,8 +363,12 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     }
     cursor_tile();
     if (!lvalid) return;                 // block without tiles (grid <= ntiles: does not happen)
-    for (int i = 0; i < R - 1 && lvalid; ++i) issue_stage();
-    wait_vm_dyn((issued - 1) * n_my);    // the weights and stage 0 have landed
+    for (int i = 0; i < R - 1; ++i) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) dma_piece(j);
+        cursor_advance();
+    }
+    wait_vm_dyn((R - 2) * n_my);         // the weights and stage 0 have landed
     if (PNT1 > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the post biases written above
     __builtin_amdgcn_s_barrier();
 
@@ -384,11 +387,16 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     // the centre pixel of this lane's accumulator rows in the staged tile: channels 16c + 4kq .. +3 of chunk c
     const int c_off = ((wv * RW + HALO) * TH + px + HALO) * 32 + (kq >> 1) * 16 + (kq & 1) * 8;
 
-    constexpr bool gres = GRES;
+    // The plain NHWC epilogue (no post chain) lives INSIDE the first MFMA group of the next tile's first stage (swap_epi):
+    // row by row, activation / rounding of the finished tile's accumulators right before the MFMAs that overwrite them, the
+    // D fragments made store-shaped by v_permlane16_swap (no LDS, no waits), their stores in the shadow of the matrix pipe.
+    // Post-chain and pixel-shuffle epilogues stay a phase of their own in front of the stage's compute.
+    const bool swap_epi = PNT1 == 0 && p.out_layout != ESR_NCHW_SHUFFLE4;
+    constexpr int SWAP_STORES = (NT / 2) * RW + (NT & 1) * (RW / 2);
     const int epi_stores = PNT1 > 0 ? (p.store_main ? 2 * RW : 0) + 2 * RW + (PNT2 > 0 ? RW : 0)
-                                    : (p.out_layout == ESR_NCHW_SHUFFLE4 ? RW * NT : (p.split < p.cout_store ? 4 * RW : 2 * RW));   // stores per wave and tile
-    const unsigned hmask = (1u << (R - 1)) - 1u;
-    unsigned hist_st = 0, hist_rs = 0;   // bit i: an epilogue's stores / a tile's residual loads were issued at the top of stage s - i
+                                    : (p.out_layout == ESR_NCHW_SHUFFLE4 ? RW * NT : (p.split < p.cout_store ? 2 : 1) * SWAP_STORES);   // stores per wave and tile
+    const unsigned hmask = (1u << (R - 2)) - 1u;
+    unsigned hist_rs = 0, hist_st = 0;   // bit i: stage s - i was a tile's last stage (residual loads) / carried an epilogue's stores
 
     f32x4 acc[NT][RW];
     uint2 rv[GRES ? NT : 1][RW];         // residual of the current tile in D-fragment layout (hidden asm loads)
@@ -397,7 +405,11 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
 #pragma unroll
         for (int r = 0; r < RW; ++r) rv[tt][r] = uint2{0u, 0u};
 
-    auto load_residual = [&](int n, int x0, int y0) __attribute__((always_inline)) {
+    // issued in a tile's LAST stage (behind the previous tile's epilogue, which frees rv; in front of the stage's DMA), one
+    // stage before the tile's epilogue wants them.  Not earlier: hipcc believes the asm's outputs are valid at once, so it may
+    // copy / spill the registers before the data has arrived -- the shorter their life, the less it is tempted (with the loads
+    // in the tile's first stage the 64-channel variants did exactly that: tools/dbg/s16_shape_probe.py).
+    auto load_residual = [&](int n, int x0, int y0, bool have) __attribute__((always_inline)) {
         if (!GRES) return;
         const kparg_t q = KP();
         const int qH = q->H, qW = q->W, qrp = q->res_pitch, qrc = q->res_coff, qcs = q->cout_store;
@@ -409,7 +421,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         // rows below the image fall past num_records and read zeros; one add per row, one per channel tile
         const unsigned rbase = (unsigned)((y0 + wv * RW) * qW + x0) * (unsigned)qrp * 2u + (__umul24(px, qrp) + (unsigned)(qrc + kq * 4)) * 2u;
         const unsigned rowb = (unsigned)qW * (unsigned)qrp * 2u;
-        const bool inx = x0 + px < qW;
+        const bool inx = have && x0 + px < qW;
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
 #pragma unroll
@@ -421,22 +433,47 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         }
     };
 
-    auto epilogue_body = [&](auto gelu_tag, int n, int x0, int y0, int younger_dma) __attribute__((always_inline)) {
-        constexpr bool GELU = decltype(gelu_tag)::value;
+    const bool act_gelu = p.act == ESR_ACT_GELU;
+    // waits for the finished tile's residual (loaded in its last stage, in front of that stage's DMA pieces)
+    auto wait_residual = [&]() __attribute__((always_inline)) {
+        if (!GRES) return;
+        wait_vm_dyn(n_my);
+#pragma unroll
+        for (int tt = 0; tt < (GRES ? NT : 1); ++tt)
+#pragma unroll
+            for (int r = 0; r < RW; ++r) asm volatile("" : "+v"(rv[tt][r]));      // uses below stay behind the wait
+    };
+
+    // GELU (and a pre-activation residual under it), applied to the accumulators at the end of the tile's last stage; the
+    // epilogue then sees an identity activation.  One fragment at a time (sched_barrier): register pressure stays flat.
+    auto gelu_inplace = [&]() __attribute__((always_inline)) {
+        const bool pre = GRES && KP()->res_mode == ESR_RES_PRE_ACT;
+        if (pre) wait_residual();        // issued at the top of this very stage: only its DMA pieces are younger
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                f32x4 v = acc[tt][r];
+                if (GRES) {
+                    const f32x4 rf = unpack4<BF16>(rv[GRES ? tt : 0][r]);
+                    if (pre) v += rf;
+                }
+                v.x = gelu16(v.x); v.y = gelu16(v.y); v.z = gelu16(v.z); v.w = gelu16(v.w);
+                acc[tt][r] = v;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+
+    // epilogue as a phase: pixel-shuffle output (PNT1 == 0) or the post chain (PNT1 > 0)
+    auto epilogue = [&](int n, int x0, int y0) __attribute__((always_inline)) {
         const kparg_t q = KP();
-        const int qH = q->H, qW = q->W, qcs = q->cout_store, qsplit = q->split, qres_mode = q->res_mode;
-        const float qslope = q->slope;
+        const int qH = q->H, qW = q->W, qcs = q->cout_store, qsplit = q->split;
+        const int qres_mode = (act_gelu && q->res_mode == ESR_RES_PRE_ACT) ? ESR_RES_NONE : q->res_mode;     // GELU: already in the accumulators
+        const float qslope = act_gelu ? 1.f : q->slope;
         const bool shuffle = q->out_layout == ESR_NCHW_SHUFFLE4;
         const bool has_split = !shuffle && qsplit < qcs;
-        if (gres) {
-            // the residual loads were issued one whole stage ago, behind them only this top's DMA
-            wait_vm_dyn(younger_dma);
-#pragma unroll
-            for (int tt = 0; tt < (GRES ? NT : 1); ++tt)
-#pragma unroll
-                for (int r = 0; r < RW; ++r) asm volatile("" : "+v"(rv[tt][r]));      // uses below stay behind the wait
-        }
-        if (shuffle) {
+        wait_residual();
+        if constexpr (PNT1 == 0) {
             // out[n, t, 4gy + kq, 4gx + 0..3] = channel 16t + 4kq + j: the D fragment is one dwordx4 of 4 adjacent HR pixels
             const int gx = x0 + px;
             const unsigned W4 = (unsigned)qW * 4u, H4 = (unsigned)qH * 4u;
@@ -449,14 +486,14 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                 for (int tt = 0; tt < NT; ++tt) {
                     const bool ok = gy < qH && gx < qW && tt * 16 + kq * 4 < qcs;
                     f32x4 v = acc[tt][r];
-                    v.x = act1<GELU>(v.x, qslope); v.y = act1<GELU>(v.y, qslope);
-                    v.z = act1<GELU>(v.z, qslope); v.w = act1<GELU>(v.w, qslope);
+                    v.x = act1(v.x, qslope); v.y = act1(v.y, qslope);
+                    v.z = act1(v.z, qslope); v.w = act1(v.w, qslope);
                     const unsigned vo = ok ? (((unsigned)tt * H4 + (unsigned)gy * 4u + (unsigned)kq) * W4 + (unsigned)gx * 4u) * 4u : OOB;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yr, vo, 0, 0);
                 }
             }
             return;
-        }
+        } else {
         // NHWC 16-bit: residual / activation / rounding in the fragment layout, then each wave transposes half a pixel row
         // at a time through its private scratch: lane (p8, cg) owns the 8 channels 8cg.. of pixel p8 -- one 16-byte store per
         // lane, 128 contiguous bytes per pixel, 1 KB per instruction
@@ -490,8 +527,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                 f32x4 rf = {0.f, 0.f, 0.f, 0.f};
                 if (GRES) rf = unpack4<BF16>(rv[GRES ? tt : 0][r]);
                 if (GRES && qres_mode == ESR_RES_PRE_ACT) v += rf;
-                v.x = act1<GELU>(v.x, qslope); v.y = act1<GELU>(v.y, qslope);
-                v.z = act1<GELU>(v.z, qslope); v.w = act1<GELU>(v.w, qslope);
+                v.x = act1(v.x, qslope); v.y = act1(v.y, qslope);
+                v.z = act1(v.z, qslope); v.w = act1(v.w, qslope);
                 if (GRES && qres_mode == ESR_RES_POST_ACT) v += rf;
                 pk[tt].x = pack2<BF16>(v.x, v.y);
                 pk[tt].y = pack2<BF16>(v.z, v.w);
@@ -582,108 +619,198 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                 if (has_split) __builtin_amdgcn_raw_buffer_store_b128(o, yr1, vb1[h] + (unsigned)r * rowb1, 0, 0);
             }
         }
-    };
-
-    auto epilogue = [&](int n, int x0, int y0, int younger_dma) __attribute__((always_inline)) {
-        if (KP()->act == ESR_ACT_GELU) epilogue_body(std::true_type{}, n, x0, y0, younger_dma);
-        else epilogue_body(std::false_type{}, n, x0, y0, younger_dma);
+        }
     };
 
     int slot = 0;
-    int s = 0;                           // stage index
     bool pend = false;                   // a finished tile waits for its epilogue
     int pn = 0, px0 = 0, py0 = 0;
-    for (int k = 0;; ++k) {
-        // the iteration behind the block's last tile only drains the pending epilogue: ONE copy of the epilogue in the
-        // code (a second call site behind the loop was 7 KB of cold instruction fetches at the end of every block)
-        const int t = tile_index(k);
-        const bool have = t >= 0;
-        if (!have && !pend) break;
-        int n = 0, x0 = 0, y0 = 0;
-        if (have) tile_coords(t, n, x0, y0);
-        const int nst = have ? p.nchunks : 1;
-        for (int c = 0; c < nst; ++c, ++s) {
-            // ---- top of stage s -----------------------------------------------------------------------------------
-            int dma_now = 0;
-            if (lvalid) {
-                issue_stage();
-                dma_now = n_my;
-            }
-            hist_st <<= 1;
-            hist_rs <<= 1;
-            if (c == 0) {
-                if (pend) {
-                    epilogue(pn, px0, py0, dma_now);
-                    hist_st |= 1u;
-                    pend = false;
-                }
-            }
-            if (!have) break;
-            if (gres && c == p.nchunks - 1) {
-                load_residual(n, x0, y0);
-                hist_rs |= 1u;
-            }
-            // ---- compute -------------------------------------------------------------------------------------------
-            const char* sb = ring + slot * STAGE_BYTES;
-            const char* wc = smem + c * W_CHUNK_BYTES + a_off;
+    bool have = false;
+    int n = 0, x0 = 0, y0 = 0;
 
-            constexpr int NBUF = (GRES || NW == 16) ? 1 : 2;               // fragment sets: the read of pair q+1 runs under the MFMAs of pair q
-            i32x4 a[NBUF][NT], b[NBUF][RW];
-            auto load_frag = [&](int buf, int q) {
+    // ---- swap epilogue: set-up per tile, then one call per accumulator row (inside the first MFMA group) ---------------
+    // v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of another: for two D fragments X, Y
+    // (lane (px, kq): channels 4kq..4kq+3 of pixel px, 8 bytes) two swaps leave lane (px, kq) with 16 CONTIGUOUS bytes --
+    // channels 8(kq >> 1) .. +7 of X (kq even) or of Y (kq odd).  X, Y = channel tiles 2j, 2j+1 of one row (shape A: 64
+    // contiguous bytes per pixel and instruction), or the odd last tile of rows r, r+1 (shape B: 32 bytes per pixel).
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    constexpr int NPAIR = NT / 2;
+    unsigned vbA0[NPAIR > 0 ? NPAIR : 1], vbA1[NPAIR > 0 ? NPAIR : 1], vbB0 = OOB, vbB1 = OOB;
+    unsigned e_rowb0 = 0, e_rowb1 = 0;
+    char* e_y0 = nullptr; char* e_y1 = nullptr;
+    int e_y0n = 0, e_y1n = 0;
+    float e_slope = 0.f;
+    int e_res_mode = 0;
+    bool e_split = false;
+    auto swap_epi_setup = [&]() __attribute__((always_inline)) {
+        const kparg_t q = KP();
+        const int qH = q->H, qW = q->W, qcs = q->cout_store, qsplit = q->split;
+        const int qy0p = q->y0_pitch, qy0c = q->y0_coff, qy1p = q->y1_pitch, qy1c = q->y1_coff;
+        e_slope = act_gelu ? 1.f : q->slope;
+        e_res_mode = (act_gelu && q->res_mode == ESR_RES_PRE_ACT) ? ESR_RES_NONE : q->res_mode;    // GELU: already in the accumulators
+        e_split = qsplit < qcs;
+        const size_t y0_img = (size_t)qH * qW * qy0p * 2, y1_img = (size_t)qH * qW * qy1p * 2;
+        e_y0 = q->y0 + (size_t)pn * y0_img; e_y0n = (int)y0_img;
+        e_y1 = q->y1 + (size_t)pn * y1_img; e_y1n = (int)y1_img;
+        e_rowb0 = (unsigned)qW * (unsigned)qy0p * 2u;
+        e_rowb1 = (unsigned)qW * (unsigned)qy1p * 2u;
+        const unsigned srow = (unsigned)((py0 + wv * RW) * qW + px0);            // wave-uniform: pixel (row 0, px = 0) of this wave
+        const unsigned s0 = srow * (unsigned)qy0p * 2u, s1 = srow * (unsigned)qy1p * 2u;
+        const unsigned l0 = (__umul24(px, qy0p) + (unsigned)qy0c) * 2u, l1 = (__umul24(px, qy1p) + (unsigned)(qy1c - qsplit)) * 2u;
+        const bool inx = px0 + px < qW;
+        // rows below the image fall past num_records (= the image's bytes): dropped by the hardware
 #pragma unroll
-                for (int tt = 0; tt < NT; ++tt) a[buf][tt] = *reinterpret_cast<const i32x4*>(wc + (q * NT + tt) * 1024);
+        for (int j = 0; j < NPAIR; ++j) {
+            const int ch = (2 * j + (kq & 1)) * 16 + (kq >> 1) * 8;
+            vbA0[j] = (inx && ch < qsplit) ? s0 + l0 + (unsigned)ch * 2u : OOB;
+            vbA1[j] = (inx && ch >= qsplit && ch < qcs) ? s1 + l1 + (unsigned)ch * 2u : OOB;
+        }
+        if (NT & 1) {
+            const int ch = (NT - 1) * 16 + (kq >> 1) * 8;
+            vbB0 = (inx && ch < qsplit) ? s0 + l0 + (unsigned)ch * 2u + ((kq & 1) ? e_rowb0 : 0u) : OOB;
+            vbB1 = (inx && ch >= qsplit && ch < qcs) ? s1 + l1 + (unsigned)ch * 2u + ((kq & 1) ? e_rowb1 : 0u) : OOB;
+        }
+    };
+    uint2 pk[NT][2];                     // rounded rows r - 1 (even), r (odd) of the finished tile
+    auto store16 = [&](uint2 X, uint2 Y, unsigned v0, unsigned v1, int r) __attribute__((always_inline)) {
+        const u32x2 a = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
+        const u32x2 b = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
+        const i32x4 o = {(int)a.x, (int)b.x, (int)a.y, (int)b.y};
+        __builtin_amdgcn_raw_buffer_store_b128(o, __builtin_amdgcn_make_buffer_rsrc(e_y0, 0, e_y0n, 0x00020000), v0 + (unsigned)r * e_rowb0, 0, 0);
+        if (e_split) __builtin_amdgcn_raw_buffer_store_b128(o, __builtin_amdgcn_make_buffer_rsrc(e_y1, 0, e_y1n, 0x00020000), v1 + (unsigned)r * e_rowb1, 0, 0);
+    };
+    auto swap_epi_act = [&](int r) __attribute__((always_inline)) {       // reads acc[.][r]
 #pragma unroll
-                for (int r = 0; r < RW; ++r) b[buf][r] = *reinterpret_cast<const i32x4*>(sb + b_off[q] + r * (TH * 32));
-            };
-            if (NBUF == 2) load_frag(0, 0);
+        for (int tt = 0; tt < NT; ++tt) {
+            f32x4 v = acc[tt][r];
+            f32x4 rf = {0.f, 0.f, 0.f, 0.f};
+            if (GRES) rf = unpack4<BF16>(rv[GRES ? tt : 0][r]);
+            if (GRES && e_res_mode == ESR_RES_PRE_ACT) v += rf;
+            v.x = act1(v.x, e_slope); v.y = act1(v.y, e_slope);
+            v.z = act1(v.z, e_slope); v.w = act1(v.w, e_slope);
+            if (GRES && e_res_mode == ESR_RES_POST_ACT) v += rf;
+            pk[tt][r & 1].x = pack2<BF16>(v.x, v.y);
+            pk[tt][r & 1].y = pack2<BF16>(v.z, v.w);
+        }
+    };
+    auto swap_epi_store = [&](int r) __attribute__((always_inline)) {                    // rows r - 1, r (r odd)
 #pragma unroll
-            for (int q = 0; q < PAIRS; ++q) {
-                const int cs = NBUF == 2 ? (q & 1) : 0;
-                if (NBUF == 2) {
-                    if (q + 1 < PAIRS) load_frag(cs ^ 1, q + 1);
-                    __builtin_amdgcn_sched_barrier(0);      // keep the prefetch above this pair's MFMAs
-                } else {
-                    load_frag(0, q);
-                }
-                if (q == 0 && c == 0) {
-                    // first MFMA group of a tile: the accumulator input is the bias
+        for (int j = 0; j < NPAIR; ++j) {
+            store16(pk[2 * j][0], pk[2 * j + 1][0], vbA0[j], vbA1[j], r - 1);
+            store16(pk[2 * j][1], pk[2 * j + 1][1], vbA0[j], vbA1[j], r);
+        }
+        if (NT & 1) store16(pk[NT - 1][0], pk[NT - 1][1], vbB0, vbB1, r - 1);
+    };
+
+    // ---- one stage: MFMA groups from ring slot `slot`, the cursor's DMA pieces between them ------------------------------
+    auto compute = [&](auto epi_tag, int c, bool last) __attribute__((always_inline)) {
+        constexpr bool EPI = decltype(epi_tag)::value;           // first stage of a tile with the swap epilogue inside
+        const bool first = EPI || c == 0;
+        const char* sb = ring + slot * STAGE_BYTES;
+        const char* wc = smem + c * W_CHUNK_BYTES + a_off;
+
+        constexpr int NBUF = (GRES || NW == 16 || NT == 4) ? 1 : 2;          // fragment sets: the read of pair q+1 runs under the MFMAs of pair q
+        i32x4 a[NBUF][NT], b[NBUF][RW];
+        auto load_frag = [&](int buf, int q) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int tt = 0; tt < NT; ++tt)
+            for (int tt = 0; tt < NT; ++tt) a[buf][tt] = *reinterpret_cast<const i32x4*>(wc + (q * NT + tt) * 1024);
 #pragma unroll
-                        for (int r = 0; r < RW; ++r)
-                            acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], biasv[tt]);
-                } else {
+            for (int r = 0; r < RW; ++r) b[buf][r] = *reinterpret_cast<const i32x4*>(sb + b_off[q] + r * (TH * 32));
+        };
+        if (NBUF == 2) load_frag(0, 0);
+        if (EPI) {
+            wait_residual();
+            swap_epi_setup();
+        }
 #pragma unroll
-                    for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                        for (int r = 0; r < RW; ++r) acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], acc[tt][r]);
-                }
+        for (int q = 0; q < PAIRS; ++q) {
+            const int cs = NBUF == 2 ? (q & 1) : 0;
+            if (NBUF == 2) {
+                if (q + 1 < PAIRS) load_frag(cs ^ 1, q + 1);
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch above this pair's MFMAs
+            } else {
+                load_frag(0, q);
             }
-            if (KS == 3 && p.res_in) {
-                // act(conv(x) + x): the residual of output channels 16c .. 16c+15 is the centre pixel of input chunk c, still in
-                // this stage's ring slot (read behind the MFMAs: nothing waits for it)
+            if (q == 0 && EPI) {
+                // the finished tile's rows leave just in front of the MFMAs that overwrite their accumulators (C input = bias)
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    swap_epi_act(r);
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], biasv[tt]);
+                    if (r & 1) swap_epi_store(r);
+                }
+            } else if (q == 0 && first) {
+                // first MFMA group of a tile: the accumulator input is the bias
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
-                    if (tt == c) {
 #pragma unroll
-                        for (int r = 0; r < RW; ++r)
-                            acc[tt][r] += unpack4<BF16>(*reinterpret_cast<const uint2*>(sb + c_off + r * (TH * 32)));
-                    }
+                    for (int r = 0; r < RW; ++r)
+                        acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], biasv[tt]);
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], acc[tt][r]);
             }
+            if (q == 0 && last) load_residual(n, x0, y0, have);      // this tile's residual: behind the epilogue, in front of the DMA
+            if (q < PPW) dma_piece(q);                               // the DMA issue rides in the shadow of the matrix pipe
+        }
+#pragma unroll
+        for (int i = PAIRS; i < PPW; ++i) dma_piece(i);
+        if (KS == 3 && p.res_in) {
+            // act(conv(x) + x): the residual of output channels 16c .. 16c+15 is the centre pixel of input chunk c, still in
+            // this stage's ring slot (read behind the MFMAs: nothing waits for it)
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                int cc = c;
+                asm volatile("" : "+s"(cc));      // opaque per tile: hipcc otherwise folds the NT tests into acc[c] and the accumulators go to scratch
+                if (tt == cc) {
+#pragma unroll
+                    for (int r = 0; r < RW; ++r)
+                        acc[tt][r] += unpack4<BF16>(*reinterpret_cast<const uint2*>(sb + c_off + r * (TH * 32)));
+                }
+            }
+        }
+        if (last && act_gelu) gelu_inplace();
+    };
+
+    for (int k = 0;; ++k) {
+        // the iteration behind the block's last tile drains the pending epilogue through the same code (its MFMAs run on
+        // whatever the ring holds and its DMA / residual loads are out of range)
+        const int t = tile_index(k);
+        have = t >= 0;
+        if (!have && !pend) break;
+        if (have) tile_coords(t, n, x0, y0);
+        const int nst = have ? p.nchunks : 1;
+        for (int c = 0; c < nst; ++c) {
+            const bool last = c == nst - 1;
+            hist_rs = (hist_rs << 1) | (last ? 1u : 0u);
+            hist_st <<= 1;
+            bool done = false;
+            if (c == 0 && pend) {
+                hist_st |= 1u;
+                if (!swap_epi) {
+                    epilogue(pn, px0, py0);
+                } else {
+                    compute(std::true_type{}, 0, last);
+                    done = true;
+                }
+            }
+            if (!done) compute(std::false_type{}, c, last);
+            cursor_advance();
             // ---- sync: stage s+1 has landed; everything issued after its DMA may stay in flight -------------------------
-            {
-                const int younger = issued - (s + 2);        // stages requested behind stage s+1
-                const int cnt = younger * n_my + epi_stores * __builtin_popcount(hist_st & hmask) +
-                                RES_LOADS * __builtin_popcount(hist_rs & hmask);
-                wait_vm_dyn(younger < 0 ? 0 : cnt);
-                __builtin_amdgcn_s_barrier();
-            }
+            // its DMA was issued R-2 stages ago, behind that stage's own stores / residual loads: younger are the DMA of the
+            // R-2 stages since and the first-stage instructions of those among them that opened a tile
+            wait_vm_dyn((R - 2) * n_my + epi_stores * __builtin_popcount(hist_st & hmask) + (GRES ? RES_LOADS : 0) * __builtin_popcount(hist_rs & hmask));
+            __builtin_amdgcn_s_barrier();
             slot = slot == R - 1 ? 0 : slot + 1;
         }
         if (!have) break;
         pend = true;
         pn = n; px0 = x0; py0 = y0;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing (zero-fill) DMA writes LDS: it must not outlive the block
 }
 
 template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 = 0>

@@ -65,6 +65,39 @@ def test_s16_conv_matches_fp64_reference(compute, cin, cout, k, hw, act, res_mod
 
 
 @pytest.mark.parametrize("compute", ["bf16", "f16"])
+@pytest.mark.parametrize("n,cin,cout,k,hw,res_mode", [
+    (1, 64, 64, 3, (270, 480), 0), (1, 64, 64, 3, (270, 480), 2), (1, 64, 64, 1, (270, 480), 2), (1, 48, 48, 3, (339, 510), 2),
+    (1, 64, 64, 3, (339, 510), 1), (3, 48, 48, 3, (256, 256), 0), (1, 16, 16, 3, (270, 480), 1), (5, 50, 50, 1, (200, 200), 0)])
+def test_s16_conv_more_tiles_than_blocks(compute, n, cin, cout, k, hw, res_mode):
+    """Shapes with MORE 16x32 tiles than the 256 persistent blocks and partial tiles at both edges: the tile-to-tile path of a
+    block (the epilogue of tile k inside the first MFMA group of tile k+1, residual registers reused across tiles, unequal
+    tile counts per block, the drain iteration) -- the small shapes above give every block at most one tile."""
+    from ntire2022_esr_amd import ops
+    from ntire2022_esr_amd.engine import pack_conv_s16, unpack_conv_s16
+    dt = DT[compute]
+    g = torch.Generator().manual_seed(n + cin + cout + hw[0] + k)
+    cp = (cin + 15) // 16 * 16
+    x = torch.randn(n, cin, *hw, generator=g).to(dt)
+    r = torch.randn(n, cout, *hw, generator=g).to(dt)
+    w = torch.randn(cout, cin, k, k, generator=g) * (0.1 if k == 3 else 0.2)
+    b = torch.randn(cout, generator=g)
+    blob = pack_conv_s16(w, b, compute, cin_phys=cp)
+    weff, _ = unpack_conv_s16(blob, cin, cout, k, compute, cin_phys=cp)
+    conv = F.conv2d(x.double().to(DEV), weff.double().to(DEV), b.double().to(DEV), padding=k // 2)
+    rd = r.double().to(DEV)
+    ref = ACTS[1](conv + rd) if res_mode == 1 else (ACTS[1](conv) + rd if res_mode == 2 else ACTS[1](conv))
+    xin = F.pad(_nhwc(x), (0, cp - cin)).to(DEV)
+    rp = F.pad(_nhwc(r), (0, (-cout) % 8)).to(DEV) if res_mode else None
+    for _ in range(3):                  # a race would not show every time
+        y = ops.conv2d(xin, w, b, act=1, res=rp, res_mode=res_mode, cin=cin, packed=blob.to(DEV))
+        got = y.permute(0, 3, 1, 2)[:, :cout].double()
+        eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+        tol = ref.abs() * eps * 1.01 + 3e-5 * max(1.0, float(ref.abs().max()))
+        bad = int(((got - ref).abs() > tol).sum())
+        assert bad == 0, bad
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
 def test_s16_split_store_slices_and_shuffle(compute):
     """channel-split store (IMDBlock: 16 -> concat slice, 48 -> next conv), reads from / writes into slices of wider
     buffers, and the PixelShuffle(4) tail writing the fp32 NCHW network output"""

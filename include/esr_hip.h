@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESR_ABI_VERSION 4
+#define ESR_ABI_VERSION 5
 
 typedef enum esr_status {
     ESR_OK = 0,
@@ -134,6 +134,14 @@ typedef struct esr_conv_desc {
     esr_view post2_out;
     int32_t post2_cout;
     int32_t reserved3;
+    /* ABI v5 -- position-dependent bias at the image border (16-bit storage, NHWC, no post chain; NULL = none): fp32 table
+     * [16][round_up(cout, 16)], row m is ADDED (before residual / activation) to the pixels whose outside-mask is m:
+     * bit 0: x == 0, bit 1: x == w-1, bit 2: y == 0, bit 3: y == h-1 (row 0 is never read).  This is what lets BSConvU
+     * (models/team18_bsrn.py:82-88: depthwise 3x3 over the ZERO-PADDED pointwise output pw(x) + b) run as ONE dense 3x3 with
+     * the merged weights dw[c,tap] * pw[c,k]: in the interior the pointwise bias contributes b[c] * sum_tap dw[c,tap] (folded
+     * into the bias), at the border the taps that fall outside the image contribute nothing -- row m holds
+     * -b[c] * sum over the taps outside for mask m of dw[c,tap]. */
+    const float* border_bias;
 } esr_conv_desc;
 
 /* Host-side weight packer (the K10 "weight packer" of SURVEY 7.2): OIHW fp32 (the layout of every

@@ -43,7 +43,7 @@ class ConvDesc(ctypes.Structure):
         ("post_wpacked", ctypes.c_void_p), ("post_out", View),
         ("post_cout", ctypes.c_int32), ("post_act", ctypes.c_int32),
         ("post2_wpacked", ctypes.c_void_p), ("post2_out", View),
-        ("post2_cout", ctypes.c_int32), ("reserved3", ctypes.c_int32),
+        ("post2_cout", ctypes.c_int32), ("reserved3", ctypes.c_int32), ("border_bias", ctypes.c_void_p),
     ]
 
 
@@ -171,7 +171,7 @@ def lib():
     L.esr_prof_collect.restype = ci
     L.esr_prof_destroy.argtypes = [vp]
     L.esr_prof_destroy.restype = None
-    if L.esr_abi_version() != 4:
+    if L.esr_abi_version() != 5:
         raise EsrError("libesr_hip.so ABI version mismatch")
     _lib = L
     return L

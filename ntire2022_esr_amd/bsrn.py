@@ -7,6 +7,11 @@ tensor is a 1x1 convolution in this engine's native layout (the reference's 131 
 epilogue.  Two load-time folds, both exact up to one fp32 rounding:
   * `cat([x,x,x,x],1)` (team18_bsrn.py:218) -> the 4 column groups of fea_conv.pw.weight[C,12] are summed to [C,3];
   * `out * cw` (team18_bsrn.py:169) -> folded into the columns of conv_out.weight.
+16-bit storage modes: a full-resolution BSConvU runs as ONE dense 3x3 on the matrix cores (conv_s16_kernel) with the merged
+weights W[c,k,tap] = dw[c,tap] * pw[c,k] -- at 16x the fp32 matrix rate the 9x larger product is cheaper than the VALU
+depthwise pass (0.12 ms against bsconv_kernel's 0.37 ms per launch at 32x256x256, C = 48).  The depthwise conv zero-pads the
+pointwise OUTPUT (bias included), which a dense conv of the input cannot express at the image border: the bias term goes
+through esr_conv_desc.border_bias (a 16-row table indexed by which sides of the pixel lie outside), see _merged_bsconv.
 """
 import torch
 
@@ -57,8 +62,41 @@ class BSRN(HipSRModel):
         self._add_dw('c2.dw', C)
         self._add_conv('upsampler.upsampleOneStep.0', C, num_out_ch * upscale * upscale, 3)
 
+    @staticmethod
+    def _merged_bsconv(pw, dw):
+        """BSConvU (team18_bsrn.py:82-88) as a dense 3x3: y[c] = sum_tap dw[c,tap] * pad0(pw[c,:] . x + bp[c]) + bd[c]
+        -> weights W[c,k,tap] = dw[c,tap] * pw[c,k], bias bd[c] + bp[c] * sum_tap dw[c,tap] for interior pixels, and for a
+        pixel whose taps with dx = -1 (mask bit 0), dx = +1 (bit 1), dy = -1 (bit 2), dy = +1 (bit 3) fall outside the image
+        the table row [mask] = -bp[c] * sum over those taps of dw[c,tap]."""
+        wp = pw.weight.detach().double().cpu().reshape(pw.weight.shape[0], -1)      # [C, cin]   (host arithmetic, fp64)
+        wd = dw.weight.detach().double().cpu().reshape(-1, 3, 3)                      # [C, ky, kx]
+        bp = pw.bias.detach().double().cpu() if pw.bias is not None else torch.zeros(wp.shape[0], dtype=torch.float64)
+        bd = dw.bias.detach().double().cpu() if dw.bias is not None else torch.zeros(wp.shape[0], dtype=torch.float64)
+        w = wd[:, None, :, :] * wp[:, :, None, None]                                  # [C, cin, 3, 3]
+        bias = bd + bp * wd.sum(dim=(1, 2))
+        c = wp.shape[0]
+        cp = (c + 15) // 16 * 16
+        table = torch.zeros(16, cp, dtype=torch.float64)
+        for m in range(1, 16):
+            out = torch.zeros(3, 3, dtype=torch.bool)
+            if m & 1: out[:, 0] = True
+            if m & 2: out[:, 2] = True
+            if m & 4: out[0, :] = True
+            if m & 8: out[2, :] = True
+            table[m, :c] = -bp * (wd * out.double()).sum(dim=(1, 2))
+        return w.float(), bias.float(), table.float().contiguous()
+
+    def _merged_paths(self):
+        """BSConvU modules that run as dense 3x3 convolutions in the 16-bit modes (the full-resolution ones)"""
+        return [f'B{k}.c{j}_r' for k in range(1, self.nb + 1) for j in (1, 2, 3)] + [f'B{k}.c4' for k in range(1, self.nb + 1)] + ['c2']
+
     def _extra_pack(self, packed, device):
         C, ic = self.C, self.in_nc
+        if self._store() != "f32":
+            for path in self._merged_paths():
+                w, bias, table = self._merged_bsconv(self._leaf(path + '.pw'), self._leaf(path + '.dw'))
+                packed[path + '#bs3#s16'] = pack_conv_s16(w, bias, self._store()).to(device)
+                packed[path + '#bs3#border'] = table.to(device)
         pw = self._leaf('fea_conv.pw')
         w = pw.weight.detach().float().reshape(C, 4, ic).sum(dim=1)           # [C,4*ic] -> [C,ic]: input replicated x4
         w3 = torch.zeros(C, ic, 3, 3)
@@ -79,6 +117,10 @@ class BSRN(HipSRModel):
         C, dc, f, nb = self.C, self.dc, self.f, self.nb
         h2, w2, h3, w3 = _lowres(plan.h, plan.w)
         g = dict(act=L.ACT_GELU)
+        merged = plan.esize == 2
+
+        def bs3(path, src, dst, cin, cout, **kw):
+            plan.conv(path + '#bs3', src, dst, cin, cout, k=3, border=path + '#bs3#border', bs_of=path, **kw)
         fea = plan.buffer('fea', C)
         bcat = plan.buffer('bcat', nb * C)                # block outputs, team18_bsrn.py:226
         cat = plan.buffer('cat', 4 * dc)                  # d1 d2 d3 r4, team18_bsrn.py:166
@@ -95,11 +137,20 @@ class BSRN(HipSRModel):
             b = f'B{k}.'
             src = cur
             for j, (rin, rout) in enumerate(((cur, r1), (r1, r2), (r2, r1)), start=1):
-                # c{j}_d (Linear + GELU) and c{j}_r = BSConvU (+ input, GELU) read the same tensor: one launch, the
-                # pointwise result stays in LDS (team18_bsrn.py:150-163)
-                plan.bsconv(b + f'c{j}_r.pw', b + f'c{j}_r.dw', rin, rout, C, C, res=rin, res_mode=L.RES_PRE_ACT,
-                            distill=dict(w=b + f'c{j}_d', dst=cat[(j - 1) * dc:j * dc], cout=dc, act=L.ACT_GELU), **g)
-            plan.bsconv(b + 'c4.pw', b + 'c4.dw', r1, cat[3 * dc:4 * dc], C, dc, **g)
+                if merged:
+                    # 16-bit storage: BSConvU as one dense 3x3 on the matrix cores (+ input from the staged tile, GELU),
+                    # the distillation Linear + GELU as a 1x1 of its own
+                    bs3(b + f'c{j}_r', rin, rout, C, C, res=rin, res_mode=L.RES_PRE_ACT, **g)
+                    plan.conv(b + f'c{j}_d', rin, cat[(j - 1) * dc:j * dc], C, dc, k=1, counted=False, **g)
+                else:
+                    # c{j}_d (Linear + GELU) and c{j}_r = BSConvU (+ input, GELU) read the same tensor: one launch, the
+                    # pointwise result stays in LDS (team18_bsrn.py:150-163)
+                    plan.bsconv(b + f'c{j}_r.pw', b + f'c{j}_r.dw', rin, rout, C, C, res=rin, res_mode=L.RES_PRE_ACT,
+                                distill=dict(w=b + f'c{j}_d', dst=cat[(j - 1) * dc:j * dc], cout=dc, act=L.ACT_GELU), **g)
+            if merged:
+                bs3(b + 'c4', r1, cat[3 * dc:4 * dc], C, dc, **g)
+            else:
+                plan.bsconv(b + 'c4.pw', b + 'c4.dw', r1, cat[3 * dc:4 * dc], C, dc, **g)
             if plan.esize == 2 and (C + 15) // 16 in (3, 4) and f <= 16:
                 # 16-bit storage: esa.conv1 rides in c5's epilogue on the fp32 tile (one launch less per block)
                 plan.conv(b + 'c5', cat, v, 4 * dc, C, k=1, counted=False,
@@ -120,7 +171,10 @@ class BSRN(HipSRModel):
             plan.conv(b + 'conv_out', u, out, C, C, k=1, res=src, res_mode=L.RES_PRE_ACT, counted=False)
             cur = out
         plan.conv('c1', bcat, v, nb * C, C, k=1, counted=False, **g)
-        plan.bsconv('c2.pw', 'c2.dw', v, u, C, C, res=fea, res_mode=L.RES_PRE_ACT)
+        if merged:
+            bs3('c2', v, u, C, C, res=fea, res_mode=L.RES_PRE_ACT)
+        else:
+            plan.bsconv('c2.pw', 'c2.dw', v, u, C, C, res=fea, res_mode=L.RES_PRE_ACT)
         plan.conv('upsampler.upsampleOneStep.0', u, OUTPUT, C, self.out_nc * 16)
 
     # -- complexity counters: what utils/model_summary.py reports for this graph -----------------------------
@@ -136,6 +190,8 @@ class BSRN(HipSRModel):
         if o["kind"] == "bs":                                             # depthwise Conv2d + 1 or 2 Linear calls in one launch
             nlin = 1 + (o["distill"] is not None)
             return 9 * o["cout"] * plan.n * h * w + nlin * plan.n * h * h, o["cout"] * plan.n * h * w, 1
+        if o["kind"] == "conv" and o.get("bs_of") is not None:           # a BSConvU run as a dense 3x3: one Linear + one depthwise Conv2d
+            return 9 * o["cout"] * plan.n * h * w + plan.n * h * h, o["cout"] * plan.n * h * w, 1
         if o["kind"] == "conv" and not o.get("counted", True):
             return plan.n * h * h, 0, 0                                   # a Linear call
         if o["kind"] == "apply":

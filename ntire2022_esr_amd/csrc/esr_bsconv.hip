@@ -36,6 +36,7 @@ constexpr int BNPX = BH * BH;          // 324 halo pixels
 constexpr int BNPT = (BNPX + 15) / 16; // 21 pixel tiles of 16
 constexpr int BPTW = (BNPT + 3) / 4;   // pixel tiles per wave (6)
 constexpr int BMAXC16 = 4;             // cin <= 64
+constexpr int BMAXC32 = 2;             // 16-bit storage: K slots of 32 channels
 constexpr unsigned BOOB = 0x80000000u;
 
 struct BsK {
@@ -159,15 +160,35 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(const BsK p)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int px = lane & 15, kq = lane >> 4;
     const int nc16 = (p.nch8 + 1) >> 1;
-    float* const tl = bsm;                                   // [BNPX][cp] pointwise result
-    float* const ipw = tl + BNPX * p.cp;                     // pointwise weight image
-    float* const idp = ipw + nc16 * NTP * 256;               // distillation weight image
-    float* const sdw = idp + nc16 * NTD * 256;               // depthwise [tap][cp] + bias[cp]
+    const int nc32 = (nc16 + 1) >> 1;
+    const int wimg = S16 ? nc32 * 512 : nc16 * 256;          // floats of weight image per output tile (16-bit: hi + lo images)
+    // pointwise result [BNPX] x tlp bytes: fp32, or fp16 when the storage is fp16 (TL16: half the LDS -- two blocks per CU --
+    // and half the depthwise conv's LDS traffic; 11 mantissa bits, the network's own storage precision).  The pixel pitch
+    // carries 16 pad bytes: at 256 (128) bytes the 16 pixels of a D fragment hit the same banks.
+    constexpr bool TL16 = ST == ESR_STORE_F16;
+    const int tlp = p.cp * (TL16 ? 2 : 4) + 16;
+    char* const tl = reinterpret_cast<char*>(bsm);
+    float* const ipw = bsm + (BNPX * tlp) / 4;               // pointwise weight image
+    float* const idp = ipw + wimg * NTP;                     // distillation weight image
+    float* const sdw = idp + wimg * NTD;                     // depthwise [tap][cp] + bias[cp]
     float* const sb = sdw + 10 * p.cp;                       // pointwise bias [NTP*16], distillation bias [NTD*16]
     if (S16) {
-        // esr_pack_conv_s16(ksize = 1) blobs are [16-channel chunk][tile][lane][8 x 16 bit]: already the lane-linear LDS image
-        for (int i = tid; i < nc16 * NTP * 256; i += 256) ipw[i] = p.pw[i];
-        if (NTD) for (int i = tid; i < nc16 * NTD * 256; i += 256) idp[i] = p.dpw[i];
+        // esr_pack_conv_s16(ksize = 1) blobs are [16-channel chunk][tile][lane = (hi|lo, half, i)][8 x 16 bit].  The LDS images
+        // are [32-channel chunk][tile][lane = kq*16+i][8 x 16 bit] = channels 32C + 8kq .. +7 of output channel i, a hi
+        // image and a lo image: lane (px, kq) of the B operand then holds 16 DISTINCT bytes and the four lanes of a pixel read
+        // 64 contiguous bytes (with the blob's own map lanes kq >= 2 re-read the bytes of kq < 2 for the lo weights).
+        auto build16 = [&](float* img, const float* blob, int ntl) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            for (int u = tid; u < nc32 * ntl * 128; u += 256) {           // 16-byte units: [C][tt][hi|lo][kq][i]
+                const int i = u & 15, kq2 = (u >> 4) & 3, lo = (u >> 6) & 1, ct = u >> 7;
+                const int tt = ct % ntl, C = ct / ntl;
+                const int c16 = 2 * C + (kq2 >> 1);
+                const f32x4 v = c16 < nc16 ? *reinterpret_cast<const f32x4*>(blob + ((size_t)(c16 * ntl + tt) * 64 + lo * 32 + (kq2 & 1) * 16 + i) * 4) : zero;
+                *reinterpret_cast<f32x4*>(img + ((size_t)((C * ntl + tt) * 2 + lo) * 64 + kq2 * 16 + i) * 4) = v;
+            }
+        };
+        build16(ipw, p.pw, NTP);
+        if (NTD) build16(idp, p.dpw, NTD);
     } else {
         build_image<NTP>(ipw, p.pw, p.nch8, tid);
         if (NTD) build_image<(NTD ? NTD : 1)>(idp, p.dpw, p.nch8, tid);
@@ -190,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(const BsK p)
             const_cast<char*>(static_cast<const char*>(p.x) + (size_t)n * img_elems * ES), 0, (int)(img_elems * ES), 0x00020000);
 
         // ---- phase 1: all B fragments of this wave's pixel tiles are requested before the first MFMA ----------------
-        f32x4 b[BPTW][BMAXC16];
+        f32x4 b[BPTW][S16 ? BMAXC32 : BMAXC16];
         bool valid[BPTW];
         int gpix[BPTW];
 #pragma unroll
@@ -201,13 +222,13 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(const BsK p)
             valid[s] = wv + 4 * s < BNPT && pl < BNPX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             gpix[s] = gy * p.W + gx;
             // fp32: lane (px, kq) holds channels 16C + 4kq .. +3 (k slot of the 16x16x4 MFMAs); 16-bit: channels
-            // 16C + 8(kq & 1) .. +7 (16 bytes), lanes kq >= 2 read the same bytes again -- their weight slots carry the lo parts
-            const int chl = S16 ? 8 * (kq & 1) : 4 * kq;
+            // 32C + 8kq .. +7 (16 bytes; the four lanes of a pixel read 64 contiguous bytes)
+            const int chl = S16 ? 8 * kq : 4 * kq;
             const unsigned vo = valid[s] ? (unsigned)(gpix[s] * p.x_pitch + p.x_coff + chl) * (unsigned)ES : BOOB;
 #pragma unroll
-            for (int C = 0; C < BMAXC16; ++C) {
-                const bool ok = C < nc16 && 16 * C + chl < cin_phys;
-                b[s][C] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? vo : BOOB, C * 16 * ES, 0));
+            for (int C = 0; C < (S16 ? BMAXC32 : BMAXC16); ++C) {
+                const bool ok = S16 ? (C < nc32 && 32 * C + chl < cin_phys) : (C < nc16 && 16 * C + chl < cin_phys);
+                b[s][C] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? vo : BOOB, C * (S16 ? 64 : 64), 0));
             }
         }
 #pragma unroll
@@ -219,22 +240,28 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(const BsK p)
 #pragma unroll
             for (int td = 0; td < NTD; ++td) dacc[td] = *reinterpret_cast<const f32x4*>(sb + NTP * 16 + td * 16 + kq * 4);
 #pragma unroll
-            for (int C = 0; C < BMAXC16; ++C) {
-                if (C >= nc16) break;
+            for (int C = 0; C < (S16 ? BMAXC32 : BMAXC16); ++C) {
+                if (C >= (S16 ? nc32 : nc16)) break;
 #pragma unroll
                 for (int tt = 0; tt < NTP; ++tt) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(ipw + ((C * NTP + tt) * 64 + lane) * 4);
-                    if (S16) acc[tt] = mfma16<ST>(a, b[s][C], acc[tt]);
-                    else {
+                    if (S16) {
+                        const float* img = ipw + ((C * NTP + tt) * 128 + lane) * 4;
+                        acc[tt] = mfma16<ST>(*reinterpret_cast<const f32x4*>(img), b[s][C], acc[tt]);
+                        acc[tt] = mfma16<ST>(*reinterpret_cast<const f32x4*>(img + 256), b[s][C], acc[tt]);       // lo weights
+                    } else {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(ipw + ((C * NTP + tt) * 64 + lane) * 4);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[s][C][j], acc[tt], 0, 0, 0);
                     }
                 }
 #pragma unroll
                 for (int td = 0; td < NTD; ++td) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(idp + ((C * NTD + td) * 64 + lane) * 4);
-                    if (S16) dacc[td] = mfma16<ST>(a, b[s][C], dacc[td]);
-                    else {
+                    if (S16) {
+                        const float* img = idp + ((C * NTD + td) * 128 + lane) * 4;
+                        dacc[td] = mfma16<ST>(*reinterpret_cast<const f32x4*>(img), b[s][C], dacc[td]);
+                        dacc[td] = mfma16<ST>(*reinterpret_cast<const f32x4*>(img + 256), b[s][C], dacc[td]);
+                    } else {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(idp + ((C * NTD + td) * 64 + lane) * 4);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) dacc[td] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[s][C][j], dacc[td], 0, 0, 0);
                     }
@@ -245,7 +272,17 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(const BsK p)
             if (pl < BNPX) {
 #pragma unroll
                 for (int tt = 0; tt < NTP; ++tt)
-                    if (tt * 16 + kq * 4 < p.cp) *reinterpret_cast<f32x4*>(tl + pl * p.cp + tt * 16 + kq * 4) = valid[s] ? acc[tt] : zero;
+                    if (tt * 16 + kq * 4 < p.cp) {
+                        const f32x4 v = valid[s] ? acc[tt] : zero;
+                        if (TL16) {
+                            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                            h2 lo2, hi2;
+                            lo2[0] = (_Float16)v.x; lo2[1] = (_Float16)v.y; hi2[0] = (_Float16)v.z; hi2[1] = (_Float16)v.w;
+                            *reinterpret_cast<uint2*>(tl + pl * tlp + (tt * 16 + kq * 4) * 2) = uint2{__builtin_bit_cast(unsigned, lo2), __builtin_bit_cast(unsigned, hi2)};
+                        } else {
+                            *reinterpret_cast<f32x4*>(tl + pl * tlp + (tt * 16 + kq * 4) * 4) = v;
+                        }
+                    }
             }
             if (NTD) {
                 const int ly = pl / BH, lx = pl - ly * BH;
@@ -298,8 +335,18 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(const BsK p)
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx)
-                        a += *reinterpret_cast<const f32x4*>(tl + ((oy + ky) * BH + ox + kx) * p.cp + q * 4) * wreg[ky * 3 + kx];
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const char* src = tl + ((oy + ky) * BH + ox + kx) * tlp;
+                        const f32x4 w = wreg[ky * 3 + kx];
+                        if (TL16) {
+                            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                            const h4 h = *reinterpret_cast<const h4*>(src + q * 8);
+                            a.x = fmaf((float)h[0], w.x, a.x); a.y = fmaf((float)h[1], w.y, a.y);       // v_fma_mix_f32: the conversion is free
+                            a.z = fmaf((float)h[2], w.z, a.z); a.w = fmaf((float)h[3], w.w, a.w);
+                        } else {
+                            a += *reinterpret_cast<const f32x4*>(src + q * 16) * w;
+                        }
+                    }
                 if (p.res_mode == ESR_RES_PRE_ACT) a += rv;
                 a.x = bs_act<ST>(a.x, p.act, p.slope); a.y = bs_act<ST>(a.y, p.act, p.slope);
                 a.z = bs_act<ST>(a.z, p.act, p.slope); a.w = bs_act<ST>(a.w, p.act, p.slope);
@@ -397,7 +444,9 @@ extern "C" int esr_bsconv_f32(const esr_bsconv_desc* d, void* hip_stream)
     k.act = d->act; k.res_mode = d->res_mode; k.d_act = d->d_act; k.slope = d->slope;
     k.tiles_x = (d->w + BT - 1) / BT; k.tiles_y = (d->h + BT - 1) / BT;
     const int nc16 = (k.nch8 + 1) / 2;
-    const size_t lds = ((size_t)BNPX * cp + (size_t)nc16 * (ntp + ntd) * 256 + 10 * cp + (ntp + ntd) * 16) * sizeof(float);
+    const int tlp = cp * (d->storage == ESR_STORE_F16 ? 2 : 4) + 16;
+    const size_t wimg = s16 ? (size_t)((nc16 + 1) / 2) * 512 : (size_t)nc16 * 256;
+    const size_t lds = (size_t)BNPX * tlp + (wimg * (ntp + ntd) + 10 * cp + (ntp + ntd) * 16) * sizeof(float);
     if (lds > 160 * 1024) return ESR_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     switch (d->storage) {

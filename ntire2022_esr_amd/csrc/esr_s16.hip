@@ -69,6 +69,7 @@ struct S16K {
     float slope;          // LeakyReLU slope; the kernel evaluates max(v, slope * v): 1 = identity, 0 = ReLU
     int res_mode;         // residual read from HBM (0 = none)
     int res_in;           // pre-activation residual == the conv input: added from the staged tile in LDS, no loads
+    int nres;             // residual from HBM staged like input chunks: this many extra 16-channel stages per tile (PNT1 == 0 kernels)
     int out_layout;
     int tiles_x, tiles_y;
     unsigned magic_x, magic_y;   // ceil(2^32 / tiles): t / tiles == umulhi(t, magic) for t * tiles < 2^32 (0: tiles == 1)
@@ -80,6 +81,7 @@ struct S16K {
     float p1_slope;                        // activation of post 1 as max(v, slope v)
     int post_lo;                           // the low-part weight images are resident too (w = hi + lo)
     int store_main;                        // 0: the conv's own result is consumed by the post chain only
+    const float* border;                   // esr_conv_desc.border_bias (PNT1 == 0 kernels), or NULL
 };
 
 template <bool BF16>
@@ -262,7 +264,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     // post images: [post 1: NT k-tiles x PNT1 tiles, hi (then lo)][post 2: PNT1 k-tiles x PNT2 tiles, hi (then lo)][biases, 1 KB]
     constexpr int P1_IMG = NT * PNT1 * 1024, P2_IMG = PNT1 * PNT2 * 1024;
     const int plo = (PNT1 > 0 && p.post_lo) ? 2 : 1;
-    const int w_bytes = w_main + (PNT1 > 0 ? plo * (P1_IMG + P2_IMG) + 1024 : 0);
+    const int w_bytes = w_main + (PNT1 > 0 ? plo * (P1_IMG + P2_IMG) + 1024 : (p.border ? NT * 1024 : 0) + 1024);
+    // the conv's own bias (NT * 16 floats): the upper half of the post-bias KB, or a KB of its own (PNT1 == 0)
+    float* const sbias = reinterpret_cast<float*>(smem + w_bytes - 512);
+    float* const btab = reinterpret_cast<float*>(smem + w_main);          // border bias table [16][NT * 16] (PNT1 == 0)
     const char* const pimg1 = smem + w_main;
     const char* const pimg2 = pimg1 + plo * P1_IMG;
     float* const pbias = reinterpret_cast<float*>(smem + w_main + plo * (P1_IMG + P2_IMG));
@@ -304,14 +309,18 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     int lc = 0;                   // chunk of the cursor
     int lslot = 0;
     bool lvalid;
-    unsigned lvoff[PPW];
-    i32x4 lrsrc;
+    static_assert(PPW <= 3, "lvr0..2");
+    unsigned lvoff[PPW];                   // input
+    unsigned lvr0 = OOB, lvr1 = OOB, lvr2 = OOB;     // residual (p.nres > 0: staged as extra chunks, added from LDS -- no registers in flight); scalars: as an array hipcc kept it in scratch
+    auto LVR = [&](int i) __attribute__((always_inline)) -> unsigned& { return i == 0 ? lvr0 : (i == 1 ? lvr1 : lvr2); };
+    i32x4 lrsrc, lrsrcr = {0, 0, 0, 0};
+    const int nstages = p.nchunks + (PNT1 == 0 ? p.nres : 0);       // stages per tile
     auto cursor_tile = [&]() __attribute__((always_inline)) {
         const int t = tile_index(lk);
         lvalid = t >= 0;
         if (!lvalid) {
 #pragma unroll
-            for (int r = 0; r < PPW; ++r) lvoff[r] = OOB;
+            for (int r = 0; r < PPW; ++r) { lvoff[r] = OOB; LVR(r) = OOB; }
             return;
         }
         int n, x0, y0;
@@ -320,6 +329,12 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         const int qH = q->H, qW = q->W, qpitch = q->in_pitch, qcoff = q->in_coff;
         const size_t img_bytes = (size_t)qH * qW * qpitch * 2;
         lrsrc = make_rsrc(q->x + (size_t)n * img_bytes, img_bytes);
+        const bool withres = PNT1 == 0 && q->nres > 0;
+        const int qrp = q->res_pitch, qrc = q->res_coff;
+        if (withres) {
+            const size_t res_bytes = (size_t)qH * qW * qrp * 2;
+            lrsrcr = make_rsrc(q->res + (size_t)n * res_bytes, res_bytes);
+        }
 #pragma unroll
         for (int r = 0; r < PPW; ++r) {
             const int pc = wv + NW * r;
@@ -329,16 +344,20 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
             const int gy = y0 - HALO + ly, gx = x0 - HALO + lx;
             const bool ok = pc < NPIECES && pl < NPX && (unsigned)gy < (unsigned)qH && (unsigned)gx < (unsigned)qW;
             lvoff[r] = ok ? (unsigned)((gy * qW + gx) * qpitch + qcoff + 8 * plane) * 2u : OOB;
+            LVR(r) = (ok && withres) ? (unsigned)((gy * qW + gx) * qrp + qrc + 8 * plane) * 2u : OOB;
         }
     };
     auto dma_piece = [&](int i) __attribute__((always_inline)) {       // piece i of this wave of the cursor's stage, into ring slot lslot
         const int pc = wv + NW * i;
-        if (NPIECES % NW == 0 || i < PPW - 1 || pc < NPIECES)           // wave-uniform
-            dma_buf16(ring_lds + (unsigned)(lslot * STAGE_BYTES) + (unsigned)pc * 1024u, lvoff[i], lrsrc, (unsigned)lc * 32u);
+        if (NPIECES % NW == 0 || i < PPW - 1 || pc < NPIECES) {         // wave-uniform
+            const unsigned dst = ring_lds + (unsigned)(lslot * STAGE_BYTES) + (unsigned)pc * 1024u;
+            if (PNT1 == 0 && lc >= p.nchunks) dma_buf16(dst, LVR(i), lrsrcr, (unsigned)(lc - p.nchunks) * 32u);     // a residual chunk
+            else dma_buf16(dst, lvoff[i], lrsrc, (unsigned)lc * 32u);
+        }
     };
     auto cursor_advance = [&]() __attribute__((always_inline)) {
         lslot = lslot == R - 1 ? 0 : lslot + 1;
-        if (++lc == p.nchunks) {
+        if (++lc == nstages) {
             lc = 0;
             ++lk;
             cursor_tile();
@@ -361,6 +380,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
             if (PNT2 > 0 && tid < PNT2 * 16) pbias[PNT1 * 16 + tid] = reinterpret_cast<const float*>(p.pw2 + 2 * P2_IMG)[tid];
         }
     }
+    if (PNT1 == 0 && p.border)
+        for (int i = tid; i < 16 * NT * 16; i += 64 * NW) btab[i] = p.border[i];
+    if (tid < NT * 16) sbias[tid] = p.bias[tid];
     cursor_tile();
     if (!lvalid) return;                 // block without tiles (grid <= ntiles: does not happen)
     for (int i = 0; i < R - 1; ++i) {
@@ -369,12 +391,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         cursor_advance();
     }
     wait_vm_dyn((R - 2) * n_my);         // the weights and stage 0 have landed
-    if (PNT1 > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the post biases written above
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the biases / border table written above
     __builtin_amdgcn_s_barrier();
 
-    f32x4 biasv[NT];
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) biasv[tt] = *reinterpret_cast<const f32x4*>(p.bias + tt * 16 + kq * 4);
+    // (the bias is re-read from LDS by each tile's first MFMA group: NT * 4 registers less across the whole loop)
 
     // lane-constant LDS offsets of the B fragments: pair q reads tap min(2q + (kq >> 1), TAPS - 1), channel half kq & 1
     int b_off[PAIRS];
@@ -396,19 +416,25 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     const int epi_stores = PNT1 > 0 ? (p.store_main ? 2 * RW : 0) + 2 * RW + (PNT2 > 0 ? RW : 0)
                                     : (p.out_layout == ESR_NCHW_SHUFFLE4 ? RW * NT : (p.split < p.cout_store ? 2 : 1) * SWAP_STORES);   // stores per wave and tile
     const unsigned hmask = (1u << (R - 2)) - 1u;
-    unsigned hist_rs = 0, hist_st = 0;   // bit i: stage s - i was a tile's last stage (residual loads) / carried an epilogue's stores
+    unsigned hist_rs = 0, hist_st = 0;   // bit i: stage s - i was a tile's first stage (residual loads) / carried an epilogue's stores
 
     f32x4 acc[NT][RW];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) acc[tt][r] = f32x4{0.f, 0.f, 0.f, 0.f};
     uint2 rv[GRES ? NT : 1][RW];         // residual of the current tile in D-fragment layout (hidden asm loads)
 #pragma unroll
     for (int tt = 0; tt < (GRES ? NT : 1); ++tt)
 #pragma unroll
         for (int r = 0; r < RW; ++r) rv[tt][r] = uint2{0u, 0u};
 
-    // issued in a tile's LAST stage (behind the previous tile's epilogue, which frees rv; in front of the stage's DMA), one
-    // stage before the tile's epilogue wants them.  Not earlier: hipcc believes the asm's outputs are valid at once, so it may
-    // copy / spill the registers before the data has arrived -- the shorter their life, the less it is tempted (with the loads
-    // in the tile's first stage the 64-channel variants did exactly that: tools/dbg/s16_shape_probe.py).
+    // Issued in a tile's FIRST stage, behind the previous tile's epilogue (which frees rv) and in front of the stage's DMA: by
+    // the time the tile's own epilogue wants them, nchunks stages of DMA are younger and stay in flight.  hipcc believes the
+    // asm's outputs are valid at once, so NOTHING may make it copy these registers before the wait: there is exactly ONE load
+    // site per kernel (two sites feeding one consumer meet in a phi, and the copies of the losing site run before the data
+    // has arrived -- seen with cin = 16), it lies behind the last use of the previous values (no interference, the loop-carried
+    // registers coalesce), and the GRES variants stay clear of spills (tools/dbg/s16_shape_probe.py, test_s16_conv_more_tiles_*).
     auto load_residual = [&](int n, int x0, int y0, bool have) __attribute__((always_inline)) {
         if (!GRES) return;
         const kparg_t q = KP();
@@ -428,47 +454,63 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
             for (int tt = 0; tt < NT; ++tt) {
                 const int cb = tt * 16 + kq * 4;
                 const unsigned vo = (inx && cb < qcs) ? rbase + (unsigned)r * rowb + (unsigned)tt * 32u : OOB;
-                asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(rv[GRES ? tt : 0][r]) : "v"(vo), "s"(rru) : "memory");
+                // "+v": the destination is TIED to the loop-carried register of rv, so the value never has to be copied into it
+                // at the loop latch (with "=v" hipcc gave the asm fresh registers and moved them over before the data was there)
+                asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "+v"(rv[GRES ? tt : 0][r]) : "v"(vo), "s"(rru) : "memory");
             }
         }
     };
 
     const bool act_gelu = p.act == ESR_ACT_GELU;
-    // waits for the finished tile's residual (loaded in its last stage, in front of that stage's DMA pieces)
+    // waits for the finished tile's residual (loaded in its first stage: the tile's nchunks stages of DMA are younger)
     auto wait_residual = [&]() __attribute__((always_inline)) {
         if (!GRES) return;
-        wait_vm_dyn(n_my);
+        wait_vm_dyn(p.nchunks * n_my);
 #pragma unroll
         for (int tt = 0; tt < (GRES ? NT : 1); ++tt)
 #pragma unroll
             for (int r = 0; r < RW; ++r) asm volatile("" : "+v"(rv[tt][r]));      // uses below stay behind the wait
     };
 
-    // GELU (and a pre-activation residual under it), applied to the accumulators at the end of the tile's last stage; the
-    // epilogue then sees an identity activation.  One fragment at a time (sched_barrier): register pressure stays flat.
+    // GELU, applied to the accumulators at the end of the tile's last stage; the epilogue then sees an identity activation.
+    // One fragment at a time (sched_barrier): register pressure stays flat.  A residual loaded from HBM can only follow the
+    // GELU (post-activation): its registers are in flight here and must not be touched -- not even by an empty asm, whose
+    // re-definition makes hipcc copy them on the paths that skip it (the host rejects GELU + pre-activation residual from HBM;
+    // the residual == input case comes from the staged tile and is already in the accumulators).
     auto gelu_inplace = [&]() __attribute__((always_inline)) {
-        const bool pre = GRES && KP()->res_mode == ESR_RES_PRE_ACT;
-        if (pre) wait_residual();        // issued at the top of this very stage: only its DMA pieces are younger
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
                 f32x4 v = acc[tt][r];
-                if (GRES) {
-                    const f32x4 rf = unpack4<BF16>(rv[GRES ? tt : 0][r]);
-                    if (pre) v += rf;
-                }
                 v.x = gelu16(v.x); v.y = gelu16(v.y); v.z = gelu16(v.z); v.w = gelu16(v.w);
                 acc[tt][r] = v;
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
 
+    // esr_conv_desc.border_bias: tiles on the image border add the table row of each pixel's outside-mask (row 0 = zeros for
+    // the interior pixels of such a tile), at the end of the tile's last stage -- in front of residual, GELU and the epilogue
+    auto border_fix = [&](int x0, int y0) __attribute__((always_inline)) {
+        const kparg_t q = KP();
+        const int qH = q->H, qW = q->W;
+        if (!(x0 == 0 || x0 + TILE >= qW || y0 == 0 || y0 + TILE_H >= qH)) return;
+        const int gx = x0 + px;
+        const int cm = (gx == 0 ? 1 : 0) | (gx == qW - 1 ? 2 : 0);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int gy = y0 + wv * RW + r;
+            const int m = cm | (gy == 0 ? 4 : 0) | (gy == qH - 1 ? 8 : 0);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) acc[tt][r] += *reinterpret_cast<const f32x4*>(btab + m * (NT * 16) + tt * 16 + kq * 4);
+        }
+    };
+
     // epilogue as a phase: pixel-shuffle output (PNT1 == 0) or the post chain (PNT1 > 0)
     auto epilogue = [&](int n, int x0, int y0) __attribute__((always_inline)) {
         const kparg_t q = KP();
         const int qH = q->H, qW = q->W, qcs = q->cout_store, qsplit = q->split;
-        const int qres_mode = (act_gelu && q->res_mode == ESR_RES_PRE_ACT) ? ESR_RES_NONE : q->res_mode;     // GELU: already in the accumulators
+        const int qres_mode = q->res_mode;
         const float qslope = act_gelu ? 1.f : q->slope;
         const bool shuffle = q->out_layout == ESR_NCHW_SHUFFLE4;
         const bool has_split = !shuffle && qsplit < qcs;
@@ -646,8 +688,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         const kparg_t q = KP();
         const int qH = q->H, qW = q->W, qcs = q->cout_store, qsplit = q->split;
         const int qy0p = q->y0_pitch, qy0c = q->y0_coff, qy1p = q->y1_pitch, qy1c = q->y1_coff;
-        e_slope = act_gelu ? 1.f : q->slope;
-        e_res_mode = (act_gelu && q->res_mode == ESR_RES_PRE_ACT) ? ESR_RES_NONE : q->res_mode;    // GELU: already in the accumulators
+        e_slope = (act_gelu || (q->nres > 0 && q->res_mode == ESR_RES_POST_ACT)) ? 1.f : q->slope;     // applied in place already
+        e_res_mode = q->res_mode;
         e_split = qsplit < qcs;
         const size_t y0_img = (size_t)qH * qW * qy0p * 2, y1_img = (size_t)qH * qW * qy1p * 2;
         e_y0 = q->y0 + (size_t)pn * y0_img; e_y0n = (int)y0_img;
@@ -657,7 +699,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         const unsigned srow = (unsigned)((py0 + wv * RW) * qW + px0);            // wave-uniform: pixel (row 0, px = 0) of this wave
         const unsigned s0 = srow * (unsigned)qy0p * 2u, s1 = srow * (unsigned)qy1p * 2u;
         const unsigned l0 = (__umul24(px, qy0p) + (unsigned)qy0c) * 2u, l1 = (__umul24(px, qy1p) + (unsigned)(qy1c - qsplit)) * 2u;
-        const bool inx = px0 + px < qW;
+        const bool inx = pend && px0 + px < qW;       // nothing pending (the block's first stage): every store out of range
         // rows below the image fall past num_records (= the image's bytes): dropped by the hardware
 #pragma unroll
         for (int j = 0; j < NPAIR; ++j) {
@@ -729,6 +771,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                 if (q + 1 < PAIRS) load_frag(cs ^ 1, q + 1);
                 __builtin_amdgcn_sched_barrier(0);      // keep the prefetch above this pair's MFMAs
             } else {
+                // single fragment set: the barrier keeps hipcc from hoisting the later groups' reads (it would, into every free
+                // register and then some: the 64-channel residual variants spilled the in-flight residual registers)
+                if (GRES && NT == 4 && q > 0) __builtin_amdgcn_sched_barrier(0);
                 load_frag(0, q);
             }
             if (q == 0 && EPI) {
@@ -737,8 +782,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                 for (int r = 0; r < RW; ++r) {
                     swap_epi_act(r);
 #pragma unroll
-                    for (int tt = 0; tt < NT; ++tt) acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], biasv[tt]);
+                    for (int tt = 0; tt < NT; ++tt) acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], *reinterpret_cast<const f32x4*>(sbias + tt * 16 + kq * 4));
                     if (r & 1) swap_epi_store(r);
+                    if (GRES && NT == 4) __builtin_amdgcn_sched_barrier(0);      // keeps the rows' residual unpacking from piling up (spills)
                 }
             } else if (q == 0 && first) {
                 // first MFMA group of a tile: the accumulator input is the bias
@@ -746,14 +792,14 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                 for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
                     for (int r = 0; r < RW; ++r)
-                        acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], biasv[tt]);
+                        acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], *reinterpret_cast<const f32x4*>(sbias + tt * 16 + kq * 4));
             } else {
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
                     for (int r = 0; r < RW; ++r) acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], acc[tt][r]);
             }
-            if (q == 0 && last) load_residual(n, x0, y0, have);      // this tile's residual: behind the epilogue, in front of the DMA
+            if (q == 0 && (EPI || (PNT1 > 0 && first))) load_residual(n, x0, y0, have);   // this tile's residual (the ONE load site): behind the epilogue, in front of the DMA
             if (q < PPW) dma_piece(q);                               // the DMA issue rides in the shadow of the matrix pipe
         }
 #pragma unroll
@@ -772,7 +818,45 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                 }
             }
         }
-        if (last && act_gelu) gelu_inplace();
+        if (PNT1 == 0 && c == p.nchunks - 1 && p.border) border_fix(x0, y0);
+        if (last && act_gelu) gelu_inplace();        // (`last` is a residual stage when there are any: residual_stage applies it)
+    };
+
+    // ---- a residual stage (p.nres > 0): the residual tensor's channels 16t .. 16t+15 were staged like an input chunk; the centre
+    // pixels are added to accumulator tile t from LDS.  Same DMA type, same ring, same counted waits as the input: nothing rides
+    // in registers while in flight (asm loads into VGPRs did, and hipcc copied those registers before the data was there).
+    auto residual_stage = [&](int c, bool last) __attribute__((always_inline)) {
+        const char* sb = ring + slot * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma_piece(i);
+        const bool post = KP()->res_mode == ESR_RES_POST_ACT;
+        if (post && c == p.nchunks) {
+            // act(conv) + res: the activation goes first, on the accumulators (the epilogue then sees slope 1)
+            if (act_gelu) {
+                gelu_inplace();
+            } else {
+                const float sl = KP()->slope;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) {
+                        f32x4 v = acc[tt][r];
+                        v.x = act1(v.x, sl); v.y = act1(v.y, sl); v.z = act1(v.z, sl); v.w = act1(v.w, sl);
+                        acc[tt][r] = v;
+                    }
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            int cc = c - p.nchunks;
+            asm volatile("" : "+s"(cc));      // opaque per tile (see the res_in block of compute)
+            if (tt == cc) {
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+                    acc[tt][r] += unpack4<BF16>(*reinterpret_cast<const uint2*>(sb + c_off + r * (TH * 32)));
+            }
+        }
+        if (last && act_gelu && !post) gelu_inplace();
     };
 
     for (int k = 0;; ++k) {
@@ -782,22 +866,23 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         have = t >= 0;
         if (!have && !pend) break;
         if (have) tile_coords(t, n, x0, y0);
-        const int nst = have ? p.nchunks : 1;
+        const int nst = have ? nstages : 1;
         for (int c = 0; c < nst; ++c) {
             const bool last = c == nst - 1;
-            hist_rs = (hist_rs << 1) | (last ? 1u : 0u);
+            hist_rs = (hist_rs << 1) | (c == 0 ? 1u : 0u);
             hist_st <<= 1;
-            bool done = false;
-            if (c == 0 && pend) {
+            if (c == 0 && swap_epi) {
+                // always through the epilogue-carrying instance (the block's first tile: nothing pending, stores out of range)
                 hist_st |= 1u;
-                if (!swap_epi) {
+                compute(std::true_type{}, 0, last);
+            } else {
+                if (c == 0 && pend) {
+                    hist_st |= 1u;
                     epilogue(pn, px0, py0);
-                } else {
-                    compute(std::true_type{}, 0, last);
-                    done = true;
                 }
+                if (PNT1 == 0 && c >= p.nchunks) residual_stage(c, last);
+                else compute(std::false_type{}, c, last);
             }
-            if (!done) compute(std::false_type{}, c, last);
             cursor_advance();
             // ---- sync: stage s+1 has landed; everything issued after its DMA may stay in flight -------------------------
             // its DMA was issued R-2 stages ago, behind that stage's own stores / residual loads: younger are the DMA of the
@@ -843,7 +928,7 @@ int launch_s16_nt(int nt, const S16K& k, size_t lds, hipStream_t st)
 template <int KS, bool BF16>
 int launch_s16_res(int nt, const S16K& k, size_t lds, hipStream_t st)
 {
-    return k.res_mode != ESR_RES_NONE ? launch_s16_nt<KS, BF16, true>(nt, k, lds, st) : launch_s16_nt<KS, BF16, false>(nt, k, lds, st);
+    return launch_s16_nt<KS, BF16, false>(nt, k, lds, st);        // (a residual from HBM is staged through LDS: S16K.nres)
 }
 
 // the post-chain variants that exist: (kernel size, main tiles, residual from HBM, post-1 tiles, post-2 tiles)
@@ -1084,6 +1169,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     if (d->in_layout != ESR_NHWC) return ESR_ERR_UNSUPPORTED;                                  // the NCHW head runs on conv_f32_kernel
     if (d->tail_wpacked) return ESR_ERR_UNSUPPORTED;
     const bool post = d->post_wpacked != nullptr;
+    if (d->border_bias && (post || d->out_layout != ESR_NHWC)) return ESR_ERR_UNSUPPORTED;
     if (!post && d->post2_wpacked) return ESR_ERR_BAD_ARG;
     if ((d->in.pitch & 7) || (d->in.coff & 7)) return ESR_ERR_BAD_ARG;                         // 16-byte granules
     const int cin_phys = esr_round_up(d->cin, 16);
@@ -1126,8 +1212,9 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         }
         if (d->post_act != ESR_ACT_NONE && d->post_act != ESR_ACT_LRELU && d->post_act != ESR_ACT_RELU) return ESR_ERR_UNSUPPORTED;
     } else {
-        while (ring > RING_MIN && s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, ring) > (size_t)LDS_LIMIT) --ring;
-        lds = s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, ring);
+        const size_t extra = (d->border_bias ? (size_t)nt * 1024 : 0) + 1024;      // border table, the bias KB
+        while (ring > RING_MIN && s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, ring, extra) > (size_t)LDS_LIMIT) --ring;
+        lds = s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, ring, extra);
     }
     if (lds > (size_t)LDS_LIMIT) return ESR_ERR_UNSUPPORTED;                                     // weight set too large to stay resident
     if (!shuffle && d->out0.ptr) {
@@ -1159,11 +1246,14 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     k.slope = d->act == ESR_ACT_LRELU ? d->slope : (d->act == ESR_ACT_RELU ? 0.f : 1.f);
     k.res_mode = d->res_mode;
     k.res_in = 0;
+    k.nres = 0;
     if (d->ksize == 3 && d->res_mode == ESR_RES_PRE_ACT && d->cin == d->cout && d->res.ptr == d->in.ptr &&
         d->res.pitch == d->in.pitch && d->res.coff == d->in.coff) {
         k.res_in = 1;                               // residual == input: added from the staged tile, no residual loads
         k.res_mode = ESR_RES_NONE;
     }
+    if (!post && k.res_mode != ESR_RES_NONE) k.nres = nt;          // residual from HBM: staged as nt extra chunks per tile
+    if (post && d->act == ESR_ACT_GELU && k.res_mode == ESR_RES_PRE_ACT) return ESR_ERR_UNSUPPORTED;   // post chain: the residual rides in registers, behind the in-place GELU
     k.out_layout = d->out_layout;
     k.tiles_x = (d->w + TILE - 1) / TILE;
     k.tiles_y = (d->h + 31) / 32;
@@ -1180,6 +1270,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     k.p1_slope = d->post_act == ESR_ACT_LRELU ? d->slope : (d->post_act == ESR_ACT_RELU ? 0.f : 1.f);
     k.post_lo = post_lo;
     k.store_main = d->out0.ptr ? 1 : 0;
+    k.border = d->border_bias;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     if (post) {
         const bool gres = k.res_mode != ESR_RES_NONE;

@@ -202,17 +202,20 @@ class Plan:
         return b
 
     def conv(self, wname, src, dst, cin, cout, k=3, act=L.ACT_NONE, slope=0.05,
-             res=None, res_mode=L.RES_NONE, dst1=None, split=0, hw=None, counted=True, tail=None, post=None, cin_alg=None):
+             res=None, res_mode=L.RES_NONE, dst1=None, split=0, hw=None, counted=True, tail=None, post=None, cin_alg=None,
+             border=None, bs_of=None):
         """src/dst/res: INPUT | OUTPUT | Buffer | (Buffer, coff, channels).  hw: spatial dims if not full-res.
         counted=False marks launches that are not an nn.Conv2d call of the reference (complexity counters).
         tail = dict(w=<1x1 weight name>, cat=<view of its other input channels>, cat_c, cout, mid_act): the 3x3 result
         (cout <= 16) feeds a fused 1x1 (esr_conv_desc.tail_*); dst/res/act/split then belong to the 1x1.
         post = dict(w=<1x1 weight name>, dst=<view>, cout, act): a 1x1 of this conv's activated output, stored to `dst`
         by the same launch (esr_conv_desc.post_*).  cin_alg: logical input channels when `cin` counts the pad slots of a
-        padded concat buffer (algorithmic flops / bytes)."""
+        padded concat buffer (algorithmic flops / bytes).  border: name of an esr_conv_desc.border_bias table.  bs_of: this
+        dense 3x3 stands for a BSConvU (pointwise 1x1 + depthwise 3x3 with merged weights): its algorithmic flops and its
+        complexity-counter terms are the BSConvU's."""
         self.ops.append(dict(kind="conv", w=wname, src=src, dst=dst, dst1=dst1, cin=cin, cout=cout, k=k, act=act,
                              slope=slope, res=res, res_mode=res_mode, split=split, hw=hw, counted=counted, tail=tail,
-                             post=post, cin_alg=cin if cin_alg is None else cin_alg))
+                             post=post, cin_alg=cin if cin_alg is None else cin_alg, border=border, bs_of=bs_of))
 
     def dwconv(self, wname, src, dst, c, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.RES_NONE, hw=None):
         """depthwise 3x3 + bias (+res) (+act): the dw half of BSConvU."""
@@ -326,6 +329,8 @@ class Plan:
                 d.compute = st
             else:
                 d.wpacked = ctypes.c_void_p(weights[o["w"]].data_ptr())
+            if o.get("border") is not None:
+                d.border_bias = ctypes.c_void_p(weights[o["border"]].data_ptr())
             t = o.get("tail")
             if t is not None:
                 d.tail_wpacked = ctypes.c_void_p(weights[t["w"]].data_ptr())
@@ -653,6 +658,9 @@ class HipSRModel(nn.Module):
                 rd = npix * (ca * e_in + (o["cout"] * e_act if o["res"] is not None else 0)) + 4.0 * ca * o["cout"] * o["k"] ** 2
                 wr = float(npix * o["cout"] * e_out) if o["dst"] is not None else 0.0
                 flops = 2.0 * npix * ca * o["cout"] * o["k"] * o["k"]
+                if o.get("bs_of") is not None:      # the BSConvU it stands for: pointwise GEMM + depthwise 3x3
+                    flops = 2.0 * npix * (ca * o["cout"] + 9 * o["cout"])
+                    rd = npix * (ca * e_in + (o["cout"] * e_act if (o["res"] is not None and o["res"] is not o["src"]) else 0)) + 4.0 * (ca * o["cout"] + 10 * o["cout"])
                 t = o.get("tail")
                 if t is not None:                   # 3x3 -> 1x1 in one kernel: both GEMMs' flops, the 1x1's traffic
                     kern = f"conv_f32_kernel<NT={nt},KS=3,NCHW_IN=0,NW=4,TAIL={(t['cout'] + 15) // 16}>"

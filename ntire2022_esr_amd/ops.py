@@ -21,7 +21,8 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
            in_nchw=False, shuffle_out=False, out=None, out_coff=0, in_coff=0, cin=None,
            split=0, out1=None, out1_coff=0, res_coff=0, packed=None, cin_map=None, store=None,
            tail_weight=None, tail_bias=None, tail_cat=None, tail_cat_coff=0, tail_mid_act=L.ACT_NONE,
-           post_weight=None, post_bias=None, post_act=L.ACT_NONE, post2_weight=None, post2_bias=None, store_main=True):
+           post_weight=None, post_bias=None, post_act=L.ACT_NONE, post2_weight=None, post2_bias=None, store_main=True,
+           border=None):
     """Fused conv (k=1|3, stride 1, same padding) on the current stream.
 
     x       NHWC [N,H,W,pitch] (channels [in_coff, in_coff+cin) are read) or NCHW fp32 if in_nchw.  The dtype of an NHWC
@@ -32,6 +33,7 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
     post_*  esr_conv_desc.post_*: post_weight [pc, cout(, 1, 1)] applied to this conv's activated output; returns (y, post).
             16-bit storage: applied to the finished fp32 result (residual included); post2_weight [pc2, pc] chains a second 1x1
             on the first (returns (y, post, post2)); store_main=False does not store y (returns None in its place)
+    border  esr_conv_desc.border_bias: fp32 [16, round_up(cout, 16)] table added by outside-mask (16-bit storage only)
     tail_*  fused 1x1 (esr_conv_desc.tail_*): tail_weight [cout1, cat_c + 16(, 1, 1)] over concat(tail_cat slice,
             mid_act(this 3x3 conv)); act / res / out then apply to the 1x1, whose output is returned
     """
@@ -68,6 +70,10 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
         d.tail_cat_c, d.tail_cout, d.tail_mid_act = tw.shape[1] - 16, tw.shape[0], tail_mid_act
         cout = tw.shape[0]                      # what the epilogue stores
     d.act, d.slope, d.res_mode, d.split = act, slope, res_mode, split
+    if border is not None:
+        if border.dtype != torch.float32 or not border.is_contiguous() or tuple(border.shape) != (16, (cout + 15) // 16 * 16):
+            raise L.EsrError("conv2d: border must be a contiguous fp32 [16, round_up(cout, 16)] tensor")
+        d.border_bias = ctypes.c_void_p(border.data_ptr())
     if shuffle_out:
         y = torch.empty((n, cout // 16, 4 * h, 4 * w), dtype=torch.float32, device=x.device) if out is None else out
         d.out_layout = L.NCHW_SHUFFLE4

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libesr_hip.so does not export {s}"
     assert set(L.EXPORTS) == set(syms), (set(L.EXPORTS) ^ set(syms))
-    assert lib.esr_abi_version() == 4
+    assert lib.esr_abi_version() == 5
     assert b"gfx950" in lib.esr_build_info()
 
 

@@ -158,3 +158,43 @@ def test_fused_bsconv(cin, c, dco, n, hw, act, res_mode):
         y = ops.bsconv(xg.to(DEV), pw, pb, dw, db, **kw)
     y = y.cpu().permute(0, 3, 1, 2)[:, :c]
     assert float((y - ref).abs().max()) / max(1.0, float(ref.abs().max())) < TOL
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
+@pytest.mark.parametrize("n,cin,c,hw,act,res_mode", [(2, 48, 48, (33, 21), 3, 1), (1, 48, 24, (20, 40), 3, 0), (1, 64, 64, (64, 17), 0, 2),
+                                                    (1, 48, 48, (270, 480), 3, 1), (2, 16, 16, (1, 50), 0, 0), (1, 32, 32, (37, 1), 1, 0)])
+def test_bsconv_as_dense3x3_with_border_table(compute, n, cin, c, hw, act, res_mode):
+    """BSConvU through conv_s16_kernel: merged weights dw[c,tap] * pw[c,k] + esr_conv_desc.border_bias (BSRN._merged_bsconv).
+    Reference: the dense conv with the blob's EFFECTIVE weights in fp64, plus the bias term derived independently as the
+    depthwise conv of the zero-padded constant image bp[c] -- which is what makes the border rows of the table necessary."""
+    import torch.nn.functional as F
+    from ntire2022_esr_amd import ops
+    from ntire2022_esr_amd.bsrn import BSRN
+    from ntire2022_esr_amd.engine import pack_conv_s16, unpack_conv_s16
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[compute]
+    g = torch.Generator().manual_seed(n + cin + c + hw[0])
+    pw = torch.nn.Linear(cin, c)
+    dw = torch.nn.Conv2d(c, c, 3, padding=1, groups=c)
+    with torch.no_grad():
+        pw.weight.copy_(torch.randn(c, cin, generator=g) * 0.2); pw.bias.copy_(torch.randn(c, generator=g))
+        dw.weight.copy_(torch.randn(c, 1, 3, 3, generator=g) * 0.3); dw.bias.copy_(torch.randn(c, generator=g))
+    w, bias, table = BSRN._merged_bsconv(pw, dw)
+    cp = (cin + 15) // 16 * 16
+    blob = pack_conv_s16(w, bias, compute, cin_phys=cp)
+    weff, _ = unpack_conv_s16(blob, cin, c, 3, compute, cin_phys=cp)
+    x = torch.randn(n, cin, *hw, generator=g).to(dt)
+    r = x if res_mode == 1 else torch.randn(n, c, *hw, generator=g).to(dt)
+    bp = pw.bias.detach().double().reshape(1, c, 1, 1).expand(1, c, *hw)
+    bias_img = F.conv2d(bp, dw.weight.detach().double(), dw.bias.detach().double(), padding=1, groups=c)      # dw(pad0(bp)) + bd
+    conv = F.conv2d(x.double(), weff.double(), None, padding=1) + bias_img
+    A = {0: lambda t: t, 1: lambda t: F.leaky_relu(t, 0.05), 3: lambda t: F.gelu(t)}[act]
+    ref = A(conv + r.double()) if res_mode == 1 else (A(conv) + r.double() if res_mode == 2 else A(conv))
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    xin = F.pad(nhwc(x), (0, cp - cin)).to(DEV)
+    rp = (xin if res_mode == 1 else F.pad(nhwc(r), (0, (-c) % 8)).to(DEV)) if res_mode else None
+    y = ops.conv2d(xin, w, bias, act=act, res=rp, res_mode=res_mode, cin=cin, packed=blob.to(DEV), border=table.to(DEV))
+    got = y.permute(0, 3, 1, 2)[:, :c].double().cpu()
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    tol = ref.abs() * eps * 1.01 + (3e-4 if act == 3 else 5e-5) * max(1.0, float(ref.abs().max()))
+    bad = (got - ref).abs() > tol
+    assert int(bad.sum()) == 0, (int(bad.sum()), float((got - ref).abs().max()))

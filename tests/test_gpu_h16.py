@@ -33,7 +33,7 @@ ACTS = {0: lambda t: t, 1: lambda t: F.leaky_relu(t, 0.05), 2: F.relu, 3: lambda
 @pytest.mark.parametrize("cin,cout,k,hw,act,res_mode", [
     (64, 64, 3, (16, 32), 1, 1), (48, 48, 3, (23, 37), 1, 2), (48, 16, 3, (17, 15), 0, 0), (64, 48, 3, (40, 56), 1, 0),
     (50, 50, 3, (20, 36), 1, 1), (16, 16, 3, (5, 3), 2, 0), (46, 46, 1, (33, 18), 0, 0), (50, 25, 1, (40, 40), 1, 0),
-    (128, 50, 1, (19, 70), 0, 0), (256, 50, 1, (35, 33), 1, 0), (48, 48, 1, (64, 64), 3, 1), (32, 64, 3, (70, 50), 1, 1)])
+    (128, 50, 1, (19, 70), 0, 0), (256, 50, 1, (35, 33), 1, 0), (48, 48, 1, (64, 64), 3, 2), (32, 64, 3, (70, 50), 1, 1)])
 def test_s16_conv_matches_fp64_reference(compute, cin, cout, k, hw, act, res_mode):
     """16-bit storage conv (esr_conv2d_f32 with storage = bf16 / f16): inputs are exact 16-bit values, the reference uses
     the EFFECTIVE weights of the packed blob (error-diffused 3x3 taps / hi + lo 1x1) in fp64, so the only differences

@@ -8,12 +8,13 @@ from ntire2022_esr_amd.engine import pack_conv_s16, unpack_conv_s16
 DEV = "cuda:0"
 def nhwc(t): return t.permute(0, 2, 3, 1).contiguous()
 for compute, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
-    for (n, cin, cout, k, hw, act, res_mode) in ((1, 64, 64, 3, (270, 480), 1, 0), (1, 64, 64, 3, (256, 512), 1, 0), (1, 48, 48, 3, (270, 480), 1, 0),
-                                                 (1, 64, 64, 1, (270, 480), 1, 0), (1, 64, 64, 1, (270, 480), 1, 2), (1, 64, 64, 3, (270, 480), 1, 1),
-                                                 (3, 64, 64, 3, (256, 256), 1, 0), (1, 32, 32, 3, (270, 480), 1, 0), (1, 64, 64, 3, (339, 510), 1, 2)):
+    for (n, cin, cout, k, hw, act, res_mode) in ((1, 16, 16, 3, (270, 480), 1, 1), (1, 16, 16, 3, (270, 480), 1, 2), (1, 16, 16, 1, (270, 480), 1, 2),
+                                                 (1, 16, 32, 3, (270, 480), 1, 2), (1, 64, 64, 3, (270, 480), 1, 2), (1, 64, 64, 1, (270, 480), 1, 2),
+                                                 (1, 48, 48, 3, (339, 510), 1, 2), (1, 32, 32, 3, (339, 510), 1, 1), (1, 64, 64, 3, (339, 510), 1, 0),
+                                                 (2, 48, 48, 1, (339, 510), 1, 2), (1, 128, 64, 1, (270, 480), 1, 2), (4, 64, 64, 3, (256, 256), 1, 2)):
         g = torch.Generator().manual_seed(cin + cout + hw[0] + k)
         x = torch.randn(n, cin, *hw, generator=g).to(dt)
-        r = torch.randn(n, cout, *hw, generator=g).to(dt)
+        r = torch.randn(n, cout, *hw, generator=g).to(dt)  # residual != input: loaded from HBM
         w = torch.randn(cout, cin, k, k, generator=g) * (0.1 if k == 3 else 0.2)
         b = torch.randn(cout, generator=g)
         blob = pack_conv_s16(w, b, compute, cin_phys=cin)

@@ -118,6 +118,8 @@ class BSRN(HipSRModel):
         h2, w2, h3, w3 = _lowres(plan.h, plan.w)
         g = dict(act=L.ACT_GELU)
         merged = plan.esize == 2
+        # the post-chain kernel variants that exist: 3 main tiles (C in 33..48) with a 2-tile post (dc in 17..32)
+        fuse_d = merged and (C + 15) // 16 == 3 and (dc + 15) // 16 == 2
 
         def bs3(path, src, dst, cin, cout, **kw):
             plan.conv(path + '#bs3', src, dst, cin, cout, k=3, border=path + '#bs3#border', bs_of=path, **kw)
@@ -138,10 +140,15 @@ class BSRN(HipSRModel):
             src = cur
             for j, (rin, rout) in enumerate(((cur, r1), (r1, r2), (r2, r1)), start=1):
                 if merged:
-                    # 16-bit storage: BSConvU as one dense 3x3 on the matrix cores (+ input from the staged tile, GELU),
-                    # the distillation Linear + GELU as a 1x1 of its own
-                    bs3(b + f'c{j}_r', rin, rout, C, C, res=rin, res_mode=L.RES_PRE_ACT, **g)
-                    plan.conv(b + f'c{j}_d', rin, cat[(j - 1) * dc:j * dc], C, dc, k=1, counted=False, **g)
+                    # 16-bit storage: BSConvU as one dense 3x3 on the matrix cores (+ input from the staged tile, GELU).  The
+                    # NEXT distillation Linear + GELU (c{j+1}_d reads this launch's result r_j) rides in its epilogue on the
+                    # fp32 tile; the block's first one (c1_d, of the block input) is a 1x1 of its own.
+                    if j == 1:
+                        plan.conv(b + 'c1_d', rin, cat[0:dc], C, dc, k=1, counted=False, **g)
+                    nxt = dict(w=b + f'c{j + 1}_d', dst=cat[j * dc:(j + 1) * dc], cout=dc, act=L.ACT_GELU) if (j < 3 and fuse_d) else None
+                    bs3(b + f'c{j}_r', rin, rout, C, C, res=rin, res_mode=L.RES_PRE_ACT, post=nxt, **g)
+                    if j < 3 and not fuse_d:
+                        plan.conv(b + f'c{j + 1}_d', rout, cat[j * dc:(j + 1) * dc], C, dc, k=1, counted=False, **g)
                 else:
                     # c{j}_d (Linear + GELU) and c{j}_r = BSConvU (+ input, GELU) read the same tensor: one launch, the
                     # pointwise result stays in LDS (team18_bsrn.py:150-163)
@@ -191,7 +198,8 @@ class BSRN(HipSRModel):
             nlin = 1 + (o["distill"] is not None)
             return 9 * o["cout"] * plan.n * h * w + nlin * plan.n * h * h, o["cout"] * plan.n * h * w, 1
         if o["kind"] == "conv" and o.get("bs_of") is not None:           # a BSConvU run as a dense 3x3: one Linear + one depthwise Conv2d
-            return 9 * o["cout"] * plan.n * h * w + plan.n * h * h, o["cout"] * plan.n * h * w, 1
+            nlin = 1 + (o.get("post") is not None)                        # (+ the next distillation Linear in its epilogue)
+            return 9 * o["cout"] * plan.n * h * w + nlin * plan.n * h * h, o["cout"] * plan.n * h * w, 1
         if o["kind"] == "conv" and not o.get("counted", True):
             return plan.n * h * h, 0, 0                                   # a Linear call
         if o["kind"] == "apply":

@@ -79,6 +79,7 @@ struct S16K {
     int py1_pitch, py1_coff, py2_pitch, py2_coff;
     int p1_cout8, p2_cout8;                // channels stored (multiples of 8 / 4)
     float p1_slope;                        // activation of post 1 as max(v, slope v)
+    int p1_gelu;                           // ... or GELU
     int post_lo;                           // the low-part weight images are resident too (w = hi + lo)
     int store_main;                        // 0: the conv's own result is consumed by the post chain only
     const float* border;                   // esr_conv_desc.border_bias (PNT1 == 0 kernels), or NULL
@@ -131,7 +132,7 @@ __device__ __forceinline__ f32x4 unpack4(uint2 u)
 // 1.3e-4 for x <= 4 and 5.3e-5 x beyond, about one fp16 step of the values that matter, far below a bf16 step -- and 11 plain VALU instructions
 // (packable two values at a time) instead of libm erff's ~40 or the 16 + v_rcp + v_exp of an erf approximation.  The fp32
 // path keeps erff.
-__device__ __forceinline__ float gelu16(float x)
+__device__ __forceinline__ __attribute__((unused)) float gelu16(float x)       // the scalar definition (esr_bsconv.hip uses it as is)
 {
     const float xc = fminf(fmaxf(x, -4.f), 4.f);
     const float t = xc * xc;
@@ -144,6 +145,33 @@ __device__ __forceinline__ float gelu16(float x)
     p = fmaf(p, t, -6.617537882e-02f);
     p = fmaf(p, t, 3.988475079e-01f);
     return fmaxf(x, -4.f) * fmaf(xc, p, 0.5f);
+}
+
+// the same arithmetic (bit for bit) on a D fragment with packed fp32 instructions: 16 v_pk_fma + 4 v_pk_mul + 4 v_med3 + 4 v_max
+// = 7 VALU instructions per value instead of 13
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu16x2(f32x2 x)
+{
+    f32x2 xc, xm;
+    xc.x = __builtin_amdgcn_fmed3f(x.x, -4.f, 4.f); xc.y = __builtin_amdgcn_fmed3f(x.y, -4.f, 4.f);
+    const f32x2 t = xc * xc;
+    f32x2 p = {-1.580786198e-09f, -1.580786198e-09f};
+    p = __builtin_elementwise_fma(p, t, f32x2{1.217111051e-07f, 1.217111051e-07f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-4.100866386e-06f, -4.100866386e-06f});
+    p = __builtin_elementwise_fma(p, t, f32x2{8.066739505e-05f, 8.066739505e-05f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-1.048204400e-03f, -1.048204400e-03f});
+    p = __builtin_elementwise_fma(p, t, f32x2{9.664874174e-03f, 9.664874174e-03f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-6.617537882e-02f, -6.617537882e-02f});
+    p = __builtin_elementwise_fma(p, t, f32x2{3.988475079e-01f, 3.988475079e-01f});
+    const float m4 = -4.f;
+    asm("v_max_f32 %0, %1, %2" : "=v"(xm.x) : "v"(x.x), "v"(m4));
+    asm("v_max_f32 %0, %1, %2" : "=v"(xm.y) : "v"(x.y), "v"(m4));
+    return xm * __builtin_elementwise_fma(xc, p, f32x2{0.5f, 0.5f});
+}
+__device__ __forceinline__ f32x4 gelu16x4(f32x4 v)
+{
+    const f32x2 a = gelu16x2(f32x2{v.x, v.y}), b = gelu16x2(f32x2{v.z, v.w});
+    return f32x4{a.x, a.y, b.x, b.y};
 }
 
 // Epilogue activation: max(v, slope * v); slope carries none (1) / LeakyReLU (s) / ReLU (0).  GELU is applied IN PLACE to the
@@ -264,10 +292,11 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     // post images: [post 1: NT k-tiles x PNT1 tiles, hi (then lo)][post 2: PNT1 k-tiles x PNT2 tiles, hi (then lo)][biases, 1 KB]
     constexpr int P1_IMG = NT * PNT1 * 1024, P2_IMG = PNT1 * PNT2 * 1024;
     const int plo = (PNT1 > 0 && p.post_lo) ? 2 : 1;
-    const int w_bytes = w_main + (PNT1 > 0 ? plo * (P1_IMG + P2_IMG) + 1024 : (p.border ? NT * 1024 : 0) + 1024);
-    // the conv's own bias (NT * 16 floats): the upper half of the post-bias KB, or a KB of its own (PNT1 == 0)
-    float* const sbias = reinterpret_cast<float*>(smem + w_bytes - 512);
-    float* const btab = reinterpret_cast<float*>(smem + w_main);          // border bias table [16][NT * 16] (PNT1 == 0)
+    // [weights][post images (PNT1 > 0)][bias KB: post biases, the conv's own bias in the upper half][border table NT KB (p.border)][ring]
+    const int bias_at = w_main + (PNT1 > 0 ? plo * (P1_IMG + P2_IMG) : 0);
+    const int w_bytes = bias_at + 1024 + (p.border ? NT * 1024 : 0);
+    float* const sbias = reinterpret_cast<float*>(smem + bias_at + 512);
+    float* const btab = reinterpret_cast<float*>(smem + bias_at + 1024);  // border bias table [16][NT * 16]
     const char* const pimg1 = smem + w_main;
     const char* const pimg2 = pimg1 + plo * P1_IMG;
     float* const pbias = reinterpret_cast<float*>(smem + w_main + plo * (P1_IMG + P2_IMG));
@@ -380,7 +409,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
             if (PNT2 > 0 && tid < PNT2 * 16) pbias[PNT1 * 16 + tid] = reinterpret_cast<const float*>(p.pw2 + 2 * P2_IMG)[tid];
         }
     }
-    if (PNT1 == 0 && p.border)
+    if (p.border)
         for (int i = tid; i < 16 * NT * 16; i += 64 * NW) btab[i] = p.border[i];
     if (tid < NT * 16) sbias[tid] = p.bias[tid];
     cursor_tile();
@@ -482,9 +511,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
-                f32x4 v = acc[tt][r];
-                v.x = gelu16(v.x); v.y = gelu16(v.y); v.z = gelu16(v.z); v.w = gelu16(v.w);
-                acc[tt][r] = v;
+                acc[tt][r] = gelu16x4(acc[tt][r]);
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
@@ -599,11 +626,13 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                     }
                 }
                 const float s1 = q->p1_slope;
+                const bool g1 = q->p1_gelu != 0;
                 uint2 pk1[PNT1 > 0 ? PNT1 : 1];
 #pragma unroll
                 for (int ot = 0; ot < PNT1; ++ot) {
                     f32x4 v = d1[ot];
-                    v.x = fmaxf(v.x, s1 * v.x); v.y = fmaxf(v.y, s1 * v.y); v.z = fmaxf(v.z, s1 * v.z); v.w = fmaxf(v.w, s1 * v.w);
+                    if (g1) v = gelu16x4(v);
+                    else { v.x = act1(v.x, s1); v.y = act1(v.y, s1); v.z = act1(v.z, s1); v.w = act1(v.w, s1); }
                     d1[ot] = v;
                     pk1[ot].x = pack2<BF16>(v.x, v.y);
                     pk1[ot].y = pack2<BF16>(v.z, v.w);
@@ -699,7 +728,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         const unsigned srow = (unsigned)((py0 + wv * RW) * qW + px0);            // wave-uniform: pixel (row 0, px = 0) of this wave
         const unsigned s0 = srow * (unsigned)qy0p * 2u, s1 = srow * (unsigned)qy1p * 2u;
         const unsigned l0 = (__umul24(px, qy0p) + (unsigned)qy0c) * 2u, l1 = (__umul24(px, qy1p) + (unsigned)(qy1c - qsplit)) * 2u;
-        const bool inx = pend && px0 + px < qW;       // nothing pending (the block's first stage): every store out of range
+        const bool inx = px0 + px < qW;
         // rows below the image fall past num_records (= the image's bytes): dropped by the hardware
 #pragma unroll
         for (int j = 0; j < NPAIR; ++j) {
@@ -818,7 +847,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                 }
             }
         }
-        if (PNT1 == 0 && c == p.nchunks - 1 && p.border) border_fix(x0, y0);
+        if (c == p.nchunks - 1 && p.border) border_fix(x0, y0);
         if (last && act_gelu) gelu_inplace();        // (`last` is a residual stage when there are any: residual_stage applies it)
     };
 
@@ -871,15 +900,25 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
             const bool last = c == nst - 1;
             hist_rs = (hist_rs << 1) | (c == 0 ? 1u : 0u);
             hist_st <<= 1;
-            if (c == 0 && swap_epi) {
-                // always through the epilogue-carrying instance (the block's first tile: nothing pending, stores out of range)
+            if (c == 0 && swap_epi && pend && have) {
                 hist_st |= 1u;
-                compute(std::true_type{}, 0, last);
+                compute(std::true_type{}, 0, last);             // the previous tile's epilogue inside this tile's first MFMA group
+            } else if (c == 0 && swap_epi && pend) {
+                // behind the block's last tile: the epilogue alone (with one or two tiles per block -- single images -- a whole
+                // stage of MFMAs on stale data would cost a quarter of the block's time)
+                swap_epi_setup();
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    swap_epi_act(r);
+                    if (r & 1) swap_epi_store(r);
+                }
+                break;
             } else {
                 if (c == 0 && pend) {
                     hist_st |= 1u;
                     epilogue(pn, px0, py0);
                 }
+                if (!have) break;                               // behind the block's last tile: the epilogue was all
                 if (PNT1 == 0 && c >= p.nchunks) residual_stage(c, last);
                 else compute(std::false_type{}, c, last);
             }
@@ -981,7 +1020,7 @@ int s16_post_plan(const esr_conv_desc* d, int nt, int nchunks, int* pnt1, int* p
     const bool gres = d->res_mode != ESR_RES_NONE && !res_is_in;
     if (!post_variant_exists(d->ksize, nt, gres, *pnt1, *pnt2)) return ESR_ERR_UNSUPPORTED;
     for (int lo = 1; lo >= 0; --lo) {
-        const size_t pb = (size_t)(lo + 1) * (nt * *pnt1 + *pnt1 * *pnt2) * 1024 + 1024;
+        const size_t pb = (size_t)(lo + 1) * (nt * *pnt1 + *pnt1 * *pnt2) * 1024 + 1024 + (d->border_bias ? (size_t)nt * 1024 : 0);
         int r = RING_MAX;
         while (r > RING_MIN && s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, r, pb) > (size_t)LDS_LIMIT) --r;
         if (s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, r, pb) <= (size_t)LDS_LIMIT) {
@@ -1169,7 +1208,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     if (d->in_layout != ESR_NHWC) return ESR_ERR_UNSUPPORTED;                                  // the NCHW head runs on conv_f32_kernel
     if (d->tail_wpacked) return ESR_ERR_UNSUPPORTED;
     const bool post = d->post_wpacked != nullptr;
-    if (d->border_bias && (post || d->out_layout != ESR_NHWC)) return ESR_ERR_UNSUPPORTED;
+    if (d->border_bias && d->out_layout != ESR_NHWC) return ESR_ERR_UNSUPPORTED;
     if (!post && d->post2_wpacked) return ESR_ERR_BAD_ARG;
     if ((d->in.pitch & 7) || (d->in.coff & 7)) return ESR_ERR_BAD_ARG;                         // 16-byte granules
     const int cin_phys = esr_round_up(d->cin, 16);
@@ -1210,7 +1249,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
             if (!d->post2_out.ptr || (d->post2_out.pitch & 3) || (d->post2_out.coff & 3) || d->post2_out.coff + p2c4 > d->post2_out.pitch) return ESR_ERR_BAD_ARG;
             if ((double)d->h * d->w * d->post2_out.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
         }
-        if (d->post_act != ESR_ACT_NONE && d->post_act != ESR_ACT_LRELU && d->post_act != ESR_ACT_RELU) return ESR_ERR_UNSUPPORTED;
+        if (d->post_act != ESR_ACT_NONE && d->post_act != ESR_ACT_LRELU && d->post_act != ESR_ACT_RELU && d->post_act != ESR_ACT_GELU) return ESR_ERR_UNSUPPORTED;
     } else {
         const size_t extra = (d->border_bias ? (size_t)nt * 1024 : 0) + 1024;      // border table, the bias KB
         while (ring > RING_MIN && s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, ring, extra) > (size_t)LDS_LIMIT) --ring;
@@ -1268,6 +1307,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     k.py1_pitch = d->post_out.pitch; k.py1_coff = d->post_out.coff; k.py2_pitch = d->post2_out.pitch; k.py2_coff = d->post2_out.coff;
     k.p1_cout8 = esr_round_up(d->post_cout > 0 ? d->post_cout : 1, 8); k.p2_cout8 = esr_round_up(d->post2_cout > 0 ? d->post2_cout : 1, 4);
     k.p1_slope = d->post_act == ESR_ACT_LRELU ? d->slope : (d->post_act == ESR_ACT_RELU ? 0.f : 1.f);
+    k.p1_gelu = d->post_act == ESR_ACT_GELU;
     k.post_lo = post_lo;
     k.store_main = d->out0.ptr ? 1 : 0;
     k.border = d->border_bias;

@@ -40,9 +40,6 @@ namespace {
 
 constexpr int TILE = 16;            // output tile width (pixels) = one MFMA's pixel dimension
 constexpr int RING_MIN = 3, RING_MAX = 8;   // input stages in LDS (as many as fit next to the resident weights)
-constexpr int SCR_ROW = 144;        // bytes per scratch pixel row: 64 channels x 2 B + 16 pad
-constexpr int SCR_PIX = 8;          // pixels per transposed half row
-constexpr int SCR_WAVE = SCR_PIX * SCR_ROW;
 constexpr unsigned OOB = 0x80000000u;
 constexpr int LDS_LIMIT = 160 * 1024;
 #ifndef ESR_S16_NW
@@ -301,7 +298,6 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     const char* const pimg2 = pimg1 + plo * P1_IMG;
     float* const pbias = reinterpret_cast<float*>(smem + w_main + plo * (P1_IMG + P2_IMG));
     char* const ring = smem + w_bytes;
-    char* const scr = ring + R * STAGE_BYTES + wv * SCR_WAVE;
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned ring_lds = smem_lds + (unsigned)w_bytes;
 
@@ -343,7 +339,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     unsigned lvr0 = OOB, lvr1 = OOB, lvr2 = OOB;     // residual (p.nres > 0: staged as extra chunks, added from LDS -- no registers in flight); scalars: as an array hipcc kept it in scratch
     auto LVR = [&](int i) __attribute__((always_inline)) -> unsigned& { return i == 0 ? lvr0 : (i == 1 ? lvr1 : lvr2); };
     i32x4 lrsrc, lrsrcr = {0, 0, 0, 0};
-    const int nstages = p.nchunks + (PNT1 == 0 ? p.nres : 0);       // stages per tile
+    const int nstages = p.nchunks + p.nres;       // stages per tile
     auto cursor_tile = [&]() __attribute__((always_inline)) {
         const int t = tile_index(lk);
         lvalid = t >= 0;
@@ -358,7 +354,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         const int qH = q->H, qW = q->W, qpitch = q->in_pitch, qcoff = q->in_coff;
         const size_t img_bytes = (size_t)qH * qW * qpitch * 2;
         lrsrc = make_rsrc(q->x + (size_t)n * img_bytes, img_bytes);
-        const bool withres = PNT1 == 0 && q->nres > 0;
+        const bool withres = q->nres > 0;
         const int qrp = q->res_pitch, qrc = q->res_coff;
         if (withres) {
             const size_t res_bytes = (size_t)qH * qW * qrp * 2;
@@ -380,7 +376,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         const int pc = wv + NW * i;
         if (NPIECES % NW == 0 || i < PPW - 1 || pc < NPIECES) {         // wave-uniform
             const unsigned dst = ring_lds + (unsigned)(lslot * STAGE_BYTES) + (unsigned)pc * 1024u;
-            if (PNT1 == 0 && lc >= p.nchunks) dma_buf16(dst, LVR(i), lrsrcr, (unsigned)(lc - p.nchunks) * 32u);     // a residual chunk
+            if (lc >= p.nchunks) dma_buf16(dst, LVR(i), lrsrcr, (unsigned)(lc - p.nchunks) * 32u);     // a residual chunk
             else dma_buf16(dst, lvoff[i], lrsrc, (unsigned)lc * 32u);
         }
     };
@@ -439,11 +435,14 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     // The plain NHWC epilogue (no post chain) lives INSIDE the first MFMA group of the next tile's first stage (swap_epi):
     // row by row, activation / rounding of the finished tile's accumulators right before the MFMAs that overwrite them, the
     // D fragments made store-shaped by v_permlane16_swap (no LDS, no waits), their stores in the shadow of the matrix pipe.
-    // Post-chain and pixel-shuffle epilogues stay a phase of their own in front of the stage's compute.
-    const bool swap_epi = PNT1 == 0 && p.out_layout != ESR_NCHW_SHUFFLE4;
+    // The post chain (PNT1 / PNT2) runs there too, row by row on the activated fp32 fragments.  Only the pixel-shuffle epilogue
+    // of the network's last convolution is a phase of its own in front of the stage's compute.
+    const bool swap_epi = p.out_layout != ESR_NCHW_SHUFFLE4;
     constexpr int SWAP_STORES = (NT / 2) * RW + (NT & 1) * (RW / 2);
-    const int epi_stores = PNT1 > 0 ? (p.store_main ? 2 * RW : 0) + 2 * RW + (PNT2 > 0 ? RW : 0)
-                                    : (p.out_layout == ESR_NCHW_SHUFFLE4 ? RW * NT : (p.split < p.cout_store ? 2 : 1) * SWAP_STORES);   // stores per wave and tile
+    constexpr int P1_STORES = (PNT1 / 2) * RW + (PNT1 & 1) * (RW / 2), P2_STORES = PNT2 > 0 ? RW / 2 : 0;
+    static_assert(PNT2 <= 1, "post 2: one tile");
+    const int epi_stores = p.out_layout == ESR_NCHW_SHUFFLE4 ? RW * NT
+                           : ((PNT1 == 0 || p.store_main) ? (p.split < p.cout_store ? 2 : 1) * SWAP_STORES : 0) + P1_STORES + P2_STORES;   // stores per wave and tile
     const unsigned hmask = (1u << (R - 2)) - 1u;
     unsigned hist_rs = 0, hist_st = 0;   // bit i: stage s - i was a tile's first stage (residual loads) / carried an epilogue's stores
 
@@ -533,15 +532,11 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         }
     };
 
-    // epilogue as a phase: pixel-shuffle output (PNT1 == 0) or the post chain (PNT1 > 0)
+    // epilogue as a phase: the pixel-shuffle output (fp32 NCHW) of the network's last convolution
     auto epilogue = [&](int n, int x0, int y0) __attribute__((always_inline)) {
         const kparg_t q = KP();
-        const int qH = q->H, qW = q->W, qcs = q->cout_store, qsplit = q->split;
-        const int qres_mode = q->res_mode;
+        const int qH = q->H, qW = q->W, qcs = q->cout_store;
         const float qslope = act_gelu ? 1.f : q->slope;
-        const bool shuffle = q->out_layout == ESR_NCHW_SHUFFLE4;
-        const bool has_split = !shuffle && qsplit < qcs;
-        wait_residual();
         if constexpr (PNT1 == 0) {
             // out[n, t, 4gy + kq, 4gx + 0..3] = channel 16t + 4kq + j: the D fragment is one dwordx4 of 4 adjacent HR pixels
             const int gx = x0 + px;
@@ -562,134 +557,6 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                 }
             }
             return;
-        } else {
-        // NHWC 16-bit: residual / activation / rounding in the fragment layout, then each wave transposes half a pixel row
-        // at a time through its private scratch: lane (p8, cg) owns the 8 channels 8cg.. of pixel p8 -- one 16-byte store per
-        // lane, 128 contiguous bytes per pixel, 1 KB per instruction
-        const int p8 = lane >> 3, cg = lane & 7;
-        const int cb = cg * 8;
-        const bool ch0 = cb < qsplit;                        // goes to out0
-        const bool ch1 = !ch0 && cb < qcs;                   // goes to out1 (split store)
-        const int qy0p = q->y0_pitch, qy0c = q->y0_coff, qy1p = q->y1_pitch, qy1c = q->y1_coff;
-        const size_t y0_img = (size_t)qH * qW * qy0p * 2, y1_img = (size_t)qH * qW * qy1p * 2;
-        const __amdgpu_buffer_rsrc_t yr0 = __builtin_amdgcn_make_buffer_rsrc(q->y0 + (size_t)n * y0_img, 0, (int)y0_img, 0x00020000);
-        const __amdgpu_buffer_rsrc_t yr1 = __builtin_amdgcn_make_buffer_rsrc(q->y1 + (size_t)n * y1_img, 0, (int)y1_img, 0x00020000);
-        // store addressing: one lane-constant byte offset per half row h (lanes right of the image or beyond the stored channels:
-        // OOB); a row step is ONE add, and rows below the image fall past num_records (= the image's bytes), so the hardware
-        // drops them -- no per-store multiply / compare / select (they were a third of the epilogue's VALU work)
-        const unsigned srow = (unsigned)((y0 + wv * RW) * qW + x0);              // wave-uniform: pixel of (r = 0, h = 0, p8 = 0)
-        const unsigned rowb0 = (unsigned)qW * (unsigned)qy0p * 2u, rowb1 = (unsigned)qW * (unsigned)qy1p * 2u;
-        unsigned vb0[2], vb1[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const bool inx = x0 + 8 * h + p8 < qW;
-            vb0[h] = (inx && ch0) ? (srow + 8u * h) * (unsigned)qy0p * 2u + (__umul24(p8, qy0p) + (unsigned)(qy0c + cb)) * 2u : OOB;
-            vb1[h] = (has_split && inx && ch1) ? (srow + 8u * h) * (unsigned)qy1p * 2u + (__umul24(p8, qy1p) + (unsigned)(qy1c + cb - qsplit)) * 2u : OOB;
-        }
-#pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            uint2 pk[NT];
-            f32x4 u[PNT1 > 0 ? NT : 1];
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt) {
-                f32x4 v = acc[tt][r];
-                f32x4 rf = {0.f, 0.f, 0.f, 0.f};
-                if (GRES) rf = unpack4<BF16>(rv[GRES ? tt : 0][r]);
-                if (GRES && qres_mode == ESR_RES_PRE_ACT) v += rf;
-                v.x = act1(v.x, qslope); v.y = act1(v.y, qslope);
-                v.z = act1(v.z, qslope); v.w = act1(v.w, qslope);
-                if (GRES && qres_mode == ESR_RES_POST_ACT) v += rf;
-                pk[tt].x = pack2<BF16>(v.x, v.y);
-                pk[tt].y = pack2<BF16>(v.z, v.w);
-                if (PNT1 > 0) u[tt] = v;
-            }
-            if (PNT1 > 0) {
-                // ---- post chain on the fp32 result ---------------------------------------------------------------------
-                auto hilo = [&](f32x4 v) __attribute__((always_inline)) -> i32x4 {
-                    const unsigned h0 = pack2<BF16>(v.x, v.y), h1 = pack2<BF16>(v.z, v.w);
-                    float a, b, c, d;
-                    unpack2<BF16>(h0, a, b);
-                    unpack2<BF16>(h1, c, d);
-                    return i32x4{(int)h0, (int)h1, (int)pack2<BF16>(v.x - a, v.y - b), (int)pack2<BF16>(v.z - c, v.w - d)};
-                };
-                f32x4 d1[PNT1 > 0 ? PNT1 : 1];
-#pragma unroll
-                for (int ot = 0; ot < PNT1; ++ot) d1[ot] = *reinterpret_cast<const f32x4*>(pbias + ot * 16 + kq * 4);
-#pragma unroll
-                for (int kt = 0; kt < NT; ++kt) {
-                    const i32x4 bsv = hilo(u[kt]);
-#pragma unroll
-                    for (int ot = 0; ot < PNT1; ++ot) {
-                        d1[ot] = mfma32<BF16>(*reinterpret_cast<const i32x4*>(pimg1 + (kt * PNT1 + ot) * 1024 + a_off), bsv, d1[ot]);
-                        if (plo == 2)
-                            d1[ot] = mfma32<BF16>(*reinterpret_cast<const i32x4*>(pimg1 + P1_IMG + (kt * PNT1 + ot) * 1024 + a_off), bsv, d1[ot]);
-                    }
-                }
-                const float s1 = q->p1_slope;
-                const bool g1 = q->p1_gelu != 0;
-                uint2 pk1[PNT1 > 0 ? PNT1 : 1];
-#pragma unroll
-                for (int ot = 0; ot < PNT1; ++ot) {
-                    f32x4 v = d1[ot];
-                    if (g1) v = gelu16x4(v);
-                    else { v.x = act1(v.x, s1); v.y = act1(v.y, s1); v.z = act1(v.z, s1); v.w = act1(v.w, s1); }
-                    d1[ot] = v;
-                    pk1[ot].x = pack2<BF16>(v.x, v.y);
-                    pk1[ot].y = pack2<BF16>(v.z, v.w);
-                }
-                // post 1 result: transposed 16-byte stores like the main output
-                {
-                    const int qp1p = q->py1_pitch, qp1c = q->py1_coff, qp1n = q->p1_cout8;
-                    const size_t p1_img = (size_t)qH * qW * qp1p * 2;
-                    const __amdgpu_buffer_rsrc_t pr1 = __builtin_amdgcn_make_buffer_rsrc(q->py1 + (size_t)n * p1_img, 0, (int)p1_img, 0x00020000);
-                    const unsigned rowbp = (unsigned)qW * (unsigned)qp1p * 2u;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        __builtin_amdgcn_wave_barrier();
-                        if ((px >> 3) == h) {
-#pragma unroll
-                            for (int ot = 0; ot < PNT1; ++ot) *reinterpret_cast<uint2*>(scr + (px & 7) * SCR_ROW + (ot * 16 + kq * 4) * 2) = pk1[ot];
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                        const i32x4 o = *reinterpret_cast<const i32x4*>(scr + p8 * SCR_ROW + min(cb, PNT1 * 16 - 8) * 2);
-                        const bool in = x0 + 8 * h + p8 < qW && cb < qp1n;
-                        const unsigned vo = in ? (srow + 8u * h) * (unsigned)qp1p * 2u + (__umul24(p8, qp1p) + (unsigned)(qp1c + cb)) * 2u +
-                                                     (unsigned)r * rowbp : OOB;
-                        __builtin_amdgcn_raw_buffer_store_b128(o, pr1, vo, 0, 0);
-                    }
-                }
-                if (PNT2 > 0) {
-                    f32x4 d2 = *reinterpret_cast<const f32x4*>(pbias + PNT1 * 16 + kq * 4);
-#pragma unroll
-                    for (int kt = 0; kt < PNT1; ++kt) {
-                        const i32x4 bsv = hilo(d1[kt]);
-                        d2 = mfma32<BF16>(*reinterpret_cast<const i32x4*>(pimg2 + kt * PNT2 * 1024 + a_off), bsv, d2);
-                        if (plo == 2) d2 = mfma32<BF16>(*reinterpret_cast<const i32x4*>(pimg2 + P2_IMG + kt * PNT2 * 1024 + a_off), bsv, d2);
-                    }
-                    // 16 channels: the D fragment as it is, 8 bytes per lane (4 channels of pixel px)
-                    const int qp2p = q->py2_pitch, qp2c = q->py2_coff, qp2n = q->p2_cout8;
-                    const size_t p2_img = (size_t)qH * qW * qp2p * 2;
-                    const __amdgpu_buffer_rsrc_t pr2 = __builtin_amdgcn_make_buffer_rsrc(q->py2 + (size_t)n * p2_img, 0, (int)p2_img, 0x00020000);
-                    const bool in = x0 + px < qW && kq * 4 < qp2n;
-                    const unsigned vo = in ? (srow + (unsigned)r * (unsigned)qW) * (unsigned)qp2p * 2u + (__umul24(px, qp2p) + (unsigned)(qp2c + kq * 4)) * 2u : OOB;
-                    typedef int i32x2 __attribute__((ext_vector_type(2)));
-                    __builtin_amdgcn_raw_buffer_store_b64(i32x2{(int)pack2<BF16>(d2.x, d2.y), (int)pack2<BF16>(d2.z, d2.w)}, pr2, vo, 0, 0);
-                }
-                if (!q->store_main) continue;
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                __builtin_amdgcn_wave_barrier();
-                if ((px >> 3) == h) {
-#pragma unroll
-                    for (int tt = 0; tt < NT; ++tt) *reinterpret_cast<uint2*>(scr + (px & 7) * SCR_ROW + (tt * 16 + kq * 4) * 2) = pk[tt];
-                }
-                __builtin_amdgcn_wave_barrier();
-                const i32x4 o = *reinterpret_cast<const i32x4*>(scr + p8 * SCR_ROW + min(cb, NT * 16 - 8) * 2);
-                __builtin_amdgcn_raw_buffer_store_b128(o, yr0, vb0[h] + (unsigned)r * rowb0, 0, 0);
-                if (has_split) __builtin_amdgcn_raw_buffer_store_b128(o, yr1, vb1[h] + (unsigned)r * rowb1, 0, 0);
-            }
-        }
         }
     };
 
@@ -712,7 +579,14 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     int e_y0n = 0, e_y1n = 0;
     float e_slope = 0.f;
     int e_res_mode = 0;
-    bool e_split = false;
+    bool e_split = false, e_main = true;
+    // post outputs: post 1 = PNT1 tiles (pairs + an odd last tile), post 2 = one tile (rows paired)
+    constexpr int NPAIR1 = PNT1 / 2;
+    unsigned vp1A[NPAIR1 > 0 ? NPAIR1 : 1], vp1B = OOB, vp2B = OOB, e_rowbp1 = 0, e_rowbp2 = 0;
+    char* e_p1 = nullptr; char* e_p2 = nullptr;
+    int e_p1n = 0, e_p2n = 0;
+    float e_s1 = 1.f;
+    bool e_g1 = false;
     auto swap_epi_setup = [&]() __attribute__((always_inline)) {
         const kparg_t q = KP();
         const int qH = q->H, qW = q->W, qcs = q->cout_store, qsplit = q->split;
@@ -728,7 +602,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         const unsigned srow = (unsigned)((py0 + wv * RW) * qW + px0);            // wave-uniform: pixel (row 0, px = 0) of this wave
         const unsigned s0 = srow * (unsigned)qy0p * 2u, s1 = srow * (unsigned)qy1p * 2u;
         const unsigned l0 = (__umul24(px, qy0p) + (unsigned)qy0c) * 2u, l1 = (__umul24(px, qy1p) + (unsigned)(qy1c - qsplit)) * 2u;
-        const bool inx = px0 + px < qW;
+        const bool inx = pend && px0 + px < qW;       // nothing pending (GRES: the block's first stage): every store out of range
         // rows below the image fall past num_records (= the image's bytes): dropped by the hardware
 #pragma unroll
         for (int j = 0; j < NPAIR; ++j) {
@@ -741,16 +615,56 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
             vbB0 = (inx && ch < qsplit) ? s0 + l0 + (unsigned)ch * 2u + ((kq & 1) ? e_rowb0 : 0u) : OOB;
             vbB1 = (inx && ch >= qsplit && ch < qcs) ? s1 + l1 + (unsigned)ch * 2u + ((kq & 1) ? e_rowb1 : 0u) : OOB;
         }
+        if (PNT1 > 0) {
+            e_main = q->store_main != 0;
+            e_s1 = q->p1_slope;
+            e_g1 = q->p1_gelu != 0;
+            const int qp1p = q->py1_pitch, qp1c = q->py1_coff, qp1n = q->p1_cout8;
+            const size_t p1_img = (size_t)qH * qW * qp1p * 2;
+            e_p1 = q->py1 + (size_t)pn * p1_img; e_p1n = (int)p1_img;
+            e_rowbp1 = (unsigned)qW * (unsigned)qp1p * 2u;
+            const unsigned sp = srow * (unsigned)qp1p * 2u + (__umul24(px, qp1p) + (unsigned)qp1c) * 2u;
+#pragma unroll
+            for (int j = 0; j < NPAIR1; ++j) {
+                const int ch = (2 * j + (kq & 1)) * 16 + (kq >> 1) * 8;
+                vp1A[j] = (inx && ch < qp1n) ? sp + (unsigned)ch * 2u : OOB;
+            }
+            if (PNT1 & 1) {
+                const int ch = (PNT1 - 1) * 16 + (kq >> 1) * 8;
+                vp1B = (inx && ch < qp1n) ? sp + (unsigned)ch * 2u + ((kq & 1) ? e_rowbp1 : 0u) : OOB;
+            }
+            if (PNT2 > 0) {
+                const int qp2p = q->py2_pitch, qp2c = q->py2_coff, qp2n = q->p2_cout8;
+                const size_t p2_img = (size_t)qH * qW * qp2p * 2;
+                e_p2 = q->py2 + (size_t)pn * p2_img; e_p2n = (int)p2_img;
+                e_rowbp2 = (unsigned)qW * (unsigned)qp2p * 2u;
+                const int ch = (kq >> 1) * 8;
+                vp2B = (inx && ch < qp2n) ? srow * (unsigned)qp2p * 2u + (__umul24(px, qp2p) + (unsigned)(qp2c + ch)) * 2u + ((kq & 1) ? e_rowbp2 : 0u) : OOB;
+            }
+        }
     };
     uint2 pk[NT][2];                     // rounded rows r - 1 (even), r (odd) of the finished tile
-    auto store16 = [&](uint2 X, uint2 Y, unsigned v0, unsigned v1, int r) __attribute__((always_inline)) {
+    uint2 pk1[PNT1 > 0 ? PNT1 : 1][2], pk2[2];          // ... of the post chain's results
+    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 {
         const u32x2 a = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
         const u32x2 b = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
-        const i32x4 o = {(int)a.x, (int)b.x, (int)a.y, (int)b.y};
+        return i32x4{(int)a.x, (int)b.x, (int)a.y, (int)b.y};
+    };
+    auto store16 = [&](uint2 X, uint2 Y, unsigned v0, unsigned v1, int r) __attribute__((always_inline)) {
+        const i32x4 o = swap16(X, Y);
         __builtin_amdgcn_raw_buffer_store_b128(o, __builtin_amdgcn_make_buffer_rsrc(e_y0, 0, e_y0n, 0x00020000), v0 + (unsigned)r * e_rowb0, 0, 0);
         if (e_split) __builtin_amdgcn_raw_buffer_store_b128(o, __builtin_amdgcn_make_buffer_rsrc(e_y1, 0, e_y1n, 0x00020000), v1 + (unsigned)r * e_rowb1, 0, 0);
     };
+    // the fp32 fragment as the B operand of the post 1x1: k slots 0..3 = the 16-bit high parts, 4..7 = the low parts
+    auto hilo = [&](f32x4 v) __attribute__((always_inline)) -> i32x4 {
+        const unsigned h0 = pack2<BF16>(v.x, v.y), h1 = pack2<BF16>(v.z, v.w);
+        float a, b, c, d;
+        unpack2<BF16>(h0, a, b);
+        unpack2<BF16>(h1, c, d);
+        return i32x4{(int)h0, (int)h1, (int)pack2<BF16>(v.x - a, v.y - b), (int)pack2<BF16>(v.z - c, v.w - d)};
+    };
     auto swap_epi_act = [&](int r) __attribute__((always_inline)) {       // reads acc[.][r]
+        f32x4 u[PNT1 > 0 ? NT : 1];
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
             f32x4 v = acc[tt][r];
@@ -762,15 +676,67 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
             if (GRES && e_res_mode == ESR_RES_POST_ACT) v += rf;
             pk[tt][r & 1].x = pack2<BF16>(v.x, v.y);
             pk[tt][r & 1].y = pack2<BF16>(v.z, v.w);
+            if (PNT1 > 0) u[tt] = v;
+        }
+        if constexpr (PNT1 > 0) {
+            // ---- post chain on this row's fp32 result (RLFB: c3_r -> c5 -> esa.conv1; RFDB / ESDB: the next distillation conv) ------
+            f32x4 d1[PNT1];
+#pragma unroll
+            for (int ot = 0; ot < PNT1; ++ot) d1[ot] = *reinterpret_cast<const f32x4*>(pbias + ot * 16 + kq * 4);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const i32x4 bsv = hilo(u[kt]);
+#pragma unroll
+                for (int ot = 0; ot < PNT1; ++ot) {
+                    d1[ot] = mfma32<BF16>(*reinterpret_cast<const i32x4*>(pimg1 + (kt * PNT1 + ot) * 1024 + a_off), bsv, d1[ot]);
+                    if (plo == 2)
+                        d1[ot] = mfma32<BF16>(*reinterpret_cast<const i32x4*>(pimg1 + P1_IMG + (kt * PNT1 + ot) * 1024 + a_off), bsv, d1[ot]);
+                }
+            }
+#pragma unroll
+            for (int ot = 0; ot < PNT1; ++ot) {
+                f32x4 v = d1[ot];
+                if (e_g1) v = gelu16x4(v);
+                else { v.x = act1(v.x, e_s1); v.y = act1(v.y, e_s1); v.z = act1(v.z, e_s1); v.w = act1(v.w, e_s1); }
+                d1[ot] = v;
+                pk1[ot][r & 1].x = pack2<BF16>(v.x, v.y);
+                pk1[ot][r & 1].y = pack2<BF16>(v.z, v.w);
+            }
+            if (PNT2 > 0) {
+                f32x4 d2 = *reinterpret_cast<const f32x4*>(pbias + PNT1 * 16 + kq * 4);
+#pragma unroll
+                for (int kt = 0; kt < PNT1; ++kt) {
+                    const i32x4 bsv = hilo(d1[kt]);
+                    d2 = mfma32<BF16>(*reinterpret_cast<const i32x4*>(pimg2 + kt * PNT2 * 1024 + a_off), bsv, d2);
+                    if (plo == 2) d2 = mfma32<BF16>(*reinterpret_cast<const i32x4*>(pimg2 + P2_IMG + kt * PNT2 * 1024 + a_off), bsv, d2);
+                }
+                pk2[r & 1].x = pack2<BF16>(d2.x, d2.y);
+                pk2[r & 1].y = pack2<BF16>(d2.z, d2.w);
+            }
         }
     };
     auto swap_epi_store = [&](int r) __attribute__((always_inline)) {                    // rows r - 1, r (r odd)
+        if (PNT1 == 0 || e_main) {
 #pragma unroll
-        for (int j = 0; j < NPAIR; ++j) {
-            store16(pk[2 * j][0], pk[2 * j + 1][0], vbA0[j], vbA1[j], r - 1);
-            store16(pk[2 * j][1], pk[2 * j + 1][1], vbA0[j], vbA1[j], r);
+            for (int j = 0; j < NPAIR; ++j) {
+                store16(pk[2 * j][0], pk[2 * j + 1][0], vbA0[j], vbA1[j], r - 1);
+                store16(pk[2 * j][1], pk[2 * j + 1][1], vbA0[j], vbA1[j], r);
+            }
+            if (NT & 1) store16(pk[NT - 1][0], pk[NT - 1][1], vbB0, vbB1, r - 1);
         }
-        if (NT & 1) store16(pk[NT - 1][0], pk[NT - 1][1], vbB0, vbB1, r - 1);
+        if constexpr (PNT1 > 0) {
+            const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(e_p1, 0, e_p1n, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < NPAIR1; ++j) {
+                __builtin_amdgcn_raw_buffer_store_b128(swap16(pk1[2 * j][0], pk1[2 * j + 1][0]), r1, vp1A[j] + (unsigned)(r - 1) * e_rowbp1, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(swap16(pk1[2 * j][1], pk1[2 * j + 1][1]), r1, vp1A[j] + (unsigned)r * e_rowbp1, 0, 0);
+            }
+            if (PNT1 & 1)
+                __builtin_amdgcn_raw_buffer_store_b128(swap16(pk1[PNT1 - 1][0], pk1[PNT1 - 1][1]), r1, vp1B + (unsigned)(r - 1) * e_rowbp1, 0, 0);
+            if (PNT2 > 0)
+                __builtin_amdgcn_raw_buffer_store_b128(swap16(pk2[0], pk2[1]), __builtin_amdgcn_make_buffer_rsrc(e_p2, 0, e_p2n, 0x00020000),
+                                                       vp2B + (unsigned)(r - 1) * e_rowbp2, 0, 0);
+        }
     };
 
     // ---- one stage: MFMA groups from ring slot `slot`, the cursor's DMA pieces between them ------------------------------
@@ -828,7 +794,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
 #pragma unroll
                     for (int r = 0; r < RW; ++r) acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], acc[tt][r]);
             }
-            if (q == 0 && (EPI || (PNT1 > 0 && first))) load_residual(n, x0, y0, have);   // this tile's residual (the ONE load site): behind the epilogue, in front of the DMA
+            if (q == 0 && EPI) load_residual(n, x0, y0, have);   // this tile's residual (the ONE load site): behind the epilogue, in front of the DMA
             if (q < PPW) dma_piece(q);                               // the DMA issue rides in the shadow of the matrix pipe
         }
 #pragma unroll
@@ -900,12 +866,15 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
             const bool last = c == nst - 1;
             hist_rs = (hist_rs << 1) | (c == 0 ? 1u : 0u);
             hist_st <<= 1;
-            if (c == 0 && swap_epi && pend && have) {
+            if (c == 0 && swap_epi && have && (pend || GRES)) {
+                // the previous tile's epilogue inside this tile's first MFMA group (GRES: also for the block's first tile, nothing
+                // pending and every store out of range -- the residual loads have their one site in there)
                 hist_st |= 1u;
-                compute(std::true_type{}, 0, last);             // the previous tile's epilogue inside this tile's first MFMA group
+                compute(std::true_type{}, 0, last);
             } else if (c == 0 && swap_epi && pend) {
                 // behind the block's last tile: the epilogue alone (with one or two tiles per block -- single images -- a whole
                 // stage of MFMAs on stale data would cost a quarter of the block's time)
+                wait_residual();
                 swap_epi_setup();
 #pragma unroll
                 for (int r = 0; r < RW; ++r) {
@@ -919,7 +888,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                     epilogue(pn, px0, py0);
                 }
                 if (!have) break;                               // behind the block's last tile: the epilogue was all
-                if (PNT1 == 0 && c >= p.nchunks) residual_stage(c, last);
+                if (c >= p.nchunks) residual_stage(c, last);
                 else compute(std::false_type{}, c, last);
             }
             cursor_advance();
@@ -991,7 +960,7 @@ int launch_s16_post(int ks, int nt, bool gres, int pnt1, int pnt2, const S16K& k
         if (nt == 4 && !gres && pnt1 == 1 && pnt2 == 0) return launch_s16<4, 1, S16_NW, BF16, false, 1, 0>(k, lds, st);
         return ESR_ERR_UNSUPPORTED;
     }
-    if (nt == 3 && gres && pnt1 == 3 && pnt2 == 1) return launch_s16<3, 3, S16_NW, BF16, true, 3, 1>(k, lds, st);
+    if (nt == 3 && gres && pnt1 == 3 && pnt2 == 1) return launch_s16<3, 3, S16_NW, BF16, false, 3, 1>(k, lds, st);    // (the residual is staged through LDS: S16K.nres)
     if (nt == 4 && !gres && pnt1 == 2 && pnt2 == 0) return launch_s16<4, 3, S16_NW, BF16, false, 2, 0>(k, lds, st);
     if (nt == 3 && !gres && pnt1 == 2 && pnt2 == 0) return launch_s16<3, 3, S16_NW, BF16, false, 2, 0>(k, lds, st);
     return ESR_ERR_UNSUPPORTED;
@@ -1003,7 +972,8 @@ size_t s16_lds_bytes(int nchunks, int nt, int ksize, int nw, int ring, size_t po
     const int halo = ksize / 2, th = TILE + 2 * halo, thy = 32 + 2 * halo;
     const int npieces = (th * thy + 31) / 32;
     const int pairs = (ksize * ksize + 1) / 2;
-    return (size_t)nchunks * pairs * nt * 1024 + post_bytes + (size_t)ring * npieces * 1024 + (size_t)nw * SCR_WAVE;
+    (void)nw;
+    return (size_t)nchunks * pairs * nt * 1024 + post_bytes + (size_t)ring * npieces * 1024;
 }
 
 // decides how a descriptor with a post chain runs: fills the tile counts and whether the low-part images are resident;
@@ -1245,8 +1215,8 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         if (!d->post_out.ptr || (d->post_out.pitch & 7) || (d->post_out.coff & 7) || d->post_out.coff + p1c8 > d->post_out.pitch) return ESR_ERR_BAD_ARG;
         if ((double)d->h * d->w * d->post_out.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
         if (pnt2) {
-            const int p2c4 = esr_round_up(d->post2_cout, 4);
-            if (!d->post2_out.ptr || (d->post2_out.pitch & 3) || (d->post2_out.coff & 3) || d->post2_out.coff + p2c4 > d->post2_out.pitch) return ESR_ERR_BAD_ARG;
+            const int p2c8 = esr_round_up(d->post2_cout, 8);
+            if (!d->post2_out.ptr || (d->post2_out.pitch & 7) || (d->post2_out.coff & 7) || d->post2_out.coff + p2c8 > d->post2_out.pitch) return ESR_ERR_BAD_ARG;
             if ((double)d->h * d->w * d->post2_out.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
         }
         if (d->post_act != ESR_ACT_NONE && d->post_act != ESR_ACT_LRELU && d->post_act != ESR_ACT_RELU && d->post_act != ESR_ACT_GELU) return ESR_ERR_UNSUPPORTED;
@@ -1291,8 +1261,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         k.res_in = 1;                               // residual == input: added from the staged tile, no residual loads
         k.res_mode = ESR_RES_NONE;
     }
-    if (!post && k.res_mode != ESR_RES_NONE) k.nres = nt;          // residual from HBM: staged as nt extra chunks per tile
-    if (post && d->act == ESR_ACT_GELU && k.res_mode == ESR_RES_PRE_ACT) return ESR_ERR_UNSUPPORTED;   // post chain: the residual rides in registers, behind the in-place GELU
+    if (k.res_mode != ESR_RES_NONE) k.nres = nt;                   // residual from HBM: staged as nt extra chunks per tile
     k.out_layout = d->out_layout;
     k.tiles_x = (d->w + TILE - 1) / TILE;
     k.tiles_y = (d->h + 31) / 32;
@@ -1305,7 +1274,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     k.pw1 = static_cast<const char*>(d->post_wpacked); k.pw2 = static_cast<const char*>(d->post2_wpacked);
     k.py1 = static_cast<char*>(d->post_out.ptr); k.py2 = static_cast<char*>(d->post2_out.ptr);
     k.py1_pitch = d->post_out.pitch; k.py1_coff = d->post_out.coff; k.py2_pitch = d->post2_out.pitch; k.py2_coff = d->post2_out.coff;
-    k.p1_cout8 = esr_round_up(d->post_cout > 0 ? d->post_cout : 1, 8); k.p2_cout8 = esr_round_up(d->post2_cout > 0 ? d->post2_cout : 1, 4);
+    k.p1_cout8 = esr_round_up(d->post_cout > 0 ? d->post_cout : 1, 8); k.p2_cout8 = esr_round_up(d->post2_cout > 0 ? d->post2_cout : 1, 8);
     k.p1_slope = d->post_act == ESR_ACT_LRELU ? d->slope : (d->post_act == ESR_ACT_RELU ? 0.f : 1.f);
     k.p1_gelu = d->post_act == ESR_ACT_GELU;
     k.post_lo = post_lo;

@@ -176,3 +176,13 @@ def test_s16_packer_layout_diffusion_and_split():
     assert lib.esr_packed_conv_s16_bytes(64, 64, 3) == 4 * 5 * 4 * 1024 + 256
     assert lib.esr_packed_conv_s16_bytes(256, 50, 1) == 16 * 1 * 4 * 1024 + 256
     assert lib.esr_packed_conv_s16_bytes(64, 64, 2) == 0
+
+
+def test_conv_s16_isa_lint():
+    """tools/lint_s16_isa.py: no scratch access / VGPR spill in any conv_s16_kernel variant (its vmcnt arithmetic counts every
+    vector-memory instruction) and no copy out of a register an in-flight residual load writes.  Cross-compiles esr_s16.hip to
+    assembly (about a minute and a half, no GPU)."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lint_s16_isa.py")],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -195,9 +195,9 @@ def test_s16_post_rfdb(compute, nf):
     wd, bd = torch.randn(dc, nf, generator=g) * 0.2, torch.randn(dc, generator=g)
     weff, _ = unpack_conv_s16(pack_conv_s16(w, b, compute, cin_phys=P), nf, nf, 3, compute, cin_phys=P)
     rr = F.leaky_relu(F.conv2d(x.double(), weff.double(), b.double(), padding=1) + x.double(), 0.05)
-    # nf = 50: four main tiles = 80 KB of resident 3x3 weights, the post weights' low-part images do not fit the LDS next to a
-    # three-stage ring, so the 1x1 multiplies by the 16-bit high parts only (esr_conv2d_s16: post_lo); nf = 40 keeps hi + lo
-    wd_eff = wd.to(dt).double() if nf > 48 else wd.double()
+    # hi + lo post weights for both shapes (the epilogue needs no LDS scratch any more: the low-part images fit next to nf = 50's
+    # 80 KB of 3x3 weights too)
+    wd_eff = wd.double()
     dd = F.leaky_relu(F.conv2d(rr, wd_eff[:, :, None, None], bd.double()), 0.05)
     xin = F.pad(_nhwc(x), (0, P - nf)).to(DEV)
     y, yd = ops.conv2d(xin, w, b, act=1, res=xin, res_mode=1, cin=nf, post_weight=wd, post_bias=bd, post_act=1)

@@ -142,6 +142,15 @@ typedef struct esr_conv_desc {
      * into the bias), at the border the taps that fall outside the image contribute nothing -- row m holds
      * -b[c] * sum over the taps outside for mask m of dw[c,tap]. */
     const float* border_bias;
+    /* ABI v5 -- segmented (planar) input for the 1x1 over a channel concat (16-bit storage): the input channels come from
+     * `cin_phys / (16 * in_seg_chunks)` tensors of identical geometry (pitch / coff as given by `in`) that lie in_seg_stride bytes
+     * apart; 16-channel chunk c is chunk c % in_seg_chunks of segment c / in_seg_chunks.  in_seg_stride == 0: one tensor.
+     * Why: a distilled slice written into a shared [.., 4 x dc] concat buffer is a partial-line store (48 of 192 bytes per
+     * pixel for BSRN) and costs 2.3x the dense store (tools/dbg/s16_1x1_probe.py); with one dense tensor per slice the
+     * producers write whole lines and torch.cat still never happens -- the consumer walks the segments. */
+    int64_t in_seg_stride;
+    int32_t in_seg_chunks;
+    int32_t reserved4;
 } esr_conv_desc;
 
 /* Host-side weight packer (the K10 "weight packer" of SURVEY 7.2): OIHW fp32 (the layout of every

@@ -43,7 +43,7 @@ class ConvDesc(ctypes.Structure):
         ("post_wpacked", ctypes.c_void_p), ("post_out", View),
         ("post_cout", ctypes.c_int32), ("post_act", ctypes.c_int32),
         ("post2_wpacked", ctypes.c_void_p), ("post2_out", View),
-        ("post2_cout", ctypes.c_int32), ("reserved3", ctypes.c_int32), ("border_bias", ctypes.c_void_p),
+        ("post2_cout", ctypes.c_int32), ("reserved3", ctypes.c_int32), ("border_bias", ctypes.c_void_p), ("in_seg_stride", ctypes.c_int64), ("in_seg_chunks", ctypes.c_int32), ("reserved4", ctypes.c_int32),
     ]
 
 

@@ -90,6 +90,13 @@ class BSRN(HipSRModel):
         """BSConvU modules that run as dense 3x3 convolutions in the 16-bit modes (the full-resolution ones)"""
         return [f'B{k}.c{j}_r' for k in range(1, self.nb + 1) for j in (1, 2, 3)] + [f'B{k}.c4' for k in range(1, self.nb + 1)] + ['c2']
 
+    def _cin_map(self, path, cin_map, store):
+        if path.endswith('.c5') and store != "f32":       # the four distilled tensors are DP = round_up(dc, 16) channels wide (engine.Planar)
+            dc = self.dc
+            DP = (dc + 15) // 16 * 16
+            return [(s // DP) * dc + s % DP if s % DP < dc else -1 for s in range(4 * DP)]
+        return cin_map
+
     def _extra_pack(self, packed, device):
         C, ic = self.C, self.in_nc
         if self._store() != "f32":
@@ -125,7 +132,11 @@ class BSRN(HipSRModel):
             plan.conv(path + '#bs3', src, dst, cin, cout, k=3, border=path + '#bs3#border', bs_of=path, **kw)
         fea = plan.buffer('fea', C)
         bcat = plan.buffer('bcat', nb * C)                # block outputs, team18_bsrn.py:226
-        cat = plan.buffer('cat', 4 * dc)                  # d1 d2 d3 r4, team18_bsrn.py:166
+        # d1 d2 d3 r4, team18_bsrn.py:166.  16-bit storage: four dense tensors of DP = round_up(dc, 16) channels (engine.Planar):
+        # a dc-channel slice of a [.., 4 dc] buffer is a partial-line store (48 of 192 bytes per pixel), 2.3x the cost of a dense one
+        DP = (dc + 15) // 16 * 16
+        cat = plan.planar('cat', 4, DP) if merged else plan.buffer('cat', 4 * dc)
+        cs = (lambda j: cat.seg(j)) if merged else (lambda j: cat[j * dc:(j + 1) * dc])
         t = plan.buffer('t', C)                           # pointwise result feeding the depthwise
         r1, r2, v, u = plan.buffer('r1', C), plan.buffer('r2', C), plan.buffer('v', C), plan.buffer('u', C)
         c1 = plan.buffer('esa_c1', FP)
@@ -144,26 +155,26 @@ class BSRN(HipSRModel):
                     # NEXT distillation Linear + GELU (c{j+1}_d reads this launch's result r_j) rides in its epilogue on the
                     # fp32 tile; the block's first one (c1_d, of the block input) is a 1x1 of its own.
                     if j == 1:
-                        plan.conv(b + 'c1_d', rin, cat[0:dc], C, dc, k=1, counted=False, **g)
-                    nxt = dict(w=b + f'c{j + 1}_d', dst=cat[j * dc:(j + 1) * dc], cout=dc, act=L.ACT_GELU) if (j < 3 and fuse_d) else None
+                        plan.conv(b + 'c1_d', rin, cs(0), C, dc, k=1, counted=False, **g)
+                    nxt = dict(w=b + f'c{j + 1}_d', dst=cs(j), cout=dc, act=L.ACT_GELU) if (j < 3 and fuse_d) else None
                     bs3(b + f'c{j}_r', rin, rout, C, C, res=rin, res_mode=L.RES_PRE_ACT, post=nxt, **g)
                     if j < 3 and not fuse_d:
-                        plan.conv(b + f'c{j + 1}_d', rout, cat[j * dc:(j + 1) * dc], C, dc, k=1, counted=False, **g)
+                        plan.conv(b + f'c{j + 1}_d', rout, cs(j), C, dc, k=1, counted=False, **g)
                 else:
                     # c{j}_d (Linear + GELU) and c{j}_r = BSConvU (+ input, GELU) read the same tensor: one launch, the
                     # pointwise result stays in LDS (team18_bsrn.py:150-163)
                     plan.bsconv(b + f'c{j}_r.pw', b + f'c{j}_r.dw', rin, rout, C, C, res=rin, res_mode=L.RES_PRE_ACT,
-                                distill=dict(w=b + f'c{j}_d', dst=cat[(j - 1) * dc:j * dc], cout=dc, act=L.ACT_GELU), **g)
+                                distill=dict(w=b + f'c{j}_d', dst=cs(j - 1), cout=dc, act=L.ACT_GELU), **g)
             if merged:
-                bs3(b + 'c4', r1, cat[3 * dc:4 * dc], C, dc, **g)
+                bs3(b + 'c4', r1, cs(3), C, dc, **g)
             else:
-                plan.bsconv(b + 'c4.pw', b + 'c4.dw', r1, cat[3 * dc:4 * dc], C, dc, **g)
+                plan.bsconv(b + 'c4.pw', b + 'c4.dw', r1, cs(3), C, dc, **g)
             if plan.esize == 2 and (C + 15) // 16 in (3, 4) and f <= 16:
                 # 16-bit storage: esa.conv1 rides in c5's epilogue on the fp32 tile (one launch less per block)
-                plan.conv(b + 'c5', cat, v, 4 * dc, C, k=1, counted=False,
+                plan.conv(b + 'c5', cat, v, 4 * DP if merged else 4 * dc, C, k=1, counted=False, cin_alg=4 * dc,
                           post=dict(w=b + 'esa.conv1', dst=c1, cout=f, act=L.ACT_NONE))
             else:
-                plan.conv(b + 'c5', cat, v, 4 * dc, C, k=1, counted=False)
+                plan.conv(b + 'c5', cat, v, 4 * DP if merged else 4 * dc, C, k=1, counted=False, cin_alg=4 * dc)
                 plan.conv(b + 'esa.conv1', v, c1, C, f, k=1, counted=False)
             plan.conv3x3s2(b + 'esa.conv2', c1, lo2, f)
             plan.maxpool7s3(lo2, la)

@@ -943,6 +943,7 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
     if (store16 && !in_nchw) return esr_conv2d_s16(d, hip_stream);         // 16-bit storage: esr_s16.hip
     if (d->compute != ESR_COMPUTE_F32) return ESR_ERR_BAD_ARG;              // fp32 MFMA from here on (incl. the NCHW head)
     if (d->border_bias) return ESR_ERR_UNSUPPORTED;                        // border table: conv_s16_kernel only
+    if (d->in_seg_stride != 0) return ESR_ERR_UNSUPPORTED;                 // segmented input: conv_s16_kernel only
     if (store16) {
         // the network head with 16-bit activations downstream: fp32 NCHW input (exact), fp32 MFMA, 16-bit NHWC store
         if (d->out_layout != ESR_NHWC || d->res_mode != ESR_RES_NONE || d->tail_wpacked || d->post_wpacked) return ESR_ERR_UNSUPPORTED;

@@ -79,7 +79,9 @@ struct S16K {
     int p1_gelu;                           // ... or GELU
     int post_lo;                           // the low-part weight images are resident too (w = hi + lo)
     int store_main;                        // 0: the conv's own result is consumed by the post chain only
-    const float* border;                   // esr_conv_desc.border_bias (PNT1 == 0 kernels), or NULL
+    const float* border;                   // esr_conv_desc.border_bias, or NULL
+    long long seg_stride;                  // segmented input: bytes between the tensors of the concat (else 0)
+    int seg_chunks;                        // chunks per input segment (one tensor: nchunks)
 };
 
 template <bool BF16>
@@ -332,6 +334,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     const int n_my = (NPIECES % NW == 0 || wv < NPIECES % NW) ? PPW : PPW - 1;     // wave-uniform
     int lk = 0;                   // tile iteration of the cursor
     int lc = 0;                   // chunk of the cursor
+    int lcc = 0;                  // ... within its input segment
+    unsigned lsoff = 0;           // ... as the DMA's scalar byte offset
     int lslot = 0;
     bool lvalid;
     static_assert(PPW <= 3, "lvr0..2");
@@ -377,13 +381,26 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         if (NPIECES % NW == 0 || i < PPW - 1 || pc < NPIECES) {         // wave-uniform
             const unsigned dst = ring_lds + (unsigned)(lslot * STAGE_BYTES) + (unsigned)pc * 1024u;
             if (lc >= p.nchunks) dma_buf16(dst, LVR(i), lrsrcr, (unsigned)(lc - p.nchunks) * 32u);     // a residual chunk
-            else dma_buf16(dst, lvoff[i], lrsrc, (unsigned)lc * 32u);
+            else dma_buf16(dst, lvoff[i], lrsrc, lsoff);
         }
     };
     auto cursor_advance = [&]() __attribute__((always_inline)) {
         lslot = lslot == R - 1 ? 0 : lslot + 1;
+        if (++lcc == p.seg_chunks) {                // (esr_conv_desc.in_seg_*: the next chunk lies in the next tensor of the concat)
+            // the buffer BASE moves on: the hardware's range check covers the scalar offset too, so a segment stride in soffset
+            // would put every later segment out of range (num_records = one tensor's image)
+            lcc = 0;
+            lsoff = 0;
+            const unsigned long long b = ((unsigned long long)(unsigned)lrsrc.x | ((unsigned long long)((unsigned)lrsrc.y & 0xffffu) << 32)) + (unsigned long long)p.seg_stride;
+            lrsrc.x = (int)(unsigned)b;
+            lrsrc.y = (int)((unsigned)(b >> 32) & 0xffffu);
+        } else {
+            lsoff += 32u;
+        }
         if (++lc == nstages) {
             lc = 0;
+            lcc = 0;
+            lsoff = 0;
             ++lk;
             cursor_tile();
         }
@@ -985,7 +1002,7 @@ int s16_post_plan(const esr_conv_desc* d, int nt, int nchunks, int* pnt1, int* p
     *pnt1 = esr_round_up(d->post_cout, 16) / 16;
     *pnt2 = d->post2_wpacked ? 1 : 0;
     if (*pnt2 && (d->post2_cout <= 0 || d->post2_cout > 16)) return ESR_ERR_UNSUPPORTED;
-    const bool res_is_in = d->res_mode == ESR_RES_PRE_ACT && d->cin == d->cout && d->res.ptr == d->in.ptr &&
+    const bool res_is_in = d->res_mode == ESR_RES_PRE_ACT && esr_round_up(d->cin, 16) == esr_round_up(d->cout, 16) && d->res.ptr == d->in.ptr &&
                            d->res.pitch == d->in.pitch && d->res.coff == d->in.coff;
     const bool gres = d->res_mode != ESR_RES_NONE && !res_is_in;
     if (!post_variant_exists(d->ksize, nt, gres, *pnt1, *pnt2)) return ESR_ERR_UNSUPPORTED;
@@ -1182,7 +1199,14 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     if (!post && d->post2_wpacked) return ESR_ERR_BAD_ARG;
     if ((d->in.pitch & 7) || (d->in.coff & 7)) return ESR_ERR_BAD_ARG;                         // 16-byte granules
     const int cin_phys = esr_round_up(d->cin, 16);
-    if (d->in.coff + cin_phys > d->in.pitch) return ESR_ERR_BAD_ARG;                           // chunk reads stay inside the pixel
+    const bool segmented = d->in_seg_stride != 0;
+    if (segmented) {
+        if (d->in_seg_chunks <= 0 || (cin_phys / 16) % d->in_seg_chunks || d->in_seg_stride < 0 || (d->in_seg_stride & 15)) return ESR_ERR_BAD_ARG;
+        if (d->in.coff + 16 * d->in_seg_chunks > d->in.pitch) return ESR_ERR_BAD_ARG;
+        if (d->ksize != 1) return ESR_ERR_UNSUPPORTED;             // (a 3x3 over a concat does not occur on the path)
+    } else if (d->in.coff + cin_phys > d->in.pitch) {
+        return ESR_ERR_BAD_ARG;                                  // chunk reads stay inside the pixel
+    }
     const int nt = esr_round_up(d->cout, 16) / 16;
     const bool shuffle = d->out_layout == ESR_NCHW_SHUFFLE4;
     const int cout8 = esr_round_up(d->cout, 8);
@@ -1256,7 +1280,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     k.res_mode = d->res_mode;
     k.res_in = 0;
     k.nres = 0;
-    if (d->ksize == 3 && d->res_mode == ESR_RES_PRE_ACT && d->cin == d->cout && d->res.ptr == d->in.ptr &&
+    if (d->ksize == 3 && d->res_mode == ESR_RES_PRE_ACT && esr_round_up(d->cin, 16) == esr_round_up(d->cout, 16) && d->res.ptr == d->in.ptr &&
         d->res.pitch == d->in.pitch && d->res.coff == d->in.coff) {
         k.res_in = 1;                               // residual == input: added from the staged tile, no residual loads
         k.res_mode = ESR_RES_NONE;
@@ -1280,6 +1304,8 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     k.post_lo = post_lo;
     k.store_main = d->out0.ptr ? 1 : 0;
     k.border = d->border_bias;
+    k.seg_chunks = segmented ? d->in_seg_chunks : nchunks;
+    k.seg_stride = segmented ? d->in_seg_stride : 0;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     if (post) {
         const bool gres = k.res_mode != ESR_RES_NONE;

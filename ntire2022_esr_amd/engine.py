@@ -164,6 +164,21 @@ class Buffer:
         return (self, a, b - a)
 
 
+class Planar:
+    """A channel concat kept as `nseg` dense tensors [n][h][w][seg_pitch] that lie `stride` bytes apart (16-bit plans): every
+    producer writes whole lines into its own tensor (`seg(j)`), the consuming 1x1 walks the segments
+    (esr_conv_desc.in_seg_stride / in_seg_chunks).  Physical channel slot s of the consumer = slot s % seg_pitch of segment
+    s // seg_pitch -- the same slot order as a dense [.., nseg * seg_pitch] buffer, so the weight blobs do not change."""
+
+    def __init__(self, segs):
+        self.segs = segs
+        self.pitch = segs[0].pitch
+        self.stride = segs[1].offset - segs[0].offset if len(segs) > 1 else 0
+
+    def seg(self, j):
+        return self.segs[j]
+
+
 INPUT = "__input__"
 OUTPUT = "__output__"
 
@@ -200,6 +215,11 @@ class Plan:
         self.total += (self.n * h * w * pitch * esize + 255) // 256 * 256
         self.buffers.append(b)
         return b
+
+    def planar(self, name, nseg, seg_pitch):
+        """nseg equal full-resolution buffers back to back (see Planar); 16-bit plans only"""
+        assert self.esize == 2 and seg_pitch % 16 == 0
+        return Planar([self.buffer(f"{name}.{j}", seg_pitch) for j in range(nseg)])
 
     def conv(self, wname, src, dst, cin, cout, k=3, act=L.ACT_NONE, slope=0.05,
              res=None, res_mode=L.RES_NONE, dst1=None, split=0, hw=None, counted=True, tail=None, post=None, cin_alg=None,
@@ -307,6 +327,11 @@ class Plan:
             if o["src"] is INPUT:
                 d.in_layout = L.NCHW_IN
                 in_idx.append(i)
+            elif isinstance(o["src"], Planar):
+                pl = o["src"]
+                d.in_layout = L.NHWC
+                d.inp = self._view(pl.seg(0), base)
+                d.in_seg_stride, d.in_seg_chunks = pl.stride, pl.pitch // 16
             else:
                 d.in_layout = L.NHWC
                 d.inp = self._view(o["src"], base)
@@ -324,6 +349,16 @@ class Plan:
                 d.res = self._view(o["res"], base)
             lowres = o["hw"] is not None
             d.storage = 0 if lowres else st                       # ESA low-resolution maps: fp32
+
+            def full_width(dst, cout):
+                """16-bit storage, destination = a WHOLE dense buffer: store the pad channels of its last K chunk too (they are
+                zeros: zero weight rows, zero bias) -- a 24-of-32-channel store leaves every 64-byte run partial, and partial-line
+                stores cost up to 2.3x a full one (tools/dbg/s16_1x1_probe.py).  Slices of shared buffers keep their width."""
+                if st and not lowres and isinstance(dst, Buffer) and o["kind"] == "conv":
+                    return min((cout + 15) // 16 * 16, dst.pitch)
+                return cout
+            if o["dst"] is not OUTPUT and o["dst"] is not None and not o["split"]:
+                d.cout = full_width(o["dst"], o["cout"])
             if st and not lowres and o["kind"] == "conv" and o["src"] is not INPUT:
                 d.wpacked = ctypes.c_void_p(weights[o["w"] + "#s16"].data_ptr())     # conv_s16_kernel
                 d.compute = st
@@ -341,7 +376,7 @@ class Plan:
                 psfx = "#post" if (st and not lowres) else ""     # 16-bit storage: esr_pack_post_s16 images
                 d.post_wpacked = ctypes.c_void_p(weights[t["w"] + psfx].data_ptr())
                 d.post_out = self._view(t["dst"], base)
-                d.post_cout, d.post_act = t["cout"], t.get("act", L.ACT_NONE)
+                d.post_cout, d.post_act = full_width(t["dst"], t["cout"]) if psfx else t["cout"], t.get("act", L.ACT_NONE)
                 t2 = t.get("post2")
                 if t2 is not None:
                     d.post2_wpacked = ctypes.c_void_p(weights[t2["w"] + psfx].data_ptr())

@@ -53,23 +53,27 @@ class IMDN(HipSRModel):
         fea = plan.buffer('fea', nc)
         xa, xb = plan.buffer('xa', nc), plan.buffer('xb', nc)
         fused = d == 16 and 48 < nc <= 64 and self.compute == 'f32'    # conv4 + 1x1 in one launch (16-bit modes keep conv4 on the 16-bit kernel)
-        cat = plan.buffer('cat', 3 * d if fused else 4 * d)              # fused: conv4's slot never reaches memory
+        # fused: conv4's slot never reaches memory.  16-bit storage (d a multiple of 16): four dense tensors (engine.Planar) instead
+        # of 32-byte slices of a 128-byte pixel -- partial-line stores cost 2.3x a dense one
+        planar = plan.esize == 2 and d % 16 == 0
+        cat = plan.planar('cat', 4, d) if planar else plan.buffer('cat', 3 * d if fused else 4 * d)
+        cs = (lambda j: cat.seg(j)) if planar else (lambda j: cat[j * d:(j + 1) * d])
         r1, r2 = plan.buffer('r1', r), plan.buffer('r2', r)
         act = dict(act=self.act, slope=self.slope)
         plan.conv('model.0', INPUT, fea, self.in_nc, nc)
         cur, nxt = fea, xa
         for i in range(self.nb):
             p = f'model.1.sub.{i}.'
-            plan.conv(p + 'conv1.0', cur, cat[0:d], nc, nc, split=d, dst1=r1, **act)
-            plan.conv(p + 'conv2.0', r1, cat[d:2 * d], r, nc, split=d, dst1=r2, **act)
-            plan.conv(p + 'conv3.0', r2, cat[2 * d:3 * d], r, nc, split=d, dst1=r1, **act)
+            plan.conv(p + 'conv1.0', cur, cs(0), nc, nc, split=d, dst1=r1, **act)
+            plan.conv(p + 'conv2.0', r1, cs(1), r, nc, split=d, dst1=r2, **act)
+            plan.conv(p + 'conv3.0', r2, cs(2), r, nc, split=d, dst1=r1, **act)
             if fused:
                 # conv4 -> cat -> conv1x1 -> + x in one kernel: the 16 conv4 channels go from the 3x3's accumulators
                 # straight into the 1x1's K loop and never reach memory
                 plan.conv(p + 'conv4', r1, nxt, r, d, res=cur, res_mode=L.RES_PRE_ACT,
                           tail=dict(w=p + 'conv1x1', cat=cat[0:3 * d], cat_c=3 * d, cout=nc))
             else:
-                plan.conv(p + 'conv4', r1, cat[3 * d:4 * d], r, d)
+                plan.conv(p + 'conv4', r1, cs(3), r, d)
                 plan.conv(p + 'conv1x1', cat, nxt, 4 * d, nc, k=1, res=cur, res_mode=L.RES_PRE_ACT)
             cur = nxt
             nxt = xb if cur is xa else xa

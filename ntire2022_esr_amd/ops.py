@@ -55,6 +55,15 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
         n, c, h, w = x.shape
         d.in_layout, cin = L.NCHW_IN, c
         d.inp = L.View(ctypes.c_void_p(x.data_ptr()), 0, 0)
+    elif x.dim() == 5:
+        # planar concat [S, N, H, W, P]: S dense tensors one stride apart (esr_conv_desc.in_seg_stride / in_seg_chunks)
+        if not s16 or not x.is_contiguous() or x.shape[-1] % 16:
+            raise L.EsrError("conv2d: a segmented input is a contiguous 16-bit [S, N, H, W, P] tensor with P a multiple of 16")
+        nseg, n, h, w, pp = x.shape
+        cin = wcin if cin is None else cin
+        d.in_layout = L.NHWC
+        d.inp = L.View(ctypes.c_void_p(x.data_ptr()), pp, 0)
+        d.in_seg_stride, d.in_seg_chunks = x.stride(0) * x.element_size(), pp // 16
     else:
         n, h, w, _ = x.shape
         cin = wcin if cin is None else cin

@@ -71,7 +71,11 @@ class RFDN(HipSRModel):
         h2, w2, h3, w3 = _lowres(plan.h, plan.w)
         fea = plan.buffer('fea', P)
         bcat = plan.buffer('bcat', 4 * P)                 # the four block outputs, RFDN.py:36
-        cat = plan.buffer('cat', _pad8(4 * DP))           # d1 d2 d3 r4, block.py:163
+        # d1 d2 d3 r4, block.py:163.  16-bit storage: four dense tensors (engine.Planar) -- a 32-channel slice of a 128-wide
+        # buffer is a partial-line store there (64 of 256 bytes per pixel), 2.3x the cost of a dense one
+        planar = plan.esize == 2
+        cat = plan.planar('cat', 4, DP) if planar else plan.buffer('cat', _pad8(4 * DP))
+        cs = (lambda j: cat.seg(j)) if planar else (lambda j: cat[j * DP:(j + 1) * DP])
         r1, r2 = plan.buffer('r1', P), plan.buffer('r2', P)
         v = plan.buffer('v', P)
         c1 = plan.buffer('esa_c1', FP)
@@ -84,21 +88,21 @@ class RFDN(HipSRModel):
         cur = fea
         for k in range(1, 5):
             b = f'B{k}.'
-            plan.conv(b + 'c1_d', cur, cat[0:DP], nf, dc, k=1, **act)
+            plan.conv(b + 'c1_d', cur, cs(0), nf, dc, k=1, **act)
             fused_post = (48 < nf <= 64 and 16 < dc <= 32) if plan.esize == 4 else ((nf + 15) // 16 in (3, 4) and 16 < dc <= 32)
             if fused_post:
                 # the distillation conv of r_j rides in the epilogue of the conv that produces r_j (block.py:150-160)
                 plan.conv(b + 'c1_r', cur, r1, nf, nf, **res(cur), **act,
-                          post=dict(w=b + 'c2_d', dst=cat[DP:2 * DP], cout=dc, act=L.ACT_LRELU))
+                          post=dict(w=b + 'c2_d', dst=cs(1), cout=dc, act=L.ACT_LRELU))
                 plan.conv(b + 'c2_r', r1, r2, nf, nf, **res(r1), **act,
-                          post=dict(w=b + 'c3_d', dst=cat[2 * DP:3 * DP], cout=dc, act=L.ACT_LRELU))
+                          post=dict(w=b + 'c3_d', dst=cs(2), cout=dc, act=L.ACT_LRELU))
             else:
                 plan.conv(b + 'c1_r', cur, r1, nf, nf, **res(cur), **act)
-                plan.conv(b + 'c2_d', r1, cat[DP:2 * DP], nf, dc, k=1, **act)
+                plan.conv(b + 'c2_d', r1, cs(1), nf, dc, k=1, **act)
                 plan.conv(b + 'c2_r', r1, r2, nf, nf, **res(r1), **act)
-                plan.conv(b + 'c3_d', r2, cat[2 * DP:3 * DP], nf, dc, k=1, **act)
+                plan.conv(b + 'c3_d', r2, cs(2), nf, dc, k=1, **act)
             plan.conv(b + 'c3_r', r2, r1, nf, nf, **res(r2), **act)
-            plan.conv(b + 'c4', r1, cat[3 * DP:4 * DP], nf, dc, **act)
+            plan.conv(b + 'c4', r1, cs(3), nf, dc, **act)
             if plan.esize == 2 and (nf + 15) // 16 in (3, 4) and f <= 16:
                 # 16-bit storage: esa.conv1 rides in c5's epilogue on the fp32 tile (one launch less per block)
                 plan.conv(b + 'c5', cat, v, 4 * DP, nf, k=1, cin_alg=4 * dc, post=dict(w=b + 'esa.conv1', dst=c1, cout=f, act=L.ACT_NONE))

@@ -98,6 +98,24 @@ def test_s16_conv_more_tiles_than_blocks(compute, n, cin, cout, k, hw, res_mode)
 
 
 @pytest.mark.parametrize("compute", ["bf16", "f16"])
+@pytest.mark.parametrize("nseg,pp,cout,hw,res_mode", [(4, 32, 48, (40, 56), 0), (4, 16, 64, (33, 70), 1), (2, 48, 50, (270, 480), 0), (5, 16, 16, (20, 20), 2)])
+def test_s16_segmented_input_equals_dense_concat(compute, nseg, pp, cout, hw, res_mode):
+    """esr_conv_desc.in_seg_stride / in_seg_chunks: the 1x1 over a concat kept as `nseg` dense tensors must give exactly what it
+    gives on the dense [.., nseg * pp] buffer holding the same channels (same blob, same chunk order, same arithmetic)."""
+    from ntire2022_esr_amd import ops
+    dt = DT[compute]
+    g = torch.Generator().manual_seed(nseg + pp + cout)
+    xs = torch.randn(nseg, 2, *hw, pp, generator=g).to(dt).to(DEV)                # planar
+    xd = torch.cat([xs[j] for j in range(nseg)], dim=-1).contiguous()             # dense concat
+    w = torch.randn(cout, nseg * pp, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(2, *hw, (cout + 7) // 8 * 8, generator=g).to(dt).to(DEV) if res_mode else None
+    yd = ops.conv2d(xd, w, b, act=1, res=r, res_mode=res_mode)
+    ys = ops.conv2d(xs, w, b, act=1, res=r, res_mode=res_mode)
+    assert torch.equal(yd, ys)
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
 def test_s16_split_store_slices_and_shuffle(compute):
     """channel-split store (IMDBlock: 16 -> concat slice, 48 -> next conv), reads from / writes into slices of wider
     buffers, and the PixelShuffle(4) tail writing the fp32 NCHW network output"""

@@ -252,7 +252,8 @@ int esr_sqerr_u8(const uint8_t* a_hwc, const uint8_t* b_hwc, int h, int w, int c
  */
 typedef enum esr_op_kind {
     ESR_OP_CONV = 0, ESR_OP_CONV3X3S2 = 1, ESR_OP_MAXPOOL7S3 = 2, ESR_OP_ESA_APPLY = 3, ESR_OP_DWCONV = 4,
-    ESR_OP_BSCONV = 5
+    ESR_OP_BSCONV = 5,
+    ESR_OP_PACK_INPUT = 6       /* esr_pack_input_s16 on esr_op.conv (ABI v5) */
 } esr_op_kind;
 
 /*
@@ -314,6 +315,13 @@ typedef struct esr_op {
     esr_esa_desc esa;           /* the three ESA kinds */
     esr_bsconv_desc bs;         /* ESR_OP_BSCONV (ABI v3) */
 } esr_op;
+
+/* ABI v5 -- the network input for the 16-bit plans: NCHW fp32 [n, cin <= 4, h, w] (d->in.ptr) -> NHWC 16-bit (d->out0, pitch >= 16,
+ * storage d->storage), 16 channels per pixel: [x_hi (cin) | x_lo (cin) | x_hi (cin) | 0 ..] with x = x_hi + x_lo in the storage type.
+ * A 3x3 conv_s16 over these slots with the weights [w_hi | w_hi | w_lo] (w = w_hi + w_lo, dropping lo x lo) reproduces the fp32 head
+ * convolution to ~2^-16 (bf16) / 2^-22 (fp16) relative -- at the 16-bit matrix rate instead of the fp32 one (conv_f32_kernel's NCHW
+ * head: 0.21 ms at batch 32 for 226 MB).  Only n, h, w, cin, storage, in.ptr, out0 of the descriptor are read. */
+int esr_pack_input_s16(const esr_conv_desc* d, void* hip_stream);
 
 int esr_run_ops(const esr_op* ops, int n_ops, void* hip_stream);
 

@@ -16,7 +16,7 @@ through esr_conv_desc.border_bias (a 16-row table indexed by which sides of the 
 import torch
 
 from . import _lib as L
-from .engine import INPUT, OUTPUT, HipSRModel, pack_conv, pack_conv_s16
+from .engine import INPUT, OUTPUT, HipSRModel, pack_conv, pack_conv_s16, pack_head_s16
 from .rlfn import FP, _lowres, _pad8
 
 
@@ -109,6 +109,8 @@ class BSRN(HipSRModel):
         w3 = torch.zeros(C, ic, 3, 3)
         w3[:, :, 1, 1] = w                                                     # 1x1 as the centre tap of the NCHW-input 3x3 path
         packed['fea_conv.pw'] = pack_conv(w3, pw.bias).to(device)
+        if self._store() != "f32":                                           # the 16-bit head (engine.Plan.conv lowers it to pack + conv_s16)
+            packed['fea_conv.pw#head#s16'] = pack_head_s16(w3, pw.bias, self._store()).to(device)
         for k in range(1, self.nb + 1):
             co = self._leaf(f'B{k}.conv_out')
             cw = self._leaf(f'B{k}').cw.detach().float().reshape(1, C)

@@ -1092,6 +1092,7 @@ static int run_one(const esr_op& op, void* hip_stream)
         case ESR_OP_ESA_APPLY: return esr_esa_apply_f32(&op.esa, hip_stream);
         case ESR_OP_DWCONV: return esr_dwconv3x3_f32(&op.conv, hip_stream);
         case ESR_OP_BSCONV: return esr_bsconv_f32(&op.bs, hip_stream);
+        case ESR_OP_PACK_INPUT: return esr_pack_input_s16(&op.conv, hip_stream);
         default: return ESR_ERR_BAD_ARG;
     }
 }

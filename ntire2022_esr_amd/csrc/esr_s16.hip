@@ -1186,6 +1186,50 @@ int esr_unpack_conv_s16(const void* packed, size_t bytes, int cin, int cout, int
 
 }  // extern "C"
 
+// ---- network input for the 16-bit plans (esr_pack_input_s16) ----------------------------------------------------------------
+namespace {
+template <bool BF16>
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, char* __restrict__ y, int C, long long hw, long long npix, int pitch, int coff)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+        const long long n = i / hw, s = i - n * hw;
+        unsigned short v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) {
+                const float f = x[(n * C + c) * hw + s];
+                const unsigned h = pack2<BF16>(f, 0.f) & 0xffffu;
+                float fh, dummy;
+                unpack2<BF16>(h, fh, dummy);
+                const unsigned l = pack2<BF16>(f - fh, 0.f) & 0xffffu;
+                v[c] = (unsigned short)h; v[C + c] = (unsigned short)l; v[2 * C + c] = (unsigned short)h;
+            }
+        uint4* o = reinterpret_cast<uint4*>(y + ((size_t)i * pitch + coff) * 2);
+        o[0] = uint4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16), (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
+        o[1] = uint4{(unsigned)v[8] | ((unsigned)v[9] << 16), (unsigned)v[10] | ((unsigned)v[11] << 16), (unsigned)v[12] | ((unsigned)v[13] << 16), (unsigned)v[14] | ((unsigned)v[15] << 16)};
+    }
+}
+}  // namespace
+
+extern "C" int esr_pack_input_s16(const esr_conv_desc* d, void* hip_stream)
+{
+    if (!d || !d->in.ptr || !d->out0.ptr || d->n <= 0 || d->h <= 0 || d->w <= 0) return ESR_ERR_BAD_ARG;
+    if (d->cin <= 0 || d->cin > 4) return ESR_ERR_UNSUPPORTED;
+    if (d->storage != ESR_STORE_BF16 && d->storage != ESR_STORE_F16) return ESR_ERR_BAD_ARG;
+    if ((d->out0.pitch & 7) || (d->out0.coff & 7) || d->out0.coff + 16 > d->out0.pitch) return ESR_ERR_BAD_ARG;
+    const long long hw = (long long)d->h * d->w, npix = hw * d->n;
+    const long long want = (npix + 255) / 256;
+    const int grid = (int)(want < 8192 ? want : 8192);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (d->storage == ESR_STORE_BF16)
+        hipLaunchKernelGGL(pack_input_kernel<true>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(d->in.ptr), static_cast<char*>(d->out0.ptr), d->cin, hw, npix, d->out0.pitch, d->out0.coff);
+    else
+        hipLaunchKernelGGL(pack_input_kernel<false>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(d->in.ptr), static_cast<char*>(d->out0.ptr), d->cin, hw, npix, d->out0.pitch, d->out0.coff);
+    return esr_check_launch("pack_input_kernel launch");
+}
+
 // called by esr_conv2d_f32 (esr_hip.hip) for descriptors with 16-bit storage
 int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
 {

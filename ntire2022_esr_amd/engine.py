@@ -75,6 +75,17 @@ def pack_conv_s16(weight, bias, compute, cin_map=None, cin_phys=None):
     return out
 
 
+def pack_head_s16(weight, bias, compute):
+    """Weights of the network's first 3x3 (NCHW fp32 input, cin <= 4) for the 16-bit head: the input arrives as 16-bit slots
+    [x_hi | x_lo | x_hi] (esr_pack_input_s16), the weights as [w_hi | w_hi | w_lo] with w = w_hi + w_lo in the storage type, so
+    the products w_hi x_hi + w_hi x_lo + w_lo x_hi keep ~fp32 accuracy on the 16-bit matrix cores."""
+    dt = torch.bfloat16 if compute == "bf16" else torch.float16
+    w = weight.detach().float().cpu()
+    hi = w.to(dt).float()
+    lo = w - hi
+    return pack_conv_s16(torch.cat([hi, hi, lo], dim=1), bias, compute)
+
+
 def pack_post_s16(weight, bias, compute):
     """[cout, cin(, 1, 1)] fp32 weights of a 1x1 evaluated in a 16-bit conv's epilogue (esr_conv_desc.post_* / post2_*) ->
     esr_pack_post_s16 blob (MFMA images of the weights' 16-bit high and low parts + fp32 bias)."""
@@ -233,9 +244,16 @@ class Plan:
         padded concat buffer (algorithmic flops / bytes).  border: name of an esr_conv_desc.border_bias table.  bs_of: this
         dense 3x3 stands for a BSConvU (pointwise 1x1 + depthwise 3x3 with merged weights): its algorithmic flops and its
         complexity-counter terms are the BSConvU's."""
+        head = None
+        if src is INPUT and self.esize == 2 and k == 3 and dst is not OUTPUT:
+            # 16-bit plans: the NCHW fp32 input is first packed to 16-bit hi / lo slots (esr_pack_input_s16), the head convolution
+            # then runs on conv_s16_kernel with hi / lo weights (`<name>#head#s16`, engine.pack_head_s16)
+            x16 = self.buffer('in16', 16)
+            self.ops.append(dict(kind="pack", src=INPUT, dst=x16, cin=cin, cout=16, hw=None, counted=False))
+            src, head, wname = x16, cin, wname + '#head'
         self.ops.append(dict(kind="conv", w=wname, src=src, dst=dst, dst1=dst1, cin=cin, cout=cout, k=k, act=act,
                              slope=slope, res=res, res_mode=res_mode, split=split, hw=hw, counted=counted, tail=tail,
-                             post=post, cin_alg=cin if cin_alg is None else cin_alg, border=border, bs_of=bs_of))
+                             post=post, cin_alg=cin if cin_alg is None else cin_alg, border=border, bs_of=bs_of, head=head))
 
     def dwconv(self, wname, src, dst, c, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.RES_NONE, hw=None):
         """depthwise 3x3 + bias (+res) (+act): the dw half of BSConvU."""
@@ -275,6 +293,13 @@ class Plan:
         base = workspace if isinstance(workspace, int) else (workspace.data_ptr() if workspace is not None else 0)
         for i, o in enumerate(self.ops):
             op = arr[i]
+            if o["kind"] == "pack":
+                op.kind = L.OP_PACK_INPUT
+                d = op.conv
+                d.n, d.h, d.w, d.cin, d.storage = self.n, self.h, self.w, o["cin"], st
+                d.out0 = self._view(o["dst"], base)
+                in_idx.append(i)
+                continue
             if o["kind"] == "bs":
                 op.kind = L.OP_BSCONV
                 d = op.bs
@@ -321,7 +346,7 @@ class Plan:
             d.n, d.h, d.w = self.n, self.h, self.w
             if o["hw"] is not None:
                 d.h, d.w = o["hw"]
-            d.cin, d.cout, d.ksize = o["cin"], o["cout"], o["k"]
+            d.cin, d.cout, d.ksize = (3 * o["head"] if o.get("head") else o["cin"]), o["cout"], o["k"]
             d.act, d.slope, d.res_mode = o["act"], o["slope"], o["res_mode"]
             d.split = o["split"]
             if o["src"] is INPUT:
@@ -496,7 +521,7 @@ class HipSRModel(nn.Module):
         """paths of the convolutions conv_s16_kernel runs in the 16-bit modes: every full-resolution NHWC conv"""
         plan = Plan(1, 32, 32, self._store())
         self._build_plan(plan, self.in_nc)
-        paths = {o["w"] for o in plan.ops if o["kind"] == "conv" and o["hw"] is None and o["src"] is not INPUT}
+        paths = {o["w"] for o in plan.ops if o["kind"] == "conv" and o["hw"] is None and o["src"] is not INPUT and not o.get("head")}
         for o in plan.ops:
             if o["kind"] == "bs":                        # BSConvU: pointwise + distillation 1x1 weights as hi + lo blobs
                 paths.add(o["pw"])
@@ -537,6 +562,12 @@ class HipSRModel(nn.Module):
                     out.add(t["post2"]["w"])
         return out
 
+    def _head_convs(self):
+        """paths of the convolutions that read the network input in the current 16-bit mode (lowered to pack + conv_s16)"""
+        plan = Plan(1, 32, 32, self._store())
+        self._build_plan(plan, self.in_nc)
+        return {o["w"][:-len('#head')] for o in plan.ops if o["kind"] == "conv" and o.get("head")}
+
     def _cin_map(self, path, cin_map, store):
         """physical-slot -> logical-channel map of a conv reading a padded concat buffer; networks whose slice padding
         depends on the storage type override this"""
@@ -554,6 +585,10 @@ class HipSRModel(nn.Module):
         for path in sorted(self._post_convs()) if self._store() != "f32" else ():
             leaf = self._leaf(path)
             packed[path + "#post"] = pack_post_s16(leaf.weight, leaf.bias, self._store()).to(device)
+        for path in sorted(self._head_convs()) if self._store() != "f32" else ():
+            if path in self._conv_specs and not self._conv_specs[path][3]:          # (custom-packed heads: _extra_pack)
+                leaf = self._leaf(path)
+                packed[path + "#head#s16"] = pack_head_s16(leaf.weight, leaf.bias, self._store()).to(device)
         for path, (cin_p, cout_p) in self._dense_specs.items():
             leaf = self._leaf(path)
             packed[path] = pack_dense(leaf.weight, leaf.bias, cin_p, cout_p).to(device)
@@ -681,6 +716,10 @@ class HipSRModel(nn.Module):
             hw = o.get("hw")
             npix = plan.npix if hw is None else plan.n * hw[0] * hw[1]
             e_act = es if hw is None else 4                       # low-resolution maps are fp32
+            if kind == "pack":                      # the network input, read once (fp32 NCHW); its 16-bit copy is an intermediate
+                out.append(dict(name="pack_input", kernel="pack_input_kernel", cin=o["cin"], cout=16, k=0, flops=0.0,
+                                read_bytes=float(npix * o["cin"] * 4), write_bytes=0.0))
+                continue
             if kind == "conv":
                 nt = (o["cout"] + 15) // 16
                 nw = L.lib().esr_conv_block_waves(ctypes.byref(arr[i].conv)) if arr is not None else 0
@@ -691,6 +730,8 @@ class HipSRModel(nn.Module):
                 e_out = 4 if o["dst"] is OUTPUT else e_act
                 ca = o["cin_alg"]
                 rd = npix * (ca * e_in + (o["cout"] * e_act if o["res"] is not None else 0)) + 4.0 * ca * o["cout"] * o["k"] ** 2
+                if o.get("head"):
+                    rd -= npix * ca * e_in            # (counted with the pack op)
                 wr = float(npix * o["cout"] * e_out) if o["dst"] is not None else 0.0
                 flops = 2.0 * npix * ca * o["cout"] * o["k"] * o["k"]
                 if o.get("bs_of") is not None:      # the BSConvU it stands for: pointwise GEMM + depthwise 3x3

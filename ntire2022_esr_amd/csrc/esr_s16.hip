@@ -763,7 +763,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         const char* sb = ring + slot * STAGE_BYTES;
         const char* wc = smem + c * W_CHUNK_BYTES + a_off;
 
-        constexpr int NBUF = (GRES || NW == 16 || NT == 4) ? 1 : 2;          // fragment sets: the read of pair q+1 runs under the MFMAs of pair q
+        constexpr int NBUF = NW == 16 ? 1 : 2;          // fragment sets: the read of pair q+1 runs under the MFMAs of pair q
         i32x4 a[NBUF][NT], b[NBUF][RW];
         auto load_frag = [&](int buf, int q) __attribute__((always_inline)) {
 #pragma unroll
@@ -783,9 +783,6 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
                 if (q + 1 < PAIRS) load_frag(cs ^ 1, q + 1);
                 __builtin_amdgcn_sched_barrier(0);      // keep the prefetch above this pair's MFMAs
             } else {
-                // single fragment set: the barrier keeps hipcc from hoisting the later groups' reads (it would, into every free
-                // register and then some: the 64-channel residual variants spilled the in-flight residual registers)
-                if (GRES && NT == 4 && q > 0) __builtin_amdgcn_sched_barrier(0);
                 load_frag(0, q);
             }
             if (q == 0 && EPI) {
@@ -796,7 +793,6 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt) acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], *reinterpret_cast<const f32x4*>(sbias + tt * 16 + kq * 4));
                     if (r & 1) swap_epi_store(r);
-                    if (GRES && NT == 4) __builtin_amdgcn_sched_barrier(0);      // keeps the rows' residual unpacking from piling up (spills)
                 }
             } else if (q == 0 && first) {
                 // first MFMA group of a tile: the accumulator input is the bias

@@ -675,6 +675,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     // the fp32 fragment as the B operand of the post 1x1: k slots 0..3 = the 16-bit high parts, 4..7 = the low parts
     auto hilo = [&](f32x4 v) __attribute__((always_inline)) -> i32x4 {
         const unsigned h0 = pack2<BF16>(v.x, v.y), h1 = pack2<BF16>(v.z, v.w);
+        if (!BF16) return i32x4{(int)h0, (int)h1, 0, 0};           // fp16: the high parts carry 11 bits, as much as anything stored
         float a, b, c, d;
         unpack2<BF16>(h0, a, b);
         unpack2<BF16>(h1, c, d);
@@ -1002,7 +1003,9 @@ int s16_post_plan(const esr_conv_desc* d, int nt, int nchunks, int* pnt1, int* p
                            d->res.pitch == d->in.pitch && d->res.coff == d->in.coff;
     const bool gres = d->res_mode != ESR_RES_NONE && !res_is_in;
     if (!post_variant_exists(d->ksize, nt, gres, *pnt1, *pnt2)) return ESR_ERR_UNSUPPORTED;
-    for (int lo = 1; lo >= 0; --lo) {
+    // fp16 storage: the post weights' low parts (and the activations' low parts, see hilo) are not needed -- 11 mantissa bits, the
+    // network's own storage precision; bf16 keeps hi + lo wherever the images fit
+    for (int lo = d->storage == ESR_STORE_F16 ? 0 : 1; lo >= 0; --lo) {
         const size_t pb = (size_t)(lo + 1) * (nt * *pnt1 + *pnt1 * *pnt2) * 1024 + 1024 + (d->border_bias ? (size_t)nt * 1024 : 0);
         int r = RING_MAX;
         while (r > RING_MIN && s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, r, pb) > (size_t)LDS_LIMIT) --r;

@@ -186,3 +186,58 @@ def test_conv_s16_isa_lint():
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lint_s16_isa.py")],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_merged_bsconv_algebra_cpu():
+    """BSRN._merged_bsconv (host arithmetic, no GPU): dense 3x3 with weights dw[c,tap] * pw[c,k] + interior bias + the 16-row border
+    table == the reference's BSConvU (pointwise Linear -> depthwise 3x3 over the zero-padded pointwise OUTPUT, team18_bsrn.py:82-88),
+    in fp64, on images as small as 1 pixel wide (all sides outside at once)."""
+    import torch.nn.functional as F
+    from ntire2022_esr_amd.bsrn import BSRN
+    g = torch.Generator().manual_seed(3)
+    for (cin, c, h, w) in ((12, 8, 9, 7), (6, 5, 1, 6), (4, 4, 5, 1), (3, 2, 1, 1)):
+        pw = torch.nn.Linear(cin, c).double()
+        dw = torch.nn.Conv2d(c, c, 3, padding=1, groups=c).double()
+        x = torch.randn(2, cin, h, w, generator=g, dtype=torch.float64)
+        with torch.no_grad():
+            ref = dw(pw(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2))
+        wm, bias, table = BSRN._merged_bsconv(pw, dw)
+        # fp64 re-derivation of what the kernel computes: conv + bias + table[outside mask of the pixel]
+        wd = dw.weight.detach().reshape(c, 1, 3, 3)
+        w64 = wd * pw.weight.detach().reshape(c, cin, 1, 1)
+        y = F.conv2d(x, w64, None, padding=1)
+        bp, bd = pw.bias.detach(), dw.bias.detach()
+        y = y + (bd + bp * wd.sum(dim=(1, 2, 3))).reshape(1, c, 1, 1)
+        ys, xs = torch.arange(h), torch.arange(w)
+        mask = ((xs == 0).long() | ((xs == w - 1).long() << 1)).reshape(1, w) | (((ys == 0).long() << 2) | ((ys == h - 1).long() << 3)).reshape(h, 1)
+        tab64 = torch.zeros(16, c, dtype=torch.float64)
+        for m in range(1, 16):
+            out = torch.zeros(3, 3, dtype=torch.bool)
+            if m & 1: out[:, 0] = True
+            if m & 2: out[:, 2] = True
+            if m & 4: out[0, :] = True
+            if m & 8: out[2, :] = True
+            tab64[m] = -bp * (wd.reshape(c, 3, 3) * out.double()).sum(dim=(1, 2))
+        y = y + tab64[mask].permute(2, 0, 1).unsqueeze(0)
+        assert float((y - ref).abs().max()) < 1e-12
+        # and the fp32 tensors the engine packs are those quantities
+        assert float((wm.double() - w64).abs().max()) < 1e-7 and float((table[:, :c].double() - tab64).abs().max()) < 1e-7
+        assert float((bias.double() - (bd + bp * wd.sum(dim=(1, 2, 3)))).abs().max()) < 1e-7
+
+
+def test_head_hi_lo_weights_cpu():
+    """engine.pack_head_s16: [w_hi | w_hi | w_lo] against the input slots [x_hi | x_lo | x_hi] reproduces w * x up to the dropped
+    lo x lo term (2^-16 relative for bf16, 2^-22 for fp16) -- checked on the unpacked blob, no GPU."""
+    from ntire2022_esr_amd.engine import pack_head_s16, unpack_conv_s16
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(20, 3, 3, 3, generator=g) * 0.1
+    b = torch.randn(20, generator=g)
+    x = torch.rand(3, generator=g) * 255
+    for compute, dt, rel in (("bf16", torch.bfloat16, 2.0 ** -15), ("f16", torch.float16, 2.0 ** -21)):
+        weff, beff = unpack_conv_s16(pack_head_s16(w, b, compute), 9, 20, 3, compute, cin_phys=16)
+        xh = x.to(dt).float()
+        slots = torch.cat([xh, (x - xh).to(dt).float(), xh])                                   # what esr_pack_input_s16 writes
+        got = (weff.double() * slots.double().reshape(1, 9, 1, 1)).sum(dim=1)                  # per tap, per output channel
+        want = (w.double() * x.double().reshape(1, 3, 1, 1)).sum(dim=1)
+        assert float((got - want).abs().max()) <= rel * float((w.abs().double() * x.double().reshape(1, 3, 1, 1)).sum(dim=1).max()) * 4
+        assert torch.equal(beff, b)

@@ -165,8 +165,9 @@ class Buffer:
     """An NHWC activation buffer inside the workspace: [n][h][w][pitch] elements of `esize` bytes
     (4 = fp32; 2 = bf16 / fp16 for the full-resolution buffers of a 16-bit-storage plan)."""
 
-    def __init__(self, name, pitch, offset_bytes, h=None, w=None, esize=4):
+    def __init__(self, name, pitch, offset_bytes, h=None, w=None, esize=4, arena=0):
         self.name, self.pitch, self.offset, self.h, self.w, self.esize = name, pitch, offset_bytes, h, w, esize
+        self.arena = arena     # 0: full-resolution buffers (the plan's storage type), 1: low-resolution fp32 maps -- kept apart, see Plan
 
     def __getitem__(self, sl):
         """buf[a:b] -> channel slice view (coff=a, channels=b-a)."""
@@ -205,7 +206,9 @@ class Plan:
         self.npix = n * h * w
         self.store = store
         self.esize = 4 if store == "f32" else 2
-        self.total = 0         # bytes
+        self.total = 0         # bytes of the full-resolution arena
+        self.total_lo = 0      # bytes of the low-resolution (always fp32) arena.  The two never overlap across plans: a 16-bit plan
+                               # laid over another shape's fp32 maps would read their bytes as bf16 / fp16 -- Inf / NaN patterns included
         self.buffers = []
         self.ops = []          # python dicts until finalize()
 
@@ -222,8 +225,13 @@ class Plan:
         assert (pitch * esize) % 16 == 0
         h = self.h if h is None else h
         w = self.w if w is None else w
-        b = Buffer(name, pitch, self.total, h, w, esize)
-        self.total += (self.n * h * w * pitch * esize + 255) // 256 * 256
+        size = (self.n * h * w * pitch * esize + 255) // 256 * 256
+        if lowres:
+            b = Buffer(name, pitch, self.total_lo, h, w, esize, arena=1)
+            self.total_lo += size
+        else:
+            b = Buffer(name, pitch, self.total, h, w, esize)
+            self.total += size
         self.buffers.append(b)
         return b
 
@@ -278,11 +286,17 @@ class Plan:
         self.ops.append(dict(kind="apply", wf=wf, w4=w4, x=x, c1=c1, c3=c3, dst=dst, c=c, f=f))
 
     @staticmethod
-    def _view(v, base_ptr):
+    def _addr(buf, base):
+        """base = (workspace address, bytes reserved for the low-resolution arena in front of the full-resolution one)"""
+        ws, lo_cap = base
+        return ws + (buf.offset if buf.arena == 1 else lo_cap + buf.offset)
+
+    @staticmethod
+    def _view(v, base):
         if isinstance(v, Buffer):
             v = (v, 0, v.pitch)
         buf, coff, _ = v
-        return L.View(ctypes.c_void_p(base_ptr + buf.offset), buf.pitch, coff)
+        return L.View(ctypes.c_void_p(Plan._addr(buf, base)), buf.pitch, coff)
 
     def finalize(self, workspace, weights):
         """weights: name -> device blob tensor (16-bit-storage plans: `name#s16` for the NHWC convs).  Returns
@@ -290,7 +304,7 @@ class Plan:
         st = L.STORE[self.store]
         arr = (L.Op * len(self.ops))()
         in_idx, out_idx = [], []
-        base = workspace if isinstance(workspace, int) else (workspace.data_ptr() if workspace is not None else 0)
+        base = workspace if isinstance(workspace, tuple) else ((workspace if isinstance(workspace, int) else (workspace.data_ptr() if workspace is not None else 0)), self.total_lo)
         for i, o in enumerate(self.ops):
             op = arr[i]
             if o["kind"] == "pack":
@@ -327,8 +341,8 @@ class Plan:
                     e.h, e.w, e.c, e.f = self.h, self.w, o["c"], o["f"]
                     e.h_lo, e.w_lo = o["c3"].h, o["c3"].w
                     e.x, e.y = self._view(o["x"], base), self._view(o["dst"], base)
-                    e.c1 = ctypes.c_void_p(base + o["c1"].offset)
-                    e.c3 = ctypes.c_void_p(base + o["c3"].offset)
+                    e.c1 = ctypes.c_void_p(self._addr(o["c1"], base))
+                    e.c3 = ctypes.c_void_p(self._addr(o["c3"], base))
                     e.w0 = ctypes.c_void_p(weights[o["wf"]].data_ptr())
                     e.w1 = ctypes.c_void_p(weights[o["w4"]].data_ptr())
                 else:
@@ -460,7 +474,8 @@ class HipSRModel(nn.Module):
         self._dirty = True         # parameters may have changed since the last repack (load_state_dict / .to() / repack())
         self._plans = collections.OrderedDict()   # (n, c, h, w, device) -> _Entry, LRU
         self._ws = None            # ONE grow-only workspace per model (all cached plans lay their buffers out in it)
-        self._ws_owner = None      # key of the plan whose zero pad layout the workspace currently holds
+        self._ws_owner = None      # key of the plan that ran last in the workspace (None: content unknown -> zero before use)
+        self._lo_cap = 0           # bytes reserved in front of the workspace for the plans' low-resolution fp32 maps (grow-only)
         self.compute = "f32"       # "f32" | "bf16" | "f16": MFMA operand format of the full-resolution 3x3 convs
         self._prof_passes = 0      # >0: record HIP events around every op (bench roofline leg)
         self._profs = {}
@@ -531,6 +546,15 @@ class HipSRModel(nn.Module):
 
     # -- packing ------------------------------------------------------------------------------
     MAX_PLANS = 128                # DIV2K has ~100 distinct LR shapes; a plan is a few tens of KB of host memory
+    # Plans of different shapes lay their buffers out in ONE workspace, so after a shape switch another shape's activations lie where
+    # this plan keeps its pad channels.  That is harmless: every pad slot is only ever multiplied by a zero weight (packers), added
+    # to an accumulator nobody stores, or copied into another pad slot -- stale FINITE values of the SAME element type cannot reach a
+    # result (bit-identical outputs in every mode: tools/dbg/rezero_probe.py, test_hundred_shapes_one_workspace).  Same type is what
+    # the two arenas of a Plan are for: the low-resolution fp32 maps of all plans live in front of the workspace (`_lo_cap` bytes),
+    # the full-resolution buffers behind them, so a 16-bit plan never reads another shape's fp32 bytes (Inf / NaN patterns).
+    # Re-zeroing 130 MB per forward was 26 us of a 0.7 ms image (every DIV2K image has its own shape): +3 % in DIV2K mode (A/B).
+    # Set True to isolate forwards from a previous one whose activations overflowed to Inf / NaN.
+    rezero_on_switch = False
 
     def _mark_dirty(self):
         self._dirty = True
@@ -630,18 +654,23 @@ class HipSRModel(nn.Module):
                     L.lib().esr_prof_destroy(prof)
         else:
             self._plans.move_to_end(key)
-        need = max(ent.plan.total, 256)
+        if ent.plan.total_lo > self._lo_cap:
+            self._lo_cap = ent.plan.total_lo           # the low-resolution arena grows: every plan's full-resolution buffers move
+            self._ws_owner = None
+        need = max(self._lo_cap + ent.plan.total, 256)
         if self._ws is None or self._ws.device != device or self._ws.numel() < need:
             self._ws = None                                             # release before the larger allocation
             self._ws = torch.zeros(need, dtype=torch.uint8, device=device)
             self._ws_owner = key                                        # fresh zeros: this plan's pad channels are 0
-        if ent.base != self._ws.data_ptr():
-            ent.arr, ent.in_idx, ent.out_idx = ent.plan.finalize(self._ws.data_ptr(), self._packed)
-            ent.base = self._ws.data_ptr()
-        if self._ws_owner != key:
-            # another shape's activations are lying where this plan keeps its zero pad channels
-            self._ws[:need].zero_()
-            self._ws_owner = key
+        base = (self._ws.data_ptr(), self._lo_cap)
+        if ent.base != base:
+            ent.arr, ent.in_idx, ent.out_idx = ent.plan.finalize(base, self._packed)
+            ent.base = base
+        if self._ws_owner is None:
+            self._ws.zero_()            # unknown content (plans dropped: another storage type's bytes; the arenas moved)
+        elif self._ws_owner != key and self.rezero_on_switch:
+            self._ws.zero_()            # isolation requested
+        self._ws_owner = key
         return ent
 
     def prepare(self, shape, device=None):
@@ -843,4 +872,4 @@ class HipSRModel(nn.Module):
     def workspace_bytes(self, n, h, w, c=3):
         plan = Plan(n, h, w, self._store())
         self._build_plan(plan, c)
-        return plan.total
+        return plan.total + plan.total_lo

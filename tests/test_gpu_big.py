@@ -110,13 +110,21 @@ def test_tiled_forward_matches_reference(name):
 
 
 def test_hundred_shapes_one_workspace():
-    """DIV2K has ~100 distinct LR shapes: plans are cached (LRU), the workspace is ONE grow-only allocation that is
-    re-zeroed on a shape switch, and results do not depend on what ran before."""
-    m, dr = _model("team04_rlfn", "f32")
+    """DIV2K has ~100 distinct LR shapes: plans are cached (LRU), the workspace is ONE grow-only allocation shared by all of them,
+    and results do not depend on what ran before -- stale activations of another shape in a plan's pad channels only ever meet zero
+    weights (engine.HipSRModel.rezero_on_switch), in the fp32 and in the 16-bit plans."""
+    _hundred_shapes("team04_rlfn", "f32")
+    _hundred_shapes("rfdn_baseline", "bf16", 30)
+    _hundred_shapes("team18_bsrn", "f16", 30)
+
+
+def _hundred_shapes(name, compute, nshapes=100):
+    m, dr = _model(name, compute)
+    assert not m.rezero_on_switch
     g = torch.Generator().manual_seed(0)
     x0 = (torch.rand(1, 3, 40, 56, generator=g) * dr).to(DEV)
     y0 = m(x0).clone()
-    shapes = [(24 + (i * 7) % 41, 20 + (i * 11) % 53) for i in range(100)]
+    shapes = [(24 + (i * 7) % 41, 20 + (i * 11) % 53) for i in range(nshapes)]
     big = max(m.workspace_bytes(1, h, w) for h, w in shapes)
     for h, w in shapes:
         m.prepare((1, 3, h, w), DEV)
@@ -129,3 +137,4 @@ def test_hundred_shapes_one_workspace():
         m((torch.rand(1, 3, h, w, generator=g) * dr).to(DEV))
         assert m._plans[(1, 3, h, w, torch.device(DEV))] is ent and m._ws.data_ptr() == base
     assert torch.equal(m(x0), y0)
+    m.set_compute("f32")

@@ -134,6 +134,11 @@ def parse_args():
     ap.add_argument("--tile", default="256x256", help="LR tile HxW (config [4]: 270x480)")
     ap.add_argument("--sizes", default="tile", choices=["tile", "div2k"],
                     help="div2k: one step = the 10 DIV2K-val-shaped LR images of DIV2K_LR_SHAPES, one image per forward")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="HIP streams the forwards of a step are spread over, round-robin (default: 1 for tiles, 4 with --sizes "
+                         "div2k).  One image per forward leaves most of the chip idle (352 tiles on 256 CUs, a third of the "
+                         "launches latency-bound low-resolution kernels); every stream has its own workspace in the engine, so "
+                         "independent images overlap.  --streams 1 is the reference's strictly serial loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--b1-latency", action="store_true",
                     help="also report the latency of a single-image forward (extra launches after the timed region: "
@@ -221,16 +226,33 @@ def main():
     xs = [(torch.rand(B, 3, h, w, generator=gen) * dr).to(device) for h, w in shapes]
     imgs_per_step = B * len(xs)
     gflop_per_step = sum(B * gflop256 * (h * w) / 65536.0 for h, w in shapes)
+    nstreams = max(1, args.streams if args.streams is not None else (4 if args.sizes == "div2k" else 1))
+    streams = [torch.cuda.Stream(device) for _ in range(nstreams)] if nstreams > 1 else None
+    if args.sizes == "tile" and nstreams > 1:
+        # the batch of a step as `nstreams` sub-batches, one forward each
+        if B % nstreams:
+            raise SystemExit(f"--streams {nstreams} does not divide the batch {B}")
+        xs = [c.contiguous() for c in xs[0].chunk(nstreams)]
+    # Per-kernel HIP events bracket every launch.  At B = 32 that is < 1 % of a step and they are recorded inside the timed
+    # region; one image per forward (20 us kernels) they cost 20 % and, with several streams, would time overlapping kernels:
+    # there the timed region runs un-instrumented and the SAME steps are replayed on one stream with events for the roofline leg.
+    events_in_region = not args.no_kernel_events and args.sizes == "tile" and nstreams == 1
+    events_after = not args.no_kernel_events and not events_in_region
 
-    def step():
-        for x in xs:
-            y = model(x)
+    def step(spread=True):
+        if streams is None or not spread:
+            for x in xs:
+                y = model(x)
+        else:
+            for i, x in enumerate(xs):
+                with torch.cuda.stream(streams[i % nstreams]):
+                    y = model(x)
         return y
 
     with torch.no_grad():
         for _ in range(args.warmup):
             y = step()
-        if not args.no_kernel_events:
+        if events_in_region:
             model.enable_profiling(args.steps)
             step()                         # creates the events outside the timed region
             torch.cuda.synchronize(device)
@@ -241,7 +263,19 @@ def main():
             y = step()
         barrier()
         elapsed = time.perf_counter() - t0
-    assert tuple(y.shape) == (B, 3, 4 * shapes[-1][0], 4 * shapes[-1][1])
+        instrumented_ms = None
+        if events_after:
+            step(False)                    # the default stream's context: plans, workspace
+            model.enable_profiling(args.steps)
+            step(False)
+            torch.cuda.synchronize(device)
+            model.collect_profile()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step(False)
+            torch.cuda.synchronize(device)
+            instrumented_ms = (time.perf_counter() - t1) / args.steps * 1e3
+    assert tuple(y.shape) == (xs[-1].shape[0], 3, 4 * shapes[-1][0], 4 * shapes[-1][1])
     elapsed, seen = reduce_elapsed(elapsed)
 
     roofline = None
@@ -297,16 +331,21 @@ def main():
             table.append({"kernel": kn, "share": round(kms / total_ms, 4), "avg_ms": round(kms / n, 4),
                           "tflops": round(fl / (kms * 1e-3) / 1e12, 2), "gbs": round(by / (kms * 1e-3) / 1e9, 1)})
         roofline["kernels"] = table
+        roofline["events"] = ("HIP event pair around every launch, inside the timed region" if events_in_region else
+                              f"HIP event pair around every launch in a replay of the same {args.steps} steps on ONE stream after the "
+                              f"timed region ({instrumented_ms:.3f} ms/step with the events; the timed region carries none)")
 
     if rank == 0:
         imgs = world * imgs_per_step * args.steps
         value = imgs / elapsed
         if args.sizes == "div2k":
             wl = (f"{args.model} x4 {args.compute}, DIV2K-val-shaped LR images {sorted(set(shapes))} "
-                  f"({len(shapes)} per step, B = {B} per forward)")
+                  f"({len(shapes)} per step, B = {B} per forward, forwards spread over {nstreams} HIP stream(s))")
             metric = "images/sec (DIV2K-val-shaped LR ~339x510 -> x4)"
         else:
             wl = f"{args.model} x4 {args.compute}, {B}x3x{th}x{tw} LR batch per GPU -> {B}x3x{4 * th}x{4 * tw}"
+            if nstreams > 1:
+                wl += f" ({nstreams} sub-batches of {B // nstreams}, one HIP stream each)"
             metric = f"images/sec ({th}x{tw}->{4 * th}x{4 * tw} x4)"
         model_tflops = world * gflop_per_step * args.steps / elapsed / 1e3
         out = {
@@ -315,7 +354,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.compute,
             "data": f"synthetic (uniform [0,{dr:g}) LR tiles resident in HBM; weights: {weights})",
-            "config": {"workload": wl, "batch_per_gpu": B, "parallelism": f"image-parallel replicas x{world}",
+            "config": {"workload": wl, "batch_per_gpu": B, "streams_per_gpu": nstreams,
+                       "parallelism": f"image-parallel replicas x{world}",
                        "algorithmic_gflop_per_step_per_gpu": round(gflop_per_step, 2)},
             "ranks_seen": seen,
             "model_tflops": round(model_tflops, 2),

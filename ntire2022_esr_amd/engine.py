@@ -460,6 +460,20 @@ class _Entry:
         self.plan, self.arr, self.in_idx, self.out_idx, self.base = plan, None, (), (), None
 
 
+class _StreamCtx:
+    """What a forward needs that is private to ONE HIP stream: the workspace, the plans finalized against it and the
+    per-kernel event sets.  Two forwards of the same model enqueued on two streams run concurrently on the GPU, so they must
+    not share activation buffers; the packed weights (read-only) are shared."""
+    __slots__ = ("plans", "ws", "ws_owner", "lo_cap", "profs")
+
+    def __init__(self):
+        self.plans = collections.OrderedDict()   # (n, c, h, w, device) -> _Entry, LRU
+        self.ws = None             # ONE grow-only workspace (all cached plans lay their buffers out in it)
+        self.ws_owner = None       # key of the plan that ran last in the workspace (None: content unknown -> zero before use)
+        self.lo_cap = 0            # bytes reserved in front of the workspace for the plans' low-resolution fp32 maps (grow-only)
+        self.profs = {}
+
+
 class HipSRModel(nn.Module):
     """Base of the drop-in nn.Modules.  Subclasses register reference-compatible parameters
     with `_add_conv` and describe their forward with `_build_plan`."""
@@ -472,13 +486,9 @@ class HipSRModel(nn.Module):
         self._packed = None        # path -> device blob
         self._packed_sig = None
         self._dirty = True         # parameters may have changed since the last repack (load_state_dict / .to() / repack())
-        self._plans = collections.OrderedDict()   # (n, c, h, w, device) -> _Entry, LRU
-        self._ws = None            # ONE grow-only workspace per model (all cached plans lay their buffers out in it)
-        self._ws_owner = None      # key of the plan that ran last in the workspace (None: content unknown -> zero before use)
-        self._lo_cap = 0           # bytes reserved in front of the workspace for the plans' low-resolution fp32 maps (grow-only)
+        self._ctxs = {}            # (device, HIP stream handle) -> _StreamCtx: workspace + plans of the forwards enqueued on that stream
         self.compute = "f32"       # "f32" | "bf16" | "f16": MFMA operand format of the full-resolution 3x3 convs
         self._prof_passes = 0      # >0: record HIP events around every op (bench roofline leg)
-        self._profs = {}
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
 
     # -- parameter registration: same key names as the reference state_dict -------------------
@@ -567,11 +577,34 @@ class HipSRModel(nn.Module):
         return tuple((p.data_ptr(), p._version, p.device) for p in self.parameters())
 
     def _drop_plans(self):
-        for prof in self._profs.values():
-            L.lib().esr_prof_destroy(prof)
-        self._profs = {}
-        self._plans.clear()
-        self._ws_owner = None
+        for ctx in self._ctxs.values():
+            for prof in ctx.profs.values():
+                L.lib().esr_prof_destroy(prof)
+            ctx.profs = {}
+            ctx.plans.clear()
+            ctx.ws_owner = None
+
+    MAX_STREAMS = 8                # contexts kept; the least recently created one beyond that is dropped (its workspace is freed)
+
+    def _ctx(self, device):
+        """The context of the CURRENT HIP stream of `device` (torch.cuda.stream(...) selects it, like every torch op)."""
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        ctx = self._ctxs.get(key)
+        if ctx is None:
+            ctx = self._ctxs[key] = _StreamCtx()
+            while len(self._ctxs) > self.MAX_STREAMS:
+                old = next(iter(self._ctxs))
+                for prof in self._ctxs.pop(old).profs.values():
+                    L.lib().esr_prof_destroy(prof)
+        return ctx
+
+    # the default-stream context under its historical names (tests, tools)
+    def _ctx0(self):
+        dev = next(self.parameters()).device
+        return self._ctxs.get((dev, torch.cuda.default_stream(dev).cuda_stream)) or _StreamCtx()
+
+    _plans = property(lambda self: self._ctx0().plans)
+    _ws = property(lambda self: self._ctx0().ws)
 
     def _post_convs(self):
         """paths of the 1x1 convolutions evaluated in a 16-bit conv's epilogue (post / post2) in the current mode"""
@@ -620,6 +653,8 @@ class HipSRModel(nn.Module):
             leaf = self._leaf(path)
             packed[path] = pack_dw(leaf.weight, leaf.bias).to(device)
         self._extra_pack(packed, device)
+        if torch.device(device).type == "cuda":
+            torch.cuda.synchronize(device)           # the blobs are read by forwards on ANY stream from here on
         self._packed = packed
         self._packed_sig = self._signature()
         self._dirty = False
@@ -638,39 +673,42 @@ class HipSRModel(nn.Module):
         if self._packed is None or self._dirty or next(iter(self._packed.values())).device != device:
             self.repack(device)
 
-    def _entry(self, key):
-        """Cached plan for (n, c, h, w, device): built on first use, finalized against the current workspace."""
+    def _entry(self, key, ctx=None):
+        """Cached plan for (n, c, h, w, device) in the current stream's context: built on first use, finalized against that
+        context's workspace."""
         n, c, h, w, device = key
-        ent = self._plans.get(key)
+        if ctx is None:
+            ctx = self._ctx(device)
+        ent = ctx.plans.get(key)
         if ent is None:
             plan = Plan(n, h, w, self._store())
             self._build_plan(plan, c)
             ent = _Entry(plan)
-            self._plans[key] = ent
-            while len(self._plans) > self.MAX_PLANS:
-                old, _ = self._plans.popitem(last=False)
-                prof = self._profs.pop(old, None)
+            ctx.plans[key] = ent
+            while len(ctx.plans) > self.MAX_PLANS:
+                old, _ = ctx.plans.popitem(last=False)
+                prof = ctx.profs.pop(old, None)
                 if prof is not None:
                     L.lib().esr_prof_destroy(prof)
         else:
-            self._plans.move_to_end(key)
-        if ent.plan.total_lo > self._lo_cap:
-            self._lo_cap = ent.plan.total_lo           # the low-resolution arena grows: every plan's full-resolution buffers move
-            self._ws_owner = None
-        need = max(self._lo_cap + ent.plan.total, 256)
-        if self._ws is None or self._ws.device != device or self._ws.numel() < need:
-            self._ws = None                                             # release before the larger allocation
-            self._ws = torch.zeros(need, dtype=torch.uint8, device=device)
-            self._ws_owner = key                                        # fresh zeros: this plan's pad channels are 0
-        base = (self._ws.data_ptr(), self._lo_cap)
+            ctx.plans.move_to_end(key)
+        if ent.plan.total_lo > ctx.lo_cap:
+            ctx.lo_cap = ent.plan.total_lo             # the low-resolution arena grows: every plan's full-resolution buffers move
+            ctx.ws_owner = None
+        need = max(ctx.lo_cap + ent.plan.total, 256)
+        if ctx.ws is None or ctx.ws.device != device or ctx.ws.numel() < need:
+            ctx.ws = None                                               # release before the larger allocation
+            ctx.ws = torch.zeros(need, dtype=torch.uint8, device=device)
+            ctx.ws_owner = key                                          # fresh zeros: this plan's pad channels are 0
+        base = (ctx.ws.data_ptr(), ctx.lo_cap)
         if ent.base != base:
             ent.arr, ent.in_idx, ent.out_idx = ent.plan.finalize(base, self._packed)
             ent.base = base
-        if self._ws_owner is None:
-            self._ws.zero_()            # unknown content (plans dropped: another storage type's bytes; the arenas moved)
-        elif self._ws_owner != key and self.rezero_on_switch:
-            self._ws.zero_()            # isolation requested
-        self._ws_owner = key
+        if ctx.ws_owner is None:
+            ctx.ws.zero_()              # unknown content (plans dropped: another storage type's bytes; the arenas moved)
+        elif ctx.ws_owner != key and self.rezero_on_switch:
+            ctx.ws.zero_()              # isolation requested
+        ctx.ws_owner = key
         return ent
 
     def prepare(self, shape, device=None):
@@ -703,7 +741,8 @@ class HipSRModel(nn.Module):
         self._ensure_packed(x.device)
         n, c, h, w = x.shape
         key = (n, c, h, w, x.device)
-        ent = self._entry(key)
+        ctx = self._ctx(x.device)
+        ent = self._entry(key, ctx)
         arr = ent.arr
         y = torch.empty((n, self.out_nc, h * self.upscale, w * self.upscale), dtype=torch.float32, device=x.device)
         for i in ent.in_idx:
@@ -712,11 +751,11 @@ class HipSRModel(nn.Module):
             arr[i].conv.out0.ptr = y.data_ptr()
         stream = torch.cuda.current_stream(x.device).cuda_stream
         if self._prof_passes > 0:
-            prof = self._profs.get(key)
+            prof = ctx.profs.get(key)
             if prof is None:
                 prof = ctypes.c_void_p()
                 L.check(lib.esr_prof_create(len(arr), self._prof_passes, ctypes.byref(prof)), "esr_prof_create")
-                self._profs[key] = prof
+                ctx.profs[key] = prof
             rc = lib.esr_run_ops_profiled(arr, len(arr), ctypes.c_void_p(stream), prof)
         else:
             rc = lib.esr_run_ops(arr, len(arr), ctypes.c_void_p(stream))
@@ -729,9 +768,10 @@ class HipSRModel(nn.Module):
         self._prof_passes = int(max_passes)
 
     def disable_profiling(self):
-        for prof in self._profs.values():
-            L.lib().esr_prof_destroy(prof)
-        self._profs = {}
+        for ctx in self._ctxs.values():
+            for prof in ctx.profs.values():
+                L.lib().esr_prof_destroy(prof)
+            ctx.profs = {}
         self._prof_passes = 0
 
     def op_costs(self, plan, arr=None):
@@ -821,17 +861,18 @@ class HipSRModel(nn.Module):
         """After a device synchronise: list of dicts {name, kernel, flops, read_bytes, write_bytes, ms_sum, passes} per
         op, summed over the recorded passes of every cached shape."""
         out = []
-        for key, prof in self._profs.items():
-            ent = self._plans.get(key)
-            if ent is None or ent.arr is None:
-                continue
-            n = len(ent.arr)
-            ms = (ctypes.c_double * n)()
-            passes = ctypes.c_int(0)
-            L.check(L.lib().esr_prof_collect(prof, ms, n, ctypes.byref(passes)), "esr_prof_collect")
-            for i, c in enumerate(self.op_costs(ent.plan, ent.arr)):
-                c.update(ms_sum=ms[i], passes=passes.value, shape=key[:4])
-                out.append(c)
+        for ctx in self._ctxs.values():
+            for key, prof in ctx.profs.items():
+                ent = ctx.plans.get(key)
+                if ent is None or ent.arr is None:
+                    continue
+                n = len(ent.arr)
+                ms = (ctypes.c_double * n)()
+                passes = ctypes.c_int(0)
+                L.check(L.lib().esr_prof_collect(prof, ms, n, ctypes.byref(passes)), "esr_prof_collect")
+                for i, c in enumerate(self.op_costs(ent.plan, ent.arr)):
+                    c.update(ms_sum=ms[i], passes=passes.value, shape=key[:4])
+                    out.append(c)
         return out
 
     def _complexity_terms(self, plan, o):

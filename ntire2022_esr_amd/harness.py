@@ -150,6 +150,12 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
         window = max(1, int(getattr(args, "inflight", 3)))
         readers, writers = ThreadPoolExecutor(nio), ThreadPoolExecutor(nio)
         copy_stream = torch.cuda.Stream(device)
+        # --gpu_streams S > 1: image k's H2D, forward and metrics go to compute stream k % S (the engine keeps one workspace per
+        # stream), so independent images overlap on the GPU.  Throughput only: an image's event-bracketed runtime then includes
+        # the time it shared the chip, so the reference's runtime column needs the default S = 1.
+        ngs = max(1, int(getattr(args, "gpu_streams", 1)))
+        compute_streams = [torch.cuda.Stream(device) for _ in range(ngs)] if ngs > 1 else [torch.cuda.current_stream(device)]
+        window = max(window, ngs)
         ahead = [readers.submit(load_pair, i) for i in mine[:nio + window]]
         nxt = len(ahead)
         inflight, writes = [], []
@@ -169,31 +175,32 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
             if nxt < len(mine):
                 ahead.append(readers.submit(load_pair, mine[nxt]))
                 nxt += 1
-            img_lr = util.uint2tensor4(lr, data_range).to(device, non_blocking=True)
-            hr_dev = torch.from_numpy(np.ascontiguousarray(img_hr)).to(device, non_blocking=True)
-            if hasattr(model, "prepare"):
-                # plan construction / workspace zero fill are not part of the forward the reference times
-                # (test_demo.py:429-432 brackets model(img_lq) only); whole-image and tiled shapes alike
-                b, c, h, w = img_lr.shape
-                t = None if tile is None else min(tile, h, w)
-                model.prepare((b, c, h, w) if t is None else (b, c, t, t), device)
-            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            start.record()
-            img_sr = forward(img_lr, model, tile)
-            end.record()
-            sr_dev = ops.tensor2uint_device(img_sr, data_range)
-            if sr_dev.shape != hr_dev.shape:
-                raise ValueError('Input images must have the same dimensions.')
-            se_dev = ops.sqerr_device(sr_dev, hr_dev, border=border)
-            ready = torch.cuda.Event()
-            ready.record()
-            sr_host = torch.empty(sr_dev.shape, dtype=torch.uint8, pin_memory=True)
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(ready)
-                sr_host.copy_(sr_dev, non_blocking=True)
-                sr_dev.record_stream(copy_stream)
-                done = torch.cuda.Event()
-                done.record()
+            with torch.cuda.stream(compute_streams[k % ngs]):
+                img_lr = util.uint2tensor4(lr, data_range).to(device, non_blocking=True)
+                hr_dev = torch.from_numpy(np.ascontiguousarray(img_hr)).to(device, non_blocking=True)
+                if hasattr(model, "prepare"):
+                    # plan construction / workspace zero fill are not part of the forward the reference times
+                    # (test_demo.py:429-432 brackets model(img_lq) only); whole-image and tiled shapes alike
+                    b, c, h, w = img_lr.shape
+                    t = None if tile is None else min(tile, h, w)
+                    model.prepare((b, c, h, w) if t is None else (b, c, t, t), device)
+                start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                start.record()
+                img_sr = forward(img_lr, model, tile)
+                end.record()
+                sr_dev = ops.tensor2uint_device(img_sr, data_range)
+                if sr_dev.shape != hr_dev.shape:
+                    raise ValueError('Input images must have the same dimensions.')
+                se_dev = ops.sqerr_device(sr_dev, hr_dev, border=border)
+                ready = torch.cuda.Event()
+                ready.record()
+                sr_host = torch.empty(sr_dev.shape, dtype=torch.uint8, pin_memory=True)
+                with torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(ready)
+                    sr_host.copy_(sr_dev, non_blocking=True)
+                    sr_dev.record_stream(copy_stream)
+                    done = torch.cuda.Event()
+                    done.record()
             hh, ww = sr_dev.shape[:2]
             inflight.append((i, start, end, done, sr_host, se_dev, (hh - 2 * border) * (ww - 2 * border) * sr_dev.shape[2], img_hr))
             if len(inflight) > window:
@@ -319,6 +326,9 @@ def build_parser():
                    help="run on N generated DIV2K-val-shaped PNG pairs under save_dir/_synthetic instead of data_dir")
     p.add_argument("--io_workers", default=8, type=int, help="PNG decode / encode threads per rank")
     p.add_argument("--inflight", default=3, type=int, help="images in flight between the GPU and the writers")
+    p.add_argument("--gpu_streams", default=1, type=int,
+                   help="compute streams per rank; > 1 overlaps independent images on the GPU (throughput; the per-image "
+                        "runtime column then includes shared time, keep 1 for the reference's runtime semantics)")
     return p
 
 

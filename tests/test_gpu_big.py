@@ -138,3 +138,30 @@ def _hundred_shapes(name, compute, nshapes=100):
         assert m._plans[(1, 3, h, w, torch.device(DEV))] is ent and m._ws.data_ptr() == base
     assert torch.equal(m(x0), y0)
     m.set_compute("f32")
+
+
+@pytest.mark.parametrize("name,compute", [("team04_rlfn", "bf16"), ("rfdn_baseline", "bf16"), ("team18_bsrn", "f16"),
+                                          ("imdn_baseline", "f32")])
+def test_forwards_on_several_streams_equal_serial(name, compute):
+    """one model, forwards enqueued round-robin on four HIP streams (bench.py --streams, harness --gpu_streams): every stream
+    has its own workspace and plans in the engine (engine._StreamCtx), so overlapping forwards are bit-identical to serial
+    ones -- DIV2K-like shapes, different per stream and changing between rounds"""
+    m, dr = _model(name, compute)
+    g = torch.Generator().manual_seed(3)
+    shapes = [(85, 128), (96, 128), (128, 85), (74, 128), (85, 128), (87, 128), (128, 96), (85, 128), (85, 128), (64, 64)]
+    xs = [(torch.rand(1, 3, h, w, generator=g) * dr).to(DEV) for h, w in shapes]
+    want = [m(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(DEV) for _ in range(4)]
+    for rnd in range(3):
+        got = []
+        for i, x in enumerate(xs):
+            with torch.cuda.stream(streams[(i + rnd) % 4]):
+                got.append(m(x))
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert torch.equal(a, b), (rnd, i)
+    dev = torch.device(DEV)
+    assert len(m._ctxs) == 5 and len({c.ws.data_ptr() for c in m._ctxs.values()}) == 5      # default stream + 4, one workspace each
+    assert all(k[0] == dev for k in m._ctxs)
+    m.set_compute("f32")

@@ -126,5 +126,12 @@ def test_pipeline_equals_serial_loop(tmp_path):
         y = util.imread_uint(str(tmp_path / "serial" / name / "valid" / f))
         assert np.array_equal(x, y), f
     assert a1.pipeline["valid"]["images"] == 6 and a1.pipeline["valid"]["images_per_s"] > 0
+    # three compute streams (one engine workspace each): same PSNRs and files again
+    a3 = types.SimpleNamespace(save_dir=str(tmp_path / "pipe3"), rank=0, world=1, io_workers=3, inflight=2, gpu_streams=3)
+    r3 = H.run(model, name, data_range, tile, log, dev, a3, mode="valid", pairs=pairs)
+    assert r3["valid_psnr"] == r2["valid_psnr"] and r3["valid_ave_psnr"] == r2["valid_ave_psnr"]
+    for f in sorted(os.listdir(str(tmp_path / "serial" / name / "valid"))):
+        assert np.array_equal(util.imread_uint(str(tmp_path / "pipe3" / name / "valid" / f)),
+                              util.imread_uint(str(tmp_path / "serial" / name / "valid" / f))), f
     # the big generated images are DIV2K-shaped: 4 x (339 x 510) etc.
     assert util.imread_uint(pairs[3][1]).shape == (1356, 2040, 3) and util.imread_uint(pairs[3][0]).shape == (339, 510, 3)

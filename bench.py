@@ -14,13 +14,15 @@ Workloads (BASELINE.json configs):
 
 A "step" is one pass of the hot path (test_demo.py forward(), :364-367) over one batch of synthetic LR input already
 resident in HBM (`--sizes div2k`: one pass over a fixed list of 10 DIV2K-val-shaped LR images, one image per forward like
-the reference's loop, test_demo.py:416-433).  Image-level data parallelism: every rank holds a full replica
+the reference's loop, test_demo.py:416-433, the forwards spread round-robin over `--streams` HIP streams -- default 4 in
+this mode, `--streams 1` = the strictly serial loop; the engine keeps one workspace per stream).  Image-level data parallelism: every rank holds a full replica
 and its own inputs, there is no collective inside the timed region ("scaling": "weak"); the only communication is the
 MAX-reduction of the elapsed time (and a gather of the ranks that took part).
 
 Prints ONE JSON line on rank 0 with the contract fields plus
   roofline      the kernel symbol with the largest share of the timed kernel time: ALGORITHMIC flops and HBM bytes per
-                launch / average launch duration from HIP events recorded on the launch stream during the timed steps,
+                launch / average launch duration from HIP events recorded on the launch stream during the timed steps
+                (DIV2K mode / several streams: during a replay of the same steps on one stream, see `roofline.events`),
                 against the dense MFMA peak of its operand type and the 8 TB/s HBM peak; `bound` names the binding one
   cpu_baseline  the reference's CPU path restated (oracle/torch_port.py: the same ATen op sequence) timed on this box's
                 host cores on a bounded sample (rank 0, N=1 only)

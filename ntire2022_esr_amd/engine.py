@@ -809,6 +809,8 @@ class HipSRModel(nn.Module):
                 t = o.get("tail")
                 if t is not None:                   # 3x3 -> 1x1 in one kernel: both GEMMs' flops, the 1x1's traffic
                     kern = f"conv_f32_kernel<NT={nt},KS=3,NCHW_IN=0,NW=4,TAIL={(t['cout'] + 15) // 16}>"
+                    if (o["cin"] + 7) // 8 == 6 and t["cat_c"] == 48 and t["cout"] == 64 and o.get("res_mode", L.RES_NONE) in (L.RES_NONE, L.RES_PRE_ACT):
+                        kern = f"imdb_tail_kernel<FOLD={int(o['res'] is not None)}>"       # esr_hip.hip: imdb_tail_shape()
                     k1 = t["cat_c"] + o["cout"]
                     flops += 2.0 * npix * k1 * t["cout"]
                     rd = npix * e_act * (o["cin"] + t["cat_c"] + (t["cout"] if o["res"] is not None else 0)) \

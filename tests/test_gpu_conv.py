@@ -181,11 +181,12 @@ def test_conv_8wave_split_store_and_shuffle():
     assert float((y - ref).abs().max()) / max(1.0, float(ref.abs().max())) < 2e-5
 
 
-@pytest.mark.parametrize("n,hw", [(1, (16, 16)), (2, (37, 45)), (3, (130, 96))])
+@pytest.mark.parametrize("n,hw", [(1, (16, 16)), (2, (37, 45)), (3, (130, 96)), (9, (150, 171))])      # the last: 990 tiles on <= 512 blocks
 @pytest.mark.parametrize("mid_act,res_mode,cat_c", [(0, 1, 48), (1, 0, 48), (0, 2, 32)])
 def test_conv3x3_with_fused_1x1_tail(n, hw, mid_act, res_mode, cat_c):
     """esr_conv_desc.tail_*: IMDBlock's conv4 -> cat -> conv1x1 -> + x (basicblock.py:263-265) in one launch, against
-    the three ATen ops; the concat part is a channel slice of a wider buffer."""
+    the three ATen ops; the concat part is a channel slice of a wider buffer.  cat_c = 48 with no / a pre-activation residual is
+    the network's own shape and runs on imdb_tail_kernel (csrc/imdb_tail.inc), the rest on conv_f32_kernel's TAIL variant."""
     from ntire2022_esr_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(n + hw[0] + 5 * mid_act + res_mode + cat_c)

@@ -715,7 +715,295 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
     }
 }
 
-#include "imdb_tail.inc"                   // IMDBlock's fused tail at the network's own shape: DMA ring of three, residual folded
+// imdb_tail.inc -- IMDBlock's conv4 -> cat -> conv1x1 -> + x (models/basicblock.py:263-265) for the shape the network has:
+// 3x3 48 -> 16, concat of 3 x 16 stored channels, 1x1 64 -> 64.  Included by esr_hip.hip inside its anonymous namespace.
+//
+// Same arithmetic as conv_f32_kernel<1,3,false,4,TAIL=4> (which stays the fallback for other shapes); what differs is the
+// memory pipeline.  With one output-channel tile a K stage is 72 MFMAs per wave (2 300 cycles), shorter than the loaded HBM
+// latency, and in the generic kernel every load has to land within about one stage (staging registers are written to LDS at
+// the end of the next stage, the concat fragments are requested at the top of the last stage, the residual in the epilogue):
+// tools/abl/f32_tail_abl.py -- without the concat loads 0.66 -> 0.46 ms, without the epilogue 0.51 ms.  Here
+//   * the halo tile and the chunk's weights go global -> LDS by DMA (no staging registers) into a ring of THREE stages and are
+//     requested TWO stages ahead; 16 DMA pieces of 1 KB per stage, four per wave, so every wave's vmcnt bookkeeping is the same;
+//   * the residual x is loaded in the D-fragment layout straight INTO the 1x1's accumulators three stages before they are
+//     used (FOLD; pre-activation residual only) -- the epilogue has no loads left;
+//   * the concat B fragments are requested two stages before the 1x1.
+// Everything is compile-time indexed (6 chunks = 2 trips round the ring per tile), the only loop is the tile walk.
+// LDS: 3 x 14 976 (ring) + 17 408 (epilogue scratch) + 16 640 (1x1 image + bias) = 78 976 B -> two blocks per CU.
+
+constexpr int IT_NCH = 6;                         // K chunks of 8 input channels (48)
+constexpr int IT_CAT = 3;                         // 16-channel chunks of the 1x1's K read from the concat buffer
+constexpr int IT_TH = TILE + 2;
+constexpr int IT_NPX = IT_TH * IT_TH;             // 324 halo pixels
+constexpr int IT_IN_BYTES = IT_NPX * 32;          // [halo pixel][8 ch]
+constexpr int IT_IN_ITEMS = IT_NPX * 2;           // 16-byte items (pixel, half)
+constexpr int IT_W_BYTES = 9 * 512;               // [tap][lane][2]
+constexpr int IT_W_ITEMS = IT_W_BYTES / 16;
+constexpr int IT_STAGE = IT_IN_BYTES + IT_W_BYTES;
+constexpr int IT_R = 3;
+static_assert((IT_IN_ITEMS + 63) / 64 == 11 && (IT_W_ITEMS + 63) / 64 == 5, "16 DMA pieces per stage: 4 per wave");
+static_assert(IT_NCH % IT_R == 0, "a tile starts at ring slot 0");
+
+typedef int it_i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ it_i32x4 it_rsrc(const void* base, size_t bytes)
+{
+    it_i32x4 r;
+    r.x = (int)(size_t)base;
+    r.y = (int)(((size_t)base >> 32) & 0xffff);
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+
+// 64 lanes x 16 bytes, global -> LDS (lds_dst + 16 * lane for the active lanes); out-of-range voff writes zeros.  Inline asm:
+// hipcc cannot see which LDS bytes a DMA touches and would put vmcnt(0) in front of later ds_reads; the stage loop counts.
+__device__ __forceinline__ void it_dma16(unsigned lds_dst, unsigned voff, it_i32x4 rsrc, unsigned soff)
+{
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    rsrc.x = __builtin_amdgcn_readfirstlane(rsrc.x); rsrc.y = __builtin_amdgcn_readfirstlane(rsrc.y);
+    rsrc.z = __builtin_amdgcn_readfirstlane(rsrc.z); rsrc.w = __builtin_amdgcn_readfirstlane(rsrc.w);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+template <bool FOLD>
+__global__ __launch_bounds__(256, 2) void imdb_tail_kernel(const ConvK p)
+{
+    constexpr int TNT = 4;
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int WL_FLOATS = TAIL_C16 * TNT * 256 + TNT * 16;
+    __shared__ __attribute__((aligned(16))) char smem[IT_R * IT_STAGE + 4 * EPI_WAVE_FLOATS * 4 + WL_FLOATS * 4];
+
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15;
+    const int kq = lane >> 4;
+    float* const scr = reinterpret_cast<float*>(smem + IT_R * IT_STAGE) + wv * EPI_WAVE_FLOATS;
+    float* const wl = reinterpret_cast<float*>(smem + IT_R * IT_STAGE + 4 * EPI_WAVE_FLOATS * 4);
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int ntiles = p.N * p.tiles_y * p.tiles_x;
+    const int G = gridDim.x;
+    auto tile_index = [&](int k) -> int {             // XCD-aware walk, as in conv_f32_kernel
+        const int base = k * G;
+        if (base >= ntiles) return -1;
+        int off = blockIdx.x;
+        if ((G & 7) == 0 && base + G <= ntiles) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+        const int t = base + off;
+        return t < ntiles ? t : -1;
+    };
+
+    // This wave's DMA pieces of a stage: input pieces wv, wv + 4 and (waves 0-2) wv + 8 -- piece 10 has 8 live lanes --,
+    // weight piece 0 (wave 3) and weight piece wv + 1 -- piece 4 has 32 live lanes.  Four instructions per wave and stage.
+    struct TileCtx { int n, x0, y0; unsigned voff[3]; };
+    auto setup_tile = [&](int t, TileCtx& c) {
+        if (t < 0) {                                   // behind the last tile: the DMAs still issue (uniform counts), all lanes out of range
+            c.n = 0; c.x0 = 0; c.y0 = 0;
+            c.voff[0] = c.voff[1] = c.voff[2] = OOB;
+            return;
+        }
+        const int tx = t % p.tiles_x;
+        const int tq = t / p.tiles_x;
+        const int ty = tq % p.tiles_y;
+        c.n = tq / p.tiles_y;
+        c.x0 = tx * TILE;
+        c.y0 = ty * TILE;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = (wv + 4 * i) * 64 + lane;
+            const int half = j & 1;
+            const int pl = j >> 1;
+            const int ly = pl / IT_TH, lx = pl - ly * IT_TH;
+            const int gy = c.y0 - 1 + ly, gx = c.x0 - 1 + lx;
+            const bool ok = j < IT_IN_ITEMS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            c.voff[i] = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff + 4 * half) * 4u : OOB;
+        }
+    };
+    const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 4;
+    const it_i32x4 wrsrc = it_rsrc(p.wp, (size_t)IT_NCH * IT_W_BYTES);
+    const bool w3 = wv == 3;                                             // uniform
+    const bool live2 = w3 || (wv + 8) * 64 + lane < IT_IN_ITEMS;         // third piece: wave 2 keeps 8 lanes
+    const bool live3 = (wv + 1) * 64 + lane < IT_W_ITEMS;                // fourth piece: wave 3 keeps 32 lanes
+    const unsigned wvoff2 = (unsigned)lane * 16u;                        // weight piece 0
+    const unsigned wvoff3 = (unsigned)((wv + 1) * 64 + lane) * 16u;
+
+    auto issue = [&](int slot, const TileCtx& tc, int chunk) __attribute__((always_inline)) {
+        const it_i32x4 xr = it_rsrc(p.x + (size_t)tc.n * (img_bytes / 4), img_bytes);
+        const unsigned base = ring_lds + (unsigned)(slot * IT_STAGE);
+        const unsigned cin_off = (unsigned)chunk * 32u, w_off = (unsigned)chunk * (unsigned)IT_W_BYTES;
+        it_dma16(base + (unsigned)wv * 1024u, tc.voff[0], xr, cin_off);
+        it_dma16(base + (unsigned)(wv + 4) * 1024u, tc.voff[1], xr, cin_off);
+        {
+            it_i32x4 r2;
+            r2.x = w3 ? wrsrc.x : xr.x; r2.y = w3 ? wrsrc.y : xr.y; r2.z = w3 ? wrsrc.z : xr.z; r2.w = xr.w;
+            const unsigned v2 = w3 ? wvoff2 : tc.voff[2];
+            const unsigned d2 = base + (w3 ? (unsigned)IT_IN_BYTES : (unsigned)(wv + 8) * 1024u);
+            if (live2) it_dma16(d2, v2, r2, w3 ? w_off : cin_off);
+        }
+        if (live3) it_dma16(base + (unsigned)IT_IN_BYTES + (unsigned)(wv + 1) * 1024u, wvoff3, wrsrc, w_off);
+    };
+
+    int k = 0;
+    int t = tile_index(0);
+    if (t < 0) return;
+    TileCtx cur, nxt;
+    setup_tile(t, cur);
+    int tn = tile_index(1);
+    setup_tile(tn, nxt);
+    issue(0, cur, 0);
+    issue(1, cur, 1);
+
+    const f32x4 biasv = *reinterpret_cast<const f32x4*>(p.bias + kq * 4);
+    {
+        // 1x1 weights: blob order in, (chunk16, tile, lane, j) order out -- as conv_f32_kernel's tail
+        const int nch8 = 2 * (IT_CAT + 1);
+        for (int q = tid; q < nch8 * TNT * 32; q += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.wp2 + (size_t)q * 4);
+            const int ip = q & 7, kq8 = (q >> 3) & 3, ct = q >> 5;
+            const int tt = ct % TNT, chunk8 = ct / TNT;
+            const int ch16 = 8 * (chunk8 & 1) + 2 * kq8;
+            float* dst = wl + (((chunk8 >> 1) * TNT + tt) * 64 + (ch16 >> 2) * 16 + 2 * ip) * 4 + (ch16 & 3);
+            dst[0] = v.x; dst[1] = v.y; dst[4] = v.z; dst[5] = v.w;
+        }
+        if (tid < TNT * 16) wl[TAIL_C16 * TNT * 256 + tid] = p.bias2[tid];
+    }
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");           // stage 0 has landed (stage 1 may still fly), wl is written
+    __builtin_amdgcn_s_barrier();
+
+    const int b_base = ((wv * 4) * IT_TH + px) * 32 + kq * 8;
+    const int a_base = IT_IN_BYTES + lane * 8;
+    const size_t cat_img_bytes = (size_t)p.H * p.W * p.cat_pitch * 4;
+    const size_t res_img_bytes = (size_t)p.H * p.W * p.res_pitch * 4;
+
+    for (;;) {
+        const bool has_next = tn >= 0;
+        f32x4 acc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = biasv;
+        f32x4 acc2[TNT][4];
+        f32x4 bc[IT_CAT][4];
+        if (!FOLD) {
+#pragma unroll
+            for (int tt = 0; tt < TNT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc2[tt][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+
+#pragma unroll
+        for (int c = 0; c < IT_NCH; ++c) {
+            // ---- top of the stage: everything stage c + 2 needs, then this tile's register loads
+            if (c + 2 < IT_NCH) issue((c + 2) % IT_R, cur, c + 2);
+            else issue((c + 2) % IT_R, nxt, c + 2 - IT_NCH);
+            if ((FOLD && c == IT_NCH - 3) || c == IT_NCH - 2) {
+                const bool is_res = FOLD && c == IT_NCH - 3;
+                const int pitch = is_res ? p.res_pitch : p.cat_pitch;
+                const int coff = is_res ? p.res_coff : p.cat_coff;
+                const size_t ibytes = is_res ? res_img_bytes : cat_img_bytes;
+                const float* ibase = (is_res ? p.res : p.cat) + (size_t)cur.n * (ibytes / 4);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ibase), 0, (int)ibytes, 0x00020000);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gy = cur.y0 + wv * 4 + r, gx = cur.x0 + px;
+                    const unsigned vo = (gy < p.H && gx < p.W) ? (unsigned)((gy * p.W + gx) * pitch + coff + 4 * kq) * 4u : OOB;
+                    if (is_res) {
+#pragma unroll
+                        for (int tt = 0; tt < TNT; ++tt)
+                            acc2[tt][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, tt * 64, 0));
+                    } else {
+#pragma unroll
+                        for (int C = 0; C < IT_CAT; ++C)
+                            bc[C][r] = f32x4{(float)vo, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
+            // ---- the chunk's 72 MFMAs, fragment reads one tap ahead
+            const char* s = smem + (c % IT_R) * IT_STAGE;
+            f32x2 a[2], b[2][4];
+            auto load_frag = [&](int slot, int tap) __attribute__((always_inline)) {
+                const int dy = tap / 3, dx = tap - dy * 3;
+                a[slot] = *reinterpret_cast<const f32x2*>(s + a_base + tap * 512);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    b[slot][r] = *reinterpret_cast<const f32x2*>(s + b_base + ((r + dy) * IT_TH + dx) * 32);
+            };
+            load_frag(0, 0);
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int cs = tap & 1;
+                if (tap + 1 < 9) load_frag(cs ^ 1, tap + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cs][j], b[cs][r][j], acc[r], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(3);
+            // ---- end of the stage: stage c + 1 (requested at the top of stage c - 1, before that stage's register loads) has
+            // landed; younger and allowed to fly: the register loads of stage c - 1, the 4 DMAs and the register loads of stage c
+            constexpr int NX = FOLD ? 4 * TNT : 0, NB = 4 * IT_CAT;
+            const int vis_prev = (c - 1 == IT_NCH - 3 ? NX : 0) + (c - 1 == IT_NCH - 2 ? NB : 0);
+            const int vis_here = (c == IT_NCH - 3 ? NX : 0) + (c == IT_NCH - 2 ? NB : 0);
+            switch (vis_prev + 4 + vis_here) {                 // compile-time after unrolling
+                case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+                case 16: asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); break;
+                case 20: asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory"); break;
+                case 32: asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+
+        // ---- 1x1: K = the three concat chunks + the 3x3 result; accumulators start at x (FOLD) + bias
+        {
+#pragma unroll
+            for (int tt = 0; tt < TNT; ++tt) {
+                const f32x4 b2 = *reinterpret_cast<const f32x4*>(wl + TAIL_C16 * TNT * 256 + tt * 16 + kq * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc2[tt][r] += b2;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x4 v = acc[r];
+                v.x = act_any(v.x, p.mid_act, p.slope); v.y = act_any(v.y, p.mid_act, p.slope);
+                v.z = act_any(v.z, p.mid_act, p.slope); v.w = act_any(v.w, p.mid_act, p.slope);
+                acc[r] = v;
+            }
+            auto tail_chunk = [&](int C, const f32x4 (&bf)[4]) __attribute__((always_inline)) {
+                f32x4 a2[TNT];
+#pragma unroll
+                for (int tt = 0; tt < TNT; ++tt) a2[tt] = *reinterpret_cast<const f32x4*>(wl + ((C * TNT + tt) * 64 + lane) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int tt = 0; tt < TNT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc2[tt][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tt][j], bf[r][j], acc2[tt][r], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            __builtin_amdgcn_s_setprio(0);
+            tail_chunk(IT_CAT, acc);                   // the 3x3 result first: it is in registers, the concat may still be landing
+#pragma unroll
+            for (int C = 0; C < IT_CAT; ++C) tail_chunk(C, bc[C]);
+            __builtin_amdgcn_s_setprio(3);
+            epilogue_nhwc<TNT>(p, acc2, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE);
+        }
+        if (!has_next) break;
+        cur = nxt;
+        ++k;
+        tn = tile_index(k + 1);
+        setup_tile(tn, nxt);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the out-of-range DMAs issued behind the last tile
+}
+                   // IMDBlock's fused tail at the network's own shape: DMA ring of three, residual folded
 
 #ifdef ESR_EXPERIMENTAL_WS
 #include "experimental/conv_ws.inc"        // wave-specialised research variant (tools/dbg builds only)

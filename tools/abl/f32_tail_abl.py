@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
-"""Ablation builds + timing of the fused IMDB tail, conv_f32_kernel<1,3,false,4,TAIL=4> (research tooling only).
+"""Ablation builds + timing of the fused IMDB tail (research tooling only): imdb_tail_kernel (csrc/imdb_tail.inc) and, as `old`,
+conv_f32_kernel<1,3,false,4,TAIL=4>, which ran this shape until the end of round 2.
 
   python tools/abl/f32_tail_abl.py build [names]   (authoring container)
   python tools/abl/f32_tail_abl.py run             (GPU box: one tail launch per variant, B = 32, 256x256, IMDBlock shapes)
 
-Variants are TEXT substitutions on a copy of csrc/esr_hip.hip (results of every variant but `prod` are wrong):
+Variants are TEXT substitutions on a copy of csrc/esr_hip.hip + imdb_tail.inc (results of every variant but `prod` / `old` are wrong):
   prod     unchanged
-  nocat    no loads of the concat slices (the 1x1 runs on stale registers)
-  no1x1    no MFMAs of the 1x1 (its A-fragment reads stay)
-  noconv   no MFMAs of the 3x3
-  noepi    no epilogue (no residual loads, no stores)
-  nostage  the staging loads / ds_writes / weight DMA of the 3x3 happen for the first tile only
+  old      the generic TAIL variant (dispatch to imdb_tail_kernel disabled)
+  nocat    no loads of the concat slices          nores   no loads of the residual
+  no1x1    no MFMAs of the 1x1                    noconv  no MFMAs of the 3x3
+  noepi    no epilogue (no stores)                nobar   no stage barriers
+  nodma    the DMAs of a stage are not issued
 """
 import ctypes, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -20,19 +21,28 @@ SRC = os.path.join(REPO, "ntire2022_esr_amd", "csrc")
 
 SUBS = {
     "prod": [],
-    "nocat": [("                        if (C < p.cat_chunks) bc[C][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(crsrc, vo, C * 64, 0));",
-               "                        if (C < p.cat_chunks && vo == 0x7fffff1u) bc[C][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(crsrc, vo, C * 64, 0));")],
-    "no1x1": [("                            acc2[tt][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tt][j], bf[r][j], acc2[tt][r], 0, 0, 0);",
-               "                            acc2[tt][r].x += a2[tt][j] * bf[r][j];")],
-    "noconv": [("                            acc[tt][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cs][tt][j], b[cs][r][j], acc[tt][r], 0, 0, 0);",
-                "                            if (TNT) acc[tt][r].x += a[cs][tt][j] * b[cs][r][j]; else acc[tt][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cs][tt][j], b[cs][r][j], acc[tt][r], 0, 0, 0);")],
-    "noepi": [("            epilogue_nhwc<(TNT ? TNT : 1)>(p, acc2, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE_H);",
-               "            if (acc2[0][0].x == 1.2345e-30f) epilogue_nhwc<(TNT ? TNT : 1)>(p, acc2, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE_H);")],
+    "old": [("    if (imdb_tail_shape(k)) {", "    if (false) {")],
+    "nocat": [("                            bc[C][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, C * 64, 0));",
+               "                            bc[C][r] = f32x4{(float)vo, 0.f, 0.f, 0.f};")],
+    "nores": [("                            acc2[tt][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, tt * 64, 0));",
+               "                            acc2[tt][r] = f32x4{(float)vo, 0.f, 0.f, 0.f};")],
+    "no1x1": [("                            acc2[tt][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tt][j], bf[r][j], acc2[tt][r], 0, 0, 0);\n                __builtin_amdgcn_sched_barrier(0);\n            };\n            __builtin_amdgcn_s_setprio(0);",
+               "                            acc2[tt][r].x += a2[tt][j] * bf[r][j];\n                __builtin_amdgcn_sched_barrier(0);\n            };\n            __builtin_amdgcn_s_setprio(0);")],
+    "noconv": [("                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cs][j], b[cs][r][j], acc[r], 0, 0, 0);",
+                "                        acc[r].x += a[cs][j] * b[cs][r][j];")],
+    "noepi": [("            epilogue_nhwc<TNT>(p, acc2, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE);",
+               "            if (acc2[0][0].x == 1.2345e-30f) epilogue_nhwc<TNT>(p, acc2, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE);")],
+    "nobar": [("                default: asm volatile(\"s_waitcnt vmcnt(0) lgkmcnt(0)\" ::: \"memory\"); break;\n            }\n            __builtin_amdgcn_s_barrier();",
+               "                default: asm volatile(\"s_waitcnt vmcnt(0) lgkmcnt(0)\" ::: \"memory\"); break;\n            }")],
+    "nodma": [("            if (c + 2 < IT_NCH) issue((c + 2) % IT_R, cur, c + 2);\n            else issue((c + 2) % IT_R, nxt, c + 2 - IT_NCH);", "            ;")],
 }
 
 
 def build(only=None):
     base = open(os.path.join(SRC, "esr_hip.hip")).read()
+    inc = '#include "imdb_tail.inc"'
+    assert inc in base
+    base = base.replace(inc, open(os.path.join(SRC, "imdb_tail.inc")).read())
     others = [os.path.join(SRC, f) for f in ("esr_s16.hip", "esr_esa.hip", "esr_bsconv.hip", "esr_ca.hip")]
     objs = []
     for f in others:

@@ -787,8 +787,11 @@ int launch_conv_tail(const ConvK& k, hipStream_t st)
     if (imdb_tail_shape(k)) {
         ConvK kk = k;
         kk.res_mode = ESR_RES_NONE;                 // folded into the 1x1's accumulators: the epilogue adds nothing
-        if (k.res_mode == ESR_RES_PRE_ACT) hipLaunchKernelGGL((imdb_tail_kernel<true>), dim3(grid), dim3(THREADS), 0, st, kk);
-        else hipLaunchKernelGGL((imdb_tail_kernel<false>), dim3(grid), dim3(THREADS), 0, st, kk);
+        kk.tiles_y = (k.H + 4 * IT_NW - 1) / (4 * IT_NW);      // 16 x 32 pixel tiles, one 8-wave block per CU
+        const int nt32 = k.N * kk.tiles_x * kk.tiles_y;
+        const int g32 = nt32 < 256 ? nt32 : 256;
+        if (k.res_mode == ESR_RES_PRE_ACT) hipLaunchKernelGGL((imdb_tail_kernel<true>), dim3(g32), dim3(64 * IT_NW), 0, st, kk);
+        else hipLaunchKernelGGL((imdb_tail_kernel<false>), dim3(g32), dim3(64 * IT_NW), 0, st, kk);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             set_err("imdb_tail_kernel launch", e);

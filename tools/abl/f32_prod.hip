@@ -719,29 +719,31 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
 // 3x3 48 -> 16, concat of 3 x 16 stored channels, 1x1 64 -> 64.  Included by esr_hip.hip inside its anonymous namespace.
 //
 // Same arithmetic as conv_f32_kernel<1,3,false,4,TAIL=4> (which stays the fallback for other shapes); what differs is the
-// memory pipeline.  With one output-channel tile a K stage is 72 MFMAs per wave (2 300 cycles), shorter than the loaded HBM
-// latency, and in the generic kernel every load has to land within about one stage (staging registers are written to LDS at
-// the end of the next stage, the concat fragments are requested at the top of the last stage, the residual in the epilogue):
-// tools/abl/f32_tail_abl.py -- without the concat loads 0.66 -> 0.46 ms, without the epilogue 0.51 ms.  Here
-//   * the halo tile and the chunk's weights go global -> LDS by DMA (no staging registers) into a ring of THREE stages and are
-//     requested TWO stages ahead; 16 DMA pieces of 1 KB per stage, four per wave, so every wave's vmcnt bookkeeping is the same;
+// pipeline.  With one output-channel tile a K stage is 72 MFMAs per wave (2 300 cycles): shorter than the loaded HBM latency,
+// and a block-wide barrier per stage costs 15 % on top (tools/abl/f32_tail_abl.py: every load of the generic kernel has to land
+// within about one stage -- without the concat loads 0.66 -> 0.46 ms, without the epilogue 0.51 ms, without barriers -15 %).  Here
+//   * NO stage barriers: every wave stages ITS OWN six halo rows (4 output rows + 2) global -> LDS by DMA into a private ring of
+//     three stages, requested two stages ahead (4 DMA instructions per wave and stage); the 3x3's weights (27 KB) and the 1x1's
+//     (16 KB) are resident in LDS for the life of the block, so nothing staged is shared between waves and the eight waves of a
+//     block drift freely -- one wave's epilogue runs under another's MFMAs;
 //   * the residual x is loaded in the D-fragment layout straight INTO the 1x1's accumulators three stages before they are
-//     used (FOLD; pre-activation residual only) -- the epilogue has no loads left;
+//     used (FOLD; pre-activation residual only): the epilogue has no loads left;
 //   * the concat B fragments are requested two stages before the 1x1.
+// The price is 1.5x the halo rows through the L1 (6 rows staged per 4 computed; the neighbour wave's copy hits the L2).
 // Everything is compile-time indexed (6 chunks = 2 trips round the ring per tile), the only loop is the tile walk.
-// LDS: 3 x 14 976 (ring) + 17 408 (epilogue scratch) + 16 640 (1x1 image + bias) = 78 976 B -> two blocks per CU.
+// LDS: 27 648 + 16 640 (weights) + 8 x 3 x 3 456 (rings) + 8 x 4 352 (epilogue scratch) = 162 048 B: one 8-wave block per CU.
 
 constexpr int IT_NCH = 6;                         // K chunks of 8 input channels (48)
 constexpr int IT_CAT = 3;                         // 16-channel chunks of the 1x1's K read from the concat buffer
+constexpr int IT_NW = 8;                          // waves per block: a 16 x 32 pixel tile, 4 rows each
 constexpr int IT_TH = TILE + 2;
-constexpr int IT_NPX = IT_TH * IT_TH;             // 324 halo pixels
-constexpr int IT_IN_BYTES = IT_NPX * 32;          // [halo pixel][8 ch]
-constexpr int IT_IN_ITEMS = IT_NPX * 2;           // 16-byte items (pixel, half)
-constexpr int IT_W_BYTES = 9 * 512;               // [tap][lane][2]
-constexpr int IT_W_ITEMS = IT_W_BYTES / 16;
-constexpr int IT_STAGE = IT_IN_BYTES + IT_W_BYTES;
+constexpr int IT_ROWS = 6;                        // halo rows a wave stages for its 4 output rows
+constexpr int IT_NPX = IT_ROWS * IT_TH;           // 108 halo pixels per wave
+constexpr int IT_IN_BYTES = IT_NPX * 32;          // [halo pixel][8 ch] = 3 456
+constexpr int IT_IN_ITEMS = IT_NPX * 2;           // 16-byte items (pixel, half): 3 full DMA pieces + one of 24 lanes
+constexpr int IT_W_BYTES = 9 * 512;               // one chunk's [tap][lane][2]
 constexpr int IT_R = 3;
-static_assert((IT_IN_ITEMS + 63) / 64 == 11 && (IT_W_ITEMS + 63) / 64 == 5, "16 DMA pieces per stage: 4 per wave");
+static_assert((IT_IN_ITEMS + 63) / 64 == 4, "4 DMA pieces per wave and stage");
 static_assert(IT_NCH % IT_R == 0, "a tile starts at ring slot 0");
 
 typedef int it_i32x4 __attribute__((ext_vector_type(4)));
@@ -770,12 +772,16 @@ __device__ __forceinline__ void it_dma16(unsigned lds_dst, unsigned voff, it_i32
 }
 
 template <bool FOLD>
-__global__ __launch_bounds__(256, 2) void imdb_tail_kernel(const ConvK p)
+__global__ __launch_bounds__(64 * IT_NW, 1) void imdb_tail_kernel(const ConvK p)
 {
     constexpr int TNT = 4;
     constexpr unsigned OOB = 0x80000000u;
+    constexpr int W3_BYTES = IT_NCH * IT_W_BYTES;                         // 27 648: [chunk][tap][lane][2]
     constexpr int WL_FLOATS = TAIL_C16 * TNT * 256 + TNT * 16;
-    __shared__ __attribute__((aligned(16))) char smem[IT_R * IT_STAGE + 4 * EPI_WAVE_FLOATS * 4 + WL_FLOATS * 4];
+    constexpr int RING_OFF = W3_BYTES + WL_FLOATS * 4;
+    constexpr int SCR_OFF = RING_OFF + IT_NW * IT_R * IT_IN_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SCR_OFF + IT_NW * EPI_WAVE_FLOATS * 4];
+    static_assert(sizeof(smem) <= 160 * 1024, "LDS");
 
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x;
@@ -783,11 +789,12 @@ __global__ __launch_bounds__(256, 2) void imdb_tail_kernel(const ConvK p)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15;
     const int kq = lane >> 4;
-    float* const scr = reinterpret_cast<float*>(smem + IT_R * IT_STAGE) + wv * EPI_WAVE_FLOATS;
-    float* const wl = reinterpret_cast<float*>(smem + IT_R * IT_STAGE + 4 * EPI_WAVE_FLOATS * 4);
-    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    float* const wl = reinterpret_cast<float*>(smem + W3_BYTES);
+    const char* const ring = smem + RING_OFF + wv * (IT_R * IT_IN_BYTES);                 // this wave's three stages
+    float* const scr = reinterpret_cast<float*>(smem + SCR_OFF) + wv * EPI_WAVE_FLOATS;
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)(RING_OFF + wv * (IT_R * IT_IN_BYTES));
 
-    const int ntiles = p.N * p.tiles_y * p.tiles_x;
+    const int ntiles = p.N * p.tiles_y * p.tiles_x;                       // tiles of 16 x 32 pixels (host: tiles_y = ceil(H / 32))
     const int G = gridDim.x;
     auto tile_index = [&](int k) -> int {             // XCD-aware walk, as in conv_f32_kernel
         const int base = k * G;
@@ -798,13 +805,13 @@ __global__ __launch_bounds__(256, 2) void imdb_tail_kernel(const ConvK p)
         return t < ntiles ? t : -1;
     };
 
-    // This wave's DMA pieces of a stage: input pieces wv, wv + 4 and (waves 0-2) wv + 8 -- piece 10 has 8 live lanes --,
-    // weight piece 0 (wave 3) and weight piece wv + 1 -- piece 4 has 32 live lanes.  Four instructions per wave and stage.
-    struct TileCtx { int n, x0, y0; unsigned voff[3]; };
+    // A wave's stage: halo rows y0 + 4 wv - 1 .. + 4 of the tile, 18 pixels each, one 8-channel chunk: 216 items of 16 bytes
+    // (pixel, half) = three full DMA pieces and one of 24 lanes.  Four instructions per wave and stage, always.
+    struct TileCtx { int n, x0, y0; unsigned voff[4]; };
     auto setup_tile = [&](int t, TileCtx& c) {
         if (t < 0) {                                   // behind the last tile: the DMAs still issue (uniform counts), all lanes out of range
             c.n = 0; c.x0 = 0; c.y0 = 0;
-            c.voff[0] = c.voff[1] = c.voff[2] = OOB;
+            c.voff[0] = c.voff[1] = c.voff[2] = c.voff[3] = OOB;
             return;
         }
         const int tx = t % p.tiles_x;
@@ -812,40 +819,29 @@ __global__ __launch_bounds__(256, 2) void imdb_tail_kernel(const ConvK p)
         const int ty = tq % p.tiles_y;
         c.n = tq / p.tiles_y;
         c.x0 = tx * TILE;
-        c.y0 = ty * TILE;
+        c.y0 = ty * (4 * IT_NW);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int j = (wv + 4 * i) * 64 + lane;
+        for (int i = 0; i < 4; ++i) {
+            const int j = i * 64 + lane;
             const int half = j & 1;
             const int pl = j >> 1;
             const int ly = pl / IT_TH, lx = pl - ly * IT_TH;
-            const int gy = c.y0 - 1 + ly, gx = c.x0 - 1 + lx;
+            const int gy = c.y0 + wv * 4 - 1 + ly, gx = c.x0 - 1 + lx;
             const bool ok = j < IT_IN_ITEMS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             c.voff[i] = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff + 4 * half) * 4u : OOB;
         }
     };
     const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 4;
-    const it_i32x4 wrsrc = it_rsrc(p.wp, (size_t)IT_NCH * IT_W_BYTES);
-    const bool w3 = wv == 3;                                             // uniform
-    const bool live2 = w3 || (wv + 8) * 64 + lane < IT_IN_ITEMS;         // third piece: wave 2 keeps 8 lanes
-    const bool live3 = (wv + 1) * 64 + lane < IT_W_ITEMS;                // fourth piece: wave 3 keeps 32 lanes
-    const unsigned wvoff2 = (unsigned)lane * 16u;                        // weight piece 0
-    const unsigned wvoff3 = (unsigned)((wv + 1) * 64 + lane) * 16u;
+    const bool live3 = 3 * 64 + lane < IT_IN_ITEMS;                      // fourth piece: 24 lanes
 
     auto issue = [&](int slot, const TileCtx& tc, int chunk) __attribute__((always_inline)) {
         const it_i32x4 xr = it_rsrc(p.x + (size_t)tc.n * (img_bytes / 4), img_bytes);
-        const unsigned base = ring_lds + (unsigned)(slot * IT_STAGE);
-        const unsigned cin_off = (unsigned)chunk * 32u, w_off = (unsigned)chunk * (unsigned)IT_W_BYTES;
-        it_dma16(base + (unsigned)wv * 1024u, tc.voff[0], xr, cin_off);
-        it_dma16(base + (unsigned)(wv + 4) * 1024u, tc.voff[1], xr, cin_off);
-        {
-            it_i32x4 r2;
-            r2.x = w3 ? wrsrc.x : xr.x; r2.y = w3 ? wrsrc.y : xr.y; r2.z = w3 ? wrsrc.z : xr.z; r2.w = xr.w;
-            const unsigned v2 = w3 ? wvoff2 : tc.voff[2];
-            const unsigned d2 = base + (w3 ? (unsigned)IT_IN_BYTES : (unsigned)(wv + 8) * 1024u);
-            if (live2) it_dma16(d2, v2, r2, w3 ? w_off : cin_off);
-        }
-        if (live3) it_dma16(base + (unsigned)IT_IN_BYTES + (unsigned)(wv + 1) * 1024u, wvoff3, wrsrc, w_off);
+        const unsigned base = ring_lds + (unsigned)(slot * IT_IN_BYTES);
+        const unsigned cin_off = (unsigned)chunk * 32u;
+        it_dma16(base, tc.voff[0], xr, cin_off);
+        it_dma16(base + 1024u, tc.voff[1], xr, cin_off);
+        it_dma16(base + 2048u, tc.voff[2], xr, cin_off);
+        if (live3) it_dma16(base + 3072u, tc.voff[3], xr, cin_off);
     };
 
     int k = 0;
@@ -860,9 +856,12 @@ __global__ __launch_bounds__(256, 2) void imdb_tail_kernel(const ConvK p)
 
     const f32x4 biasv = *reinterpret_cast<const f32x4*>(p.bias + kq * 4);
     {
-        // 1x1 weights: blob order in, (chunk16, tile, lane, j) order out -- as conv_f32_kernel's tail
+        // resident weights.  3x3: the packed blob as it is ([chunk][tap][lane][2]).  1x1: blob order in, (chunk16, tile, lane, j)
+        // order out -- as conv_f32_kernel's tail
+        for (int q = tid; q < W3_BYTES / 16; q += 64 * IT_NW)
+            *reinterpret_cast<f32x4*>(smem + q * 16) = *reinterpret_cast<const f32x4*>(p.wp + (size_t)q * 4);
         const int nch8 = 2 * (IT_CAT + 1);
-        for (int q = tid; q < nch8 * TNT * 32; q += 256) {
+        for (int q = tid; q < nch8 * TNT * 32; q += 64 * IT_NW) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(p.wp2 + (size_t)q * 4);
             const int ip = q & 7, kq8 = (q >> 3) & 3, ct = q >> 5;
             const int tt = ct % TNT, chunk8 = ct / TNT;
@@ -872,11 +871,11 @@ __global__ __launch_bounds__(256, 2) void imdb_tail_kernel(const ConvK p)
         }
         if (tid < TNT * 16) wl[TAIL_C16 * TNT * 256 + tid] = p.bias2[tid];
     }
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");           // stage 0 has landed (stage 1 may still fly), wl is written
-    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                          // the only one: the weights are in LDS
 
-    const int b_base = ((wv * 4) * IT_TH + px) * 32 + kq * 8;
-    const int a_base = IT_IN_BYTES + lane * 8;
+    const int b_base = px * 32 + kq * 8;
+    const int a_base = lane * 8;
     const size_t cat_img_bytes = (size_t)p.H * p.W * p.cat_pitch * 4;
     const size_t res_img_bytes = (size_t)p.H * p.W * p.res_pitch * 4;
 
@@ -896,7 +895,7 @@ __global__ __launch_bounds__(256, 2) void imdb_tail_kernel(const ConvK p)
 
 #pragma unroll
         for (int c = 0; c < IT_NCH; ++c) {
-            // ---- top of the stage: everything stage c + 2 needs, then this tile's register loads
+            // ---- top of the stage: the input of stage c + 2, then this tile's register loads
             if (c + 2 < IT_NCH) issue((c + 2) % IT_R, cur, c + 2);
             else issue((c + 2) % IT_R, nxt, c + 2 - IT_NCH);
             if ((FOLD && c == IT_NCH - 3) || c == IT_NCH - 2) {
@@ -917,16 +916,17 @@ __global__ __launch_bounds__(256, 2) void imdb_tail_kernel(const ConvK p)
                     } else {
 #pragma unroll
                         for (int C = 0; C < IT_CAT; ++C)
-                            bc[C][r] = f32x4{(float)vo, 0.f, 0.f, 0.f};
+                            bc[C][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, C * 64, 0));
                     }
                 }
             }
             // ---- the chunk's 72 MFMAs, fragment reads one tap ahead
-            const char* s = smem + (c % IT_R) * IT_STAGE;
+            const char* s = ring + (c % IT_R) * IT_IN_BYTES;
+            const char* w = smem + c * IT_W_BYTES;
             f32x2 a[2], b[2][4];
             auto load_frag = [&](int slot, int tap) __attribute__((always_inline)) {
                 const int dy = tap / 3, dx = tap - dy * 3;
-                a[slot] = *reinterpret_cast<const f32x2*>(s + a_base + tap * 512);
+                a[slot] = *reinterpret_cast<const f32x2*>(w + a_base + tap * 512);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     b[slot][r] = *reinterpret_cast<const f32x2*>(s + b_base + ((r + dy) * IT_TH + dx) * 32);
@@ -945,19 +945,19 @@ __global__ __launch_bounds__(256, 2) void imdb_tail_kernel(const ConvK p)
                         acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cs][j], b[cs][r][j], acc[r], 0, 0, 0);
             }
             __builtin_amdgcn_s_setprio(3);
-            // ---- end of the stage: stage c + 1 (requested at the top of stage c - 1, before that stage's register loads) has
-            // landed; younger and allowed to fly: the register loads of stage c - 1, the 4 DMAs and the register loads of stage c
+            // ---- end of the stage: this wave's stage c + 1 (requested at the top of stage c - 1, before that stage's register
+            // loads) has landed; younger and allowed to fly: the register loads of stage c - 1, the 4 DMAs and the register loads
+            // of stage c.  Nobody else reads this ring: no barrier.
             constexpr int NX = FOLD ? 4 * TNT : 0, NB = 4 * IT_CAT;
             const int vis_prev = (c - 1 == IT_NCH - 3 ? NX : 0) + (c - 1 == IT_NCH - 2 ? NB : 0);
             const int vis_here = (c == IT_NCH - 3 ? NX : 0) + (c == IT_NCH - 2 ? NB : 0);
             switch (vis_prev + 4 + vis_here) {                 // compile-time after unrolling
-                case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
-                case 16: asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); break;
-                case 20: asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory"); break;
-                case 32: asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+                case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+                case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
             }
-            __builtin_amdgcn_s_barrier();
         }
 
         // ---- 1x1: K = the three concat chunks + the 3x3 result; accumulators start at x (FOLD) + bias
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(256, 2) void imdb_tail_kernel(const ConvK p)
 #pragma unroll
             for (int C = 0; C < IT_CAT; ++C) tail_chunk(C, bc[C]);
             __builtin_amdgcn_s_setprio(3);
-            epilogue_nhwc<TNT>(p, acc2, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE);
+            epilogue_nhwc<TNT>(p, acc2, scr, cur.n, cur.x0, cur.y0, wv, lane, 4 * IT_NW);
         }
         if (!has_next) break;
         cur = nxt;
@@ -1075,8 +1075,11 @@ int launch_conv_tail(const ConvK& k, hipStream_t st)
     if (imdb_tail_shape(k)) {
         ConvK kk = k;
         kk.res_mode = ESR_RES_NONE;                 // folded into the 1x1's accumulators: the epilogue adds nothing
-        if (k.res_mode == ESR_RES_PRE_ACT) hipLaunchKernelGGL((imdb_tail_kernel<true>), dim3(grid), dim3(THREADS), 0, st, kk);
-        else hipLaunchKernelGGL((imdb_tail_kernel<false>), dim3(grid), dim3(THREADS), 0, st, kk);
+        kk.tiles_y = (k.H + 4 * IT_NW - 1) / (4 * IT_NW);      // 16 x 32 pixel tiles, one 8-wave block per CU
+        const int nt32 = k.N * kk.tiles_x * kk.tiles_y;
+        const int g32 = nt32 < 256 ? nt32 : 256;
+        if (k.res_mode == ESR_RES_PRE_ACT) hipLaunchKernelGGL((imdb_tail_kernel<true>), dim3(g32), dim3(64 * IT_NW), 0, st, kk);
+        else hipLaunchKernelGGL((imdb_tail_kernel<false>), dim3(g32), dim3(64 * IT_NW), 0, st, kk);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             set_err("imdb_tail_kernel launch", e);

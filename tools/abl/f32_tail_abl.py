@@ -10,7 +10,7 @@ Variants are TEXT substitutions on a copy of csrc/esr_hip.hip + imdb_tail.inc (r
   old      the generic TAIL variant (dispatch to imdb_tail_kernel disabled)
   nocat    no loads of the concat slices          nores   no loads of the residual
   no1x1    no MFMAs of the 1x1                    noconv  no MFMAs of the 3x3
-  noepi    no epilogue (no stores)                nobar   no stage barriers
+  noepi    no epilogue (no stores)
   nodma    the DMAs of a stage are not issued
 """
 import ctypes, os, subprocess, sys
@@ -32,8 +32,6 @@ SUBS = {
                 "                        acc[r].x += a[cs][j] * b[cs][r][j];")],
     "noepi": [("            epilogue_nhwc<TNT>(p, acc2, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE);",
                "            if (acc2[0][0].x == 1.2345e-30f) epilogue_nhwc<TNT>(p, acc2, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE);")],
-    "nobar": [("                default: asm volatile(\"s_waitcnt vmcnt(0) lgkmcnt(0)\" ::: \"memory\"); break;\n            }\n            __builtin_amdgcn_s_barrier();",
-               "                default: asm volatile(\"s_waitcnt vmcnt(0) lgkmcnt(0)\" ::: \"memory\"); break;\n            }")],
     "nodma": [("            if (c + 2 < IT_NCH) issue((c + 2) % IT_R, cur, c + 2);\n            else issue((c + 2) % IT_R, nxt, c + 2 - IT_NCH);", "            ;")],
 }
 

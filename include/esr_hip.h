@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESR_ABI_VERSION 5
+#define ESR_ABI_VERSION 6
 
 typedef enum esr_status {
     ESR_OK = 0,
@@ -150,8 +150,19 @@ typedef struct esr_conv_desc {
      * producers write whole lines and torch.cat still never happens -- the consumer walks the segments. */
     int64_t in_seg_stride;
     int32_t in_seg_chunks;
-    int32_t reserved4;
+    /* ABI v6 -- channel-blocked fp32 tensors ("NC/8HW8"): bit 0 (ESR_BLOCKED_IN): `in`, bit 1 (ESR_BLOCKED_OUT1): `out1` is stored as
+     * [n][pitch / 8][h][w][8] instead of [n][h][w][pitch] (pitch and coff multiples of 8): element (n, y, x, c) of the view lies at
+     * ptr[((n * pitch / 8 + (coff + c) / 8) * h * w + y * w + x) * 8 + (coff + c) % 8].
+     * Why: conv_f32_kernel and imdb_tail_kernel stage the input one 8-channel K chunk at a time, so a 128-byte line of an
+     * [.., 48]-channel NHWC pixel is touched by four stages microseconds apart and is re-fetched when the L2 has dropped it in
+     * between (PMC: 1.33x the algorithmic reads for the memory-bound IMDB tail); in the blocked layout a stage reads whole lines
+     * and every line exactly once.  Supported: ESR_BLOCKED_OUT1 for fp32 NHWC convolutions with a split store (the "remaining"
+     * channels of IMDBlock's conv3), ESR_BLOCKED_IN for the fused IMDB tail at the network's shape (imdb_tail_kernel); any
+     * other use returns ESR_ERR_UNSUPPORTED. */
+    int32_t blocked8;
 } esr_conv_desc;
+#define ESR_BLOCKED_IN   1
+#define ESR_BLOCKED_OUT1 2
 
 /* Host-side weight packer (the K10 "weight packer" of SURVEY 7.2): OIHW fp32 (the layout of every
  * Conv2d in the reference state_dicts; nn.Linear [out,in] is the k=1 case) + bias -> the MFMA-tiled,

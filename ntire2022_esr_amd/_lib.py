@@ -16,6 +16,7 @@ STATUS = {0: "ESR_OK", -1: "ESR_ERR_BAD_ARG", -2: "ESR_ERR_UNSUPPORTED", -3: "ES
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
 RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
 NHWC, NCHW_IN, NCHW_SHUFFLE4 = 0, 1, 2
+BLOCKED_IN, BLOCKED_OUT1 = 1, 2          # esr_conv_desc.blocked8 bits (ABI v6)
 OP_CONV, OP_CONV3X3S2, OP_MAXPOOL7S3, OP_ESA_APPLY, OP_DWCONV, OP_BSCONV, OP_PACK_INPUT = 0, 1, 2, 3, 4, 5, 6
 ESA_FP = 16
 COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2
@@ -43,7 +44,7 @@ class ConvDesc(ctypes.Structure):
         ("post_wpacked", ctypes.c_void_p), ("post_out", View),
         ("post_cout", ctypes.c_int32), ("post_act", ctypes.c_int32),
         ("post2_wpacked", ctypes.c_void_p), ("post2_out", View),
-        ("post2_cout", ctypes.c_int32), ("reserved3", ctypes.c_int32), ("border_bias", ctypes.c_void_p), ("in_seg_stride", ctypes.c_int64), ("in_seg_chunks", ctypes.c_int32), ("reserved4", ctypes.c_int32),
+        ("post2_cout", ctypes.c_int32), ("reserved3", ctypes.c_int32), ("border_bias", ctypes.c_void_p), ("in_seg_stride", ctypes.c_int64), ("in_seg_chunks", ctypes.c_int32), ("blocked8", ctypes.c_int32),
     ]
 
 
@@ -171,7 +172,7 @@ def lib():
     L.esr_prof_collect.restype = ci
     L.esr_prof_destroy.argtypes = [vp]
     L.esr_prof_destroy.restype = None
-    if L.esr_abi_version() != 5:
+    if L.esr_abi_version() != 6:
         raise EsrError("libesr_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -70,6 +70,8 @@ struct ConvK {
     int y2_pitch, y2_coff, y2_cout4, post_act, post_nch8;
     int res_in;           // the (pre-activation) residual IS the conv input: taken from the staged tile, no residual loads
     int out16;            // NCHW head only: the NHWC output is stored as bf16 (1) / fp16 (2) (esr_storage), 0 = fp32
+    int y1_blk;           // esr_conv_desc.blocked8 & ESR_BLOCKED_OUT1: y1 is [n][y1_pitch / 8][H][W][8]
+    int in_blk;           // ... & ESR_BLOCKED_IN (imdb_tail_kernel only): x is [n][in_pitch / 8][H][W][8]
 #ifdef ESR_EXPERIMENTAL_WS
     int hand_rows;        // accumulator rows (of 4) finished by the loader partner
 #endif
@@ -117,7 +119,7 @@ constexpr int EPI_PITCH = 68;                       // floats per scratch pixel 
 constexpr int EPI_WAVE_FLOATS = 16 * EPI_PITCH;     // one 16-pixel row per wave
 
 // generic (bounds-checked) version: edge tiles and rarely used activation / residual combinations
-template <int NT>
+template <int NT, bool Y1BLK = false>
 __device__ __forceinline__ void epilogue_nhwc_checked(const ConvK& p, f32x4 (&acc)[NT][4], float* scr, int n, int x0, int y0,
                                                    int wv, int lane)
 {
@@ -126,8 +128,11 @@ __device__ __forceinline__ void epilogue_nhwc_checked(const ConvK& p, f32x4 (&ac
     const int cb = ch * 4;
     const bool ch_ok = cb < p.cout_store;
     const bool to0 = cb < p.split;
-    float* const ybase = to0 ? p.y0 + p.y0_coff + cb : p.y1 + p.y1_coff + (cb - p.split);
-    const int ypitch = to0 ? p.y0_pitch : p.y1_pitch;
+    const int c1 = p.y1_coff + cb - p.split;          // channel inside the y1 tensor
+    const size_t hw8 = (size_t)p.H * p.W * 8;
+    float* const ybase = to0 ? p.y0 + p.y0_coff + cb
+                             : (Y1BLK ? p.y1 + (size_t)n * hw8 * (p.y1_pitch / 8 - 1) + (size_t)(c1 >> 3) * hw8 + (c1 & 7) : p.y1 + c1);
+    const int ypitch = to0 ? p.y0_pitch : (Y1BLK ? 8 : p.y1_pitch);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int gy = y0 + wv * 4 + r;
@@ -151,7 +156,7 @@ __device__ __forceinline__ void epilogue_nhwc_checked(const ConvK& p, f32x4 (&ac
 
 // fast path: the 16x16 tile lies inside the image.  Row/pixel-group bases are wave-uniform (scalar), each
 // lane adds one precomputed offset; no bounds checks; activation and residual mode are compile-time.
-template <int ACT, int RES, int NT>
+template <int ACT, int RES, int NT, bool Y1BLK = false>
 __device__ __forceinline__ void epilogue_nhwc_fast(const ConvK& p, f32x4 (&acc)[NT][4], float* scr, int n, int x0, int y0,
                                                    int wv, int lane)
 {
@@ -162,7 +167,11 @@ __device__ __forceinline__ void epilogue_nhwc_fast(const ConvK& p, f32x4 (&acc)[
     const bool to0 = cb < p.split;
     const bool to1 = !to0 && cb < p.cout_store;
     const unsigned off0 = (unsigned)(prow * p.y0_pitch + p.y0_coff + cb);
-    const unsigned off1 = (unsigned)(prow * p.y1_pitch + p.y1_coff + cb - p.split);
+    // blocked y1 ([n][C/8][H][W][8]): element (pixel pu, channel c1) lies at pu * 8 + n * HW8 * (C/8 - 1) + (c1 / 8) * HW8 + c1 % 8
+    const int c1 = p.y1_coff + cb - p.split;
+    const unsigned hw8 = (unsigned)(p.H * p.W * 8);
+    const unsigned off1 = Y1BLK ? (unsigned)(c1 >> 3) * hw8 + (unsigned)(prow * 8 + (c1 & 7)) : (unsigned)(prow * p.y1_pitch + c1);
+    float* const y1c = p.y1 + (Y1BLK ? (size_t)n * hw8 * (p.y1_pitch / 8 - 1) : 0);
     const bool has_split = p.split < p.cout_store;                                        // uniform
     const int rd = (NT == 4) ? cb : min(cb, NT * 16 - 4);
 
@@ -195,32 +204,32 @@ __device__ __forceinline__ void epilogue_nhwc_fast(const ConvK& p, f32x4 (&acc)[
                 // split store (IMDBlock: 16 channels to the concat slice, 48 to the next stage) as ONE instruction with
                 // per-lane 64-bit addresses: two lane-masked stores cost twice the issue time of this kernel's scarcest
                 // resource, the VMEM issue slot
-                float* const dst = to0 ? p.y0 + pu * p.y0_pitch + off0 : p.y1 + pu * p.y1_pitch + off1;
+                float* const dst = to0 ? p.y0 + pu * p.y0_pitch + off0 : (Y1BLK ? y1c + pu * 8 + off1 : p.y1 + pu * p.y1_pitch + off1);
                 if (to0 || to1) *reinterpret_cast<f32x4*>(dst) = o;
             }
         }
     }
 }
 
-template <int ACT, int NT>
+template <int ACT, int NT, bool Y1BLK = false>
 __device__ __forceinline__ void epilogue_nhwc_fast_res(const ConvK& p, f32x4 (&acc)[NT][4], float* scr, int n, int x0, int y0,
                                                        int wv, int lane)
 {
-    if (p.res_mode == ESR_RES_NONE) epilogue_nhwc_fast<ACT, ESR_RES_NONE, NT>(p, acc, scr, n, x0, y0, wv, lane);
-    else if (p.res_mode == ESR_RES_PRE_ACT) epilogue_nhwc_fast<ACT, ESR_RES_PRE_ACT, NT>(p, acc, scr, n, x0, y0, wv, lane);
-    else epilogue_nhwc_fast<ACT, ESR_RES_POST_ACT, NT>(p, acc, scr, n, x0, y0, wv, lane);
+    if (p.res_mode == ESR_RES_NONE) epilogue_nhwc_fast<ACT, ESR_RES_NONE, NT, Y1BLK>(p, acc, scr, n, x0, y0, wv, lane);
+    else if (p.res_mode == ESR_RES_PRE_ACT) epilogue_nhwc_fast<ACT, ESR_RES_PRE_ACT, NT, Y1BLK>(p, acc, scr, n, x0, y0, wv, lane);
+    else epilogue_nhwc_fast<ACT, ESR_RES_POST_ACT, NT, Y1BLK>(p, acc, scr, n, x0, y0, wv, lane);
 }
 
-template <int NT>
+template <int NT, bool Y1BLK = false>
 __device__ __forceinline__ void epilogue_nhwc(const ConvK& p, f32x4 (&acc)[NT][4], float* scr, int n, int x0, int y0,
                                               int wv, int lane, int tile_h = TILE)
 {
     const bool inside = x0 + TILE <= p.W && y0 + tile_h <= p.H && (NT < 4 || p.cout_store == 64);   // uniform
-    if (inside && p.act == ESR_ACT_LRELU) epilogue_nhwc_fast_res<ESR_ACT_LRELU, NT>(p, acc, scr, n, x0, y0, wv, lane);
-    else if (inside && p.act == ESR_ACT_NONE) epilogue_nhwc_fast_res<ESR_ACT_NONE, NT>(p, acc, scr, n, x0, y0, wv, lane);
+    if (inside && p.act == ESR_ACT_LRELU) epilogue_nhwc_fast_res<ESR_ACT_LRELU, NT, Y1BLK>(p, acc, scr, n, x0, y0, wv, lane);
+    else if (inside && p.act == ESR_ACT_NONE) epilogue_nhwc_fast_res<ESR_ACT_NONE, NT, Y1BLK>(p, acc, scr, n, x0, y0, wv, lane);
     else if (inside && p.act == ESR_ACT_GELU && p.res_mode == ESR_RES_NONE)
-        epilogue_nhwc_fast<ESR_ACT_GELU, ESR_RES_NONE, NT>(p, acc, scr, n, x0, y0, wv, lane);
-    else epilogue_nhwc_checked<NT>(p, acc, scr, n, x0, y0, wv, lane);
+        epilogue_nhwc_fast<ESR_ACT_GELU, ESR_RES_NONE, NT, Y1BLK>(p, acc, scr, n, x0, y0, wv, lane);
+    else epilogue_nhwc_checked<NT, Y1BLK>(p, acc, scr, n, x0, y0, wv, lane);
 }
 
 // NCHW head of a 16-bit-storage network: the native fragment (4 channels of one pixel per lane) goes out as 8 bytes per lane.
@@ -312,9 +321,10 @@ constexpr int TAIL_C16 = 4;                           // K of the 1x1 <= 64
 // are this conv's output-channel tiles) also feeds a second 1x1 whose result goes to another view: RFDB's distillation
 // conv c{j+1}_d = lrelu(W . r_j) is computed by the kernel that produces r_j (rfdn_baseline/block.py:150-160) instead of
 // by a launch of its own that reads r_j back.
-template <int NT, int KS, bool IN_NCHW, int NW, int TNT = 0, int PNT = 0>
+template <int NT, int KS, bool IN_NCHW, int NW, int TNT = 0, int PNT = 0, bool Y1BLK = false>
 __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
 {
+    static_assert(!Y1BLK || (NT == 4 && KS == 3 && !IN_NCHW && TNT == 0 && PNT == 0), "blocked y1: the 64-output 3x3 with a split store");
     static_assert(PNT == 0 || (TNT == 0 && KS == 3 && !IN_NCHW && NW == 8), "post 1x1: 8-wave 3x3 NHWC kernels");
     static_assert(TNT == 0 || (NT == 1 && KS == 3 && !IN_NCHW && NW == 4), "tail: 3x3, <= 16 channels, 4-wave blocks");
     constexpr int THREADS = 64 * NW;                  // shadows the file-scope constant: NW waves of 4 rows each
@@ -706,7 +716,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
             epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE_H);
         } else if (p.out_layout == ESR_NCHW_SHUFFLE4) epilogue_shuffle<NT>(p, acc, cur.n, cur.x0, cur.y0, wv, lane);
         else if (IN_NCHW && p.out16) epilogue_nhwc_store16<NT>(p, acc, cur.n, cur.x0, cur.y0, wv, lane);
-        else epilogue_nhwc<NT>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE_H);
+        else epilogue_nhwc<NT, Y1BLK>(p, acc, scr, cur.n, cur.x0, cur.y0, wv, lane, TILE_H);
         if (!has_next) break;
         cur = nxt;
         ++k;
@@ -752,6 +762,8 @@ int launch_conv(const ConvK& k, hipStream_t st)
         const int grid = ntall < 256 ? ntall : 256;
         if (NT == 4 && kk.wp3)
             hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, CAN_TALL ? 8 : 4, 0, (CAN_TALL && NT == 4) ? 2 : 0>), dim3(grid), dim3(512), 0, st, kk);
+        else if (NT == 4 && kk.y1_blk)
+            hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, CAN_TALL ? 8 : 4, 0, 0, CAN_TALL && NT == 4>), dim3(grid), dim3(512), 0, st, kk);
         else
             hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, CAN_TALL ? 8 : 4>), dim3(grid), dim3(512), 0, st, kk);
         const hipError_t e = hipGetLastError();
@@ -762,7 +774,8 @@ int launch_conv(const ConvK& k, hipStream_t st)
         return ESR_OK;
     }
     const int grid = ntiles < MAX_RESIDENT_BLOCKS ? ntiles : MAX_RESIDENT_BLOCKS;
-    hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, 4>), dim3(grid), dim3(THREADS), 0, st, k);
+    if (CAN_TALL && NT == 4 && k.y1_blk) hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, 4, 0, 0, CAN_TALL && NT == 4>), dim3(grid), dim3(THREADS), 0, st, k);
+    else hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, 4>), dim3(grid), dim3(THREADS), 0, st, k);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_err("conv_f32_kernel launch", e);
@@ -1057,6 +1070,16 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
     k.split = split;
     k.act = d->act; k.slope = d->slope; k.res_mode = d->res_mode;
     k.res_in = 0;
+    // channel-blocked views (ABI v6): out1 of an fp32 NHWC split store; in of the fused IMDB tail at the network's shape
+    k.y1_blk = (d->blocked8 & ESR_BLOCKED_OUT1) ? 1 : 0;
+    k.in_blk = (d->blocked8 & ESR_BLOCKED_IN) ? 1 : 0;
+    if (d->blocked8 & ~(ESR_BLOCKED_IN | ESR_BLOCKED_OUT1)) return ESR_ERR_BAD_ARG;
+    if (k.y1_blk) {
+        if (d->out_layout != ESR_NHWC || tail || post || store16 || split >= cout4 || d->ksize != 3 || in_nchw || d->cout <= 48 || d->cout > 64 || (d->out1.pitch & 7) || (d->out1.coff & 7) || (split & 7) ||
+            (double)d->h * d->w * d->out1.pitch * 4.0 >= 2147483647.0)
+            return ESR_ERR_UNSUPPORTED;
+    }
+    if (k.in_blk && (!tail || in_nchw || (d->in.pitch & 7) || (d->in.coff & 7))) return ESR_ERR_UNSUPPORTED;
     if (!tail && d->ksize == 3 && !in_nchw && d->res_mode == ESR_RES_PRE_ACT && d->cin == d->cout &&
         d->res.ptr == d->in.ptr && d->res.pitch == d->in.pitch && d->res.coff == d->in.coff) {
         k.res_in = 1;                               // residual == input: added from the staged input tile inside the K loop
@@ -1102,6 +1125,7 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
             const double px_all = (double)d->n * d->h * d->w;
             if (px_all * d->tail_cat.pitch >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
         }
+        if (k.in_blk && !imdb_tail_shape(k)) return ESR_ERR_UNSUPPORTED;      // only imdb_tail_kernel reads the blocked layout
         return launch_conv_tail(k, st);
     }
     if (in_nchw) return launch_conv_nt<3, true>(nt, k, st);

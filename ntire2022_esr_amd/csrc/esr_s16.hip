@@ -1236,7 +1236,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     if (d->storage != ESR_STORE_BF16 && d->storage != ESR_STORE_F16) return ESR_ERR_BAD_ARG;
     if (d->compute != (bf16 ? ESR_COMPUTE_BF16 : ESR_COMPUTE_F16)) return ESR_ERR_BAD_ARG;   // operand type = storage type
     if (d->in_layout != ESR_NHWC) return ESR_ERR_UNSUPPORTED;                                  // the NCHW head runs on conv_f32_kernel
-    if (d->tail_wpacked) return ESR_ERR_UNSUPPORTED;
+    if (d->tail_wpacked || d->blocked8) return ESR_ERR_UNSUPPORTED;                            // fp32 features
     const bool post = d->post_wpacked != nullptr;
     if (d->border_bias && d->out_layout != ESR_NHWC) return ESR_ERR_UNSUPPORTED;
     if (!post && d->post2_wpacked) return ESR_ERR_BAD_ARG;

@@ -165,9 +165,10 @@ class Buffer:
     """An NHWC activation buffer inside the workspace: [n][h][w][pitch] elements of `esize` bytes
     (4 = fp32; 2 = bf16 / fp16 for the full-resolution buffers of a 16-bit-storage plan)."""
 
-    def __init__(self, name, pitch, offset_bytes, h=None, w=None, esize=4, arena=0):
+    def __init__(self, name, pitch, offset_bytes, h=None, w=None, esize=4, arena=0, blocked=False):
         self.name, self.pitch, self.offset, self.h, self.w, self.esize = name, pitch, offset_bytes, h, w, esize
         self.arena = arena     # 0: full-resolution buffers (the plan's storage type), 1: low-resolution fp32 maps -- kept apart, see Plan
+        self.blocked = blocked # fp32 only: stored [n][pitch / 8][h][w][8] (esr_conv_desc.blocked8) -- same bytes, other order
 
     def __getitem__(self, sl):
         """buf[a:b] -> channel slice view (coff=a, channels=b-a)."""
@@ -218,9 +219,11 @@ class Plan:
         m = 8 if self.esize == 4 else 16
         return (c + m - 1) // m * m
 
-    def buffer(self, name, pitch, h=None, w=None):
-        """Full-resolution buffer by default; (h, w) gives a low-resolution fp32 one (ESA maps)."""
+    def buffer(self, name, pitch, h=None, w=None, blocked=False):
+        """Full-resolution buffer by default; (h, w) gives a low-resolution fp32 one (ESA maps).  blocked: channel-blocked
+        [n][pitch / 8][h][w][8] (fp32 plans; only as the dst1 of a split store and the input of the fused IMDB tail)."""
         lowres = h is not None
+        assert not blocked or (self.esize == 4 and not lowres and pitch % 8 == 0)
         esize = 4 if lowres else self.esize
         assert (pitch * esize) % 16 == 0
         h = self.h if h is None else h
@@ -230,7 +233,7 @@ class Plan:
             b = Buffer(name, pitch, self.total_lo, h, w, esize, arena=1)
             self.total_lo += size
         else:
-            b = Buffer(name, pitch, self.total, h, w, esize)
+            b = Buffer(name, pitch, self.total, h, w, esize, blocked=blocked)
             self.total += size
         self.buffers.append(b)
         return b
@@ -384,6 +387,10 @@ class Plan:
                 d.out0 = self._view(o["dst"], base)
             if o["dst1"] is not None:
                 d.out1 = self._view(o["dst1"], base)
+            def _blk(v):
+                return v is not None and v is not INPUT and v is not OUTPUT and not isinstance(v, Planar) and (v if isinstance(v, Buffer) else v[0]).blocked
+            assert not _blk(o["dst"]) and not _blk(o["res"]), "blocked buffers: dst1 of a split store / input of the fused tail only"
+            d.blocked8 = (L.BLOCKED_IN if _blk(o["src"]) else 0) | (L.BLOCKED_OUT1 if _blk(o["dst1"]) else 0)
             if o["res"] is not None:
                 d.res = self._view(o["res"], base)
             lowres = o["hw"] is not None

@@ -59,6 +59,11 @@ class IMDN(HipSRModel):
         cat = plan.planar('cat', 4, d) if planar else plan.buffer('cat', 3 * d if fused else 4 * d)
         cs = (lambda j: cat.seg(j)) if planar else (lambda j: cat[j * d:(j + 1) * d])
         r1, r2 = plan.buffer('r1', r), plan.buffer('r2', r)
+        # fused tail: its 3x3 input (conv3's remaining channels) is stored channel-blocked [n][r/8][h][w][8] -- imdb_tail_kernel
+        # stages one 8-channel K chunk at a time, and in NHWC every 128-byte line of a 192-byte pixel would be fetched by four
+        # stages microseconds apart (esr_conv_desc.blocked8)
+        blk = fused and r == 48 and nc == 64
+        r3 = plan.buffer('r3', r, blocked=True) if blk else r1
         act = dict(act=self.act, slope=self.slope)
         plan.conv('model.0', INPUT, fea, self.in_nc, nc)
         cur, nxt = fea, xa
@@ -66,11 +71,11 @@ class IMDN(HipSRModel):
             p = f'model.1.sub.{i}.'
             plan.conv(p + 'conv1.0', cur, cs(0), nc, nc, split=d, dst1=r1, **act)
             plan.conv(p + 'conv2.0', r1, cs(1), r, nc, split=d, dst1=r2, **act)
-            plan.conv(p + 'conv3.0', r2, cs(2), r, nc, split=d, dst1=r1, **act)
+            plan.conv(p + 'conv3.0', r2, cs(2), r, nc, split=d, dst1=r3, **act)
             if fused:
                 # conv4 -> cat -> conv1x1 -> + x in one kernel: the 16 conv4 channels go from the 3x3's accumulators
                 # straight into the 1x1's K loop and never reach memory
-                plan.conv(p + 'conv4', r1, nxt, r, d, res=cur, res_mode=L.RES_PRE_ACT,
+                plan.conv(p + 'conv4', r3, nxt, r, d, res=cur, res_mode=L.RES_PRE_ACT,
                           tail=dict(w=p + 'conv1x1', cat=cat[0:3 * d], cat_c=3 * d, cout=nc))
             else:
                 plan.conv(p + 'conv4', r1, cs(3), r, d)

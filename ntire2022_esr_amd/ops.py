@@ -22,7 +22,7 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
            split=0, out1=None, out1_coff=0, res_coff=0, packed=None, cin_map=None, store=None,
            tail_weight=None, tail_bias=None, tail_cat=None, tail_cat_coff=0, tail_mid_act=L.ACT_NONE,
            post_weight=None, post_bias=None, post_act=L.ACT_NONE, post2_weight=None, post2_bias=None, store_main=True,
-           border=None):
+           border=None, blocked_in=False, blocked_out1=False):
     """Fused conv (k=1|3, stride 1, same padding) on the current stream.
 
     x       NHWC [N,H,W,pitch] (channels [in_coff, in_coff+cin) are read) or NCHW fp32 if in_nchw.  The dtype of an NHWC
@@ -34,6 +34,7 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
             16-bit storage: applied to the finished fp32 result (residual included); post2_weight [pc2, pc] chains a second 1x1
             on the first (returns (y, post, post2)); store_main=False does not store y (returns None in its place)
     border  esr_conv_desc.border_bias: fp32 [16, round_up(cout, 16)] table added by outside-mask (16-bit storage only)
+    blocked_in / blocked_out1   esr_conv_desc.blocked8: x / out1 is a channel-blocked fp32 tensor [N, C/8, H, W, 8]
     tail_*  fused 1x1 (esr_conv_desc.tail_*): tail_weight [cout1, cat_c + 16(, 1, 1)] over concat(tail_cat slice,
             mid_act(this 3x3 conv)); act / res / out then apply to the 1x1, whose output is returned
     """
@@ -55,6 +56,14 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
         n, c, h, w = x.shape
         d.in_layout, cin = L.NCHW_IN, c
         d.inp = L.View(ctypes.c_void_p(x.data_ptr()), 0, 0)
+    elif blocked_in:
+        if x.dim() != 5 or x.shape[-1] != 8 or x.dtype != torch.float32 or not x.is_contiguous():
+            raise L.EsrError("conv2d: a blocked input is a contiguous fp32 [N, C/8, H, W, 8] tensor")
+        n, pl, h, w, _ = x.shape
+        cin = wcin if cin is None else cin
+        d.in_layout = L.NHWC
+        d.inp = L.View(ctypes.c_void_p(x.data_ptr()), pl * 8, in_coff)
+        d.blocked8 |= L.BLOCKED_IN
     elif x.dim() == 5:
         # planar concat [S, N, H, W, P]: S dense tensors one stride apart (esr_conv_desc.in_seg_stride / in_seg_chunks)
         if not s16 or not x.is_contiguous() or x.shape[-1] % 16:
@@ -99,7 +108,13 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
                 y = out
             d.out0 = _view(y, out_coff)
         if out1 is not None:
-            d.out1 = _view(out1, out1_coff)
+            if blocked_out1:
+                if out1.dim() != 5 or out1.shape[-1] != 8 or out1.dtype != torch.float32 or not out1.is_contiguous():
+                    raise L.EsrError("conv2d: a blocked out1 is a contiguous fp32 [N, C/8, H, W, 8] tensor")
+                d.out1 = L.View(ctypes.c_void_p(out1.data_ptr()), out1.shape[1] * 8, out1_coff)
+                d.blocked8 |= L.BLOCKED_OUT1
+            else:
+                d.out1 = _view(out1, out1_coff)
     if res is not None:
         d.res = _view(res, res_coff)
     d.wpacked = ctypes.c_void_p(packed.data_ptr())

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libesr_hip.so does not export {s}"
     assert set(L.EXPORTS) == set(syms), (set(L.EXPORTS) ^ set(syms))
-    assert lib.esr_abi_version() == 5
+    assert lib.esr_abi_version() == 6
     assert b"gfx950" in lib.esr_build_info()
 
 
@@ -121,7 +121,10 @@ def test_imdn_plan_shape():
     m._build_plan(plan, 3)
     assert len(plan.ops) == 3 + 4 * 8
     assert sum(o.get("tail") is not None for o in plan.ops) == 8
-    assert plan.total == 4 * 2 * 40 * 56 * (64 * 3 + 48 * 3)                  # bytes: fea, xa, xb | cat (d1 d2 d3), r1, r2
+    assert plan.total == 4 * 2 * 40 * 56 * (64 * 3 + 48 * 4)                  # bytes: fea, xa, xb | cat (d1 d2 d3), r1, r2, r3
+    blk = [bf for bf in plan.buffers if bf.blocked]
+    assert [bf.name for bf in blk] == ["r3"]                                  # conv3's remaining channels, channel-blocked for the tail
+    assert all((o["dst1"] is blk[0]) == o["w"].endswith("conv3.0") and (o["src"] is blk[0]) == (o.get("tail") is not None) for o in plan.ops)
     assert m.workspace_bytes(2, 40, 56) == plan.total
     total_macs = sum(cin * cout * k * k for o in plan.ops for (cin, cout, k, _, _) in m._counted_convs(plan, o))
     assert total_macs == 891584                                                # MAC per LR pixel

@@ -207,6 +207,42 @@ def test_conv3x3_with_fused_1x1_tail(n, hw, mid_act, res_mode, cat_c):
     _check(y, ref)
 
 
+@pytest.mark.parametrize("n,h,wd", [(2, 19, 21), (6, 160, 144), (3, 37, 130)])
+def test_split_store_into_blocked_out1_and_blocked_tail_input(n, h, wd):
+    """esr_conv_desc.blocked8 (ABI v6): IMDBlock's conv3 stores its remaining 48 channels channel-blocked [N, 6, H, W, 8]
+    (4-wave and 8-wave epilogues, edge tiles), pad planes stay untouched; the fused tail reads that layout (imdb_tail_kernel) and
+    gives the NHWC result bit for bit."""
+    from ntire2022_esr_amd import _lib as L
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(n + h)
+    x = torch.randn(n, 48, h, wd, generator=g)
+    w = torch.randn(64, 48, 3, 3, generator=g) * 0.1
+    b = torch.randn(64, generator=g)
+    ref = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.05)
+    cat = torch.full((n, h, wd, 48), 7.0, device=dev)
+    rem = torch.full((n, 7, h, wd, 8), 9.0, device=dev)             # 56-channel blocked tensor, channels 8..55 are written
+    ops.conv2d(_nhwc(x).to(dev), w, b, act=1, split=16, out=cat, out_coff=32, out1=rem, out1_coff=8, blocked_out1=True)
+    rem_c = rem.cpu()
+    assert torch.all(rem_c[:, 0] == 9.0) and torch.all(cat.cpu()[..., :32] == 7.0)
+    _check(cat.cpu()[..., 32:48], ref[:, :16])
+    got = rem_c[:, 1:].permute(0, 2, 3, 1, 4).reshape(n, h, wd, 48)            # [N, 6, H, W, 8] -> NHWC
+    _check(got, ref[:, 16:])
+    with pytest.raises(L.EsrError):                                # blocked out1 without a split store
+        ops.conv2d(_nhwc(x).to(dev), w, b, out1=rem, blocked_out1=True)
+    # the fused tail on the blocked tensor == on its NHWC copy
+    r = torch.randn(n, h, wd, 64, generator=g).to(dev)
+    w3, b3 = torch.randn(16, 48, 3, 3, generator=g) * 0.1, torch.randn(16, generator=g)
+    w1, b1 = torch.randn(64, 64, 1, 1, generator=g) * 0.1, torch.randn(64, generator=g)
+    nhwc = got.contiguous().to(dev)
+    kw = dict(res=r, res_mode=1, tail_weight=w1, tail_bias=b1, tail_cat=cat, tail_cat_coff=0)
+    y_a = ops.conv2d(nhwc, w3, b3, **kw)
+    y_b = ops.conv2d(rem, w3, b3, in_coff=8, cin=48, blocked_in=True, **kw)
+    assert torch.equal(y_a, y_b)
+    with pytest.raises(L.EsrError):                                # a blocked input anywhere else
+        ops.conv2d(rem, w, b, in_coff=8, cin=48, blocked_in=True)
+
+
 def test_fused_tail_argument_checks():
     import ctypes
     from ntire2022_esr_amd import _lib as L

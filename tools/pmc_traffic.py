@@ -43,6 +43,9 @@ def label(sym, compute):
         if m.group(6) != "0":
             base += f",POST={m.group(6)}"
         return base + ">"
+    m = re.search(r"imdb_tail_kernel<(true|false)>", sym)
+    if m:
+        return f"imdb_tail_kernel<FOLD={int(m.group(1) == 'true')}>"
     m = re.search(r"conv_s16_kernel<(\d+), (\d+), (\d+), (true|false), (true|false), (\d+), (\d+)>", sym)
     if m:
         base = f"conv_s16_kernel<NT={m.group(1)},KS={m.group(2)},NW={m.group(3)},{compute}"

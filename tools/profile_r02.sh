@@ -30,15 +30,20 @@ cp profiles/pmc_traffic.json $O/pmc_traffic.json 2>/dev/null
 run_cfg c1_imdn_f32
 pmc_cfg c1_imdn_f32
 run_cfg c2_rfdn_bf16_div2k --model rfdn_baseline --compute bf16 --sizes div2k --no-cpu-baseline
+run_cfg c2_rfdn_bf16_div2k_s1 --model rfdn_baseline --compute bf16 --sizes div2k --streams 1 --no-cpu-baseline
 run_cfg c2_rfdn_bf16_b32 --model rfdn_baseline --compute bf16 --no-cpu-baseline
 pmc_cfg c2_rfdn_bf16_b32 --model rfdn_baseline --compute bf16
 run_cfg c3_rlfn_bf16_div2k --model team04_rlfn --compute bf16 --sizes div2k --no-cpu-baseline
+run_cfg c3_rlfn_bf16_div2k_s1 --model team04_rlfn --compute bf16 --sizes div2k --streams 1 --no-cpu-baseline
 run_cfg c3_rlfn_bf16_b32 --model team04_rlfn --compute bf16 --no-cpu-baseline
 pmc_cfg c3_rlfn_bf16_b32 --model team04_rlfn --compute bf16
 run_cfg c4_bsrn_f16_270x480 --model team18_bsrn --compute f16 --tile 270x480 --no-cpu-baseline
 pmc_cfg c4_bsrn_f16_270x480 --model team18_bsrn --compute f16 --tile 270x480
 run_cfg x_imdn_bf16_b32 --model imdn_baseline --compute bf16 --no-cpu-baseline
 python bench.py --b1-latency --no-cpu-baseline --no-kernel-events > $O/b1_imdn_f32.json 2>/dev/null
+python bench.py --streams 2 --no-cpu-baseline --no-kernel-events > $O/bench_c1_imdn_f32_2streams.json 2>/dev/null
+python bench.py --sizes div2k --no-cpu-baseline > $O/bench_x_imdn_f32_div2k.json 2>/dev/null
+python bench.py --model team18_bsrn --compute f16 --sizes div2k --no-cpu-baseline > $O/bench_x_bsrn_f16_div2k.json 2>/dev/null
 for mc in "rfdn_baseline bf16" "team04_rlfn bf16" "team18_bsrn f16" "imdn_baseline f32"; do set -- $mc
   python bench.py --model $1 --compute $2 --tile 339x510 --batch 1 --b1-latency --no-cpu-baseline --no-kernel-events --steps 50 > $O/b1_$1_$2_339x510.json 2>/dev/null
 done

@@ -802,6 +802,8 @@ class HipSRModel(nn.Module):
                 kern = f"conv_f32_kernel<NT={nt},KS={o['k']},NCHW_IN={int(o['src'] is INPUT)},NW={nw}>"
                 if plan.esize == 2 and hw is None and o["src"] is not INPUT:
                     kern = f"conv_s16_kernel<NT={nt},KS={o['k']},NW=8,{plan.store}>"
+                if isinstance(o.get("dst1"), Buffer) and o["dst1"].blocked:
+                    kern = kern[:-1] + ",BLK>"          # the instantiation with the channel-blocked split store
                 e_in = 4 if o["src"] is INPUT else e_act
                 e_out = 4 if o["dst"] is OUTPUT else e_act
                 ca = o["cin_alg"]

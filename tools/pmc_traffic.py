@@ -35,13 +35,15 @@ def per_kernel(d, counter):
 
 def label(sym, compute):
     """rocprofv3 kernel symbol -> the kernel label of engine.op_costs / bench.py"""
-    m = re.search(r"conv_f32_kernel<(\d+), (\d+), (true|false), (\d+), (\d+), (\d+)>", sym)
+    m = re.search(r"conv_f32_kernel<(\d+), (\d+), (true|false), (\d+), (\d+), (\d+)(?:, (true|false))?>", sym)
     if m:
         base = f"conv_f32_kernel<NT={m.group(1)},KS={m.group(2)},NCHW_IN={int(m.group(3) == 'true')},NW={m.group(4)}"
         if m.group(5) != "0":
             base += f",TAIL={m.group(5)}"
         if m.group(6) != "0":
             base += f",POST={m.group(6)}"
+        if m.group(7) == "true":
+            base += ",BLK"                  # split store into a channel-blocked out1 (esr_conv_desc.blocked8)
         return base + ">"
     m = re.search(r"imdb_tail_kernel<(true|false)>", sym)
     if m:

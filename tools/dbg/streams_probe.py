@@ -50,6 +50,6 @@ def run(name, compute, nstreams, steps=6):
 if __name__ == "__main__":
     pairs = sys.argv[1:] or ["team04_rlfn", "bf16", "rfdn_baseline", "bf16", "team18_bsrn", "f16", "imdn_baseline", "f32"]
     for name, compute in zip(pairs[0::2], pairs[1::2]):
-        for s in (1, 2, 3, 4):
+        for s in (1, 2, 4, 6, 8):
             v, host = run(name, compute, s)
             print(f"{name:14s} {compute:5s} streams={s}: {v:8.1f} images/s   host enqueue {host:.3f} ms/image", flush=True)

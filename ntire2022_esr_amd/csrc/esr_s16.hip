@@ -264,6 +264,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
     constexpr int NPIECES = (NPX + 31) / 32;     // 1 KB DMA pieces: 32 halo pixels x 32 bytes (lane pair = the 16 channels of a pixel)
     constexpr int STAGE_BYTES = NPIECES * 1024;  // [halo pixel][half][8 channels]
     constexpr int PPW = (NPIECES + NW - 1) / NW; // pieces per wave and stage (waves >= NPIECES % NW: one fewer)
+    // 1x1: no halo, so a wave can stage exactly the pixels it computes (pieces PPW wv ..): nothing staged is shared between waves,
+    // the stage loop needs NO barrier and the eight waves drift freely (the weights, biases and tables in LDS are read-only)
+    constexpr bool OWN_PIECES = KS == 1 && NPIECES == NW * PPW && PPW * 32 == RW * TH;
+    static_assert(KS != 1 || OWN_PIECES, "1x1: pieces = the wave's own rows");
     constexpr int TAPS = KS * KS;
     constexpr int PAIRS = (TAPS + 1) / 2;
     constexpr int W_CHUNK_BYTES = PAIRS * NT * 1024;   // [pair][tile][lane][16 B]
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         }
 #pragma unroll
         for (int r = 0; r < PPW; ++r) {
-            const int pc = wv + NW * r;
+            const int pc = OWN_PIECES ? wv * PPW + r : wv + NW * r;
             const int plane = lane & 1;                       // channel half
             const int pl = pc * 32 + (lane >> 1);
             const int ly = pl / TH, lx = pl - ly * TH;
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
         }
     };
     auto dma_piece = [&](int i) __attribute__((always_inline)) {       // piece i of this wave of the cursor's stage, into ring slot lslot
-        const int pc = wv + NW * i;
+        const int pc = OWN_PIECES ? wv * PPW + i : wv + NW * i;
         if (NPIECES % NW == 0 || i < PPW - 1 || pc < NPIECES) {         // wave-uniform
             const unsigned dst = ring_lds + (unsigned)(lslot * STAGE_BYTES) + (unsigned)pc * 1024u;
             if (lc >= p.nchunks) dma_buf16(dst, LVR(i), lrsrcr, (unsigned)(lc - p.nchunks) * 32u);     // a residual chunk
@@ -910,7 +914,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
             // its DMA was issued R-2 stages ago, behind that stage's own stores / residual loads: younger are the DMA of the
             // R-2 stages since and the first-stage instructions of those among them that opened a tile
             wait_vm_dyn((R - 2) * n_my + epi_stores * __builtin_popcount(hist_st & hmask) + (GRES ? RES_LOADS : 0) * __builtin_popcount(hist_rs & hmask));
-            __builtin_amdgcn_s_barrier();
+            if (!OWN_PIECES) __builtin_amdgcn_s_barrier();
             slot = slot == R - 1 ? 0 : slot + 1;
         }
         if (!have) break;

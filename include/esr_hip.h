@@ -351,6 +351,10 @@ void esr_prof_destroy(esr_profiler* prof);
 /* diagnostics */
 int         esr_abi_version(void);
 const char* esr_last_hip_error(void);     /* thread-local, "" if none */
+/* sizeof of the ABI structs as this library was compiled -- 0: esr_view, 1: esr_conv_desc, 2: esr_esa_desc, 3: esr_bsconv_desc,
+ * 4: esr_ca_desc, 5: esr_op; anything else: 0.  A binding checks its own struct definitions against these once at load time (the
+ * reference has no counterpart: its boundary is Python objects). */
+size_t      esr_sizeof(int which);
 const char* esr_build_info(void);         /* e.g. "gfx950 f32-mfma16x16x4 tile16x16 chunk8" */
 
 #ifdef __cplusplus

@@ -87,7 +87,7 @@ class Op(ctypes.Structure):
 
 # every symbol include/esr_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "esr_abi_version", "esr_last_hip_error", "esr_build_info",
+    "esr_abi_version", "esr_last_hip_error", "esr_build_info", "esr_sizeof",
     "esr_packed_conv_bytes", "esr_pack_conv_f32", "esr_unpack_conv_f32",
     "esr_packed_conv_s16_bytes", "esr_pack_conv_s16", "esr_unpack_conv_s16",
     "esr_packed_post_s16_bytes", "esr_pack_post_s16", "esr_conv_post_supported",
@@ -174,6 +174,11 @@ def lib():
     L.esr_prof_destroy.restype = None
     if L.esr_abi_version() != 6:
         raise EsrError("libesr_hip.so ABI version mismatch")
+    L.esr_sizeof.argtypes = [ci]
+    L.esr_sizeof.restype = ctypes.c_size_t
+    for which, st in enumerate((View, ConvDesc, EsaDesc, BsDesc, CaDesc, Op)):
+        if L.esr_sizeof(which) != ctypes.sizeof(st):
+            raise EsrError(f"libesr_hip.so: sizeof({st.__name__}) is {L.esr_sizeof(which)} in the library, {ctypes.sizeof(st)} in the binding")
     _lib = L
     return L
 

@@ -889,6 +889,19 @@ extern "C" {
 
 int esr_abi_version(void) { return ESR_ABI_VERSION; }
 const char* esr_last_hip_error(void) { return g_err; }
+size_t esr_sizeof(int which)
+{
+    switch (which) {
+        case 0: return sizeof(esr_view);
+        case 1: return sizeof(esr_conv_desc);
+        case 2: return sizeof(esr_esa_desc);
+        case 3: return sizeof(esr_bsconv_desc);
+        case 4: return sizeof(esr_ca_desc);
+        case 5: return sizeof(esr_op);
+        default: return 0;
+    }
+}
+
 const char* esr_build_info(void) { return "gfx950 f32:v_mfma_f32_16x16x4_f32 (tiles 16x16/16x32, chunk 8) s16:v_mfma_f32_16x16x32_{bf16,f16} (16-bit storage, LDS-DMA ring, chunk 16) persistent"; }
 
 size_t esr_packed_conv_bytes(int cin_phys, int cout, int ksize)

@@ -135,3 +135,31 @@ def test_pipeline_equals_serial_loop(tmp_path):
                               util.imread_uint(str(tmp_path / "serial" / name / "valid" / f))), f
     # the big generated images are DIV2K-shaped: 4 x (339 x 510) etc.
     assert util.imread_uint(pairs[3][1]).shape == (1356, 2040, 3) and util.imread_uint(pairs[3][0]).shape == (339, 510, 3)
+
+
+@pytest.mark.parametrize("extra,streams,events", [
+    (["--batch", "4"], 1, "inside the timed region"),
+    (["--batch", "4", "--streams", "2"], 2, "replay"),
+    (["--model", "team04_rlfn", "--compute", "bf16", "--sizes", "div2k"], 4, "replay"),
+    (["--model", "team04_rlfn", "--compute", "bf16", "--sizes", "div2k", "--streams", "1"], 1, "replay"),
+])
+def test_bench_json_contract(extra, streams, events):
+    """bench.py prints ONE JSON line with the contract fields; the batch mode on one stream records its per-kernel events inside
+    the timed region, the DIV2K mode / several streams in a replay of the same steps (roofline.events says which)"""
+    import subprocess
+    import sys
+    from conftest import REPO
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert j["unit"] == "images/s" and j["value"] > 0 and j["n_gpus"] == 1 and j["steps"] == 2 and j["scaling"] == "weak"
+    assert j["config"]["streams_per_gpu"] == streams and "workload" in j["config"]
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] <= 1.2 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert events in r["events"] and r["kernels"][0]["kernel"] == r["kernel"]

@@ -974,7 +974,7 @@ int esr_unpack_conv_f32(const void* packed, size_t bytes, int cin, int cout, int
 int esr_conv_block_waves(const esr_conv_desc* d)
 {
     if (!d || d->cin <= 0 || d->cout <= 0) return 0;
-    if (d->storage != ESR_STORE_F32 && d->in_layout == ESR_NHWC) return 8;      // conv_s16_kernel: 8-wave blocks
+    if (d->storage != ESR_STORE_F32 && d->in_layout == ESR_NHWC) return esr_s16_block_waves(d);      // conv_s16_kernel: 8-wave blocks, or two of 4
     const bool in_nchw = d->in_layout == ESR_NCHW_IN;
     const int cin_phys = in_nchw ? CHUNK : round_up(d->cin, CHUNK);
     return conv_block_waves(d->ksize, in_nchw, round_up(d->cout, 16) / 16, cin_phys / CHUNK, d->n, d->h, d->w);

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 
@@ -251,14 +252,16 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, size_t bytes)
 // without being rounded: k slots (kq, 0..3) carry the 16-bit high parts of the four values, (kq, 4..7) their low parts, so the
 // intermediate tensor (RLFB's u, which nothing else reads) is neither stored nor quantised.
 template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 = 0>
-__global__ __launch_bounds__(64 * NW, 1) void conv_s16_kernel(const S16K p)
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(const S16K p)
 {
     static_assert(PNT2 == 0 || PNT1 > 0, "post 2 needs post 1");
     constexpr int HALO = KS / 2;
     constexpr int TH = TILE + 2 * HALO;          // halo tile width = LDS row pitch in pixels
-    constexpr int TILE_H = 32;                   // tile height; wave wv owns rows RW wv .. RW wv + RW-1
-    constexpr int RW = TILE_H / NW;              // rows per wave: 4 (8 waves) or 2 (16 waves: 4 per SIMD hide each other's LDS / issue stalls)
-    static_assert(NW == 8 || NW == 16, "8 or 16 waves per tile");
+    // NW = 4: 16 x 16 tiles and TWO independent blocks per CU (each with its own copy of the weights: only where that fits 80 KB) --
+    // the two waves of a SIMD then belong to different blocks and do not share a stage barrier
+    constexpr int TILE_H = NW == 4 ? 16 : 32;    // tile height; wave wv owns rows RW wv .. RW wv + RW-1
+    constexpr int RW = TILE_H / NW;              // rows per wave: 4 (4 / 8 waves) or 2 (16 waves: 4 per SIMD hide each other's LDS / issue stalls)
+    static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves per tile");
     constexpr int THY = TILE_H + 2 * HALO;
     constexpr int NPX = TH * THY;
     constexpr int NPIECES = (NPX + 31) / 32;     // 1 KB DMA pieces: 32 halo pixels x 32 bytes (lane pair = the 16 channels of a pixel)
@@ -934,7 +937,8 @@ int launch_s16(const S16K& k, size_t lds, hipStream_t st)
         attr = true;
     }
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
-    const int grid = ntiles < 256 ? ntiles : 256;          // one block per CU (LDS), persistent over the tiles
+    const int cap = NW == 4 ? 512 : 256;                   // one block per CU (LDS; NW = 4: two), persistent over the tiles
+    const int grid = ntiles < cap ? ntiles : cap;
     hipLaunchKernelGGL((conv_s16_kernel<NT, KS, NW, BF16, GRES, PNT1, PNT2>), dim3(grid), dim3(64 * NW), lds, st, k);
     return esr_check_launch("conv_s16_kernel launch");
 }
@@ -987,11 +991,27 @@ int launch_s16_post(int ks, int nt, bool gres, int pnt1, int pnt2, const S16K& k
 // LDS bytes of a launch: resident weights + `ring` input stages + epilogue scratch
 size_t s16_lds_bytes(int nchunks, int nt, int ksize, int nw, int ring, size_t post_bytes = 0)
 {
-    const int halo = ksize / 2, th = TILE + 2 * halo, thy = 32 + 2 * halo;
+    const int halo = ksize / 2, th = TILE + 2 * halo, thy = (nw == 4 ? 16 : 32) + 2 * halo;
     const int npieces = (th * thy + 31) / 32;
     const int pairs = (ksize * ksize + 1) / 2;
-    (void)nw;
     return (size_t)nchunks * pairs * nt * 1024 + post_bytes + (size_t)ring * npieces * 1024;
+}
+
+// residual == input of a 3x3 with as many output as input chunks: taken from the staged tile (S16K.res_in), not from HBM
+static bool s16_res_is_input(const esr_conv_desc* d)
+{
+    return d->ksize == 3 && d->res_mode == ESR_RES_PRE_ACT && esr_round_up(d->cin, 16) == esr_round_up(d->cout, 16) && d->res.ptr == d->in.ptr &&
+           d->res.pitch == d->in.pitch && d->res.coff == d->in.coff;
+}
+
+// 4: the launch takes the two-blocks-per-CU shape (4 waves, 16 x 16 tiles), 8: one 8-wave block per CU on 16 x 32 tiles
+int s16_block_waves(const esr_conv_desc* d)
+{
+    const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
+    const bool res_hbm = d->res_mode != ESR_RES_NONE && !s16_res_is_input(d);
+    if (d->ksize != 3 || nt != 3 || d->border_bias || d->post_wpacked || res_hbm || d->out_layout != ESR_NHWC || d->in_seg_stride != 0) return 8;
+    if ((long)d->n * ((d->w + TILE - 1) / TILE) * ((d->h + 15) / 16) < 512) return 8;           // fewer tiles than resident blocks
+    return s16_lds_bytes(nchunks, nt, 3, 4, RING_MIN, 1024) <= (size_t)LDS_LIMIT / 2 ? 4 : 8;
 }
 
 // decides how a descriptor with a post chain runs: fills the tile counts and whether the low-part images are resident;
@@ -1234,6 +1254,8 @@ extern "C" int esr_pack_input_s16(const esr_conv_desc* d, void* hip_stream)
 }
 
 // called by esr_conv2d_f32 (esr_hip.hip) for descriptors with 16-bit storage
+int esr_s16_block_waves(const esr_conv_desc* d) { return s16_block_waves(d); }
+
 int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
 {
     const bool bf16 = d->storage == ESR_STORE_BF16;
@@ -1327,8 +1349,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     k.res_mode = d->res_mode;
     k.res_in = 0;
     k.nres = 0;
-    if (d->ksize == 3 && d->res_mode == ESR_RES_PRE_ACT && esr_round_up(d->cin, 16) == esr_round_up(d->cout, 16) && d->res.ptr == d->in.ptr &&
-        d->res.pitch == d->in.pitch && d->res.coff == d->in.coff) {
+    if (s16_res_is_input(d)) {
         k.res_in = 1;                               // residual == input: added from the staged tile, no residual loads
         k.res_mode = ESR_RES_NONE;
     }
@@ -1358,6 +1379,21 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         const bool gres = k.res_mode != ESR_RES_NONE;
         return bf16 ? launch_s16_post<true>(d->ksize, nt, gres, pnt1, pnt2, k, lds, st)
                     : launch_s16_post<false>(d->ksize, nt, gres, pnt1, pnt2, k, lds, st);
+    }
+    // the plain 48-channel 3x3 (RLFB c1_r / c2_r): 46 KB of weights + a ring of three 11 KB stages fit 80 KB, so TWO 4-wave blocks
+    // share a CU -- their stage barriers are independent and one block's memory phase runs under the other's MFMAs (-2.5 % on the
+    // kernel, +1 % RLFN, A/B; 16 x 16 tiles carry more halo and the ring is the shortest, which is why it is not more)
+    if (s16_block_waves(d) == 4) {
+        const size_t lds4 = s16_lds_bytes(nchunks, nt, 3, 4, RING_MIN, 1024);
+        {
+            S16K k4 = k;
+            k4.ring = RING_MIN;
+            k4.tiles_y = (d->h + 15) / 16;
+            k4.magic_y = k4.tiles_y > 1 ? (unsigned)((0x100000000ull + k4.tiles_y - 1) / k4.tiles_y) : 0u;
+            const double nt_all = (double)d->n * k4.tiles_x * k4.tiles_y;
+            if (nt_all * (k4.tiles_x > k4.tiles_y ? k4.tiles_x : k4.tiles_y) < 4294967296.0)
+                return bf16 ? launch_s16<3, 3, 4, true, false>(k4, lds4, st) : launch_s16<3, 3, 4, false, false>(k4, lds4, st);
+        }
     }
     if (d->ksize == 3) return bf16 ? launch_s16_res<3, true>(nt, k, lds, st) : launch_s16_res<3, false>(nt, k, lds, st);
     return bf16 ? launch_s16_res<1, true>(nt, k, lds, st) : launch_s16_res<1, false>(nt, k, lds, st);

@@ -801,7 +801,7 @@ class HipSRModel(nn.Module):
                 nw = L.lib().esr_conv_block_waves(ctypes.byref(arr[i].conv)) if arr is not None else 0
                 kern = f"conv_f32_kernel<NT={nt},KS={o['k']},NCHW_IN={int(o['src'] is INPUT)},NW={nw}>"
                 if plan.esize == 2 and hw is None and o["src"] is not INPUT:
-                    kern = f"conv_s16_kernel<NT={nt},KS={o['k']},NW=8,{plan.store}>"
+                    kern = f"conv_s16_kernel<NT={nt},KS={o['k']},NW={nw or 8},{plan.store}>"
                 if isinstance(o.get("dst1"), Buffer) and o["dst1"].blocked:
                     kern = kern[:-1] + ",BLK>"          # the instantiation with the channel-blocked split store
                 e_in = 4 if o["src"] is INPUT else e_act

@@ -67,11 +67,13 @@ def test_s16_conv_matches_fp64_reference(compute, cin, cout, k, hw, act, res_mod
 @pytest.mark.parametrize("compute", ["bf16", "f16"])
 @pytest.mark.parametrize("n,cin,cout,k,hw,res_mode", [
     (1, 64, 64, 3, (270, 480), 0), (1, 64, 64, 3, (270, 480), 2), (1, 64, 64, 1, (270, 480), 2), (1, 48, 48, 3, (339, 510), 2),
-    (1, 64, 64, 3, (339, 510), 1), (3, 48, 48, 3, (256, 256), 0), (1, 16, 16, 3, (270, 480), 1), (5, 50, 50, 1, (200, 200), 0)])
+    (1, 64, 64, 3, (339, 510), 1), (3, 48, 48, 3, (256, 256), 0), (1, 16, 16, 3, (270, 480), 1), (5, 50, 50, 1, (200, 200), 0),
+    (2, 48, 48, 3, (339, 510), 0), (1, 40, 44, 3, (339, 510), 0)])      # >= 512 tiles of 16x16, three output tiles, no HBM residual: two 4-wave blocks per CU
 def test_s16_conv_more_tiles_than_blocks(compute, n, cin, cout, k, hw, res_mode):
     """Shapes with MORE 16x32 tiles than the 256 persistent blocks and partial tiles at both edges: the tile-to-tile path of a
     block (the epilogue of tile k inside the first MFMA group of tile k+1, residual registers reused across tiles, unequal
-    tile counts per block, the drain iteration) -- the small shapes above give every block at most one tile."""
+    tile counts per block, the drain iteration) -- the small shapes above give every block at most one tile.  The 48-channel 3x3s
+    without a residual from HBM take the two-blocks-per-CU shape (NW = 4, 16x16 tiles, esr_conv_block_waves)."""
     from ntire2022_esr_amd import ops
     from ntire2022_esr_amd.engine import pack_conv_s16, unpack_conv_s16
     dt = DT[compute]

@@ -248,3 +248,28 @@ def test_head_hi_lo_weights_cpu():
         want = (w.double() * x.double().reshape(1, 3, 1, 1)).sum(dim=1)
         assert float((got - want).abs().max()) <= rel * float((w.abs().double() * x.double().reshape(1, 3, 1, 1)).sum(dim=1).max()) * 4
         assert torch.equal(beff, b)
+
+
+def test_block_shape_query_cpu():
+    """esr_conv_block_waves (host-only): which block shape a descriptor's launch takes -- fp32: 8-wave blocks for large 3x3s with
+    >= 3 output tiles; 16-bit storage: two 4-wave blocks per CU for the plain 48-channel 3x3 with >= 512 tiles of 16x16, else 8"""
+    from ntire2022_esr_amd import _lib as L
+    lib = L.lib()
+
+    def waves(n, h, w, cin, cout, k=3, store="f32", **kw):
+        d = L.ConvDesc()
+        d.n, d.h, d.w, d.cin, d.cout, d.ksize = n, h, w, cin, cout, k
+        d.in_layout = d.out_layout = L.NHWC
+        d.storage = L.STORE[store]
+        for key, v in kw.items():
+            setattr(d, key, v)
+        return lib.esr_conv_block_waves(ctypes.byref(d))
+
+    assert waves(32, 256, 256, 64, 64) == 8 and waves(1, 64, 64, 64, 64) == 4 and waves(32, 256, 256, 48, 16) == 4
+    assert waves(32, 256, 256, 48, 48, store="bf16") == 4 and waves(1, 339, 510, 46, 46, store="f16") == 4
+    assert waves(1, 128, 128, 48, 48, store="bf16") == 8                        # 64 tiles: fewer than resident blocks
+    assert waves(32, 256, 256, 64, 64, store="bf16") == 8                        # 74 KB of weights: one block per CU
+    assert waves(32, 256, 256, 48, 48, k=1, store="bf16") == 8
+    assert waves(32, 256, 256, 48, 48, store="bf16", res_mode=L.RES_POST_ACT) == 8          # residual from HBM
+    assert waves(32, 256, 256, 48, 48, store="bf16", out_layout=L.NCHW_SHUFFLE4) == 8
+    assert lib.esr_conv_block_waves(None) == 0

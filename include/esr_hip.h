@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESR_ABI_VERSION 6
+#define ESR_ABI_VERSION 7
 
 typedef enum esr_status {
     ESR_OK = 0,
@@ -160,6 +160,14 @@ typedef struct esr_conv_desc {
      * channels of IMDBlock's conv3), ESR_BLOCKED_IN for the fused IMDB tail at the network's shape (imdb_tail_kernel); any
      * other use returns ESR_ERR_UNSUPPORTED. */
     int32_t blocked8;
+    int32_t reserved4;
+    /* ABI v7 -- Winograd F(2x2, 3x3) weights (esr_pack_wino_f32) of the SAME convolution; NULL = none.  When set and
+     * esr_wino_supported(d) (fp32 storage and compute, ksize 3, NHWC in / NHWC out, round_up(cin, 8) / 8 even and >= 4, no tail /
+     * post / border table / segmented or blocked input, a split store only at a multiple of 16 channels), esr_conv2d_f32 runs
+     * wino_f32_kernel: 16 transformed-domain products per 2x2 output pixels and (cin, cout) instead of 36 -- 2.25x fewer MFMAs,
+     * fp32 throughout (its rounding differs from the direct sum's by ~1e-6 relative, inside the 2e-5 budget of SURVEY 8c).
+     * Otherwise the descriptor takes conv_f32_kernel with `wpacked`, which must always be valid. */
+    const void* wino_wpacked;
 } esr_conv_desc;
 #define ESR_BLOCKED_IN   1
 #define ESR_BLOCKED_OUT1 2
@@ -192,6 +200,17 @@ int    esr_unpack_conv_s16(const void* packed, size_t bytes, int cin, int cout, 
 size_t esr_packed_post_s16_bytes(int cin, int cout);
 int    esr_pack_post_s16(const float* w_oi, const float* bias, int cin, int cout, int compute, void* out, size_t out_bytes);
 int    esr_conv_post_supported(const esr_conv_desc* d);   /* 1: the descriptor's post chain has a fused kernel that fits */
+
+/* Winograd F(2x2, 3x3) weight packer (host C++, no GPU needed): OIHW fp32 3x3 weights -> U = G g G^T (computed in fp64, rounded
+ * once) in the MFMA A-operand order wino_f32_kernel stages: [cin chunk of 8][cout half of 32][position 16][lane 64][ct0 s0, ct0 s1,
+ * ct1 s0, ct1 s1] floats, followed by round_up(cout, 32) bias floats.  cin_map / cin_phys as for esr_pack_conv_f32.
+ * esr_unpack_wino_f32 (tests) returns U as [cout][cin][16] and the bias. */
+size_t esr_packed_wino_bytes(int cin_phys, int cout);
+int    esr_pack_wino_f32(const float* w_oihw, const float* bias, int cin, int cout, const int32_t* cin_map, int cin_phys,
+                         void* out, size_t out_bytes);
+int    esr_unpack_wino_f32(const void* packed, size_t bytes, int cin, int cout, const int32_t* cin_map, int cin_phys,
+                           float* u_oc16, float* bias);
+int    esr_wino_supported(const esr_conv_desc* d);   /* 1: a descriptor of this shape runs on wino_f32_kernel when wino_wpacked is set */
 
 int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream);
 /* Diagnostics: waves per block of the conv_f32_kernel variant esr_conv2d_f32 launches for `d` (4 = 16x16-pixel tiles,

@@ -45,6 +45,7 @@ class ConvDesc(ctypes.Structure):
         ("post_cout", ctypes.c_int32), ("post_act", ctypes.c_int32),
         ("post2_wpacked", ctypes.c_void_p), ("post2_out", View),
         ("post2_cout", ctypes.c_int32), ("reserved3", ctypes.c_int32), ("border_bias", ctypes.c_void_p), ("in_seg_stride", ctypes.c_int64), ("in_seg_chunks", ctypes.c_int32), ("blocked8", ctypes.c_int32),
+        ("reserved4", ctypes.c_int32), ("wino_wpacked", ctypes.c_void_p),      # ABI v7
     ]
 
 
@@ -91,6 +92,7 @@ EXPORTS = [
     "esr_packed_conv_bytes", "esr_pack_conv_f32", "esr_unpack_conv_f32",
     "esr_packed_conv_s16_bytes", "esr_pack_conv_s16", "esr_unpack_conv_s16",
     "esr_packed_post_s16_bytes", "esr_pack_post_s16", "esr_conv_post_supported",
+    "esr_packed_wino_bytes", "esr_pack_wino_f32", "esr_unpack_wino_f32", "esr_wino_supported",
     "esr_conv2d_f32", "esr_conv_block_waves", "esr_run_ops", "esr_pack_input_s16",
     "esr_prof_create", "esr_run_ops_profiled", "esr_prof_collect", "esr_prof_destroy",
     "esr_packed_dense_bytes", "esr_pack_dense_f32",
@@ -137,6 +139,14 @@ def lib():
     L.esr_pack_post_s16.restype = ci
     L.esr_conv_post_supported.argtypes = [ctypes.POINTER(ConvDesc)]
     L.esr_conv_post_supported.restype = ci
+    L.esr_packed_wino_bytes.argtypes = [ci, ci]
+    L.esr_packed_wino_bytes.restype = sz
+    L.esr_pack_wino_f32.argtypes = [vp, vp, ci, ci, vp, ci, vp, sz]
+    L.esr_pack_wino_f32.restype = ci
+    L.esr_unpack_wino_f32.argtypes = [vp, sz, ci, ci, vp, ci, vp, vp]
+    L.esr_unpack_wino_f32.restype = ci
+    L.esr_wino_supported.argtypes = [ctypes.POINTER(ConvDesc)]
+    L.esr_wino_supported.restype = ci
     L.esr_conv2d_f32.argtypes = [ctypes.POINTER(ConvDesc), vp]
     L.esr_conv2d_f32.restype = ci
     L.esr_conv_block_waves.argtypes = [ctypes.POINTER(ConvDesc)]
@@ -172,7 +182,7 @@ def lib():
     L.esr_prof_collect.restype = ci
     L.esr_prof_destroy.argtypes = [vp]
     L.esr_prof_destroy.restype = None
-    if L.esr_abi_version() != 6:
+    if L.esr_abi_version() != 7:
         raise EsrError("libesr_hip.so ABI version mismatch")
     L.esr_sizeof.argtypes = [ci]
     L.esr_sizeof.restype = ctypes.c_size_t

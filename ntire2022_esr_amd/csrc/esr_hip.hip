@@ -1062,6 +1062,8 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
         if (px_img * (in_nchw ? d->cin : d->in.pitch) * 4.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
     }
 
+    if (d->wino_wpacked && !store16 && esr_wino_supported(d)) return esr_conv2d_wino(d, hip_stream);
+
     const int nt = round_up(d->cout, 16) / 16;
     const int taps = d->ksize * d->ksize;
     ConvK k;

@@ -10,3 +10,6 @@ static inline int esr_round_up(int v, int m) { return (v + m - 1) / m * m; }
 // esr_s16.hip: NHWC convolution on 16-bit storage (called by esr_conv2d_f32 when d->storage != ESR_STORE_F32)
 int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream);
 int esr_s16_block_waves(const esr_conv_desc* d);      // 4: two 4-wave blocks per CU (16 x 16 tiles), 8: one 8-wave block (16 x 32)
+
+// esr_wino.hip: Winograd F(2x2, 3x3) fp32 convolution (called by esr_conv2d_f32 when d->wino_wpacked is set and the shape qualifies)
+int esr_conv2d_wino(const esr_conv_desc* d, void* hip_stream);

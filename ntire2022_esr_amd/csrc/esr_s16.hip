@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <type_traits>
 
 #include "esr_internal.h"
@@ -43,10 +44,8 @@ constexpr int TILE = 16;            // output tile width (pixels) = one MFMA's p
 constexpr int RING_MIN = 3, RING_MAX = 8;   // input stages in LDS (as many as fit next to the resident weights)
 constexpr unsigned OOB = 0x80000000u;
 constexpr int LDS_LIMIT = 160 * 1024;
-#ifndef ESR_S16_NW
-#define ESR_S16_NW 8
-#endif
-constexpr int S16_NW = ESR_S16_NW;     // waves per tile
+constexpr int MAX_DEVICES = 64;     // per-device launch attributes (launch_s16)
+constexpr int S16_NW = 8;           // waves per tile
 
 struct S16K {
     const char* x;        // NHWC 16-bit input
@@ -930,11 +929,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
 template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 = 0>
 int launch_s16(const S16K& k, size_t lds, hipStream_t st)
 {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<NT, KS, NW, BF16, GRES, PNT1, PNT2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-        attr = true;
+    // the attribute belongs to the (device, instantiation) pair: one process may drive several GPUs (engine contexts are keyed by
+    // device).  Relaxed atomics: a racing thread at worst sets the same value twice.
+    static std::atomic<unsigned> attr_set[MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
+    if (!attr_set[dev].load(std::memory_order_relaxed)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<NT, KS, NW, BF16, GRES, PNT1, PNT2>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+        if (e != hipSuccess) {
+            esr_set_err("hipFuncSetAttribute(conv_s16_kernel, MaxDynamicSharedMemorySize)", e);
+            return ESR_ERR_LAUNCH;
+        }
+        attr_set[dev].store(1u, std::memory_order_relaxed);
     }
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int cap = NW == 4 ? 512 : 256;                   // one block per CU (LDS; NW = 4: two), persistent over the tiles

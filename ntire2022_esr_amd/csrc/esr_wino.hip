@@ -1,0 +1,514 @@
+// esr_wino.hip -- Winograd F(2x2, 3x3) fp32 convolution on v_mfma_f32_16x16x4_f32 (gfx950), NHWC in / NHWC out.
+// Interface: esr_conv_desc.wino_wpacked (include/esr_hip.h, ABI v7); design notes: DESIGN.md section 4.1w.
+//
+// Same operation as conv_f32_kernel<.,3,..> (nn.Conv2d(k=3, s=1, p=1, bias) + fused epilogue, models/basicblock.py:61-98),
+// other arithmetic: 16 transformed-domain products per 2x2 output pixels and (cin, cout) instead of 36,
+//     Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A           (Lavin & Gray; B^T, G, A^T below)
+// i.e. 2.25x fewer MFMAs than the direct form, fp32 throughout (rounding ~1e-6 relative: tools/wino/wino_numerics.py).
+//
+//   work item   one 16x16-pixel tile (8x8 Winograd tiles) x 32 output channels (a "cout half")
+//   block       4 waves, TWO blocks per CU (68 KB LDS each, <= 256 registers per wave): the blocks drift apart, one block's
+//               epilogue / barrier stalls run under the other's MFMAs
+//   wave w      Winograd tile rows 2w, 2w+1 (16 tiles = the N side of the MFMA) x 2 cout tiles x ALL 16 positions:
+//               128 accumulator registers; the output transform is register-local
+//   MFMA        A = U = G g G^T (lane (i, k): cout i of the tile, cin 2k+s of the chunk), B = V = B^T d B (lane (j, k): Winograd
+//               tile j, cin 2k+s), D[cout][tile]: lane (j, g) holds couts 4g..4g+3 of tile j
+//   K loop      cin in chunks of 8.  Per chunk the block stages, global -> LDS by DMA (buffer_load ... lds):
+//                 U chunk    16 KB  [pos][lane][ct0 s0, ct0 s1, ct1 s0, ct1 s1]   ring of 2 (always an L2 hit)
+//                 raw halo   18x18 pixels x 32 B = 10.4 KB, [half][row pair][37 slots of 16 B]   ring of 3
+//               V NEVER touches LDS: lane (j, k) reads the 4x4 patch of ITS tile and ITS channel pair from the raw stage
+//               (16 ds_read_b64), transforms it (32 v_pk_add_f32) and holds the 16 positions in registers as the B operands of
+//               the NEXT chunk while the current chunk's 64 MFMAs run.  One s_barrier per chunk (stage hand-over).
+//   LDS reads   per wave and chunk: 16 ds_read_b128 (A) + 16 ds_read_b64 (raw) for 64 MFMAs
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "esr_hip.h"
+#include "esr_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int wn_i32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int WN_THREADS = 256;
+constexpr int WN_TILE = 16;                 // output pixels per tile edge
+constexpr int WN_HALO = WN_TILE + 2;
+constexpr int WN_PAIR = 37;                 // 16-byte slots per pair of halo rows: 18 + 18 + 1 pad (see wn_slot)
+constexpr int WN_PLANE = 352;               // slots per channel-half plane: 9 row pairs x 37 = 333 used, padded to 5.5 DMA pieces
+constexpr int WN_RAW_PIECES = 12;           // 64 x 16 B pieces reserved per raw stage: 11 carry data, every wave issues 3
+constexpr int WN_RAW_BYTES = WN_RAW_PIECES * 1024;
+constexpr int WN_U_BYTES = 16 * 1024;
+constexpr int WN_RAW_RING = 3, WN_U_RING = 2;
+constexpr int WN_RAW_OFF = WN_U_RING * WN_U_BYTES;
+constexpr int WN_BIAS_OFF = WN_RAW_OFF + WN_RAW_RING * WN_RAW_BYTES;
+constexpr int WN_LDS = WN_BIAS_OFF + 256;                            // 69 888 B
+constexpr int WN_MAX_BLOCKS = 512;          // 256 CUs x 2
+constexpr unsigned WN_OOB = 0x80000000u;
+
+struct WinoK {
+    const float* x;
+    const float* up;          // packed U blob
+    const float* bias;        // nhalves * 32 floats inside the blob
+    const float* res;
+    float* y0;
+    float* y1;
+    int N, H, W;
+    int nchunks, nhalves;
+    unsigned up_bytes;
+    int in_pitch, in_coff;
+    int res_pitch, res_coff;
+    int y0_pitch, y0_coff, y1_pitch, y1_coff;
+    int cout_store, split;
+    int act;
+    float slope;
+    int res_mode;
+    int tiles_x, tiles_y;
+    int y1_blk;
+};
+
+__device__ __forceinline__ wn_i32x4 wn_rsrc(const void* base, size_t bytes)
+{
+    wn_i32x4 r;
+    r.x = (int)(size_t)base;
+    r.y = (int)(((size_t)base >> 32) & 0xffff);
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+
+// 64 lanes x 16 bytes, global -> LDS (lds_dst + 16 * lane); an out-of-range voff writes zeros.  Inline asm: hipcc cannot see which
+// LDS bytes a DMA touches and would put vmcnt(0) in front of later ds_reads; the stage loop counts instead.
+__device__ __forceinline__ void wn_dma16(unsigned lds_dst, unsigned voff, wn_i32x4 rsrc, unsigned soff)
+{
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    rsrc.x = __builtin_amdgcn_readfirstlane(rsrc.x); rsrc.y = __builtin_amdgcn_readfirstlane(rsrc.y);
+    rsrc.z = __builtin_amdgcn_readfirstlane(rsrc.z); rsrc.w = __builtin_amdgcn_readfirstlane(rsrc.w);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+__device__ __forceinline__ float wn_act1(float v, int act, float slope)
+{
+    switch (act) {
+        case ESR_ACT_LRELU: return fmaxf(v, slope * v);
+        case ESR_ACT_RELU: return fmaxf(v, 0.f);
+        case ESR_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        default: return v;
+    }
+}
+
+// ACT: compile-time activation of the hot instantiations (ESR_ACT_LRELU / ESR_ACT_NONE); -1 = read p.act at run time.
+template <int ACT>
+__device__ __forceinline__ f32x4 wn_act4(f32x4 v, int act, float slope)
+{
+    if (ACT == ESR_ACT_LRELU) {
+        const f32x4 m = v * slope;
+        v.x = fmaxf(v.x, m.x); v.y = fmaxf(v.y, m.y); v.z = fmaxf(v.z, m.z); v.w = fmaxf(v.w, m.w);
+    } else if (ACT < 0) {
+        v.x = wn_act1(v.x, act, slope); v.y = wn_act1(v.y, act, slope);
+        v.z = wn_act1(v.z, act, slope); v.w = wn_act1(v.w, act, slope);
+    }
+    return v;
+}
+
+// slot (16-byte granule) of halo pixel (ly, lx) inside a channel-half plane.  Rows come in pairs of 37 slots so that two rows
+// down is an ODD number of slots: lane (tile (tx, ty), k) reads pixel (2 tx + dx, 4 w + 2 ty + r), and for the 32 lanes
+// (16 tiles x k in {0, 1}) one ds_read_b64 services together the dword address is 8 tx + 148 ty + 2 k + {0, 1} (+ const):
+// all 64 banks once.
+__device__ __forceinline__ int wn_slot(int ly, int lx) { return (ly >> 1) * WN_PAIR + (ly & 1) * WN_HALO + lx; }
+
+template <int ACT, int RES, bool Y1BLK>
+__global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[WN_LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;          // MFMA column (Winograd tile) / K slot (B side), cout group (D side)
+    const int tx = j & 7, ty = j >> 3;
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    // ---- work walk: item = (tile, cout half); XCD x (blocks b % 8 == x) takes a contiguous run, the halves of a tile are neighbours
+    const int nwork = p.N * p.tiles_y * p.tiles_x * p.nhalves;
+    const int G = gridDim.x;
+    auto work_index = [&](int k) -> int {
+        const int base = k * G;
+        if (base >= nwork) return -1;
+        int off = blockIdx.x;
+        if ((G & 7) == 0 && base + G <= nwork) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+        const int t = base + off;
+        return t < nwork ? t : -1;
+    };
+
+    struct Ctx { int n, x0, y0, half; unsigned voff[3]; };
+    auto setup = [&](int work, Ctx& c) {
+        if (work < 0) {                              // behind the last item: the DMAs still issue (uniform counts), all lanes out of range
+            c.n = 0; c.x0 = 0; c.y0 = 0; c.half = 0;
+            c.voff[0] = c.voff[1] = c.voff[2] = WN_OOB;
+            return;
+        }
+        const int t = work / p.nhalves;
+        c.half = work - t * p.nhalves;
+        const int txi = t % p.tiles_x;
+        const int tq = t / p.tiles_x;
+        const int tyi = tq % p.tiles_y;
+        c.n = tq / p.tiles_y;
+        c.x0 = txi * WN_TILE;
+        c.y0 = tyi * WN_TILE;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int item = (wv * 3 + i) * 64 + lane;
+            const int half = item >= WN_PLANE ? 1 : 0;
+            const int slot = item - half * WN_PLANE;
+            const int pr = slot / WN_PAIR, rem = slot - pr * WN_PAIR;
+            const int odd = rem >= WN_HALO ? 1 : 0;
+            const int ly = 2 * pr + odd, lx = rem - odd * WN_HALO;
+            const int gy = c.y0 - 1 + ly, gx = c.x0 - 1 + lx;
+            const bool ok = item < 2 * WN_PLANE && pr < WN_HALO / 2 && rem < 2 * WN_HALO && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            c.voff[i] = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff + 4 * half) * 4u : WN_OOB;
+        }
+    };
+    const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 4;
+    const wn_i32x4 ursrc = wn_rsrc(p.up, p.up_bytes);
+
+    // raw halo of chunk `chunk` of item `c` -> raw ring slot `rs`
+    auto issue_raw = [&](int rs, const Ctx& c, int chunk) __attribute__((always_inline)) {
+        const wn_i32x4 xr = wn_rsrc(p.x + (size_t)c.n * (img_bytes / 4), img_bytes);
+        const unsigned base = smem_lds + (unsigned)(WN_RAW_OFF + rs * WN_RAW_BYTES + wv * 3 * 1024);
+        const unsigned soff = (unsigned)chunk * 32u;
+        wn_dma16(base, c.voff[0], xr, soff);
+        wn_dma16(base + 1024u, c.voff[1], xr, soff);
+        wn_dma16(base + 2048u, c.voff[2], xr, soff);
+    };
+    // U chunk -> U ring slot `us`; live = false: out of range (zeros into a slot nobody reads)
+    auto issue_u = [&](int us, const Ctx& c, int chunk, bool live) __attribute__((always_inline)) {
+        const unsigned base = smem_lds + (unsigned)(us * WN_U_BYTES + wv * 4 * 1024);
+        const unsigned soff = (unsigned)((chunk * p.nhalves + c.half) * WN_U_BYTES + wv * 4 * 1024);
+        const unsigned vo = live ? (unsigned)lane * 16u : WN_OOB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wn_dma16(base + i * 1024u, vo, ursrc, soff + i * 1024u);
+    };
+
+    // lane-constant LDS byte offsets
+    const int raw_lane = (g >> 1) * (WN_PLANE * 16) + wn_slot(4 * wv + 2 * ty, 2 * tx) * 16 + (g & 1) * 8;
+    const int u_lane = lane * 16;
+
+    // ---- input transform of one (tile, channel pair): V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+    // row pass (needs one patch row): w[r][.] = d[r][.] B;   column pass: V[.][c] = B^T w[.][c];   position = 4 * row + column
+    auto raw_row = [&](const char* rs, int r, f32x2 (&d)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx)
+            d[dx] = *reinterpret_cast<const f32x2*>(rs + raw_lane + ((r >> 1) * WN_PAIR + (r & 1) * WN_HALO + dx) * 16);
+    };
+    auto row_pass = [&](f32x2 (&V)[16], int r, const f32x2 (&d)[4]) __attribute__((always_inline)) {
+        V[4 * r + 0] = d[0] - d[2];
+        V[4 * r + 1] = d[1] + d[2];
+        V[4 * r + 2] = d[2] - d[1];
+        V[4 * r + 3] = d[1] - d[3];
+    };
+    auto col_pass = [&](f32x2 (&V)[16], int c) __attribute__((always_inline)) {
+        const f32x2 w0 = V[c], w1 = V[4 + c], w2 = V[8 + c], w3 = V[12 + c];
+        V[c] = w0 - w2;
+        V[4 + c] = w1 + w2;
+        V[8 + c] = w2 - w1;
+        V[12 + c] = w1 - w3;
+    };
+
+    int k = 0;
+    int work = work_index(0);
+    if (work < 0) return;
+    Ctx cur, nxt;
+    setup(work, cur);
+    int wn = work_index(1);
+    setup(wn, nxt);
+
+    // ---- prologue: raw stages 0..2 and U stage 0 of the first item; V of chunk 0 is computed alone
+    issue_raw(0, cur, 0);
+    issue_raw(1, cur, 1);
+    issue_raw(2, cur, 2);
+    issue_u(0, cur, 0, true);
+    // bias of both cout halves -> LDS (a per-item global load would make hipcc wait vmcnt(0), i.e. for the DMAs in flight)
+    if (tid < p.nhalves * 8) *reinterpret_cast<f32x4*>(smem + WN_BIAS_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(p.bias + tid * 4);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x2 V0[16], V1[16];
+    {
+        const char* rs = smem + WN_RAW_OFF;
+        f32x2 d[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { raw_row(rs, r, d); row_pass(V0, r, d); }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) col_pass(V0, c);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // raw slot 0 is overwritten by the first loop iteration
+
+    int us = 0;                                   // U ring slot of the current stage
+    int rsn = 1;                                  // raw ring slot of the NEXT stage (read by this stage's transform)
+
+    f32x4 acc[16][2];
+    for (;;) {
+        const bool has_next = wn >= 0;
+        f32x4 biasv[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) biasv[ct] = *reinterpret_cast<const f32x4*>(smem + WN_BIAS_OFF + (cur.half * 32 + ct * 16 + g * 4) * 4);
+        // A^T M A of a bias b placed at position (1, 1) is b in all four outputs: no bias add in the epilogue
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[pos][ct] = pos == 5 ? biasv[ct] : f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // one K stage: 64 MFMAs from (U ring slot us, Vc) while Vn = transform(raw ring slot rsn) is built
+        auto stage = [&](int c, f32x2 (&Vc)[16], f32x2 (&Vn)[16]) __attribute__((always_inline)) {
+            // DMA of U stage +1 and raw stage +3 (ring slots free since the barrier that ended the previous stage)
+            {
+                const int c1 = c + 1;
+                if (c1 < p.nchunks) issue_u(us ^ 1, cur, c1, true);
+                else issue_u(us ^ 1, nxt, 0, has_next);
+                const int c3 = c + 3;
+                int rs3 = rsn + 2;
+                rs3 = rs3 >= 3 ? rs3 - 3 : rs3;
+                if (c3 < p.nchunks) issue_raw(rs3, cur, c3);
+                else issue_raw(rs3, nxt, c3 - p.nchunks);
+            }
+            const char* ust = smem + us * WN_U_BYTES + u_lane;
+            const char* rs = smem + WN_RAW_OFF + rsn * WN_RAW_BYTES;
+            f32x4 a[2];
+            f32x2 d[2][4];
+            a[0] = *reinterpret_cast<const f32x4*>(ust);
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos) {
+                const int cs = pos & 1;
+                if (pos + 1 < 16) a[cs ^ 1] = *reinterpret_cast<const f32x4*>(ust + (pos + 1) * 1024);
+                if (pos < 4) raw_row(rs, pos, d[pos & 1]);
+                if (pos >= 1 && pos < 5) row_pass(Vn, pos - 1, d[(pos - 1) & 1]);
+                if (pos >= 5 && pos < 9) col_pass(Vn, pos - 5);
+                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cs].x, Vc[pos].x, acc[pos][0], 0, 0, 0);
+                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cs].z, Vc[pos].x, acc[pos][1], 0, 0, 0);
+                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cs].y, Vc[pos].y, acc[pos][0], 0, 0, 0);
+                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cs].w, Vc[pos].y, acc[pos][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // hand-over: U stage +1 (issued above, older than the 3 raw pieces) and raw stage +2 (issued a stage ago) have landed
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            us ^= 1;
+            rsn = rsn == 2 ? 0 : rsn + 1;
+        };
+        for (int c = 0; c < p.nchunks; c += 2) {
+            stage(c, V0, V1);
+            stage(c + 1, V1, V0);
+        }
+
+        // ---- output transform  Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1], then residual / activation / store
+        {
+            const int ybase = cur.y0 + 4 * wv + 2 * ty, xbase = cur.x0 + 2 * tx;
+            unsigned pix[2][2];
+            bool pok[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    pok[a][b] = ybase + a < p.H && xbase + b < p.W;
+                    pix[a][b] = (unsigned)((ybase + a) * p.W + xbase + b);
+                }
+            const size_t hw = (size_t)p.H * p.W;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int cg = cur.half * 32 + ct * 16 + g * 4;            // this lane's first output channel
+                const bool to0 = cur.half * 32 + ct * 16 < p.split;        // uniform: host guarantees split % 16 == 0 or no split
+                const bool cok = cg < p.cout_store;
+                const int ch = to0 ? p.y0_coff + cg : p.y1_coff + cg - p.split;
+                const bool blk = Y1BLK && !to0;
+                char* const dbase = reinterpret_cast<char*>(to0 ? p.y0 : p.y1) + (size_t)cur.n * hw * (size_t)((to0 ? p.y0_pitch : p.y1_pitch) * 4);
+                const unsigned dps = blk ? 32u : (unsigned)((to0 ? p.y0_pitch : p.y1_pitch) * 4);
+                const size_t dlane = blk ? (size_t)(ch >> 3) * hw * 32 + (size_t)(ch & 7) * 4 : (size_t)ch * 4;
+                f32x4 rv[2][2];
+                if (RES != ESR_RES_NONE) {
+                    const char* rbase = reinterpret_cast<const char*>(p.res) + (size_t)cur.n * hw * (size_t)(p.res_pitch * 4) + (size_t)(p.res_coff + cg) * 4;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            rv[a][b] = (pok[a][b] && cok) ? *reinterpret_cast<const f32x4*>(rbase + (size_t)pix[a][b] * (unsigned)(p.res_pitch * 4))
+                                                          : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                f32x4 Y[2][2];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const f32x4 m0 = acc[jj][ct], m1 = acc[4 + jj][ct], m2 = acc[8 + jj][ct], m3 = acc[12 + jj][ct];
+                    const f32x4 t0 = m0 + m1 + m2, t1 = m1 - m2 - m3;
+                    if (jj == 0) { Y[0][0] = t0; Y[1][0] = t1; }
+                    else if (jj == 1) { Y[0][0] += t0; Y[1][0] += t1; Y[0][1] = t0; Y[1][1] = t1; }
+                    else if (jj == 2) { Y[0][0] += t0; Y[1][0] += t1; Y[0][1] -= t0; Y[1][1] -= t1; }
+                    else { Y[0][1] -= t0; Y[1][1] -= t1; }
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        f32x4 v = Y[a][b];
+                        if (RES == ESR_RES_PRE_ACT) v = wn_act4<ACT>(v + rv[a][b], p.act, p.slope);
+                        else if (RES == ESR_RES_POST_ACT) v = wn_act4<ACT>(v, p.act, p.slope) + rv[a][b];
+                        else v = wn_act4<ACT>(v, p.act, p.slope);
+                        if (pok[a][b] && cok) *reinterpret_cast<f32x4*>(dbase + dlane + (size_t)pix[a][b] * dps) = v;
+                    }
+            }
+        }
+        if (!has_next) break;
+        cur = nxt;
+        ++k;
+        wn = work_index(k + 1);
+        setup(wn, nxt);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the out-of-range DMAs issued behind the last item
+}
+
+template <int ACT, int RES>
+int wn_launch_blk(const WinoK& k, int grid, hipStream_t st)
+{
+    if (k.y1_blk) hipLaunchKernelGGL((wino_f32_kernel<ACT, RES, true>), dim3(grid), dim3(WN_THREADS), 0, st, k);
+    else hipLaunchKernelGGL((wino_f32_kernel<ACT, RES, false>), dim3(grid), dim3(WN_THREADS), 0, st, k);
+    return esr_check_launch("wino_f32_kernel launch");
+}
+
+// G of F(2x2, 3x3)
+const double WN_G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+
+inline size_t wn_index(int nhalves, int slot, int pos, int o)
+{
+    const int chunk = slot / 8, within = slot % 8;
+    const int kq = within / 2, s = within % 2;
+    const int half = o / 32, ctl = (o % 32) / 16, i = o % 16;
+    return ((((size_t)chunk * nhalves + half) * 16 + pos) * 64 + kq * 16 + i) * 4 + ctl * 2 + s;
+}
+
+}  // namespace
+
+// Shapes the Winograd kernel takes (everything else stays on conv_f32_kernel): see esr_conv_desc.wino_wpacked.
+int esr_wino_supported(const esr_conv_desc* d)
+{
+    if (!d || d->ksize != 3 || d->in_layout != ESR_NHWC || d->out_layout != ESR_NHWC) return 0;
+    if (d->storage != ESR_STORE_F32 || d->compute != ESR_COMPUTE_F32) return 0;
+    if (d->tail_wpacked || d->post_wpacked || d->border_bias || d->in_seg_stride) return 0;
+    if (d->blocked8 & ESR_BLOCKED_IN) return 0;
+    if (d->cin <= 0 || d->cout <= 0 || d->cout > 64) return 0;
+    const int cin_phys = esr_round_up(d->cin, 8);
+    const int nchunks = cin_phys / 8;
+    if (nchunks < 4 || (nchunks & 1)) return 0;                  // raw ring looks 3 chunks ahead; stages are unrolled in pairs
+    const int cout4 = esr_round_up(d->cout, 4);
+    int split = d->split <= 0 ? cout4 : d->split;
+    if (split >= d->cout) split = cout4;
+    if (split < cout4 && (split & 15)) return 0;                 // a cout tile goes to ONE destination
+    return 1;
+}
+
+extern "C" {
+
+size_t esr_packed_wino_bytes(int cin_phys, int cout)
+{
+    if (cin_phys <= 0 || cout <= 0) return 0;
+    const size_t nchunks = (size_t)esr_round_up(cin_phys, 8) / 8;
+    const size_t nhalves = (size_t)esr_round_up(cout, 32) / 32;
+    return (nchunks * nhalves * 16 * 256 + nhalves * 32) * sizeof(float);
+}
+
+int esr_pack_wino_f32(const float* w, const float* bias, int cin, int cout, const int32_t* cin_map, int cin_phys, void* out, size_t out_bytes)
+{
+    if (!w || !out || cin <= 0 || cout <= 0) return ESR_ERR_BAD_ARG;
+    if (!cin_map && cin_phys < cin) return ESR_ERR_BAD_ARG;
+    const size_t need = esr_packed_wino_bytes(cin_phys, cout);
+    if (need == 0 || out_bytes < need) return ESR_ERR_BAD_ARG;
+    const int nhalves = esr_round_up(cout, 32) / 32;
+    float* o = static_cast<float*>(out);
+    memset(o, 0, need);
+    for (int s = 0; s < cin_phys; ++s) {
+        const int c = cin_map ? cin_map[s] : (s < cin ? s : -1);
+        if (c < 0) continue;
+        if (c >= cin) return ESR_ERR_BAD_ARG;
+        for (int oc = 0; oc < cout; ++oc) {
+            const float* g = w + ((size_t)oc * cin + c) * 9;
+            double t[4][3];                                        // G g
+            for (int i = 0; i < 4; ++i)
+                for (int b = 0; b < 3; ++b) t[i][b] = WN_G[i][0] * g[b] + WN_G[i][1] * g[3 + b] + WN_G[i][2] * g[6 + b];
+            for (int i = 0; i < 4; ++i)
+                for (int jj = 0; jj < 4; ++jj) {
+                    const double u = t[i][0] * WN_G[jj][0] + t[i][1] * WN_G[jj][1] + t[i][2] * WN_G[jj][2];
+                    o[wn_index(nhalves, s, 4 * i + jj, oc)] = (float)u;          // ONE rounding of the fp64 value
+                }
+        }
+    }
+    float* bo = o + (size_t)(esr_round_up(cin_phys, 8) / 8) * nhalves * 16 * 256;
+    if (bias)
+        for (int oc = 0; oc < cout; ++oc) bo[oc] = bias[oc];
+    return ESR_OK;
+}
+
+int esr_unpack_wino_f32(const void* packed, size_t bytes, int cin, int cout, const int32_t* cin_map, int cin_phys, float* u, float* bias)
+{
+    if (!packed || !u || cin <= 0 || cout <= 0) return ESR_ERR_BAD_ARG;
+    if (bytes < esr_packed_wino_bytes(cin_phys, cout)) return ESR_ERR_BAD_ARG;
+    const int nhalves = esr_round_up(cout, 32) / 32;
+    const float* o = static_cast<const float*>(packed);
+    memset(u, 0, sizeof(float) * (size_t)cout * cin * 16);
+    for (int s = 0; s < cin_phys; ++s) {
+        const int c = cin_map ? cin_map[s] : (s < cin ? s : -1);
+        if (c < 0) continue;
+        for (int oc = 0; oc < cout; ++oc)
+            for (int pos = 0; pos < 16; ++pos) u[((size_t)oc * cin + c) * 16 + pos] = o[wn_index(nhalves, s, pos, oc)];
+    }
+    if (bias) {
+        const float* bo = o + (size_t)(esr_round_up(cin_phys, 8) / 8) * nhalves * 16 * 256;
+        for (int oc = 0; oc < cout; ++oc) bias[oc] = bo[oc];
+    }
+    return ESR_OK;
+}
+
+}  // extern "C"
+
+// Called by esr_conv2d_f32 after its argument checks when d->wino_wpacked is set and esr_wino_supported(d).
+int esr_conv2d_wino(const esr_conv_desc* d, void* hip_stream)
+{
+    const int cin_phys = esr_round_up(d->cin, 8);
+    const int cout4 = esr_round_up(d->cout, 4);
+    int split = d->split <= 0 ? cout4 : d->split;
+    if (split >= d->cout) split = cout4;
+    WinoK k;
+    k.x = static_cast<const float*>(d->in.ptr);
+    k.up = static_cast<const float*>(d->wino_wpacked);
+    k.nchunks = cin_phys / 8;
+    k.nhalves = esr_round_up(d->cout, 32) / 32;
+    k.up_bytes = (unsigned)esr_packed_wino_bytes(cin_phys, d->cout);
+    k.bias = k.up + (size_t)k.nchunks * k.nhalves * 16 * 256;
+    k.res = static_cast<const float*>(d->res.ptr);
+    k.y0 = static_cast<float*>(d->out0.ptr);
+    k.y1 = static_cast<float*>(d->out1.ptr);
+    k.N = d->n; k.H = d->h; k.W = d->w;
+    k.in_pitch = d->in.pitch; k.in_coff = d->in.coff;
+    k.res_pitch = d->res.pitch; k.res_coff = d->res.coff;
+    k.y0_pitch = d->out0.pitch; k.y0_coff = d->out0.coff;
+    k.y1_pitch = d->out1.pitch; k.y1_coff = d->out1.coff;
+    k.cout_store = cout4;
+    k.split = split;
+    k.act = d->act; k.slope = d->slope; k.res_mode = d->res_mode;
+    k.tiles_x = (d->w + WN_TILE - 1) / WN_TILE;
+    k.tiles_y = (d->h + WN_TILE - 1) / WN_TILE;
+    k.y1_blk = (d->blocked8 & ESR_BLOCKED_OUT1) ? 1 : 0;
+    const long nwork = (long)k.N * k.tiles_x * k.tiles_y * k.nhalves;
+    const int grid = nwork < WN_MAX_BLOCKS ? (int)nwork : WN_MAX_BLOCKS;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (d->res_mode == ESR_RES_NONE) {
+        if (d->act == ESR_ACT_LRELU) return wn_launch_blk<ESR_ACT_LRELU, ESR_RES_NONE>(k, grid, st);
+        if (d->act == ESR_ACT_NONE) return wn_launch_blk<ESR_ACT_NONE, ESR_RES_NONE>(k, grid, st);
+        return wn_launch_blk<-1, ESR_RES_NONE>(k, grid, st);
+    }
+    if (d->res_mode == ESR_RES_PRE_ACT) return wn_launch_blk<-1, ESR_RES_PRE_ACT>(k, grid, st);
+    return wn_launch_blk<-1, ESR_RES_POST_ACT>(k, grid, st);
+}

@@ -51,6 +51,43 @@ def pack_conv(weight, bias, cin_map=None, cin_phys=None):
     return out
 
 
+def pack_wino(weight, bias, cin_map=None, cin_phys=None):
+    """OIHW fp32 3x3 weights + bias -> the Winograd F(2x2, 3x3) blob of esr_pack_wino_f32 (U = G g G^T, computed in fp64 and
+    rounded once, in wino_f32_kernel's A-operand order).  Host-side, no GPU needed."""
+    lib = L.lib()
+    w = weight.detach().to("cpu", torch.float32).contiguous()
+    cout, cin, k, k2 = w.shape
+    assert k == 3 and k2 == 3
+    b = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
+    if cin_map is not None:
+        cm = np.ascontiguousarray(np.asarray(cin_map, dtype=np.int32))
+        cin_phys, cm_p = len(cm), cm.ctypes.data_as(ctypes.c_void_p)
+    else:
+        cm_p = None
+        cin_phys = cin if cin_phys is None else cin_phys
+    nbytes = lib.esr_packed_wino_bytes(cin_phys, cout)
+    out = torch.empty(nbytes // 4, dtype=torch.float32)
+    L.check(lib.esr_pack_wino_f32(_ptr(w), _ptr(b) if b is not None else None, cin, cout, cm_p, cin_phys, _ptr(out), nbytes),
+            "esr_pack_wino_f32")
+    return out
+
+
+def unpack_wino(blob, cin, cout, cin_map=None, cin_phys=None):
+    """U [cout, cin, 16] and bias of a pack_wino blob (tests)."""
+    lib = L.lib()
+    blob = blob.detach().to("cpu", torch.float32).contiguous()
+    if cin_map is not None:
+        cm = np.ascontiguousarray(np.asarray(cin_map, dtype=np.int32))
+        cin_phys, cm_p = len(cm), cm.ctypes.data_as(ctypes.c_void_p)
+    else:
+        cm_p = None
+        cin_phys = cin if cin_phys is None else cin_phys
+    u = torch.empty(cout, cin, 16)
+    b = torch.empty(cout)
+    L.check(lib.esr_unpack_wino_f32(_ptr(blob), blob.numel() * 4, cin, cout, cm_p, cin_phys, _ptr(u), _ptr(b)), "esr_unpack_wino_f32")
+    return u, b
+
+
 def pack_conv_s16(weight, bias, compute, cin_map=None, cin_phys=None):
     """OIHW (or [out,in]) fp32 weights -> the 16-bit-storage blob of esr_pack_conv_s16 (bf16 or fp16; 3x3 taps rounded
     with error diffusion, 1x1 as hi + lo) + fp32 bias."""
@@ -410,6 +447,9 @@ class Plan:
                 d.compute = st
             else:
                 d.wpacked = ctypes.c_void_p(weights[o["w"]].data_ptr())
+                wn = weights.get(o["w"] + "#wino") if o["kind"] == "conv" else None
+                if wn is not None and o.get("tail") is None and o.get("post") is None and L.lib().esr_wino_supported(ctypes.byref(d)):
+                    d.wino_wpacked = ctypes.c_void_p(wn.data_ptr())      # Winograd F(2x2, 3x3): wino_f32_kernel
             if o.get("border") is not None:
                 d.border_bias = ctypes.c_void_p(weights[o["border"]].data_ptr())
             t = o.get("tail")
@@ -495,6 +535,7 @@ class HipSRModel(nn.Module):
         self._dirty = True         # parameters may have changed since the last repack (load_state_dict / .to() / repack())
         self._ctxs = {}            # (device, HIP stream handle) -> _StreamCtx: workspace + plans of the forwards enqueued on that stream
         self.compute = "f32"       # "f32" | "bf16" | "f16": MFMA operand format of the full-resolution 3x3 convs
+        self.winograd = True       # fp32 plans: 3x3 convs whose shape qualifies run as Winograd F(2x2, 3x3) (esr_conv_desc.wino_wpacked)
         self._prof_passes = 0      # >0: record HIP events around every op (bench roofline leg)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
 
@@ -643,6 +684,8 @@ class HipSRModel(nn.Module):
         for path, (cin, cout, k, cin_map) in self._conv_specs.items():
             leaf = self._leaf(path)
             packed[path] = pack_conv(leaf.weight, leaf.bias, cin_map=self._cin_map(path, cin_map, "f32")).to(device)
+            if k == 3 and self.winograd and self._store() == "f32" and cin >= 32 and cout <= 64:
+                packed[path + "#wino"] = pack_wino(leaf.weight, leaf.bias, cin_map=self._cin_map(path, cin_map, "f32")).to(device)
             if path in s16:
                 packed[path + "#s16"] = pack_conv_s16(leaf.weight, leaf.bias, self._store(),
                                                       cin_map=self._cin_map(path, cin_map, self._store())).to(device)

@@ -1,6 +1,6 @@
 """Host-side image conversion and metric helpers around the forward path.
 
-Restates the six `utils/utils_image.py` functions `test_demo.run()` calls
+Restates the `utils/utils_image.py` functions `test_demo.run()` calls (mkdir :73-83)
 with PIL instead of cv2 (PNG/BMP decoding is lossless, so the arrays are identical):
   imread_uint :122-134   imsave :137-141   uint2tensor4 :190-193
   tensor2uint :204-208   modcrop :442-455  calculate_psnr :490-503   calculate_ssim / ssim :509-554
@@ -14,6 +14,20 @@ import os
 import numpy as np
 import torch
 from PIL import Image
+
+
+def mkdir(path):
+    """utils_image.mkdir (utils/utils_image.py:73-75; run() calls it on the save path, test_demo.py:411)."""
+    os.makedirs(path, exist_ok=True)
+
+
+def mkdirs(paths):
+    """utils_image.mkdirs (utils/utils_image.py:78-83): one path or an iterable of paths."""
+    if isinstance(paths, str):
+        mkdir(paths)
+    else:
+        for path in paths:
+            mkdir(path)
 
 
 def imread_uint(path, n_channels=3):

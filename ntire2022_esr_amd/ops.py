@@ -6,7 +6,7 @@ import ctypes
 import torch
 
 from . import _lib as L
-from .engine import pack_conv, pack_conv_s16, pack_post_s16
+from .engine import pack_conv, pack_conv_s16, pack_post_s16, pack_wino
 
 
 def _view(t, coff=0):
@@ -22,7 +22,7 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
            split=0, out1=None, out1_coff=0, res_coff=0, packed=None, cin_map=None, store=None,
            tail_weight=None, tail_bias=None, tail_cat=None, tail_cat_coff=0, tail_mid_act=L.ACT_NONE,
            post_weight=None, post_bias=None, post_act=L.ACT_NONE, post2_weight=None, post2_bias=None, store_main=True,
-           border=None, blocked_in=False, blocked_out1=False):
+           border=None, blocked_in=False, blocked_out1=False, wino=False):
     """Fused conv (k=1|3, stride 1, same padding) on the current stream.
 
     x       NHWC [N,H,W,pitch] (channels [in_coff, in_coff+cin) are read) or NCHW fp32 if in_nchw.  The dtype of an NHWC
@@ -35,6 +35,7 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
             on the first (returns (y, post, post2)); store_main=False does not store y (returns None in its place)
     border  esr_conv_desc.border_bias: fp32 [16, round_up(cout, 16)] table added by outside-mask (16-bit storage only)
     blocked_in / blocked_out1   esr_conv_desc.blocked8: x / out1 is a channel-blocked fp32 tensor [N, C/8, H, W, 8]
+    wino    fp32 3x3: also pass Winograd F(2x2, 3x3) weights (esr_conv_desc.wino_wpacked); raises if the shape does not qualify
     tail_*  fused 1x1 (esr_conv_desc.tail_*): tail_weight [cout1, cat_c + 16(, 1, 1)] over concat(tail_cat slice,
             mid_act(this 3x3 conv)); act / res / out then apply to the 1x1, whose output is returned
     """
@@ -118,6 +119,11 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
     if res is not None:
         d.res = _view(res, res_coff)
     d.wpacked = ctypes.c_void_p(packed.data_ptr())
+    if wino:
+        keepw = pack_wino(w4, bias, cin_map=cin_map).to(x.device)
+        if not lib.esr_wino_supported(ctypes.byref(d)):
+            raise L.EsrError("conv2d: this descriptor does not qualify for the Winograd kernel (esr_wino_supported)")
+        d.wino_wpacked = ctypes.c_void_p(keepw.data_ptr())
     yp = yp2 = None
     if post_weight is not None:
         pw = post_weight if post_weight.dim() == 4 else post_weight[:, :, None, None]

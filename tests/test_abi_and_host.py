@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libesr_hip.so does not export {s}"
     assert set(L.EXPORTS) == set(syms), (set(L.EXPORTS) ^ set(syms))
-    assert lib.esr_abi_version() == 6
+    assert lib.esr_abi_version() == 7
     # the ctypes mirrors of the ABI structs have the library's sizes (also checked by _lib.lib() at load time)
     for which, st in enumerate((L.View, L.ConvDesc, L.EsaDesc, L.BsDesc, L.CaDesc, L.Op)):
         assert lib.esr_sizeof(which) == ctypes.sizeof(st) > 0, st.__name__
@@ -273,3 +273,27 @@ def test_block_shape_query_cpu():
     assert waves(32, 256, 256, 48, 48, store="bf16", res_mode=L.RES_POST_ACT) == 8          # residual from HBM
     assert waves(32, 256, 256, 48, 48, store="bf16", out_layout=L.NCHW_SHUFFLE4) == 8
     assert lib.esr_conv_block_waves(None) == 0
+
+
+def test_wino_packer_is_G_g_Gt_rounded_once():
+    """esr_pack_wino_f32 (host C++): U = G g G^T in fp64, one rounding; lane order round-trips; pad slots are zero
+    (Lavin & Gray F(2x2,3x3); replaces the OIHW weights of basicblock.conv, models/basicblock.py:61-65)."""
+    import torch
+    from ntire2022_esr_amd import engine
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(50, 40, 3, 3, generator=g)
+    b = torch.randn(50, generator=g)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    U = torch.einsum('ia,ocab,jb->ocij', G, w.double(), G).float().reshape(50, 40, 16)
+    blob = engine.pack_wino(w, b)
+    u, bb = engine.unpack_wino(blob, 40, 50)
+    assert torch.equal(u, U) and torch.equal(bb, b)
+    # padded concat map: physical slots 10, 11, 22, 23 are padding
+    cmap = list(range(10)) + [-1, -1] + list(range(10, 20)) + [-1, -1]
+    w2 = torch.randn(32, 20, 3, 3, generator=g)
+    blob2 = engine.pack_wino(w2, None, cin_map=cmap)
+    u2, b2 = engine.unpack_wino(blob2, 20, 32, cin_map=cmap)
+    U2 = torch.einsum('ia,ocab,jb->ocij', G, w2.double(), G).float().reshape(32, 20, 16)
+    assert torch.equal(u2, U2) and float(b2.abs().max()) == 0.0
+    # everything that is not a (slot, cout) of the logical tensor is zero: total mass matches
+    assert abs(float(blob2.double().abs().sum()) - float(U2.double().abs().sum())) < 1e-6 * float(U2.double().abs().sum())

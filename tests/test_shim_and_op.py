@@ -86,3 +86,105 @@ def test_forward_is_a_registered_custom_op_with_fake_impl():
     r = RFDN()
     with FakeTensorMode():
         assert tuple(r(torch.empty(1, 3, 33, 21)).shape) == (1, 3, 132, 84)
+
+
+REF_DEMO = "/root/reference/test_demo.py"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DEMO), reason="authoring container only: parses the reference's test_demo.py")
+def test_every_name_test_demo_uses_resolves_in_the_shim():
+    """ast-parse the reference's test_demo.py (never imported, never copied): every `util.<name>` / `utils_logger.<name>`
+    attribute it touches, every name it imports from utils.model_summary, and the `from models... import ...` lines of ids
+    -1 / 0 / 4 / 18 (+ riders 6, 8, 22, 26, 40) must resolve in shim/ with a compatible call signature
+    (test_demo.py:8-10, 17-30, 52-58, 150-157, 411-465)."""
+    import ast
+    import inspect
+    tree = ast.parse(open(REF_DEMO).read())
+    aliases = {}                                         # local alias -> shim module
+    from_summary = []
+    for node in ast.walk(tree):
+        if isinstance(node, ast.ImportFrom) and node.module == "utils":
+            for a in node.names:
+                aliases[a.asname or a.name] = "utils." + a.name
+        if isinstance(node, ast.ImportFrom) and node.module == "utils.model_summary":
+            from_summary += [a.name for a in node.names]
+    assert aliases == {"utils_logger": "utils.utils_logger", "util": "utils.utils_image"}, aliases
+    used = {}                                            # (alias, attr) -> list of ast.Call (for the signature check)
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Attribute) and isinstance(node.value, ast.Name) and node.value.id in aliases:
+            used.setdefault((node.value.id, node.attr), [])
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and isinstance(node.func.value, ast.Name) \
+                and node.func.value.id in aliases:
+            used.setdefault((node.func.value.id, node.func.attr), []).append(node)
+    assert ("util", "mkdir") in used and ("util", "imsave") in used and ("utils_logger", "logger_info") in used
+    # registry entries this engine implements: model_id -> (module, class) from the select_model body
+    sel = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "select_model")
+    model_imports = {}
+    for node in ast.walk(sel):
+        if isinstance(node, ast.If) and isinstance(node.test, ast.Compare) and isinstance(node.test.left, ast.Name) \
+                and node.test.left.id == "model_id" and isinstance(node.test.comparators[0], (ast.Constant, ast.UnaryOp)):
+            mid = ast.literal_eval(node.test.comparators[0])
+            for st in node.body:
+                if isinstance(st, ast.ImportFrom):
+                    model_imports[mid] = (st.module, [a.name for a in st.names])
+    want_ids = [-1, 0, 4, 18, 6, 8, 22, 26, 40]
+    assert all(i in model_imports for i in want_ids), sorted(model_imports)
+    code = ["import importlib, inspect, json", "out = {}"]
+    for (alias, attr), calls in sorted(used.items()):
+        code.append(f"f = getattr(importlib.import_module({aliases[alias]!r}), {attr!r}); out[{alias + '.' + attr!r}] = str(inspect.signature(f))")
+    for name in from_summary:
+        code.append(f"f = getattr(importlib.import_module('utils.model_summary'), {name!r}); out['summary.{name}'] = str(inspect.signature(f))")
+    for mid in want_ids:
+        mod, names = model_imports[mid]
+        for nm in names:
+            code.append(f"getattr(importlib.import_module({mod!r}), {nm!r}); out['id{mid}'] = {mod + '.' + nm!r}")
+    code.append("print(json.dumps(out))")
+    got = json.loads(_run_in_shim("\n".join(code)).strip().splitlines()[-1])
+    # every call site binds to the shim function's signature (positional count + keyword names)
+    sys.path.insert(0, SHIM)
+    try:
+        for (alias, attr), calls in used.items():
+            mod = importlib.import_module(aliases[alias])
+            sig = inspect.signature(getattr(mod, attr))
+            for c in calls:
+                sig.bind(*[None] * len(c.args), **{k.arg: None for k in c.keywords})
+    finally:
+        sys.path.remove(SHIM)
+        for m in [m for m in sys.modules if m == "utils" or m.startswith("utils.")]:
+            del sys.modules[m]
+    assert len(got) >= len(used) + len(from_summary) + len(want_ids)
+
+
+def test_run_body_against_the_shim_with_a_stub_model(tmp_path):
+    """The sequence of helper calls of the reference's run() (test_demo.py:411-465), executed against shim/utils with a stub
+    model on the CPU: mkdir -> imread_uint -> uint2tensor4 -> forward -> tensor2uint -> modcrop -> calculate_psnr -> imsave."""
+    code = r'''
+import os, sys, numpy as np, torch
+from utils import utils_image as util
+from utils import utils_logger
+import logging
+d = sys.argv[1]
+save_path = os.path.join(d, "out", "stub", "valid")
+util.mkdir(save_path)                                            # test_demo.py:411
+util.mkdir(save_path)                                            # idempotent
+util.mkdirs([os.path.join(d, "a"), os.path.join(d, "b")])
+rng = np.random.RandomState(0)
+hr = rng.randint(0, 256, (40, 48, 3)).astype(np.uint8)
+lr = hr[::4, ::4].copy()
+util.imsave(hr, os.path.join(d, "0801.png")); util.imsave(lr, os.path.join(d, "0801x4.png"))
+utils_logger.logger_info("stub", log_path=os.path.join(d, "log.txt"))
+logger = logging.getLogger("stub")
+img_lr = util.uint2tensor4(util.imread_uint(os.path.join(d, "0801x4.png"), n_channels=3), 1.0)
+img_sr = torch.nn.functional.interpolate(img_lr, scale_factor=4, mode="nearest")     # the stub "model"
+img_sr = util.tensor2uint(img_sr, 1.0)
+img_hr = util.modcrop(util.imread_uint(os.path.join(d, "0801.png"), n_channels=3).squeeze(), 4)
+psnr = util.calculate_psnr(img_sr, img_hr, border=4)
+logger.info("{:s} - PSNR: {:.2f} dB".format("0801.png", psnr))
+util.imsave(img_sr, os.path.join(save_path, "0801.png"))
+assert os.path.exists(os.path.join(save_path, "0801.png")) and os.path.isdir(os.path.join(d, "b"))
+print("ok", round(psnr, 2))
+'''
+    env = dict(os.environ, PYTHONPATH=SHIM + os.pathsep + REPO)
+    out = subprocess.run([sys.executable, "-c", code, str(tmp_path)], capture_output=True, text=True, env=env, cwd=SHIM, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.stdout.strip().splitlines()[-1].startswith("ok ")

@@ -28,7 +28,7 @@ WAIT = ("            wait_vm_dyn((R - 2) * n_my + epi_stores * __builtin_popcoun
 DMA = ("            dma_buf16(ring_lds + (unsigned)(lslot * STAGE_BYTES) + (unsigned)pc * 1024u, lvoff[i], lrsrc, (unsigned)lc * 32u);", "            ;")
 SUBS = {
     "prod": [],
-    "nw16": [],      # built with -DESR_S16_NW=16: 16 waves per tile, 2 rows each
+    "nw16": [("constexpr int S16_NW = 8;", "constexpr int S16_NW = 16;")],      # 16 waves per tile, 2 rows each
     "nomfma": MF,                                   # the memory pipeline alone (DMA issue, waits, epilogue stores)
     "nowait": [WAIT],                               # no vmcnt wait before the stage barrier (results wrong)
     "nodma": [DMA, WAIT],                           # LDS reads + MFMA + epilogue only (results wrong)
@@ -40,7 +40,7 @@ SUBS = {
 
 def build(only=None):
     base = open(os.path.join(SRC, "esr_s16.hip")).read()
-    others = [os.path.join(SRC, f) for f in ("esr_hip.hip", "esr_esa.hip", "esr_bsconv.hip")]
+    others = [os.path.join(SRC, f) for f in sorted(os.listdir(SRC)) if f.endswith(".hip") and f != "esr_s16.hip"]
     objs = []
     for f in others:                                   # compiled once
         o = os.path.join(HERE, "obj_" + os.path.basename(f).replace(".hip", "") + ".o")
@@ -62,7 +62,7 @@ def build(only=None):
         open(src, "w").write(s)
         vo = os.path.join(HERE, f"obj_s16_{name}.o")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-I", os.path.join(REPO, "include"),
-                               "-I", SRC, src, "-o", vo] + (["-DESR_S16_NW=16"] if "nw16" in name else []))
+                               "-I", SRC, src, "-o", vo])
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", vo] + objs +
                               ["-o", os.path.join(HERE, f"libesr_{name}.so")])
         os.remove(src)

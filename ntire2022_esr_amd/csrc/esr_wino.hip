@@ -7,23 +7,29 @@
 // i.e. 2.25x fewer MFMAs than the direct form, fp32 throughout (rounding ~1e-6 relative: tools/wino/wino_numerics.py).
 //
 //   work item   one 16x16-pixel tile (8x8 Winograd tiles) x 32 output channels (a "cout half")
-//   block       4 waves, TWO blocks per CU (68 KB LDS each, <= 256 registers per wave): the blocks drift apart, one block's
+//   block       4 waves, TWO blocks per CU (81 376 B of LDS each, <= 256 registers per wave): the blocks drift apart, one block's
 //               epilogue / barrier stalls run under the other's MFMAs
 //   wave w      Winograd tile rows 2w, 2w+1 (16 tiles = the N side of the MFMA) x 2 cout tiles x ALL 16 positions:
 //               128 accumulator registers; the output transform is register-local
 //   MFMA        A = U = G g G^T (lane (i, k): cout i of the tile, cin 2k+s of the chunk), B = V = B^T d B (lane (j, k): Winograd
 //               tile j, cin 2k+s), D[cout][tile]: lane (j, g) holds couts 4g..4g+3 of tile j
-//   K loop      cin in chunks of 8.  Per chunk the block stages, global -> LDS by DMA (buffer_load ... lds):
-//                 U chunk    16 KB  [pos][lane][ct0 s0, ct0 s1, ct1 s0, ct1 s1]   ring of 2 (always an L2 hit)
-//                 raw halo   18x18 pixels x 32 B = 10.4 KB, [half][row pair][37 slots of 16 B]   ring of 3
+//   K loop      cin in chunks of 8.  Per chunk the block stages, global -> LDS by DMA (buffer_load ... lds), rings of 3:
+//                 U chunk    16 KB  [pos][lane][ct0 s0, ct0 s1, ct1 s0, ct1 s1]   (always an L2 hit)
+//                 raw halo   18x18 pixels x 32 B = 10.4 KB, [half][row pair][37 slots of 16 B]
 //               V NEVER touches LDS: lane (j, k) reads the 4x4 patch of ITS tile and ITS channel pair from the raw stage
 //               (16 ds_read_b64), transforms it (32 v_pk_add_f32) and holds the 16 positions in registers as the B operands of
-//               the NEXT chunk while the current chunk's 64 MFMAs run.  One s_barrier per chunk (stage hand-over).
+//               the NEXT chunk while the current chunk's 64 MFMAs run.
+//   stage       16 positions x 4 MFMAs; everything else rides between them: A fragments two positions ahead, the transform in
+//               positions 0..8, the raw DMA (chunk +3) at positions 2 / 4 / 6, the ONE barrier of the stage at position 12
+//               (hand-over of U +1 and raw +2), behind it the U DMA (chunk +2) and the first A fragments of the next stage --
+//               no bubble at the stage boundary.  One M0 write serves all pieces of a DMA group (the instruction's immediate
+//               offset moves the LDS destination AND the global address: tools/wino/m0_offset_probe.hip).
 //   LDS reads   per wave and chunk: 16 ds_read_b128 (A) + 16 ds_read_b64 (raw) for 64 MFMAs
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#include <type_traits>
 
 #include "esr_hip.h"
 #include "esr_internal.h"
@@ -38,16 +44,20 @@ constexpr int WN_THREADS = 256;
 constexpr int WN_TILE = 16;                 // output pixels per tile edge
 constexpr int WN_HALO = WN_TILE + 2;
 constexpr int WN_PAIR = 37;                 // 16-byte slots per pair of halo rows: 18 + 18 + 1 pad (see wn_slot)
-constexpr int WN_PLANE = 352;               // slots per channel-half plane: 9 row pairs x 37 = 333 used, padded to 5.5 DMA pieces
-constexpr int WN_RAW_PIECES = 12;           // 64 x 16 B pieces reserved per raw stage: 11 carry data, every wave issues 3
-constexpr int WN_RAW_BYTES = WN_RAW_PIECES * 1024;
+constexpr int WN_PLANE = 9 * WN_PAIR;       // 333 slots per channel-half plane
+constexpr int WN_RAW_SLOTS = 2 * WN_PLANE;  // 666 = 10 full DMA pieces + one of 26 lanes
+constexpr int WN_LAST_LANES = WN_RAW_SLOTS - 640;
+constexpr int WN_RAW_BYTES = WN_RAW_SLOTS * 16;
 constexpr int WN_U_BYTES = 16 * 1024;
-constexpr int WN_RAW_RING = 3, WN_U_RING = 2;
-constexpr int WN_RAW_OFF = WN_U_RING * WN_U_BYTES;
-constexpr int WN_BIAS_OFF = WN_RAW_OFF + WN_RAW_RING * WN_RAW_BYTES;
-constexpr int WN_LDS = WN_BIAS_OFF + 256;                            // 69 888 B
+constexpr int WN_RING = 3;                  // both rings
+constexpr int WN_RAW_OFF = WN_RING * WN_U_BYTES;
+constexpr int WN_BIAS_OFF = WN_RAW_OFF + WN_RING * WN_RAW_BYTES;
+constexpr int WN_LDS = WN_BIAS_OFF + 256;                            // 81 376 B: two blocks per CU (163 840 B)
+static_assert(2 * WN_LDS <= 160 * 1024, "two blocks per CU");
 constexpr int WN_MAX_BLOCKS = 512;          // 256 CUs x 2
 constexpr unsigned WN_OOB = 0x80000000u;
+constexpr int WN_BARRIER_POS = 12;
+constexpr int WN_FIRST_SHARE = 9;           // 9/16 of the items to the first-dispatched half of the grid
 
 struct WinoK {
     const float* x;
@@ -67,30 +77,33 @@ struct WinoK {
     float slope;
     int res_mode;
     int tiles_x, tiles_y;
+    unsigned magic_x, magic_y;   // floor(2^32 / d) + 1 (0 for d == 1): n / d == umulhi(n, magic) for n * d < 2^32 (host-checked)
     int y1_blk;
+    int first_share;             // 1/16ths of the items the first-dispatched half of the blocks takes (8 = even split)
 };
+
+__device__ __forceinline__ unsigned wn_div(unsigned n, unsigned d, unsigned magic) { return d == 1 ? n : __umulhi(n, magic); }
 
 __device__ __forceinline__ wn_i32x4 wn_rsrc(const void* base, size_t bytes)
 {
     wn_i32x4 r;
-    r.x = (int)(size_t)base;
-    r.y = (int)(((size_t)base >> 32) & 0xffff);
-    r.z = (int)bytes;
+    r.x = __builtin_amdgcn_readfirstlane((int)(size_t)base);
+    r.y = __builtin_amdgcn_readfirstlane((int)(((size_t)base >> 32) & 0xffff));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
     r.w = 0x00020000;
     return r;
 }
 
-// 64 lanes x 16 bytes, global -> LDS (lds_dst + 16 * lane); an out-of-range voff writes zeros.  Inline asm: hipcc cannot see which
-// LDS bytes a DMA touches and would put vmcnt(0) in front of later ds_reads; the stage loop counts instead.
-__device__ __forceinline__ void wn_dma16(unsigned lds_dst, unsigned voff, wn_i32x4 rsrc, unsigned soff)
+// 64 lanes x 16 bytes, global -> LDS: lane l's 16 bytes land at m0 + OFF + 16 l, read from rsrc + soff + voff + OFF (the immediate
+// offset moves BOTH addresses: tools/wino/m0_offset_probe.hip); an out-of-range voff writes zeros.  Inline asm: hipcc cannot see
+// which LDS bytes a DMA touches and would put vmcnt(0) in front of later ds_reads; the stage loop counts instead.  M0 is bound
+// through the "{m0}" constraint: hipcc writes it once per run of pieces that share a base.  s_nop: the wait state between an M0
+// write and its LDS-DMA use.
+template <int OFF>
+__device__ __forceinline__ void wn_dma16(unsigned m0_base, unsigned voff, wn_i32x4 rsrc, unsigned soff)
 {
-    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
-    soff = __builtin_amdgcn_readfirstlane(soff);
-    rsrc.x = __builtin_amdgcn_readfirstlane(rsrc.x); rsrc.y = __builtin_amdgcn_readfirstlane(rsrc.y);
-    rsrc.z = __builtin_amdgcn_readfirstlane(rsrc.z); rsrc.w = __builtin_amdgcn_readfirstlane(rsrc.w);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds"
+                 :: "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF), "{m0}"(m0_base) : "memory");
 }
 
 __device__ __forceinline__ float wn_act1(float v, int act, float slope)
@@ -123,6 +136,18 @@ __device__ __forceinline__ f32x4 wn_act4(f32x4 v, int act, float slope)
 // all 64 banks once.
 __device__ __forceinline__ int wn_slot(int ly, int lx) { return (ly >> 1) * WN_PAIR + (ly & 1) * WN_HALO + lx; }
 
+// one ds_read_b64 from an LDS byte address.  Volatile (on an explicit LDS pointer: a volatile generic pointer becomes a flat load)
+// so that hipcc does not fuse two of them into ds_read2_b64 -- half the rate, and 32 banks instead of 64 (MI355X_MICROARCH.md, LDS)
+__device__ __forceinline__ f32x2 wn_lds_b64(unsigned addr)
+{
+    typedef const volatile __attribute__((address_space(3))) f32x2* lds_ptr;
+    return *(lds_ptr)addr;
+}
+
+// keeps a value's computation where it is written: without it hipcc sinks the whole input transform (it is only consumed by the
+// NEXT stage's MFMAs) out of this stage's MFMA stream into the top of the next stage
+#define WN_PIN(x) asm volatile("" : "+v"(x))
+
 template <int ACT, int RES, bool Y1BLK>
 __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
 {
@@ -135,18 +160,32 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
     const int tx = j & 7, ty = j >> 3;
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
-    // ---- work walk: item = (tile, cout half); XCD x (blocks b % 8 == x) takes a contiguous run, the halves of a tile are neighbours
+    // ---- work walk: item = (tile, cout half); within a pass XCD x (blocks b % 8 == x) takes a contiguous run and the two halves of a
+    // tile go to neighbouring blocks.  The two blocks of a CU do not share the MFMA pipe evenly: the older wave of a SIMD is served
+    // first and gets through an item ~25 % sooner (tools/wino/abl.py probe: 4.6 k against 5.8 k cycles per stage), and the hardware
+    // places blocks 0 .. G/2-1 first, so they are the older ones.  With an even split the younger block of every CU runs alone at the
+    // end; the first half of the grid therefore takes first_share/16 of the items.  Speed only: any map is correct.
     const int nwork = p.N * p.tiles_y * p.tiles_x * p.nhalves;
     const int G = gridDim.x;
+    const bool classes = p.first_share != 8 && (G & 15) == 0;
+    const int GC = classes ? G >> 1 : G;                                   // blocks per class
+    const bool second = classes && (int)blockIdx.x >= GC;
+    const int n_first = classes ? (int)(((long)nwork * p.first_share / 16) & ~1L) : nwork;
+    const int cbase = second ? n_first : 0, cend = second || !classes ? nwork : n_first;
+    const int bl = second ? (int)blockIdx.x - GC : (int)blockIdx.x;
     auto work_index = [&](int k) -> int {
-        const int base = k * G;
-        if (base >= nwork) return -1;
-        int off = blockIdx.x;
-        if ((G & 7) == 0 && base + G <= nwork) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+        const int base = cbase + k * GC;
+        if (base >= cend) return -1;
+        int off = bl;
+        if ((GC & 7) == 0 && base + GC <= cend) off = (bl & 7) * (GC >> 3) + (bl >> 3);
         const int t = base + off;
-        return t < nwork ? t : -1;
+        return t < cend ? t : -1;
     };
 
+    // A wave issues 3 raw pieces per stage: slots (3 wv + i) * 64 + lane of the stage image.  Pieces 0 and 1 share one M0 (piece 1
+    // through the immediate offset 1024, so its per-lane offset is stored 1024 lower); piece 2 has its own M0.  Wave 3's piece 1 is
+    // the partial one (26 lanes: the others stay off, they would write into the neighbouring stage), its piece 2 does not exist:
+    // it repeats piece 0 (same bytes to the same place) so that every wave issues the same number of instructions.
     struct Ctx { int n, x0, y0, half; unsigned voff[3]; };
     auto setup = [&](int work, Ctx& c) {
         if (work < 0) {                              // behind the last item: the DMAs still issue (uniform counts), all lanes out of range
@@ -154,46 +193,52 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
             c.voff[0] = c.voff[1] = c.voff[2] = WN_OOB;
             return;
         }
-        const int t = work / p.nhalves;
-        c.half = work - t * p.nhalves;
-        const int txi = t % p.tiles_x;
-        const int tq = t / p.tiles_x;
-        const int tyi = tq % p.tiles_y;
-        c.n = tq / p.tiles_y;
-        c.x0 = txi * WN_TILE;
-        c.y0 = tyi * WN_TILE;
+        const unsigned t = p.nhalves == 2 ? (unsigned)work >> 1 : (unsigned)work;
+        c.half = p.nhalves == 2 ? work & 1 : 0;
+        const unsigned tq = wn_div(t, (unsigned)p.tiles_x, p.magic_x);
+        const unsigned txi = t - tq * p.tiles_x;
+        c.n = (int)wn_div(tq, (unsigned)p.tiles_y, p.magic_y);
+        const unsigned tyi = tq - (unsigned)c.n * p.tiles_y;
+        c.x0 = (int)txi * WN_TILE;
+        c.y0 = (int)tyi * WN_TILE;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int item = (wv * 3 + i) * 64 + lane;
+            const int item = (wv * 3 + (wv == 3 && i == 2 ? 0 : i)) * 64 + lane;
             const int half = item >= WN_PLANE ? 1 : 0;
             const int slot = item - half * WN_PLANE;
             const int pr = slot / WN_PAIR, rem = slot - pr * WN_PAIR;
             const int odd = rem >= WN_HALO ? 1 : 0;
             const int ly = 2 * pr + odd, lx = rem - odd * WN_HALO;
             const int gy = c.y0 - 1 + ly, gx = c.x0 - 1 + lx;
-            const bool ok = item < 2 * WN_PLANE && pr < WN_HALO / 2 && rem < 2 * WN_HALO && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            c.voff[i] = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff + 4 * half) * 4u : WN_OOB;
+            const bool ok = item < WN_RAW_SLOTS && rem < 2 * WN_HALO && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            c.voff[i] = (ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff + 4 * half) * 4u : WN_OOB) - (i == 1 ? 1024u : 0u);
         }
     };
     const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 4;
     const wn_i32x4 ursrc = wn_rsrc(p.up, p.up_bytes);
+    const bool live1 = wv != 3 || lane < WN_LAST_LANES;
+    const unsigned raw_m0 = smem_lds + (unsigned)(WN_RAW_OFF + wv * 3 * 1024);            // + ring slot * WN_RAW_BYTES
+    const unsigned raw_m0_2 = raw_m0 + (wv == 3 ? 0u : 2048u);
+    const unsigned u_m0 = smem_lds + (unsigned)(wv * 4 * 1024);                             // + ring slot * WN_U_BYTES
 
-    // raw halo of chunk `chunk` of item `c` -> raw ring slot `rs`
-    auto issue_raw = [&](int rs, const Ctx& c, int chunk) __attribute__((always_inline)) {
-        const wn_i32x4 xr = wn_rsrc(p.x + (size_t)c.n * (img_bytes / 4), img_bytes);
-        const unsigned base = smem_lds + (unsigned)(WN_RAW_OFF + rs * WN_RAW_BYTES + wv * 3 * 1024);
+    // piece i of the raw halo of chunk `chunk` of an item (image rsrc xr, per-lane offset v) -> raw ring slot `rs`
+    auto issue_raw = [&](int i, int rs, wn_i32x4 xr, int chunk, unsigned v) __attribute__((always_inline)) {
         const unsigned soff = (unsigned)chunk * 32u;
-        wn_dma16(base, c.voff[0], xr, soff);
-        wn_dma16(base + 1024u, c.voff[1], xr, soff);
-        wn_dma16(base + 2048u, c.voff[2], xr, soff);
+        const unsigned ro = (unsigned)(rs * WN_RAW_BYTES);
+        if (i == 0) wn_dma16<0>(raw_m0 + ro, v, xr, soff);
+        else if (i == 1) { if (live1) wn_dma16<1024>(raw_m0 + ro, v, xr, soff); }
+        else wn_dma16<0>(raw_m0_2 + ro, v, xr, soff);
     };
-    // U chunk -> U ring slot `us`; live = false: out of range (zeros into a slot nobody reads)
-    auto issue_u = [&](int us, const Ctx& c, int chunk, bool live) __attribute__((always_inline)) {
-        const unsigned base = smem_lds + (unsigned)(us * WN_U_BYTES + wv * 4 * 1024);
-        const unsigned soff = (unsigned)((chunk * p.nhalves + c.half) * WN_U_BYTES + wv * 4 * 1024);
+    auto image_rsrc = [&](int n) { return wn_rsrc(p.x + (size_t)n * (img_bytes / 4), img_bytes); };
+    // piece i of the U chunk of cout half `half` -> U ring slot `us`; live = false: out of range (zeros into a slot nobody reads)
+    auto issue_u = [&](int i, int us, int half, int chunk, bool live) __attribute__((always_inline)) {
+        const unsigned soff = (unsigned)((chunk * p.nhalves + half) * WN_U_BYTES + wv * 4 * 1024);
         const unsigned vo = live ? (unsigned)lane * 16u : WN_OOB;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wn_dma16(base + i * 1024u, vo, ursrc, soff + i * 1024u);
+        const unsigned m = u_m0 + (unsigned)(us * WN_U_BYTES);
+        if (i == 0) wn_dma16<0>(m, vo, ursrc, soff);
+        else if (i == 1) wn_dma16<1024>(m, vo, ursrc, soff);
+        else if (i == 2) wn_dma16<2048>(m, vo, ursrc, soff);
+        else wn_dma16<3072>(m, vo, ursrc, soff);
     };
 
     // lane-constant LDS byte offsets
@@ -201,11 +246,13 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
     const int u_lane = lane * 16;
 
     // ---- input transform of one (tile, channel pair): V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-    // row pass (needs one patch row): w[r][.] = d[r][.] B;   column pass: V[.][c] = B^T w[.][c];   position = 4 * row + column
-    auto raw_row = [&](const char* rs, int r, f32x2 (&d)[4]) __attribute__((always_inline)) {
+    // row pass (needs one patch row): w[r][.] = d[r][.] B;   column pass: V[.][c] = B^T w[.][c];   position = 4 * row + column.
+    // The patch reads stay single ds_read_b64 (wn_lds_b64: two 32-lane groups, 64 banks -- conflict-free for this layout); fused
+    // into ds_read2_b64 they ran at half the rate on 32 banks (PMC: a third of all LDS cycles were bank conflicts).
+    auto raw_row = [&](unsigned rs, int r, f32x2 (&d)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int dx = 0; dx < 4; ++dx)
-            d[dx] = *reinterpret_cast<const f32x2*>(rs + raw_lane + ((r >> 1) * WN_PAIR + (r & 1) * WN_HALO + dx) * 16);
+            d[dx] = wn_lds_b64(rs + raw_lane + ((r >> 1) * WN_PAIR + (r & 1) * WN_HALO + dx) * 16);
     };
     auto row_pass = [&](f32x2 (&V)[16], int r, const f32x2 (&d)[4]) __attribute__((always_inline)) {
         V[4 * r + 0] = d[0] - d[2];
@@ -229,18 +276,23 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
     int wn = work_index(1);
     setup(wn, nxt);
 
-    // ---- prologue: raw stages 0..2 and U stage 0 of the first item; V of chunk 0 is computed alone
-    issue_raw(0, cur, 0);
-    issue_raw(1, cur, 1);
-    issue_raw(2, cur, 2);
-    issue_u(0, cur, 0, true);
+    // ---- prologue: raw chunks 0..2 and U chunk 0 of the first item; V of chunk 0 is computed alone
+    {
+        const wn_i32x4 xr = image_rsrc(cur.n);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) issue_raw(i, c, xr, c, cur.voff[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_u(i, 0, cur.half, 0, true);
+    }
     // bias of both cout halves -> LDS (a per-item global load would make hipcc wait vmcnt(0), i.e. for the DMAs in flight)
     if (tid < p.nhalves * 8) *reinterpret_cast<f32x4*>(smem + WN_BIAS_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(p.bias + tid * 4);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     f32x2 V0[16], V1[16];
     {
-        const char* rs = smem + WN_RAW_OFF;
+        const unsigned rs = smem_lds + WN_RAW_OFF;
         f32x2 d[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { raw_row(rs, r, d); row_pass(V0, r, d); }
@@ -248,7 +300,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
         for (int c = 0; c < 4; ++c) col_pass(V0, c);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                 // raw slot 0 is overwritten by the first loop iteration
+    __builtin_amdgcn_s_barrier();                 // raw slot 0 is overwritten by the first stage
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_u(i, 1, cur.half, 1, true);
+    f32x4 a[4];                                   // A fragments two positions ahead of their MFMAs, across stage boundaries
+    a[0] = *reinterpret_cast<const f32x4*>(smem + u_lane);
+    a[1] = *reinterpret_cast<const f32x4*>(smem + u_lane + 1024);
 
     int us = 0;                                   // U ring slot of the current stage
     int rsn = 1;                                  // raw ring slot of the NEXT stage (read by this stage's transform)
@@ -259,52 +316,72 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
         f32x4 biasv[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) biasv[ct] = *reinterpret_cast<const f32x4*>(smem + WN_BIAS_OFF + (cur.half * 32 + ct * 16 + g * 4) * 4);
-        // A^T M A of a bias b placed at position (1, 1) is b in all four outputs: no bias add in the epilogue
-#pragma unroll
-        for (int pos = 0; pos < 16; ++pos)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) acc[pos][ct] = pos == 5 ? biasv[ct] : f32x4{0.f, 0.f, 0.f, 0.f};
 
-        // one K stage: 64 MFMAs from (U ring slot us, Vc) while Vn = transform(raw ring slot rsn) is built
-        auto stage = [&](int c, f32x2 (&Vc)[16], f32x2 (&Vn)[16]) __attribute__((always_inline)) {
-            // DMA of U stage +1 and raw stage +3 (ring slots free since the barrier that ended the previous stage)
-            {
-                const int c1 = c + 1;
-                if (c1 < p.nchunks) issue_u(us ^ 1, cur, c1, true);
-                else issue_u(us ^ 1, nxt, 0, has_next);
-                const int c3 = c + 3;
-                int rs3 = rsn + 2;
-                rs3 = rs3 >= 3 ? rs3 - 3 : rs3;
-                if (c3 < p.nchunks) issue_raw(rs3, cur, c3);
-                else issue_raw(rs3, nxt, c3 - p.nchunks);
-            }
+        // one K stage g (chunk c of the item): 64 MFMAs from (U ring slot us, Vc) while Vn = transform(raw ring slot rsn) is built.
+        // Ring contents: behind the barrier of stage h the block issues U chunk h + 2 and (in the first positions of stage h + 1) raw
+        // chunk h + 4; the barrier of stage g hands over U g + 1 and raw g + 2.
+        // FIRST: the item's first stage -- the accumulators start from constants (A^T M A of a bias b placed at position (1, 1)
+        // is b in all four outputs: no bias add in the epilogue, no accumulator clearing)
+        auto stage = [&](auto first_tag, int c, f32x2 (&Vc)[16], f32x2 (&Vn)[16]) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const bool rc = c + 3 < p.nchunks;
+            const wn_i32x4 xr = image_rsrc(rc ? cur.n : nxt.n);
+            const int rchunk = rc ? c + 3 : c + 3 - p.nchunks;
+            int rs3 = rsn + 2;
+            rs3 = rs3 >= 3 ? rs3 - 3 : rs3;
+            const bool uc = c + 2 < p.nchunks;
+            const int uhalf = uc ? cur.half : nxt.half, uchunk = uc ? c + 2 : c + 2 - p.nchunks;
+            const bool ulive = uc || has_next;
+            int us1 = us + 1, us2 = us + 2;
+            us1 = us1 >= 3 ? us1 - 3 : us1;
+            us2 = us2 >= 3 ? us2 - 3 : us2;
             const char* ust = smem + us * WN_U_BYTES + u_lane;
-            const char* rs = smem + WN_RAW_OFF + rsn * WN_RAW_BYTES;
-            f32x4 a[2];
+            const char* ust1 = smem + us1 * WN_U_BYTES + u_lane;
+            const unsigned rs = smem_lds + (unsigned)(WN_RAW_OFF + rsn * WN_RAW_BYTES);
             f32x2 d[2][4];
-            a[0] = *reinterpret_cast<const f32x4*>(ust);
 #pragma unroll
             for (int pos = 0; pos < 16; ++pos) {
-                const int cs = pos & 1;
-                if (pos + 1 < 16) a[cs ^ 1] = *reinterpret_cast<const f32x4*>(ust + (pos + 1) * 1024);
+                if (pos == WN_BARRIER_POS) {
+                    // hand-over: U chunk +1 (older than the 3 raw pieces of this stage) and raw chunk +2 (issued a stage ago) have landed
+                    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                if (pos + 2 < 16) a[(pos + 2) & 3] = *reinterpret_cast<const f32x4*>(ust + (pos + 2) * 1024);
+                else a[(pos + 2) & 3] = *reinterpret_cast<const f32x4*>(ust1 + (pos + 2 - 16) * 1024);
                 if (pos < 4) raw_row(rs, pos, d[pos & 1]);
-                if (pos >= 1 && pos < 5) row_pass(Vn, pos - 1, d[(pos - 1) & 1]);
-                if (pos >= 5 && pos < 9) col_pass(Vn, pos - 5);
-                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cs].x, Vc[pos].x, acc[pos][0], 0, 0, 0);
-                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cs].z, Vc[pos].x, acc[pos][1], 0, 0, 0);
-                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cs].y, Vc[pos].y, acc[pos][0], 0, 0, 0);
-                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cs].w, Vc[pos].y, acc[pos][1], 0, 0, 0);
+                if (pos >= 1 && pos < 5) {
+                    row_pass(Vn, pos - 1, d[(pos - 1) & 1]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) WN_PIN(Vn[4 * (pos - 1) + q]);
+                }
+                if (pos >= 5 && pos < 9) {
+                    col_pass(Vn, pos - 5);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) WN_PIN(Vn[4 * q + pos - 5]);
+                }
+                if (pos == 2 || pos == 4 || pos == 6) {
+                    const int i = pos / 2 - 1;
+                    issue_raw(i, rs3, xr, rchunk, rc ? cur.voff[i] : nxt.voff[i]);
+                }
+                if (pos >= WN_BARRIER_POS) issue_u(pos - WN_BARRIER_POS, us2, uhalf, uchunk, ulive);
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 c0 = FIRST ? (pos == 5 ? biasv[0] : zero) : acc[pos][0];
+                const f32x4 c1 = FIRST ? (pos == 5 ? biasv[1] : zero) : acc[pos][1];
+                const f32x4 af = a[pos & 3];
+                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, Vc[pos].x, c0, 0, 0, 0);
+                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, Vc[pos].x, c1, 0, 0, 0);
+                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, Vc[pos].y, acc[pos][0], 0, 0, 0);
+                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, Vc[pos].y, acc[pos][1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // hand-over: U stage +1 (issued above, older than the 3 raw pieces) and raw stage +2 (issued a stage ago) have landed
-            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            us ^= 1;
+            us = us1;
             rsn = rsn == 2 ? 0 : rsn + 1;
         };
-        for (int c = 0; c < p.nchunks; c += 2) {
-            stage(c, V0, V1);
-            stage(c + 1, V1, V0);
+        stage(std::true_type{}, 0, V0, V1);
+        stage(std::false_type{}, 1, V1, V0);
+        for (int c = 2; c < p.nchunks; c += 2) {
+            stage(std::false_type{}, c, V0, V1);
+            stage(std::false_type{}, c + 1, V1, V0);
         }
 
         // ---- output transform  Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1], then residual / activation / store
@@ -407,6 +484,10 @@ int esr_wino_supported(const esr_conv_desc* d)
     int split = d->split <= 0 ? cout4 : d->split;
     if (split >= d->cout) split = cout4;
     if (split < cout4 && (split & 15)) return 0;                 // a cout tile goes to ONE destination
+    // tile decode by multiplication (wn_div): tiles * max(tiles_x, tiles_y) < 2^32; per-image raw buffer < 2 GiB - 1 KB (OOB offsets)
+    const double tx = (d->w + 15) / 16, ty = (d->h + 15) / 16;
+    if ((double)d->n * tx * ty * (tx > ty ? tx : ty) >= 4294967296.0) return 0;
+    if ((double)d->h * d->w * d->in.pitch * 4.0 >= 2147482624.0) return 0;
     return 1;
 }
 
@@ -501,8 +582,13 @@ int esr_conv2d_wino(const esr_conv_desc* d, void* hip_stream)
     k.tiles_x = (d->w + WN_TILE - 1) / WN_TILE;
     k.tiles_y = (d->h + WN_TILE - 1) / WN_TILE;
     k.y1_blk = (d->blocked8 & ESR_BLOCKED_OUT1) ? 1 : 0;
+    k.magic_x = k.tiles_x == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)k.tiles_x) + 1u;
+    k.magic_y = k.tiles_y == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)k.tiles_y) + 1u;
     const long nwork = (long)k.N * k.tiles_x * k.tiles_y * k.nhalves;
     const int grid = nwork < WN_MAX_BLOCKS ? (int)nwork : WN_MAX_BLOCKS;
+    // uneven split between the first- and the second-dispatched half of the grid (see the kernel's work walk): only when both
+    // blocks of every CU are there and walk several items
+    k.first_share = (grid == WN_MAX_BLOCKS && nwork >= 8L * grid) ? WN_FIRST_SHARE : 8;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     if (d->res_mode == ESR_RES_NONE) {
         if (d->act == ESR_ACT_LRELU) return wn_launch_blk<ESR_ACT_LRELU, ESR_RES_NONE>(k, grid, st);

@@ -132,3 +132,17 @@ def test_wino_unsupported_shapes_fall_back():
     x = torch.randn(1, 9, 9, 16, device=dev)
     with pytest.raises(L.EsrError):
         ops.conv2d(x, torch.randn(16, 16, 3, 3), None, wino=True)      # 2 chunks
+
+
+def test_wino_uneven_split_between_block_classes():
+    """>= 8 items per block: the first-dispatched half of the grid takes 9/16 of the items (two walks over two ranges); every
+    output pixel is still written exactly once"""
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(12, 64, 200, 216, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    b = torch.randn(64, generator=g)
+    ref = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.05)
+    y = ops.conv2d(_nhwc(x).to(dev), w, b, act=1, wino=True)
+    _check(y, ref)

@@ -23,10 +23,10 @@ for (cin, cout, split) in ((64, 64, 16), (48, 64, 16), (64, 64, 0)):
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for name, wp in (("direct", None), ("wino", wb.data_ptr())):
         d.wino_wpacked = wp
-        for _ in range(3): assert lib.esr_conv2d_f32(ctypes.byref(d), st) == 0, lib.esr_last_hip_error()
+        for _ in range(int(os.environ.get('WARM', '30'))): assert lib.esr_conv2d_f32(ctypes.byref(d), st) == 0, lib.esr_last_hip_error()
         torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); e0.record()
         for _ in range(20): lib.esr_conv2d_f32(ctypes.byref(d), st)
         e1.record(); torch.cuda.synchronize(); ms = e0.elapsed_time(e1) / 20
         fl = 2.0 * B * H * W * cin * cout * 9
         ex = fl * (16 / 36 if wp else 1.0)
-        print(f"{cin:3d}->{cout:3d} split{split:2d} {name:6s}: {ms:.4f} ms  direct-equivalent {fl / ms / 1e9:6.1f} TFLOP/s  executed {ex / ms / 1e9:6.1f} TFLOP/s = {ex / ms / 1e9 / 157.3:.3f} of the fp32 MFMA peak", flush=True)
+        print(f"{cin:3d}->{cout:3d} split{split:2d} {name:8s}: {ms:.4f} ms  direct-equivalent {fl / ms / 1e9:6.1f} TFLOP/s  executed {ex / ms / 1e9:6.1f} TFLOP/s = {ex / ms / 1e9 / 157.3:.3f} of the fp32 MFMA peak", flush=True)

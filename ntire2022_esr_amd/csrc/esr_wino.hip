@@ -148,7 +148,9 @@ __device__ __forceinline__ f32x2 wn_lds_b64(unsigned addr)
 // NEXT stage's MFMAs) out of this stage's MFMA stream into the top of the next stage
 #define WN_PIN(x) asm volatile("" : "+v"(x))
 
-template <int ACT, int RES, bool Y1BLK>
+// OUT: 0 = NHWC views (split store allowed), 1 = out1 channel-blocked [n][C/8][h][w][8] (esr_conv_desc.blocked8), 2 = the network
+// output, conv + nn.PixelShuffle(4) fused (ESR_NCHW_SHUFFLE4: out[n, c, 4y+i, 4x+j] = conv[n, 16c+4i+j, y, x], basicblock.py:84-85,446-449)
+template <int ACT, int RES, int OUT>
 __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
 {
     __shared__ __attribute__((aligned(16))) char smem[WN_LDS];
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
                 const bool to0 = cur.half * 32 + ct * 16 < p.split;        // uniform: host guarantees split % 16 == 0 or no split
                 const bool cok = cg < p.cout_store;
                 const int ch = to0 ? p.y0_coff + cg : p.y1_coff + cg - p.split;
-                const bool blk = Y1BLK && !to0;
+                const bool blk = OUT == 1 && !to0;
                 char* const dbase = reinterpret_cast<char*>(to0 ? p.y0 : p.y1) + (size_t)cur.n * hw * (size_t)((to0 ? p.y0_pitch : p.y1_pitch) * 4);
                 const unsigned dps = blk ? 32u : (unsigned)((to0 ? p.y0_pitch : p.y1_pitch) * 4);
                 const size_t dlane = blk ? (size_t)(ch >> 3) * hw * 32 + (size_t)(ch & 7) * 4 : (size_t)ch * 4;
@@ -435,7 +437,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
                         if (RES == ESR_RES_PRE_ACT) v = wn_act4<ACT>(v + rv[a][b], p.act, p.slope);
                         else if (RES == ESR_RES_POST_ACT) v = wn_act4<ACT>(v, p.act, p.slope) + rv[a][b];
                         else v = wn_act4<ACT>(v, p.act, p.slope);
-                        if (pok[a][b] && cok) *reinterpret_cast<f32x4*>(dbase + dlane + (size_t)pix[a][b] * dps) = v;
+                        if (OUT == 2) {
+                            // lane (tile, g) holds channels 16c + 4g + {0..3} of pixel (y, x): the four HR pixels (4y + g, 4x .. 4x+3) of plane c
+                            const int cidx = cur.half * 2 + ct, nco = p.cout_store >> 4;
+                            float* const o = p.y0 + ((size_t)(cur.n * nco + cidx) * (4 * p.H) + 4 * (ybase + a) + g) * (size_t)(4 * p.W) + 4 * (xbase + b);
+                            if (pok[a][b] && cidx < nco) *reinterpret_cast<f32x4*>(o) = v;
+                        } else if (pok[a][b] && cok) *reinterpret_cast<f32x4*>(dbase + dlane + (size_t)pix[a][b] * dps) = v;
                     }
             }
         }
@@ -448,11 +455,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the out-of-range DMAs issued behind the last item
 }
 
-template <int ACT, int RES>
-int wn_launch_blk(const WinoK& k, int grid, hipStream_t st)
+template <int ACT, int RES, int OUT>
+int wn_launch(const WinoK& k, int grid, hipStream_t st)
 {
-    if (k.y1_blk) hipLaunchKernelGGL((wino_f32_kernel<ACT, RES, true>), dim3(grid), dim3(WN_THREADS), 0, st, k);
-    else hipLaunchKernelGGL((wino_f32_kernel<ACT, RES, false>), dim3(grid), dim3(WN_THREADS), 0, st, k);
+    hipLaunchKernelGGL((wino_f32_kernel<ACT, RES, OUT>), dim3(grid), dim3(WN_THREADS), 0, st, k);
     return esr_check_launch("wino_f32_kernel launch");
 }
 
@@ -472,10 +478,14 @@ inline size_t wn_index(int nhalves, int slot, int pos, int o)
 // Shapes the Winograd kernel takes (everything else stays on conv_f32_kernel): see esr_conv_desc.wino_wpacked.
 int esr_wino_supported(const esr_conv_desc* d)
 {
-    if (!d || d->ksize != 3 || d->in_layout != ESR_NHWC || d->out_layout != ESR_NHWC) return 0;
+    if (!d || d->ksize != 3 || d->in_layout != ESR_NHWC) return 0;
+    if (d->out_layout == ESR_NCHW_SHUFFLE4) {                      // the network's last convolution: no residual, no split
+        if ((d->cout & 15) || d->res_mode != ESR_RES_NONE || (d->split > 0 && d->split < d->cout) || (d->blocked8 & ESR_BLOCKED_OUT1)) return 0;
+    } else if (d->out_layout != ESR_NHWC) return 0;
     if (d->storage != ESR_STORE_F32 || d->compute != ESR_COMPUTE_F32) return 0;
     if (d->tail_wpacked || d->post_wpacked || d->border_bias || d->in_seg_stride) return 0;
     if (d->blocked8 & ESR_BLOCKED_IN) return 0;
+    if ((d->blocked8 & ESR_BLOCKED_OUT1) && d->res_mode != ESR_RES_NONE) return 0;
     if (d->cin <= 0 || d->cout <= 0 || d->cout > 64) return 0;
     const int cin_phys = esr_round_up(d->cin, 8);
     const int nchunks = cin_phys / 8;
@@ -590,11 +600,17 @@ int esr_conv2d_wino(const esr_conv_desc* d, void* hip_stream)
     // blocks of every CU are there and walk several items
     k.first_share = (grid == WN_MAX_BLOCKS && nwork >= 8L * grid) ? WN_FIRST_SHARE : 8;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    if (d->res_mode == ESR_RES_NONE) {
-        if (d->act == ESR_ACT_LRELU) return wn_launch_blk<ESR_ACT_LRELU, ESR_RES_NONE>(k, grid, st);
-        if (d->act == ESR_ACT_NONE) return wn_launch_blk<ESR_ACT_NONE, ESR_RES_NONE>(k, grid, st);
-        return wn_launch_blk<-1, ESR_RES_NONE>(k, grid, st);
-    }
-    if (d->res_mode == ESR_RES_PRE_ACT) return wn_launch_blk<-1, ESR_RES_PRE_ACT>(k, grid, st);
-    return wn_launch_blk<-1, ESR_RES_POST_ACT>(k, grid, st);
+    // instantiations: the activation is a template constant for LeakyReLU / none (the networks' cases), read at run time otherwise
+    const int a = d->act;
+    if (d->out_layout == ESR_NCHW_SHUFFLE4)
+        return a == ESR_ACT_NONE ? wn_launch<ESR_ACT_NONE, ESR_RES_NONE, 2>(k, grid, st) : wn_launch<-1, ESR_RES_NONE, 2>(k, grid, st);
+    if (k.y1_blk)
+        return a == ESR_ACT_LRELU ? wn_launch<ESR_ACT_LRELU, ESR_RES_NONE, 1>(k, grid, st) : wn_launch<-1, ESR_RES_NONE, 1>(k, grid, st);
+    if (d->res_mode == ESR_RES_NONE)
+        return a == ESR_ACT_LRELU ? wn_launch<ESR_ACT_LRELU, ESR_RES_NONE, 0>(k, grid, st)
+             : a == ESR_ACT_NONE  ? wn_launch<ESR_ACT_NONE, ESR_RES_NONE, 0>(k, grid, st) : wn_launch<-1, ESR_RES_NONE, 0>(k, grid, st);
+    if (d->res_mode == ESR_RES_PRE_ACT)
+        return a == ESR_ACT_LRELU ? wn_launch<ESR_ACT_LRELU, ESR_RES_PRE_ACT, 0>(k, grid, st)
+             : a == ESR_ACT_NONE  ? wn_launch<ESR_ACT_NONE, ESR_RES_PRE_ACT, 0>(k, grid, st) : wn_launch<-1, ESR_RES_PRE_ACT, 0>(k, grid, st);
+    return a == ESR_ACT_LRELU ? wn_launch<ESR_ACT_LRELU, ESR_RES_POST_ACT, 0>(k, grid, st) : wn_launch<-1, ESR_RES_POST_ACT, 0>(k, grid, st);
 }

@@ -835,8 +835,9 @@ class HipSRModel(nn.Module):
             hw = o.get("hw")
             npix = plan.npix if hw is None else plan.n * hw[0] * hw[1]
             e_act = es if hw is None else 4                       # low-resolution maps are fp32
+            wino = False
             if kind == "pack":                      # the network input, read once (fp32 NCHW); its 16-bit copy is an intermediate
-                out.append(dict(name="pack_input", kernel="pack_input_kernel", cin=o["cin"], cout=16, k=0, flops=0.0,
+                out.append(dict(name="pack_input", kernel="pack_input_kernel", cin=o["cin"], cout=16, k=0, flops=0.0, flops_exec=0.0,
                                 read_bytes=float(npix * o["cin"] * 4), write_bytes=0.0))
                 continue
             if kind == "conv":
@@ -847,6 +848,13 @@ class HipSRModel(nn.Module):
                     kern = f"conv_s16_kernel<NT={nt},KS={o['k']},NW={nw or 8},{plan.store}>"
                 if isinstance(o.get("dst1"), Buffer) and o["dst1"].blocked:
                     kern = kern[:-1] + ",BLK>"          # the instantiation with the channel-blocked split store
+                wino = arr is not None and bool(arr[i].conv.wino_wpacked) and bool(L.lib().esr_wino_supported(ctypes.byref(arr[i].conv)))
+                if wino:
+                    # the device symbol as rocprofv3 prints it: wino_f32_kernel<ACT, RES, Y1BLK> (esr_wino.hip: esr_conv2d_wino)
+                    rm = o.get("res_mode", L.RES_NONE) if o["res"] is not None else L.RES_NONE
+                    at = o["act"] if (o["act"] == L.ACT_LRELU or (o["act"] == L.ACT_NONE and rm != L.RES_POST_ACT)) else -1
+                    blk = isinstance(o.get("dst1"), Buffer) and o["dst1"].blocked
+                    kern = f"wino_f32_kernel<{at}, {rm}, {2 if o['dst'] is OUTPUT else int(blk)}>"
                 e_in = 4 if o["src"] is INPUT else e_act
                 e_out = 4 if o["dst"] is OUTPUT else e_act
                 ca = o["cin_alg"]
@@ -907,8 +915,11 @@ class HipSRModel(nn.Module):
                 flops = 2.0 * plan.npix * (o["f"] * o["f"] + o["f"] * o["c"])
                 rd = float(plan.npix * es * (o["c"] + o["f"]) + plan.n * o["c3"].h * o["c3"].w * o["f"] * 4)
                 wr = float(plan.npix * es * o["c"])
+            # flops = ALGORITHMIC (direct-convolution) flops; flops_exec = what the matrix cores execute: Winograd F(2x2,3x3) does 16
+            # multiplications per 2x2 outputs where the direct form does 36
+            fexec = flops * (16.0 / 36.0) if (kind == "conv" and wino) else flops
             out.append(dict(name=o.get("w", kind), kernel=kern, cin=o.get("cin", 0), cout=o.get("cout", 0), k=o.get("k", 0),
-                            flops=flops, read_bytes=rd, write_bytes=wr))
+                            flops=flops, flops_exec=fexec, read_bytes=rd, write_bytes=wr))
         return out
 
     def collect_profile(self):

@@ -146,3 +146,18 @@ def test_wino_uneven_split_between_block_classes():
     ref = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.05)
     y = ops.conv2d(_nhwc(x).to(dev), w, b, act=1, wino=True)
     _check(y, ref)
+
+
+@pytest.mark.parametrize("hw", [(21, 30), (32, 32), (17, 15)])
+def test_wino_pixelshuffle_output(hw):
+    """the network's last convolution: conv + nn.PixelShuffle(4) fused into the store (basicblock.py:446-449, 84-85)"""
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5 + hw[0])
+    t = torch.randn(2, 64, *hw, generator=g)
+    w2 = torch.randn(48, 64, 3, 3, generator=g) * 0.05
+    b2 = torch.randn(48, generator=g)
+    ref = F.pixel_shuffle(F.conv2d(t, w2, b2, padding=1), 4)
+    out = ops.conv2d(_nhwc(t).to(dev), w2, b2, shuffle_out=True, wino=True).cpu()
+    assert out.shape == ref.shape
+    assert float((out - ref).abs().max()) / max(1.0, float(ref.abs().max())) < 2e-5

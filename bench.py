@@ -105,13 +105,13 @@ def cpu_baseline(name, shape, budget_s=16.0):
         fwd(sd, x)
         p1 = time.perf_counter() - t0
     times.sort()
-    med = times[len(times) // 2]
+    med = min(times[len(times) // 2], sweep[best])        # the sweep's own point at this thread count counts too: the STRONGEST baseline
     pts = {"1": round(p1 * 1e3, 1)}
     pts.update({str(c): round(v * 1e3, 1) for c, v in sweep.items()})
     return {"value": round(1.0 / med, 3), "unit": "images/s", "cores": int(best), "kind": "port",
             "points_ms": pts, "physical_cores": int(phys),
             "p1_images_per_s": round(1.0 / p1, 3), "pall_images_per_s": round(1.0 / sweep[max(sweep)], 3),
-            "sample": f"{len(times)} forwards of 1x3x{shape[0]}x{shape[1]} fp32 (median {med * 1e3:.1f} ms) with "
+            "sample": f"{len(times)} forwards of 1x3x{shape[0]}x{shape[1]} fp32 (value = min(median of these, sweep point) = {med * 1e3:.1f} ms) with "
                       f"torch.set_num_threads({best}) = fastest of the sweep in points_ms (1 = one core, {max(sweep)} = all "
                       f"{phys} physical cores); oracle/torch_port.py = the reference's ATen op sequence on oneDNN"}
 
@@ -309,9 +309,10 @@ def main():
         f_mfma, f_hbm = tflops / kpeak, gbs / HBM_PEAK_GBS
         traffic, traffic_src = None, None
         tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and args.sizes == "tile":
+        if os.path.exists(tpath):
             try:
-                ent = json.load(open(tpath)).get(f"{args.model}:{args.compute}:{B}x{th}x{tw}", {})
+                tkey = f"{args.model}:{args.compute}:div2k" if args.sizes == "div2k" else f"{args.model}:{args.compute}:{B}x{th}x{tw}"
+                ent = json.load(open(tpath)).get(tkey, {})
                 traffic = ent.get(dom_name, {}).get("hbm_bytes_per_launch")
                 if traffic is not None:
                     traffic_src = (f"profiles/pmc_traffic.json, {ent.get('_round', '?')}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "

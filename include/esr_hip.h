@@ -366,6 +366,10 @@ int  esr_prof_create(int n_ops, int max_passes, esr_profiler** out);
 int  esr_run_ops_profiled(const esr_op* ops, int n_ops, void* hip_stream, esr_profiler* prof);
 int  esr_prof_collect(esr_profiler* prof, double* ms_sum, int n_ops, int* passes);
 void esr_prof_destroy(esr_profiler* prof);
+/* Device symbol(s) of op `op` as launched in the last profiled pass, in rocprofv3's spelling ("wino_f32_kernel<1, 0, 0>",
+ * "conv_s16_kernel<4, 3, 8, true, false, 2, 0>", ...; "a + b" when an op was lowered to two launches): what a profiler matches its
+ * kernel trace against (the reference has torch.profiler for that). */
+int  esr_prof_kernel_symbol(esr_profiler* prof, int op, char* buf, size_t n);
 
 /* diagnostics */
 int         esr_abi_version(void);

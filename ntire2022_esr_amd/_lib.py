@@ -94,7 +94,7 @@ EXPORTS = [
     "esr_packed_post_s16_bytes", "esr_pack_post_s16", "esr_conv_post_supported",
     "esr_packed_wino_bytes", "esr_pack_wino_f32", "esr_unpack_wino_f32", "esr_wino_supported",
     "esr_conv2d_f32", "esr_conv_block_waves", "esr_run_ops", "esr_pack_input_s16",
-    "esr_prof_create", "esr_run_ops_profiled", "esr_prof_collect", "esr_prof_destroy",
+    "esr_prof_create", "esr_run_ops_profiled", "esr_prof_collect", "esr_prof_destroy", "esr_prof_kernel_symbol",
     "esr_packed_dense_bytes", "esr_pack_dense_f32",
     "esr_conv3x3s2_f32", "esr_maxpool7s3_f32", "esr_esa_apply_f32",
     "esr_packed_dw_bytes", "esr_pack_dw_f32", "esr_dwconv3x3_f32", "esr_bsconv_f32",
@@ -180,6 +180,8 @@ def lib():
     L.esr_run_ops_profiled.restype = ci
     L.esr_prof_collect.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ci, ctypes.POINTER(ci)]
     L.esr_prof_collect.restype = ci
+    L.esr_prof_kernel_symbol.argtypes = [vp, ci, ctypes.c_char_p, sz]
+    L.esr_prof_kernel_symbol.restype = ci
     L.esr_prof_destroy.argtypes = [vp]
     L.esr_prof_destroy.restype = None
     if L.esr_abi_version() != 7:

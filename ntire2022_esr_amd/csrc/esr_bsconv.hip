@@ -368,6 +368,7 @@ int launch_bs(const BsK& k, size_t lds, hipStream_t st)
     }
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int grid = ntiles < 512 ? ntiles : 512;
+    esr_note_kernel("bsconv_kernel<%d, %d, %d>", NTP, NTD, ST);
     hipLaunchKernelGGL((bsconv_kernel<NTP, NTD, ST>), dim3(grid), dim3(256), lds, st, k);
     return esr_check_launch("bsconv_kernel launch");
 }

@@ -414,8 +414,8 @@ int launch_esa_mfma(const EsaK& k, hipStream_t st)
     const unsigned grid = (unsigned)nwg;
     const int np = (k.Cp4 + 31) / 32;
     switch (np) {
-        case 1: hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 1>), dim3(grid), dim3(256), 0, st, k); break;
-        case 2: hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 2>), dim3(grid), dim3(256), 0, st, k); break;
+        case 1: esr_note_kernel("esa_apply_mfma_kernel<%d, 1>", ST); hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 1>), dim3(grid), dim3(256), 0, st, k); break;
+        case 2: esr_note_kernel("esa_apply_mfma_kernel<%d, 2>", ST); hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 2>), dim3(grid), dim3(256), 0, st, k); break;
         default: return ESR_ERR_UNSUPPORTED;
     }
     return esr_check_launch("esa_apply_mfma_kernel launch");
@@ -570,9 +570,9 @@ int esr_dwconv3x3_f32(const esr_conv_desc* d, void* hip_stream)
     const size_t lds = (size_t)10 * cp * sizeof(float);
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     switch (d->storage) {
-        case ESR_STORE_F32: hipLaunchKernelGGL(dwconv3x3_kernel<ESR_STORE_F32>, grid, dim3(256), lds, st, k); break;
-        case ESR_STORE_BF16: hipLaunchKernelGGL(dwconv3x3_kernel<ESR_STORE_BF16>, grid, dim3(256), lds, st, k); break;
-        case ESR_STORE_F16: hipLaunchKernelGGL(dwconv3x3_kernel<ESR_STORE_F16>, grid, dim3(256), lds, st, k); break;
+        case ESR_STORE_F32: esr_note_kernel("dwconv3x3_kernel<0>"); hipLaunchKernelGGL(dwconv3x3_kernel<ESR_STORE_F32>, grid, dim3(256), lds, st, k); break;
+        case ESR_STORE_BF16: esr_note_kernel("dwconv3x3_kernel<1>"); hipLaunchKernelGGL(dwconv3x3_kernel<ESR_STORE_BF16>, grid, dim3(256), lds, st, k); break;
+        case ESR_STORE_F16: esr_note_kernel("dwconv3x3_kernel<2>"); hipLaunchKernelGGL(dwconv3x3_kernel<ESR_STORE_F16>, grid, dim3(256), lds, st, k); break;
         default: return ESR_ERR_BAD_ARG;
     }
     return esr_check_launch("dwconv3x3_kernel launch");
@@ -624,9 +624,9 @@ int esr_conv3x3s2_f32(const esr_esa_desc* d, void* hip_stream)
     const float* w0 = static_cast<const float*>(d->w0);
     float* y = static_cast<float*>(d->y.ptr);                 // the half-resolution map is fp32 in every storage mode
     switch (d->storage) {
-        case ESR_STORE_F32: hipLaunchKernelGGL(conv3x3s2_kernel<ESR_STORE_F32>, grid, dim3(256), 0, st, d->x.ptr, w0, y, d->n, d->h, d->w, Ho, Wo); break;
-        case ESR_STORE_BF16: hipLaunchKernelGGL(conv3x3s2_kernel<ESR_STORE_BF16>, grid, dim3(256), 0, st, d->x.ptr, w0, y, d->n, d->h, d->w, Ho, Wo); break;
-        case ESR_STORE_F16: hipLaunchKernelGGL(conv3x3s2_kernel<ESR_STORE_F16>, grid, dim3(256), 0, st, d->x.ptr, w0, y, d->n, d->h, d->w, Ho, Wo); break;
+        case ESR_STORE_F32: esr_note_kernel("conv3x3s2_kernel<0>"); hipLaunchKernelGGL(conv3x3s2_kernel<ESR_STORE_F32>, grid, dim3(256), 0, st, d->x.ptr, w0, y, d->n, d->h, d->w, Ho, Wo); break;
+        case ESR_STORE_BF16: esr_note_kernel("conv3x3s2_kernel<1>"); hipLaunchKernelGGL(conv3x3s2_kernel<ESR_STORE_BF16>, grid, dim3(256), 0, st, d->x.ptr, w0, y, d->n, d->h, d->w, Ho, Wo); break;
+        case ESR_STORE_F16: esr_note_kernel("conv3x3s2_kernel<2>"); hipLaunchKernelGGL(conv3x3s2_kernel<ESR_STORE_F16>, grid, dim3(256), 0, st, d->x.ptr, w0, y, d->n, d->h, d->w, Ho, Wo); break;
         default: return ESR_ERR_BAD_ARG;
     }
     return esr_check_launch("conv3x3s2_kernel launch");
@@ -641,6 +641,7 @@ int esr_maxpool7s3_f32(const esr_esa_desc* d, void* hip_stream)
     const int Ho = (d->h - 7) / 3 + 1, Wo = (d->w - 7) / 3 + 1;
     if (d->h_lo != Ho || d->w_lo != Wo) return ESR_ERR_BAD_ARG;
     const long long npix = (long long)d->n * Ho * Wo;
+    esr_note_kernel("maxpool7s3_kernel");
     hipLaunchKernelGGL(maxpool7s3_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
                        static_cast<const float*>(d->x.ptr), static_cast<float*>(d->y.ptr), d->n, d->h, d->w, Ho, Wo);
     return esr_check_launch("maxpool7s3_kernel launch");
@@ -675,7 +676,7 @@ int esr_esa_apply_f32(const esr_esa_desc* d, void* hip_stream)
     const unsigned grid = (unsigned)(ngroups < 8192 ? ngroups : 8192);        // 256 CUs x 8 blocks x 4 rounds
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     switch (d->storage) {
-        case ESR_STORE_F32: hipLaunchKernelGGL(esa_apply_kernel<ESR_STORE_F32>, dim3(grid), dim3(256), lds, st, k); break;
+        case ESR_STORE_F32: esr_note_kernel("esa_apply_kernel<0>"); hipLaunchKernelGGL(esa_apply_kernel<ESR_STORE_F32>, dim3(grid), dim3(256), lds, st, k); break;
         case ESR_STORE_BF16: return launch_esa_mfma<ESR_STORE_BF16>(k, st);
         case ESR_STORE_F16: return launch_esa_mfma<ESR_STORE_F16>(k, st);
         default: return ESR_ERR_BAD_ARG;

@@ -21,7 +21,9 @@
 //                identical on the A and B side by construction of the packer below.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdarg.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -72,9 +74,6 @@ struct ConvK {
     int out16;            // NCHW head only: the NHWC output is stored as bf16 (1) / fp16 (2) (esr_storage), 0 = fp32
     int y1_blk;           // esr_conv_desc.blocked8 & ESR_BLOCKED_OUT1: y1 is [n][y1_pitch / 8][H][W][8]
     int in_blk;           // ... & ESR_BLOCKED_IN (imdb_tail_kernel only): x is [n][in_pitch / 8][H][W][8]
-#ifdef ESR_EXPERIMENTAL_WS
-    int hand_rows;        // accumulator rows (of 4) finished by the loader partner
-#endif
 };
 
 __device__ __forceinline__ float act_any(float v, int act, float slope)
@@ -727,11 +726,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_f32_kernel(const ConvK p)
 
 #include "imdb_tail.inc"                   // IMDBlock's fused tail at the network's own shape: DMA ring of three, residual folded
 
-#ifdef ESR_EXPERIMENTAL_WS
-#include "experimental/conv_ws.inc"        // wave-specialised research variant (tools/dbg builds only)
-#endif
-
 thread_local char g_err[256] = "";
+thread_local char g_kname[256] = "";       // device symbol(s) of the op being run (esr_note_kernel)
+thread_local bool g_ktrace = false;
 
 inline void set_err(const char* what, hipError_t e) { esr_set_err(what, e); }
 inline int round_up(int v, int m) { return esr_round_up(v, m); }
@@ -760,6 +757,7 @@ int launch_conv(const ConvK& k, hipStream_t st)
         ConvK kk = k;
         kk.tiles_y = tall_y;
         const int grid = ntall < 256 ? ntall : 256;
+        esr_note_kernel("conv_f32_kernel<%d, %d, %s, 8, 0, %d, %s>", NT, KS, esr_tf(IN_NCHW), (NT == 4 && kk.wp3) ? 2 : 0, esr_tf(NT == 4 && !kk.wp3 && kk.y1_blk));
         if (NT == 4 && kk.wp3)
             hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, CAN_TALL ? 8 : 4, 0, (CAN_TALL && NT == 4) ? 2 : 0>), dim3(grid), dim3(512), 0, st, kk);
         else if (NT == 4 && kk.y1_blk)
@@ -774,6 +772,7 @@ int launch_conv(const ConvK& k, hipStream_t st)
         return ESR_OK;
     }
     const int grid = ntiles < MAX_RESIDENT_BLOCKS ? ntiles : MAX_RESIDENT_BLOCKS;
+    esr_note_kernel("conv_f32_kernel<%d, %d, %s, 4, 0, 0, %s>", NT, KS, esr_tf(IN_NCHW), esr_tf(CAN_TALL && NT == 4 && k.y1_blk));
     if (CAN_TALL && NT == 4 && k.y1_blk) hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, 4, 0, 0, CAN_TALL && NT == 4>), dim3(grid), dim3(THREADS), 0, st, k);
     else hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, 4>), dim3(grid), dim3(THREADS), 0, st, k);
     const hipError_t e = hipGetLastError();
@@ -803,6 +802,7 @@ int launch_conv_tail(const ConvK& k, hipStream_t st)
         kk.tiles_y = (k.H + 4 * IT_NW - 1) / (4 * IT_NW);      // 16 x 32 pixel tiles, one 8-wave block per CU
         const int nt32 = k.N * kk.tiles_x * kk.tiles_y;
         const int g32 = nt32 < 256 ? nt32 : 256;
+        esr_note_kernel("imdb_tail_kernel<%s>", esr_tf(k.res_mode == ESR_RES_PRE_ACT));
         if (k.res_mode == ESR_RES_PRE_ACT) hipLaunchKernelGGL((imdb_tail_kernel<true>), dim3(g32), dim3(64 * IT_NW), 0, st, kk);
         else hipLaunchKernelGGL((imdb_tail_kernel<false>), dim3(g32), dim3(64 * IT_NW), 0, st, kk);
         const hipError_t e = hipGetLastError();
@@ -812,6 +812,7 @@ int launch_conv_tail(const ConvK& k, hipStream_t st)
         }
         return ESR_OK;
     }
+    esr_note_kernel("conv_f32_kernel<1, 3, false, 4, 4, 0, false>");
     hipLaunchKernelGGL((conv_f32_kernel<1, 3, false, 4, 4>), dim3(grid), dim3(THREADS), 0, st, k);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -821,41 +822,9 @@ int launch_conv_tail(const ConvK& k, hipStream_t st)
     return ESR_OK;
 }
 
-#ifdef ESR_EXPERIMENTAL_WS
-template <int NT>
-int launch_conv_ws(const ConvK& k, hipStream_t st)
-{
-    const int ntiles = k.N * k.tiles_x * k.tiles_y;
-    const int grid = ntiles < WS_MAX_BLOCKS ? ntiles : WS_MAX_BLOCKS;
-    static const int hand_rows = getenv("ESR_WS_HAND_ROWS") ? atoi(getenv("ESR_WS_HAND_ROWS")) : 2;
-    ConvK kk = k;
-    kk.hand_rows = hand_rows;
-    hipLaunchKernelGGL((conv_f32_ws_kernel<NT>), dim3(grid), dim3(WS_THREADS), 0, st, kk);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        set_err("conv_f32_ws_kernel launch", e);
-        return ESR_ERR_LAUNCH;
-    }
-    return ESR_OK;
-}
-#endif
-
 template <int KS, bool IN_NCHW>
 int launch_conv_nt(int nt, const ConvK& k, hipStream_t st)
 {
-#ifdef ESR_EXPERIMENTAL_WS
-    if (KS == 3 && !IN_NCHW) {
-        static const int ws_min_nt = getenv("ESR_WS_MIN_NT") ? atoi(getenv("ESR_WS_MIN_NT")) : 99;
-        if (nt >= ws_min_nt) {
-            switch (nt) {
-                case 1: return launch_conv_ws<1>(k, st);
-                case 2: return launch_conv_ws<2>(k, st);
-                case 3: return launch_conv_ws<3>(k, st);
-                case 4: return launch_conv_ws<4>(k, st);
-            }
-        }
-    }
-#endif
     switch (nt) {
         case 1: return launch_conv<1, KS, IN_NCHW>(k, st);
         case 2: return launch_conv<2, KS, IN_NCHW>(k, st);
@@ -870,6 +839,17 @@ int launch_conv_nt(int nt, const ConvK& k, hipStream_t st)
 void esr_set_err(const char* what, hipError_t e)
 {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+}
+
+void esr_note_kernel(const char* fmt, ...)
+{
+    if (!g_ktrace) return;
+    size_t n = strlen(g_kname);
+    if (n && n + 3 < sizeof(g_kname)) { memcpy(g_kname + n, " + ", 4); n += 3; }      // an op lowered to two launches
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kname + n, sizeof(g_kname) - n, fmt, ap);
+    va_end(ap);
 }
 
 int esr_check_launch(const char* what)
@@ -1165,12 +1145,15 @@ static int run_one(const esr_op& op, void* hip_stream)
 struct esr_profiler {
     int n_ops, max_passes, passes;
     hipEvent_t* ev;   // [max_passes][n_ops][2]
+    char (*sym)[256]; // [n_ops]: device symbol(s) of each op's launch(es) in the last profiled pass
 };
 
 int esr_prof_create(int n_ops, int max_passes, esr_profiler** out)
 {
     if (!out || n_ops <= 0 || max_passes <= 0) return ESR_ERR_BAD_ARG;
-    esr_profiler* p = new esr_profiler{n_ops, max_passes, 0, nullptr};
+    esr_profiler* p = new esr_profiler{n_ops, max_passes, 0, nullptr, nullptr};
+    p->sym = new char[n_ops][256];
+    for (int i = 0; i < n_ops; ++i) p->sym[i][0] = 0;
     const size_t n = (size_t)n_ops * max_passes * 2;
     p->ev = new hipEvent_t[n];
     for (size_t i = 0; i < n; ++i) {
@@ -1179,6 +1162,7 @@ int esr_prof_create(int n_ops, int max_passes, esr_profiler** out)
             set_err("hipEventCreate", e);
             for (size_t j = 0; j < i; ++j) (void)hipEventDestroy(p->ev[j]);
             delete[] p->ev;
+            delete[] p->sym;
             delete p;
             return ESR_ERR_LAUNCH;
         }
@@ -1193,7 +1177,15 @@ void esr_prof_destroy(esr_profiler* p)
     const size_t n = (size_t)p->n_ops * p->max_passes * 2;
     for (size_t i = 0; i < n; ++i) (void)hipEventDestroy(p->ev[i]);
     delete[] p->ev;
+    delete[] p->sym;
     delete p;
+}
+
+int esr_prof_kernel_symbol(esr_profiler* p, int op, char* buf, size_t n)
+{
+    if (!p || !buf || n == 0 || op < 0 || op >= p->n_ops) return ESR_ERR_BAD_ARG;
+    snprintf(buf, n, "%s", p->sym[op]);
+    return ESR_OK;
 }
 
 int esr_run_ops_profiled(const esr_op* ops, int n_ops, void* hip_stream, esr_profiler* p)
@@ -1202,12 +1194,16 @@ int esr_run_ops_profiled(const esr_op* ops, int n_ops, void* hip_stream, esr_pro
     if (p->passes >= p->max_passes) return esr_run_ops(ops, n_ops, hip_stream);   // full: run untimed
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     hipEvent_t* ev = p->ev + (size_t)p->passes * n_ops * 2;
+    g_ktrace = true;
     for (int i = 0; i < n_ops; ++i) {
+        g_kname[0] = 0;
         (void)hipEventRecord(ev[2 * i], st);
         const int rc = run_one(ops[i], hip_stream);
         (void)hipEventRecord(ev[2 * i + 1], st);
-        if (rc != ESR_OK) return rc;
+        memcpy(p->sym[i], g_kname, sizeof(g_kname));
+        if (rc != ESR_OK) { g_ktrace = false; return rc; }
     }
+    g_ktrace = false;
     p->passes++;
     return ESR_OK;
 }

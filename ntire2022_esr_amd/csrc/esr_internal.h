@@ -5,6 +5,10 @@
 
 void esr_set_err(const char* what, hipError_t e);
 int esr_check_launch(const char* what);
+// Records the device symbol of the launch that follows, as rocprofv3 prints it -- only while esr_run_ops_profiled runs (a bench /
+// profile leg names its kernels by the symbol that really ran: esr_prof_kernel_symbol).  printf-style.
+void esr_note_kernel(const char* fmt, ...);
+static inline const char* esr_tf(bool b) { return b ? "true" : "false"; }
 static inline int esr_round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // esr_s16.hip: NHWC convolution on 16-bit storage (called by esr_conv2d_f32 when d->storage != ESR_STORE_F32)

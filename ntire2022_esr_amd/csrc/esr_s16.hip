@@ -946,6 +946,7 @@ int launch_s16(const S16K& k, size_t lds, hipStream_t st)
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int cap = NW == 4 ? 512 : 256;                   // one block per CU (LDS; NW = 4: two), persistent over the tiles
     const int grid = ntiles < cap ? ntiles : cap;
+    esr_note_kernel("conv_s16_kernel<%d, %d, %d, %s, %s, %d, %d>", NT, KS, NW, esr_tf(BF16), esr_tf(GRES), PNT1, PNT2);
     hipLaunchKernelGGL((conv_s16_kernel<NT, KS, NW, BF16, GRES, PNT1, PNT2>), dim3(grid), dim3(64 * NW), lds, st, k);
     return esr_check_launch("conv_s16_kernel launch");
 }
@@ -1253,6 +1254,7 @@ extern "C" int esr_pack_input_s16(const esr_conv_desc* d, void* hip_stream)
     const long long want = (npix + 255) / 256;
     const int grid = (int)(want < 8192 ? want : 8192);
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    esr_note_kernel("pack_input_kernel<%s>", esr_tf(d->storage == ESR_STORE_BF16));
     if (d->storage == ESR_STORE_BF16)
         hipLaunchKernelGGL(pack_input_kernel<true>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(d->in.ptr), static_cast<char*>(d->out0.ptr), d->cin, hw, npix, d->out0.pitch, d->out0.coff);
     else

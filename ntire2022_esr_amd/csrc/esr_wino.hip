@@ -458,6 +458,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
 template <int ACT, int RES, int OUT>
 int wn_launch(const WinoK& k, int grid, hipStream_t st)
 {
+    esr_note_kernel("wino_f32_kernel<%d, %d, %d>", ACT, RES, OUT);
     hipLaunchKernelGGL((wino_f32_kernel<ACT, RES, OUT>), dim3(grid), dim3(WN_THREADS), 0, st, k);
     return esr_check_launch("wino_f32_kernel launch");
 }

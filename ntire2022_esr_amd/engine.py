@@ -9,6 +9,7 @@ and the stream handle.
 """
 import collections
 import ctypes
+import itertools
 import weakref
 
 import numpy as np
@@ -477,8 +478,11 @@ class Plan:
 # `model(x)` goes through ONE registered operator, esr::sr_forward(x, handle) -> y, so that graph capture / FakeTensor
 # tracing / torch.compile see an opaque op with a shape function instead of ctypes calls: the "thin PyTorch-ROCm custom-op
 # layer" the drop-in modules sit on.  The real implementation replays the fused op list through the C ABI; the fake (meta)
-# implementation only computes the output shape.  `handle` identifies the live module (weak reference, id-keyed).
+# implementation only computes the output shape.  `handle` identifies the live module: a key from a process-wide counter handed out
+# at construction and never reused (an `id()` can be recycled by another object once its owner is collected); the registry holds
+# weak references, so an entry disappears with its module.
 _LIVE = weakref.WeakValueDictionary()
+_HANDLES = itertools.count(1)
 
 
 @torch.library.custom_op("esr::sr_forward", mutates_args=())
@@ -537,6 +541,8 @@ class HipSRModel(nn.Module):
         self.compute = "f32"       # "f32" | "bf16" | "f16": MFMA operand format of the full-resolution 3x3 convs
         self.winograd = True       # fp32 plans: 3x3 convs whose shape qualifies run as Winograd F(2x2, 3x3) (esr_conv_desc.wino_wpacked)
         self._prof_passes = 0      # >0: record HIP events around every op (bench roofline leg)
+        self.handle = next(_HANDLES)       # the `handle` argument of esr::sr_forward
+        _LIVE[self.handle] = self
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
 
     # -- parameter registration: same key names as the reference state_dict -------------------
@@ -777,8 +783,10 @@ class HipSRModel(nn.Module):
 
     def forward(self, x):
         """NCHW fp32 [N, in_nc, H, W] on the GPU -> NCHW fp32 [N, out_nc, 4H, 4W]: one esr::sr_forward call."""
-        _LIVE[id(self)] = self
-        return torch.ops.esr.sr_forward(x, id(self))
+        if _LIVE.get(self.handle) is not self:          # a copy.deepcopy of a module carries its source's handle: take a fresh one
+            self.handle = next(_HANDLES)
+            _LIVE[self.handle] = self
+        return torch.ops.esr.sr_forward(x, self.handle)
 
     def _forward_impl(self, x):
         if not x.is_cuda:
@@ -935,8 +943,12 @@ class HipSRModel(nn.Module):
                 ms = (ctypes.c_double * n)()
                 passes = ctypes.c_int(0)
                 L.check(L.lib().esr_prof_collect(prof, ms, n, ctypes.byref(passes)), "esr_prof_collect")
+                buf = ctypes.create_string_buffer(256)
                 for i, c in enumerate(self.op_costs(ent.plan, ent.arr)):
-                    c.update(ms_sum=ms[i], passes=passes.value, shape=key[:4])
+                    c.update(ms_sum=ms[i], passes=passes.value, shape=key[:4], label=c["kernel"])
+                    # the device symbol the library launched for this op (rocprofv3's spelling); `label` keeps the descriptive name
+                    if L.lib().esr_prof_kernel_symbol(prof, i, buf, 256) == 0 and buf.value:
+                        c["kernel"] = buf.value.decode()
                     out.append(c)
         return out
 

@@ -257,3 +257,98 @@ def channel_attention(x, w1, b1, w2, b2, *, contrast=False, nchw=False, out=None
     stream = torch.cuda.current_stream(x.device).cuda_stream
     L.check(L.lib().esr_channel_attention_f32(ctypes.byref(d), ctypes.c_void_p(stream)), "esr_channel_attention_f32")
     return y
+
+
+def esa_apply(x, c1, c3, wf, bf, w4, b4, *, out=None):
+    """ESA's full-resolution tail in one launch (esr_esa_apply_f32): y = x * sigmoid(conv4(bilinear(c3 -> HxW) + conv_f(c1)))
+    (models/rfdn_baseline/block.py:124-129).  x: NHWC [N,H,W,pitch] (fp32 / bf16 / fp16 storage), c channels = w4.shape[0];
+    c1: NHWC [N,H,W,16] of the same dtype (conv1's output, f = wf.shape[0] <= 16 channels, pads zero); c3: fp32 NHWC [N,h_lo,w_lo,16];
+    wf [f,f(,1,1)], w4 [c,f(,1,1)]."""
+    from .engine import pack_dense
+    if not x.is_cuda:
+        raise L.EsrError("esa_apply: tensors must live on the GPU; there is no CPU fallback")
+    n, h, w, pitch = x.shape
+    c, f = w4.shape[0], wf.shape[0]
+    cp4 = (c + 3) // 4 * 4
+    keep = [pack_dense(wf.reshape(f, f, 1, 1), bf, 16, 16).to(x.device), pack_dense(w4.reshape(c, f, 1, 1), b4, 16, cp4).to(x.device)]
+    y = torch.zeros_like(x) if out is None else out
+    d = L.EsaDesc()
+    d.n, d.h, d.w, d.c, d.f, d.h_lo, d.w_lo = n, h, w, c, f, c3.shape[1], c3.shape[2]
+    d.storage = L.STORE[_STORE_OF[x.dtype]]
+    d.x, d.y = _view(x), _view(y)
+    d.c1, d.c3, d.w0, d.w1 = c1.data_ptr(), c3.data_ptr(), keep[0].data_ptr(), keep[1].data_ptr()
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    L.check(L.lib().esr_esa_apply_f32(ctypes.byref(d), ctypes.c_void_p(stream)), "esr_esa_apply_f32")
+    return y
+
+
+# ---- torch.library operators over the kernels --------------------------------------------------------------------------------
+# The "thin PyTorch-ROCm custom-op layer" of BASELINE.json's north star at KERNEL granularity (engine.py registers the whole-network
+# op esr::sr_forward): every hot kernel family is a registered operator with a fake (shape) implementation, so FakeTensor tracing /
+# torch.compile / export see opaque ops instead of ctypes calls.  Real implementations = the functions above; tensors are NHWC views
+# as the C ABI sees them.  These replace nn.Conv2d + activation (+ residual) (models/basicblock.py:61-98), BSConvU
+# (models/team18_bsrn.py:44-88), the ESA tail (models/rfdn_baseline/block.py:124-129) and CALayer / CCALayer
+# (models/basicblock.py:333-348, models/team05_efdn/plainblock.py:106-122).
+from typing import Optional  # noqa: E402
+
+Tensor = torch.Tensor
+
+
+def _pad_c(c, dtype):
+    g = 4 if dtype == torch.float32 else 8
+    return (c + g - 1) // g * g
+
+
+@torch.library.custom_op("esr::conv2d", mutates_args=())
+def conv2d_op(x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int, slope: float, res: Optional[Tensor], res_mode: int,
+              winograd: bool) -> Tensor:
+    """act(conv(x) [+ res]) on NHWC x [N,H,W,pitch >= cin]; weight OIHW (k = 1 | 3); returns NHWC [N,H,W,pad(cout)].
+    winograd: fp32 3x3 as Winograd F(2x2,3x3) when the shape qualifies (esr_wino_supported), else the direct kernel."""
+    d = L.ConvDesc()
+    d.ksize, d.in_layout, d.out_layout, d.cin, d.cout = weight.shape[2], L.NHWC, L.NHWC, weight.shape[1], weight.shape[0]
+    d.inp = L.View(None, x.shape[-1], 0)
+    d.res_mode = res_mode
+    use_wino = bool(winograd) and x.dtype == torch.float32 and bool(L.lib().esr_wino_supported(ctypes.byref(d)))
+    return conv2d(x, weight, bias, act=act, slope=slope, res=res, res_mode=res_mode, wino=use_wino)
+
+
+@conv2d_op.register_fake
+def _conv2d_fake(x, weight, bias, act, slope, res, res_mode, winograd):
+    if x.dim() != 4 or weight.dim() != 4 or weight.shape[2] not in (1, 3) or weight.shape[1] > x.shape[-1]:
+        raise L.EsrError("esr::conv2d: NHWC x [N,H,W,pitch >= cin], OIHW weight with k in {1, 3}")
+    return x.new_empty((x.shape[0], x.shape[1], x.shape[2], _pad_c(weight.shape[0], x.dtype)))
+
+
+@torch.library.custom_op("esr::bsconv", mutates_args=())
+def bsconv_op(x: Tensor, pw_weight: Tensor, pw_bias: Optional[Tensor], dw_weight: Tensor, dw_bias: Optional[Tensor], act: int,
+              slope: float, res: Optional[Tensor], res_mode: int) -> Tensor:
+    """BSConvU in one launch: act(dw3x3(pw1x1(x)) [+ res]); NHWC in / out"""
+    return bsconv(x, pw_weight, pw_bias, dw_weight, dw_bias, act=act, slope=slope, res=res, res_mode=res_mode)
+
+
+@bsconv_op.register_fake
+def _bsconv_fake(x, pw_weight, pw_bias, dw_weight, dw_bias, act, slope, res, res_mode):
+    return x.new_empty((x.shape[0], x.shape[1], x.shape[2], (pw_weight.shape[0] + 3) // 4 * 4))
+
+
+@torch.library.custom_op("esr::esa_apply", mutates_args=())
+def esa_apply_op(x: Tensor, c1: Tensor, c3: Tensor, wf: Tensor, bf: Optional[Tensor], w4: Tensor, b4: Optional[Tensor]) -> Tensor:
+    """x * sigmoid(conv4(bilinear(c3) + conv_f(c1))): ESA's full-resolution tail"""
+    return esa_apply(x, c1, c3, wf, bf, w4, b4)
+
+
+@esa_apply_op.register_fake
+def _esa_apply_fake(x, c1, c3, wf, bf, w4, b4):
+    return torch.empty_like(x)
+
+
+@torch.library.custom_op("esr::channel_attention", mutates_args=())
+def channel_attention_op(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], contrast: bool,
+                         nchw: bool) -> Tensor:
+    """CALayer (contrast = False) / CCALayer (True): x * sigmoid(W2 . relu(W1 . s + b1) + b2)"""
+    return channel_attention(x, w1, b1, w2, b2, contrast=contrast, nchw=nchw)
+
+
+@channel_attention_op.register_fake
+def _channel_attention_fake(x, w1, b1, w2, b2, contrast, nchw):
+    return torch.empty_like(x)

@@ -165,3 +165,31 @@ def test_forwards_on_several_streams_equal_serial(name, compute):
     assert len(m._ctxs) == 5 and len({c.ws.data_ptr() for c in m._ctxs.values()}) == 5      # default stream + 4, one workspace each
     assert all(k[0] == dev for k in m._ctxs)
     m.set_compute("f32")
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
+@pytest.mark.parametrize("name", ["imdn_baseline", "rfdn_baseline", "team04_rlfn", "team18_bsrn"])
+def test_16bit_batch_equals_per_image(name, compute):
+    """images of a batch are independent in the 16-bit plans too (esr_pack_input_s16, Planar concats, the two-blocks-per-CU
+    shapes at N > 1): model(x[B = 4]) == cat(model(x[i])) bit for bit, all four networks, 256 x 256"""
+    m, dr = _model(name, compute)
+    x = torch.rand(4, 3, 256, 256, generator=torch.Generator().manual_seed(3)).to(DEV) * dr
+    y = m(x)
+    assert tuple(y.shape) == (4, 3, 1024, 1024) and bool(torch.isfinite(y).all())
+    for i in range(4):
+        assert torch.equal(y[i:i + 1], m(x[i:i + 1].contiguous())), (name, compute, i)
+
+
+@pytest.mark.parametrize("name,compute,h,w", [("team04_rlfn", "bf16", 256, 256), ("team18_bsrn", "f16", 270, 480),
+                                              ("rfdn_baseline", "bf16", 256, 256), ("imdn_baseline", "f32", 256, 256)])
+def test_bench_batch32_image0_equals_single_forward(name, compute, h, w):
+    """the bench workloads (BASELINE.json configs, batch 32 per GPU): image 0 and image 31 of the batch-32 forward are bit-identical
+    to the N = 1 forwards of those images, and image 0 of a natural-image batch reproduces the reference fixture's PSNR budget"""
+    m, dr = _model(name, compute)
+    x = torch.rand(32, 3, h, w, generator=torch.Generator().manual_seed(11)).to(DEV) * dr
+    y = m(x)
+    assert tuple(y.shape) == (32, 3, 4 * h, 4 * w)
+    for i in (0, 31):
+        assert torch.equal(y[i:i + 1], m(x[i:i + 1].contiguous())), (name, compute, i)
+    del y
+    torch.cuda.empty_cache()

@@ -334,3 +334,34 @@ def test_conv_with_post_1x1(n, hw, c, pc, res_in):
                        post_weight=wp, post_bias=bp, post_act=1)
     _check(y, r)
     _check(yd, dref)
+
+
+def test_kernel_level_custom_ops_run_the_hip_kernels():
+    """torch.ops.esr.conv2d / esa_apply (ops.py: torch.library operators over the C ABI) against ATen"""
+    from ntire2022_esr_amd import ops  # noqa: F401
+    dev = _dev()
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 64, 33, 47, generator=g)
+    r = torch.randn(2, 64, 33, 47, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    b = torch.randn(64, generator=g)
+    for wino in (False, True):
+        y = torch.ops.esr.conv2d(_nhwc(x).to(dev), w, b, 1, 0.05, _nhwc(r).to(dev), 1, wino)
+        _check(y, F.leaky_relu(F.conv2d(x, w, b, padding=1) + r, 0.05))
+    y1 = torch.ops.esr.conv2d(_nhwc(x).to(dev), w[:, :, 1:2, 1:2].contiguous(), None, 0, 0.05, None, 0, True)     # 1x1: the direct kernel
+    _check(y1, F.conv2d(x, w[:, :, 1:2, 1:2]))
+    c, f, hw, lo = 50, 12, (40, 56), (5, 8)
+    xx = torch.randn(2, c, *hw, generator=g) * 30
+    c1 = torch.randn(2, f, *hw, generator=g)
+    c3 = torch.randn(2, f, *lo, generator=g)
+    wf, bf = torch.randn(f, f, generator=g) * 0.3, torch.randn(f, generator=g)
+    w4, b4 = torch.randn(c, f, generator=g) * 0.3, torch.randn(c, generator=g)
+    ref = xx * torch.sigmoid(F.conv2d(F.interpolate(c3, hw, mode="bilinear", align_corners=False) + F.conv2d(c1, wf[:, :, None, None], bf),
+                                      w4[:, :, None, None], b4))
+
+    def pad16(t, p):
+        o = torch.zeros(t.shape[0], t.shape[2], t.shape[3], p)
+        o[..., :t.shape[1]] = t.permute(0, 2, 3, 1)
+        return o.to(dev)
+    ye = torch.ops.esr.esa_apply(pad16(xx, 56), pad16(c1, 16), pad16(c3, 16), wf, bf, w4, b4)
+    _check(ye[..., :c], ref)

@@ -79,10 +79,18 @@ def test_forward_is_a_registered_custom_op_with_fake_impl():
     with FakeTensorMode():
         y = m(torch.empty(2, 3, 40, 56))                              # shape function only, nothing runs
         assert tuple(y.shape) == (2, 3, 160, 224) and y.dtype == torch.float32
-    y = torch.ops.esr.sr_forward(torch.empty(1, 3, 17, 15, device="meta"), id(m))
+    y = torch.ops.esr.sr_forward(torch.empty(1, 3, 17, 15, device="meta"), m.handle)
     assert tuple(y.shape) == (1, 3, 68, 60)
     with pytest.raises(Exception):
         torch.ops.esr.sr_forward(torch.empty(1, 3, 17, 15, device="meta"), 12345)       # no live model with that handle
+    # handles come from a counter: never recycled, gone from the registry with their module
+    h = m.handle
+    m2 = IMDN()
+    assert m2.handle > h and engine._LIVE.get(h) is m
+    del m, y
+    import gc
+    gc.collect()
+    assert engine._LIVE.get(h) is None and IMDN().handle > m2.handle
     r = RFDN()
     with FakeTensorMode():
         assert tuple(r(torch.empty(1, 3, 33, 21)).shape) == (1, 3, 132, 84)
@@ -188,3 +196,28 @@ print("ok", round(psnr, 2))
     out = subprocess.run([sys.executable, "-c", code, str(tmp_path)], capture_output=True, text=True, env=env, cwd=SHIM, timeout=300)
     assert out.returncode == 0, out.stderr[-3000:]
     assert out.stdout.strip().splitlines()[-1].startswith("ok ")
+
+
+def test_kernel_level_custom_ops_are_registered_with_fake_impls():
+    """BASELINE.json north star: "a thin PyTorch-ROCm custom-op layer exposes these [kernels]" -- esr::conv2d / esr::bsconv /
+    esr::esa_apply / esr::channel_attention are registered operators whose fake implementations give the output shapes (FakeTensor
+    tracing works without a GPU); the real ones refuse CPU tensors like every op of this engine."""
+    from ntire2022_esr_amd import _lib as L, ops  # noqa: F401  (registers the operators)
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    for name in ("conv2d", "bsconv", "esa_apply", "channel_attention", "sr_forward"):
+        assert hasattr(torch.ops.esr, name), name
+    with FakeTensorMode():
+        x = torch.empty(2, 40, 56, 64)
+        y = torch.ops.esr.conv2d(x, torch.empty(50, 64, 3, 3), torch.empty(50), 1, 0.05, None, 0, True)
+        assert tuple(y.shape) == (2, 40, 56, 52)
+        yb = torch.ops.esr.conv2d(x.to(torch.bfloat16), torch.empty(50, 64, 1, 1), None, 0, 0.05, None, 0, False)
+        assert tuple(yb.shape) == (2, 40, 56, 56) and yb.dtype == torch.bfloat16
+        z = torch.ops.esr.bsconv(torch.empty(1, 20, 20, 48), torch.empty(48, 48), None, torch.empty(48, 1, 3, 3), None, 3, 0.05, None, 0)
+        assert tuple(z.shape) == (1, 20, 20, 48)
+        e = torch.ops.esr.esa_apply(torch.empty(1, 30, 30, 56), torch.empty(1, 30, 30, 16), torch.empty(1, 4, 4, 16), torch.empty(12, 12),
+                                    None, torch.empty(50, 12), None)
+        assert tuple(e.shape) == (1, 30, 30, 56)
+        c = torch.ops.esr.channel_attention(torch.empty(2, 64, 24, 24), torch.empty(4, 64), None, torch.empty(64, 4), None, True, True)
+        assert tuple(c.shape) == (2, 64, 24, 24)
+    with pytest.raises(Exception):
+        torch.ops.esr.conv2d(torch.rand(1, 8, 8, 64), torch.rand(64, 64, 3, 3), None, 0, 0.05, None, 0, True)      # CPU tensor: no fallback

@@ -5,7 +5,16 @@ usage: make_ws_dbg.py [variant]   variants: plain | probe | noepi | solo | solo_
 import os, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 s = open(os.path.join(R, 'ntire2022_esr_amd/csrc/esr_hip.hip')).read()
-s = s.replace('#include "experimental/conv_ws.inc"        // wave-specialised research variant (tools/dbg builds only; see DESIGN.md)\n', open(os.path.join(R, 'ntire2022_esr_amd/csrc/experimental/conv_ws.inc')).read())
+# the product source carries no research hooks: put them back into this private copy (tools/dbg/ws_hooks.py)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ws_hooks
+WS_INC = open(os.path.join(R, 'tools/dbg/conv_ws.inc')).read()
+for anchor, text in ws_hooks.HOOKS:
+    assert anchor in s, anchor[:60]
+    if text is None:                       # the launcher goes in FRONT of launch_conv_nt
+        s = s.replace(anchor, ws_hooks.LAUNCHER + "\n" + anchor, 1)
+    else:
+        s = s.replace(anchor, anchor + text.replace('@@CONV_WS_INC@@', WS_INC), 1)
 def rep(a, b, count=1):
     global s
     assert a in s, a[:70]

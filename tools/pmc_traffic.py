@@ -7,7 +7,8 @@ Each pass:  rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -d <dir
 Counter units are KB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies 128-byte requests at
 64 B, so read bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact.  Infinity-Cache hits are counted, so this is fabric traffic,
 an upper bound on HBM traffic.  The algorithmic bytes come from the op list of the model (engine.op_costs).
-The file is keyed by workload ("<model>:<compute>:<batch>x<H>x<W>"), then by kernel label; an existing file is updated."""
+The file is keyed by workload ("<model>:<compute>:<batch>x<H>x<W>", or "<model>:<compute>:div2k" for --sizes div2k), then by
+device symbol (the spelling of esr_prof_kernel_symbol = rocprofv3's, namespace and argument list dropped); an existing file is updated."""
 import argparse
 import collections
 import csv
@@ -33,34 +34,13 @@ def per_kernel(d, counter):
     return {k: (v[0], v[1]) for k, v in acc.items()}        # total, launches
 
 
-def label(sym, compute):
-    """rocprofv3 kernel symbol -> the kernel label of engine.op_costs / bench.py"""
-    m = re.search(r"conv_f32_kernel<(\d+), (\d+), (true|false), (\d+), (\d+), (\d+)(?:, (true|false))?>", sym)
-    if m:
-        base = f"conv_f32_kernel<NT={m.group(1)},KS={m.group(2)},NCHW_IN={int(m.group(3) == 'true')},NW={m.group(4)}"
-        if m.group(5) != "0":
-            base += f",TAIL={m.group(5)}"
-        if m.group(6) != "0":
-            base += f",POST={m.group(6)}"
-        if m.group(7) == "true":
-            base += ",BLK"                  # split store into a channel-blocked out1 (esr_conv_desc.blocked8)
-        return base + ">"
-    m = re.search(r"imdb_tail_kernel<(true|false)>", sym)
-    if m:
-        return f"imdb_tail_kernel<FOLD={int(m.group(1) == 'true')}>"
-    m = re.search(r"conv_s16_kernel<(\d+), (\d+), (\d+), (true|false), (true|false), (\d+), (\d+)>", sym)
-    if m:
-        base = f"conv_s16_kernel<NT={m.group(1)},KS={m.group(2)},NW={m.group(3)},{compute}"
-        if m.group(6) != "0":
-            base += f",POST={m.group(6)}" + (f"+{m.group(7)}" if m.group(7) != "0" else "")
-        return base + ">"
-    m = re.search(r"bsconv_kernel<(\d+), (\d+), (\d+)>", sym)
-    if m:
-        return f"bsconv_kernel<NTP={m.group(1)},NTD={m.group(2)}>"
-    for k in ("esa_apply", "dwconv3x3_kernel", "conv3x3s2_kernel", "maxpool7s3_kernel"):
-        if k in sym:
-            return "esa_apply_kernel" if k == "esa_apply" else k
-    return None
+def normalize(sym):
+    """rocprofv3 kernel name -> the spelling of esr_prof_kernel_symbol: 'void (anonymous namespace)::wino_f32_kernel<1, 0, 0>((anonymous
+    namespace)::WinoK)' -> 'wino_f32_kernel<1, 0, 0>'"""
+    m = re.search(r"([A-Za-z_0-9]+_kernel)(<[^()]*?>)?\(", sym)
+    if not m:
+        m = re.search(r"([A-Za-z_0-9]+_kernel)(<[^()]*?>)?", sym)
+    return (m.group(1) + (m.group(2) or "")) if m else None
 
 
 def main():
@@ -69,7 +49,8 @@ def main():
     ap.add_argument("--model", default="imdn_baseline")
     ap.add_argument("--compute", default="f32")
     ap.add_argument("--tile", default="256x256")
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--sizes", default="tile")
     a, _ = ap.parse_known_args(sys.argv[5:])
     import torch
     import bench
@@ -77,23 +58,34 @@ def main():
     m, _, dr, _ = select_model(bench.MODELS[a.model][0], torch.device("cuda:0"))
     m.set_compute(a.compute)
     h, w = (int(v) for v in a.tile.split("x"))
-    ent = m.prepare((a.batch, 3, h, w), "cuda:0")
+    if a.sizes == "div2k":
+        batch, shapes, key = a.batch or 1, bench.DIV2K_LR_SHAPES, f"{a.model}:{a.compute}:div2k"
+    else:
+        batch, shapes = a.batch or 32, [(h, w)]
+        key = f"{a.model}:{a.compute}:{batch}x{h}x{w}"
+    # algorithmic bytes per device symbol: one profiled forward per shape of the step (the library names the symbol of every op)
+    m.enable_profiling(1)
+    with torch.no_grad():
+        for sh in shapes:
+            m(torch.rand(batch, 3, sh[0], sh[1], device="cuda:0") * dr)
+    torch.cuda.synchronize()
     algo = collections.defaultdict(lambda: [0.0, 0.0, 0])
-    for o in m.op_costs(ent.plan, ent.arr):
-        x = algo[o["kernel"]]
-        x[0] += o["read_bytes"]; x[1] += o["write_bytes"]; x[2] += 1
+    for o in m.collect_profile():
+        for sym in o["kernel"].split(" + "):               # (an op lowered to two launches: bytes attributed to the first)
+            x = algo[sym]
+            x[0] += o["read_bytes"] * o["passes"]; x[1] += o["write_bytes"] * o["passes"]; x[2] += o["passes"]
+            break
+    m.disable_profiling()
     fetch, write = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
-    # several device symbols can share a label (the residual / no-residual variants of conv_s16_kernel): totals, then per launch
     tot = collections.defaultdict(lambda: [0.0, 0.0, 0])
     for sym, (fkb, n) in fetch.items():
-        lab = label(sym, a.compute)
+        lab = normalize(sym)
         if lab is None or lab not in algo:
             continue
         t = tot[lab]
         t[0] += fkb; t[1] += write.get(sym, (0.0, 0))[0]; t[2] += n
     res = json.load(open(out)) if os.path.exists(out) else {}
     res["_how"] = __doc__.split("usage:")[1].strip()
-    key = f"{a.model}:{a.compute}:{a.batch}x{h}x{w}"
     cur = {"_round": tag}
     for lab, (fkb, wkb, n) in tot.items():
         ar, aw, na = algo[lab]

@@ -141,6 +141,11 @@ def parse_args():
                          "div2k).  One image per forward leaves most of the chip idle (352 tiles on 256 CUs, a third of the "
                          "launches latency-bound low-resolution kernels); every stream has its own workspace in the engine, so "
                          "independent images overlap.  --streams 1 is the reference's strictly serial loop")
+    ap.add_argument("--dataset", type=int, default=0, metavar="N",
+                    help="with --sizes div2k: one step = a synthetic N-image DIV2K-shaped list (shapes cycle through DIV2K_LR_SHAPES) "
+                         "SHARDED round-robin over the ranks (image i -> rank i mod W, test_demo.py:416 loop -> dist.shard), per-image "
+                         "runtimes gathered once after the timed region (dist.gather_rows): BASELINE.json config [3] with N = 200 "
+                         "(DIV2K valid + test).  The total work is fixed, so the line says \"scaling\": \"strong\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--b1-latency", action="store_true",
                     help="also report the latency of a single-image forward (extra launches after the timed region: "
@@ -189,25 +194,42 @@ def main():
         if not selftest:
             torch.cuda.synchronize(device)
 
-    def reduce_elapsed(elapsed):
+    def device_identity():
+        """what tells two GPUs of a node apart: UUID (when torch exposes it) and PCI address"""
+        if selftest:
+            return f"cpu:{socket.gethostname()}:{os.getpid()}"
+        pr = torch.cuda.get_device_properties(device)
+        uuid = str(getattr(pr, "uuid", ""))
+        pci = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+        return f"{pr.name}|{uuid}|{pci}"
+
+    def reduce_elapsed(elapsed, images=0):
+        """MAX over ranks of the elapsed time (all_reduce) + one record per rank gathered over the same process group (RCCL on GPUs):
+        rank, its own elapsed time, its images, the identity of its device -- a multi-GPU line proves by itself that N distinct
+        devices took part and how evenly they ran."""
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        seen = [rank]
+        recs = [{"rank": rank, "elapsed_s": round(elapsed, 6), "images": images, "device": device_identity()}]
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            r = torch.tensor([rank], dtype=torch.int64, device=device)
-            allr = [torch.zeros_like(r) for _ in range(world)]
-            dist.all_gather(allr, r)
-            seen = sorted(int(v.item()) for v in allr)
-        return float(t.item()), seen
+            recs = [None] * world
+            dist.all_gather_object(recs, {"rank": rank, "elapsed_s": round(elapsed, 6), "images": images, "device": device_identity()})
+            recs.sort(key=lambda r: r["rank"])
+        for r in recs:
+            r["images_per_s"] = round(r["images"] / r["elapsed_s"], 2) if r["elapsed_s"] > 0 else None
+        devs = sorted({r["device"] for r in recs})
+        if len(devs) != world:
+            raise SystemExit(f"{world} ranks but {len(devs)} distinct devices: {devs}")
+        return float(t.item()), recs
 
     if selftest:
         barrier()
         t0 = time.perf_counter()
         time.sleep(0.01 * (rank + 1))
         barrier()
-        elapsed, seen = reduce_elapsed(time.perf_counter() - t0)
+        elapsed, recs = reduce_elapsed(time.perf_counter() - t0)
+        seen = [r["rank"] for r in recs]
         if rank == 0:
-            print(json.dumps({"launcher_selftest": True, "n_gpus": world, "ranks_seen": seen,
+            print(json.dumps({"launcher_selftest": True, "n_gpus": world, "ranks_seen": seen, "ranks": recs,
                               "max_elapsed_s": round(elapsed, 4), "note": "no forward was run; not a measurement"}), flush=True)
         if dist is not None:
             dist.barrier()
@@ -224,10 +246,18 @@ def main():
     else:
         B = args.batch or 32
         shapes = [(th, tw)]
-    gen = torch.Generator().manual_seed(rank)
+    sharded = args.sizes == "div2k" and args.dataset > 0
+    gen = torch.Generator().manual_seed(0 if sharded else rank)       # sharded: every rank holds the same image list
     xs = [(torch.rand(B, 3, h, w, generator=gen) * dr).to(device) for h, w in shapes]
-    imgs_per_step = B * len(xs)
-    gflop_per_step = sum(B * gflop256 * (h * w) / 65536.0 for h, w in shapes)
+    if sharded:
+        from ntire2022_esr_amd import dist as D
+        my_items = D.shard(args.dataset, rank, world)                 # image i -> rank i mod W
+        imgs_per_step = B * len(my_items)
+        gflop_per_step = sum(B * gflop256 * (shapes[i % len(shapes)][0] * shapes[i % len(shapes)][1]) / 65536.0 for i in my_items)
+    else:
+        my_items = list(range(len(xs)))
+        imgs_per_step = B * len(xs)
+        gflop_per_step = sum(B * gflop256 * (h * w) / 65536.0 for h, w in shapes)
     nstreams = max(1, args.streams if args.streams is not None else (4 if args.sizes == "div2k" else 1))
     streams = [torch.cuda.Stream(device) for _ in range(nstreams)] if nstreams > 1 else None
     if args.sizes == "tile" and nstreams > 1:
@@ -242,13 +272,14 @@ def main():
     events_after = not args.no_kernel_events and not events_in_region
 
     def step(spread=True):
+        y = None
         if streams is None or not spread:
-            for x in xs:
-                y = model(x)
+            for i in my_items:
+                y = model(xs[i % len(xs)])
         else:
-            for i, x in enumerate(xs):
-                with torch.cuda.stream(streams[i % nstreams]):
-                    y = model(x)
+            for k, i in enumerate(my_items):
+                with torch.cuda.stream(streams[k % nstreams]):
+                    y = model(xs[i % len(xs)])
         return y
 
     with torch.no_grad():
@@ -280,8 +311,30 @@ def main():
                 step(False)
             torch.cuda.synchronize(device)
             instrumented_ms = (time.perf_counter() - t1) / args.steps * 1e3
-    assert tuple(y.shape) == (xs[-1].shape[0], 3, 4 * shapes[-1][0], 4 * shapes[-1][1])
-    elapsed, seen = reduce_elapsed(elapsed)
+    if my_items:
+        hl, wl_ = shapes[my_items[-1] % len(shapes)]
+        assert tuple(y.shape) == (xs[my_items[-1] % len(xs)].shape[0], 3, 4 * hl, 4 * wl_)
+    elapsed, recs = reduce_elapsed(elapsed, imgs_per_step * args.steps)
+    seen = [r["rank"] for r in recs]
+    per_image = None
+    if sharded:
+        # the reference's per-image runtime (test_demo.py:429-433: an event pair around each forward), one extra pass over this
+        # rank's shard on ONE stream; rows gathered ONCE over the process group and averaged in index order (dist.gather_rows)
+        rows = []
+        with torch.no_grad():
+            for i in my_items:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                model(xs[i % len(xs)])
+                e1.record()
+                rows.append((i, e0, e1))
+            torch.cuda.synchronize(device)
+        rows = [(i, e0.elapsed_time(e1), float("nan"), float("nan")) for i, e0, e1 in rows]
+        allrows = D.gather_rows(rows, args.dataset, rank, world, device)
+        per_image = {"images": int(args.dataset), "ave_runtime_ms": round(D.ordered_mean(allrows[:, 1]), 4),
+                     "max_runtime_ms": round(float(allrows[:, 1].max()), 4), "gathered_rows": int(len(allrows)),
+                     "how": "one event pair per forward in an extra pass on one stream (test_demo.py:429-433), rows gathered with one "
+                            "all_gather_into_tensor and averaged in index order in float64 (ntire2022_esr_amd/dist.py)"}
 
     roofline = None
     if not args.no_kernel_events:
@@ -353,30 +406,35 @@ def main():
                               f"timed region ({instrumented_ms:.3f} ms/step with the events; the timed region carries none)")
 
     if rank == 0:
-        imgs = world * imgs_per_step * args.steps
+        imgs = sum(r["images"] for r in recs)
         value = imgs / elapsed
         if args.sizes == "div2k":
             wl = (f"{args.model} x4 {args.compute}, DIV2K-val-shaped LR images {sorted(set(shapes))} "
-                  f"({len(shapes)} per step, B = {B} per forward, forwards spread over {nstreams} HIP stream(s))")
+                  f"({args.dataset if sharded else len(shapes)} per step{' SHARDED round-robin over the ranks' if sharded else ''}, "
+                  f"B = {B} per forward, forwards spread over {nstreams} HIP stream(s))")
             metric = "images/sec (DIV2K-val-shaped LR ~339x510 -> x4)"
         else:
             wl = f"{args.model} x4 {args.compute}, {B}x3x{th}x{tw} LR batch per GPU -> {B}x3x{4 * th}x{4 * tw}"
             if nstreams > 1:
                 wl += f" ({nstreams} sub-batches of {B // nstreams}, one HIP stream each)"
             metric = f"images/sec ({th}x{tw}->{4 * th}x{4 * tw} x4)"
-        model_tflops = world * gflop_per_step * args.steps / elapsed / 1e3       # algorithmic (direct-convolution) flops: SURVEY 8d
+        gflop_all = gflop_per_step * world if not sharded else sum(
+            B * gflop256 * (shapes[i % len(shapes)][0] * shapes[i % len(shapes)][1]) / 65536.0 for i in range(args.dataset))
+        model_tflops = gflop_all * args.steps / elapsed / 1e3       # algorithmic (direct-convolution) flops: SURVEY 8d
         out = {
             "metric": metric,
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.compute,
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": args.compute,
             "data": f"synthetic (uniform [0,{dr:g}) LR tiles resident in HBM; weights: {weights})",
             "config": {"workload": wl, "batch_per_gpu": B, "streams_per_gpu": nstreams,
                        "parallelism": f"image-parallel replicas x{world}",
                        "algorithmic_gflop_per_step_per_gpu": round(gflop_per_step, 2)},
             "ranks_seen": seen,
+            "ranks": recs,                      # per rank: its own elapsed time, images, images/s, device identity (N distinct, checked)
+            "per_image": per_image,
             "model_tflops": round(model_tflops, 2),                   # direct-equivalent (algorithmic flops / time)
-            "model_executed_tflops": None if roofline is None else round(exec_per_step / (elapsed / args.steps) / 1e12, 2),
+            "model_executed_tflops": None if roofline is None else round(world * exec_per_step / (elapsed / args.steps) / 1e12, 2),
             "model_frac_of_mfma_peak": None if roofline is None else round(exec_per_step / (elapsed / args.steps) / 1e12 / peak, 4),
             "roofline": roofline,
         }

@@ -1,0 +1,73 @@
+"""-m gpu: the stated-size parity budgets on EIGHT DIV2K-val-shaped 339x510 images of different textures instead of one
+(tests/golden/multi/, generated from the real reference by tools/gen_golden_r3.py): three mini_div2k photographs, test.bmp rolled /
+flipped / shifted, two noise tiles with 1/f and 1/f^2 spectra -- mirror-tiled to 1356x2040 as HR, PIL-bicubic LR stored.
+Asserted: fp32 -- every image's SR sample <= 2e-5 * data_range from the reference's and
+|dPSNR| <= 0.002 dB; 16-bit modes -- the MEAN |dPSNR| against the REFERENCE's PSNR over the eight images <= 0.01 dB (bf16) /
+0.005 dB (fp16), no single image beyond twice that."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from conftest import GOLD
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+IDS = {"imdn_baseline": -1, "rfdn_baseline": 0, "team04_rlfn": 4, "team18_bsrn": 18}
+H, W = 339, 510
+_models = {}
+
+
+def _model(name, compute):
+    from ntire2022_esr_amd.registry import select_model
+    if name not in _models:
+        _models[name] = select_model(IDS[name], torch.device(DEV))
+    m, _, dr, _ = _models[name]
+    m.set_compute(compute)
+    return m, dr
+
+
+def hr_source(k):
+    """the k-th HR image, rebuilt exactly as tools/gen_golden_r3.py built it"""
+    bmp = np.array(Image.open(os.path.join(GOLD, "test.bmp")).convert("RGB"))
+    mini = lambda n: np.array(Image.open(os.path.join(GOLD, "mini_div2k", "DIV2K_valid_HR", n)).convert("RGB"))
+    noise = lambda n: np.array(Image.open(os.path.join(GOLD, "multi", n)).convert("RGB"))
+    src = [lambda: mini("0801.png"), lambda: mini("0802.png"), lambda: mini("0803.png"),
+           lambda: np.roll(bmp, (97, 53), axis=(0, 1)), lambda: np.ascontiguousarray(bmp[:, ::-1].transpose(1, 0, 2)),
+           lambda: noise("src_noise_f1.png"), lambda: noise("src_noise_f2.png"), lambda: np.roll(bmp, (128, 128), axis=(0, 1))][k]()
+    return np.pad(src, ((0, 4 * H - src.shape[0]), (0, 4 * W - src.shape[1]), (0, 0)), mode="symmetric")
+
+
+def _psnrs(name, compute):
+    from ntire2022_esr_amd import image_util as util
+    m, dr = _model(name, compute)
+    out = []
+    for k in range(8):
+        g = np.load(os.path.join(GOLD, "multi", f"multi_{k}.npz"))
+        assert float(g[f"{name}_dr"]) == dr and g["lr"].shape == (H, W, 3)
+        y = m(util.uint2tensor4(g["lr"], dr).to(DEV))
+        err = float(np.abs(y[0, :, ::31, ::31].cpu().numpy().astype(np.float64) - g[f"{name}_sample"]).max()) / dr
+        psnr = util.calculate_psnr(util.tensor2uint(y, dr), hr_source(k), border=4)
+        out.append((psnr - float(g[f"{name}_psnr"]), err, float(g[f"{name}_psnr"])))
+    return out
+
+
+@pytest.mark.parametrize("name", ["imdn_baseline", "rfdn_baseline", "team04_rlfn", "team18_bsrn"])
+def test_fp32_eight_textures(name):
+    r = _psnrs(name, "f32")
+    print(name, "f32 dPSNR", [round(d, 5) for d, _, _ in r], "max sample err", max(e for _, e, _ in r))
+    for d, err, _ in r:
+        assert err < 2e-5, err
+        assert abs(d) <= 0.002, d
+
+
+@pytest.mark.parametrize("name,compute,budget", [("team04_rlfn", "bf16", 0.01), ("rfdn_baseline", "bf16", 0.01), ("imdn_baseline", "bf16", 0.01),
+                                                 ("team18_bsrn", "f16", 0.005), ("team18_bsrn", "bf16", 0.01), ("team04_rlfn", "f16", 0.005)])
+def test_16bit_mean_psnr_budget_over_eight_textures(name, compute, budget):
+    r = _psnrs(name, compute)
+    ds = [d for d, _, _ in r]
+    print(name, compute, "dPSNR per image", [round(d, 5) for d in ds], "mean |d|", round(float(np.mean(np.abs(ds))), 5))
+    assert float(np.mean(np.abs(ds))) <= budget, ds
+    assert max(abs(d) for d in ds) <= 2 * budget, ds

@@ -623,6 +623,13 @@ class HipSRModel(nn.Module):
     def _mark_dirty(self):
         self._dirty = True
 
+    def invalidate_workspaces(self):
+        """Forget what the per-stream workspaces hold: the next forward on each stream zero-fills before it runs.  For callers that
+        saw a non-finite output (overflowing activations in a 16-bit mode): with rezero_on_switch = False another shape's pad
+        channels may lie where Inf / NaN were stored, and 0 * Inf = NaN would reach its results."""
+        for ctx in self._ctxs.values():
+            ctx.ws_owner = None
+
     def _apply(self, fn, *args, **kwargs):          # .to() / .cuda() / .float(): parameters move or change
         self._dirty = True
         return super()._apply(fn, *args, **kwargs)

@@ -160,10 +160,17 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
         nxt = len(ahead)
         inflight, writes = [], []
 
+        prep_ms = []
+
         def retire():
-            i, start, end, done, sr_host, se_dev, count, img_hr = inflight.pop(0)
+            i, start, end, done, sr_host, se_dev, count, img_hr, fin_dev = inflight.pop(0)
             done.synchronize()                                   # this image's D2H (and everything before it) has finished
             ms = start.elapsed_time(end)
+            if not bool(fin_dev.item()) and hasattr(model, "invalidate_workspaces"):
+                # Inf / NaN in this output (activations overflowed, 16-bit modes): the workspaces are shared between shapes without
+                # re-zeroing, so isolate the following images from whatever this one left in other shapes' pad slots
+                logger.warning("non-finite values in the output of image %d: workspaces will be cleared", i)
+                model.invalidate_workspaces()
             se = int(se_dev.item())
             psnr = float("inf") if se == 0 else 20 * math.log10(255.0 / math.sqrt(se / count))
             img_sr = sr_host.numpy()
@@ -183,11 +190,14 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
                     # (test_demo.py:429-432 brackets model(img_lq) only); whole-image and tiled shapes alike
                     b, c, h, w = img_lr.shape
                     t = None if tile is None else min(tile, h, w)
+                    tp = time.perf_counter()
                     model.prepare((b, c, h, w) if t is None else (b, c, t, t), device)
+                    prep_ms.append((time.perf_counter() - tp) * 1e3)
                 start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 start.record()
                 img_sr = forward(img_lr, model, tile)
                 end.record()
+                fin_dev = torch.isfinite(img_sr).all()
                 sr_dev = ops.tensor2uint_device(img_sr, data_range)
                 if sr_dev.shape != hr_dev.shape:
                     raise ValueError('Input images must have the same dimensions.')
@@ -202,7 +212,7 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
                     done = torch.cuda.Event()
                     done.record()
             hh, ww = sr_dev.shape[:2]
-            inflight.append((i, start, end, done, sr_host, se_dev, (hh - 2 * border) * (ww - 2 * border) * sr_dev.shape[2], img_hr))
+            inflight.append((i, start, end, done, sr_host, se_dev, (hh - 2 * border) * (ww - 2 * border) * sr_dev.shape[2], img_hr, fin_dev))
             if len(inflight) > window:
                 retire()
         while inflight:
@@ -211,6 +221,17 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
             w_.result()
         readers.shutdown()
         writers.shutdown()
+        if not hasattr(args, "pipeline"):
+            args.pipeline = {}
+        # how this loop's columns relate to the reference's (test_demo.py:429-433, 467): reported next to the results, not in them
+        args.pipeline[mode + "_measurement"] = {
+            "runtime_bracket": "event pair around forward() only; prepare() (plan construction, weight repack after load_state_dict, "
+                               "workspace growth / zero fill -- lazy work the reference's bracket would contain on an image's first "
+                               "shape) runs before start.record(); its host time is listed here",
+            "prepare_host_ms_total": round(sum(prep_ms), 3), "prepare_host_ms_max": round(max(prep_ms), 3) if prep_ms else 0.0,
+            "memory": "max_memory_allocated includes the pipeline's own device buffers (the HR image, the uint8 SR image and up to "
+                      f"{window} images in flight); the serial loop (device_metrics=False) keeps only the reference's tensors",
+            "gpu_streams": ngs}
     wall = time.perf_counter() - t_wall
     allrows = D.gather_rows(rows, len(data_path), rank, world, device)
     results = {f"{mode}_runtime": [float(v) for v in allrows[:, 1]],

@@ -56,9 +56,10 @@ class IMDN(HipSRModel):
         # fused: conv4's slot never reaches memory.  16-bit storage (d a multiple of 16): four dense tensors (engine.Planar) instead
         # of 32-byte slices of a 128-byte pixel -- partial-line stores cost 2.3x a dense one
         planar = plan.esize == 2 and d % 16 == 0
-        cat = plan.planar('cat', 4, d) if planar else plan.buffer('cat', 3 * d if fused else 4 * d)
+        cat = plan.planar('cat', 4, d) if planar else plan.buffer('cat', plan.cpad(3 * d if fused else 4 * d))
         cs = (lambda j: cat.seg(j)) if planar else (lambda j: cat[j * d:(j + 1) * d])
-        r1, r2 = plan.buffer('r1', r), plan.buffer('r2', r)
+        # pitches are whole K chunks of the plan's storage type (8 fp32 / 16 16-bit channels): r = 24 (nc = 32) needs 32 slots in bf16 / fp16
+        r1, r2 = plan.buffer('r1', plan.cpad(r)), plan.buffer('r2', plan.cpad(r))
         # fused tail: its 3x3 input (conv3's remaining channels) is stored channel-blocked [n][r/8][h][w][8] -- imdb_tail_kernel
         # stages one 8-channel K chunk at a time, and in NHWC every 128-byte line of a 192-byte pixel would be fetched by four
         # stages microseconds apart (esr_conv_desc.blocked8)

@@ -88,3 +88,19 @@ def test_strict_state_dict_surface():
     assert set(sd.keys()) == set(want.keys())
     for k, shp in want.items():
         assert list(sd[k].shape) == shp, k
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
+def test_nc32_runs_in_16bit_storage(compute):
+    """IMDN(nc=32): d = 8, r = 24 -- in the 16-bit plans the 24-channel buffers need a 32-slot pitch (whole 16-channel K chunks,
+    ADVICE r02); the 16-bit forward must run and agree with the fp32 forward of the same random weights to 16-bit accuracy."""
+    from ntire2022_esr_amd import IMDN
+    torch.manual_seed(1)
+    m = IMDN(nc=32, nb=2).eval().to("cuda:0")
+    x = torch.rand(2, 3, 40, 56, device="cuda:0")
+    y32 = m(x)
+    m.set_compute(compute)
+    y16 = m(x)
+    assert y16.shape == y32.shape == (2, 3, 160, 224) and bool(torch.isfinite(y16).all())
+    tol = 3e-2 if compute == "bf16" else 4e-3
+    assert float((y16 - y32).abs().max()) < tol * max(1.0, float(y32.abs().max()))

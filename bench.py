@@ -265,6 +265,7 @@ def main():
         if B % nstreams:
             raise SystemExit(f"--streams {nstreams} does not divide the batch {B}")
         xs = [c.contiguous() for c in xs[0].chunk(nstreams)]
+        my_items = list(range(len(xs)))           # (imgs_per_step stays B: the same batch, in sub-batches)
     # Per-kernel HIP events bracket every launch.  At B = 32 that is < 1 % of a step and they are recorded inside the timed
     # region; one image per forward (20 us kernels) they cost 20 % and, with several streams, would time overlapping kernels:
     # there the timed region runs un-instrumented and the SAME steps are replayed on one stream with events for the roofline leg.

@@ -249,6 +249,39 @@ typedef struct esr_esa_desc {
     const void* w1;             /* apply: conv4 packed dense k=1 (16 x round_up(c,4)) */
 } esr_esa_desc;
 
+/*
+ * esr_esa_lowres_f32 -- ESA's whole low-resolution branch in two launches (ABI v7):
+ *     c3 = layers(max_pool2d(conv2(c1_), 7, 3))
+ * conv2 = nn.Conv2d(f, f, 3, stride 2, padding 0) (rfdn_baseline/block.py:110,119), the pooling (:120), then `n_layers` (1..3)
+ * 3x3 / padding 1 layers on the pooled map: kind 0 = nn.Conv2d(f, f, 3, padding 1) (block.py:121-123 conv_max, conv3, conv3_;
+ * team04_rlfn.py:81 conv3), kind 1 = BSConvU (pointwise nn.Linear + depthwise 3x3 over the zero-padded pointwise output,
+ * team18_bsrn.py:113-116), each followed by `act` (esr_act).  Halo recompute instead of intermediate tensors: conv2's output and
+ * the layers' intermediates never reach memory; only the pooled map does (`pooled`, caller-provided scratch [n][h3][w3][16] fp32).
+ * x: the conv1 map [n][h][w][16] in `storage`; y: [n][h3][w3][16] fp32 with h2 = (h-3)/2+1, h3 = (h2-7)/3+1 (likewise w).
+ * Weights: w_s2 and kind-0 layers esr_pack_dense_f32(k = 3, 16, 16); kind-1 layers w = esr_pack_dense_f32(k = 1, 16, 16) (pointwise),
+ * w_dw = esr_pack_dw_f32.  Replaces esr_conv3x3s2_f32 + esr_maxpool7s3_f32 + 1..6 small esr_conv2d_f32 / esr_dwconv3x3_f32 launches
+ * (which stay available): on one DIV2K image they were a third of a forward's launches for < 1 % of its arithmetic.
+ */
+#define ESR_ESA_MAX_LAYERS 3
+typedef struct esr_esa_layer {
+    int32_t kind;               /* 0: dense 3x3, 1: BSConvU */
+    int32_t act;                /* esr_act behind the layer */
+    const void* w;
+    const void* w_dw;           /* kind 1 only */
+} esr_esa_layer;
+typedef struct esr_esa_lowres_desc {
+    int32_t n, h, w;            /* full-resolution dims of the conv1 map */
+    int32_t f;                  /* ESA width (<= 16) */
+    int32_t storage;            /* esr_storage of x */
+    int32_t n_layers;
+    esr_view x;                 /* pitch 16, coff 0 */
+    const void* w_s2;
+    void* pooled;               /* scratch, n * h3 * w3 * 16 floats */
+    void* y;                    /* result, n * h3 * w3 * 16 floats */
+    esr_esa_layer layer[ESR_ESA_MAX_LAYERS];
+} esr_esa_lowres_desc;
+int esr_esa_lowres_f32(const esr_esa_lowres_desc* d, void* hip_stream);
+
 int esr_conv3x3s2_f32(const esr_esa_desc* d, void* hip_stream);   /* x: [n][h][w][16] -> y: [n][h_lo][w_lo][16] */
 int esr_maxpool7s3_f32(const esr_esa_desc* d, void* hip_stream);  /* x: [n][h][w][16] -> y: [n][h_lo][w_lo][16] */
 int esr_esa_apply_f32(const esr_esa_desc* d, void* hip_stream);
@@ -283,7 +316,8 @@ int esr_sqerr_u8(const uint8_t* a_hwc, const uint8_t* b_hwc, int h, int w, int c
 typedef enum esr_op_kind {
     ESR_OP_CONV = 0, ESR_OP_CONV3X3S2 = 1, ESR_OP_MAXPOOL7S3 = 2, ESR_OP_ESA_APPLY = 3, ESR_OP_DWCONV = 4,
     ESR_OP_BSCONV = 5,
-    ESR_OP_PACK_INPUT = 6       /* esr_pack_input_s16 on esr_op.conv (ABI v5) */
+    ESR_OP_PACK_INPUT = 6,      /* esr_pack_input_s16 on esr_op.conv (ABI v5) */
+    ESR_OP_ESA_LOWRES = 7       /* esr_esa_lowres_f32 on esr_op.lo (ABI v7) */
 } esr_op_kind;
 
 /*
@@ -344,6 +378,7 @@ typedef struct esr_op {
     esr_conv_desc conv;         /* ESR_OP_CONV, ESR_OP_DWCONV */
     esr_esa_desc esa;           /* the three ESA kinds */
     esr_bsconv_desc bs;         /* ESR_OP_BSCONV (ABI v3) */
+    esr_esa_lowres_desc lo;     /* ESR_OP_ESA_LOWRES (ABI v7) */
 } esr_op;
 
 /* ABI v5 -- the network input for the 16-bit plans: NCHW fp32 [n, cin <= 4, h, w] (d->in.ptr) -> NHWC 16-bit (d->out0, pitch >= 16,
@@ -375,7 +410,7 @@ int  esr_prof_kernel_symbol(esr_profiler* prof, int op, char* buf, size_t n);
 int         esr_abi_version(void);
 const char* esr_last_hip_error(void);     /* thread-local, "" if none */
 /* sizeof of the ABI structs as this library was compiled -- 0: esr_view, 1: esr_conv_desc, 2: esr_esa_desc, 3: esr_bsconv_desc,
- * 4: esr_ca_desc, 5: esr_op; anything else: 0.  A binding checks its own struct definitions against these once at load time (the
+ * 4: esr_ca_desc, 5: esr_op, 6: esr_esa_lowres_desc; anything else: 0.  A binding checks its own struct definitions against these once at load time (the
  * reference has no counterpart: its boundary is Python objects). */
 size_t      esr_sizeof(int which);
 const char* esr_build_info(void);         /* e.g. "gfx950 f32-mfma16x16x4 tile16x16 chunk8" */

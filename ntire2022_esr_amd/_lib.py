@@ -17,7 +17,8 @@ ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
 RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
 NHWC, NCHW_IN, NCHW_SHUFFLE4 = 0, 1, 2
 BLOCKED_IN, BLOCKED_OUT1 = 1, 2          # esr_conv_desc.blocked8 bits (ABI v6)
-OP_CONV, OP_CONV3X3S2, OP_MAXPOOL7S3, OP_ESA_APPLY, OP_DWCONV, OP_BSCONV, OP_PACK_INPUT = 0, 1, 2, 3, 4, 5, 6
+OP_CONV, OP_CONV3X3S2, OP_MAXPOOL7S3, OP_ESA_APPLY, OP_DWCONV, OP_BSCONV, OP_PACK_INPUT, OP_ESA_LOWRES = 0, 1, 2, 3, 4, 5, 6, 7
+ESA_MAX_LAYERS = 3
 ESA_FP = 16
 COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2
 COMPUTE = {"f32": 0, "bf16": 1, "f16": 2}
@@ -81,9 +82,22 @@ class CaDesc(ctypes.Structure):
     ]
 
 
+class EsaLayer(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("act", ctypes.c_int32), ("w", ctypes.c_void_p), ("w_dw", ctypes.c_void_p)]
+
+
+class EsaLowresDesc(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_int32), ("h", ctypes.c_int32), ("w", ctypes.c_int32), ("f", ctypes.c_int32),
+        ("storage", ctypes.c_int32), ("n_layers", ctypes.c_int32),
+        ("x", View), ("w_s2", ctypes.c_void_p), ("pooled", ctypes.c_void_p), ("y", ctypes.c_void_p),
+        ("layer", EsaLayer * ESA_MAX_LAYERS),
+    ]
+
+
 class Op(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("conv", ConvDesc), ("esa", EsaDesc),
-                ("bs", BsDesc)]
+                ("bs", BsDesc), ("lo", EsaLowresDesc)]
 
 
 # every symbol include/esr_hip.h declares (tests check the .so exports all of them)
@@ -96,7 +110,7 @@ EXPORTS = [
     "esr_conv2d_f32", "esr_conv_block_waves", "esr_run_ops", "esr_pack_input_s16",
     "esr_prof_create", "esr_run_ops_profiled", "esr_prof_collect", "esr_prof_destroy", "esr_prof_kernel_symbol",
     "esr_packed_dense_bytes", "esr_pack_dense_f32",
-    "esr_conv3x3s2_f32", "esr_maxpool7s3_f32", "esr_esa_apply_f32",
+    "esr_conv3x3s2_f32", "esr_maxpool7s3_f32", "esr_esa_apply_f32", "esr_esa_lowres_f32",
     "esr_packed_dw_bytes", "esr_pack_dw_f32", "esr_dwconv3x3_f32", "esr_bsconv_f32",
     "esr_tensor2uint_u8", "esr_sqerr_u8", "esr_channel_attention_f32",
 ]
@@ -160,6 +174,8 @@ def lib():
     for fn in (L.esr_conv3x3s2_f32, L.esr_maxpool7s3_f32, L.esr_esa_apply_f32):
         fn.argtypes = [ctypes.POINTER(EsaDesc), vp]
         fn.restype = ci
+    L.esr_esa_lowres_f32.argtypes = [ctypes.POINTER(EsaLowresDesc), vp]
+    L.esr_esa_lowres_f32.restype = ci
     L.esr_packed_dw_bytes.argtypes = [ci]
     L.esr_packed_dw_bytes.restype = sz
     L.esr_pack_dw_f32.argtypes = [vp, vp, ci, vp, sz]
@@ -188,7 +204,7 @@ def lib():
         raise EsrError("libesr_hip.so ABI version mismatch")
     L.esr_sizeof.argtypes = [ci]
     L.esr_sizeof.restype = ctypes.c_size_t
-    for which, st in enumerate((View, ConvDesc, EsaDesc, BsDesc, CaDesc, Op)):
+    for which, st in enumerate((View, ConvDesc, EsaDesc, BsDesc, CaDesc, Op, EsaLowresDesc)):
         if L.esr_sizeof(which) != ctypes.sizeof(st):
             raise EsrError(f"libesr_hip.so: sizeof({st.__name__}) is {L.esr_sizeof(which)} in the library, {ctypes.sizeof(st)} in the binding")
     _lib = L

@@ -178,6 +178,7 @@ class BSRN(HipSRModel):
             else:
                 plan.conv(b + 'c5', cat, v, 4 * DP if merged else 4 * dc, C, k=1, counted=False, cin_alg=4 * dc)
                 plan.conv(b + 'esa.conv1', v, c1, C, f, k=1, counted=False)
+            mark = len(plan.ops)
             plan.conv3x3s2(b + 'esa.conv2', c1, lo2, f)
             plan.maxpool7s3(lo2, la)
             plan.conv(b + 'esa.conv_max.pw', la, lt, f, f, k=1, hw=lo, counted=False)
@@ -186,6 +187,13 @@ class BSRN(HipSRModel):
             plan.dwconv(b + 'esa.conv3.dw', lt, la, f, hw=lo, **g)
             plan.conv(b + 'esa.conv3_.pw', la, lt, f, f, k=1, hw=lo, counted=False)
             plan.dwconv(b + 'esa.conv3_.dw', lt, lb, f, hw=lo)
+            if self.fuse_esa_lowres:
+                # the eight launches above as one op of two (halo recompute; only the pooled map reaches memory)
+                ga = g.get("act", L.ACT_NONE)
+                plan.esa_lowres(mark, c1, la, lb, f, b + 'esa.conv2',
+                                [dict(kind=1, act=ga, w=b + 'esa.conv_max.pw', w_dw=b + 'esa.conv_max.dw'),
+                                 dict(kind=1, act=ga, w=b + 'esa.conv3.pw', w_dw=b + 'esa.conv3.dw'),
+                                 dict(kind=1, act=L.ACT_NONE, w=b + 'esa.conv3_.pw', w_dw=b + 'esa.conv3_.dw')])
             plan.esa_apply(b + 'esa.conv_f', b + 'esa.conv4', v, c1, lb, u, C, f)
             out = bcat[(k - 1) * C:k * C]
             plan.conv(b + 'conv_out', u, out, C, C, k=1, res=src, res_mode=L.RES_PRE_ACT, counted=False)

@@ -878,6 +878,7 @@ size_t esr_sizeof(int which)
         case 3: return sizeof(esr_bsconv_desc);
         case 4: return sizeof(esr_ca_desc);
         case 5: return sizeof(esr_op);
+        case 6: return sizeof(esr_esa_lowres_desc);
         default: return 0;
     }
 }
@@ -1138,6 +1139,7 @@ static int run_one(const esr_op& op, void* hip_stream)
         case ESR_OP_DWCONV: return esr_dwconv3x3_f32(&op.conv, hip_stream);
         case ESR_OP_BSCONV: return esr_bsconv_f32(&op.bs, hip_stream);
         case ESR_OP_PACK_INPUT: return esr_pack_input_s16(&op.conv, hip_stream);
+        case ESR_OP_ESA_LOWRES: return esr_esa_lowres_f32(&op.lo, hip_stream);
         default: return ESR_ERR_BAD_ARG;
     }
 }

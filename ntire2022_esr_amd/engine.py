@@ -322,6 +322,16 @@ class Plan:
     def maxpool7s3(self, src, dst):
         self.ops.append(dict(kind="pool", src=src, dst=dst))
 
+    def esa_lowres(self, mark, c1, pooled, dst, f, s2, layers):
+        """ESA's low-resolution branch as ONE op (esr_esa_lowres_f32: two launches with halo recompute) in place of the ops appended
+        since `mark = len(plan.ops)` -- conv3x3s2, maxpool7s3 and the 1..3 small 3x3 layers (RFDN / RLFN: dense convs, BSRN: pointwise +
+        depthwise pairs); those op dicts stay attached as `replaces`: the complexity counters and the algorithmic costs are theirs.
+        layers: [dict(kind=0|1, act, w=<path of the dense 3x3 / pointwise weights>, w_dw=<path of the depthwise weights>)]"""
+        sub = self.ops[mark:]
+        del self.ops[mark:]
+        self.ops.append(dict(kind="lowres", src=c1, pooled=pooled, dst=dst, f=f, w=s2, layers=layers, replaces=sub,
+                             cin=f, cout=f, k=3))
+
     def esa_apply(self, wf, w4, x, c1, c3, dst, c, f):
         """y = x * sigmoid(conv4(bilinear(c3) + conv_f(c1)));  two nn.Conv2d calls of the reference."""
         self.ops.append(dict(kind="apply", wf=wf, w4=w4, x=x, c1=c1, c3=c3, dst=dst, c=c, f=f))
@@ -372,6 +382,20 @@ class Plan:
                     d.d_packed = ctypes.c_void_p(weights[t["w"] + sfx].data_ptr())
                     d.d_cout, d.d_act = t["cout"], t.get("act", L.ACT_NONE)
                     d.d_out = self._view(t["dst"], base)
+                continue
+            if o["kind"] == "lowres":
+                op.kind = L.OP_ESA_LOWRES
+                d = op.lo
+                d.n, d.h, d.w, d.f, d.storage, d.n_layers = self.n, self.h, self.w, o["f"], st, len(o["layers"])
+                d.x = self._view(o["src"], base)
+                d.w_s2 = ctypes.c_void_p(weights[o["w"]].data_ptr())
+                d.pooled = ctypes.c_void_p(self._addr(o["pooled"], base))
+                d.y = ctypes.c_void_p(self._addr(o["dst"], base))
+                for l, ly in enumerate(o["layers"]):
+                    d.layer[l].kind, d.layer[l].act = ly["kind"], ly.get("act", L.ACT_NONE)
+                    d.layer[l].w = ctypes.c_void_p(weights[ly["w"] + "#dense"].data_ptr())
+                    if ly["kind"] == 1:
+                        d.layer[l].w_dw = ctypes.c_void_p(weights[ly["w_dw"]].data_ptr())
                 continue
             if o["kind"] not in ("conv", "dw"):
                 e = op.esa
@@ -539,6 +563,7 @@ class HipSRModel(nn.Module):
         self._dirty = True         # parameters may have changed since the last repack (load_state_dict / .to() / repack())
         self._ctxs = {}            # (device, HIP stream handle) -> _StreamCtx: workspace + plans of the forwards enqueued on that stream
         self.compute = "f32"       # "f32" | "bf16" | "f16": MFMA operand format of the full-resolution 3x3 convs
+        self.fuse_esa_lowres = True   # ESA's low-resolution branch as one esr_esa_lowres_f32 op (two launches) instead of 3 .. 8 launches
         self.winograd = True       # fp32 plans: 3x3 convs whose shape qualifies run as Winograd F(2x2, 3x3) (esr_conv_desc.wino_wpacked)
         self._prof_passes = 0      # >0: record HIP events around every op (bench roofline leg)
         self.handle = next(_HANDLES)       # the `handle` argument of esr::sr_forward
@@ -680,6 +705,12 @@ class HipSRModel(nn.Module):
                     out.add(t["post2"]["w"])
         return out
 
+    def _lowres_dense(self):
+        """paths of the layers evaluated inside esr_esa_lowres_f32 (dense 16 x 16 blobs: esr_pack_dense_f32)"""
+        plan = Plan(1, 32, 32, self._store())
+        self._build_plan(plan, self.in_nc)
+        return {ly["w"] for o in plan.ops if o["kind"] == "lowres" for ly in o["layers"]}
+
     def _head_convs(self):
         """paths of the convolutions that read the network input in the current 16-bit mode (lowered to pack + conv_s16)"""
         plan = Plan(1, 32, 32, self._store())
@@ -712,6 +743,9 @@ class HipSRModel(nn.Module):
         for path, (cin_p, cout_p) in self._dense_specs.items():
             leaf = self._leaf(path)
             packed[path] = pack_dense(leaf.weight, leaf.bias, cin_p, cout_p).to(device)
+        for path in sorted(self._lowres_dense()):        # 3x3 / pointwise layers of the fused ESA branch: plain dense layout
+            leaf = self._leaf(path)
+            packed[path + "#dense"] = pack_dense(leaf.weight, leaf.bias, L.ESA_FP, L.ESA_FP).to(device)
         for path in self._dw_specs:
             leaf = self._leaf(path)
             packed[path] = pack_dw(leaf.weight, leaf.bias).to(device)
@@ -902,6 +936,17 @@ class HipSRModel(nn.Module):
                         kern = kern[:-1] + f"+{(t2['cout'] + 15) // 16}>"
                         flops += 2.0 * npix * t["cout"] * t2["cout"]
                         wr += npix * e_act * t2["cout"]
+            elif kind == "lowres":                  # conv2 (s2) + pooling + the 3x3 layers behind it: two launches, only the pooled map in between
+                src, dst = o["src"], o["dst"]
+                npl = plan.n * dst.h * dst.w
+                h2, w2 = (src.h - 3) // 2 + 1, (src.w - 3) // 2 + 1
+                f = o["f"]
+                kern = f"esa_s2pool_kernel<{L.STORE[plan.store]}> + esa_chain_kernel"
+                flops = 2.0 * 9 * f * f * plan.n * h2 * w2
+                for ly in o["layers"]:
+                    flops += 2.0 * npl * (9 * f * f if ly["kind"] == 0 else f * f + 9 * f)
+                rd = float(plan.n * src.h * src.w * f * src.esize + npl * f * 4)
+                wr = float(2 * npl * f * 4)
             elif kind == "bs":                      # pointwise (+ distillation) GEMM + depthwise, one launch
                 t = o["distill"]
                 dco = t["cout"] if t is not None else 0
@@ -962,6 +1007,11 @@ class HipSRModel(nn.Module):
     def _complexity_terms(self, plan, o):
         """(flops, activations, n_conv) that the reference's model_summary hooks would count for op `o`."""
         flops = acts = nconv = 0
+        if o["kind"] == "lowres":                   # the fused ESA branch counts as the nn.Conv2d / nn.Linear calls it replaces
+            for sub in o["replaces"]:
+                f_, a_, n_ = self._complexity_terms(plan, sub)
+                flops, acts, nconv = flops + f_, acts + a_, nconv + n_
+            return flops, acts, nconv
         for (cin, cout, k, npix, act) in self._counted_convs(plan, o):
             flops += k * k * cin * cout * npix
             acts += cout * npix

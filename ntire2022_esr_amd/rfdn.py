@@ -109,11 +109,17 @@ class RFDN(HipSRModel):
             else:
                 plan.conv(b + 'c5', cat, v, 4 * DP, nf, k=1, cin_alg=4 * dc)
                 plan.conv(b + 'esa.conv1', v, c1, nf, f, k=1)
+            mark = len(plan.ops)
             plan.conv3x3s2(b + 'esa.conv2', c1, lo2, f)
             plan.maxpool7s3(lo2, la)
             plan.conv(b + 'esa.conv_max', la, lb, f, f, act=L.ACT_RELU, **lo)
             plan.conv(b + 'esa.conv3', lb, la, f, f, act=L.ACT_RELU, **lo)
             plan.conv(b + 'esa.conv3_', la, lb, f, f, **lo)
+            if self.fuse_esa_lowres:
+                # the five launches above as one op of two (halo recompute; only the pooled map reaches memory)
+                plan.esa_lowres(mark, c1, la, lb, f, b + 'esa.conv2',
+                                [dict(kind=0, act=L.ACT_RELU, w=b + 'esa.conv_max'), dict(kind=0, act=L.ACT_RELU, w=b + 'esa.conv3'),
+                                 dict(kind=0, act=L.ACT_NONE, w=b + 'esa.conv3_')])
             out = bcat[(k - 1) * P:k * P]
             plan.esa_apply(b + 'esa.conv_f', b + 'esa.conv4', v, c1, lb, out, nf, f)
             cur = out

@@ -83,9 +83,12 @@ class RLFN_cut(HipSRModel):
                 plan.conv(b + 'c3_r', t2, u, mf, nf, res=cur, res_mode=L.RES_POST_ACT, **act)
                 plan.conv(b + 'c5', u, v, nf, nf, k=1)
                 plan.conv(b + 'esa.conv1', v, c1, nf, f, k=1)
+            mark = len(plan.ops)
             plan.conv3x3s2(b + 'esa.conv2', c1, lo2, f)
             plan.maxpool7s3(lo2, lo3)
             plan.conv(b + 'esa.conv3', lo3, lo4, f, f, hw=(h3, w3))
+            if self.fuse_esa_lowres:
+                plan.esa_lowres(mark, c1, lo3, lo4, f, b + 'esa.conv2', [dict(kind=0, act=L.ACT_NONE, w=b + 'esa.conv3')])
             plan.esa_apply(b + 'esa.conv_f', b + 'esa.conv4', v, c1, lo4, nxt, nf, f)
             cur = nxt
             nxt = xb if cur is xa else xa

@@ -8,15 +8,17 @@
 // On one DIV2K image (339x510 -> 169x254 -> 55x83 x f <= 16 channels) every one of those is a launch of a few microseconds of work
 // and ~10-15 us of latency: a third of a forward's launches for < 1 % of its arithmetic.  The grid-barrier fusion of round 2 lost
 // (a co-resident grid runs every latency-bound layer at a quarter of its occupancy); this one needs no barrier -- HALO RECOMPUTE:
-//   s2pool_kernel   one block = a 4x4 tile of the POOLED map: the 16x16 conv2 outputs under it go to LDS (1.8x recompute at the tile
+//   s2pool_kernel   one block = a 4x4 tile of the POOLED map: its 33x33 input patch is staged in LDS, the 16x16 conv2 outputs under it go to LDS (1.8x recompute at the tile
 //                   seams), the 7x7/3 maxima are taken from there.  conv2's output never reaches memory.
-//   chain_kernel    one block = an 8x8 tile of the LAST layer: the (8 + 2L)^2 pooled patch goes to LDS and the L layers run on
+//   chain_kernel    one block = a 6x6 tile of the LAST layer: the (6 + 2L)^2 pooled patch goes to LDS and the L layers run on
 //                   shrinking patches in two LDS buffers; positions outside the map are written as zeros, which is each layer's
-//                   zero padding.  Weights of all layers sit in LDS.
-// VALU fp32 kernels (thread = output pixel x quad of channels, float4 everywhere): the branch is 0.3 % of a network's MACs.
+//                   zero padding.
+// The convolutions run on the matrix cores in exact fp32 with their weights in registers; pooling and the depthwise 3x3 on the
+// vector units.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
+#include <atomic>
 
 #include "esr_internal.h"
 
@@ -26,10 +28,40 @@ namespace {
 
 constexpr int FP = ESR_ESA_FP;                 // 16: channel pitch of every map here
 constexpr int PT = 4;                          // pooled tile edge of s2pool_kernel
-constexpr int CT = 3 * PT + 4;                 // conv2 outputs under it per edge: 16
-constexpr int OT = 8;                          // output tile edge of chain_kernel
+constexpr int CT = 3 * PT + 4;                 // conv2 outputs under it per edge: 16 (= one MFMA pixel group per row)
+constexpr int OT = 6;                          // output tile edge of chain_kernel (339x510: 10 x 14 = 140 blocks)
+constexpr int BP = 20;                         // floats per pixel of the LDS patches (16 + 4: adjacent pixels on different banks)
 constexpr int ML = ESR_ESA_MAX_LAYERS;
-constexpr int PMAX = OT + 2 * ML;              // 14
+constexpr int PMAX = OT + 2 * ML;              // 12
+
+// The small convolutions run on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32): D[cout][pixel] += W[cout][cin] X[cin][pixel]
+// per tap, 16 pixels per group.  Lane (j = l & 15, g = l >> 4): A = W[cout j][cin 4g + s], B = X[pixel j][cin 4g + s] for the four
+// K steps s of a tap -- one 16-byte read of the pixel's channels 4g .. 4g+3 per tap; D: lane (j, g) holds output channels
+// 4g .. 4g+3 of pixel j (one float4 of an NHWC pixel).  The weights of a layer sit in REGISTERS (9 taps x float4 per lane) for the
+// life of the block.  (As VALU kernels with per-lane or scalar weight loads these were LDS-return- or latency-bound: 50 - 90 us per
+// ESA block on one image, no better than the five launches they replace.)
+template <int TAPS>
+__device__ __forceinline__ void lo_load_weights(const float* __restrict__ wp, f32x4 (&wr)[TAPS], f32x4& bias, int lane)
+{
+    const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        f32x4 v;
+        v.x = wp[(t * FP + 4 * g + 0) * FP + j]; v.y = wp[(t * FP + 4 * g + 1) * FP + j];
+        v.z = wp[(t * FP + 4 * g + 2) * FP + j]; v.w = wp[(t * FP + 4 * g + 3) * FP + j];
+        wr[t] = v;
+    }
+    bias = *reinterpret_cast<const f32x4*>(wp + TAPS * FP * FP + 4 * g);
+}
+
+__device__ __forceinline__ f32x4 lo_mfma4(f32x4 a, f32x4 b, f32x4 acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    return acc;
+}
 
 template <int ST>
 __device__ __forceinline__ f32x4 lo_ld4(const void* base, size_t idx)
@@ -49,47 +81,61 @@ __device__ __forceinline__ f32x4 lo_ld4(const void* base, size_t idx)
 }
 
 // ---- conv2 (3x3 / 2) + max pool (7 / 3) ---------------------------------------------------------------------------------------
+// The 33x33-pixel input patch of the tile is staged in LDS first (every load of the block in flight at once), in the storage
+// type, pixel pitch padded so that the sixteen stride-2 pixels a wave reads per tap fall on different banks.
+constexpr int IT = 2 * CT + 1;                                               // 33 input pixels per edge
+template <int ST> struct S2In {
+    static constexpr int PITCH = ST == ESR_STORE_F32 ? 80 : 40;              // bytes per staged pixel (16 channels + padding)
+    static constexpr int BYTES = IT * IT * PITCH;
+};
+
 template <int ST>
 __global__ __launch_bounds__(256) void esa_s2pool_kernel(const void* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
                                                          int H, int W, int H2, int W2, int H3, int W3, int tiles_x, int tiles_y)
 {
-    __shared__ __attribute__((aligned(16))) float sw[9 * FP * FP + FP];
-    __shared__ __attribute__((aligned(16))) float sc[CT * CT * FP];          // conv2 outputs of this tile, [y][x][16]
-    for (int i = threadIdx.x; i < 9 * FP * FP + FP; i += 256) sw[i] = wp[i];
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    float* const sc = reinterpret_cast<float*>(dyn);                         // conv2 outputs of this tile, [y][x][16]
+    char* const sin = reinterpret_cast<char*>(sc + CT * CT * FP);            // the input patch
+    constexpr int PITCH = S2In<ST>::PITCH;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, g = lane >> 4;
     int t = blockIdx.x;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int n = t / tiles_y;
     const int cy0 = 3 * PT * ty, cx0 = 3 * PT * tx;                          // first conv2 output of the tile
-    __syncthreads();
-    // conv2: 256 outputs x 4 channel quads over 256 threads
-    for (int it = threadIdx.x; it < CT * CT * 4; it += 256) {
-        const int q = it & 3, pl = it >> 2;
-        const int ly = pl / CT, lx = pl - ly * CT;
-        const int oy = cy0 + ly, ox = cx0 + lx;
-        f32x4 acc = *reinterpret_cast<const f32x4*>(sw + 9 * FP * FP + q * 4);
-        if (oy < H2 && ox < W2) {
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const size_t xi = (((size_t)n * H + (oy * 2 + ky)) * W + (ox * 2 + kx)) * FP;
-                    const float* wt = sw + (ky * 3 + kx) * FP * FP + q * 4;
-#pragma unroll
-                    for (int cq = 0; cq < FP / 4; ++cq) {
-                        const f32x4 xv = lo_ld4<ST>(x, xi + cq * 4);
-                        acc += xv.x * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 0) * FP);
-                        acc += xv.y * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 1) * FP);
-                        acc += xv.z * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 2) * FP);
-                        acc += xv.w * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 3) * FP);
-                    }
-                }
+    const int iy0 = 2 * cy0, ix0 = 2 * cx0;
+    f32x4 wr[9], bias;
+    lo_load_weights<9>(wp, wr, bias, lane);
+    for (int it = threadIdx.x; it < IT * IT * 4; it += 256) {
+        const int qq = it & 3, pl = it >> 2;
+        const int ly = pl / IT, lx = pl - ly * IT;
+        const int gy = iy0 + ly, gx = ix0 + lx;
+        if (ST == ESR_STORE_F32) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy < H && gx < W) v = *reinterpret_cast<const f32x4*>(static_cast<const float*>(x) + (((size_t)n * H + gy) * W + gx) * FP + qq * 4);
+            *reinterpret_cast<f32x4*>(sin + pl * PITCH + qq * 16) = v;
+        } else {
+            uint2 v = {0u, 0u};
+            if (gy < H && gx < W) v = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(x) + (((size_t)n * H + gy) * W + gx) * FP + qq * 4);
+            *reinterpret_cast<uint2*>(sin + pl * PITCH + qq * 8) = v;
         }
-        *reinterpret_cast<f32x4*>(sc + pl * FP + q * 4) = acc;               // (outside the map: never read by a valid window)
+    }
+    __syncthreads();
+    // conv2 on the matrix cores: one pixel group = one row of 16 conv2 outputs; wave w takes rows w, w + 4, ...
+    for (int ly = wv; ly < CT; ly += 4) {
+        f32x4 acc = bias;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                acc = lo_mfma4(wr[ky * 3 + kx], lo_ld4<ST>(sin + ((2 * ly + ky) * IT + 2 * j + kx) * PITCH, 4 * g), acc);
+        *reinterpret_cast<f32x4*>(sc + (ly * CT + j) * FP + 4 * g) = acc;    // (outputs outside the map are never read by a valid window)
     }
     __syncthreads();
     if (threadIdx.x < PT * PT * 4) {
-        const int q = threadIdx.x & 3, pl = threadIdx.x >> 2;
+        const int qq = threadIdx.x & 3, pl = threadIdx.x >> 2;
         const int py = pl / PT, pxx = pl - py * PT;
         const int gy = PT * ty + py, gx = PT * tx + pxx;
         if (gy < H3 && gx < W3) {
@@ -98,10 +144,10 @@ __global__ __launch_bounds__(256) void esa_s2pool_kernel(const void* __restrict_
             for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 7; ++kx) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(sc + ((3 * py + ky) * CT + 3 * pxx + kx) * FP + q * 4);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(sc + ((3 * py + ky) * CT + 3 * pxx + kx) * FP + qq * 4);
                     m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
                 }
-            *reinterpret_cast<f32x4*>(y + (((size_t)n * H3 + gy) * W3 + gx) * FP + q * 4) = m;
+            *reinterpret_cast<f32x4*>(y + (((size_t)n * H3 + gy) * W3 + gx) * FP + qq * 4) = m;
         }
     }
 }
@@ -128,17 +174,11 @@ __device__ __forceinline__ float lo_act(float v, int act)
 
 __global__ __launch_bounds__(256) void esa_chain_kernel(const ChainK p)
 {
-    constexpr int WL = 9 * FP * FP + FP;                       // floats reserved per layer's weights (dense 3x3 is the largest)
-    __shared__ __attribute__((aligned(16))) float sw[ML * WL];
-    __shared__ __attribute__((aligned(16))) float sdw[ML * (10 * FP)];
-    __shared__ __attribute__((aligned(16))) float buf[2][PMAX * PMAX * FP];
+    __shared__ __attribute__((aligned(16))) float buf[2][PMAX * PMAX * BP];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, g = lane >> 4;
     const int L = p.n_layers;
-    for (int l = 0; l < L; ++l) {
-        const int nw = p.kind[l] == 0 ? 9 * FP * FP + FP : FP * FP + FP;
-        for (int i = threadIdx.x; i < nw; i += 256) sw[l * WL + i] = p.w[l][i];
-        if (p.kind[l] == 1)
-            for (int i = threadIdx.x; i < 10 * p.cp[l]; i += 256) sdw[l * 10 * FP + i] = p.wdw[l][i];
-    }
     int t = blockIdx.x;
     const int tx = t % p.tiles_x; t /= p.tiles_x;
     const int ty = t % p.tiles_y;
@@ -147,94 +187,109 @@ __global__ __launch_bounds__(256) void esa_chain_kernel(const ChainK p)
     int S = OT + 2 * L;
     int oy = OT * ty - L, ox = OT * tx - L;                    // map coordinates of the current patch's (0, 0)
     for (int it = threadIdx.x; it < S * S * 4; it += 256) {
-        const int q = it & 3, pl = it >> 2;
+        const int qq = it & 3, pl = it >> 2;
         const int ly = pl / S, lx = pl - ly * S;
         const int gy = oy + ly, gx = ox + lx;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gy >= 0 && gy < p.H3 && gx >= 0 && gx < p.W3) v = *reinterpret_cast<const f32x4*>(p.x + (((size_t)n * p.H3 + gy) * p.W3 + gx) * FP + q * 4);
-        *reinterpret_cast<f32x4*>(buf[0] + pl * FP + q * 4) = v;
+        if (gy >= 0 && gy < p.H3 && gx >= 0 && gx < p.W3) v = *reinterpret_cast<const f32x4*>(p.x + (((size_t)n * p.H3 + gy) * p.W3 + gx) * FP + qq * 4);
+        *reinterpret_cast<f32x4*>(buf[0] + pl * BP + qq * 4) = v;
     }
     __syncthreads();
     int cur = 0;
     for (int l = 0; l < L; ++l) {
-        const float* wl = sw + l * WL;
-        const int act = p.act[l];
-        if (p.kind[l] == 1) {
-            // BSConvU, first half: pointwise 1x1 in place geometry (S x S -> S x S); outside the map the depthwise conv must see
-            // zeros, not the pointwise bias (team18_bsrn.py:82-88 pads the pointwise OUTPUT)
-            for (int it = threadIdx.x; it < S * S * 4; it += 256) {
-                const int q = it & 3, pl = it >> 2;
-                const int ly = pl / S, lx = pl - ly * S;
-                const int gy = oy + ly, gx = ox + lx;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                if (gy >= 0 && gy < p.H3 && gx >= 0 && gx < p.W3) {
-                    acc = *reinterpret_cast<const f32x4*>(wl + FP * FP + q * 4);
-                    const float* in = buf[cur] + pl * FP;
+        const int act = p.act[l], kind = p.kind[l];
+        const bool last = l == L - 1;
+        if (kind == 0) {
+            // dense 3x3 on the matrix cores: S x S -> (S - 2) x (S - 2), 16 output pixels (raster order) per group
+            f32x4 wr[9], bias;
+            lo_load_weights<9>(p.w[l], wr, bias, lane);
+            const int So = S - 2, npx = So * So;
+            for (int grp = wv; grp * 16 < npx; grp += 4) {
+                const int pl = grp * 16 + j;
+                const bool live = pl < npx;
+                const int plc = live ? pl : 0;
+                const int ly = plc / So, lx = plc - ly * So;
+                const float* in = buf[cur] + (ly * S + lx) * BP + 4 * g;
+                f32x4 acc = bias;
 #pragma unroll
-                    for (int cq = 0; cq < FP / 4; ++cq) {
-                        const f32x4 xv = *reinterpret_cast<const f32x4*>(in + cq * 4);
-                        acc += xv.x * *reinterpret_cast<const f32x4*>(wl + (cq * 4 + 0) * FP + q * 4);
-                        acc += xv.y * *reinterpret_cast<const f32x4*>(wl + (cq * 4 + 1) * FP + q * 4);
-                        acc += xv.z * *reinterpret_cast<const f32x4*>(wl + (cq * 4 + 2) * FP + q * 4);
-                        acc += xv.w * *reinterpret_cast<const f32x4*>(wl + (cq * 4 + 3) * FP + q * 4);
-                    }
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+                        acc = lo_mfma4(wr[ky * 3 + kx], *reinterpret_cast<const f32x4*>(in + (ky * S + kx) * BP), acc);
+                const int gy = oy + 1 + ly, gx = ox + 1 + lx;
+                const bool inside = gy >= 0 && gy < p.H3 && gx >= 0 && gx < p.W3;
+                acc.x = lo_act(acc.x, act); acc.y = lo_act(acc.y, act); acc.z = lo_act(acc.z, act); acc.w = lo_act(acc.w, act);
+                if (!inside) acc = f32x4{0.f, 0.f, 0.f, 0.f};                  // the next layer's zero padding
+                if (live) {
+                    if (last) { if (inside) *reinterpret_cast<f32x4*>(p.y + (((size_t)n * p.H3 + gy) * p.W3 + gx) * FP + 4 * g) = acc; }
+                    else *reinterpret_cast<f32x4*>(buf[cur ^ 1] + pl * BP + 4 * g) = acc;
                 }
-                *reinterpret_cast<f32x4*>(buf[cur ^ 1] + pl * FP + q * 4) = acc;
             }
             __syncthreads();
             cur ^= 1;
-        }
-        // 3x3 (dense, or depthwise for BSConvU): S x S -> (S - 2) x (S - 2); outside the map -> 0 (the next layer's padding)
-        const int So = S - 2;
-        const bool last = l == L - 1;
-        const float* dwl = sdw + l * 10 * FP;
-        const int cp = p.cp[l];
-        for (int it = threadIdx.x; it < So * So * 4; it += 256) {
-            const int q = it & 3, pl = it >> 2;
-            const int ly = pl / So, lx = pl - ly * So;
-            const int gy = oy + 1 + ly, gx = ox + 1 + lx;
-            const bool inside = gy >= 0 && gy < p.H3 && gx >= 0 && gx < p.W3;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (inside) {
-                if (p.kind[l] == 0) {
-                    acc = *reinterpret_cast<const f32x4*>(wl + 9 * FP * FP + q * 4);
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const float* in = buf[cur] + ((ly + ky) * S + lx + kx) * FP;
-                            const float* wt = wl + (ky * 3 + kx) * FP * FP + q * 4;
-#pragma unroll
-                            for (int cq = 0; cq < FP / 4; ++cq) {
-                                const f32x4 xv = *reinterpret_cast<const f32x4*>(in + cq * 4);
-                                acc += xv.x * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 0) * FP);
-                                acc += xv.y * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 1) * FP);
-                                acc += xv.z * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 2) * FP);
-                                acc += xv.w * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 3) * FP);
-                            }
-                        }
-                } else if (q * 4 < cp) {
-                    acc = *reinterpret_cast<const f32x4*>(dwl + 9 * cp + q * 4);
+            S = So;
+            ++oy; ++ox;
+        } else {
+            // BSConvU: pointwise 1x1 on the whole patch (matrix cores), zero outside the map (team18_bsrn.py:82-88 pads the pointwise
+            // OUTPUT), then the depthwise 3x3 on the vector units
+            {
+                f32x4 wr[1], bias;
+                lo_load_weights<1>(p.w[l], wr, bias, lane);
+                const int npx = S * S;
+                for (int grp = wv; grp * 16 < npx; grp += 4) {
+                    const int pl = grp * 16 + j;
+                    const bool live = pl < npx;
+                    const int plc = live ? pl : 0;
+                    const int ly = plc / S, lx = plc - ly * S;
+                    f32x4 acc = lo_mfma4(wr[0], *reinterpret_cast<const f32x4*>(buf[cur] + plc * BP + 4 * g), bias);
+                    const int gy = oy + ly, gx = ox + lx;
+                    if (!(gy >= 0 && gy < p.H3 && gx >= 0 && gx < p.W3)) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (live) *reinterpret_cast<f32x4*>(buf[cur ^ 1] + pl * BP + 4 * g) = acc;
+                }
+            }
+            __syncthreads();
+            cur ^= 1;
+            const int So = S - 2, cp = p.cp[l];
+            const float* __restrict__ dwl = p.wdw[l];
+            for (int it = threadIdx.x; it < So * So * 4; it += 256) {
+                const int qq = it & 3, pl = it >> 2;
+                const int ly = pl / So, lx = pl - ly * So;
+                const int gy = oy + 1 + ly, gx = ox + 1 + lx;
+                const bool inside = gy >= 0 && gy < p.H3 && gx >= 0 && gx < p.W3;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (inside && qq * 4 < cp) {
+                    acc = *reinterpret_cast<const f32x4*>(dwl + 9 * cp + qq * 4);
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx)
-                            acc += *reinterpret_cast<const f32x4*>(buf[cur] + ((ly + ky) * S + lx + kx) * FP + q * 4) *
-                                   *reinterpret_cast<const f32x4*>(dwl + (ky * 3 + kx) * cp + q * 4);
+                            acc += *reinterpret_cast<const f32x4*>(buf[cur] + ((ly + ky) * S + lx + kx) * BP + qq * 4) *
+                                   *reinterpret_cast<const f32x4*>(dwl + (ky * 3 + kx) * cp + qq * 4);
+                    acc.x = lo_act(acc.x, act); acc.y = lo_act(acc.y, act); acc.z = lo_act(acc.z, act); acc.w = lo_act(acc.w, act);
                 }
-                acc.x = lo_act(acc.x, act); acc.y = lo_act(acc.y, act); acc.z = lo_act(acc.z, act); acc.w = lo_act(acc.w, act);
+                if (last) { if (inside) *reinterpret_cast<f32x4*>(p.y + (((size_t)n * p.H3 + gy) * p.W3 + gx) * FP + qq * 4) = acc; }
+                else *reinterpret_cast<f32x4*>(buf[cur ^ 1] + pl * BP + qq * 4) = acc;
             }
-            if (last) {
-                if (inside) *reinterpret_cast<f32x4*>(p.y + (((size_t)n * p.H3 + gy) * p.W3 + gx) * FP + q * 4) = acc;
-            } else {
-                *reinterpret_cast<f32x4*>(buf[cur ^ 1] + pl * FP + q * 4) = acc;
-            }
+            __syncthreads();
+            cur ^= 1;
+            S = So;
+            ++oy; ++ox;
         }
-        __syncthreads();
-        cur ^= 1;
-        S = So;
-        ++oy; ++ox;
     }
+}
+
+template <int ST>
+size_t s2_lds()
+{
+    // conv2 tile + input patch; > 64 KB for fp32 storage: the attribute is set once per device (as esr_s16.hip does)
+    const size_t bytes = CT * CT * FP * sizeof(float) + S2In<ST>::BYTES;
+    static std::atomic<unsigned> attr_set[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_set[dev].load(std::memory_order_relaxed)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&esa_s2pool_kernel<ST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess)
+            attr_set[dev].store(1u, std::memory_order_relaxed);
+    }
+    return bytes;
 }
 
 }  // namespace
@@ -264,9 +319,9 @@ extern "C" int esr_esa_lowres_f32(const esr_esa_lowres_desc* d, void* hip_stream
     const float* w0 = static_cast<const float*>(d->w_s2);
     float* pooled = static_cast<float*>(d->pooled);
     switch (d->storage) {
-        case ESR_STORE_F32: esr_note_kernel("esa_s2pool_kernel<0>"); hipLaunchKernelGGL(esa_s2pool_kernel<ESR_STORE_F32>, grid, dim3(256), 0, st, d->x.ptr, w0, pooled, d->h, d->w, H2, W2, H3, W3, tx, ty); break;
-        case ESR_STORE_BF16: esr_note_kernel("esa_s2pool_kernel<1>"); hipLaunchKernelGGL(esa_s2pool_kernel<ESR_STORE_BF16>, grid, dim3(256), 0, st, d->x.ptr, w0, pooled, d->h, d->w, H2, W2, H3, W3, tx, ty); break;
-        case ESR_STORE_F16: esr_note_kernel("esa_s2pool_kernel<2>"); hipLaunchKernelGGL(esa_s2pool_kernel<ESR_STORE_F16>, grid, dim3(256), 0, st, d->x.ptr, w0, pooled, d->h, d->w, H2, W2, H3, W3, tx, ty); break;
+        case ESR_STORE_F32: esr_note_kernel("esa_s2pool_kernel<0>"); hipLaunchKernelGGL(esa_s2pool_kernel<ESR_STORE_F32>, grid, dim3(256), s2_lds<ESR_STORE_F32>(), st, d->x.ptr, w0, pooled, d->h, d->w, H2, W2, H3, W3, tx, ty); break;
+        case ESR_STORE_BF16: esr_note_kernel("esa_s2pool_kernel<1>"); hipLaunchKernelGGL(esa_s2pool_kernel<ESR_STORE_BF16>, grid, dim3(256), s2_lds<ESR_STORE_BF16>(), st, d->x.ptr, w0, pooled, d->h, d->w, H2, W2, H3, W3, tx, ty); break;
+        case ESR_STORE_F16: esr_note_kernel("esa_s2pool_kernel<2>"); hipLaunchKernelGGL(esa_s2pool_kernel<ESR_STORE_F16>, grid, dim3(256), s2_lds<ESR_STORE_F16>(), st, d->x.ptr, w0, pooled, d->h, d->w, H2, W2, H3, W3, tx, ty); break;
         default: return ESR_ERR_BAD_ARG;
     }
     int rc = esr_check_launch("esa_s2pool_kernel launch");

@@ -63,12 +63,14 @@ class BSRN(HipSRModel):
         self._add_conv('upsampler.upsampleOneStep.0', C, num_out_ch * upscale * upscale, 3)
 
     @staticmethod
-    def _merged_bsconv(pw, dw):
+    def _merged_bsconv(pw, dw, wp=None):
         """BSConvU (team18_bsrn.py:82-88) as a dense 3x3: y[c] = sum_tap dw[c,tap] * pad0(pw[c,:] . x + bp[c]) + bd[c]
         -> weights W[c,k,tap] = dw[c,tap] * pw[c,k], bias bd[c] + bp[c] * sum_tap dw[c,tap] for interior pixels, and for a
         pixel whose taps with dx = -1 (mask bit 0), dx = +1 (bit 1), dy = -1 (bit 2), dy = +1 (bit 3) fall outside the image
         the table row [mask] = -bp[c] * sum over those taps of dw[c,tap]."""
-        wp = pw.weight.detach().double().cpu().reshape(pw.weight.shape[0], -1)      # [C, cin]   (host arithmetic, fp64)
+        if wp is None:
+            wp = pw.weight.detach().reshape(pw.weight.shape[0], -1)
+        wp = wp.detach().double().cpu()                                               # [C, cin]   (host arithmetic, fp64)
         wd = dw.weight.detach().double().cpu().reshape(-1, 3, 3)                      # [C, ky, kx]
         bp = pw.bias.detach().double().cpu() if pw.bias is not None else torch.zeros(wp.shape[0], dtype=torch.float64)
         bd = dw.bias.detach().double().cpu() if dw.bias is not None else torch.zeros(wp.shape[0], dtype=torch.float64)
@@ -111,6 +113,11 @@ class BSRN(HipSRModel):
         packed['fea_conv.pw'] = pack_conv(w3, pw.bias).to(device)
         if self._store() != "f32":                                           # the 16-bit head (engine.Plan.conv lowers it to pack + conv_s16)
             packed['fea_conv.pw#head#s16'] = pack_head_s16(w3, pw.bias, self._store()).to(device)
+            # ... and fea_conv as ONE dense 3x3 of the packed input (pointwise x depthwise merged like the blocks' BSConvUs): the
+            # depthwise pass of the head was a launch of its own at 2.2x its algorithmic bytes
+            wm, bm, table = self._merged_bsconv(pw, self._leaf('fea_conv.dw'), wp=w)
+            packed['fea_conv#bs3#head#s16'] = pack_head_s16(wm, bm, self._store()).to(device)
+            packed['fea_conv#bs3#border'] = table.to(device)
         for k in range(1, self.nb + 1):
             co = self._leaf(f'B{k}.conv_out')
             cw = self._leaf(f'B{k}').cw.detach().float().reshape(1, C)
@@ -133,20 +140,27 @@ class BSRN(HipSRModel):
         def bs3(path, src, dst, cin, cout, **kw):
             plan.conv(path + '#bs3', src, dst, cin, cout, k=3, border=path + '#bs3#border', bs_of=path, **kw)
         fea = plan.buffer('fea', C)
-        bcat = plan.buffer('bcat', nb * C)                # block outputs, team18_bsrn.py:226
+        # block outputs, team18_bsrn.py:226.  16-bit storage: nb dense tensors (engine.Planar) -- as C-channel slices of one [.., nb C]
+        # buffer every block wrote 96 of 384 bytes per pixel (partial lines) and the next block's first convolutions read them back
+        # at 1.7x their algorithmic bytes (profiles/pmc_traffic.json, r03b)
+        bplanar = merged and C % 16 == 0
+        bcat = plan.planar('bcat', nb, C) if bplanar else plan.buffer('bcat', nb * C)
         # d1 d2 d3 r4, team18_bsrn.py:166.  16-bit storage: four dense tensors of DP = round_up(dc, 16) channels (engine.Planar):
         # a dc-channel slice of a [.., 4 dc] buffer is a partial-line store (48 of 192 bytes per pixel), 2.3x the cost of a dense one
         DP = (dc + 15) // 16 * 16
         cat = plan.planar('cat', 4, DP) if merged else plan.buffer('cat', 4 * dc)
         cs = (lambda j: cat.seg(j)) if merged else (lambda j: cat[j * dc:(j + 1) * dc])
-        t = plan.buffer('t', C)                           # pointwise result feeding the depthwise
+        t = None if merged else plan.buffer('t', C)       # pointwise result feeding the head's depthwise
         r1, r2, v, u = plan.buffer('r1', C), plan.buffer('r2', C), plan.buffer('v', C), plan.buffer('u', C)
         c1 = plan.buffer('esa_c1', FP)
         lo2 = plan.buffer('esa_s2', FP, h2, w2)
         la, lb, lt = (plan.buffer(n, FP, h3, w3) for n in ('esa_a', 'esa_b', 'esa_t'))
         lo = (h3, w3)
-        plan.conv('fea_conv.pw', INPUT, t, self.in_nc, C, counted=False)
-        plan.dwconv('fea_conv.dw', t, fea, C)
+        if merged:
+            plan.conv('fea_conv#bs3', INPUT, fea, self.in_nc, C, k=3, border='fea_conv#bs3#border', bs_of='fea_conv')
+        else:
+            plan.conv('fea_conv.pw', INPUT, t, self.in_nc, C, counted=False)
+            plan.dwconv('fea_conv.dw', t, fea, C)
         cur = fea
         for k in range(1, nb + 1):
             b = f'B{k}.'
@@ -195,7 +209,7 @@ class BSRN(HipSRModel):
                                  dict(kind=1, act=ga, w=b + 'esa.conv3.pw', w_dw=b + 'esa.conv3.dw'),
                                  dict(kind=1, act=L.ACT_NONE, w=b + 'esa.conv3_.pw', w_dw=b + 'esa.conv3_.dw')])
             plan.esa_apply(b + 'esa.conv_f', b + 'esa.conv4', v, c1, lb, u, C, f)
-            out = bcat[(k - 1) * C:k * C]
+            out = bcat.seg(k - 1) if bplanar else bcat[(k - 1) * C:k * C]
             plan.conv(b + 'conv_out', u, out, C, C, k=1, res=src, res_mode=L.RES_PRE_ACT, counted=False)
             cur = out
         plan.conv('c1', bcat, v, nb * C, C, k=1, counted=False, **g)

@@ -915,6 +915,8 @@ class HipSRModel(nn.Module):
                 if o.get("bs_of") is not None:      # the BSConvU it stands for: pointwise GEMM + depthwise 3x3
                     flops = 2.0 * npix * (ca * o["cout"] + 9 * o["cout"])
                     rd = npix * (ca * e_in + (o["cout"] * e_act if (o["res"] is not None and o["res"] is not o["src"]) else 0)) + 4.0 * (ca * o["cout"] + 10 * o["cout"])
+                    if o.get("head"):
+                        rd -= npix * ca * e_in
                 t = o.get("tail")
                 if t is not None:                   # 3x3 -> 1x1 in one kernel: both GEMMs' flops, the 1x1's traffic
                     kern = f"conv_f32_kernel<NT={nt},KS=3,NCHW_IN=0,NW=4,TAIL={(t['cout'] + 15) // 16}>"

@@ -19,22 +19,24 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, REPO)
 SRC = os.path.join(REPO, "ntire2022_esr_amd", "csrc")
 
-MF = [("                    for (int r = 0; r < RW; ++r) acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], acc[tt][r]);",
-       "                    for (int r = 0; r < RW; ++r) acc[tt][r].x += 1.f;"),
-      ("        if (NBUF == 2) load_frag(0, 0);", "        ;"),
-      ("                if (q + 1 < PAIRS) load_frag(cs ^ 1, q + 1);", "                ;"),
-      ("                load_frag(0, q);", "                ;")]
+MFMA_LINE = "acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], acc[tt][r]);"
+NEXT_LOADS = [("                        if (q + 1 < PAIRS && m < NFRAG) load_one(cs ^ 1, q + 1, m, false);", "                        ;", 2),
+              ("                for (int i = NT * RW; i < NFRAG; ++i) load_one(cs ^ 1, q + 1, i, false);", "                ;")]
+MF = [(MFMA_LINE, "acc[tt][r].x += 1.f;", 2), ("        for (int i = 0; i < NFRAG; ++i) load_one(0, 0, i, EPI);", "        ;")] + NEXT_LOADS
+# the fragment reads of the stage's first pair only (both sets), every later MFMA reuses them: LDS read traffic / waits removed
+NODS = [("        for (int i = 0; i < NFRAG; ++i) load_one(0, 0, i, EPI);", "        for (int i = 0; i < NFRAG; ++i) { load_one(0, 0, i, EPI); load_one(1, 0, i, EPI); }")] + NEXT_LOADS
 WAIT = ("            wait_vm_dyn((R - 2) * n_my + epi_stores * __builtin_popcount(hist_st & hmask) + (GRES ? RES_LOADS : 0) * __builtin_popcount(hist_rs & hmask));", "            ;")
-DMA = ("            dma_buf16(ring_lds + (unsigned)(lslot * STAGE_BYTES) + (unsigned)pc * 1024u, lvoff[i], lrsrc, (unsigned)lc * 32u);", "            ;")
+DMA = ("            else dma_buf16(dst, lvoff[i], lrsrc, lsoff);", "            else ;")
 SUBS = {
     "prod": [],
     "nw16": [("constexpr int S16_NW = 8;", "constexpr int S16_NW = 16;")],      # 16 waves per tile, 2 rows each
+    "nods": NODS,
     "nomfma": MF,                                   # the memory pipeline alone (DMA issue, waits, epilogue stores)
     "nowait": [WAIT],                               # no vmcnt wait before the stage barrier (results wrong)
     "nodma": [DMA, WAIT],                           # LDS reads + MFMA + epilogue only (results wrong)
     "nostore": [("        __builtin_amdgcn_raw_buffer_store_b128(o, __builtin_amdgcn_make_buffer_rsrc(e_y0, 0, e_y0n, 0x00020000), v0 + (unsigned)r * e_rowb0, 0, 0);",
                  "        if (o.x == 0x7fc12345) __builtin_amdgcn_raw_buffer_store_b128(o, __builtin_amdgcn_make_buffer_rsrc(e_y0, 0, e_y0n, 0x00020000), v0 + (unsigned)r * e_rowb0, 0, 0);")],
-    "nobar": [("            __builtin_amdgcn_s_barrier();\n            slot = slot == R - 1 ? 0 : slot + 1;", "            slot = slot == R - 1 ? 0 : slot + 1;")],   # no stage barrier (results wrong)
+    "nobar": [("            if (!OWN_PIECES) __builtin_amdgcn_s_barrier();\n            slot = slot == R - 1 ? 0 : slot + 1;", "            slot = slot == R - 1 ? 0 : slot + 1;")],   # no stage barrier (results wrong)
 }
 
 
@@ -57,7 +59,8 @@ def build(only=None):
                 s += b
                 continue
             assert a in s, (name, a)
-            s = s.replace(a, b, *sub[2:])
+            assert s.count(a) == (sub[2] if len(sub) > 2 else 1), (name, a, s.count(a))
+            s = s.replace(a, b)
         src = os.path.join(HERE, f"s16_{name}.hip")
         open(src, "w").write(s)
         vo = os.path.join(HERE, f"obj_s16_{name}.o")

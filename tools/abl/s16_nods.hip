@@ -1,0 +1,1436 @@
+// esr_s16.hip -- the 16-bit-STORAGE convolution of libesr_hip.so (BASELINE.json configs [2]-[4]: bf16 / fp16).
+// Interface: include/esr_hip.h (esr_conv_desc.storage != ESR_STORE_F32).  Design notes: DESIGN.md section 4.
+//
+// Activations live in HBM as NHWC bf16 / fp16; the matrix products run on v_mfma_f32_16x16x32_{bf16,f16} with fp32
+// accumulation; bias, residual, activation are applied in fp32 and the result is rounded ONCE (RNE) when it is stored.
+// At 16x the fp32 matrix rate the layer is HBM-bound, so the kernel is built around the memory pipe:
+//   * the input halo tile goes global -> LDS by DMA (`buffer_load_dwordx4 ... lds`): no staging VGPRs, no ds_write, no
+//     conversion (the storage type IS the operand type); out-of-image halo pixels use an out-of-range buffer offset and
+//     the hardware writes zeros (the convolution's zero padding);
+//   * a ring of R = 3..8 K stages (16 channels = 32 bytes per pixel each, as many as fit next to the weights): while
+//     stage s is multiplied, s+1 .. s+R-1 are in flight, across tile boundaries of the persistent block;
+//   * the layer's whole weight set is resident in LDS for the life of the block (<= 80 KB: 64 -> 64 channels, 3x3);
+//   * one barrier per stage with an EXACT `s_waitcnt vmcnt(N)`: N counts every vector-memory instruction the wave issued
+//     after the DMA of the stage it needs (younger stages, the previous tile's stores, residual loads), so nothing but
+//     the needed stage is waited for; the previous tile's epilogue runs behind the DMA issue of the next tile's stage.
+// GEMM view and fragment maps: D[cout][pixel], A = weights, B = 16 consecutive pixels of one image row, D gives lane
+// (px, kq) 4 consecutive output channels of one pixel -- exactly as conv_f32_kernel (esr_hip.hip).  K slots of one MFMA:
+// lane (i, kq) holds 8 consecutive k = 8 channels (16 bytes) of ONE tap: kq & 1 selects the channel half of the chunk,
+// kq >> 1 the tap of a tap PAIR, so the 9 taps of a chunk take 5 MFMAs (the 10th tap slot holds zero weights).
+// For 1x1 convolutions the second tap slot is not wasted: it carries the LOW part of the weights (w = hi + lo, both
+// 16-bit), so 1x1 layers see effectively fp32-accurate weights at no cost.  3x3 weights are rounded with error
+// diffusion over the 9 taps of each (cout, cin) filter (esr_pack_conv_s16): the filter's DC gain, which dominates the
+// response to natural features, keeps fp32 accuracy.  Measured effect on RLFN bf16: tools/emulate_s16.py, DESIGN.md.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <atomic>
+#include <type_traits>
+
+#include "esr_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int TILE = 16;            // output tile width (pixels) = one MFMA's pixel dimension
+constexpr int RING_MIN = 3, RING_MAX = 8;   // input stages in LDS (as many as fit next to the resident weights)
+constexpr unsigned OOB = 0x80000000u;
+constexpr int LDS_LIMIT = 160 * 1024;
+constexpr int MAX_DEVICES = 64;     // per-device launch attributes (launch_s16)
+constexpr int S16_NW = 8;           // waves per tile
+
+struct S16K {
+    const char* x;        // NHWC 16-bit input
+    const char* wp;       // esr_pack_conv_s16 blob: weight image, then fp32 bias
+    const float* bias;
+    const char* res;      // NHWC 16-bit residual
+    char* y0;             // NHWC 16-bit output, or NCHW fp32 (ESR_NCHW_SHUFFLE4)
+    char* y1;
+    int N, H, W;
+    int nchunks;          // ceil(cin_phys / 16)
+    int ring;             // input stages in LDS
+    int in_pitch, in_coff;
+    int res_pitch, res_coff;
+    int y0_pitch, y0_coff, y1_pitch, y1_coff;
+    int cout_store;       // NHWC: round_up8(cout) -- channels >= this are never stored; SHUFFLE4: cout
+    int split;
+    int act;
+    float slope;          // LeakyReLU slope; the kernel evaluates max(v, slope * v): 1 = identity, 0 = ReLU
+    int res_mode;         // residual read from HBM (0 = none)
+    int res_in;           // pre-activation residual == the conv input: added from the staged tile in LDS, no loads
+    int nres;             // residual from HBM staged like input chunks: this many extra 16-channel stages per tile (PNT1 == 0 kernels)
+    int out_layout;
+    int tiles_x, tiles_y;
+    unsigned magic_x, magic_y;   // ceil(2^32 / tiles): t / tiles == umulhi(t, magic) for t * tiles < 2^32 (0: tiles == 1)
+    // post chain (PNT1 > 0 kernels): 1x1 convolution(s) of the epilogue result, evaluated in the epilogue (esr_conv_desc.post_*)
+    const char* pw1; const char* pw2;      // esr_pack_post_s16 blobs: hi images, lo images, fp32 bias
+    char* py1; char* py2;
+    int py1_pitch, py1_coff, py2_pitch, py2_coff;
+    int p1_cout8, p2_cout8;                // channels stored (multiples of 8 / 4)
+    float p1_slope;                        // activation of post 1 as max(v, slope v)
+    int p1_gelu;                           // ... or GELU
+    int post_lo;                           // the low-part weight images are resident too (w = hi + lo)
+    int store_main;                        // 0: the conv's own result is consumed by the post chain only
+    const float* border;                   // esr_conv_desc.border_bias, or NULL
+    long long seg_stride;                  // segmented input: bytes between the tensors of the concat (else 0)
+    int seg_chunks;                        // chunks per input segment (one tensor: nchunks)
+};
+
+template <bool BF16>
+__device__ __forceinline__ f32x4 mfma32(i32x4 a, i32x4 b, f32x4 c)
+{
+    if (BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// two fp32 -> one dword of two 16-bit values (RNE), and back
+template <bool BF16>
+__device__ __forceinline__ unsigned pack2(float a, float b)
+{
+    if (BF16) {
+        bf16x2 v;
+        v[0] = (__bf16)a; v[1] = (__bf16)b;
+        return __builtin_bit_cast(unsigned, v);
+    }
+    f16x2 v;
+    v[0] = (_Float16)a; v[1] = (_Float16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <bool BF16>
+__device__ __forceinline__ void unpack2(unsigned u, float& a, float& b)
+{
+    if (BF16) {
+        a = __builtin_bit_cast(float, u << 16);
+        b = __builtin_bit_cast(float, u & 0xffff0000u);
+    } else {
+        const f16x2 v = __builtin_bit_cast(f16x2, u);
+        a = (float)v[0]; b = (float)v[1];
+    }
+}
+
+template <bool BF16>
+__device__ __forceinline__ f32x4 unpack4(uint2 u)
+{
+    float a, b, c, d;
+    unpack2<BF16>(u.x, a, b);
+    unpack2<BF16>(u.y, c, d);
+    return f32x4{a, b, c, d};
+}
+
+// GELU for the 16-bit storage modes: x * Phi(x) with Phi(x) - 0.5 = x * P(x^2), P a degree-7 minimax polynomial on |x| <= 4
+// (|error| of Phi <= 2.1e-5, tools/fit_gelu.py), the argument clamped to [-4, 4] and the factor x to [-4, inf): |gelu error| <=
+// 1.3e-4 for x <= 4 and 5.3e-5 x beyond, about one fp16 step of the values that matter, far below a bf16 step -- and 11 plain VALU instructions
+// (packable two values at a time) instead of libm erff's ~40 or the 16 + v_rcp + v_exp of an erf approximation.  The fp32
+// path keeps erff.
+__device__ __forceinline__ __attribute__((unused)) float gelu16(float x)       // the scalar definition (esr_bsconv.hip uses it as is)
+{
+    const float xc = fminf(fmaxf(x, -4.f), 4.f);
+    const float t = xc * xc;
+    float p = -1.580786198e-09f;
+    p = fmaf(p, t, 1.217111051e-07f);
+    p = fmaf(p, t, -4.100866386e-06f);
+    p = fmaf(p, t, 8.066739505e-05f);
+    p = fmaf(p, t, -1.048204400e-03f);
+    p = fmaf(p, t, 9.664874174e-03f);
+    p = fmaf(p, t, -6.617537882e-02f);
+    p = fmaf(p, t, 3.988475079e-01f);
+    return fmaxf(x, -4.f) * fmaf(xc, p, 0.5f);
+}
+
+// the same arithmetic (bit for bit) on a D fragment with packed fp32 instructions: 16 v_pk_fma + 4 v_pk_mul + 4 v_med3 + 4 v_max
+// = 7 VALU instructions per value instead of 13
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu16x2(f32x2 x)
+{
+    f32x2 xc, xm;
+    xc.x = __builtin_amdgcn_fmed3f(x.x, -4.f, 4.f); xc.y = __builtin_amdgcn_fmed3f(x.y, -4.f, 4.f);
+    const f32x2 t = xc * xc;
+    f32x2 p = {-1.580786198e-09f, -1.580786198e-09f};
+    p = __builtin_elementwise_fma(p, t, f32x2{1.217111051e-07f, 1.217111051e-07f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-4.100866386e-06f, -4.100866386e-06f});
+    p = __builtin_elementwise_fma(p, t, f32x2{8.066739505e-05f, 8.066739505e-05f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-1.048204400e-03f, -1.048204400e-03f});
+    p = __builtin_elementwise_fma(p, t, f32x2{9.664874174e-03f, 9.664874174e-03f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-6.617537882e-02f, -6.617537882e-02f});
+    p = __builtin_elementwise_fma(p, t, f32x2{3.988475079e-01f, 3.988475079e-01f});
+    const float m4 = -4.f;
+    asm("v_max_f32 %0, %1, %2" : "=v"(xm.x) : "v"(x.x), "v"(m4));
+    asm("v_max_f32 %0, %1, %2" : "=v"(xm.y) : "v"(x.y), "v"(m4));
+    return xm * __builtin_elementwise_fma(xc, p, f32x2{0.5f, 0.5f});
+}
+__device__ __forceinline__ f32x4 gelu16x4(f32x4 v)
+{
+    const f32x2 a = gelu16x2(f32x2{v.x, v.y}), b = gelu16x2(f32x2{v.z, v.w});
+    return f32x4{a.x, a.y, b.x, b.y};
+}
+
+// Epilogue activation: max(v, slope * v); slope carries none (1) / LeakyReLU (s) / ReLU (0).  GELU is applied IN PLACE to the
+// accumulators at the end of a tile's last stage (gelu_inplace below), after which the epilogue runs with slope = 1: as a
+// second body of the epilogue its polynomials cost every variant ~50 VGPRs (or spills) for an activation only a few
+// launches use.  asm: fmaxf() on an MFMA result costs a second v_max (hipcc canonicalises the operand first).
+__device__ __forceinline__ float act1(float v, float slope)
+{
+    float r;
+    const float sv = slope * v;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(sv));
+    return r;
+}
+
+// LDS-DMA: every lane moves 16 bytes from (buffer base + voff + soff) to LDS byte (lds_dst + lane * 16); an out-of-range
+// voff writes zeros.  Issued from inline asm so that hipcc does not put vmcnt(0) in front of later ds_reads (it cannot see
+// which LDS bytes the DMA touches); completion is tracked by the counted waits of the stage loop.
+__device__ __forceinline__ void dma_buf16(unsigned lds_dst, unsigned voff, i32x4 rsrc, unsigned soff)
+{
+    // wave-uniform by construction; readfirstlane pins them to SGPRs where hipcc's uniformity analysis gives up
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    rsrc.x = __builtin_amdgcn_readfirstlane(rsrc.x); rsrc.y = __builtin_amdgcn_readfirstlane(rsrc.y);
+    rsrc.z = __builtin_amdgcn_readfirstlane(rsrc.z); rsrc.w = __builtin_amdgcn_readfirstlane(rsrc.w);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+__device__ __forceinline__ void dma_glb16(unsigned lds_dst, const void* g)
+{
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(g) : "memory");
+}
+
+// s_waitcnt vmcnt(cnt) for a wave-uniform runtime cnt (the immediate has to be a constant): a branch tree over the values
+// the stage loop produces; rounding DOWN is always safe (waits for more).
+__device__ __forceinline__ void wait_vm_dyn(int cnt)
+{
+#define ESR_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (cnt < 0 ? 0 : (cnt > 47 ? 47 : cnt)) {
+        ESR_W(0) ESR_W(1) ESR_W(2) ESR_W(3) ESR_W(4) ESR_W(5) ESR_W(6) ESR_W(7) ESR_W(8) ESR_W(9) ESR_W(10) ESR_W(11)
+        ESR_W(12) ESR_W(13) ESR_W(14) ESR_W(15) ESR_W(16) ESR_W(17) ESR_W(18) ESR_W(19) ESR_W(20) ESR_W(21) ESR_W(22) ESR_W(23)
+        ESR_W(24) ESR_W(25) ESR_W(26) ESR_W(27) ESR_W(28) ESR_W(29) ESR_W(30) ESR_W(31) ESR_W(32) ESR_W(33) ESR_W(34) ESR_W(35)
+        ESR_W(36) ESR_W(37) ESR_W(38) ESR_W(39) ESR_W(40) ESR_W(41) ESR_W(42) ESR_W(43) ESR_W(44) ESR_W(45) ESR_W(46) ESR_W(47)
+    }
+#undef ESR_W
+}
+
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, size_t bytes)
+{
+    i32x4 r;
+    r.x = (int)(size_t)base;
+    r.y = (int)(((size_t)base >> 32) & 0xffff);
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+
+// Pipeline (per block, stages s = (tile, 16-channel chunk) in order; R = ring slots):
+//   top of stage s   stage s has landed (previous sync).  DMA of stage s+R-1 into the slot stage s-1 just released; then the
+//                    EPILOGUE of the previous tile if s is a tile's first stage (its stores are issued behind the DMA, so the
+//                    memory pipe never waits for them); then, if s is the tile's last stage, the residual loads of THIS tile
+//   compute(s)       5 tap-pair MFMA groups per chunk (1 for 1x1) from ring slot s % R and the resident weights
+//   sync             s_waitcnt vmcnt(N) + s_barrier with N = the exact number of vector-memory instructions this wave has
+//                    issued AFTER the DMA of stage s+1 (younger stages, epilogue stores, residual loads): loads and stores
+//                    retire in issue order, so stage s+1 has landed while everything younger stays in flight -- R-1 stages
+//                    (20 KB each for a 3x3 on 16x32 tiles) are on their way from HBM at any time.
+// Every vector-memory instruction is issued unconditionally (invalid lanes use out-of-range buffer offsets: loads return
+// zero, stores are dropped), which is what makes the count exact.
+// GRES: the launch reads a residual from HBM (its 8 NT registers exist only in these variants, which in exchange keep a
+// single set of MFMA operand fragments: they are memory-bound twice over).
+// PNT1 / PNT2: output tiles of a chain of 1x1 convolutions evaluated in the epilogue on the fp32 result tile (RLFB: c3_r -> c5 ->
+// esa.conv1, team04_rlfn.py:117-121 / :76; RFDB: c{j}_r -> c{j+1}_d, rfdn_baseline/block.py:150-160).  The D fragment of the
+// producing GEMM (lane (px, kq): 4 channels of one pixel, fp32) becomes the B operand of the next WITHOUT leaving the lane and
+// without being rounded: k slots (kq, 0..3) carry the 16-bit high parts of the four values, (kq, 4..7) their low parts, so the
+// intermediate tensor (RLFB's u, which nothing else reads) is neither stored nor quantised.
+template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 = 0>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(const S16K p)
+{
+    static_assert(PNT2 == 0 || PNT1 > 0, "post 2 needs post 1");
+    constexpr int HALO = KS / 2;
+    constexpr int TH = TILE + 2 * HALO;          // halo tile width = LDS row pitch in pixels
+    // NW = 4: 16 x 16 tiles and TWO independent blocks per CU (each with its own copy of the weights: only where that fits 80 KB) --
+    // the two waves of a SIMD then belong to different blocks and do not share a stage barrier
+    constexpr int TILE_H = NW == 4 ? 16 : 32;    // tile height; wave wv owns rows RW wv .. RW wv + RW-1
+    constexpr int RW = TILE_H / NW;              // rows per wave: 4 (4 / 8 waves) or 2 (16 waves: 4 per SIMD hide each other's LDS / issue stalls)
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per tile");
+    constexpr int THY = TILE_H + 2 * HALO;
+    constexpr int NPX = TH * THY;
+    constexpr int NPIECES = (NPX + 31) / 32;     // 1 KB DMA pieces: 32 halo pixels x 32 bytes (lane pair = the 16 channels of a pixel)
+    constexpr int STAGE_BYTES = NPIECES * 1024;  // [halo pixel][half][8 channels]
+    constexpr int PPW = (NPIECES + NW - 1) / NW; // pieces per wave and stage (waves >= NPIECES % NW: one fewer)
+    // 1x1: no halo, so a wave can stage exactly the pixels it computes (pieces PPW wv ..): nothing staged is shared between waves,
+    // the stage loop needs NO barrier and the eight waves drift freely (the weights, biases and tables in LDS are read-only)
+    constexpr bool OWN_PIECES = KS == 1 && NPIECES == NW * PPW && PPW * 32 == RW * TH;
+    static_assert(KS != 1 || OWN_PIECES, "1x1: pieces = the wave's own rows");
+    constexpr int TAPS = KS * KS;
+    constexpr int PAIRS = (TAPS + 1) / 2;
+    constexpr int W_CHUNK_BYTES = PAIRS * NT * 1024;   // [pair][tile][lane][16 B]
+    constexpr int RES_LOADS = NT * RW;           // residual loads per wave and tile (8 bytes per lane each)
+
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15;
+    const int kq = lane >> 4;
+    // The launch parameters are re-read from the kernarg segment where they are used (tile set-up, epilogue) instead of living
+    // in SGPRs across the stage loop: with ~40 parameters + loop state hipcc spilled 70-160 SGPRs to VGPR lanes and the
+    // v_readlane / v_writelane traffic was a third of the kernel's VALU instructions.  The asm makes the pointer opaque, so the
+    // scalar loads (a few s_load_dwordx8 per tile) cannot be hoisted back out of the loop.
+    typedef const __attribute__((address_space(4))) S16K* kparg_t;
+    const kparg_t kp0 = (kparg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    auto KP = [&]() __attribute__((always_inline)) -> kparg_t {
+        kparg_t q = kp0;
+        asm volatile("" : "+s"(q));
+        return q;
+    };
+    const int R = p.ring;
+    const int w_main = p.nchunks * W_CHUNK_BYTES;
+    // post images: [post 1: NT k-tiles x PNT1 tiles, hi (then lo)][post 2: PNT1 k-tiles x PNT2 tiles, hi (then lo)][biases, 1 KB]
+    constexpr int P1_IMG = NT * PNT1 * 1024, P2_IMG = PNT1 * PNT2 * 1024;
+    const int plo = (PNT1 > 0 && p.post_lo) ? 2 : 1;
+    // [weights][post images (PNT1 > 0)][bias KB: post biases, the conv's own bias in the upper half][border table NT KB (p.border)][ring]
+    const int bias_at = w_main + (PNT1 > 0 ? plo * (P1_IMG + P2_IMG) : 0);
+    const int w_bytes = bias_at + 1024 + (p.border ? NT * 1024 : 0);
+    float* const sbias = reinterpret_cast<float*>(smem + bias_at + 512);
+    float* const btab = reinterpret_cast<float*>(smem + bias_at + 1024);  // border bias table [16][NT * 16]
+    const char* const pimg1 = smem + w_main;
+    const char* const pimg2 = pimg1 + plo * P1_IMG;
+    float* const pbias = reinterpret_cast<float*>(smem + w_main + plo * (P1_IMG + P2_IMG));
+    char* const ring = smem + w_bytes;
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ring_lds = smem_lds + (unsigned)w_bytes;
+
+    // ---- tile walk (persistent; XCD-aware order as in conv_f32_kernel) ---------------------------------------------
+    const int ntiles = p.N * p.tiles_y * p.tiles_x;
+    const int G = gridDim.x;
+    auto tile_index = [&](int k) -> int {
+        const int base = k * G;
+        if (base >= ntiles) return -1;
+        int off = blockIdx.x;
+        if ((G & 7) == 0 && base + G <= ntiles) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+        const int t = base + off;
+        return t < ntiles ? t : -1;
+    };
+    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) {
+        const kparg_t q = KP();
+        const unsigned mx = q->magic_x, my = q->magic_y;
+        const int tsx = q->tiles_x, tsy = q->tiles_y;
+        const int tq = mx ? (int)__umulhi((unsigned)t, mx) : t;          // t / tiles_x without the 25-instruction division
+        const int tx = t - tq * tsx;
+        n = my ? (int)__umulhi((unsigned)tq, my) : tq;
+        const int ty = tq - n * tsy;
+        x0 = tx * TILE;
+        y0 = ty * TILE_H;
+    };
+
+    // ---- load cursor: the (tile, chunk) stage requested next ---------------------------------------------------------
+    // piece pc = wv + NW * i of a stage: halo pixels 32 pc + (lane >> 1), channel half lane & 1 -- a lane PAIR reads the 32
+    // contiguous bytes of a pixel's chunk (32-byte runs cost the memory pipe 12 % less than 16-byte ones: tools/abl nomfma_r*).
+    // Behind the block's last tile the cursor keeps issuing (out-of-range offsets: zeros into a ring slot nobody reads), so
+    // every stage carries the same number of DMA instructions and the vmcnt arithmetic has no special cases.
+    const int n_my = (NPIECES % NW == 0 || wv < NPIECES % NW) ? PPW : PPW - 1;     // wave-uniform
+    int lk = 0;                   // tile iteration of the cursor
+    int lc = 0;                   // chunk of the cursor
+    int lcc = 0;                  // ... within its input segment
+    unsigned lsoff = 0;           // ... as the DMA's scalar byte offset
+    int lslot = 0;
+    bool lvalid;
+    static_assert(PPW <= 3, "lvr0..2");
+    unsigned lvoff[PPW];                   // input
+    unsigned lvr0 = OOB, lvr1 = OOB, lvr2 = OOB;     // residual (p.nres > 0: staged as extra chunks, added from LDS -- no registers in flight); scalars: as an array hipcc kept it in scratch
+    auto LVR = [&](int i) __attribute__((always_inline)) -> unsigned& { return i == 0 ? lvr0 : (i == 1 ? lvr1 : lvr2); };
+    i32x4 lrsrc, lrsrcr = {0, 0, 0, 0};
+    const int nstages = p.nchunks + p.nres;       // stages per tile
+    auto cursor_tile = [&]() __attribute__((always_inline)) {
+        const int t = tile_index(lk);
+        lvalid = t >= 0;
+        if (!lvalid) {
+#pragma unroll
+            for (int r = 0; r < PPW; ++r) { lvoff[r] = OOB; LVR(r) = OOB; }
+            return;
+        }
+        int n, x0, y0;
+        tile_coords(t, n, x0, y0);
+        const kparg_t q = KP();
+        const int qH = q->H, qW = q->W, qpitch = q->in_pitch, qcoff = q->in_coff;
+        const size_t img_bytes = (size_t)qH * qW * qpitch * 2;
+        lrsrc = make_rsrc(q->x + (size_t)n * img_bytes, img_bytes);
+        const bool withres = q->nres > 0;
+        const int qrp = q->res_pitch, qrc = q->res_coff;
+        if (withres) {
+            const size_t res_bytes = (size_t)qH * qW * qrp * 2;
+            lrsrcr = make_rsrc(q->res + (size_t)n * res_bytes, res_bytes);
+        }
+#pragma unroll
+        for (int r = 0; r < PPW; ++r) {
+            const int pc = OWN_PIECES ? wv * PPW + r : wv + NW * r;
+            const int plane = lane & 1;                       // channel half
+            const int pl = pc * 32 + (lane >> 1);
+            const int ly = pl / TH, lx = pl - ly * TH;
+            const int gy = y0 - HALO + ly, gx = x0 - HALO + lx;
+            const bool ok = pc < NPIECES && pl < NPX && (unsigned)gy < (unsigned)qH && (unsigned)gx < (unsigned)qW;
+            lvoff[r] = ok ? (unsigned)((gy * qW + gx) * qpitch + qcoff + 8 * plane) * 2u : OOB;
+            LVR(r) = (ok && withres) ? (unsigned)((gy * qW + gx) * qrp + qrc + 8 * plane) * 2u : OOB;
+        }
+    };
+    auto dma_piece = [&](int i) __attribute__((always_inline)) {       // piece i of this wave of the cursor's stage, into ring slot lslot
+        const int pc = OWN_PIECES ? wv * PPW + i : wv + NW * i;
+        if (NPIECES % NW == 0 || i < PPW - 1 || pc < NPIECES) {         // wave-uniform
+            const unsigned dst = ring_lds + (unsigned)(lslot * STAGE_BYTES) + (unsigned)pc * 1024u;
+            const bool isres = lc >= p.nchunks;                        // a residual chunk: selects, not a branch (ONE asm site per piece)
+            i32x4 rs;
+            rs.x = isres ? lrsrcr.x : lrsrc.x; rs.y = isres ? lrsrcr.y : lrsrc.y; rs.z = isres ? lrsrcr.z : lrsrc.z; rs.w = isres ? lrsrcr.w : lrsrc.w;
+            dma_buf16(dst, isres ? LVR(i) : lvoff[i], rs, isres ? (unsigned)(lc - p.nchunks) * 32u : lsoff);
+        }
+    };
+    auto cursor_advance = [&]() __attribute__((always_inline)) {
+        lslot = lslot == R - 1 ? 0 : lslot + 1;
+        if (++lcc == p.seg_chunks) {                // (esr_conv_desc.in_seg_*: the next chunk lies in the next tensor of the concat)
+            // the buffer BASE moves on: the hardware's range check covers the scalar offset too, so a segment stride in soffset
+            // would put every later segment out of range (num_records = one tensor's image)
+            lcc = 0;
+            lsoff = 0;
+            const unsigned long long b = ((unsigned long long)(unsigned)lrsrc.x | ((unsigned long long)((unsigned)lrsrc.y & 0xffffu) << 32)) + (unsigned long long)p.seg_stride;
+            lrsrc.x = (int)(unsigned)b;
+            lrsrc.y = (int)((unsigned)(b >> 32) & 0xffffu);
+        } else {
+            lsoff += 32u;
+        }
+        if (++lc == nstages) {
+            lc = 0;
+            lcc = 0;
+            lsoff = 0;
+            ++lk;
+            cursor_tile();
+        }
+    };
+
+    // ---- prologue: weights (resident), the first R-1 stages ---------------------------------------------------------
+    {
+        const int wpieces = w_main / 1024;
+        for (int pc = wv; pc < wpieces; pc += NW)
+            dma_glb16(smem_lds + (unsigned)pc * 1024u, p.wp + (size_t)pc * 1024 + lane * 16);
+        if (PNT1 > 0) {
+            // blob: hi images, lo images, bias; resident: hi (then lo when post_lo)
+            const int n1 = plo * P1_IMG / 1024, n2 = plo * P2_IMG / 1024;
+            for (int pc = wv; pc < n1; pc += NW)
+                dma_glb16(smem_lds + (unsigned)(w_main + pc * 1024), p.pw1 + (size_t)pc * 1024 + lane * 16);
+            for (int pc = wv; pc < n2; pc += NW)
+                dma_glb16(smem_lds + (unsigned)(w_main + plo * P1_IMG + pc * 1024), p.pw2 + (size_t)pc * 1024 + lane * 16);
+            if (tid < PNT1 * 16) pbias[tid] = reinterpret_cast<const float*>(p.pw1 + 2 * P1_IMG)[tid];
+            if (PNT2 > 0 && tid < PNT2 * 16) pbias[PNT1 * 16 + tid] = reinterpret_cast<const float*>(p.pw2 + 2 * P2_IMG)[tid];
+        }
+    }
+    if (p.border)
+        for (int i = tid; i < 16 * NT * 16; i += 64 * NW) btab[i] = p.border[i];
+    if (tid < NT * 16) sbias[tid] = p.bias[tid];
+    cursor_tile();
+    if (!lvalid) return;                 // block without tiles (grid <= ntiles: does not happen)
+    for (int i = 0; i < R - 1; ++i) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) dma_piece(j);
+        cursor_advance();
+    }
+    wait_vm_dyn((R - 2) * n_my);         // the weights and stage 0 have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the biases / border table written above
+    __builtin_amdgcn_s_barrier();
+
+    // (the bias is re-read from LDS by each tile's first MFMA group: NT * 4 registers less across the whole loop)
+
+    // lane-constant LDS offsets of the B fragments: pair q reads tap min(2q + (kq >> 1), TAPS - 1), channel half kq & 1
+    int b_off[PAIRS];
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+        const int tap = min(2 * q + (kq >> 1), TAPS - 1);
+        b_off[q] = (((wv * RW) + tap / KS) * TH + px + tap % KS) * 32 + (kq & 1) * 16;
+    }
+    const int a_off = lane * 16;
+    // the centre pixel of this lane's accumulator rows in the staged tile: channels 16c + 4kq .. +3 of chunk c
+    const int c_off = ((wv * RW + HALO) * TH + px + HALO) * 32 + (kq >> 1) * 16 + (kq & 1) * 8;
+
+    // The plain NHWC epilogue (no post chain) lives INSIDE the first MFMA group of the next tile's first stage (swap_epi):
+    // row by row, activation / rounding of the finished tile's accumulators right before the MFMAs that overwrite them, the
+    // D fragments made store-shaped by v_permlane16_swap (no LDS, no waits), their stores in the shadow of the matrix pipe.
+    // The post chain (PNT1 / PNT2) runs there too, row by row on the activated fp32 fragments.  Only the pixel-shuffle epilogue
+    // of the network's last convolution is a phase of its own in front of the stage's compute.
+    const bool swap_epi = p.out_layout != ESR_NCHW_SHUFFLE4;
+    constexpr int SWAP_STORES = (NT / 2) * RW + (NT & 1) * (RW / 2);
+    constexpr int P1_STORES = (PNT1 / 2) * RW + (PNT1 & 1) * (RW / 2), P2_STORES = PNT2 > 0 ? RW / 2 : 0;
+    static_assert(PNT2 <= 1, "post 2: one tile");
+    const int epi_stores = p.out_layout == ESR_NCHW_SHUFFLE4 ? RW * NT
+                           : ((PNT1 == 0 || p.store_main) ? (p.split < p.cout_store ? 2 : 1) * SWAP_STORES : 0) + P1_STORES + P2_STORES;   // stores per wave and tile
+    const unsigned hmask = (1u << (R - 2)) - 1u;
+    unsigned hist_rs = 0, hist_st = 0;   // bit i: stage s - i was a tile's first stage (residual loads) / carried an epilogue's stores
+
+    f32x4 acc[NT][RW];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) acc[tt][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint2 rv[GRES ? NT : 1][RW];         // residual of the current tile in D-fragment layout (hidden asm loads)
+#pragma unroll
+    for (int tt = 0; tt < (GRES ? NT : 1); ++tt)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) rv[tt][r] = uint2{0u, 0u};
+
+    // Issued in a tile's FIRST stage, behind the previous tile's epilogue (which frees rv) and in front of the stage's DMA: by
+    // the time the tile's own epilogue wants them, nchunks stages of DMA are younger and stay in flight.  hipcc believes the
+    // asm's outputs are valid at once, so NOTHING may make it copy these registers before the wait: there is exactly ONE load
+    // site per kernel (two sites feeding one consumer meet in a phi, and the copies of the losing site run before the data
+    // has arrived -- seen with cin = 16), it lies behind the last use of the previous values (no interference, the loop-carried
+    // registers coalesce), and the GRES variants stay clear of spills (tools/dbg/s16_shape_probe.py, test_s16_conv_more_tiles_*).
+    auto load_residual = [&](int n, int x0, int y0, bool have) __attribute__((always_inline)) {
+        if (!GRES) return;
+        const kparg_t q = KP();
+        const int qH = q->H, qW = q->W, qrp = q->res_pitch, qrc = q->res_coff, qcs = q->cout_store;
+        const size_t res_img = (size_t)qH * qW * qrp * 2;
+        const i32x4 rr = make_rsrc(q->res + (size_t)n * res_img, res_img);
+        i32x4 rru;
+        rru.x = __builtin_amdgcn_readfirstlane(rr.x); rru.y = __builtin_amdgcn_readfirstlane(rr.y);
+        rru.z = __builtin_amdgcn_readfirstlane(rr.z); rru.w = __builtin_amdgcn_readfirstlane(rr.w);
+        // rows below the image fall past num_records and read zeros; one add per row, one per channel tile
+        const unsigned rbase = (unsigned)((y0 + wv * RW) * qW + x0) * (unsigned)qrp * 2u + (__umul24(px, qrp) + (unsigned)(qrc + kq * 4)) * 2u;
+        const unsigned rowb = (unsigned)qW * (unsigned)qrp * 2u;
+        const bool inx = have && x0 + px < qW;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                const int cb = tt * 16 + kq * 4;
+                const unsigned vo = (inx && cb < qcs) ? rbase + (unsigned)r * rowb + (unsigned)tt * 32u : OOB;
+                // "+v": the destination is TIED to the loop-carried register of rv, so the value never has to be copied into it
+                // at the loop latch (with "=v" hipcc gave the asm fresh registers and moved them over before the data was there)
+                asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "+v"(rv[GRES ? tt : 0][r]) : "v"(vo), "s"(rru) : "memory");
+            }
+        }
+    };
+
+    const bool act_gelu = p.act == ESR_ACT_GELU;
+    // waits for the finished tile's residual (loaded in its first stage: the tile's nchunks stages of DMA are younger)
+    auto wait_residual = [&]() __attribute__((always_inline)) {
+        if (!GRES) return;
+        wait_vm_dyn(p.nchunks * n_my);
+#pragma unroll
+        for (int tt = 0; tt < (GRES ? NT : 1); ++tt)
+#pragma unroll
+            for (int r = 0; r < RW; ++r) asm volatile("" : "+v"(rv[tt][r]));      // uses below stay behind the wait
+    };
+
+    // GELU, applied to the accumulators at the end of the tile's last stage; the epilogue then sees an identity activation.
+    // One fragment at a time (sched_barrier): register pressure stays flat.  A residual loaded from HBM can only follow the
+    // GELU (post-activation): its registers are in flight here and must not be touched -- not even by an empty asm, whose
+    // re-definition makes hipcc copy them on the paths that skip it (the host rejects GELU + pre-activation residual from HBM;
+    // the residual == input case comes from the staged tile and is already in the accumulators).
+    auto gelu_inplace = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                acc[tt][r] = gelu16x4(acc[tt][r]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+
+    // esr_conv_desc.border_bias: tiles on the image border add the table row of each pixel's outside-mask (row 0 = zeros for
+    // the interior pixels of such a tile), at the end of the tile's last stage -- in front of residual, GELU and the epilogue
+    auto border_fix = [&](int x0, int y0) __attribute__((always_inline)) {
+        const kparg_t q = KP();
+        const int qH = q->H, qW = q->W;
+        if (!(x0 == 0 || x0 + TILE >= qW || y0 == 0 || y0 + TILE_H >= qH)) return;
+        const int gx = x0 + px;
+        const int cm = (gx == 0 ? 1 : 0) | (gx == qW - 1 ? 2 : 0);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int gy = y0 + wv * RW + r;
+            const int m = cm | (gy == 0 ? 4 : 0) | (gy == qH - 1 ? 8 : 0);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) acc[tt][r] += *reinterpret_cast<const f32x4*>(btab + m * (NT * 16) + tt * 16 + kq * 4);
+        }
+    };
+
+    // epilogue as a phase: the pixel-shuffle output (fp32 NCHW) of the network's last convolution
+    auto epilogue = [&](int n, int x0, int y0) __attribute__((always_inline)) {
+        const kparg_t q = KP();
+        const int qH = q->H, qW = q->W, qcs = q->cout_store;
+        const float qslope = act_gelu ? 1.f : q->slope;
+        if constexpr (PNT1 == 0) {
+            // out[n, t, 4gy + kq, 4gx + 0..3] = channel 16t + 4kq + j: the D fragment is one dwordx4 of 4 adjacent HR pixels
+            const int gx = x0 + px;
+            const unsigned W4 = (unsigned)qW * 4u, H4 = (unsigned)qH * 4u;
+            const size_t y0_img = (size_t)qcs * qH * qW * 4;                 // NCHW fp32: cout / 16 planes of 4H x 4W
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(q->y0 + (size_t)n * y0_img, 0, (int)y0_img, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int gy = y0 + wv * RW + r;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    const bool ok = gy < qH && gx < qW && tt * 16 + kq * 4 < qcs;
+                    f32x4 v = acc[tt][r];
+                    v.x = act1(v.x, qslope); v.y = act1(v.y, qslope);
+                    v.z = act1(v.z, qslope); v.w = act1(v.w, qslope);
+                    const unsigned vo = ok ? (((unsigned)tt * H4 + (unsigned)gy * 4u + (unsigned)kq) * W4 + (unsigned)gx * 4u) * 4u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yr, vo, 0, 0);
+                }
+            }
+            return;
+        }
+    };
+
+    int slot = 0;
+    bool pend = false;                   // a finished tile waits for its epilogue
+    int pn = 0, px0 = 0, py0 = 0;
+    bool have = false;
+    int n = 0, x0 = 0, y0 = 0;
+
+    // ---- swap epilogue: set-up per tile, then one call per accumulator row (inside the first MFMA group) ---------------
+    // v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of another: for two D fragments X, Y
+    // (lane (px, kq): channels 4kq..4kq+3 of pixel px, 8 bytes) two swaps leave lane (px, kq) with 16 CONTIGUOUS bytes --
+    // channels 8(kq >> 1) .. +7 of X (kq even) or of Y (kq odd).  X, Y = channel tiles 2j, 2j+1 of one row (shape A: 64
+    // contiguous bytes per pixel and instruction), or the odd last tile of rows r, r+1 (shape B: 32 bytes per pixel).
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    constexpr int NPAIR = NT / 2;
+    unsigned vbA0[NPAIR > 0 ? NPAIR : 1], vbA1[NPAIR > 0 ? NPAIR : 1], vbB0 = OOB, vbB1 = OOB;
+    unsigned e_rowb0 = 0, e_rowb1 = 0;
+    char* e_y0 = nullptr; char* e_y1 = nullptr;
+    int e_y0n = 0, e_y1n = 0;
+    float e_slope = 0.f;
+    int e_res_mode = 0;
+    bool e_split = false, e_main = true;
+    // post outputs: post 1 = PNT1 tiles (pairs + an odd last tile), post 2 = one tile (rows paired)
+    constexpr int NPAIR1 = PNT1 / 2;
+    unsigned vp1A[NPAIR1 > 0 ? NPAIR1 : 1], vp1B = OOB, vp2B = OOB, e_rowbp1 = 0, e_rowbp2 = 0;
+    char* e_p1 = nullptr; char* e_p2 = nullptr;
+    int e_p1n = 0, e_p2n = 0;
+    float e_s1 = 1.f;
+    bool e_g1 = false;
+    auto swap_epi_setup = [&]() __attribute__((always_inline)) {
+        const kparg_t q = KP();
+        const int qH = q->H, qW = q->W, qcs = q->cout_store, qsplit = q->split;
+        const int qy0p = q->y0_pitch, qy0c = q->y0_coff, qy1p = q->y1_pitch, qy1c = q->y1_coff;
+        e_slope = (act_gelu || (q->nres > 0 && q->res_mode == ESR_RES_POST_ACT)) ? 1.f : q->slope;     // applied in place already
+        e_res_mode = q->res_mode;
+        e_split = qsplit < qcs;
+        const size_t y0_img = (size_t)qH * qW * qy0p * 2, y1_img = (size_t)qH * qW * qy1p * 2;
+        e_y0 = q->y0 + (size_t)pn * y0_img; e_y0n = (int)y0_img;
+        e_y1 = q->y1 + (size_t)pn * y1_img; e_y1n = (int)y1_img;
+        e_rowb0 = (unsigned)qW * (unsigned)qy0p * 2u;
+        e_rowb1 = (unsigned)qW * (unsigned)qy1p * 2u;
+        const unsigned srow = (unsigned)((py0 + wv * RW) * qW + px0);            // wave-uniform: pixel (row 0, px = 0) of this wave
+        const unsigned s0 = srow * (unsigned)qy0p * 2u, s1 = srow * (unsigned)qy1p * 2u;
+        const unsigned l0 = (__umul24(px, qy0p) + (unsigned)qy0c) * 2u, l1 = (__umul24(px, qy1p) + (unsigned)(qy1c - qsplit)) * 2u;
+        const bool inx = pend && px0 + px < qW;       // nothing pending (GRES: the block's first stage): every store out of range
+        // rows below the image fall past num_records (= the image's bytes): dropped by the hardware
+#pragma unroll
+        for (int j = 0; j < NPAIR; ++j) {
+            const int ch = (2 * j + (kq & 1)) * 16 + (kq >> 1) * 8;
+            vbA0[j] = (inx && ch < qsplit) ? s0 + l0 + (unsigned)ch * 2u : OOB;
+            vbA1[j] = (inx && ch >= qsplit && ch < qcs) ? s1 + l1 + (unsigned)ch * 2u : OOB;
+        }
+        if (NT & 1) {
+            const int ch = (NT - 1) * 16 + (kq >> 1) * 8;
+            vbB0 = (inx && ch < qsplit) ? s0 + l0 + (unsigned)ch * 2u + ((kq & 1) ? e_rowb0 : 0u) : OOB;
+            vbB1 = (inx && ch >= qsplit && ch < qcs) ? s1 + l1 + (unsigned)ch * 2u + ((kq & 1) ? e_rowb1 : 0u) : OOB;
+        }
+        if (PNT1 > 0) {
+            e_main = q->store_main != 0;
+            e_s1 = q->p1_slope;
+            e_g1 = q->p1_gelu != 0;
+            const int qp1p = q->py1_pitch, qp1c = q->py1_coff, qp1n = q->p1_cout8;
+            const size_t p1_img = (size_t)qH * qW * qp1p * 2;
+            e_p1 = q->py1 + (size_t)pn * p1_img; e_p1n = (int)p1_img;
+            e_rowbp1 = (unsigned)qW * (unsigned)qp1p * 2u;
+            const unsigned sp = srow * (unsigned)qp1p * 2u + (__umul24(px, qp1p) + (unsigned)qp1c) * 2u;
+#pragma unroll
+            for (int j = 0; j < NPAIR1; ++j) {
+                const int ch = (2 * j + (kq & 1)) * 16 + (kq >> 1) * 8;
+                vp1A[j] = (inx && ch < qp1n) ? sp + (unsigned)ch * 2u : OOB;
+            }
+            if (PNT1 & 1) {
+                const int ch = (PNT1 - 1) * 16 + (kq >> 1) * 8;
+                vp1B = (inx && ch < qp1n) ? sp + (unsigned)ch * 2u + ((kq & 1) ? e_rowbp1 : 0u) : OOB;
+            }
+            if (PNT2 > 0) {
+                const int qp2p = q->py2_pitch, qp2c = q->py2_coff, qp2n = q->p2_cout8;
+                const size_t p2_img = (size_t)qH * qW * qp2p * 2;
+                e_p2 = q->py2 + (size_t)pn * p2_img; e_p2n = (int)p2_img;
+                e_rowbp2 = (unsigned)qW * (unsigned)qp2p * 2u;
+                const int ch = (kq >> 1) * 8;
+                vp2B = (inx && ch < qp2n) ? srow * (unsigned)qp2p * 2u + (__umul24(px, qp2p) + (unsigned)(qp2c + ch)) * 2u + ((kq & 1) ? e_rowbp2 : 0u) : OOB;
+            }
+        }
+    };
+    uint2 pk[NT][2];                     // rounded rows r - 1 (even), r (odd) of the finished tile
+    uint2 pk1[PNT1 > 0 ? PNT1 : 1][2], pk2[2];          // ... of the post chain's results
+    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 {
+        const u32x2 a = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
+        const u32x2 b = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
+        return i32x4{(int)a.x, (int)b.x, (int)a.y, (int)b.y};
+    };
+    auto store16 = [&](uint2 X, uint2 Y, unsigned v0, unsigned v1, int r) __attribute__((always_inline)) {
+        const i32x4 o = swap16(X, Y);
+        __builtin_amdgcn_raw_buffer_store_b128(o, __builtin_amdgcn_make_buffer_rsrc(e_y0, 0, e_y0n, 0x00020000), v0 + (unsigned)r * e_rowb0, 0, 0);
+        if (e_split) __builtin_amdgcn_raw_buffer_store_b128(o, __builtin_amdgcn_make_buffer_rsrc(e_y1, 0, e_y1n, 0x00020000), v1 + (unsigned)r * e_rowb1, 0, 0);
+    };
+    // the fp32 fragment as the B operand of the post 1x1: k slots 0..3 = the 16-bit high parts, 4..7 = the low parts
+    auto hilo = [&](f32x4 v) __attribute__((always_inline)) -> i32x4 {
+        const unsigned h0 = pack2<BF16>(v.x, v.y), h1 = pack2<BF16>(v.z, v.w);
+        if (!BF16) return i32x4{(int)h0, (int)h1, 0, 0};           // fp16: the high parts carry 11 bits, as much as anything stored
+        float a, b, c, d;
+        unpack2<BF16>(h0, a, b);
+        unpack2<BF16>(h1, c, d);
+        return i32x4{(int)h0, (int)h1, (int)pack2<BF16>(v.x - a, v.y - b), (int)pack2<BF16>(v.z - c, v.w - d)};
+    };
+    auto swap_epi_act = [&](int r) __attribute__((always_inline)) {       // reads acc[.][r]
+        f32x4 u[PNT1 > 0 ? NT : 1];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            f32x4 v = acc[tt][r];
+            f32x4 rf = {0.f, 0.f, 0.f, 0.f};
+            if (GRES) rf = unpack4<BF16>(rv[GRES ? tt : 0][r]);
+            if (GRES && e_res_mode == ESR_RES_PRE_ACT) v += rf;
+            v.x = act1(v.x, e_slope); v.y = act1(v.y, e_slope);
+            v.z = act1(v.z, e_slope); v.w = act1(v.w, e_slope);
+            if (GRES && e_res_mode == ESR_RES_POST_ACT) v += rf;
+            pk[tt][r & 1].x = pack2<BF16>(v.x, v.y);
+            pk[tt][r & 1].y = pack2<BF16>(v.z, v.w);
+            if (PNT1 > 0) u[tt] = v;
+        }
+        if constexpr (PNT1 > 0) {
+            // ---- post chain on this row's fp32 result (RLFB: c3_r -> c5 -> esa.conv1; RFDB / ESDB: the next distillation conv) ------
+            f32x4 d1[PNT1];
+#pragma unroll
+            for (int ot = 0; ot < PNT1; ++ot) d1[ot] = *reinterpret_cast<const f32x4*>(pbias + ot * 16 + kq * 4);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const i32x4 bsv = hilo(u[kt]);
+#pragma unroll
+                for (int ot = 0; ot < PNT1; ++ot) {
+                    d1[ot] = mfma32<BF16>(*reinterpret_cast<const i32x4*>(pimg1 + (kt * PNT1 + ot) * 1024 + a_off), bsv, d1[ot]);
+                    if (plo == 2)
+                        d1[ot] = mfma32<BF16>(*reinterpret_cast<const i32x4*>(pimg1 + P1_IMG + (kt * PNT1 + ot) * 1024 + a_off), bsv, d1[ot]);
+                }
+            }
+#pragma unroll
+            for (int ot = 0; ot < PNT1; ++ot) {
+                f32x4 v = d1[ot];
+                if (e_g1) v = gelu16x4(v);
+                else { v.x = act1(v.x, e_s1); v.y = act1(v.y, e_s1); v.z = act1(v.z, e_s1); v.w = act1(v.w, e_s1); }
+                d1[ot] = v;
+                pk1[ot][r & 1].x = pack2<BF16>(v.x, v.y);
+                pk1[ot][r & 1].y = pack2<BF16>(v.z, v.w);
+            }
+            if (PNT2 > 0) {
+                f32x4 d2 = *reinterpret_cast<const f32x4*>(pbias + PNT1 * 16 + kq * 4);
+#pragma unroll
+                for (int kt = 0; kt < PNT1; ++kt) {
+                    const i32x4 bsv = hilo(d1[kt]);
+                    d2 = mfma32<BF16>(*reinterpret_cast<const i32x4*>(pimg2 + kt * PNT2 * 1024 + a_off), bsv, d2);
+                    if (plo == 2) d2 = mfma32<BF16>(*reinterpret_cast<const i32x4*>(pimg2 + P2_IMG + kt * PNT2 * 1024 + a_off), bsv, d2);
+                }
+                pk2[r & 1].x = pack2<BF16>(d2.x, d2.y);
+                pk2[r & 1].y = pack2<BF16>(d2.z, d2.w);
+            }
+        }
+    };
+    auto swap_epi_store = [&](int r) __attribute__((always_inline)) {                    // rows r - 1, r (r odd)
+        if (PNT1 == 0 || e_main) {
+#pragma unroll
+            for (int j = 0; j < NPAIR; ++j) {
+                store16(pk[2 * j][0], pk[2 * j + 1][0], vbA0[j], vbA1[j], r - 1);
+                store16(pk[2 * j][1], pk[2 * j + 1][1], vbA0[j], vbA1[j], r);
+            }
+            if (NT & 1) store16(pk[NT - 1][0], pk[NT - 1][1], vbB0, vbB1, r - 1);
+        }
+        if constexpr (PNT1 > 0) {
+            const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(e_p1, 0, e_p1n, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < NPAIR1; ++j) {
+                __builtin_amdgcn_raw_buffer_store_b128(swap16(pk1[2 * j][0], pk1[2 * j + 1][0]), r1, vp1A[j] + (unsigned)(r - 1) * e_rowbp1, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(swap16(pk1[2 * j][1], pk1[2 * j + 1][1]), r1, vp1A[j] + (unsigned)r * e_rowbp1, 0, 0);
+            }
+            if (PNT1 & 1)
+                __builtin_amdgcn_raw_buffer_store_b128(swap16(pk1[PNT1 - 1][0], pk1[PNT1 - 1][1]), r1, vp1B + (unsigned)(r - 1) * e_rowbp1, 0, 0);
+            if (PNT2 > 0)
+                __builtin_amdgcn_raw_buffer_store_b128(swap16(pk2[0], pk2[1]), __builtin_amdgcn_make_buffer_rsrc(e_p2, 0, e_p2n, 0x00020000),
+                                                       vp2B + (unsigned)(r - 1) * e_rowbp2, 0, 0);
+        }
+    };
+
+    // ---- one stage: MFMA groups from ring slot `slot`, the cursor's DMA pieces between them ------------------------------
+    auto compute = [&](auto epi_tag, int c, bool last) __attribute__((always_inline)) {
+        constexpr bool EPI = decltype(epi_tag)::value;           // first stage of a tile with the swap epilogue inside
+        const char* sb = ring + slot * STAGE_BYTES;
+        const char* wc = smem + c * W_CHUNK_BYTES + a_off;
+
+        // two fragment sets: the reads of pair q+1 are issued ONE BY ONE behind the MFMAs of pair q (in the order the next group uses
+        // them), the cursor's DMA piece behind a later MFMA of the group -- a wave issues in order, so a clump of seven ds_reads and a
+        // DMA piece in front of twelve MFMAs is 150-300 cycles in which this wave feeds the matrix pipe nothing (s_memtime probes,
+        // tools/abl/s16_probe.py); sched_barriers pin the order
+        i32x4 a[2][NT], b[2][RW];
+        constexpr int NFRAG = NT + RW;
+        auto load_one = [&](int buf, int q, int i, bool rows_first) __attribute__((always_inline)) {
+            // use order of a tt-major group: a0, b0 .. b(RW-1), a1 ..; of the row-major epilogue group: a0 .. a(NT-1), b0 ..
+            const int ia = rows_first ? (i < NT ? i : -1) : (i == 0 ? 0 : (i > RW ? i - RW : -1));
+            const int ib = rows_first ? i - NT : i - 1;
+            if (ia >= 0) a[buf][ia] = *reinterpret_cast<const i32x4*>(wc + (q * NT + ia) * 1024);
+            else b[buf][ib] = *reinterpret_cast<const i32x4*>(sb + b_off[q] + ib * (TH * 32));
+        };
+#pragma unroll
+        for (int i = 0; i < NFRAG; ++i) { load_one(0, 0, i, EPI); load_one(1, 0, i, EPI); }
+        if (EPI) {
+            wait_residual();
+            swap_epi_setup();
+        }
+        constexpr int DMA_AT = NFRAG < NT * RW - 1 ? NFRAG : NT * RW - 1;       // MFMA of the group behind which the DMA piece is issued
+        // a tile's accumulators START as the bias (re-read from LDS: one ds_read_b128 per fragment and tile), so that every MFMA of
+        // the kernel accumulates in place -- with the bias as the C operand of a tile's first group the accumulators of the two
+        // code paths met in phis and hipcc copied all of them (24 v_mov_b64) at the latch of EVERY stage
+        if (!EPI && c == 0) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < RW; ++r) acc[tt][r] = *reinterpret_cast<const f32x4*>(sbias + tt * 16 + kq * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) {
+            const int cs = q & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if (q == 0 && EPI) {
+                // the finished tile's rows leave just in front of the MFMAs that overwrite their accumulators
+                swap_epi_act(0);
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) acc[tt][0] = *reinterpret_cast<const f32x4*>(sbias + tt * 16 + kq * 4);
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    if (r & 1) swap_epi_store(r);    // rows r-1, r: before row r+1's values take row r-1's registers
+                    if (r + 1 < RW) {
+                        swap_epi_act(r + 1);         // (the VALU work of row r+1 covers the latency of row r's bias reads)
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) acc[tt][r + 1] = *reinterpret_cast<const f32x4*>(sbias + tt * 16 + kq * 4);
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) {
+                        acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], acc[tt][r]);
+                        const int m = r * NT + tt;
+                        ;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                load_residual(n, x0, y0, have);                      // this tile's residual (the ONE load site): behind the epilogue, in front of the DMA
+                if (q < PPW) dma_piece(q);
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) {
+                        acc[tt][r] = mfma32<BF16>(a[cs][tt], b[cs][r], acc[tt][r]);
+                        const int m = tt * RW + r;
+                        ;
+                        if (m == DMA_AT && q < PPW) dma_piece(q);     // the DMA issue rides in the shadow of the matrix pipe
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
+            if (q + 1 < PAIRS) {
+#pragma unroll
+                ;        // (one channel tile: fewer MFMAs than fragments)
+            }
+        }
+#pragma unroll
+        for (int i = PAIRS; i < PPW; ++i) dma_piece(i);
+        if (KS == 3 && p.res_in) {
+            // act(conv(x) + x): the residual of output channels 16c .. 16c+15 is the centre pixel of input chunk c, still in
+            // this stage's ring slot (read behind the MFMAs: nothing waits for it)
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                int cc = c;
+                asm volatile("" : "+s"(cc));      // opaque per tile: hipcc otherwise folds the NT tests into acc[c] and the accumulators go to scratch
+                if (tt == cc) {
+#pragma unroll
+                    for (int r = 0; r < RW; ++r)
+                        acc[tt][r] += unpack4<BF16>(*reinterpret_cast<const uint2*>(sb + c_off + r * (TH * 32)));
+                }
+            }
+        }
+        if (c == p.nchunks - 1 && p.border) border_fix(x0, y0);
+        if (last && act_gelu) gelu_inplace();        // (`last` is a residual stage when there are any: residual_stage applies it)
+    };
+
+    // ---- a residual stage (p.nres > 0): the residual tensor's channels 16t .. 16t+15 were staged like an input chunk; the centre
+    // pixels are added to accumulator tile t from LDS.  Same DMA type, same ring, same counted waits as the input: nothing rides
+    // in registers while in flight (asm loads into VGPRs did, and hipcc copied those registers before the data was there).
+    auto residual_stage = [&](int c, bool last) __attribute__((always_inline)) {
+        const char* sb = ring + slot * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma_piece(i);
+        const bool post = KP()->res_mode == ESR_RES_POST_ACT;
+        if (post && c == p.nchunks) {
+            // act(conv) + res: the activation goes first, on the accumulators (the epilogue then sees slope 1)
+            if (act_gelu) {
+                gelu_inplace();
+            } else {
+                const float sl = KP()->slope;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) {
+                        f32x4 v = acc[tt][r];
+                        v.x = act1(v.x, sl); v.y = act1(v.y, sl); v.z = act1(v.z, sl); v.w = act1(v.w, sl);
+                        acc[tt][r] = v;
+                    }
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            int cc = c - p.nchunks;
+            asm volatile("" : "+s"(cc));      // opaque per tile (see the res_in block of compute)
+            if (tt == cc) {
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+                    acc[tt][r] += unpack4<BF16>(*reinterpret_cast<const uint2*>(sb + c_off + r * (TH * 32)));
+            }
+        }
+        if (last && act_gelu && !post) gelu_inplace();
+    };
+
+    for (int k = 0;; ++k) {
+        // the iteration behind the block's last tile drains the pending epilogue through the same code (its MFMAs run on
+        // whatever the ring holds and its DMA / residual loads are out of range)
+        const int t = tile_index(k);
+        have = t >= 0;
+        if (!have && !pend) break;
+        if (have) tile_coords(t, n, x0, y0);
+        const int nst = have ? nstages : 1;
+        for (int c = 0; c < nst; ++c) {
+            const bool last = c == nst - 1;
+            hist_rs = (hist_rs << 1) | (c == 0 ? 1u : 0u);
+            hist_st <<= 1;
+            if (c == 0 && swap_epi && have && (pend || GRES)) {
+                // the previous tile's epilogue inside this tile's first MFMA group (GRES: also for the block's first tile, nothing
+                // pending and every store out of range -- the residual loads have their one site in there)
+                hist_st |= 1u;
+                compute(std::true_type{}, 0, last);
+            } else if (c == 0 && swap_epi && pend) {
+                // behind the block's last tile: the epilogue alone (with one or two tiles per block -- single images -- a whole
+                // stage of MFMAs on stale data would cost a quarter of the block's time)
+                wait_residual();
+                swap_epi_setup();
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    swap_epi_act(r);
+                    if (r & 1) swap_epi_store(r);
+                }
+                break;
+            } else {
+                if (c == 0 && pend) {
+                    hist_st |= 1u;
+                    epilogue(pn, px0, py0);
+                }
+                if (!have) break;                               // behind the block's last tile: the epilogue was all
+                if (c >= p.nchunks) residual_stage(c, last);
+                else compute(std::false_type{}, c, last);
+            }
+            cursor_advance();
+            // ---- sync: stage s+1 has landed; everything issued after its DMA may stay in flight -------------------------
+            // its DMA was issued R-2 stages ago, behind that stage's own stores / residual loads: younger are the DMA of the
+            // R-2 stages since and the first-stage instructions of those among them that opened a tile
+            wait_vm_dyn((R - 2) * n_my + epi_stores * __builtin_popcount(hist_st & hmask) + (GRES ? RES_LOADS : 0) * __builtin_popcount(hist_rs & hmask));
+            if (!OWN_PIECES) __builtin_amdgcn_s_barrier();
+            slot = slot == R - 1 ? 0 : slot + 1;
+        }
+        if (!have) break;
+        pend = true;
+        pn = n; px0 = x0; py0 = y0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing (zero-fill) DMA writes LDS: it must not outlive the block
+}
+
+template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 = 0>
+int launch_s16(const S16K& k, size_t lds, hipStream_t st)
+{
+    // the attribute belongs to the (device, instantiation) pair: one process may drive several GPUs (engine contexts are keyed by
+    // device).  Relaxed atomics: a racing thread at worst sets the same value twice.
+    static std::atomic<unsigned> attr_set[MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
+    if (!attr_set[dev].load(std::memory_order_relaxed)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<NT, KS, NW, BF16, GRES, PNT1, PNT2>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+        if (e != hipSuccess) {
+            esr_set_err("hipFuncSetAttribute(conv_s16_kernel, MaxDynamicSharedMemorySize)", e);
+            return ESR_ERR_LAUNCH;
+        }
+        attr_set[dev].store(1u, std::memory_order_relaxed);
+    }
+    const int ntiles = k.N * k.tiles_x * k.tiles_y;
+    const int cap = NW == 4 ? 512 : 256;                   // one block per CU (LDS; NW = 4: two), persistent over the tiles
+    const int grid = ntiles < cap ? ntiles : cap;
+    esr_note_kernel("conv_s16_kernel<%d, %d, %d, %s, %s, %d, %d>", NT, KS, NW, esr_tf(BF16), esr_tf(GRES), PNT1, PNT2);
+    hipLaunchKernelGGL((conv_s16_kernel<NT, KS, NW, BF16, GRES, PNT1, PNT2>), dim3(grid), dim3(64 * NW), lds, st, k);
+    return esr_check_launch("conv_s16_kernel launch");
+}
+
+template <int KS, bool BF16, bool GRES>
+int launch_s16_nt(int nt, const S16K& k, size_t lds, hipStream_t st)
+{
+    switch (nt) {
+        case 1: return launch_s16<1, KS, S16_NW, BF16, GRES>(k, lds, st);
+        case 2: return launch_s16<2, KS, S16_NW, BF16, GRES>(k, lds, st);
+        case 3: return launch_s16<3, KS, S16_NW, BF16, GRES>(k, lds, st);
+        case 4: return launch_s16<4, KS, S16_NW, BF16, GRES>(k, lds, st);
+    }
+    return ESR_ERR_UNSUPPORTED;
+}
+
+template <int KS, bool BF16>
+int launch_s16_res(int nt, const S16K& k, size_t lds, hipStream_t st)
+{
+    return launch_s16_nt<KS, BF16, false>(nt, k, lds, st);        // (a residual from HBM is staged through LDS: S16K.nres)
+}
+
+// the post-chain variants that exist: (kernel size, main tiles, residual from HBM, post-1 tiles, post-2 tiles)
+//   (3, 3, yes, 3, 1)  RLFB  c3_r (+ block input, after the activation) -> c5 -> esa.conv1     nf = 46
+//   (3, 4, no,  2, 0)  RFDB  c{j}_r (residual = its input, from LDS) -> c{j+1}_d               nf = 50
+//   (3, 3, no,  2, 0)  RFDB                                                                   nf = 40
+//   (1, 3 | 4, no, 1, 0)  c5 (the 1x1 over the distillation concat) -> esa.conv1: BSRN / RFDN (team18_bsrn.py:167,110;
+//                         rfdn_baseline/block.py:164,118)
+inline bool post_variant_exists(int ks, int nt, bool gres, int pnt1, int pnt2)
+{
+    if (ks == 1) return (nt == 3 || nt == 4) && !gres && pnt1 == 1 && pnt2 == 0;
+    return (nt == 3 && gres && pnt1 == 3 && pnt2 == 1) || (nt == 4 && !gres && pnt1 == 2 && pnt2 == 0) ||
+           (nt == 3 && !gres && pnt1 == 2 && pnt2 == 0);
+}
+
+template <bool BF16>
+int launch_s16_post(int ks, int nt, bool gres, int pnt1, int pnt2, const S16K& k, size_t lds, hipStream_t st)
+{
+    if (ks == 1) {
+        if (nt == 3 && !gres && pnt1 == 1 && pnt2 == 0) return launch_s16<3, 1, S16_NW, BF16, false, 1, 0>(k, lds, st);
+        if (nt == 4 && !gres && pnt1 == 1 && pnt2 == 0) return launch_s16<4, 1, S16_NW, BF16, false, 1, 0>(k, lds, st);
+        return ESR_ERR_UNSUPPORTED;
+    }
+    if (nt == 3 && gres && pnt1 == 3 && pnt2 == 1) return launch_s16<3, 3, S16_NW, BF16, false, 3, 1>(k, lds, st);    // (the residual is staged through LDS: S16K.nres)
+    if (nt == 4 && !gres && pnt1 == 2 && pnt2 == 0) return launch_s16<4, 3, S16_NW, BF16, false, 2, 0>(k, lds, st);
+    if (nt == 3 && !gres && pnt1 == 2 && pnt2 == 0) return launch_s16<3, 3, S16_NW, BF16, false, 2, 0>(k, lds, st);
+    return ESR_ERR_UNSUPPORTED;
+}
+
+// LDS bytes of a launch: resident weights + `ring` input stages + epilogue scratch
+size_t s16_lds_bytes(int nchunks, int nt, int ksize, int nw, int ring, size_t post_bytes = 0)
+{
+    const int halo = ksize / 2, th = TILE + 2 * halo, thy = (nw == 4 ? 16 : 32) + 2 * halo;
+    const int npieces = (th * thy + 31) / 32;
+    const int pairs = (ksize * ksize + 1) / 2;
+    return (size_t)nchunks * pairs * nt * 1024 + post_bytes + (size_t)ring * npieces * 1024;
+}
+
+// residual == input of a 3x3 with as many output as input chunks: taken from the staged tile (S16K.res_in), not from HBM
+static bool s16_res_is_input(const esr_conv_desc* d)
+{
+    return d->ksize == 3 && d->res_mode == ESR_RES_PRE_ACT && esr_round_up(d->cin, 16) == esr_round_up(d->cout, 16) && d->res.ptr == d->in.ptr &&
+           d->res.pitch == d->in.pitch && d->res.coff == d->in.coff;
+}
+
+// 4: the launch takes the two-blocks-per-CU shape (4 waves, 16 x 16 tiles), 8: one 8-wave block per CU on 16 x 32 tiles
+int s16_block_waves(const esr_conv_desc* d)
+{
+    const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
+    const bool res_hbm = d->res_mode != ESR_RES_NONE && !s16_res_is_input(d);
+    if (d->ksize != 3 || nt != 3 || d->border_bias || d->post_wpacked || res_hbm || d->out_layout != ESR_NHWC || d->in_seg_stride != 0) return 8;
+    if ((long)d->n * ((d->w + TILE - 1) / TILE) * ((d->h + 15) / 16) < 512) return 8;           // fewer tiles than resident blocks
+    return s16_lds_bytes(nchunks, nt, 3, 4, RING_MIN, 1024) <= (size_t)LDS_LIMIT / 2 ? 4 : 8;
+}
+
+// decides how a descriptor with a post chain runs: fills the tile counts and whether the low-part images are resident;
+// returns ESR_OK if a fused variant exists and fits the LDS
+int s16_post_plan(const esr_conv_desc* d, int nt, int nchunks, int* pnt1, int* pnt2, int* post_lo, int* ring, size_t* lds)
+{
+    if (d->out_layout != ESR_NHWC || (d->split > 0 && d->split < d->cout)) return ESR_ERR_UNSUPPORTED;
+    if (d->post_cout <= 0 || d->post_cout > 48) return ESR_ERR_UNSUPPORTED;
+    *pnt1 = esr_round_up(d->post_cout, 16) / 16;
+    *pnt2 = d->post2_wpacked ? 1 : 0;
+    if (*pnt2 && (d->post2_cout <= 0 || d->post2_cout > 16)) return ESR_ERR_UNSUPPORTED;
+    const bool res_is_in = d->res_mode == ESR_RES_PRE_ACT && esr_round_up(d->cin, 16) == esr_round_up(d->cout, 16) && d->res.ptr == d->in.ptr &&
+                           d->res.pitch == d->in.pitch && d->res.coff == d->in.coff;
+    const bool gres = d->res_mode != ESR_RES_NONE && !res_is_in;
+    if (!post_variant_exists(d->ksize, nt, gres, *pnt1, *pnt2)) return ESR_ERR_UNSUPPORTED;
+    // fp16 storage: the post weights' low parts (and the activations' low parts, see hilo) are not needed -- 11 mantissa bits, the
+    // network's own storage precision; bf16 keeps hi + lo wherever the images fit
+    for (int lo = d->storage == ESR_STORE_F16 ? 0 : 1; lo >= 0; --lo) {
+        const size_t pb = (size_t)(lo + 1) * (nt * *pnt1 + *pnt1 * *pnt2) * 1024 + 1024 + (d->border_bias ? (size_t)nt * 1024 : 0);
+        int r = RING_MAX;
+        while (r > RING_MIN && s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, r, pb) > (size_t)LDS_LIMIT) --r;
+        if (s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, r, pb) <= (size_t)LDS_LIMIT) {
+            *post_lo = lo; *ring = r; *lds = s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, r, pb);
+            return ESR_OK;
+        }
+    }
+    return ESR_ERR_UNSUPPORTED;
+}
+
+inline uint16_t f32_to_bf16(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);       // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_to_f32(uint16_t h)
+{
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+inline uint16_t f32_to_f16(float f)
+{
+    const _Float16 h = (_Float16)f;        // host compiler: IEEE RNE
+    uint16_t r;
+    memcpy(&r, &h, 2);
+    return r;
+}
+inline float f16_to_f32(uint16_t h)
+{
+    _Float16 v;
+    memcpy(&v, &h, 2);
+    return (float)v;
+}
+inline uint16_t to16(double v, int compute) { return compute == ESR_COMPUTE_BF16 ? f32_to_bf16((float)v) : f32_to_f16((float)v); }
+inline double from16(uint16_t h, int compute) { return compute == ESR_COMPUTE_BF16 ? bf16_to_f32(h) : f16_to_f32(h); }
+
+// element index of (physical slot s, tap slot ts in {0..2*pairs-1}, output channel oc) in the weight image
+inline size_t s16_index(int nt, int pairs, int s, int ts, int oc)
+{
+    const int chunk = s / 16, within = s % 16;
+    const int q = ts / 2, kq = (ts & 1) * 2 + within / 8, j = within % 8;
+    return ((((size_t)chunk * pairs + q) * nt + oc / 16) * 64 + kq * 16 + oc % 16) * 8 + j;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t esr_packed_conv_s16_bytes(int cin_phys, int cout, int ksize)
+{
+    if (cin_phys <= 0 || cout <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    const size_t nt = (size_t)esr_round_up(cout, 16) / 16;
+    const size_t nchunks = (size_t)esr_round_up(cin_phys, 16) / 16;
+    const size_t pairs = (size_t)(ksize * ksize + 1) / 2;
+    return nchunks * pairs * nt * 1024 + nt * 16 * sizeof(float);
+}
+
+int esr_pack_conv_s16(const float* w, const float* bias, int cin, int cout, int ksize, const int32_t* cin_map, int cin_phys,
+                      int compute, void* out, size_t out_bytes)
+{
+    if (!w || !out || cin <= 0 || cout <= 0 || (ksize != 1 && ksize != 3)) return ESR_ERR_BAD_ARG;
+    if (compute != ESR_COMPUTE_BF16 && compute != ESR_COMPUTE_F16) return ESR_ERR_BAD_ARG;
+    if (!cin_map && cin_phys < cin) return ESR_ERR_BAD_ARG;
+    const size_t need = esr_packed_conv_s16_bytes(cin_phys, cout, ksize);
+    if (need == 0 || out_bytes < need) return ESR_ERR_BAD_ARG;
+    const int nt = esr_round_up(cout, 16) / 16, taps = ksize * ksize, pairs = (taps + 1) / 2;
+    const int nchunks = esr_round_up(cin_phys, 16) / 16;
+    memset(out, 0, need);
+    uint16_t* o = static_cast<uint16_t*>(out);
+    for (int s = 0; s < cin_phys; ++s) {
+        const int c = cin_map ? cin_map[s] : (s < cin ? s : -1);
+        if (c < 0) continue;
+        if (c >= cin) return ESR_ERR_BAD_ARG;
+        for (int oc = 0; oc < cout; ++oc) {
+            const float* wf = w + ((size_t)oc * cin + c) * taps;
+            if (ksize == 1) {
+                // w = hi + lo: the second tap slot of the pair carries the rounding residual of the first
+                const uint16_t hi = to16(wf[0], compute);
+                const uint16_t lo = to16((double)wf[0] - from16(hi, compute), compute);
+                o[s16_index(nt, pairs, s, 0, oc)] = hi;
+                o[s16_index(nt, pairs, s, 1, oc)] = lo;
+            } else {
+                // error diffusion over the 9 taps: tap k is rounded after adding the rounding error carried from tap k-1,
+                // so the SUM of the filter's taps (its DC gain) is exact to one rounding of the last tap
+                double e = 0.0;
+                for (int tap = 0; tap < taps; ++tap) {
+                    const double t = (double)wf[tap] + e;
+                    const uint16_t q = to16(t, compute);
+                    e = t - from16(q, compute);
+                    o[s16_index(nt, pairs, s, tap, oc)] = q;
+                }
+            }
+        }
+    }
+    float* bo = reinterpret_cast<float*>(static_cast<char*>(out) + (size_t)nchunks * pairs * nt * 1024);
+    if (bias)
+        for (int oc = 0; oc < cout; ++oc) bo[oc] = bias[oc];
+    return ESR_OK;
+}
+
+size_t esr_packed_post_s16_bytes(int cin, int cout)
+{
+    if (cin <= 0 || cout <= 0) return 0;
+    const size_t kt = (size_t)esr_round_up(cin, 16) / 16, ot = (size_t)esr_round_up(cout, 16) / 16;
+    return 2 * kt * ot * 1024 + ot * 16 * sizeof(float);
+}
+
+int esr_pack_post_s16(const float* w, const float* bias, int cin, int cout, int compute, void* out, size_t out_bytes)
+{
+    if (!w || !out || cin <= 0 || cout <= 0) return ESR_ERR_BAD_ARG;
+    if (compute != ESR_COMPUTE_BF16 && compute != ESR_COMPUTE_F16) return ESR_ERR_BAD_ARG;
+    const size_t need = esr_packed_post_s16_bytes(cin, cout);
+    if (out_bytes < need) return ESR_ERR_BAD_ARG;
+    const int kt = esr_round_up(cin, 16) / 16, ot = esr_round_up(cout, 16) / 16;
+    memset(out, 0, need);
+    uint16_t* hi = static_cast<uint16_t*>(out);
+    uint16_t* lo = hi + (size_t)kt * ot * 512;
+    // image [k tile][out tile][lane = kq * 16 + i][j]: input channel 16 kt + 4 kq + (j & 3) for output channel 16 ot + i; the
+    // B operand carries the high parts of the four fp32 inputs in slots 0..3 and their low parts in 4..7, so the hi image has
+    // the weight's high part in all eight slots, the lo image its low part in slots 0..3 only (lo x lo is dropped)
+    for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c) {
+            const float wv = w[(size_t)o * cin + c];
+            const uint16_t h = to16(wv, compute);
+            const uint16_t l = to16((double)wv - from16(h, compute), compute);
+            const size_t base = ((((size_t)(c / 16) * ot + o / 16) * 64 + ((c % 16) / 4) * 16 + o % 16) * 8) + (c % 4);
+            hi[base] = h;
+            hi[base + 4] = h;
+            lo[base] = l;
+        }
+    float* bo = reinterpret_cast<float*>(static_cast<char*>(out) + 2 * (size_t)kt * ot * 1024);
+    if (bias)
+        for (int o = 0; o < cout; ++o) bo[o] = bias[o];
+    return ESR_OK;
+}
+
+int esr_conv_post_supported(const esr_conv_desc* d)
+{
+    if (!d || !d->post_wpacked || (d->storage != ESR_STORE_BF16 && d->storage != ESR_STORE_F16)) return 0;
+    int a, b, c, r;
+    size_t l;
+    return s16_post_plan(d, esr_round_up(d->cout, 16) / 16, esr_round_up(d->cin, 16) / 16, &a, &b, &c, &r, &l) == ESR_OK;
+}
+
+int esr_unpack_conv_s16(const void* packed, size_t bytes, int cin, int cout, int ksize, const int32_t* cin_map, int cin_phys,
+                        int compute, float* w, float* bias)
+{
+    if (!packed || !w || cin <= 0 || cout <= 0 || (ksize != 1 && ksize != 3)) return ESR_ERR_BAD_ARG;
+    if (compute != ESR_COMPUTE_BF16 && compute != ESR_COMPUTE_F16) return ESR_ERR_BAD_ARG;
+    if (bytes < esr_packed_conv_s16_bytes(cin_phys, cout, ksize)) return ESR_ERR_BAD_ARG;
+    const int nt = esr_round_up(cout, 16) / 16, taps = ksize * ksize, pairs = (taps + 1) / 2;
+    const int nchunks = esr_round_up(cin_phys, 16) / 16;
+    const uint16_t* o = static_cast<const uint16_t*>(packed);
+    memset(w, 0, sizeof(float) * (size_t)cout * cin * taps);
+    for (int s = 0; s < cin_phys; ++s) {
+        const int c = cin_map ? cin_map[s] : (s < cin ? s : -1);
+        if (c < 0) continue;
+        for (int oc = 0; oc < cout; ++oc)
+            for (int tap = 0; tap < taps; ++tap) {
+                double v = from16(o[s16_index(nt, pairs, s, tap, oc)], compute);
+                if (ksize == 1) v += from16(o[s16_index(nt, pairs, s, 1, oc)], compute);
+                w[((size_t)oc * cin + c) * taps + tap] = (float)v;       // the EFFECTIVE weight the kernel multiplies by
+            }
+    }
+    if (bias) {
+        const float* bo = reinterpret_cast<const float*>(static_cast<const char*>(packed) + (size_t)nchunks * pairs * nt * 1024);
+        for (int oc = 0; oc < cout; ++oc) bias[oc] = bo[oc];
+    }
+    return ESR_OK;
+}
+
+}  // extern "C"
+
+// ---- network input for the 16-bit plans (esr_pack_input_s16) ----------------------------------------------------------------
+namespace {
+template <bool BF16>
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, char* __restrict__ y, int C, long long hw, long long npix, int pitch, int coff)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+        const long long n = i / hw, s = i - n * hw;
+        unsigned short v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) {
+                const float f = x[(n * C + c) * hw + s];
+                const unsigned h = pack2<BF16>(f, 0.f) & 0xffffu;
+                float fh, dummy;
+                unpack2<BF16>(h, fh, dummy);
+                const unsigned l = pack2<BF16>(f - fh, 0.f) & 0xffffu;
+                v[c] = (unsigned short)h; v[C + c] = (unsigned short)l; v[2 * C + c] = (unsigned short)h;
+            }
+        uint4* o = reinterpret_cast<uint4*>(y + ((size_t)i * pitch + coff) * 2);
+        o[0] = uint4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16), (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
+        o[1] = uint4{(unsigned)v[8] | ((unsigned)v[9] << 16), (unsigned)v[10] | ((unsigned)v[11] << 16), (unsigned)v[12] | ((unsigned)v[13] << 16), (unsigned)v[14] | ((unsigned)v[15] << 16)};
+    }
+}
+}  // namespace
+
+extern "C" int esr_pack_input_s16(const esr_conv_desc* d, void* hip_stream)
+{
+    if (!d || !d->in.ptr || !d->out0.ptr || d->n <= 0 || d->h <= 0 || d->w <= 0) return ESR_ERR_BAD_ARG;
+    if (d->cin <= 0 || d->cin > 4) return ESR_ERR_UNSUPPORTED;
+    if (d->storage != ESR_STORE_BF16 && d->storage != ESR_STORE_F16) return ESR_ERR_BAD_ARG;
+    if ((d->out0.pitch & 7) || (d->out0.coff & 7) || d->out0.coff + 16 > d->out0.pitch) return ESR_ERR_BAD_ARG;
+    const long long hw = (long long)d->h * d->w, npix = hw * d->n;
+    const long long want = (npix + 255) / 256;
+    const int grid = (int)(want < 8192 ? want : 8192);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    esr_note_kernel("pack_input_kernel<%s>", esr_tf(d->storage == ESR_STORE_BF16));
+    if (d->storage == ESR_STORE_BF16)
+        hipLaunchKernelGGL(pack_input_kernel<true>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(d->in.ptr), static_cast<char*>(d->out0.ptr), d->cin, hw, npix, d->out0.pitch, d->out0.coff);
+    else
+        hipLaunchKernelGGL(pack_input_kernel<false>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(d->in.ptr), static_cast<char*>(d->out0.ptr), d->cin, hw, npix, d->out0.pitch, d->out0.coff);
+    return esr_check_launch("pack_input_kernel launch");
+}
+
+// called by esr_conv2d_f32 (esr_hip.hip) for descriptors with 16-bit storage
+int esr_s16_block_waves(const esr_conv_desc* d) { return s16_block_waves(d); }
+
+int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
+{
+    const bool bf16 = d->storage == ESR_STORE_BF16;
+    if (d->storage != ESR_STORE_BF16 && d->storage != ESR_STORE_F16) return ESR_ERR_BAD_ARG;
+    if (d->compute != (bf16 ? ESR_COMPUTE_BF16 : ESR_COMPUTE_F16)) return ESR_ERR_BAD_ARG;   // operand type = storage type
+    if (d->in_layout != ESR_NHWC) return ESR_ERR_UNSUPPORTED;                                  // the NCHW head runs on conv_f32_kernel
+    if (d->tail_wpacked || d->blocked8) return ESR_ERR_UNSUPPORTED;                            // fp32 features
+    const bool post = d->post_wpacked != nullptr;
+    if (d->border_bias && d->out_layout != ESR_NHWC) return ESR_ERR_UNSUPPORTED;
+    if (!post && d->post2_wpacked) return ESR_ERR_BAD_ARG;
+    if ((d->in.pitch & 7) || (d->in.coff & 7)) return ESR_ERR_BAD_ARG;                         // 16-byte granules
+    const int cin_phys = esr_round_up(d->cin, 16);
+    const bool segmented = d->in_seg_stride != 0;
+    if (segmented) {
+        if (d->in_seg_chunks <= 0 || (cin_phys / 16) % d->in_seg_chunks || d->in_seg_stride < 0 || (d->in_seg_stride & 15)) return ESR_ERR_BAD_ARG;
+        if (d->in.coff + 16 * d->in_seg_chunks > d->in.pitch) return ESR_ERR_BAD_ARG;
+        if (d->ksize != 1) return ESR_ERR_UNSUPPORTED;             // (a 3x3 over a concat does not occur on the path)
+    } else if (d->in.coff + cin_phys > d->in.pitch) {
+        return ESR_ERR_BAD_ARG;                                  // chunk reads stay inside the pixel
+    }
+    const int nt = esr_round_up(d->cout, 16) / 16;
+    const bool shuffle = d->out_layout == ESR_NCHW_SHUFFLE4;
+    const int cout8 = esr_round_up(d->cout, 8);
+    int split = d->split <= 0 ? cout8 : d->split;
+    if (split >= d->cout) split = cout8;
+    if (split & 7) return ESR_ERR_BAD_ARG;
+    if (shuffle) {
+        if (d->cout % 16 || d->res_mode != ESR_RES_NONE) return ESR_ERR_UNSUPPORTED;
+    } else if (d->out_layout == ESR_NHWC && post && !d->out0.ptr) {
+        // the conv's own result feeds the post chain only
+    } else if (d->out_layout == ESR_NHWC) {
+        if (!d->out0.ptr) return ESR_ERR_BAD_ARG;
+        if ((d->out0.pitch & 7) || (d->out0.coff & 7) || d->out0.coff + split > d->out0.pitch) return ESR_ERR_BAD_ARG;
+        if (split < cout8 && (!d->out1.ptr || (d->out1.pitch & 7) || (d->out1.coff & 7) || d->out1.coff + (cout8 - split) > d->out1.pitch))
+            return ESR_ERR_BAD_ARG;
+    } else {
+        return ESR_ERR_BAD_ARG;
+    }
+    if (d->res_mode != ESR_RES_NONE && (!d->res.ptr || (d->res.pitch & 7) || (d->res.coff & 7) || d->res.coff + cout8 > d->res.pitch))
+        return ESR_ERR_BAD_ARG;
+    if ((double)d->h * d->w * d->in.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;   // per-image raw buffer < 2 GiB
+    const int nchunks = cin_phys / 16;
+    int ring = RING_MAX;                                     // as many input stages as fit next to the resident weights
+    size_t lds = 0;
+    int pnt1 = 0, pnt2 = 0, post_lo = 0;
+    if (post) {
+        const int rc = s16_post_plan(d, nt, nchunks, &pnt1, &pnt2, &post_lo, &ring, &lds);
+        if (rc != ESR_OK) return rc;
+        const int p1c8 = esr_round_up(d->post_cout, 8);
+        if (!d->post_out.ptr || (d->post_out.pitch & 7) || (d->post_out.coff & 7) || d->post_out.coff + p1c8 > d->post_out.pitch) return ESR_ERR_BAD_ARG;
+        if ((double)d->h * d->w * d->post_out.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
+        if (pnt2) {
+            const int p2c8 = esr_round_up(d->post2_cout, 8);
+            if (!d->post2_out.ptr || (d->post2_out.pitch & 7) || (d->post2_out.coff & 7) || d->post2_out.coff + p2c8 > d->post2_out.pitch) return ESR_ERR_BAD_ARG;
+            if ((double)d->h * d->w * d->post2_out.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
+        }
+        if (d->post_act != ESR_ACT_NONE && d->post_act != ESR_ACT_LRELU && d->post_act != ESR_ACT_RELU && d->post_act != ESR_ACT_GELU) return ESR_ERR_UNSUPPORTED;
+    } else {
+        const size_t extra = (d->border_bias ? (size_t)nt * 1024 : 0) + 1024;      // border table, the bias KB
+        while (ring > RING_MIN && s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, ring, extra) > (size_t)LDS_LIMIT) --ring;
+        lds = s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, ring, extra);
+    }
+    if (lds > (size_t)LDS_LIMIT) return ESR_ERR_UNSUPPORTED;                                     // weight set too large to stay resident
+    if (!shuffle && d->out0.ptr) {
+        if ((double)d->h * d->w * d->out0.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
+        if (split < cout8 && (double)d->h * d->w * d->out1.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
+    } else if (shuffle && (double)d->cout * d->h * d->w * 4.0 >= 2147483647.0) {
+        return ESR_ERR_UNSUPPORTED;                          // per-image raw buffers < 2 GiB (out-of-range offset 0x80000000)
+    }
+    if (d->res_mode != ESR_RES_NONE && (double)d->h * d->w * d->res.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
+    const int pairs = (d->ksize * d->ksize + 1) / 2;
+
+    S16K k;
+    k.x = static_cast<const char*>(d->in.ptr);
+    k.wp = static_cast<const char*>(d->wpacked);
+    k.bias = reinterpret_cast<const float*>(k.wp + (size_t)nchunks * pairs * nt * 1024);
+    k.res = static_cast<const char*>(d->res.ptr);
+    k.y0 = static_cast<char*>(d->out0.ptr);
+    k.y1 = static_cast<char*>(d->out1.ptr);
+    k.N = d->n; k.H = d->h; k.W = d->w;
+    k.nchunks = nchunks;
+    k.ring = ring;
+    k.in_pitch = d->in.pitch; k.in_coff = d->in.coff;
+    k.res_pitch = d->res.pitch; k.res_coff = d->res.coff;
+    k.y0_pitch = d->out0.pitch; k.y0_coff = d->out0.coff;
+    k.y1_pitch = d->out1.pitch; k.y1_coff = d->out1.coff;
+    k.cout_store = shuffle ? d->cout : cout8;
+    k.split = split;
+    k.act = d->act;
+    k.slope = d->act == ESR_ACT_LRELU ? d->slope : (d->act == ESR_ACT_RELU ? 0.f : 1.f);
+    k.res_mode = d->res_mode;
+    k.res_in = 0;
+    k.nres = 0;
+    if (s16_res_is_input(d)) {
+        k.res_in = 1;                               // residual == input: added from the staged tile, no residual loads
+        k.res_mode = ESR_RES_NONE;
+    }
+    if (k.res_mode != ESR_RES_NONE) k.nres = nt;                   // residual from HBM: staged as nt extra chunks per tile
+    k.out_layout = d->out_layout;
+    k.tiles_x = (d->w + TILE - 1) / TILE;
+    k.tiles_y = (d->h + 31) / 32;
+    k.magic_x = k.tiles_x > 1 ? (unsigned)((0x100000000ull + k.tiles_x - 1) / k.tiles_x) : 0u;
+    k.magic_y = k.tiles_y > 1 ? (unsigned)((0x100000000ull + k.tiles_y - 1) / k.tiles_y) : 0u;
+    {
+        const double nt_all = (double)d->n * k.tiles_x * k.tiles_y;
+        if (nt_all * (k.tiles_x > k.tiles_y ? k.tiles_x : k.tiles_y) >= 4294967296.0) return ESR_ERR_UNSUPPORTED;   // magic division range
+    }
+    k.pw1 = static_cast<const char*>(d->post_wpacked); k.pw2 = static_cast<const char*>(d->post2_wpacked);
+    k.py1 = static_cast<char*>(d->post_out.ptr); k.py2 = static_cast<char*>(d->post2_out.ptr);
+    k.py1_pitch = d->post_out.pitch; k.py1_coff = d->post_out.coff; k.py2_pitch = d->post2_out.pitch; k.py2_coff = d->post2_out.coff;
+    k.p1_cout8 = esr_round_up(d->post_cout > 0 ? d->post_cout : 1, 8); k.p2_cout8 = esr_round_up(d->post2_cout > 0 ? d->post2_cout : 1, 8);
+    k.p1_slope = d->post_act == ESR_ACT_LRELU ? d->slope : (d->post_act == ESR_ACT_RELU ? 0.f : 1.f);
+    k.p1_gelu = d->post_act == ESR_ACT_GELU;
+    k.post_lo = post_lo;
+    k.store_main = d->out0.ptr ? 1 : 0;
+    k.border = d->border_bias;
+    k.seg_chunks = segmented ? d->in_seg_chunks : nchunks;
+    k.seg_stride = segmented ? d->in_seg_stride : 0;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (post) {
+        const bool gres = k.res_mode != ESR_RES_NONE;
+        return bf16 ? launch_s16_post<true>(d->ksize, nt, gres, pnt1, pnt2, k, lds, st)
+                    : launch_s16_post<false>(d->ksize, nt, gres, pnt1, pnt2, k, lds, st);
+    }
+    // the plain 48-channel 3x3 (RLFB c1_r / c2_r): 46 KB of weights + a ring of three 11 KB stages fit 80 KB, so TWO 4-wave blocks
+    // share a CU -- their stage barriers are independent and one block's memory phase runs under the other's MFMAs (-2.5 % on the
+    // kernel, +1 % RLFN, A/B; 16 x 16 tiles carry more halo and the ring is the shortest, which is why it is not more)
+    if (s16_block_waves(d) == 4) {
+        const size_t lds4 = s16_lds_bytes(nchunks, nt, 3, 4, RING_MIN, 1024);
+        {
+            S16K k4 = k;
+            k4.ring = RING_MIN;
+            k4.tiles_y = (d->h + 15) / 16;
+            k4.magic_y = k4.tiles_y > 1 ? (unsigned)((0x100000000ull + k4.tiles_y - 1) / k4.tiles_y) : 0u;
+            const double nt_all = (double)d->n * k4.tiles_x * k4.tiles_y;
+            if (nt_all * (k4.tiles_x > k4.tiles_y ? k4.tiles_x : k4.tiles_y) < 4294967296.0)
+                return bf16 ? launch_s16<3, 3, 4, true, false>(k4, lds4, st) : launch_s16<3, 3, 4, false, false>(k4, lds4, st);
+        }
+    }
+    if (d->ksize == 3) return bf16 ? launch_s16_res<3, true>(nt, k, lds, st) : launch_s16_res<3, false>(nt, k, lds, st);
+    return bf16 ? launch_s16_res<1, true>(nt, k, lds, st) : launch_s16_res<1, false>(nt, k, lds, st);
+}

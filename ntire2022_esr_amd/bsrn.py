@@ -156,8 +156,12 @@ class BSRN(HipSRModel):
         lo2 = plan.buffer('esa_s2', FP, h2, w2)
         la, lb, lt = (plan.buffer(n, FP, h3, w3) for n in ('esa_a', 'esa_b', 'esa_t'))
         lo = (h3, w3)
+        # a block's FIRST distillation Linear + GELU (c1_d reads the block input) rides in the epilogue of the launch that produces
+        # that input: the head for block 1, the previous block's conv_out for the others (one launch and one read of the tensor less)
+        def first_d(k):
+            return dict(w=f'B{k}.c1_d', dst=cs(0), cout=dc, act=L.ACT_GELU) if fuse_d else None
         if merged:
-            plan.conv('fea_conv#bs3', INPUT, fea, self.in_nc, C, k=3, border='fea_conv#bs3#border', bs_of='fea_conv')
+            plan.conv('fea_conv#bs3', INPUT, fea, self.in_nc, C, k=3, border='fea_conv#bs3#border', bs_of='fea_conv', post=first_d(1))
         else:
             plan.conv('fea_conv.pw', INPUT, t, self.in_nc, C, counted=False)
             plan.dwconv('fea_conv.dw', t, fea, C)
@@ -169,8 +173,8 @@ class BSRN(HipSRModel):
                 if merged:
                     # 16-bit storage: BSConvU as one dense 3x3 on the matrix cores (+ input from the staged tile, GELU).  The
                     # NEXT distillation Linear + GELU (c{j+1}_d reads this launch's result r_j) rides in its epilogue on the
-                    # fp32 tile; the block's first one (c1_d, of the block input) is a 1x1 of its own.
-                    if j == 1:
+                    # fp32 tile; the block's first one (c1_d, of the block input) rides with the producer of the block input (first_d).
+                    if j == 1 and not fuse_d:
                         plan.conv(b + 'c1_d', rin, cs(0), C, dc, k=1, counted=False, **g)
                     nxt = dict(w=b + f'c{j + 1}_d', dst=cs(j), cout=dc, act=L.ACT_GELU) if (j < 3 and fuse_d) else None
                     bs3(b + f'c{j}_r', rin, rout, C, C, res=rin, res_mode=L.RES_PRE_ACT, post=nxt, **g)
@@ -210,7 +214,8 @@ class BSRN(HipSRModel):
                                  dict(kind=1, act=L.ACT_NONE, w=b + 'esa.conv3_.pw', w_dw=b + 'esa.conv3_.dw')])
             plan.esa_apply(b + 'esa.conv_f', b + 'esa.conv4', v, c1, lb, u, C, f)
             out = bcat.seg(k - 1) if bplanar else bcat[(k - 1) * C:k * C]
-            plan.conv(b + 'conv_out', u, out, C, C, k=1, res=src, res_mode=L.RES_PRE_ACT, counted=False)
+            plan.conv(b + 'conv_out', u, out, C, C, k=1, res=src, res_mode=L.RES_PRE_ACT, counted=False,
+                      post=first_d(k + 1) if (merged and k < nb) else None)
             cur = out
         plan.conv('c1', bcat, v, nb * C, C, k=1, counted=False, **g)
         if merged:
@@ -236,7 +241,7 @@ class BSRN(HipSRModel):
             nlin = 1 + (o.get("post") is not None)                        # (+ the next distillation Linear in its epilogue)
             return 9 * o["cout"] * plan.n * h * w + nlin * plan.n * h * h, o["cout"] * plan.n * h * w, 1
         if o["kind"] == "conv" and not o.get("counted", True):
-            return plan.n * h * h, 0, 0                                   # a Linear call
+            return (1 + (o.get("post") is not None)) * plan.n * h * h, 0, 0      # a Linear call (+ the one in its epilogue)
         if o["kind"] == "apply":
             return 2 * plan.n * plan.h * plan.h, 0, 0                     # conv_f and conv4 are Linear here
         return super()._complexity_terms(plan, o)

@@ -975,9 +975,10 @@ int launch_s16_res(int nt, const S16K& k, size_t lds, hipStream_t st)
 //   (3, 3, no,  2, 0)  RFDB                                                                   nf = 40
 //   (1, 3 | 4, no, 1, 0)  c5 (the 1x1 over the distillation concat) -> esa.conv1: BSRN / RFDN (team18_bsrn.py:167,110;
 //                         rfdn_baseline/block.py:164,118)
+//   (1, 3, any, 2, 0)     ESDB conv_out (+ block input) -> the NEXT block's c1_d + GELU (team18_bsrn.py:170-172 -> :150)
 inline bool post_variant_exists(int ks, int nt, bool gres, int pnt1, int pnt2)
 {
-    if (ks == 1) return (nt == 3 || nt == 4) && !gres && pnt1 == 1 && pnt2 == 0;
+    if (ks == 1) return pnt2 == 0 && (((nt == 3 || nt == 4) && !gres && pnt1 == 1) || (nt == 3 && pnt1 == 2));
     return (nt == 3 && gres && pnt1 == 3 && pnt2 == 1) || (nt == 4 && !gres && pnt1 == 2 && pnt2 == 0) ||
            (nt == 3 && !gres && pnt1 == 2 && pnt2 == 0);
 }
@@ -988,6 +989,7 @@ int launch_s16_post(int ks, int nt, bool gres, int pnt1, int pnt2, const S16K& k
     if (ks == 1) {
         if (nt == 3 && !gres && pnt1 == 1 && pnt2 == 0) return launch_s16<3, 1, S16_NW, BF16, false, 1, 0>(k, lds, st);
         if (nt == 4 && !gres && pnt1 == 1 && pnt2 == 0) return launch_s16<4, 1, S16_NW, BF16, false, 1, 0>(k, lds, st);
+        if (nt == 3 && pnt1 == 2 && pnt2 == 0) return launch_s16<3, 1, S16_NW, BF16, false, 2, 0>(k, lds, st);    // (residual, if any, staged through LDS)
         return ESR_ERR_UNSUPPORTED;
     }
     if (nt == 3 && gres && pnt1 == 3 && pnt2 == 1) return launch_s16<3, 3, S16_NW, BF16, false, 3, 1>(k, lds, st);    // (the residual is staged through LDS: S16K.nres)

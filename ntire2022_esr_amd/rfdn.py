@@ -70,7 +70,10 @@ class RFDN(HipSRModel):
         P = plan.cpad(nf)                                 # 56 fp32 channels / 64 16-bit channels: whole K chunks
         h2, w2, h3, w3 = _lowres(plan.h, plan.w)
         fea = plan.buffer('fea', P)
-        bcat = plan.buffer('bcat', 4 * P)                 # the four block outputs, RFDN.py:36
+        # the four block outputs, RFDN.py:36: four dense tensors in the 16-bit modes (engine.Planar; same slot order as the padded
+        # [.., 4 P] buffer, so c.0's weight blob does not change)
+        bplanar = plan.esize == 2
+        bcat = plan.planar('bcat', 4, P) if bplanar else plan.buffer('bcat', 4 * P)
         # d1 d2 d3 r4, block.py:163.  16-bit storage: four dense tensors (engine.Planar) -- a 32-channel slice of a 128-wide
         # buffer is a partial-line store there (64 of 256 bytes per pixel), 2.3x the cost of a dense one
         planar = plan.esize == 2
@@ -84,12 +87,15 @@ class RFDN(HipSRModel):
         act = dict(act=L.ACT_LRELU, slope=0.05)
         lo = dict(hw=(h3, w3))
         res = (lambda v: dict(res=v, res_mode=L.RES_PRE_ACT)) if self.block_residual else (lambda v: {})
-        plan.conv('fea_conv', INPUT, fea, self.in_nc, nf)
+        fused_post = (48 < nf <= 64 and 16 < dc <= 32) if plan.esize == 4 else ((nf + 15) // 16 in (3, 4) and 16 < dc <= 32)
+        # 16-bit modes: block 1's first distillation conv (c1_d of fea) rides in the head convolution's epilogue
+        head_d = plan.esize == 2 and fused_post
+        plan.conv('fea_conv', INPUT, fea, self.in_nc, nf, post=dict(w='B1.c1_d', dst=cs(0), cout=dc, act=L.ACT_LRELU) if head_d else None)
         cur = fea
         for k in range(1, 5):
             b = f'B{k}.'
-            plan.conv(b + 'c1_d', cur, cs(0), nf, dc, k=1, **act)
-            fused_post = (48 < nf <= 64 and 16 < dc <= 32) if plan.esize == 4 else ((nf + 15) // 16 in (3, 4) and 16 < dc <= 32)
+            if not (head_d and k == 1):
+                plan.conv(b + 'c1_d', cur, cs(0), nf, dc, k=1, **act)
             if fused_post:
                 # the distillation conv of r_j rides in the epilogue of the conv that produces r_j (block.py:150-160)
                 plan.conv(b + 'c1_r', cur, r1, nf, nf, **res(cur), **act,
@@ -120,7 +126,7 @@ class RFDN(HipSRModel):
                 plan.esa_lowres(mark, c1, la, lb, f, b + 'esa.conv2',
                                 [dict(kind=0, act=L.ACT_RELU, w=b + 'esa.conv_max'), dict(kind=0, act=L.ACT_RELU, w=b + 'esa.conv3'),
                                  dict(kind=0, act=L.ACT_NONE, w=b + 'esa.conv3_')])
-            out = bcat[(k - 1) * P:k * P]
+            out = bcat.seg(k - 1) if bplanar else bcat[(k - 1) * P:k * P]
             plan.esa_apply(b + 'esa.conv_f', b + 'esa.conv4', v, c1, lb, out, nf, f)
             cur = out
         plan.conv('c.0', bcat, v, 4 * P, nf, k=1, cin_alg=4 * nf, **act)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESR_ABI_VERSION 7
+#define ESR_ABI_VERSION 8
 
 typedef enum esr_status {
     ESR_OK = 0,
@@ -235,6 +235,30 @@ size_t esr_packed_dense_bytes(int cin_p, int cout_p, int ksize);
 int    esr_pack_dense_f32(const float* w_oihw, const float* bias, int cin, int cout, int ksize,
                           int cin_p, int cout_p, void* out, size_t out_bytes);
 
+/*
+ * A 1x1 convolution riding in esr_esa_apply_f32's launch (ABI v8, 16-bit storage only): post[0] is evaluated on the apply result
+ * y AS STORED (the 16-bit rounded values: exactly what a separate 1x1 launch would read back), post[1] on post[0]'s fp32 result
+ * (16-bit high + low parts, as esr_conv_desc.post_* does).  v = W.in + b (+ res, ESR_RES_PRE_ACT) -> act -> 16-bit store to `out`.
+ *   RFDN  : y = the RFDB's output, post[0] = the NEXT block's c1_d + LeakyReLU (rfdn_baseline/block.py:150)
+ *   BSRN  : y = the ESA output (store_y = 0: nothing else reads it), post[0] = conv_out . cw + block input (team18_bsrn.py:169-172),
+ *           post[1] = the next block's c1_d + GELU (:150)
+ * Weights: esr_esa_desc.post_w, ONE esr_pack_apply_post blob for the chain (MFMA images of the weights' 16-bit high and low parts
+ * + fp32 biases).
+ */
+typedef struct esr_esa_post {
+    int32_t cout;               /* 0: unused */
+    int32_t act;                /* esr_act */
+    float   slope;
+    int32_t res_mode;           /* ESR_RES_NONE | ESR_RES_PRE_ACT (post[0] only) */
+    esr_view res;
+    esr_view out;
+} esr_esa_post;
+int    esr_esa_apply_post_supported(int c, int cout0, int cout1);   /* 1: esr_esa_apply_f32 has a kernel for this chain (cout1 = 0: post[0] only) */
+size_t esr_packed_apply_post_bytes(int cin, int cout0, int cout1, int storage);
+/* w0: [cout0][cin] fp32 (+ b0[cout0] or NULL), w1: [cout1][cout0] (+ b1) or NULL with cout1 = 0 */
+int    esr_pack_apply_post(const float* w0, const float* b0, const float* w1, const float* b1, int cin, int cout0, int cout1,
+                           int storage, void* out, size_t out_bytes);
+
 typedef struct esr_esa_desc {
     int32_t n, h, w;            /* full-resolution dims */
     int32_t c;                  /* n_feats (logical channels of x / y) */
@@ -247,6 +271,10 @@ typedef struct esr_esa_desc {
     const void* c3;             /* apply: low-res map [n][h_lo][w_lo][16] */
     const void* w0;             /* conv3x3s2: packed dense k=3 ; apply: conv_f packed dense k=1 (16 x 16) */
     const void* w1;             /* apply: conv4 packed dense k=1 (16 x round_up(c,4)) */
+    const void* post_w;         /* apply, ABI v8: esr_pack_apply_post blob of post[0] (+ post[1]), or NULL */
+    esr_esa_post post[2];
+    int32_t skip_y;             /* apply: 1 = y is not stored (only the post chain consumes it) */
+    int32_t reserved;
 } esr_esa_desc;
 
 /*

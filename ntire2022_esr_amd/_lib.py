@@ -50,6 +50,13 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class EsaPost(ctypes.Structure):
+    _fields_ = [
+        ("cout", ctypes.c_int32), ("act", ctypes.c_int32), ("slope", ctypes.c_float), ("res_mode", ctypes.c_int32),
+        ("res", View), ("out", View),
+    ]
+
+
 class EsaDesc(ctypes.Structure):
     _fields_ = [
         ("n", ctypes.c_int32), ("h", ctypes.c_int32), ("w", ctypes.c_int32),
@@ -57,6 +64,7 @@ class EsaDesc(ctypes.Structure):
         ("storage", ctypes.c_int32),
         ("x", View), ("y", View),
         ("c1", ctypes.c_void_p), ("c3", ctypes.c_void_p), ("w0", ctypes.c_void_p), ("w1", ctypes.c_void_p),
+        ("post_w", ctypes.c_void_p), ("post", EsaPost * 2), ("skip_y", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
 
@@ -111,6 +119,7 @@ EXPORTS = [
     "esr_prof_create", "esr_run_ops_profiled", "esr_prof_collect", "esr_prof_destroy", "esr_prof_kernel_symbol",
     "esr_packed_dense_bytes", "esr_pack_dense_f32",
     "esr_conv3x3s2_f32", "esr_maxpool7s3_f32", "esr_esa_apply_f32", "esr_esa_lowres_f32",
+    "esr_esa_apply_post_supported", "esr_packed_apply_post_bytes", "esr_pack_apply_post",
     "esr_packed_dw_bytes", "esr_pack_dw_f32", "esr_dwconv3x3_f32", "esr_bsconv_f32",
     "esr_tensor2uint_u8", "esr_sqerr_u8", "esr_channel_attention_f32",
 ]
@@ -200,7 +209,13 @@ def lib():
     L.esr_prof_kernel_symbol.restype = ci
     L.esr_prof_destroy.argtypes = [vp]
     L.esr_prof_destroy.restype = None
-    if L.esr_abi_version() != 7:
+    L.esr_esa_apply_post_supported.argtypes = [ci, ci, ci]
+    L.esr_esa_apply_post_supported.restype = ci
+    L.esr_packed_apply_post_bytes.argtypes = [ci, ci, ci, ci]
+    L.esr_packed_apply_post_bytes.restype = sz
+    L.esr_pack_apply_post.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, sz]
+    L.esr_pack_apply_post.restype = ci
+    if L.esr_abi_version() != 8:
         raise EsrError("libesr_hip.so ABI version mismatch")
     L.esr_sizeof.argtypes = [ci]
     L.esr_sizeof.restype = ctypes.c_size_t

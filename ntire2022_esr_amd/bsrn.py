@@ -16,7 +16,7 @@ through esr_conv_desc.border_bias (a 16-row table indexed by which sides of the 
 import torch
 
 from . import _lib as L
-from .engine import INPUT, OUTPUT, HipSRModel, pack_conv, pack_conv_s16, pack_head_s16
+from .engine import INPUT, OUTPUT, HipSRModel, pack_apply_post, pack_conv, pack_conv_s16, pack_head_s16
 from .rlfn import FP, _lowres, _pad8
 
 
@@ -124,6 +124,10 @@ class BSRN(HipSRModel):
             packed[f'B{k}.conv_out'] = pack_conv(co.weight.detach().float() * cw, co.bias).to(device)
             if self._store() != "f32":
                 packed[f'B{k}.conv_out#s16'] = pack_conv_s16(co.weight.detach().float() * cw, co.bias, self._store()).to(device)
+                if L.lib().esr_esa_apply_post_supported(C, C, self.dc):      # the chain of the ESA apply launch (engine.Plan.esa_apply)
+                    nd = self._leaf(f'B{k + 1}.c1_d') if k < self.nb else None
+                    packed[f'B{k}.conv_out#apost'] = pack_apply_post(co.weight.detach().float() * cw, co.bias, None if nd is None else nd.weight,
+                                                                     None if nd is None else nd.bias, self._store()).to(device)
 
     def _build_plan(self, plan, c):
         if c != self.in_nc:
@@ -158,6 +162,7 @@ class BSRN(HipSRModel):
         lo = (h3, w3)
         # a block's FIRST distillation Linear + GELU (c1_d reads the block input) rides in the epilogue of the launch that produces
         # that input: the head for block 1, the previous block's conv_out for the others (one launch and one read of the tensor less)
+        apply_out = fuse_d and bplanar and bool(L.lib().esr_esa_apply_post_supported(C, C, dc))
         def first_d(k):
             return dict(w=f'B{k}.c1_d', dst=cs(0), cout=dc, act=L.ACT_GELU) if fuse_d else None
         if merged:
@@ -212,10 +217,17 @@ class BSRN(HipSRModel):
                                 [dict(kind=1, act=ga, w=b + 'esa.conv_max.pw', w_dw=b + 'esa.conv_max.dw'),
                                  dict(kind=1, act=ga, w=b + 'esa.conv3.pw', w_dw=b + 'esa.conv3.dw'),
                                  dict(kind=1, act=L.ACT_NONE, w=b + 'esa.conv3_.pw', w_dw=b + 'esa.conv3_.dw')])
-            plan.esa_apply(b + 'esa.conv_f', b + 'esa.conv4', v, c1, lb, u, C, f)
             out = bcat.seg(k - 1) if bplanar else bcat[(k - 1) * C:k * C]
-            plan.conv(b + 'conv_out', u, out, C, C, k=1, res=src, res_mode=L.RES_PRE_ACT, counted=False,
-                      post=first_d(k + 1) if (merged and k < nb) else None)
+            if apply_out:
+                # conv_out (. cw, + block input) and the next block's c1_d in the ESA apply launch: the attention output never reaches memory
+                chain = [dict(w=b + 'conv_out', dst=out, cout=C, act=L.ACT_NONE, res=src)]
+                if k < nb:
+                    chain.append(dict(w=f'B{k + 1}.c1_d', dst=cs(0), cout=dc, act=L.ACT_GELU))
+                plan.esa_apply(b + 'esa.conv_f', b + 'esa.conv4', v, c1, lb, out, C, f, post=chain, skip_y=True)
+            else:
+                plan.esa_apply(b + 'esa.conv_f', b + 'esa.conv4', v, c1, lb, u, C, f)
+                plan.conv(b + 'conv_out', u, out, C, C, k=1, res=src, res_mode=L.RES_PRE_ACT, counted=False,
+                          post=first_d(k + 1) if (merged and k < nb) else None)
             cur = out
         plan.conv('c1', bcat, v, nb * C, C, k=1, counted=False, **g)
         if merged:
@@ -243,5 +255,5 @@ class BSRN(HipSRModel):
         if o["kind"] == "conv" and not o.get("counted", True):
             return (1 + (o.get("post") is not None)) * plan.n * h * h, 0, 0      # a Linear call (+ the one in its epilogue)
         if o["kind"] == "apply":
-            return 2 * plan.n * plan.h * plan.h, 0, 0                     # conv_f and conv4 are Linear here
+            return (2 + len(o.get("post") or ())) * plan.n * plan.h * plan.h, 0, 0       # conv_f and conv4 are Linear here (+ those riding in the launch)
         return super()._complexity_terms(plan, o)

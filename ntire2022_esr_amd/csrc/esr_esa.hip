@@ -127,6 +127,14 @@ struct EsaK {
     int x_pitch, x_coff, y_pitch, y_coff;
     int N, H, W, Cp4, cp, h3, w3;
     float sh, sw;
+    // post chain (esr_esa_desc.post_w / post[]: 16-bit storage, esa_apply_mfma_kernel<.., NP0 > 0, ..>)
+    const unsigned short* pimg;
+    const void* pres; void* pout0; void* pout1;
+    int pres_pitch, pres_coff, pout0_pitch, pout0_coff, pout1_pitch, pout1_coff;
+    int p0_c8, p1_c8;           // channels stored (multiples of 8)
+    int p0_act, p1_act, p0_res;
+    float p0_slope, p1_slope;
+    int skip_y;
 };
 
 template <int ST>
@@ -243,10 +251,28 @@ __device__ __forceinline__ f32x4 mfma_k32(i32x4_t a, i32x4_t b, f32x4 c)
 // Channel <-> MFMA row map of conv4: tile t, row i (= 4 kq + r) computes channel 32 (t >> 1) + 8 kq + 4 (t & 1) + r, so a lane's
 // results of a tile PAIR are 8 CONSECUTIVE channels: x is read and y written as 16 bytes per lane, 64 contiguous bytes per
 // pixel and instruction (the natural 16 t + 4 kq + r map gives 8-byte pieces, 32 bytes per pixel: twice the requests).
-template <int ST, int NP>                         // NP = channel pairs of tiles = ceil(C / 32)
+//
+// Post chain (NP0 / NP1 = channel pairs of tiles of post 0 / post 1, esr_esa_desc.post[]): the packed 16-bit result of a tile pair
+// -- 8 consecutive channels per lane -- IS the B operand of the next 1x1's K block of 32 channels (k slot (kq, j) = channel
+// 32 q + 8 kq + j), so post 0 runs on the values a separate launch would have read back from memory; its D fragments (same row
+// map, so again 8 consecutive channels per lane and tile pair) feed post 1 as fp32 high + low parts.  RFDN: y + the next block's
+// c1_d; BSRN: conv_out (+ block input) and the next block's c1_d, the attention output itself never reaches memory.
+template <int ST, int NP, int NP0 = 0, int NP1 = 0>     // NP = channel pairs of tiles = ceil(C / 32)
 __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
 {
     constexpr int NT = 2 * NP;
+    constexpr int NT0 = 2 * NP0, NT1 = 2 * NP1;
+    constexpr int LO1 = ST == ESR_STORE_BF16 ? 2 : 1;                        // post 1: high (+ low) weight images; post 0: always both
+    constexpr int P0_IMGS = 2 * NT0 * NP, P1_IMGS = LO1 * NT1 * NT0;
+    __shared__ __attribute__((aligned(16))) unsigned short spimg[(P0_IMGS + P1_IMGS > 0 ? P0_IMGS + P1_IMGS : 1) * 512];
+    __shared__ __attribute__((aligned(16))) float spbias[(NT0 + NT1 > 0 ? NT0 + NT1 : 1) * 16];
+    if (NP0 > 0) {
+        // esr_pack_apply_post blob: the images in this order, then the biases
+        const i32x4_t* src = reinterpret_cast<const i32x4_t*>(p.pimg);
+        for (int e = threadIdx.x; e < (P0_IMGS + P1_IMGS) * 64; e += 256) reinterpret_cast<i32x4_t*>(spimg)[e] = src[e];
+        const float* bsrc = reinterpret_cast<const float*>(p.pimg + (size_t)(P0_IMGS + P1_IMGS) * 512);
+        for (int e = threadIdx.x; e < (NT0 + NT1) * 16; e += 256) spbias[e] = bsrc[e];
+    }
     // LDS: A images, lane-linear 16 bytes per lane: [Wf][W4 hi x NT][W4 lo x NT], then bf[16] and b4[NT*16] as floats
     __shared__ __attribute__((aligned(16))) unsigned short simg[(1 + 2 * NT) * 64 * 8];
     __shared__ __attribute__((aligned(16))) float sbias[16 + NT * 16];
@@ -296,6 +322,9 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
     bool chan_ok[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) chan_ok[q] = 32 * q + 8 * kq < p.Cp4;
+    const unsigned short* rs = static_cast<const unsigned short*>(p.pres);
+    unsigned short* o0 = static_cast<unsigned short*>(p.pout0);
+    unsigned short* o1 = static_cast<unsigned short*>(p.pout1);
 
     // everything a group reads, requested one group ahead of its arithmetic
     struct Grp {
@@ -303,6 +332,7 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
         bool live;
         i32x4_t bc1;
         i32x4_t xv[NP];
+        i32x4_t rv[NP0 > 0 ? NP0 : 1];          // residual of post 0 (8 channels per pair)
         f32x4 ta, tb, tc, td;
         float ly, lx;
     };
@@ -332,6 +362,14 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
         for (int q = 0; q < NP; ++q) {
             g.xv[q] = i32x4_t{0, 0, 0, 0};
             if (chan_ok[q]) g.xv[q] = *reinterpret_cast<const i32x4_t*>(xs + (size_t)g.pix * p.x_pitch + p.x_coff + 32 * q + 8 * kq);
+        }
+        if (NP0 > 0) {
+#pragma unroll
+            for (int q = 0; q < (NP0 > 0 ? NP0 : 1); ++q) {
+                g.rv[q] = i32x4_t{0, 0, 0, 0};
+                if (p.p0_res && 32 * q + 8 * kq < p.p0_c8)
+                    g.rv[q] = *reinterpret_cast<const i32x4_t*>(rs + (size_t)g.pix * p.pres_pitch + p.pres_coff + 32 * q + 8 * kq);
+            }
         }
         // bilinear source coordinates: ATen area_pixel_compute_source_index, fused multiply-add (see oracle)
         float fy = fmaf((float)oy + 0.5f, p.sh, -0.5f);
@@ -366,14 +404,26 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
         i32x4_t bs;
         bs.x = (int)((unsigned)h[0] | ((unsigned)h[1] << 16)); bs.y = (int)((unsigned)h[2] | ((unsigned)h[3] << 16));
         bs.z = (int)((unsigned)l[0] | ((unsigned)l[1] << 16)); bs.w = (int)((unsigned)l[2] | ((unsigned)l[3] << 16));
+        i32x4_t yv[NP];                  // the result as stored: 8 consecutive channels per lane and pair
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             f32x4 m0 = *reinterpret_cast<const f32x4*>(sbias + 16 + (2 * q) * 16 + kq * 4);
             f32x4 m1 = *reinterpret_cast<const f32x4*>(sbias + 16 + (2 * q + 1) * 16 + kq * 4);
-            m0 = mfma_k32<ST>(a_hi[2 * q], bs, m0);
-            m1 = mfma_k32<ST>(a_hi[2 * q + 1], bs, m1);
-            m0 = mfma_k32<ST>(a_lo[2 * q], bs, m0);
-            m1 = mfma_k32<ST>(a_lo[2 * q + 1], bs, m1);
+            if constexpr (NP0 > 0) {
+                // (with a post chain conv4's images stay in LDS too: 32 registers that decide between two and three waves per SIMD)
+                int sio = lane * 8;
+                asm volatile("" : "+v"(sio));
+                const unsigned short* const sim = simg + sio;
+                m0 = mfma_k32<ST>(*reinterpret_cast<const i32x4_t*>(sim + (1 + 2 * q) * 512), bs, m0);
+                m1 = mfma_k32<ST>(*reinterpret_cast<const i32x4_t*>(sim + (1 + 2 * q + 1) * 512), bs, m1);
+                m0 = mfma_k32<ST>(*reinterpret_cast<const i32x4_t*>(sim + (1 + NT + 2 * q) * 512), bs, m0);
+                m1 = mfma_k32<ST>(*reinterpret_cast<const i32x4_t*>(sim + (1 + NT + 2 * q + 1) * 512), bs, m1);
+            } else {
+                m0 = mfma_k32<ST>(a_hi[2 * q], bs, m0);
+                m1 = mfma_k32<ST>(a_hi[2 * q + 1], bs, m1);
+                m0 = mfma_k32<ST>(a_lo[2 * q], bs, m0);
+                m1 = mfma_k32<ST>(a_lo[2 * q + 1], bs, m1);
+            }
             const unsigned xw[4] = {(unsigned)g.xv[q].x, (unsigned)g.xv[q].y, (unsigned)g.xv[q].z, (unsigned)g.xv[q].w};
             const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
             unsigned ow[4];
@@ -383,9 +433,77 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
                 ow[d] = (unsigned)to16<ST>(xa * sigmoid(mm[2 * d])) | ((unsigned)to16<ST>(xb * sigmoid(mm[2 * d + 1])) << 16);
             }
             // only the store is predicated: the MFMAs above must run with every lane active (a lane supplies A / B operands)
-            if (g.live && chan_ok[q])
-                *reinterpret_cast<i32x4_t*>(ys + (size_t)g.pix * p.y_pitch + p.y_coff + 32 * q + 8 * kq) =
-                    i32x4_t{(int)ow[0], (int)ow[1], (int)ow[2], (int)ow[3]};
+            yv[q] = i32x4_t{(int)ow[0], (int)ow[1], (int)ow[2], (int)ow[3]};
+            if (g.live && chan_ok[q] && !(NP0 > 0 && p.skip_y))
+                *reinterpret_cast<i32x4_t*>(ys + (size_t)g.pix * p.y_pitch + p.y_coff + 32 * q + 8 * kq) = yv[q];
+        }
+        if constexpr (NP0 > 0) {
+            auto pact = [&](f32x4 v, int act, float slope) __attribute__((always_inline)) -> f32x4 {
+                if (act == ESR_ACT_GELU) return f32x4{esr_gelu16(v.x), esr_gelu16(v.y), esr_gelu16(v.z), esr_gelu16(v.w)};
+                return f32x4{fmaxf(v.x, slope * v.x), fmaxf(v.y, slope * v.y), fmaxf(v.z, slope * v.z), fmaxf(v.w, slope * v.w)};     // slope 1: none, 0: ReLU
+            };
+            auto pack8 = [&](f32x4 a, f32x4 b) __attribute__((always_inline)) -> i32x4_t {
+                return i32x4_t{(int)((unsigned)to16<ST>(a.x) | ((unsigned)to16<ST>(a.y) << 16)), (int)((unsigned)to16<ST>(a.z) | ((unsigned)to16<ST>(a.w) << 16)),
+                               (int)((unsigned)to16<ST>(b.x) | ((unsigned)to16<ST>(b.y) << 16)), (int)((unsigned)to16<ST>(b.z) | ((unsigned)to16<ST>(b.w) << 16))};
+            };
+            // the weight images are re-read from LDS for every group: made loop-variant on purpose -- hoisted out of the group loop they
+            // are 100+ registers (hipcc did exactly that: 364 VGPRs, one wave per SIMD)
+            int pio = lane * 8;
+            asm volatile("" : "+v"(pio));
+            const unsigned short* const pim = spimg + pio;
+            f32x4 d0[NT0];
+#pragma unroll
+            for (int t = 0; t < NT0; ++t) {
+                d0[t] = *reinterpret_cast<const f32x4*>(spbias + t * 16 + kq * 4);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    d0[t] = mfma_k32<ST>(*reinterpret_cast<const i32x4_t*>(pim + ((0 * NT0 + t) * NP + q) * 512), yv[q], d0[t]);
+                    d0[t] = mfma_k32<ST>(*reinterpret_cast<const i32x4_t*>(pim + ((1 * NT0 + t) * NP + q) * 512), yv[q], d0[t]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NP0; ++q) {
+                const unsigned rw[4] = {(unsigned)g.rv[q].x, (unsigned)g.rv[q].y, (unsigned)g.rv[q].z, (unsigned)g.rv[q].w};
+                f32x4 ra, rb;          // (zeros when there is no residual)
+                ra.x = from16<ST>((unsigned short)(rw[0] & 0xffffu)); ra.y = from16<ST>((unsigned short)(rw[0] >> 16));
+                ra.z = from16<ST>((unsigned short)(rw[1] & 0xffffu)); ra.w = from16<ST>((unsigned short)(rw[1] >> 16));
+                rb.x = from16<ST>((unsigned short)(rw[2] & 0xffffu)); rb.y = from16<ST>((unsigned short)(rw[2] >> 16));
+                rb.z = from16<ST>((unsigned short)(rw[3] & 0xffffu)); rb.w = from16<ST>((unsigned short)(rw[3] >> 16));
+                d0[2 * q] = pact(d0[2 * q] + ra, p.p0_act, p.p0_slope);
+                d0[2 * q + 1] = pact(d0[2 * q + 1] + rb, p.p0_act, p.p0_slope);
+                if (g.live && 32 * q + 8 * kq < p.p0_c8)
+                    *reinterpret_cast<i32x4_t*>(o0 + (size_t)g.pix * p.pout0_pitch + p.pout0_coff + 32 * q + 8 * kq) = pack8(d0[2 * q], d0[2 * q + 1]);
+            }
+            if constexpr (NP1 > 0) {
+                f32x4 d1[NT1];
+#pragma unroll
+                for (int t = 0; t < NT1; ++t) d1[t] = *reinterpret_cast<const f32x4*>(spbias + (NT0 + t) * 16 + kq * 4);
+#pragma unroll
+                for (int T = 0; T < NT0; ++T) {
+                    // fp32 fragment -> B operand: k slots 0..3 = the 16-bit high parts, 4..7 = the low parts (bf16; fp16's 11 bits are the storage precision)
+                    unsigned short h[4], l[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        h[j] = to16<ST>(d0[T][j]);
+                        l[j] = LO1 == 2 ? to16<ST>(d0[T][j] - from16<ST>(h[j])) : (unsigned short)0;
+                    }
+                    const i32x4_t bs = {(int)((unsigned)h[0] | ((unsigned)h[1] << 16)), (int)((unsigned)h[2] | ((unsigned)h[3] << 16)),
+                                        (int)((unsigned)l[0] | ((unsigned)l[1] << 16)), (int)((unsigned)l[2] | ((unsigned)l[3] << 16))};
+#pragma unroll
+                    for (int t = 0; t < NT1; ++t) {
+                        d1[t] = mfma_k32<ST>(*reinterpret_cast<const i32x4_t*>(pim + (P0_IMGS + (0 * NT1 + t) * NT0 + T) * 512), bs, d1[t]);
+                        if (LO1 == 2)
+                            d1[t] = mfma_k32<ST>(*reinterpret_cast<const i32x4_t*>(pim + (P0_IMGS + (1 * NT1 + t) * NT0 + T) * 512), bs, d1[t]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NP1; ++q) {
+                    d1[2 * q] = pact(d1[2 * q], p.p1_act, p.p1_slope);
+                    d1[2 * q + 1] = pact(d1[2 * q + 1], p.p1_act, p.p1_slope);
+                    if (g.live && 32 * q + 8 * kq < p.p1_c8)
+                        *reinterpret_cast<i32x4_t*>(o1 + (size_t)g.pix * p.pout1_pitch + p.pout1_coff + 32 * q + 8 * kq) = pack8(d1[2 * q], d1[2 * q + 1]);
+                }
+            }
         }
     };
     long long grp = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wv);
@@ -403,22 +521,62 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
     }
 }
 
+// the post-chain shapes that exist: (pairs of the apply, pairs of post 0, pairs of post 1)
+static bool esa_post_variant(int np, int np0, int np1) { return np == 2 && ((np0 == 1 && np1 == 0) || (np0 == 2 && np1 <= 1)); }
+
 template <int ST>
-int launch_esa_mfma(const EsaK& k, hipStream_t st)
+int launch_esa_mfma(const EsaK& k, int np0, int np1, hipStream_t st)
 {
     const long long npix = (long long)k.N * k.H * k.W;
-    // every block first builds the MFMA weight images (~2 us): give each wave at least ~4 pixel groups of work
+    // every block first builds the MFMA weight images (~2 us; with a post chain it also copies 16-32 KB of images): give each wave
+    // at least ~4 (8) pixel groups of work
     const long long ngroups = (npix + 15) / 16;
-    long long nwg = (ngroups + 15) / 16;
+    long long nwg = np0 > 0 ? (ngroups + 31) / 32 : (ngroups + 15) / 16;
     nwg = nwg < 1 ? 1 : (nwg > 4096 ? 4096 : nwg);
     const unsigned grid = (unsigned)nwg;
     const int np = (k.Cp4 + 31) / 32;
+    if (np0 > 0) {
+        if (!esa_post_variant(np, np0, np1)) return ESR_ERR_UNSUPPORTED;
+        esr_note_kernel("esa_apply_mfma_kernel<%d, 2, %d, %d>", ST, np0, np1);
+        if (np0 == 1) hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 2, 1, 0>), dim3(grid), dim3(256), 0, st, k);
+        else if (np1 == 0) hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 2, 2, 0>), dim3(grid), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 2, 2, 1>), dim3(grid), dim3(256), 0, st, k);
+        return esr_check_launch("esa_apply_mfma_kernel launch");
+    }
     switch (np) {
-        case 1: esr_note_kernel("esa_apply_mfma_kernel<%d, 1>", ST); hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 1>), dim3(grid), dim3(256), 0, st, k); break;
-        case 2: esr_note_kernel("esa_apply_mfma_kernel<%d, 2>", ST); hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 2>), dim3(grid), dim3(256), 0, st, k); break;
+        case 1: esr_note_kernel("esa_apply_mfma_kernel<%d, 1, 0, 0>", ST); hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 1>), dim3(grid), dim3(256), 0, st, k); break;
+        case 2: esr_note_kernel("esa_apply_mfma_kernel<%d, 2, 0, 0>", ST); hipLaunchKernelGGL((esa_apply_mfma_kernel<ST, 2>), dim3(grid), dim3(256), 0, st, k); break;
         default: return ESR_ERR_UNSUPPORTED;
     }
     return esr_check_launch("esa_apply_mfma_kernel launch");
+}
+
+// 16-bit rounding on the host (RNE), as the kernels' conversions
+static unsigned short host_to16(float f, int storage)
+{
+    if (storage == ESR_STORE_BF16) {
+        unsigned u;
+        memcpy(&u, &f, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    }
+    const _Float16 h = (_Float16)f;
+    unsigned short r;
+    memcpy(&r, &h, 2);
+    return r;
+}
+static float host_from16(unsigned short h, int storage)
+{
+    if (storage == ESR_STORE_BF16) {
+        const unsigned u = (unsigned)h << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    }
+    _Float16 v;
+    memcpy(&v, &h, 2);
+    return (float)v;
 }
 
 // ---- depthwise 3x3, zero padding, fused residual / activation -------------------------------------
@@ -647,6 +805,61 @@ int esr_maxpool7s3_f32(const esr_esa_desc* d, void* hip_stream)
     return esr_check_launch("maxpool7s3_kernel launch");
 }
 
+int esr_esa_apply_post_supported(int c, int cout0, int cout1)
+{
+    if (c <= 0 || cout0 <= 0 || cout1 < 0) return 0;
+    return esa_post_variant((esr_round_up(c, 4) + 31) / 32, (cout0 + 31) / 32, (cout1 + 31) / 32) ? 1 : 0;
+}
+
+size_t esr_packed_apply_post_bytes(int cin, int cout0, int cout1, int storage)
+{
+    if (cin <= 0 || cout0 <= 0 || cout1 < 0 || (storage != ESR_STORE_BF16 && storage != ESR_STORE_F16)) return 0;
+    const int np = (esr_round_up(cin, 4) + 31) / 32, nt0 = 2 * ((cout0 + 31) / 32), nt1 = 2 * ((cout1 + 31) / 32);
+    const int lo1 = storage == ESR_STORE_BF16 ? 2 : 1;
+    return (size_t)(2 * nt0 * np + lo1 * nt1 * nt0) * 1024 + (size_t)(nt0 + nt1) * 64;
+}
+
+int esr_pack_apply_post(const float* w0, const float* b0, const float* w1, const float* b1, int cin, int cout0, int cout1,
+                        int storage, void* out, size_t out_bytes)
+{
+    const size_t need = esr_packed_apply_post_bytes(cin, cout0, cout1, storage);
+    if (!need || !w0 || !out || out_bytes < need || (cout1 > 0 && !w1)) return ESR_ERR_BAD_ARG;
+    const int np = (esr_round_up(cin, 4) + 31) / 32, nt0 = 2 * ((cout0 + 31) / 32), nt1 = 2 * ((cout1 + 31) / 32);
+    const int lo1 = storage == ESR_STORE_BF16 ? 2 : 1;
+    unsigned short* img = static_cast<unsigned short*>(out);
+    // row i of tile t <-> channel 32 (t >> 1) + 8 (i >> 2) + 4 (t & 1) + (i & 3): a lane's results of a tile pair are 8 consecutive channels
+    auto chan = [](int t, int i) { return 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3); };
+    for (int lo = 0; lo < 2; ++lo)
+        for (int t = 0; t < nt0; ++t)
+            for (int q = 0; q < np; ++q)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int oc = chan(t, l & 15), ic = 32 * q + 8 * (l >> 4) + j;
+                        const float w = (oc < cout0 && ic < cin) ? w0[(size_t)oc * cin + ic] : 0.f;
+                        const unsigned short hi = host_to16(w, storage);
+                        img[((size_t)((lo * nt0 + t) * np + q) * 64 + l) * 8 + j] = lo ? host_to16(w - host_from16(hi, storage), storage) : hi;
+                    }
+    unsigned short* img1 = img + (size_t)2 * nt0 * np * 512;
+    for (int lo = 0; lo < lo1; ++lo)
+        for (int t = 0; t < nt1; ++t)
+            for (int T = 0; T < nt0; ++T)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        // k slot (kq, j): the high (j < 4) / low (j >= 4) part of the lane's value j & 3 of post 0's tile T
+                        const int oc = chan(t, l & 15), ic = chan(T, 4 * (l >> 4) + (j & 3));
+                        const float w = (oc < cout1 && ic < cout0) ? w1[(size_t)oc * cout0 + ic] : 0.f;
+                        const unsigned short hi = host_to16(w, storage);
+                        const unsigned short v = lo == 0 ? hi : (j < 4 ? host_to16(w - host_from16(hi, storage), storage) : (unsigned short)0);
+                        img1[((size_t)((lo * nt1 + t) * nt0 + T) * 64 + l) * 8 + j] = (storage == ESR_STORE_F16 && j >= 4) ? (unsigned short)0 : v;
+                    }
+    float* bias = reinterpret_cast<float*>(img1 + (size_t)lo1 * nt1 * nt0 * 512);
+    for (int t = 0; t < nt0; ++t)
+        for (int i = 0; i < 16; ++i) bias[t * 16 + i] = (b0 && chan(t, i) < cout0) ? b0[chan(t, i)] : 0.f;
+    for (int t = 0; t < nt1; ++t)
+        for (int i = 0; i < 16; ++i) bias[(nt0 + t) * 16 + i] = (b1 && chan(t, i) < cout1) ? b1[chan(t, i)] : 0.f;
+    return ESR_OK;
+}
+
 int esr_esa_apply_f32(const esr_esa_desc* d, void* hip_stream)
 {
     if (!d || !d->x.ptr || !d->y.ptr || !d->c1 || !d->c3 || !d->w0 || !d->w1) return ESR_ERR_BAD_ARG;
@@ -671,14 +884,50 @@ int esr_esa_apply_f32(const esr_esa_desc* d, void* hip_stream)
     k.sw = (float)d->w_lo / (float)d->w;
     const long long npix = (long long)d->n * d->h * d->w;
     if (npix >= 2147483647LL) return ESR_ERR_UNSUPPORTED;                 // 32-bit pixel indices inside the kernels
+    // post chain (ABI v8)
+    int np0 = 0, np1 = 0;
+    k.pimg = nullptr; k.pres = nullptr; k.pout0 = nullptr; k.pout1 = nullptr;
+    k.pres_pitch = k.pres_coff = k.pout0_pitch = k.pout0_coff = k.pout1_pitch = k.pout1_coff = 0;
+    k.p0_c8 = k.p1_c8 = 0; k.p0_act = k.p1_act = ESR_ACT_NONE; k.p0_res = 0; k.p0_slope = k.p1_slope = 1.f; k.skip_y = 0;
+    if (d->post_w) {
+        if (d->storage == ESR_STORE_F32) return ESR_ERR_UNSUPPORTED;
+        const esr_esa_post& p0 = d->post[0];
+        const esr_esa_post& p1 = d->post[1];
+        if (p0.cout <= 0 || p0.cout > 64 || p1.cout < 0 || p1.cout > 32) return ESR_ERR_UNSUPPORTED;
+        auto view_ok = [](const esr_view& v, int c8) { return v.ptr && !(v.pitch & 7) && !(v.coff & 7) && v.coff + c8 <= v.pitch; };
+        auto act_ok = [](int a) { return a == ESR_ACT_NONE || a == ESR_ACT_LRELU || a == ESR_ACT_RELU || a == ESR_ACT_GELU; };
+        k.p0_c8 = esr_round_up(p0.cout, 8);
+        if (!view_ok(p0.out, k.p0_c8) || !act_ok(p0.act)) return ESR_ERR_BAD_ARG;
+        if (p0.res_mode != ESR_RES_NONE && p0.res_mode != ESR_RES_PRE_ACT) return ESR_ERR_UNSUPPORTED;
+        if (p0.res_mode == ESR_RES_PRE_ACT && !view_ok(p0.res, k.p0_c8)) return ESR_ERR_BAD_ARG;
+        np0 = (p0.cout + 31) / 32;
+        k.pimg = static_cast<const unsigned short*>(d->post_w);
+        k.pout0 = p0.out.ptr; k.pout0_pitch = p0.out.pitch; k.pout0_coff = p0.out.coff;
+        k.p0_res = p0.res_mode == ESR_RES_PRE_ACT;
+        if (k.p0_res) { k.pres = p0.res.ptr; k.pres_pitch = p0.res.pitch; k.pres_coff = p0.res.coff; }
+        k.p0_act = p0.act;
+        k.p0_slope = p0.act == ESR_ACT_LRELU ? p0.slope : (p0.act == ESR_ACT_RELU ? 0.f : 1.f);
+        if (p1.cout > 0) {
+            k.p1_c8 = esr_round_up(p1.cout, 8);
+            if (!view_ok(p1.out, k.p1_c8) || !act_ok(p1.act) || p1.res_mode != ESR_RES_NONE) return ESR_ERR_BAD_ARG;
+            np1 = (p1.cout + 31) / 32;
+            k.pout1 = p1.out.ptr; k.pout1_pitch = p1.out.pitch; k.pout1_coff = p1.out.coff;
+            k.p1_act = p1.act;
+            k.p1_slope = p1.act == ESR_ACT_LRELU ? p1.slope : (p1.act == ESR_ACT_RELU ? 0.f : 1.f);
+        }
+        k.skip_y = d->skip_y ? 1 : 0;
+        if (!esa_post_variant((cp4 + 31) / 32, np0, np1)) return ESR_ERR_UNSUPPORTED;
+    } else if (d->skip_y) {
+        return ESR_ERR_BAD_ARG;
+    }
     const size_t lds = ((size_t)FP * FP + FP + (((size_t)FP * cp4 + cp4 + 3) & ~(size_t)3) + 16 * FP) * sizeof(float);
     const long long ngroups = (npix + 15) / 16;
     const unsigned grid = (unsigned)(ngroups < 8192 ? ngroups : 8192);        // 256 CUs x 8 blocks x 4 rounds
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     switch (d->storage) {
         case ESR_STORE_F32: esr_note_kernel("esa_apply_kernel<0>"); hipLaunchKernelGGL(esa_apply_kernel<ESR_STORE_F32>, dim3(grid), dim3(256), lds, st, k); break;
-        case ESR_STORE_BF16: return launch_esa_mfma<ESR_STORE_BF16>(k, st);
-        case ESR_STORE_F16: return launch_esa_mfma<ESR_STORE_F16>(k, st);
+        case ESR_STORE_BF16: return launch_esa_mfma<ESR_STORE_BF16>(k, np0, np1, st);
+        case ESR_STORE_F16: return launch_esa_mfma<ESR_STORE_F16>(k, np0, np1, st);
         default: return ESR_ERR_BAD_ARG;
     }
     return esr_check_launch("esa_apply_kernel launch");

@@ -17,3 +17,22 @@ int esr_s16_block_waves(const esr_conv_desc* d);      // 4: two 4-wave blocks pe
 
 // esr_wino.hip: Winograd F(2x2, 3x3) fp32 convolution (called by esr_conv2d_f32 when d->wino_wpacked is set and the shape qualifies)
 int esr_conv2d_wino(const esr_conv_desc* d, void* hip_stream);
+
+#ifdef __HIPCC__
+// GELU of the 16-bit storage modes (the scalar definition conv_s16_kernel's packed version follows bit for bit; accuracy and
+// derivation: esr_s16.hip, tools/fit_gelu.py)
+__device__ __forceinline__ float esr_gelu16(float x)
+{
+    const float xc = fminf(fmaxf(x, -4.f), 4.f);
+    const float t = xc * xc;
+    float p = -1.580786198e-09f;
+    p = fmaf(p, t, 1.217111051e-07f);
+    p = fmaf(p, t, -4.100866386e-06f);
+    p = fmaf(p, t, 8.066739505e-05f);
+    p = fmaf(p, t, -1.048204400e-03f);
+    p = fmaf(p, t, 9.664874174e-03f);
+    p = fmaf(p, t, -6.617537882e-02f);
+    p = fmaf(p, t, 3.988475079e-01f);
+    return fmaxf(x, -4.f) * fmaf(xc, p, 0.5f);
+}
+#endif

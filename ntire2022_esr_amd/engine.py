@@ -138,6 +138,31 @@ def pack_post_s16(weight, bias, compute):
     return out
 
 
+def pack_apply_post(w0, b0, w1, b1, store):
+    """Weights of the 1x1 chain riding in esr_esa_apply_f32's launch (esr_esa_desc.post_w): w0 [cout0, cin(, 1, 1)] applied to the
+    apply result, w1 [cout1, cout0(, 1, 1)] (or None) applied to w0's result -> esr_pack_apply_post blob."""
+    lib = L.lib()
+    w0 = w0.detach().to("cpu", torch.float32).reshape(w0.shape[0], -1).contiguous()
+    cout0, cin = w0.shape
+    b0 = None if b0 is None else b0.detach().to("cpu", torch.float32).contiguous()
+    cout1 = 0
+    if w1 is not None:
+        w1 = w1.detach().to("cpu", torch.float32).reshape(w1.shape[0], -1).contiguous()
+        cout1 = w1.shape[0]
+        if w1.shape[1] != cout0:
+            raise L.EsrError("pack_apply_post: w1 must take w0's outputs")
+        b1 = None if b1 is None else b1.detach().to("cpu", torch.float32).contiguous()
+    st = L.STORE[store]
+    nbytes = lib.esr_packed_apply_post_bytes(cin, cout0, cout1, st)
+    if not nbytes:
+        raise L.EsrError("pack_apply_post: unsupported shape / storage")
+    out = torch.empty((nbytes + 3) // 4, dtype=torch.float32)
+    L.check(lib.esr_pack_apply_post(_ptr(w0), _ptr(b0) if b0 is not None else None, _ptr(w1) if w1 is not None else None,
+                                    _ptr(b1) if (w1 is not None and b1 is not None) else None, cin, cout0, cout1, st, _ptr(out), nbytes),
+            "esr_pack_apply_post")
+    return out
+
+
 def unpack_conv_s16(blob, cin, cout, k, compute, cin_map=None, cin_phys=None):
     """EFFECTIVE fp32 weights (what the 16-bit kernel multiplies by) + bias of a pack_conv_s16 blob."""
     lib = L.lib()
@@ -332,9 +357,13 @@ class Plan:
         self.ops.append(dict(kind="lowres", src=c1, pooled=pooled, dst=dst, f=f, w=s2, layers=layers, replaces=sub,
                              cin=f, cout=f, k=3))
 
-    def esa_apply(self, wf, w4, x, c1, c3, dst, c, f):
-        """y = x * sigmoid(conv4(bilinear(c3) + conv_f(c1)));  two nn.Conv2d calls of the reference."""
-        self.ops.append(dict(kind="apply", wf=wf, w4=w4, x=x, c1=c1, c3=c3, dst=dst, c=c, f=f))
+    def esa_apply(self, wf, w4, x, c1, c3, dst, c, f, post=None, skip_y=False):
+        """y = x * sigmoid(conv4(bilinear(c3) + conv_f(c1)));  two nn.Conv2d calls of the reference.
+        post (16-bit plans): [dict(w=<1x1 path>, dst=<view>, cout, act, slope, res=<view>|None, linear=bool), ...] -- one or two 1x1
+        convolutions evaluated in the same launch (esr_esa_desc.post[]): the first on y as stored, the second on the first's fp32
+        result; their weights are ONE blob `<post[0].w>#apost` (engine.pack_apply_post, packed by the network).  skip_y: y itself
+        is not stored (nothing but the chain reads it)."""
+        self.ops.append(dict(kind="apply", wf=wf, w4=w4, x=x, c1=c1, c3=c3, dst=dst, c=c, f=f, post=post, skip_y=skip_y))
 
     @staticmethod
     def _addr(buf, base):
@@ -410,6 +439,15 @@ class Plan:
                     e.c3 = ctypes.c_void_p(self._addr(o["c3"], base))
                     e.w0 = ctypes.c_void_p(weights[o["wf"]].data_ptr())
                     e.w1 = ctypes.c_void_p(weights[o["w4"]].data_ptr())
+                    if o.get("post"):
+                        e.post_w = ctypes.c_void_p(weights[o["post"][0]["w"] + "#apost"].data_ptr())
+                        e.skip_y = 1 if o.get("skip_y") else 0
+                        for k_, t in enumerate(o["post"]):
+                            pp = e.post[k_]
+                            pp.cout, pp.act, pp.slope = t["cout"], t.get("act", L.ACT_NONE), t.get("slope", 0.05)
+                            pp.out = self._view(t["dst"], base)
+                            if t.get("res") is not None:
+                                pp.res_mode, pp.res = L.RES_PRE_ACT, self._view(t["res"], base)
                 else:
                     op.kind = L.OP_CONV3X3S2 if o["kind"] == "s2" else L.OP_MAXPOOL7S3
                     e.h, e.w = o["src"].h, o["src"].w
@@ -976,7 +1014,13 @@ class HipSRModel(nn.Module):
                 kern = "esa_apply_kernel"
                 flops = 2.0 * plan.npix * (o["f"] * o["f"] + o["f"] * o["c"])
                 rd = float(plan.npix * es * (o["c"] + o["f"]) + plan.n * o["c3"].h * o["c3"].w * o["f"] * 4)
-                wr = float(plan.npix * es * o["c"])
+                wr = 0.0 if o.get("skip_y") else float(plan.npix * es * o["c"])
+                kin = o["c"]
+                for t in o.get("post") or ():       # 1x1 convolutions in the same launch: their flops, residual reads and stores
+                    flops += 2.0 * plan.npix * kin * t["cout"]
+                    rd += float(plan.npix * es * t["cout"]) if t.get("res") is not None else 0.0
+                    wr += float(plan.npix * es * t["cout"])
+                    kin = t["cout"]
             # flops = ALGORITHMIC (direct-convolution) flops; flops_exec = what the matrix cores execute: Winograd F(2x2,3x3) does 16
             # multiplications per 2x2 outputs where the direct form does 36
             fexec = flops * (16.0 / 36.0) if (kind == "conv" and wino) else flops
@@ -1042,8 +1086,13 @@ class HipSRModel(nn.Module):
             return [(o["cin"], o["cout"], o["k"], npix, o["act"])]
         if o["kind"] == "s2":
             return [(o["f"], o["f"], 3, plan.n * o["dst"].h * o["dst"].w, L.ACT_NONE)]
-        if o["kind"] == "apply":   # conv_f (f->f) and conv4 (f->c), both full resolution
-            return [(o["f"], o["f"], 1, plan.npix, L.ACT_NONE), (o["f"], o["c"], 1, plan.npix, L.ACT_NONE)]
+        if o["kind"] == "apply":   # conv_f (f->f) and conv4 (f->c), both full resolution (+ the 1x1s riding in the launch)
+            r = [(o["f"], o["f"], 1, plan.npix, L.ACT_NONE), (o["f"], o["c"], 1, plan.npix, L.ACT_NONE)]
+            kin = o["c"]
+            for t in o.get("post") or ():
+                r.append((t.get("cin_alg", kin), t.get("cout_alg", t["cout"]), 1, plan.npix, t.get("act", L.ACT_NONE)))
+                kin = t["cout"]
+            return r
         return []
 
     def workspace_bytes(self, n, h, w, c=3):

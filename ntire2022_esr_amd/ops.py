@@ -259,12 +259,15 @@ def channel_attention(x, w1, b1, w2, b2, *, contrast=False, nchw=False, out=None
     return y
 
 
-def esa_apply(x, c1, c3, wf, bf, w4, b4, *, out=None):
+def esa_apply(x, c1, c3, wf, bf, w4, b4, *, out=None, post=None, skip_y=False):
     """ESA's full-resolution tail in one launch (esr_esa_apply_f32): y = x * sigmoid(conv4(bilinear(c3 -> HxW) + conv_f(c1)))
     (models/rfdn_baseline/block.py:124-129).  x: NHWC [N,H,W,pitch] (fp32 / bf16 / fp16 storage), c channels = w4.shape[0];
     c1: NHWC [N,H,W,16] of the same dtype (conv1's output, f = wf.shape[0] <= 16 channels, pads zero); c3: fp32 NHWC [N,h_lo,w_lo,16];
-    wf [f,f(,1,1)], w4 [c,f(,1,1)]."""
-    from .engine import pack_dense
+    wf [f,f(,1,1)], w4 [c,f(,1,1)].
+    post (16-bit storage): one or two dicts(weight [cout, cin(,1,1)], bias, act, slope, res) -- 1x1 convolutions evaluated in the same
+    launch (esr_esa_desc.post[]): the first on y as stored (+ res, NHWC of x's dtype), the second on the first's fp32 result.  Returns
+    (y, [out0(, out1)]) then; skip_y: y is not stored."""
+    from .engine import pack_apply_post, pack_dense
     if not x.is_cuda:
         raise L.EsrError("esa_apply: tensors must live on the GPU; there is no CPU fallback")
     n, h, w, pitch = x.shape
@@ -277,9 +280,25 @@ def esa_apply(x, c1, c3, wf, bf, w4, b4, *, out=None):
     d.storage = L.STORE[_STORE_OF[x.dtype]]
     d.x, d.y = _view(x), _view(y)
     d.c1, d.c3, d.w0, d.w1 = c1.data_ptr(), c3.data_ptr(), keep[0].data_ptr(), keep[1].data_ptr()
+    outs = []
+    if post:
+        p0, p1 = post[0], (post[1] if len(post) > 1 else None)
+        keep.append(pack_apply_post(p0["weight"], p0.get("bias"), None if p1 is None else p1["weight"], None if p1 is None else p1.get("bias"),
+                                    _STORE_OF[x.dtype]).to(x.device))
+        d.post_w = keep[-1].data_ptr()
+        d.skip_y = 1 if skip_y else 0
+        for k, t in enumerate(post):
+            co = t["weight"].shape[0]
+            o = torch.zeros(n, h, w, (co + 7) // 8 * 8, dtype=x.dtype, device=x.device)
+            outs.append(o)
+            pp = d.post[k]
+            pp.cout, pp.act, pp.slope = co, t.get("act", L.ACT_NONE), t.get("slope", 0.05)
+            pp.out = _view(o)
+            if t.get("res") is not None:
+                pp.res_mode, pp.res = L.RES_PRE_ACT, _view(t["res"])
     stream = torch.cuda.current_stream(x.device).cuda_stream
     L.check(L.lib().esr_esa_apply_f32(ctypes.byref(d), ctypes.c_void_p(stream)), "esr_esa_apply_f32")
-    return y
+    return (y, outs) if post else y
 
 
 # ---- torch.library operators over the kernels --------------------------------------------------------------------------------

@@ -91,10 +91,12 @@ class RFDN(HipSRModel):
         # 16-bit modes: block 1's first distillation conv (c1_d of fea) rides in the head convolution's epilogue
         head_d = plan.esize == 2 and fused_post
         plan.conv('fea_conv', INPUT, fea, self.in_nc, nf, post=dict(w='B1.c1_d', dst=cs(0), cout=dc, act=L.ACT_LRELU) if head_d else None)
+        # ... and the other blocks' in the ESA apply launch that produces their input (esr_esa_desc.post[])
+        apply_d = head_d and bool(L.lib().esr_esa_apply_post_supported(nf, dc, 0))
         cur = fea
         for k in range(1, 5):
             b = f'B{k}.'
-            if not (head_d and k == 1):
+            if not ((head_d and k == 1) or (apply_d and k > 1)):
                 plan.conv(b + 'c1_d', cur, cs(0), nf, dc, k=1, **act)
             if fused_post:
                 # the distillation conv of r_j rides in the epilogue of the conv that produces r_j (block.py:150-160)
@@ -127,7 +129,8 @@ class RFDN(HipSRModel):
                                 [dict(kind=0, act=L.ACT_RELU, w=b + 'esa.conv_max'), dict(kind=0, act=L.ACT_RELU, w=b + 'esa.conv3'),
                                  dict(kind=0, act=L.ACT_NONE, w=b + 'esa.conv3_')])
             out = bcat.seg(k - 1) if bplanar else bcat[(k - 1) * P:k * P]
-            plan.esa_apply(b + 'esa.conv_f', b + 'esa.conv4', v, c1, lb, out, nf, f)
+            nxt_d = [dict(w=f'B{k + 1}.c1_d', dst=cs(0), cout=dc, act=L.ACT_LRELU, slope=0.05)] if (apply_d and k < 4) else None
+            plan.esa_apply(b + 'esa.conv_f', b + 'esa.conv4', v, c1, lb, out, nf, f, post=nxt_d)
             cur = out
         plan.conv('c.0', bcat, v, 4 * P, nf, k=1, cin_alg=4 * nf, **act)
         plan.conv('LR_conv', v, r1, nf, nf, res=fea, res_mode=L.RES_PRE_ACT)
@@ -139,6 +142,12 @@ class RFDN(HipSRModel):
         return cin_map
 
     def _extra_pack(self, packed, device):
+        if self._store() != "f32":               # c1_d of blocks 2..4 as the post of the previous block's ESA apply launch
+            from .engine import pack_apply_post
+            if L.lib().esr_esa_apply_post_supported(self.nf, self.dc, 0):
+                for k in range(2, 5):
+                    leaf = self._leaf(f'B{k}.c1_d')
+                    packed[f'B{k}.c1_d#apost'] = pack_apply_post(leaf.weight, leaf.bias, None, None, self._store()).to(device)
         if not self.esa_conv_f:                  # SFDN: c3 + c1_  ==  c3 + conv_f(c1_) with conv_f = identity
             import torch
             from .engine import pack_dense

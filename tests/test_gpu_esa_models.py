@@ -97,6 +97,68 @@ def test_esa_apply(c, f, hw, lo):
     assert torch.all(yc[..., :8] == 5.0) and torch.all(yc[..., 8 + cp4:] == 5.0)
 
 
+@pytest.mark.parametrize("store,c,c0,c1,act0,act1,res,skip", [
+    ("bf16", 50, 25, 0, "lrelu", None, False, False),          # RFDN: y + the next block's c1_d
+    ("f16", 48, 48, 24, "none", "gelu", True, True),            # BSRN: conv_out + block input, then the next block's c1_d; y not stored
+    ("bf16", 48, 48, 24, "none", "gelu", True, True),
+    ("f16", 48, 48, 0, "none", None, True, True),               # BSRN's last block
+])
+def test_esa_apply_post_chain(store, c, c0, c1, act0, act1, res, skip):
+    """esr_esa_desc.post[]: 1x1 convolutions riding in the ESA apply launch, against ATen on the values the launch stores
+    (post 0 reads y as stored; post 1 reads post 0's fp32 result)."""
+    from ntire2022_esr_amd import _lib as L
+    from ntire2022_esr_amd import ops
+    dt = torch.bfloat16 if store == "bf16" else torch.float16
+    f, hw, lo = 12, (37, 45), (5, 7)
+    g = torch.Generator().manual_seed(c + c0 + c1)
+    x = torch.randn(2, c, *hw, generator=g) * 3
+    c1_ = torch.randn(2, f, *hw, generator=g)
+    c3 = torch.randn(2, f, *lo, generator=g)
+    wf, bf = torch.randn(f, f, generator=g) * 0.3, torch.randn(f, generator=g)
+    w4, b4 = torch.randn(c, f, generator=g) * 0.3, torch.randn(c, generator=g)
+    w0, b0 = torch.randn(c0, c, generator=g) * 0.2, torch.randn(c0, generator=g)
+    w1, b1 = (torch.randn(c1, c0, generator=g) * 0.2, torch.randn(c1, generator=g)) if c1 else (None, None)
+    r = torch.randn(2, c0, *hw, generator=g)
+
+    def nhwc(t, pitch):
+        o = torch.zeros(t.shape[0], t.shape[2], t.shape[3], pitch)
+        o[..., :t.shape[1]] = t.permute(0, 2, 3, 1)
+        return o.to(dt).to(DEV)
+    pitch = (c + 15) // 16 * 16
+    xg, c1g, rg = nhwc(x, pitch), nhwc(c1_, 16), nhwc(r, (c0 + 15) // 16 * 16)
+    c3g = _nhwc16(c3)
+    acts = {"none": L.ACT_NONE, "lrelu": L.ACT_LRELU, "gelu": L.ACT_GELU}
+    post = [dict(weight=w0, bias=b0, act=acts[act0], slope=0.05, res=rg if res else None)]
+    if c1:
+        post.append(dict(weight=w1, bias=b1, act=acts[act1], slope=0.05))
+    ysent = torch.full((2, hw[0], hw[1], pitch), 7.0, dtype=dt, device=DEV)
+    y, outs = ops.esa_apply(xg, c1g, c3g, wf, bf, w4, b4, out=ysent, post=post, skip_y=skip)
+    # reference on the rounded inputs; y as the kernel stores it = the plain launch's result (tested above), bit for bit
+    yplain = ops.esa_apply(xg, c1g, c3g, wf, bf, w4, b4)
+    if skip:
+        assert torch.all(y == 7.0)
+    else:
+        assert torch.equal(y[..., :c], yplain[..., :c])
+    fa = {"none": lambda t: t, "lrelu": lambda t: F.leaky_relu(t, 0.05), "gelu": F.gelu}
+    yin = yplain.float().cpu()[..., :c].permute(0, 3, 1, 2).double()
+    v0 = F.conv2d(yin, w0.double()[:, :, None, None], b0.double())
+    if res:
+        v0 = v0 + rg.float().cpu()[..., :c0].permute(0, 3, 1, 2).double()
+    v0 = fa[act0](v0)
+    eps = 2.0 ** -8 if store == "bf16" else 2.0 ** -11
+    got0 = outs[0].float().cpu()[..., :c0].permute(0, 3, 1, 2).double()
+    # one rounding of the stored result (+ the 16-bit GELU polynomial's 1.3e-4)
+    assert float((got0 - v0).abs().max()) <= eps * float(v0.abs().max()) + 3e-4
+    assert torch.all(outs[0].float().cpu()[..., c0:] == 0)
+    if c1:
+        v1 = fa[act1](F.conv2d(v0, w1.double()[:, :, None, None], b1.double()))
+        got1 = outs[1].float().cpu()[..., :c1].permute(0, 3, 1, 2).double()
+        # post 1 sees post 0's fp32 result: hi + lo for bf16 (16 bits), the fp16 high part only for fp16 (11 bits)
+        tol_in = (2.0 ** -11) * float(v0.abs().max()) * float(w1.abs().sum(dim=1).max())
+        assert float((got1 - v1).abs().max()) <= eps * float(v1.abs().max()) + 2 * tol_in + 3e-4     # (fp16: post 1 weights carry 11 bits too)
+        assert torch.all(outs[1].float().cpu()[..., c1:] == 0)
+
+
 def _model(name):
     from ntire2022_esr_amd import RFDN, RLFN_cut
     m = {"rfdn_baseline": RFDN, "team04_rlfn": lambda: RLFN_cut(in_nc=3, out_nc=3)}[name]()

@@ -23,6 +23,9 @@
 #include "esr_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 lo_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 lo_f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -147,6 +150,162 @@ __global__ __launch_bounds__(256) void esa_s2pool_kernel(const void* __restrict_
                     const f32x4 v = *reinterpret_cast<const f32x4*>(sc + ((3 * py + ky) * CT + 3 * pxx + kx) * FP + qq * 4);
                     m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
                 }
+            *reinterpret_cast<f32x4*>(y + (((size_t)n * H3 + gy) * W3 + gx) * FP + qq * 4) = m;
+        }
+    }
+}
+
+// ---- 16-bit storage: conv2 on the 16-bit matrix cores, pooling out of the accumulators -------------------------------------------
+// Round 3 (second version).  At batch 32 the kernel above took 115 us per launch (RLFN: 13 % of a step) for 67 MB of input: its fp32
+// MFMAs alone are 32 us of matrix-pipe time (16x16x4: 36 per 16 outputs, one dependent chain per wave), the pooling phase ran on 64
+// of 256 threads with 49 LDS reads each, and 60 KB of LDS allowed two blocks per CU.  Here the patch stays as stored (bf16 / fp16):
+//   * B operand of v_mfma_f32_16x16x32 = a TAP PAIR x 16 channels, read as stored: lane (j, kq) takes the 16 bytes of channel half
+//     kq & 1 of pixel 2j + kx of tap 2q + (kq >> 1) -- ONE ds_read_b128 per pair, 5 pairs per 16 outputs (the tenth tap slot has
+//     zero weights).  The patch is split by column parity ([row][x & 1][x >> 1][32 B]) so that the stride-2 pixels of a tap are
+//     consecutive 32-byte slots: conflict-free without padding (the 16 lanes of an LDS group cover 16 different 16-byte slots).
+//   * A operand = the fp32 weights split into 16-bit parts at block start (bf16: hi + mid + lo = 24 mantissa bits, fp16: hi + lo =
+//     22), so the products are those of the fp32 weights: 15 / 10 MFMAs of 16 cycles per 16 outputs instead of 36 of 32 cycles.
+//   * four independent accumulators per wave (rows w, w+4, w+8, w+12);
+//   * the horizontal 7-window maximum is taken in the D fragments (lane j = conv2 column j: three DPP row shifts), only the 4 pooled
+//     columns of each row go to LDS (4 KB), the vertical maximum reads 7 rows from there.  max() is exact: same result as above.
+// 40 KB of LDS: four blocks per CU.
+constexpr int S16_HALF = 17 * 32;                        // one column-parity half of a patch row: 17 pixels x 16 channels x 2 B
+constexpr int S16_ROW = 2 * S16_HALF;
+constexpr int S16_PATCH = IT * S16_ROW;                  // 35 904 B
+constexpr int S16_ITEMS = IT * IT * 2;                   // 16-byte items of the patch
+constexpr int S16_PER = (S16_ITEMS + 255) / 256;         // 9 per thread
+
+template <int ST>
+__device__ __forceinline__ f32x4 lo_mfma32(i32x4 a, i32x4 b, f32x4 c)
+{
+    if (ST == ESR_STORE_BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lo_bf16x8, a), __builtin_bit_cast(lo_bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(lo_f16x8, a), __builtin_bit_cast(lo_f16x8, b), c, 0, 0, 0);
+}
+
+template <int ST>
+__device__ __forceinline__ unsigned lo_to16(float v, float& back)
+{
+    if (ST == ESR_STORE_BF16) {
+        const unsigned short h = __builtin_bit_cast(unsigned short, (__bf16)v);
+        back = __builtin_bit_cast(float, (unsigned)h << 16);
+        return h;
+    }
+    const _Float16 h = (_Float16)v;
+    back = (float)h;
+    return __builtin_bit_cast(unsigned short, h);
+}
+
+template <int CTRL>
+__device__ __forceinline__ f32x4 lo_max_shl(f32x4 m)
+{
+    // lane i takes max(own, lane i + n of its row of 16); lanes whose source lies outside the row keep their value
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float f = m[e];                                                  // (a copy: __builtin_bit_cast of the element lvalue m[e] reads element 0)
+        const int own = __builtin_bit_cast(int, f);
+        r[e] = fmaxf(f, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(own, own, CTRL, 0xf, 0xf, false)));
+    }
+    return r;
+}
+
+template <int ST>
+__global__ __launch_bounds__(256) void esa_s2pool16_kernel(const void* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
+                                                           int H, int W, int H3, int W3, int tiles_x, int tiles_y)
+{
+    constexpr int NPART = ST == ESR_STORE_BF16 ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) char sin[S16_PATCH];
+    __shared__ __attribute__((aligned(16))) float hb[CT * PT * FP];           // horizontal maxima [conv2 row][pooled column][16]
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, kq = lane >> 4;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int n = t / tiles_y;
+    const int iy0 = 6 * PT * ty, ix0 = 6 * PT * tx;                            // first input pixel of the tile (2 x 3 x PT per tile)
+    // the patch: every load of the block in flight at once, rows of 1056 contiguous bytes.  Pixels past the image edge are read from
+    // the edge instead (clamped): they only reach conv2 outputs outside the map, which no valid pooling window contains.
+    const char* const xb = static_cast<const char*>(x) + (size_t)n * H * W * (FP * 2);
+    uint4 v[S16_PER];
+#pragma unroll
+    for (int i = 0; i < S16_PER; ++i) {
+        int it = threadIdx.x + 256 * i;
+        it = it < S16_ITEMS ? it : S16_ITEMS - 1;
+        const int row = it / (2 * IT), rem = it - row * (2 * IT);
+        int gy = iy0 + row, gx = ix0 + (rem >> 1);
+        gy = gy < H ? gy : H - 1; gx = gx < W ? gx : W - 1;
+        v[i] = *reinterpret_cast<const uint4*>(xb + ((size_t)gy * W + gx) * (FP * 2) + (rem & 1) * 16);
+    }
+    // A fragments: lane (cout j, kq) holds k = 8 kq .. 8 kq + 7 of the pair's 32: tap 2q + (kq >> 1), channels 8 (kq & 1) + e
+    i32x4 wa[5][NPART];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int tap = 2 * q + (kq >> 1);
+        unsigned short part[NPART][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float w = tap < 9 ? wp[(tap * FP + 8 * (kq & 1) + e) * FP + j] : 0.f;
+#pragma unroll
+            for (int pp = 0; pp < NPART; ++pp) {
+                float back;
+                part[pp][e] = (unsigned short)lo_to16<ST>(w, back);
+                w -= back;
+            }
+        }
+#pragma unroll
+        for (int pp = 0; pp < NPART; ++pp)
+#pragma unroll
+            for (int dw = 0; dw < 4; ++dw) wa[q][pp][dw] = (int)((unsigned)part[pp][2 * dw] | ((unsigned)part[pp][2 * dw + 1] << 16));
+    }
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(wp + 9 * FP * FP + 4 * kq);
+#pragma unroll
+    for (int i = 0; i < S16_PER; ++i) {
+        const int it = threadIdx.x + 256 * i;
+        if (it < S16_ITEMS) {
+            const int row = it / (2 * IT), rem = it - row * (2 * IT), px = rem >> 1;
+            *reinterpret_cast<uint4*>(sin + row * S16_ROW + (px & 1) * S16_HALF + (px >> 1) * 32 + (rem & 1) * 16) = v[i];
+        }
+    }
+    __syncthreads();
+    int off[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        int tap = 2 * q + (kq >> 1);
+        tap = tap < 9 ? tap : 8;                                               // the tenth slot: zero weights, any finite data
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        off[q] = ky * S16_ROW + (kx & 1) * S16_HALF + (j + (kx >> 1)) * 32 + (kq & 1) * 16;
+    }
+    f32x4 acc[4] = {bias, bias, bias, bias};
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const i32x4 b = *reinterpret_cast<const i32x4*>(sin + 2 * (wv + 4 * r) * S16_ROW + off[q]);
+#pragma unroll
+            for (int pp = 0; pp < NPART; ++pp) acc[r] = lo_mfma32<ST>(wa[q][pp], b, acc[r]);
+        }
+    // D fragment: lane (j, kq) = channels 4 kq .. 4 kq + 3 of conv2 column j.  Window of pooled column p: columns 3p .. 3p + 6.
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        f32x4 m = lo_max_shl<0x101>(acc[r]);                                   // columns j .. j + 1
+        m = lo_max_shl<0x102>(m);                                              // j .. j + 3
+        m = lo_max_shl<0x103>(m);                                              // j .. j + 6
+        if (j == 0 || j == 3 || j == 6 || j == 9)
+            *reinterpret_cast<f32x4*>(hb + ((wv + 4 * r) * PT + j / 3) * FP + 4 * kq) = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < PT * PT * 4) {
+        const int qq = threadIdx.x & 3, pl = threadIdx.x >> 2;
+        const int py = pl / PT, pxx = pl - py * PT;
+        const int gy = PT * ty + py, gx = PT * tx + pxx;
+        if (gy < H3 && gx < W3) {
+            f32x4 m = *reinterpret_cast<const f32x4*>(hb + ((3 * py) * PT + pxx) * FP + qq * 4);
+#pragma unroll
+            for (int ky = 1; ky < 7; ++ky) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(hb + ((3 * py + ky) * PT + pxx) * FP + qq * 4);
+                m.x = fmaxf(m.x, u.x); m.y = fmaxf(m.y, u.y); m.z = fmaxf(m.z, u.z); m.w = fmaxf(m.w, u.w);
+            }
             *reinterpret_cast<f32x4*>(y + (((size_t)n * H3 + gy) * W3 + gx) * FP + qq * 4) = m;
         }
     }
@@ -320,8 +479,8 @@ extern "C" int esr_esa_lowres_f32(const esr_esa_lowres_desc* d, void* hip_stream
     float* pooled = static_cast<float*>(d->pooled);
     switch (d->storage) {
         case ESR_STORE_F32: esr_note_kernel("esa_s2pool_kernel<0>"); hipLaunchKernelGGL(esa_s2pool_kernel<ESR_STORE_F32>, grid, dim3(256), s2_lds<ESR_STORE_F32>(), st, d->x.ptr, w0, pooled, d->h, d->w, H2, W2, H3, W3, tx, ty); break;
-        case ESR_STORE_BF16: esr_note_kernel("esa_s2pool_kernel<1>"); hipLaunchKernelGGL(esa_s2pool_kernel<ESR_STORE_BF16>, grid, dim3(256), s2_lds<ESR_STORE_BF16>(), st, d->x.ptr, w0, pooled, d->h, d->w, H2, W2, H3, W3, tx, ty); break;
-        case ESR_STORE_F16: esr_note_kernel("esa_s2pool_kernel<2>"); hipLaunchKernelGGL(esa_s2pool_kernel<ESR_STORE_F16>, grid, dim3(256), s2_lds<ESR_STORE_F16>(), st, d->x.ptr, w0, pooled, d->h, d->w, H2, W2, H3, W3, tx, ty); break;
+        case ESR_STORE_BF16: esr_note_kernel("esa_s2pool16_kernel<1>"); hipLaunchKernelGGL(esa_s2pool16_kernel<ESR_STORE_BF16>, grid, dim3(256), 0, st, d->x.ptr, w0, pooled, d->h, d->w, H3, W3, tx, ty); break;
+        case ESR_STORE_F16: esr_note_kernel("esa_s2pool16_kernel<2>"); hipLaunchKernelGGL(esa_s2pool16_kernel<ESR_STORE_F16>, grid, dim3(256), 0, st, d->x.ptr, w0, pooled, d->h, d->w, H3, W3, tx, ty); break;
         default: return ESR_ERR_BAD_ARG;
     }
     int rc = esr_check_launch("esa_s2pool_kernel launch");

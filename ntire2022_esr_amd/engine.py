@@ -981,7 +981,7 @@ class HipSRModel(nn.Module):
                 npl = plan.n * dst.h * dst.w
                 h2, w2 = (src.h - 3) // 2 + 1, (src.w - 3) // 2 + 1
                 f = o["f"]
-                kern = f"esa_s2pool_kernel<{L.STORE[plan.store]}> + esa_chain_kernel"
+                kern = f"esa_s2pool{'16' if plan.store else ''}_kernel<{L.STORE[plan.store]}> + esa_chain_kernel"
                 flops = 2.0 * 9 * f * f * plan.n * h2 * w2
                 for ly in o["layers"]:
                     flops += 2.0 * npl * (9 * f * f if ly["kind"] == 0 else f * f + 9 * f)

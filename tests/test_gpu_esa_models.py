@@ -206,3 +206,46 @@ def test_vs_c_oracle_and_natural_image(name):
     u8 = np.uint8((y[0].clamp(0, dr).permute(1, 2, 0).numpy() * 255.0 / dr).round())
     crop = u8[400:528, 300:428]
     assert np.mean(crop != g["sr_u8_crop"]) < 2e-4 and np.max(np.abs(crop.astype(int) - g["sr_u8_crop"].astype(int))) <= 1
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("f,n,hw,layers", [(12, 1, (31, 30), 3), (16, 2, (64, 37), 1), (16, 3, (127, 150), 1), (12, 1, (339, 510), 3),
+                                           (16, 4, (256, 256), 2)])
+def test_esa_lowres_op(storage, f, n, hw, layers):
+    """esr_esa_lowres_f32 (conv2 s2 + max_pool2d(7, 3) + 1..3 3x3 layers, two launches with halo recompute) against ATen on the values
+    the kernel reads (the 16-bit storages hold the conv1 map as bf16 / fp16: the reference gets the same rounded map).  The 16-bit
+    kernels multiply by the fp32 weights split into 16-bit parts (bf16: 24 mantissa bits, fp16: 22), accumulate in fp32."""
+    from ntire2022_esr_amd import _lib as L
+    from ntire2022_esr_amd.engine import pack_dense
+    lib = L.lib()
+    g = torch.Generator().manual_seed(1000 * f + 10 * n + hw[0] + layers)
+    h, w = hw
+    x = torch.randn(n, f, h, w, generator=g)
+    st = {"f32": (0, torch.float32), "bf16": (1, torch.bfloat16), "f16": (2, torch.float16)}[storage]
+    xq = x.to(st[1]).float()
+    w2, b2 = torch.randn(f, f, 3, 3, generator=g) * 0.2, torch.randn(f, generator=g) * 0.1
+    ws = [(torch.randn(f, f, 3, 3, generator=g) * 0.2, torch.randn(f, generator=g) * 0.1) for _ in range(layers)]
+    ref = F.max_pool2d(F.conv2d(xq.double(), w2.double(), b2.double(), stride=2), 7, 3)
+    for i, (wl, bl) in enumerate(ws):
+        ref = F.conv2d(ref, wl.double(), bl.double(), padding=1)
+        if i + 1 < layers:
+            ref = F.relu(ref)
+    h3, w3 = ref.shape[2:]
+    xd = _nhwc16(xq).to(st[1]).contiguous()
+    blobs = [pack_dense(w2, b2, 16, 16).to(DEV)] + [pack_dense(wl, bl, 16, 16).to(DEV) for wl, bl in ws]
+    pooled = torch.full((n, h3, w3, 16), float("nan"), device=DEV)
+    y = torch.full((n, h3, w3, 16), float("nan"), device=DEV)
+    d = L.EsaLowresDesc()
+    d.n, d.h, d.w, d.f, d.storage, d.n_layers = n, h, w, f, st[0], layers
+    d.x = L.View(ctypes.c_void_p(xd.data_ptr()), 16, 0)
+    d.w_s2, d.pooled, d.y = blobs[0].data_ptr(), pooled.data_ptr(), y.data_ptr()
+    for i in range(layers):
+        d.layer[i].kind, d.layer[i].act, d.layer[i].w = 0, (L.ACT_RELU if i + 1 < layers else L.ACT_NONE), blobs[1 + i].data_ptr()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.esr_esa_lowres_f32(ctypes.byref(d), stream), "esr_esa_lowres_f32")
+    torch.cuda.synchronize()
+    got = y.cpu()[..., :f].permute(0, 3, 1, 2).double()
+    pref = F.max_pool2d(F.conv2d(xq.double(), w2.double(), b2.double(), stride=2), 7, 3)
+    perr = float((pooled.cpu()[..., :f].permute(0, 3, 1, 2).double() - pref).abs().max() / pref.abs().max())
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert perr < 2e-6 and err < 4e-6, (perr, err)

@@ -512,18 +512,17 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
             }
         }
     };
-    long long grp = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wv);
-    if (grp >= ngroups) return;
-    Grp cur, nxt;
-    fetch(grp, cur);
-    for (;;) {
-        const long long gn = grp + gstep;
-        const bool more = gn < ngroups;                          // wave-uniform
-        if (more) fetch(gn, nxt);
+    // One group per iteration, fetched and finished in the SAME iteration.  Until round 3 the next group was fetched in front of
+    // finish(cur) and carried over the loop's back edge (`cur = nxt`); that bought nothing -- hipcc put the waits for the
+    // prefetched loads in front of finish()'s first use of the (already landed) current group anyway -- and it was the one structural
+    // difference between builds whose forwards, overlapped on several HIP streams, differed from serial ones in 2-7 % of RLFN's
+    // forwards (one 16-pixel group of one apply launch off by about one 16-bit unit in the last place, only groups of a wave's
+    // second or later iteration, inputs verified intact) and builds with 0 in 2000: tools/dbg/race_variants.py (`nopref` against
+    // `prefwait` / `prefafter` / `pingpong`), race_where.py, race_what.py; DESIGN.md section 8.
+    for (long long grp = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wv); grp < ngroups; grp += gstep) {
+        Grp cur;
+        fetch(grp, cur);
         finish(cur);
-        if (!more) break;
-        cur = nxt;
-        grp = gn;
     }
 }
 

@@ -30,6 +30,8 @@ for rnd in range(rounds):
     for i, x in enumerate(xs):
         with torch.cuda.stream(streams[(i + rnd) % 4]):
             got.append(m(x))
+        if "sync" in sys.argv:
+            torch.cuda.synchronize()        # same stream assignment (same per-stream workspace history), no overlap
     torch.cuda.synchronize()
     for i, (a, b) in enumerate(zip(got, want)):
         if not torch.equal(a, b):
@@ -39,6 +41,12 @@ for rnd in range(rounds):
             print(f"round {rnd} image {i} shape {tuple(a.shape)}: {int((d > 0).sum())} differing values, max {float(d.max()):.3e}, "
                   f"rows {int(nz[:, 2].min())}..{int(nz[:, 2].max())} cols {int(nz[:, 3].min())}..{int(nz[:, 3].max())} chans {sorted(set(nz[:, 1].tolist()))}")
 print(f"{bad} mismatching forwards in {rounds} rounds x {len(xs)} images")
+try:
+    f = L.lib().esr_dbg_pool_bad
+    f.restype = __import__("ctypes").c_uint
+    print("s2pool16 vs fp32-MFMA s2pool on the same input: differing elements", f(0), "max index", f(1), "launches compared", f(2))
+except AttributeError:
+    pass
 try:
     f = L.lib().esr_dbg_lds_bad
     f.restype = __import__("ctypes").c_uint

@@ -276,6 +276,23 @@ def v_pingpong(src):   # prefetch kept, no register copies: the loop body twice 
     }""")}
 
 
+def v_nops(src):       # 16 extra wait states behind every MFMA of esr_esa.hip before its result can be read
+    s = src["esr_esa.hip"]
+    s = sub(s, """    if (ST == ESR_STORE_BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+// Channel <-> MFMA row map""", """    f32x4 r_;
+    if (ST == ESR_STORE_BF16) r_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    else r_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    asm volatile("s_nop 15" : "+v"(r_));
+    return r_;
+}
+
+// Channel <-> MFMA row map""")
+    return {"esr_esa.hip": s}
+
+
 def v_x4plain(src):    # the gathers as asm dwordx4 loads + vmcnt(0), no scope bits (timing control for x4sc0 / x4sc1)
     return _c3asm(src, "")
 
@@ -300,7 +317,7 @@ def v_nop(src):        # an empty launch in front of the MFMA apply kernel
     return {"esr_esa.hip": s}
 
 
-VARIANTS = {"prefwait": v_prefwait, "prefafter": v_prefafter, "pingpong": v_pingpong, "nopref": v_nopref, "dwplain": v_dwplain, "dwsc0": v_dwsc0, "x4plain": v_x4plain, "x4sc0": v_x4sc0, "x4sc1": v_x4sc1, "inv": v_inv, "c3sc": v_c3sc, "c3ag": v_c3ag, "c3wg": v_c3wg, "chainfence": v_chainfence, "nop": v_nop, "log": v_log, "check": v_check, "oldpool": v_oldpool, "zero": v_zero, "pool3": v_pool3, "nw8": v_nw8, "tail": v_tail, "wait0": v_wait0}
+VARIANTS = {"nops": v_nops, "prefwait": v_prefwait, "prefafter": v_prefafter, "pingpong": v_pingpong, "nopref": v_nopref, "dwplain": v_dwplain, "dwsc0": v_dwsc0, "x4plain": v_x4plain, "x4sc0": v_x4sc0, "x4sc1": v_x4sc1, "inv": v_inv, "c3sc": v_c3sc, "c3ag": v_c3ag, "c3wg": v_c3wg, "chainfence": v_chainfence, "nop": v_nop, "log": v_log, "check": v_check, "oldpool": v_oldpool, "zero": v_zero, "pool3": v_pool3, "nw8": v_nw8, "tail": v_tail, "wait0": v_wait0}
 
 
 def build(name):

@@ -260,6 +260,7 @@ __device__ __forceinline__ f32x4 mfma_k32(i32x4_t a, i32x4_t b, f32x4 c)
 template <int ST, int NP, int NP0 = 0, int NP1 = 0>     // NP = channel pairs of tiles = ceil(C / 32)
 __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
 {
+#pragma clang fp contract(off)
     constexpr int NT = 2 * NP;
     constexpr int NT0 = 2 * NP0, NT1 = 2 * NP1;
     constexpr int LO1 = ST == ESR_STORE_BF16 ? 2 : 1;                        // post 1: high (+ low) weight images; post 0: always both
@@ -512,17 +513,21 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
             }
         }
     };
-    // One group per iteration, fetched and finished in the SAME iteration.  Until round 3 the next group was fetched in front of
-    // finish(cur) and carried over the loop's back edge (`cur = nxt`); that bought nothing -- hipcc put the waits for the
-    // prefetched loads in front of finish()'s first use of the (already landed) current group anyway -- and it was the one structural
-    // difference between builds whose forwards, overlapped on several HIP streams, differed from serial ones in 2-7 % of RLFN's
-    // forwards (one 16-pixel group of one apply launch off by about one 16-bit unit in the last place, only groups of a wave's
-    // second or later iteration, inputs verified intact) and builds with 0 in 2000: tools/dbg/race_variants.py (`nopref` against
-    // `prefwait` / `prefafter` / `pingpong`), race_where.py, race_what.py; DESIGN.md section 8.
-    for (long long grp = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wv); grp < ngroups; grp += gstep) {
-        Grp cur;
-        fetch(grp, cur);
-        finish(cur);
+    // TWO groups per iteration, both fetched, then both finished: the second group's loads are in flight while the first is computed
+    // and stored (the kernel is latency x concurrency bound: ~3 us of load latency against ~0.5 us of arithmetic per group).  The second
+    // fetch is UNCONDITIONAL (behind the last group it re-reads the first one's addresses): with a branch around it hipcc's wait-count
+    // pass merges "7 younger loads" with "none" and puts vmcnt(0) in front of finish(ga) -- no overlap at all (which is also what it did
+    // to the loop this replaces: the next group fetched in front of finish(cur) and carried over the back edge; see DESIGN.md section 8
+    // for why nothing fetched is carried across iterations any more).  Both inlined copies of finish() must round alike, whichever
+    // copy a group meets (batch == per-image, test_16bit_batch_equals_per_image): floating-point contraction is off in this kernel.
+    for (long long grp = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wv); grp < ngroups; grp += 2 * gstep) {
+        Grp ga, gb;
+        const long long g2 = grp + gstep;
+        const bool two = g2 < ngroups;                           // wave-uniform
+        fetch(grp, ga);
+        fetch(two ? g2 : grp, gb);
+        finish(ga);
+        if (two) finish(gb);
     }
 }
 

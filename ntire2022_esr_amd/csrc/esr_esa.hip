@@ -307,14 +307,6 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
     const int lane = tid & 63, wv = tid >> 6;
     const int px = lane & 15, kq = lane >> 4;
     const i32x4_t a_f = *reinterpret_cast<const i32x4_t*>(simg + lane * 8);
-    i32x4_t a_hi[NP0 > 0 ? 1 : NT], a_lo[NP0 > 0 ? 1 : NT];
-    if (NP0 == 0) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            a_hi[t] = *reinterpret_cast<const i32x4_t*>(simg + ((1 + t) * 64 + lane) * 8);
-            a_lo[t] = *reinterpret_cast<const i32x4_t*>(simg + ((1 + NT + t) * 64 + lane) * 8);
-        }
-    }
     const f32x4 bf4 = *reinterpret_cast<const f32x4*>(sbias + kq * 4);
     const long long npix = (long long)p.N * p.H * p.W;
     const long long ngroups = (npix + 15) / 16;
@@ -412,12 +404,12 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
         for (int q = 0; q < NP; ++q) {
             f32x4 m0 = *reinterpret_cast<const f32x4*>(sbias + 16 + (2 * q) * 16 + kq * 4);
             f32x4 m1 = *reinterpret_cast<const f32x4*>(sbias + 16 + (2 * q + 1) * 16 + kq * 4);
-            if constexpr (NP0 > 0) {
-                // with a post chain conv4's images are re-read from LDS for every group (made loop-variant on purpose): 32 registers
-                // that decide between two and three waves per SIMD.  NOT done for the plain kernel although it would run four waves
-                // per SIMD (104 VGPRs, +1.7 % RLFN): at four blocks per CU, forwards overlapping on several HIP streams came out
-                // different from serial ones in 3-5 % of RLFN's forwards (one 16-pixel group of an apply launch wrong; never in serial
-                // runs, never at three blocks per CU -- tools/dbg/streams_race.py)
+            {
+                // conv4's images are re-read from LDS for every group (made loop-variant on purpose): as loop-invariant registers they are
+                // 32 VGPRs that decide between three and four waves per SIMD (plain kernel: 154 -> ~120 registers).  The build of round 3's
+                // first half that did this for the plain kernel was withdrawn because forwards overlapping on several HIP streams differed
+                // from serial ones -- that turned out to be the loop that carried a fetched group over its back edge (below, DESIGN.md
+                // section 8), not the occupancy.
                 int sio = lane * 8;
                 asm volatile("" : "+v"(sio));
                 const unsigned short* const sim = simg + sio;
@@ -425,11 +417,6 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
                 m1 = mfma_k32<ST>(*reinterpret_cast<const i32x4_t*>(sim + (1 + 2 * q + 1) * 512), bs, m1);
                 m0 = mfma_k32<ST>(*reinterpret_cast<const i32x4_t*>(sim + (1 + NT + 2 * q) * 512), bs, m0);
                 m1 = mfma_k32<ST>(*reinterpret_cast<const i32x4_t*>(sim + (1 + NT + 2 * q + 1) * 512), bs, m1);
-            } else {
-                m0 = mfma_k32<ST>(a_hi[2 * q], bs, m0);
-                m1 = mfma_k32<ST>(a_hi[2 * q + 1], bs, m1);
-                m0 = mfma_k32<ST>(a_lo[2 * q], bs, m0);
-                m1 = mfma_k32<ST>(a_lo[2 * q + 1], bs, m1);
             }
             const unsigned xw[4] = {(unsigned)g.xv[q].x, (unsigned)g.xv[q].y, (unsigned)g.xv[q].z, (unsigned)g.xv[q].w};
             const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};

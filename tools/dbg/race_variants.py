@@ -293,6 +293,18 @@ def v_nops(src):       # 16 extra wait states behind every MFMA of esr_esa.hip b
     return {"esr_esa.hip": s}
 
 
+def v_abl_nosig(src):  # ABLATION (wrong results): no v_exp / v_rcp in the apply -- y = x * m
+    s = src["esr_esa.hip"]
+    return {"esr_esa.hip": sub(s, "        return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * m));", "        return m;")}
+
+
+def v_abl_nomath(src): # ABLATION (wrong results): finish() stores x unchanged -- no MFMA, no bilinear, no sigmoid
+    s = src["esr_esa.hip"]
+    s = sub(s, "        return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * m));", "        return m;")
+    s = sub(s, "                ow[d] = (unsigned)to16<ST>(xa * sigmoid(mm[2 * d])) | ((unsigned)to16<ST>(xb * sigmoid(mm[2 * d + 1])) << 16);", "                ow[d] = xw[d] + (unsigned)g.bc1.x + __builtin_bit_cast(unsigned, g.ta.x + g.tb.x + g.tc.x + g.td.x);")
+    return {"esr_esa.hip": s}
+
+
 def v_x4plain(src):    # the gathers as asm dwordx4 loads + vmcnt(0), no scope bits (timing control for x4sc0 / x4sc1)
     return _c3asm(src, "")
 
@@ -317,7 +329,7 @@ def v_nop(src):        # an empty launch in front of the MFMA apply kernel
     return {"esr_esa.hip": s}
 
 
-VARIANTS = {"nops": v_nops, "prefwait": v_prefwait, "prefafter": v_prefafter, "pingpong": v_pingpong, "nopref": v_nopref, "dwplain": v_dwplain, "dwsc0": v_dwsc0, "x4plain": v_x4plain, "x4sc0": v_x4sc0, "x4sc1": v_x4sc1, "inv": v_inv, "c3sc": v_c3sc, "c3ag": v_c3ag, "c3wg": v_c3wg, "chainfence": v_chainfence, "nop": v_nop, "log": v_log, "check": v_check, "oldpool": v_oldpool, "zero": v_zero, "pool3": v_pool3, "nw8": v_nw8, "tail": v_tail, "wait0": v_wait0}
+VARIANTS = {"abl_nosig": v_abl_nosig, "abl_nomath": v_abl_nomath, "nops": v_nops, "prefwait": v_prefwait, "prefafter": v_prefafter, "pingpong": v_pingpong, "nopref": v_nopref, "dwplain": v_dwplain, "dwsc0": v_dwsc0, "x4plain": v_x4plain, "x4sc0": v_x4sc0, "x4sc1": v_x4sc1, "inv": v_inv, "c3sc": v_c3sc, "c3ag": v_c3ag, "c3wg": v_c3wg, "chainfence": v_chainfence, "nop": v_nop, "log": v_log, "check": v_check, "oldpool": v_oldpool, "zero": v_zero, "pool3": v_pool3, "nw8": v_nw8, "tail": v_tail, "wait0": v_wait0}
 
 
 def build(name):

@@ -926,6 +926,209 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing (zero-fill) DMA writes LDS: it must not outlive the block
 }
 
+// ---- conv48r_kernel: the plain 48 -> 48 3x3 with its WEIGHTS IN REGISTERS (end of round 3) -----------------------------------------
+// conv_s16_kernel is bound by the length of a wave's own instruction stream per MFMA: per 60 MFMAs a wave issues 35
+// ds_read_b128 (15 of them weight fragments), a stage barrier and the cursor's bookkeeping, three times per tile.  For the shape
+// RLFN spends a third of its time in (RLFB c1_r / c2_r, team04_rlfn.py:109-116: 48 -> 48, LeakyReLU, nothing else) everything
+// that repeats per K chunk can go:
+//   * ONE 4-wave block per CU, one wave per SIMD, up to 512 registers per lane: the layer's 45 MFMA weight fragments (3 chunks x 5
+//     tap pairs x 3 output tiles, 180 registers) are loaded ONCE per block and stay in registers as the A operands;
+//   * the LDS holds nothing but input: two WHOLE-PIXEL halo tiles (18 x 34 pixels x 96 bytes = 57.4 KB each).  A tile is one stage:
+//     one barrier per tile instead of three per tile, 96 contiguous bytes per pixel and DMA lane group instead of 32;
+//   * a wave owns 8 rows of the 16 x 32-pixel tile: one B fragment (ds_read_b128) feeds 3 MFMAs, 120 reads per 360 MFMAs
+//     (conv_s16: 35 per 60).  Pixel pitch 96 B: the 16 lanes of an LDS read group cover 16 different 16-byte slots (6 px + 2 c + h
+//     mod 16 is a permutation over the group) -- conflict-free without padding;
+//   * the next tile's 58 DMA pieces are issued one per tap-pair group inside the MFMA stream, the epilogue (round, permlane swap,
+//     12 stores per wave) follows the tile's last MFMA group; `s_waitcnt vmcnt(12)` (the stores are younger than the DMA) + one
+//     s_barrier close the tile.
+// Same packed weights (esr_pack_conv_s16), same fragment maps, same rounding as conv_s16_kernel: results are bit-identical.
+template <bool BF16>
+__global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
+{
+    constexpr int NT = 3, NCH = 3, PAIRS = 5, TH = 18, THY = 34, RW = 8;
+    constexpr int PIXB = NCH * 32;                 // 96 bytes per staged pixel
+    constexpr int NSLOT = TH * THY * (PIXB / 16);  // 3672 16-byte slots
+    constexpr int NPIECES = (NSLOT + 63) / 64;     // 58 DMA pieces of 1 KB
+    constexpr int STAGE = NPIECES * 1024;
+    constexpr int PPW = (NPIECES + 3) / 4;         // 15 per wave (waves 2, 3: 14)
+    constexpr int STORES = (NT / 2) * RW + (NT & 1) * (RW / 2);     // 12 per wave and tile
+    static_assert(PPW == NCH * PAIRS, "one DMA piece per tap-pair group");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, kq = lane >> 4;
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    // ---- the weights: 45 fragments, registers for the life of the block --------------------------------------------------------
+    i32x4 wr[NCH][PAIRS][NT];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                wr[c][q][t] = *reinterpret_cast<const i32x4*>(p.wp + (size_t)((c * PAIRS + q) * NT + t) * 1024 + lane * 16);
+    f32x4 bia[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bia[t] = *reinterpret_cast<const f32x4*>(p.bias + t * 16 + kq * 4);
+
+    const int ntiles = p.N * p.tiles_y * p.tiles_x;
+    const int G = gridDim.x;
+    auto tile_index = [&](int k) -> int {
+        const int base = k * G;
+        if (base >= ntiles) return -1;
+        int off = blockIdx.x;
+        if ((G & 7) == 0 && base + G <= ntiles) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+        const int t = base + off;
+        return t < ntiles ? t : -1;
+    };
+    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) {
+        const unsigned mx = p.magic_x, my = p.magic_y;
+        const int tq = mx ? (int)__umulhi((unsigned)t, mx) : t;
+        const int tx = t - tq * p.tiles_x;
+        n = my ? (int)__umulhi((unsigned)tq, my) : tq;
+        const int ty = tq - n * p.tiles_y;
+        x0 = tx * TILE;
+        y0 = ty * 32;
+    };
+    const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 2;
+    // piece i of this wave of the tile (n, x0, y0) into stage `slot`; nothing valid (behind the last tile): zeros
+    auto dma_piece = [&](int i, bool valid, int n, int x0, int y0, int slot) __attribute__((always_inline)) {
+        const int pc = wv + 4 * i;
+        if (i < PPW - 1 || pc < NPIECES) {                             // wave-uniform
+            const unsigned sl = (unsigned)(pc * 64 + lane);             // 16-byte slot of the stage: pixel sl / 6, part sl % 6
+            const unsigned pixel = sl / 6u, part = sl - pixel * 6u;
+            const unsigned ly = pixel / (unsigned)TH, lx = pixel - ly * (unsigned)TH;
+            const int gy = y0 - 1 + (int)ly, gx = x0 - 1 + (int)lx;
+            const bool ok = valid && sl < (unsigned)NSLOT && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const unsigned voff = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff) * 2u + part * 16u : OOB;
+            dma_buf16(smem_lds + (unsigned)(slot * STAGE + pc * 1024), voff, make_rsrc(p.x + (size_t)(valid ? n : 0) * img_bytes, img_bytes), 0u);
+        }
+    };
+    const int n_my = wv < NPIECES - 4 * (PPW - 1) ? PPW : PPW - 1;     // wave-uniform: 15 or 14
+
+    int n, x0, y0;
+    {
+        const int t0 = tile_index(0);
+        if (t0 < 0) return;
+        tile_coords(t0, n, x0, y0);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma_piece(i, true, n, x0, y0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // lane-constant offsets of the B fragments: pair q reads tap min(2q + (kq >> 1), 8), channel half kq & 1 of the chunk
+    int b_off[PAIRS];
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+        const int tap = min(2 * q + (kq >> 1), 8);
+        b_off[q] = ((wv * RW + tap / 3) * TH + px + tap % 3) * PIXB + (kq & 1) * 16;
+    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 {
+        const u32x2 a = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
+        const u32x2 b = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
+        return i32x4{(int)a.x, (int)b.x, (int)a.y, (int)b.y};
+    };
+    const float slope = p.slope;
+    const size_t y_img = (size_t)p.H * p.W * p.y0_pitch * 2;
+    const unsigned rowb = (unsigned)p.W * (unsigned)p.y0_pitch * 2u;
+
+    for (int k = 0;; ++k) {
+        const int tn = tile_index(k + 1);
+        const bool more = tn >= 0;
+        int nn = 0, nx0 = 0, ny0 = 0;
+        if (more) tile_coords(tn, nn, nx0, ny0);
+        const char* sb = smem + (k & 1) * STAGE;
+        f32x4 acc[NT][RW];
+        i32x4 b[2][RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) b[0][r] = *reinterpret_cast<const i32x4*>(sb + b_off[0] + r * (TH * PIXB));
+#pragma unroll
+        for (int g = 0; g < NCH * PAIRS; ++g) {
+            const int c = g / PAIRS, q = g % PAIRS, cs = g & 1;
+            if (g + 1 < NCH * PAIRS) {
+                const int c1 = (g + 1) / PAIRS, q1 = (g + 1) % PAIRS;
+#pragma unroll
+                for (int r = 0; r < RW; ++r) b[cs ^ 1][r] = *reinterpret_cast<const i32x4*>(sb + b_off[q1] + c1 * 32 + r * (TH * PIXB));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    // the weight fragment as an ACCUMULATION-register operand ("a"): left to itself hipcc parks the 180 weight registers in
+                    // AGPRs and copies 40 fragments back into VGPRs per tile (160 v_accvgpr_read); the 24 MFMAs of a group are independent
+                    if (g == 0) {
+                        if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=v"(acc[t][r]) : "a"(wr[c][q][t]), "v"(b[cs][r]), "v"(bia[t]));
+                        else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=v"(acc[t][r]) : "a"(wr[c][q][t]), "v"(b[cs][r]), "v"(bia[t]));
+                    } else {
+                        if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[t][r]) : "a"(wr[c][q][t]), "v"(b[cs][r]));
+                        else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[t][r]) : "a"(wr[c][q][t]), "v"(b[cs][r]));
+                    }
+                }
+            dma_piece(g, more, nn, nx0, ny0, (k + 1) & 1);              // the next tile's DMA rides in the shadow of the matrix pipe
+        }
+        // ---- epilogue: activation, one rounding, 64-byte runs per pixel for the tile pair 0 / 1, 32-byte runs over two rows for tile 2
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");     // (asm MFMAs: hipcc does not pad MFMA -> VALU reads of their results)
+        {
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)n * y_img, 0, (int)y_img, 0x00020000);
+            const bool inx = x0 + px < p.W;
+            const unsigned base = ((unsigned)((y0 + wv * RW) * p.W + x0 + px) * (unsigned)p.y0_pitch + (unsigned)p.y0_coff) * 2u;
+            const int chA = (kq & 1) * 16 + (kq >> 1) * 8, chB = 32 + (kq >> 1) * 8;
+            const unsigned vA = (inx && chA < p.cout_store) ? base + (unsigned)chA * 2u : OOB;
+            const unsigned vB = (inx && chB < p.cout_store) ? base + (unsigned)chB * 2u + ((kq & 1) ? rowb : 0u) : OOB;
+#pragma unroll
+            for (int r = 0; r < RW; r += 2) {
+                uint2 pk[NT][2];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        f32x4 v = acc[t][r + e];
+                        v.x = act1(v.x, slope); v.y = act1(v.y, slope); v.z = act1(v.z, slope); v.w = act1(v.w, slope);
+                        pk[t][e].x = pack2<BF16>(v.x, v.y);
+                        pk[t][e].y = pack2<BF16>(v.z, v.w);
+                    }
+                __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[0][0], pk[1][0]), yr, vA + (unsigned)r * rowb, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[0][1], pk[1][1]), yr, vA + (unsigned)(r + 1) * rowb, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[2][0], pk[2][1]), yr, vB + (unsigned)r * rowb, 0, 0);
+            }
+        }
+        // the next tile has landed: younger than its DMA are only this tile's stores
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(STORES) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (!more) break;
+        n = nn; x0 = nx0; y0 = ny0;
+    }
+    (void)n_my;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the trailing zero-fill DMA must not outlive the block)
+}
+
+template <bool BF16>
+int launch_conv48r(const S16K& k, hipStream_t st)
+{
+    constexpr int LDS = 2 * 58 * 1024;
+    static std::atomic<unsigned> attr_set[MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
+    if (!attr_set[dev].load(std::memory_order_relaxed)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv48r_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            esr_set_err("hipFuncSetAttribute(conv48r_kernel, MaxDynamicSharedMemorySize)", e);
+            return ESR_ERR_LAUNCH;
+        }
+        attr_set[dev].store(1u, std::memory_order_relaxed);
+    }
+    const int ntiles = k.N * k.tiles_x * k.tiles_y;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    esr_note_kernel("conv48r_kernel<%s>", esr_tf(BF16));
+    hipLaunchKernelGGL((conv48r_kernel<BF16>), dim3(grid), dim3(256), LDS, st, k);
+    return esr_check_launch("conv48r_kernel launch");
+}
+
 template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 = 0>
 int launch_s16(const S16K& k, size_t lds, hipStream_t st)
 {
@@ -1394,6 +1597,8 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     // the plain 48-channel 3x3 (RLFB c1_r / c2_r): 46 KB of weights + a ring of three 11 KB stages fit 80 KB, so TWO 4-wave blocks
     // share a CU -- their stage barriers are independent and one block's memory phase runs under the other's MFMAs (-2.5 % on the
     // kernel, +1 % RLFN, A/B; 16 x 16 tiles carry more halo and the ring is the shortest, which is why it is not more)
+    if (s16_block_waves(d) == 4 && nchunks == 3 && (long)d->n * k.tiles_x * k.tiles_y >= 256 && (getenv("ESR_NO_CONV48R") == nullptr))
+        return bf16 ? launch_conv48r<true>(k, st) : launch_conv48r<false>(k, st);
     if (s16_block_waves(d) == 4) {
         const size_t lds4 = s16_lds_bytes(nchunks, nt, 3, 4, RING_MIN, 1024);
         {

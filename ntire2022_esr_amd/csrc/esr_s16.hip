@@ -1036,74 +1036,100 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
     const size_t y_img = (size_t)p.H * p.W * p.y0_pitch * 2;
     const unsigned rowb = (unsigned)p.W * (unsigned)p.y0_pitch * 2u;
 
+    // ROW PAIRS are the outer loop of a tile: the weights are registers, so walking the 15 tap-pair groups four times costs nothing,
+    // and (a) the accumulators of a row pair (24 registers) are finished after its 15 groups -- their activation / rounding / stores run
+    // between the MFMA groups of the NEXT row pair (the last pair's: of the next tile's first), nothing of the epilogue is exposed;
+    // (b) the next tile's 15 DMA pieces are all issued during the FIRST row pair, three quarters of a tile ahead of their wait.
+    f32x4 acc[2][NT][2];                 // [row pair & 1][channel tile][row of the pair]
+    uint2 pk[NT][2];                     // the finished row pair, rounded
+    unsigned e_vA = OOB, e_vB = OOB;     // store offsets (row 0 of the wave) of the tile whose epilogue is in flight
+    int e_n = 0;
+    auto epi_pack = [&](int par, int f) __attribute__((always_inline)) {          // fragment f = 2 t + e of the finished pair
+        const int t = f >> 1, e = f & 1;
+        f32x4 v = acc[par][t][e];
+        v.x = act1(v.x, slope); v.y = act1(v.y, slope); v.z = act1(v.z, slope); v.w = act1(v.w, slope);
+        pk[t][e].x = pack2<BF16>(v.x, v.y);
+        pk[t][e].y = pack2<BF16>(v.z, v.w);
+    };
+    auto epi_store = [&](int i, int r) __attribute__((always_inline)) {           // store i of the pair whose first row is r
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)e_n * y_img, 0, (int)y_img, 0x00020000);
+        if (i == 0) __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[0][0], pk[1][0]), yr, e_vA + (unsigned)r * rowb, 0, 0);
+        else if (i == 1) __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[0][1], pk[1][1]), yr, e_vA + (unsigned)(r + 1) * rowb, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[2][0], pk[2][1]), yr, e_vB + (unsigned)r * rowb, 0, 0);
+    };
+    auto store_offsets = [&](int nn_, int x0_, int y0_, bool valid) __attribute__((always_inline)) {
+        const bool inx = valid && x0_ + px < p.W;
+        const unsigned base = ((unsigned)((y0_ + wv * RW) * p.W + x0_ + px) * (unsigned)p.y0_pitch + (unsigned)p.y0_coff) * 2u;
+        const int chA = (kq & 1) * 16 + (kq >> 1) * 8, chB = 32 + (kq >> 1) * 8;
+        e_vA = (inx && chA < p.cout_store) ? base + (unsigned)chA * 2u : OOB;
+        e_vB = (inx && chB < p.cout_store) ? base + (unsigned)chB * 2u + ((kq & 1) ? rowb : 0u) : OOB;
+        e_n = nn_;
+    };
+    bool pend = false;                   // a finished tile's last row pair waits for its epilogue
     for (int k = 0;; ++k) {
         const int tn = tile_index(k + 1);
         const bool more = tn >= 0;
         int nn = 0, nx0 = 0, ny0 = 0;
         if (more) tile_coords(tn, nn, nx0, ny0);
         const char* sb = smem + (k & 1) * STAGE;
-        f32x4 acc[NT][RW];
-        i32x4 b[2][RW];
+        // B fragments: a ring of four (two rows each), read THREE groups ahead of their MFMAs (a group is 6 MFMAs = ~100 cycles, an LDS
+        // read returns after ~130): linear group index L = 15 rp + g over the tile's 60 groups
+        constexpr int NG = NCH * PAIRS, AHEAD = 3;
+        i32x4 b[4][2];
+        auto read_b = [&](int L) __attribute__((always_inline)) {
+            const int rp_ = L / NG, g_ = L % NG, c_ = g_ / PAIRS, q_ = g_ % PAIRS;
 #pragma unroll
-        for (int r = 0; r < RW; ++r) b[0][r] = *reinterpret_cast<const i32x4*>(sb + b_off[0] + r * (TH * PIXB));
+            for (int e = 0; e < 2; ++e) b[L & 3][e] = *reinterpret_cast<const i32x4*>(sb + b_off[q_] + c_ * 32 + (2 * rp_ + e) * (TH * PIXB));
+        };
 #pragma unroll
-        for (int g = 0; g < NCH * PAIRS; ++g) {
-            const int c = g / PAIRS, q = g % PAIRS, cs = g & 1;
-            if (g + 1 < NCH * PAIRS) {
-                const int c1 = (g + 1) / PAIRS, q1 = (g + 1) % PAIRS;
+        for (int L = 0; L < AHEAD; ++L) read_b(L);
 #pragma unroll
-                for (int r = 0; r < RW; ++r) b[cs ^ 1][r] = *reinterpret_cast<const i32x4*>(sb + b_off[q1] + c1 * 32 + r * (TH * PIXB));
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int rp = 0; rp < RW / 2; ++rp) {
+            const int par = rp & 1;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < RW; ++r) {
-                    // the weight fragment as an ACCUMULATION-register operand ("a"): left to itself hipcc parks the 180 weight registers in
-                    // AGPRs and copies 40 fragments back into VGPRs per tile (160 v_accvgpr_read); the 24 MFMAs of a group are independent
-                    if (g == 0) {
-                        if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=v"(acc[t][r]) : "a"(wr[c][q][t]), "v"(b[cs][r]), "v"(bia[t]));
-                        else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=v"(acc[t][r]) : "a"(wr[c][q][t]), "v"(b[cs][r]), "v"(bia[t]));
-                    } else {
-                        if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[t][r]) : "a"(wr[c][q][t]), "v"(b[cs][r]));
-                        else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[t][r]) : "a"(wr[c][q][t]), "v"(b[cs][r]));
-                    }
-                }
-            dma_piece(g, more, nn, nx0, ny0, (k + 1) & 1);              // the next tile's DMA rides in the shadow of the matrix pipe
-        }
-        // ---- epilogue: activation, one rounding, 64-byte runs per pixel for the tile pair 0 / 1, 32-byte runs over two rows for tile 2
-        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");     // (asm MFMAs: hipcc does not pad MFMA -> VALU reads of their results)
-        {
-            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)n * y_img, 0, (int)y_img, 0x00020000);
-            const bool inx = x0 + px < p.W;
-            const unsigned base = ((unsigned)((y0 + wv * RW) * p.W + x0 + px) * (unsigned)p.y0_pitch + (unsigned)p.y0_coff) * 2u;
-            const int chA = (kq & 1) * 16 + (kq >> 1) * 8, chB = 32 + (kq >> 1) * 8;
-            const unsigned vA = (inx && chA < p.cout_store) ? base + (unsigned)chA * 2u : OOB;
-            const unsigned vB = (inx && chB < p.cout_store) ? base + (unsigned)chB * 2u + ((kq & 1) ? rowb : 0u) : OOB;
-#pragma unroll
-            for (int r = 0; r < RW; r += 2) {
-                uint2 pk[NT][2];
+            for (int g = 0; g < NG; ++g) {
+                const int c = g / PAIRS, q = g % PAIRS, L = rp * NG + g, cs = L & 3;
+                if (L + AHEAD < (RW / 2) * NG) read_b(L + AHEAD);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        f32x4 v = acc[t][r + e];
-                        v.x = act1(v.x, slope); v.y = act1(v.y, slope); v.z = act1(v.z, slope); v.w = act1(v.w, slope);
-                        pk[t][e].x = pack2<BF16>(v.x, v.y);
-                        pk[t][e].y = pack2<BF16>(v.z, v.w);
+                        // the weight fragment as an ACCUMULATION-register operand ("a"): left to itself hipcc parks the 180 weight registers
+                        // in AGPRs and copies 40 fragments back into VGPRs per tile (160 v_accvgpr_read); the 6 MFMAs of a group are independent
+                        if (g == 0) {
+                            if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=v"(acc[par][t][e]) : "a"(wr[c][q][t]), "v"(b[cs][e]), "v"(bia[t]));
+                            else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=v"(acc[par][t][e]) : "a"(wr[c][q][t]), "v"(b[cs][e]), "v"(bia[t]));
+                        } else {
+                            if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "a"(wr[c][q][t]), "v"(b[cs][e]));
+                            else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "a"(wr[c][q][t]), "v"(b[cs][e]));
+                        }
                     }
-                __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[0][0], pk[1][0]), yr, vA + (unsigned)r * rowb, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[0][1], pk[1][1]), yr, vA + (unsigned)(r + 1) * rowb, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[2][0], pk[2][1]), yr, vB + (unsigned)r * rowb, 0, 0);
+                if (rp == 0) dma_piece(g, more, nn, nx0, ny0, (k + 1) & 1);      // the next tile's DMA, in the shadow of the matrix pipe
+                // the previous row pair's epilogue (rp == 0: the previous TILE's last pair), piecewise behind this pair's groups 1 .. 9:
+                // its accumulators were last written 15 groups ago
+                if (rp > 0 || pend) {
+                    const int r_prev = rp == 0 ? RW - 2 : 2 * rp - 2;
+                    if (g >= 1 && g <= 6) epi_pack(par ^ 1, g - 1);
+                    if (g >= 7 && g <= 9) epi_store(g - 7, r_prev);
+                }
+                if (rp == 0 && g == 10) store_offsets(n, x0, y0, true);          // (behind the previous tile's last store)
             }
         }
-        // the next tile has landed: younger than its DMA are only this tile's stores
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(STORES) : "memory");
+        // the next tile has landed: younger than its DMA are the 9 stores of this tile's first three row pairs
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        pend = true;
         if (!more) break;
         n = nn; x0 = nx0; y0 = ny0;
     }
-    (void)n_my;
+    // the last tile's last row pair
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");     // (asm MFMAs: hipcc does not pad MFMA -> VALU reads of their results)
+#pragma unroll
+    for (int f = 0; f < 2 * NT; ++f) epi_pack(1, f);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) epi_store(i, RW - 2);
+    (void)n_my; (void)STORES;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the trailing zero-fill DMA must not outlive the block)
 }
 

@@ -926,41 +926,49 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing (zero-fill) DMA writes LDS: it must not outlive the block
 }
 
-// ---- conv48r_kernel: the plain 48 -> 48 3x3 with its WEIGHTS IN REGISTERS (end of round 3) -----------------------------------------
+// ---- conv48r_kernel: 3x3 convolutions over 48 input channels with their WEIGHTS IN REGISTERS (end of round 3) ---------------------
 // conv_s16_kernel is bound by the length of a wave's own instruction stream per MFMA: per 60 MFMAs a wave issues 35
-// ds_read_b128 (15 of them weight fragments), a stage barrier and the cursor's bookkeeping, three times per tile.  For the shape
-// RLFN spends a third of its time in (RLFB c1_r / c2_r, team04_rlfn.py:109-116: 48 -> 48, LeakyReLU, nothing else) everything
-// that repeats per K chunk can go:
-//   * ONE 4-wave block per CU, one wave per SIMD, up to 512 registers per lane: the layer's 45 MFMA weight fragments (3 chunks x 5
-//     tap pairs x 3 output tiles, 180 registers) are loaded ONCE per block and stay in registers as the A operands;
+// ds_read_b128 (15 of them weight fragments), a stage barrier and the cursor's bookkeeping, three times per tile.  For the 48-channel
+// 3x3s RLFN and BSRN spend a third to a half of their time in (RLFB c1_r / c2_r, team04_rlfn.py:109-116; ESDB c{j}_r / c4 as dense
+// BSConvU, team18_bsrn.py:150-163) everything that repeats per K chunk can go:
+//   * ONE 4-wave block per CU, one wave per SIMD, up to 512 registers per lane: the layer's 45 (NT = 2: 30) MFMA weight fragments
+//     -- 3 chunks x 5 tap pairs x NT output tiles, 180 registers -- are loaded ONCE per block and stay in ACCUMULATION registers as
+//     the A operands (asm MFMAs with an "a" constraint: left to itself hipcc parks them in AGPRs and copies 40 fragments back per tile);
 //   * the LDS holds nothing but input: two WHOLE-PIXEL halo tiles (18 x 34 pixels x 96 bytes = 57.4 KB each).  A tile is one stage:
-//     one barrier per tile instead of three per tile, 96 contiguous bytes per pixel and DMA lane group instead of 32;
-//   * a wave owns 8 rows of the 16 x 32-pixel tile: one B fragment (ds_read_b128) feeds 3 MFMAs, 120 reads per 360 MFMAs
-//     (conv_s16: 35 per 60).  Pixel pitch 96 B: the 16 lanes of an LDS read group cover 16 different 16-byte slots (6 px + 2 c + h
-//     mod 16 is a permutation over the group) -- conflict-free without padding;
-//   * the next tile's 58 DMA pieces are issued one per tap-pair group inside the MFMA stream, the epilogue (round, permlane swap,
-//     12 stores per wave) follows the tile's last MFMA group; `s_waitcnt vmcnt(12)` (the stores are younger than the DMA) + one
-//     s_barrier close the tile.
-// Same packed weights (esr_pack_conv_s16), same fragment maps, same rounding as conv_s16_kernel: results are bit-identical.
-template <bool BF16>
+//     one barrier per tile instead of three, 96 contiguous bytes per pixel and DMA lane group instead of 32.  Pixel pitch 96 B: the 16
+//     lanes of an LDS read group cover 16 different 16-byte slots (6 px + 2 c + h mod 16 is a permutation) -- conflict-free, no padding;
+//   * ROW PAIRS are the outer loop of a tile (a wave owns 8 rows of the 16 x 32 tile): walking the 15 tap-pair groups four times costs
+//     nothing with the weights in registers, and (a) a pair's 6 NT accumulators are finished after its 15 groups -- activation,
+//     rounding, post 1x1 and stores run piecewise between the MFMA groups of the NEXT pair (the last pair's: of the next tile's first),
+//     nothing of the epilogue is exposed; (b) the next tile's 58 DMA pieces are all issued during the FIRST pair, three quarters of a
+//     tile ahead of their wait; (c) B fragments (one ds_read_b128 feeds NT MFMAs) are read three groups ahead through a ring of four.
+// EXT adds what ESDB's dense BSConvU needs, in conv_s16_kernel's order of operations: the residual == input from the staged tile behind
+// its chunk's groups, the border-bias table and GELU; PNT1 = 2 the distillation 1x1 (+ GELU) of the finished rows (esr_conv_desc.post_*).
+// Same packed weights, fragment maps, operation order and rounding as conv_s16_kernel: results are bit-identical (a batch takes this
+// kernel, a single small image conv_s16_kernel: test_16bit_batch_equals_per_image).
+template <bool BF16, int NT, int PNT1, bool EXT>
 __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
 {
-    constexpr int NT = 3, NCH = 3, PAIRS = 5, TH = 18, THY = 34, RW = 8;
+    constexpr int NCH = 3, PAIRS = 5, TH = 18, THY = 34, RW = 8;
     constexpr int PIXB = NCH * 32;                 // 96 bytes per staged pixel
     constexpr int NSLOT = TH * THY * (PIXB / 16);  // 3672 16-byte slots
     constexpr int NPIECES = (NSLOT + 63) / 64;     // 58 DMA pieces of 1 KB
     constexpr int STAGE = NPIECES * 1024;
     constexpr int PPW = (NPIECES + 3) / 4;         // 15 per wave (waves 2, 3: 14)
-    constexpr int STORES = (NT / 2) * RW + (NT & 1) * (RW / 2);     // 12 per wave and tile
-    static_assert(PPW == NCH * PAIRS, "one DMA piece per tap-pair group");
+    constexpr int NG = NCH * PAIRS;                // tap-pair groups per row pair
+    constexpr int MAIN_ST = NT == 3 ? 3 : 2, POST_ST = PNT1 > 0 ? 2 : 0, SPP = MAIN_ST + POST_ST;   // stores per row pair
+    static_assert(PPW == NG, "one DMA piece per tap-pair group");
+    static_assert((NT == 2 || NT == 3) && (PNT1 == 0 || PNT1 == 2), "shapes");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
+    float* const btab = reinterpret_cast<float*>(smem + 2 * STAGE);          // border bias table [16][NT * 16] (EXT && p.border)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15, kq = lane >> 4;
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const bool has_border = EXT && p.border != nullptr, res_in = EXT && p.res_in != 0, gelu = EXT && p.act == ESR_ACT_GELU;
 
-    // ---- the weights: 45 fragments, registers for the life of the block --------------------------------------------------------
+    // ---- the weights: registers for the life of the block ---------------------------------------------------------------------
     i32x4 wr[NCH][PAIRS][NT];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
@@ -972,6 +980,25 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
     f32x4 bia[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bia[t] = *reinterpret_cast<const f32x4*>(p.bias + t * 16 + kq * 4);
+    // post 1x1 (esr_pack_post_s16 blob: hi images [k tile][out tile], lo images, fp32 bias)
+    constexpr int P1N = PNT1 > 0 ? PNT1 : 1;
+    i32x4 pw_hi[NT][P1N], pw_lo[NT][P1N];
+    f32x4 pb[P1N];
+    const bool plo = PNT1 > 0 && BF16 && p.post_lo != 0;
+    if (PNT1 > 0) {
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int ot = 0; ot < P1N; ++ot) {
+                pw_hi[kt][ot] = *reinterpret_cast<const i32x4*>(p.pw1 + (size_t)(kt * PNT1 + ot) * 1024 + lane * 16);
+                pw_lo[kt][ot] = i32x4{0, 0, 0, 0};
+                if (plo) pw_lo[kt][ot] = *reinterpret_cast<const i32x4*>(p.pw1 + (size_t)(NT * PNT1 + kt * PNT1 + ot) * 1024 + lane * 16);
+            }
+#pragma unroll
+        for (int ot = 0; ot < P1N; ++ot) pb[ot] = *reinterpret_cast<const f32x4*>(p.pw1 + (size_t)2 * NT * PNT1 * 1024 + (ot * 16 + kq * 4) * 4);
+    }
+    if (has_border)
+        for (int i = tid; i < 16 * NT * 16; i += 256) btab[i] = p.border[i];
 
     const int ntiles = p.N * p.tiles_y * p.tiles_x;
     const int G = gridDim.x;
@@ -1006,7 +1033,6 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
             dma_buf16(smem_lds + (unsigned)(slot * STAGE + pc * 1024), voff, make_rsrc(p.x + (size_t)(valid ? n : 0) * img_bytes, img_bytes), 0u);
         }
     };
-    const int n_my = wv < NPIECES - 4 * (PPW - 1) ? PPW : PPW - 1;     // wave-uniform: 15 or 14
 
     int n, x0, y0;
     {
@@ -1016,7 +1042,7 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
 #pragma unroll
         for (int i = 0; i < PPW; ++i) dma_piece(i, true, n, x0, y0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     // lane-constant offsets of the B fragments: pair q reads tap min(2q + (kq >> 1), 8), channel half kq & 1 of the chunk
@@ -1026,43 +1052,84 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
         const int tap = min(2 * q + (kq >> 1), 8);
         b_off[q] = ((wv * RW + tap / 3) * TH + px + tap % 3) * PIXB + (kq & 1) * 16;
     }
+    const int c_off = ((wv * RW + 1) * TH + px + 1) * PIXB + kq * 8;      // centre pixel of row 0 of the wave: channels 16 c + 4 kq .. +3 at + 32 c
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 {
         const u32x2 a = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
         const u32x2 b = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
         return i32x4{(int)a.x, (int)b.x, (int)a.y, (int)b.y};
     };
-    const float slope = p.slope;
-    const size_t y_img = (size_t)p.H * p.W * p.y0_pitch * 2;
-    const unsigned rowb = (unsigned)p.W * (unsigned)p.y0_pitch * 2u;
+    auto hilo = [&](f32x4 v) __attribute__((always_inline)) -> i32x4 {     // fp32 fragment -> B operand of the post 1x1 (as conv_s16_kernel)
+        const unsigned h0 = pack2<BF16>(v.x, v.y), h1 = pack2<BF16>(v.z, v.w);
+        if (!BF16) return i32x4{(int)h0, (int)h1, 0, 0};
+        float a, b, c, d;
+        unpack2<BF16>(h0, a, b);
+        unpack2<BF16>(h1, c, d);
+        return i32x4{(int)h0, (int)h1, (int)pack2<BF16>(v.x - a, v.y - b), (int)pack2<BF16>(v.z - c, v.w - d)};
+    };
+    const float slope = gelu ? 1.f : p.slope;
+    const size_t y_img = (size_t)p.H * p.W * p.y0_pitch * 2, p1_img = (size_t)p.H * p.W * p.py1_pitch * 2;
+    const unsigned rowb = (unsigned)p.W * (unsigned)p.y0_pitch * 2u, rowbp = (unsigned)p.W * (unsigned)p.py1_pitch * 2u;
 
-    // ROW PAIRS are the outer loop of a tile: the weights are registers, so walking the 15 tap-pair groups four times costs nothing,
-    // and (a) the accumulators of a row pair (24 registers) are finished after its 15 groups -- their activation / rounding / stores run
-    // between the MFMA groups of the NEXT row pair (the last pair's: of the next tile's first), nothing of the epilogue is exposed;
-    // (b) the next tile's 15 DMA pieces are all issued during the FIRST row pair, three quarters of a tile ahead of their wait.
     f32x4 acc[2][NT][2];                 // [row pair & 1][channel tile][row of the pair]
     uint2 pk[NT][2];                     // the finished row pair, rounded
-    unsigned e_vA = OOB, e_vB = OOB;     // store offsets (row 0 of the wave) of the tile whose epilogue is in flight
+    f32x4 u[PNT1 > 0 ? NT : 1][2];       // ... its fp32 values (the post 1x1 reads them unrounded)
+    uint2 pk1[P1N][2];
+    unsigned e_vA = OOB, e_vB = OOB, e_vP = OOB;     // store offsets (row 0 of the wave) of the tile whose epilogue is in flight
     int e_n = 0;
     auto epi_pack = [&](int par, int f) __attribute__((always_inline)) {          // fragment f = 2 t + e of the finished pair
         const int t = f >> 1, e = f & 1;
         f32x4 v = acc[par][t][e];
-        v.x = act1(v.x, slope); v.y = act1(v.y, slope); v.z = act1(v.z, slope); v.w = act1(v.w, slope);
+        if (gelu) v = gelu16x4(v);
+        else { v.x = act1(v.x, slope); v.y = act1(v.y, slope); v.z = act1(v.z, slope); v.w = act1(v.w, slope); }
         pk[t][e].x = pack2<BF16>(v.x, v.y);
         pk[t][e].y = pack2<BF16>(v.z, v.w);
+        if (PNT1 > 0) u[PNT1 > 0 ? t : 0][e] = v;
+    };
+    auto epi_post = [&](int e) __attribute__((always_inline)) {                    // the post 1x1 of row e of the finished pair
+        if constexpr (PNT1 > 0) {
+            f32x4 d1[PNT1];
+#pragma unroll
+            for (int ot = 0; ot < PNT1; ++ot) d1[ot] = pb[ot];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const i32x4 bsv = hilo(u[kt][e]);
+#pragma unroll
+                for (int ot = 0; ot < PNT1; ++ot) {
+                    d1[ot] = mfma32<BF16>(pw_hi[kt][ot], bsv, d1[ot]);
+                    if (plo) d1[ot] = mfma32<BF16>(pw_lo[kt][ot], bsv, d1[ot]);
+                }
+            }
+#pragma unroll
+            for (int ot = 0; ot < PNT1; ++ot) {
+                f32x4 v = d1[ot];
+                if (p.p1_gelu) v = gelu16x4(v);
+                else { v.x = act1(v.x, p.p1_slope); v.y = act1(v.y, p.p1_slope); v.z = act1(v.z, p.p1_slope); v.w = act1(v.w, p.p1_slope); }
+                pk1[ot][e].x = pack2<BF16>(v.x, v.y);
+                pk1[ot][e].y = pack2<BF16>(v.z, v.w);
+            }
+        }
     };
     auto epi_store = [&](int i, int r) __attribute__((always_inline)) {           // store i of the pair whose first row is r
-        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)e_n * y_img, 0, (int)y_img, 0x00020000);
-        if (i == 0) __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[0][0], pk[1][0]), yr, e_vA + (unsigned)r * rowb, 0, 0);
-        else if (i == 1) __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[0][1], pk[1][1]), yr, e_vA + (unsigned)(r + 1) * rowb, 0, 0);
-        else __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[2][0], pk[2][1]), yr, e_vB + (unsigned)r * rowb, 0, 0);
+        if (i < MAIN_ST) {
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)e_n * y_img, 0, (int)y_img, 0x00020000);
+            if (i == 0) __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[0][0], pk[1][0]), yr, e_vA + (unsigned)r * rowb, 0, 0);
+            else if (i == 1) __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[0][1], pk[1][1]), yr, e_vA + (unsigned)(r + 1) * rowb, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[NT - 1][0], pk[NT - 1][1]), yr, e_vB + (unsigned)r * rowb, 0, 0);
+        } else if constexpr (PNT1 > 0) {
+            const int e = i - MAIN_ST;
+            const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(p.py1 + (size_t)e_n * p1_img, 0, (int)p1_img, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(swap16(pk1[0][e], pk1[1][e]), pr, e_vP + (unsigned)(r + e) * rowbp, 0, 0);
+        }
     };
-    auto store_offsets = [&](int nn_, int x0_, int y0_, bool valid) __attribute__((always_inline)) {
-        const bool inx = valid && x0_ + px < p.W;
-        const unsigned base = ((unsigned)((y0_ + wv * RW) * p.W + x0_ + px) * (unsigned)p.y0_pitch + (unsigned)p.y0_coff) * 2u;
+    auto store_offsets = [&](int nn_, int x0_, int y0_) __attribute__((always_inline)) {
+        const bool inx = x0_ + px < p.W;
+        const unsigned pix = (unsigned)((y0_ + wv * RW) * p.W + x0_ + px);
+        const unsigned base = (pix * (unsigned)p.y0_pitch + (unsigned)p.y0_coff) * 2u;
         const int chA = (kq & 1) * 16 + (kq >> 1) * 8, chB = 32 + (kq >> 1) * 8;
         e_vA = (inx && chA < p.cout_store) ? base + (unsigned)chA * 2u : OOB;
         e_vB = (inx && chB < p.cout_store) ? base + (unsigned)chB * 2u + ((kq & 1) ? rowb : 0u) : OOB;
+        if (PNT1 > 0) e_vP = (inx && chA < p.p1_cout8) ? (pix * (unsigned)p.py1_pitch + (unsigned)p.py1_coff) * 2u + (unsigned)chA * 2u : OOB;
         e_n = nn_;
     };
     bool pend = false;                   // a finished tile's last row pair waits for its epilogue
@@ -1072,9 +1139,10 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
         int nn = 0, nx0 = 0, ny0 = 0;
         if (more) tile_coords(tn, nn, nx0, ny0);
         const char* sb = smem + (k & 1) * STAGE;
-        // B fragments: a ring of four (two rows each), read THREE groups ahead of their MFMAs (a group is 6 MFMAs = ~100 cycles, an LDS
-        // read returns after ~130): linear group index L = 15 rp + g over the tile's 60 groups
-        constexpr int NG = NCH * PAIRS, AHEAD = 3;
+        const bool on_border = has_border && (x0 == 0 || x0 + TILE >= p.W || y0 == 0 || y0 + 32 >= p.H);
+        // B fragments: a ring of four (two rows each), read THREE groups ahead of their MFMAs (a group is 2 NT MFMAs = ~100 cycles, an
+        // LDS read returns after ~130): linear group index L = 15 rp + g over the tile's 60 groups
+        constexpr int AHEAD = 3;
         i32x4 b[4][2];
         auto read_b = [&](int L) __attribute__((always_inline)) {
             const int rp_ = L / NG, g_ = L % NG, c_ = g_ / PAIRS, q_ = g_ % PAIRS;
@@ -1086,6 +1154,13 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
 #pragma unroll
         for (int rp = 0; rp < RW / 2; ++rp) {
             const int par = rp & 1;
+            uint2 cen[NT][2];            // residual == input: the centre pixels of this pair's rows, 4 channels per tile
+            if (EXT && res_in) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) cen[t][e] = *reinterpret_cast<const uint2*>(sb + c_off + t * 32 + (2 * rp + e) * (TH * PIXB));
+            }
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int c = g / PAIRS, q = g % PAIRS, L = rp * NG + g, cs = L & 3;
@@ -1095,8 +1170,6 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        // the weight fragment as an ACCUMULATION-register operand ("a"): left to itself hipcc parks the 180 weight registers
-                        // in AGPRs and copies 40 fragments back into VGPRs per tile (160 v_accvgpr_read); the 6 MFMAs of a group are independent
                         if (g == 0) {
                             if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=v"(acc[par][t][e]) : "a"(wr[c][q][t]), "v"(b[cs][e]), "v"(bia[t]));
                             else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=v"(acc[par][t][e]) : "a"(wr[c][q][t]), "v"(b[cs][e]), "v"(bia[t]));
@@ -1106,42 +1179,65 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
                         }
                     }
                 if (rp == 0) dma_piece(g, more, nn, nx0, ny0, (k + 1) & 1);      // the next tile's DMA, in the shadow of the matrix pipe
-                // the previous row pair's epilogue (rp == 0: the previous TILE's last pair), piecewise behind this pair's groups 1 .. 9:
-                // its accumulators were last written 15 groups ago
+                // the previous row pair's epilogue (rp == 0: the previous TILE's last pair), one piece per group: its accumulators were
+                // last written 15 groups ago
                 if (rp > 0 || pend) {
                     const int r_prev = rp == 0 ? RW - 2 : 2 * rp - 2;
-                    if (g >= 1 && g <= 6) epi_pack(par ^ 1, g - 1);
-                    if (g >= 7 && g <= 9) epi_store(g - 7, r_prev);
+                    if (g >= 1 && g <= 2 * NT) epi_pack(par ^ 1, g - 1);
+                    if (PNT1 > 0 && (g == 7 || g == 8)) epi_post(g - 7);
+                    if (g >= 9 && g < 9 + SPP) epi_store(g - 9, r_prev);
                 }
-                if (rp == 0 && g == 10) store_offsets(n, x0, y0, true);          // (behind the previous tile's last store)
+                if (rp == 0 && g == NG - 1) store_offsets(n, x0, y0);              // (behind the previous tile's last store)
+                if (EXT && q == PAIRS - 1 && (res_in || (on_border && c == NCH - 1))) {
+                    // conv_s16_kernel's order: act(conv(x) + x) adds the centre pixels of chunk c to channel tile c BEHIND chunk c's
+                    // groups; the border table follows the last chunk.  The MFMAs above are asm: hipcc pads neither the read of their
+                    // results (XDL write -> VALU read) nor the next group's read of what is written here
+                    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+                    if (res_in && c < NT) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) acc[par][c < NT ? c : 0][e] += unpack4<BF16>(cen[c < NT ? c : 0][e]);
+                    }
+                    if (on_border && c == NCH - 1) {
+                        const int gx = x0 + px;
+                        const int cm = (gx == 0 ? 1 : 0) | (gx == p.W - 1 ? 2 : 0);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int gy = y0 + wv * RW + 2 * rp + e;
+                            const int m = cm | (gy == 0 ? 4 : 0) | (gy == p.H - 1 ? 8 : 0);
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) acc[par][t][e] += *reinterpret_cast<const f32x4*>(btab + m * (NT * 16) + t * 16 + kq * 4);
+                        }
+                    }
+                    asm volatile("s_nop 3" ::: "memory");
+                }
             }
         }
-        // the next tile has landed: younger than its DMA are the 9 stores of this tile's first three row pairs
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        // the next tile has landed: younger than its DMA are the stores of this tile's first three row pairs
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * SPP) : "memory");
         __builtin_amdgcn_s_barrier();
         pend = true;
         if (!more) break;
         n = nn; x0 = nx0; y0 = ny0;
     }
     // the last tile's last row pair
-    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");     // (asm MFMAs: hipcc does not pad MFMA -> VALU reads of their results)
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // (asm MFMAs: hipcc does not pad MFMA -> VALU reads of their results)
 #pragma unroll
     for (int f = 0; f < 2 * NT; ++f) epi_pack(1, f);
+    if (PNT1 > 0) { epi_post(0); epi_post(1); }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) epi_store(i, RW - 2);
-    (void)n_my; (void)STORES;
+    for (int i = 0; i < SPP; ++i) epi_store(i, RW - 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the trailing zero-fill DMA must not outlive the block)
 }
 
-template <bool BF16>
+template <bool BF16, int NT, int PNT1, bool EXT>
 int launch_conv48r(const S16K& k, hipStream_t st)
 {
-    constexpr int LDS = 2 * 58 * 1024;
+    const int LDS = 2 * 58 * 1024 + ((EXT && k.border) ? NT * 1024 : 0);
     static std::atomic<unsigned> attr_set[MAX_DEVICES];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
     if (!attr_set[dev].load(std::memory_order_relaxed)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv48r_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv48r_kernel<BF16, NT, PNT1, EXT>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 58 * 1024 + NT * 1024);
         if (e != hipSuccess) {
             esr_set_err("hipFuncSetAttribute(conv48r_kernel, MaxDynamicSharedMemorySize)", e);
             return ESR_ERR_LAUNCH;
@@ -1150,9 +1246,31 @@ int launch_conv48r(const S16K& k, hipStream_t st)
     }
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int grid = ntiles < 256 ? ntiles : 256;
-    esr_note_kernel("conv48r_kernel<%s>", esr_tf(BF16));
-    hipLaunchKernelGGL((conv48r_kernel<BF16>), dim3(grid), dim3(256), LDS, st, k);
+    esr_note_kernel("conv48r_kernel<%s, %d, %d, %s>", esr_tf(BF16), NT, PNT1, esr_tf(EXT));
+    hipLaunchKernelGGL((conv48r_kernel<BF16, NT, PNT1, EXT>), dim3(grid), dim3(256), LDS, st, k);
     return esr_check_launch("conv48r_kernel launch");
+}
+
+// the descriptors conv48r_kernel takes (after esr_conv2d_s16 filled S16K): 48 physical input channels, 2 or 3 output tiles, a batch of
+// at least one tile per CU, no residual from HBM, no split, a post chain of one 2-tile 1x1 at most
+template <bool BF16>
+int try_conv48r(const esr_conv_desc* d, const S16K& k, int nt, int pnt1, int pnt2, bool post, hipStream_t st, bool* taken)
+{
+    *taken = false;
+    if (d->ksize != 3 || k.nchunks != 3 || (nt != 2 && nt != 3) || k.nres != 0 || k.res_mode != ESR_RES_NONE || d->out_layout != ESR_NHWC) return ESR_OK;
+    if (k.seg_stride != 0 || k.split < k.cout_store || !k.store_main) return ESR_OK;
+    if ((long)k.N * k.tiles_x * k.tiles_y < 256) return ESR_OK;
+    if (d->act == ESR_ACT_GELU && k.res_mode != ESR_RES_NONE) return ESR_OK;
+    if (getenv("ESR_NO_CONV48R")) return ESR_OK;
+    const bool ext = k.border != nullptr || k.res_in || d->act == ESR_ACT_GELU;
+    // a post chain stays on conv_s16_kernel: the PNT1 = 2 instantiation (ESDB c{j}_r + the next distillation 1x1, two GELUs per pixel)
+    // measured 0.396 against 0.368 ms at 32 x 270 x 480 -- with ONE wave per SIMD the ~380 VALU instructions of a row pair's epilogue
+    // have to fit the shadow of its 102 MFMAs exactly, conv_s16_kernel's second wave absorbs them (tools/gpu_c48.sh)
+    (void)pnt1; (void)pnt2;
+    if (post) return ESR_OK;
+    *taken = true;
+    if (nt == 2) return launch_conv48r<BF16, 2, 0, true>(k, st);
+    return ext ? launch_conv48r<BF16, 3, 0, true>(k, st) : launch_conv48r<BF16, 3, 0, false>(k, st);
 }
 
 template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 = 0>
@@ -1615,6 +1733,11 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     k.seg_chunks = segmented ? d->in_seg_chunks : nchunks;
     k.seg_stride = segmented ? d->in_seg_stride : 0;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    {
+        bool taken = false;
+        const int rc = bf16 ? try_conv48r<true>(d, k, nt, pnt1, pnt2, post, st, &taken) : try_conv48r<false>(d, k, nt, pnt1, pnt2, post, st, &taken);
+        if (taken) return rc;
+    }
     if (post) {
         const bool gres = k.res_mode != ESR_RES_NONE;
         return bf16 ? launch_s16_post<true>(d->ksize, nt, gres, pnt1, pnt2, k, lds, st)
@@ -1623,8 +1746,6 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     // the plain 48-channel 3x3 (RLFB c1_r / c2_r): 46 KB of weights + a ring of three 11 KB stages fit 80 KB, so TWO 4-wave blocks
     // share a CU -- their stage barriers are independent and one block's memory phase runs under the other's MFMAs (-2.5 % on the
     // kernel, +1 % RLFN, A/B; 16 x 16 tiles carry more halo and the ring is the shortest, which is why it is not more)
-    if (s16_block_waves(d) == 4 && nchunks == 3 && (long)d->n * k.tiles_x * k.tiles_y >= 256 && (getenv("ESR_NO_CONV48R") == nullptr))
-        return bf16 ? launch_conv48r<true>(k, st) : launch_conv48r<false>(k, st);
     if (s16_block_waves(d) == 4) {
         const size_t lds4 = s16_lds_bytes(nchunks, nt, 3, 4, RING_MIN, 1024);
         {

@@ -214,8 +214,10 @@ int    esr_wino_supported(const esr_conv_desc* d);   /* 1: a descriptor of this 
 
 int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream);
 /* Diagnostics: waves per block of the conv_f32_kernel variant esr_conv2d_f32 launches for `d` (4 = 16x16-pixel tiles,
- * two blocks per CU; 8 = 16x32-pixel tiles, one block per CU, used for large 3x3 launches; likewise for conv_s16_kernel), 0 for a
- * NULL / empty descriptor.  Lets a profiler name the device symbol that ran (the reference has torch.profiler for that). */
+ * two blocks per CU; 8 = 16x32-pixel tiles, one block per CU, used for large 3x3 launches; likewise for conv_s16_kernel;
+ * 1 = conv48r_kernel: 16-bit storage, a 3x3 over 48 physical input channels with 2 or 3 output tiles and at least 256 tiles of
+ * 16x32 -- one 4-wave block per CU, one wave per SIMD, weights in registers), 0 for a NULL / empty descriptor.  Lets a profiler
+ * name the device symbol that ran (the reference has torch.profiler for that). */
 int esr_conv_block_waves(const esr_conv_desc* d);
 
 /*

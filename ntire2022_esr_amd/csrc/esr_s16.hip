@@ -1251,28 +1251,6 @@ int launch_conv48r(const S16K& k, hipStream_t st)
     return esr_check_launch("conv48r_kernel launch");
 }
 
-// the descriptors conv48r_kernel takes (after esr_conv2d_s16 filled S16K): 48 physical input channels, 2 or 3 output tiles, a batch of
-// at least one tile per CU, no residual from HBM, no split, a post chain of one 2-tile 1x1 at most
-template <bool BF16>
-int try_conv48r(const esr_conv_desc* d, const S16K& k, int nt, int pnt1, int pnt2, bool post, hipStream_t st, bool* taken)
-{
-    *taken = false;
-    if (d->ksize != 3 || k.nchunks != 3 || (nt != 2 && nt != 3) || k.nres != 0 || k.res_mode != ESR_RES_NONE || d->out_layout != ESR_NHWC) return ESR_OK;
-    if (k.seg_stride != 0 || k.split < k.cout_store || !k.store_main) return ESR_OK;
-    if ((long)k.N * k.tiles_x * k.tiles_y < 256) return ESR_OK;
-    if (d->act == ESR_ACT_GELU && k.res_mode != ESR_RES_NONE) return ESR_OK;
-    if (getenv("ESR_NO_CONV48R")) return ESR_OK;
-    const bool ext = k.border != nullptr || k.res_in || d->act == ESR_ACT_GELU;
-    // a post chain stays on conv_s16_kernel: the PNT1 = 2 instantiation (ESDB c{j}_r + the next distillation 1x1, two GELUs per pixel)
-    // measured 0.396 against 0.368 ms at 32 x 270 x 480 -- with ONE wave per SIMD the ~380 VALU instructions of a row pair's epilogue
-    // have to fit the shadow of its 102 MFMAs exactly, conv_s16_kernel's second wave absorbs them (tools/gpu_c48.sh)
-    (void)pnt1; (void)pnt2;
-    if (post) return ESR_OK;
-    *taken = true;
-    if (nt == 2) return launch_conv48r<BF16, 2, 0, true>(k, st);
-    return ext ? launch_conv48r<BF16, 3, 0, true>(k, st) : launch_conv48r<BF16, 3, 0, false>(k, st);
-}
-
 template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 = 0>
 int launch_s16(const S16K& k, size_t lds, hipStream_t st)
 {
@@ -1361,9 +1339,22 @@ static bool s16_res_is_input(const esr_conv_desc* d)
            d->res.pitch == d->in.pitch && d->res.coff == d->in.coff;
 }
 
-// 4: the launch takes the two-blocks-per-CU shape (4 waves, 16 x 16 tiles), 8: one 8-wave block per CU on 16 x 32 tiles
+// conv48r_kernel's descriptors: a 3x3 over 48 physical input channels with 2 or 3 output tiles, at least one 16 x 32 tile per CU, no
+// residual from HBM, no split, no post chain (measured slower there), NHWC, one input tensor
+static bool conv48r_takes(const esr_conv_desc* d)
+{
+    const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
+    if (d->ksize != 3 || nchunks != 3 || (nt != 2 && nt != 3) || d->out_layout != ESR_NHWC || d->in_seg_stride != 0 || d->post_wpacked) return false;
+    if (d->res_mode != ESR_RES_NONE && !s16_res_is_input(d)) return false;
+    if (d->split > 0 && d->split < d->cout) return false;
+    return (long)d->n * ((d->w + TILE - 1) / TILE) * ((d->h + 31) / 32) >= 256;
+}
+
+// 1: conv48r_kernel (one 4-wave block per CU, weights in registers), 4: conv_s16_kernel's two-blocks-per-CU shape (4 waves, 16 x 16
+// tiles), 8: one 8-wave block per CU on 16 x 32 tiles
 int s16_block_waves(const esr_conv_desc* d)
 {
+    if (conv48r_takes(d)) return 1;
     const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
     const bool res_hbm = d->res_mode != ESR_RES_NONE && !s16_res_is_input(d);
     if (d->ksize != 3 || nt != 3 || d->border_bias || d->post_wpacked || res_hbm || d->out_layout != ESR_NHWC || d->in_seg_stride != 0) return 8;
@@ -1733,10 +1724,14 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     k.seg_chunks = segmented ? d->in_seg_chunks : nchunks;
     k.seg_stride = segmented ? d->in_seg_stride : 0;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    {
-        bool taken = false;
-        const int rc = bf16 ? try_conv48r<true>(d, k, nt, pnt1, pnt2, post, st, &taken) : try_conv48r<false>(d, k, nt, pnt1, pnt2, post, st, &taken);
-        if (taken) return rc;
+    if (conv48r_takes(d)) {
+        // (a post chain stays on conv_s16_kernel: the PNT1 = 2 instantiation -- ESDB c{j}_r + the next distillation 1x1, two GELUs per
+        // pixel -- measured 0.396 against 0.368 ms at 32 x 270 x 480: with ONE wave per SIMD the ~380 VALU instructions of a row pair's
+        // epilogue have to fit the shadow of its 102 MFMAs exactly, conv_s16_kernel's second wave absorbs them)
+        const bool ext = k.border != nullptr || k.res_in || d->act == ESR_ACT_GELU;
+        if (nt == 2) return bf16 ? launch_conv48r<true, 2, 0, true>(k, st) : launch_conv48r<false, 2, 0, true>(k, st);
+        if (ext) return bf16 ? launch_conv48r<true, 3, 0, true>(k, st) : launch_conv48r<false, 3, 0, true>(k, st);
+        return bf16 ? launch_conv48r<true, 3, 0, false>(k, st) : launch_conv48r<false, 3, 0, false>(k, st);
     }
     if (post) {
         const bool gres = k.res_mode != ESR_RES_NONE;

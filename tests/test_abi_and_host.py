@@ -252,7 +252,8 @@ def test_head_hi_lo_weights_cpu():
 
 def test_block_shape_query_cpu():
     """esr_conv_block_waves (host-only): which block shape a descriptor's launch takes -- fp32: 8-wave blocks for large 3x3s with
-    >= 3 output tiles; 16-bit storage: two 4-wave blocks per CU for the plain 48-channel 3x3 with >= 512 tiles of 16x16, else 8"""
+    >= 3 output tiles; 16-bit storage: 1 = conv48r_kernel (3x3 over 48 physical input channels, 2 or 3 output tiles, >= 256 tiles of
+    16x32, no residual from HBM / post chain), else two 4-wave blocks per CU for the plain 48-channel 3x3 with >= 512 tiles of 16x16, else 8"""
     from ntire2022_esr_amd import _lib as L
     lib = L.lib()
 
@@ -266,7 +267,9 @@ def test_block_shape_query_cpu():
         return lib.esr_conv_block_waves(ctypes.byref(d))
 
     assert waves(32, 256, 256, 64, 64) == 8 and waves(1, 64, 64, 64, 64) == 4 and waves(32, 256, 256, 48, 16) == 4
-    assert waves(32, 256, 256, 48, 48, store="bf16") == 4 and waves(1, 339, 510, 46, 46, store="f16") == 4
+    assert waves(32, 256, 256, 48, 48, store="bf16") == 1 and waves(1, 339, 510, 46, 46, store="f16") == 1
+    assert waves(32, 256, 256, 48, 24, store="bf16") == 1 and waves(2, 256, 256, 48, 48, store="f16") == 1     # two output tiles; exactly 256 tiles
+    assert waves(1, 256, 256, 48, 48, store="bf16") == 8 and waves(32, 256, 256, 32, 48, store="bf16") == 4     # 128 tiles; two input chunks (the two-blocks-per-CU shape)
     assert waves(1, 128, 128, 48, 48, store="bf16") == 8                        # 64 tiles: fewer than resident blocks
     assert waves(32, 256, 256, 64, 64, store="bf16") == 8                        # 74 KB of weights: one block per CU
     assert waves(32, 256, 256, 48, 48, k=1, store="bf16") == 8

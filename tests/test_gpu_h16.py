@@ -1,6 +1,7 @@
 """-m gpu: the 16-bit-STORAGE path (bf16 / fp16 activations in HBM = MFMA operands, fp32 accumulate, one rounding at
 the store).  Kernel logic is checked against an fp64 reference on the same 16-bit inputs and the blob's effective
 weights (tolerance: that one rounding); the rounding itself is then bounded at network level as a PSNR shift."""
+import ctypes
 import os
 
 import numpy as np
@@ -68,12 +69,12 @@ def test_s16_conv_matches_fp64_reference(compute, cin, cout, k, hw, act, res_mod
 @pytest.mark.parametrize("n,cin,cout,k,hw,res_mode", [
     (1, 64, 64, 3, (270, 480), 0), (1, 64, 64, 3, (270, 480), 2), (1, 64, 64, 1, (270, 480), 2), (1, 48, 48, 3, (339, 510), 2),
     (1, 64, 64, 3, (339, 510), 1), (3, 48, 48, 3, (256, 256), 0), (1, 16, 16, 3, (270, 480), 1), (5, 50, 50, 1, (200, 200), 0),
-    (2, 48, 48, 3, (339, 510), 0), (1, 40, 44, 3, (339, 510), 0)])      # >= 512 tiles of 16x16, three output tiles, no HBM residual: two 4-wave blocks per CU
+    (2, 48, 48, 3, (339, 510), 0), (1, 40, 44, 3, (339, 510), 0)])      # three output tiles, no HBM residual, >= 256 tiles: conv48r_kernel (48 channels)
 def test_s16_conv_more_tiles_than_blocks(compute, n, cin, cout, k, hw, res_mode):
     """Shapes with MORE 16x32 tiles than the 256 persistent blocks and partial tiles at both edges: the tile-to-tile path of a
     block (the epilogue of tile k inside the first MFMA group of tile k+1, residual registers reused across tiles, unequal
-    tile counts per block, the drain iteration) -- the small shapes above give every block at most one tile.  The 48-channel 3x3s
-    without a residual from HBM take the two-blocks-per-CU shape (NW = 4, 16x16 tiles, esr_conv_block_waves)."""
+    tile counts per block, the drain iteration) -- the small shapes above give every block at most one tile.  The 3x3s over 48
+    physical channels without a residual from HBM take conv48r_kernel (esr_conv_block_waves == 1)."""
     from ntire2022_esr_amd import ops
     from ntire2022_esr_amd.engine import pack_conv_s16, unpack_conv_s16
     dt = DT[compute]
@@ -276,3 +277,57 @@ def test_network_psnr_shift(mid, compute, max_dpsnr):
     assert abs(p16 - p32) < 1.5 * max_dpsnr
     model.set_compute("f32")
     assert torch.equal(model(x), y32)                       # switching back restores the exact fp32 path
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,act,res_in,border,hw,n", [
+    (48, 48, 1, False, False, (128, 128), 8),      # RLFB c1_r / c2_r: plain, LeakyReLU
+    (46, 46, 1, False, False, (150, 97), 9),       # logical 46 channels, ragged edges, tiles not a multiple of the grid
+    (48, 48, 3, True, True, (128, 128), 8),        # ESDB c{j}_r as a dense BSConvU: + input, border table, GELU
+    (48, 48, 3, True, True, (90, 130), 12),
+    (48, 24, 3, False, True, (128, 128), 8),       # ESDB c4: two output tiles
+    (48, 48, 0, True, False, (128, 128), 8)])      # residual == input without activation
+def test_conv48r_equals_conv_s16(compute, cin, cout, act, res_in, border, hw, n):
+    """conv48r_kernel (3x3 over 48 physical input channels, >= 256 tiles of 16 x 32: weights in registers, one wave per SIMD, row pairs
+    as the outer loop) against conv_s16_kernel: the batch takes the new kernel (esr_conv_block_waves == 1), each image alone the old
+    one (<= 72 tiles), same packed weights -- bit-identical results, and both within storage precision of the fp64 convolution."""
+    from ntire2022_esr_amd import ops, _lib as L
+    from ntire2022_esr_amd.engine import pack_conv_s16, unpack_conv_s16
+    dt = DT[compute]
+    g = torch.Generator().manual_seed(cin + cout + act + hw[0] + n)
+    cp = 48
+    x = torch.randn(n, cin, *hw, generator=g).to(dt)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    table = (torch.randn(16, (cout + 15) // 16 * 16, generator=g) * 0.2) if border else None
+    if table is not None:
+        table[0] = 0                                    # row 0 = interior pixels of a border tile
+    blob = pack_conv_s16(w, b, compute, cin_phys=cp).to(DEV)
+    xin = F.pad(_nhwc(x), (0, cp - cin)).to(DEV)
+    kw = dict(act=act, cin=cin, packed=blob, border=None if table is None else table.to(DEV))
+    if res_in:
+        kw.update(res=xin, res_mode=L.RES_PRE_ACT)
+    d = L.ConvDesc()
+    d.n, d.h, d.w, d.cin, d.cout, d.ksize = n, hw[0], hw[1], cin, cout, 3
+    d.in_layout = d.out_layout = L.NHWC
+    d.storage = L.STORE[compute]
+    assert L.lib().esr_conv_block_waves(ctypes.byref(d)) == 1
+    d.n = 1
+    assert L.lib().esr_conv_block_waves(ctypes.byref(d)) != 1
+    y = ops.conv2d(xin, w, b, **kw)
+    for i in range(n):
+        kw1 = dict(kw)
+        if res_in:
+            kw1["res"] = xin[i:i + 1]
+        y1 = ops.conv2d(xin[i:i + 1].contiguous(), w, b, **kw1)
+        assert torch.equal(y[i:i + 1], y1), i
+    if not border:
+        weff, _ = unpack_conv_s16(blob.cpu(), cin, cout, 3, compute, cin_phys=cp)
+        conv = F.conv2d(x.double().to(DEV), weff.double().to(DEV), b.double().to(DEV), padding=1)
+        if res_in:
+            conv = conv + x.double().to(DEV)[:, :cout]
+        ref = ACTS[act](conv)
+        got = y.permute(0, 3, 1, 2)[:, :cout].double()
+        eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+        tol = ref.abs() * eps * 1.01 + (3e-4 if act == 3 else 5e-5) * max(1.0, float(ref.abs().max()))
+        assert int(((got - ref).abs() > tol).sum()) == 0

@@ -1,8 +1,7 @@
 #!/bin/bash
-# conv48r_kernel: correctness (16-bit kernel tests + networks) and benches with / without it (ESR_NO_CONV48R=1)
+# conv48r_kernel: correctness (16-bit kernel tests + networks), benches
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd $R
 timeout 900 python -m pytest tests/test_gpu_h16.py tests/test_gpu_bsrn.py tests/test_gpu_big.py tests/test_gpu_multi.py -m gpu -x -q 2>&1 | tail -6
 python tools/dbg/batch_eq.py - 2>&1 | grep -E "equal|DIFF"
-for m in "team18_bsrn f16 --tile 270x480" "team04_rlfn bf16" "team18_bsrn bf16 --tile 270x480"; do
-for v in 0 1; do if [ $v = 1 ]; then export ESR_NO_CONV48R=1; else unset ESR_NO_CONV48R; fi
-  set -- $m; python bench.py --model $1 --compute $2 $3 $4 --no-cpu-baseline --steps 20 > /tmp/b.json 2>/dev/null; python tools/show_bench.py /tmp/b.json | head -6 | cut -c1-150; done; done
+for m in "team18_bsrn f16 --tile 270x480" "team04_rlfn bf16" "team04_rlfn bf16 --sizes div2k --streams 1" "team18_bsrn f16 --sizes div2k --streams 1"; do
+  set -- $m; python bench.py --model $1 --compute $2 $3 $4 $5 $6 --no-cpu-baseline --steps 20 > /tmp/b.json 2>/dev/null; python tools/show_bench.py /tmp/b.json | head -4 | cut -c1-170; done

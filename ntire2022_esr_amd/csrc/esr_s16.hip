@@ -969,14 +969,15 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
     const bool has_border = EXT && p.border != nullptr, res_in = EXT && p.res_in != 0, gelu = EXT && p.act == ESR_ACT_GELU;
 
     // ---- the weights: registers for the life of the block ---------------------------------------------------------------------
+    // (the blob goes global -> LDS ONCE per block -- stage 1 is free until the first tile's DMA issue -- and from there into each wave's
+    // registers: read straight from global by all four waves it was 180 KB per block, 46 MB per launch on a single DIV2K image)
+    constexpr int WPIECES = NCH * PAIRS * NT;      // 1 KB fragments
+#pragma unroll
+    for (int i = 0; i < (WPIECES + 3) / 4; ++i) {
+        const int pc = wv + 4 * i;
+        if (pc < WPIECES) dma_glb16(smem_lds + (unsigned)(STAGE + pc * 1024), p.wp + (size_t)pc * 1024 + lane * 16);
+    }
     i32x4 wr[NCH][PAIRS][NT];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int q = 0; q < PAIRS; ++q)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                wr[c][q][t] = *reinterpret_cast<const i32x4*>(p.wp + (size_t)((c * PAIRS + q) * NT + t) * 1024 + lane * 16);
     f32x4 bia[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bia[t] = *reinterpret_cast<const f32x4*>(p.bias + t * 16 + kq * 4);
@@ -1044,6 +1045,15 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                wr[c][q][t] = *reinterpret_cast<const i32x4*>(smem + STAGE + ((c * PAIRS + q) * NT + t) * 1024 + lane * 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // every wave holds its fragments: stage 1 may be overwritten
 
     // lane-constant offsets of the B fragments: pair q reads tap min(2q + (kq >> 1), 8), channel half kq & 1 of the chunk
     int b_off[PAIRS];

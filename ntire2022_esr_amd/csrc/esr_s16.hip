@@ -1239,6 +1239,313 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the trailing zero-fill DMA must not outlive the block)
 }
 
+// ---- conv48rp_kernel: RLFB's c3_r -- a 48 -> 48 3x3 + LeakyReLU + the block input (residual from HBM, post-activation), whose result
+// only feeds a chain of two 1x1 convolutions (c5 48 -> 48, esa.conv1 48 -> 16: team04_rlfn.py:117-121, 76) -- on conv48r_kernel's plan:
+// weights in accumulation registers, whole-pixel stages, row pairs, the finished pair's epilogue between the next pair's MFMA groups.
+// What the shape adds:
+//   * 16 x 16 tiles (a wave owns 4 rows = two pairs): input stage 18 x 18 x 96 B = 31 KB, and a RESIDUAL stage of the tile's own 16 x 16
+//     pixels (24 KB) next to it, both double-buffered.  A wave stages exactly its own four residual rows (6 pieces) and is their only
+//     reader, so the residual needs no barrier of its own; its DMA for the next tile is issued behind the groups in which the carried
+//     epilogue (the previous tile's last pair) reads the slot it overwrites;
+//   * the post images (18 + 6 KB, hi + lo for bf16) are resident in LDS; the chain runs row by row on the fp32 values exactly as
+//     conv_s16_kernel's swap_epi_act does (same order of MFMAs: results are bit-identical);
+//   * per tile and wave 8 + 6 DMA pieces in the first pair's groups, four stores per pair; the tile closes with ONE counted wait.
+template <bool BF16>
+__global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
+{
+    constexpr int NT = 3, NCH = 3, PAIRS = 5, TH = 18, THY = 18, RW = 4, PNT1 = 3;
+    constexpr int PIXB = NCH * 32;
+    constexpr int NSLOT = TH * THY * (PIXB / 16);  // 1944
+    constexpr int NPIECES = (NSLOT + 63) / 64;     // 31
+    constexpr int STAGE = NPIECES * 1024;          // 31 744
+    constexpr int RSTAGE = 16 * 16 * PIXB;         // 24 576: the tile's own pixels of the residual, [row][px][96 B]
+    constexpr int RPW = RSTAGE / 4 / 1024;         // 6 pieces per wave: its own four rows
+    constexpr int IPW = (NPIECES + 3) / 4;         // 8 input pieces per wave (wave 3: 7)
+    constexpr int NG = NCH * PAIRS;
+    constexpr int P1_IMG = NT * PNT1 * 1024, P2_IMG = PNT1 * 1024;
+    constexpr int OFF_RES = 2 * STAGE, OFF_POST = OFF_RES + 2 * RSTAGE;       // LDS map: [input x 2][residual x 2][P1 hi, lo][P2 hi, lo]
+    static_assert(IPW + RPW <= NG - 1, "DMA pieces fit the first pair's groups");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, kq = lane >> 4;
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    constexpr bool plo = BF16;                    // bf16: hi + lo post images (the host takes this kernel only when conv_s16_kernel would use them too)
+    const bool res_post = p.res_mode == ESR_RES_POST_ACT;
+
+    // ---- prologue: conv weights through the (still unused) residual stages into registers, post images to their place ----------
+    constexpr int WPIECES = NCH * PAIRS * NT;      // 45 <= 48 KB of residual stages
+#pragma unroll
+    for (int i = 0; i < (WPIECES + 3) / 4; ++i) {
+        const int pc = wv + 4 * i;
+        if (pc < WPIECES) dma_glb16(smem_lds + (unsigned)(OFF_RES + pc * 1024), p.wp + (size_t)pc * 1024 + lane * 16);
+    }
+    for (int pc = wv; pc < 2 * (P1_IMG / 1024); pc += 4) dma_glb16(smem_lds + (unsigned)(OFF_POST + pc * 1024), p.pw1 + (size_t)pc * 1024 + lane * 16);
+    for (int pc = wv; pc < 2 * (P2_IMG / 1024); pc += 4) dma_glb16(smem_lds + (unsigned)(OFF_POST + 2 * P1_IMG + pc * 1024), p.pw2 + (size_t)pc * 1024 + lane * 16);
+    i32x4 wr[NCH][PAIRS][NT];
+    f32x4 bia[NT], pb1[PNT1], pb2;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bia[t] = *reinterpret_cast<const f32x4*>(p.bias + t * 16 + kq * 4);
+#pragma unroll
+    for (int t = 0; t < PNT1; ++t) pb1[t] = *reinterpret_cast<const f32x4*>(p.pw1 + (size_t)2 * P1_IMG + (t * 16 + kq * 4) * 4);
+    pb2 = *reinterpret_cast<const f32x4*>(p.pw2 + (size_t)2 * P2_IMG + (kq * 4) * 4);
+    const char* const img1 = smem + OFF_POST + lane * 16;                     // hi [k tile][out tile], lo at + P1_IMG
+    const char* const img2 = smem + OFF_POST + 2 * P1_IMG + lane * 16;        // hi [k tile], lo at + P2_IMG
+
+    const int ntiles = p.N * p.tiles_y * p.tiles_x;
+    const int G = gridDim.x;
+    auto tile_index = [&](int k) -> int {
+        const int base = k * G;
+        if (base >= ntiles) return -1;
+        int off = blockIdx.x;
+        if ((G & 7) == 0 && base + G <= ntiles) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+        const int t = base + off;
+        return t < ntiles ? t : -1;
+    };
+    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) {
+        const unsigned mx = p.magic_x, my = p.magic_y;
+        const int tq = mx ? (int)__umulhi((unsigned)t, mx) : t;
+        const int tx = t - tq * p.tiles_x;
+        n = my ? (int)__umulhi((unsigned)tq, my) : tq;
+        const int ty = tq - n * p.tiles_y;
+        x0 = tx * TILE;
+        y0 = ty * 16;
+    };
+    const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 2, res_bytes = (size_t)p.H * p.W * p.res_pitch * 2;
+    auto dma_in = [&](int i, bool valid, int n, int x0, int y0, int slot) __attribute__((always_inline)) {
+        const int pc = wv + 4 * i;
+        if (i < IPW - 1 || pc < NPIECES) {                             // wave-uniform
+            const unsigned sl = (unsigned)(pc * 64 + lane);
+            const unsigned pixel = sl / 6u, part = sl - pixel * 6u;
+            const unsigned ly = pixel / (unsigned)TH, lx = pixel - ly * (unsigned)TH;
+            const int gy = y0 - 1 + (int)ly, gx = x0 - 1 + (int)lx;
+            const bool ok = valid && sl < (unsigned)NSLOT && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const unsigned voff = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff) * 2u + part * 16u : OOB;
+            dma_buf16(smem_lds + (unsigned)(slot * STAGE + pc * 1024), voff, make_rsrc(p.x + (size_t)(valid ? n : 0) * img_bytes, img_bytes), 0u);
+        }
+    };
+    auto dma_res = [&](int i, bool valid, int n, int x0, int y0, int slot) __attribute__((always_inline)) {      // piece i (< 6) of this wave's own rows
+        const unsigned sl = (unsigned)((wv * RPW + i) * 64 + lane);     // slot of the residual stage: pixel sl / 6 = 16 row + col
+        const unsigned pixel = sl / 6u, part = sl - pixel * 6u;
+        const int gy = y0 + (int)(pixel >> 4), gx = x0 + (int)(pixel & 15u);
+        const bool ok = valid && gy < p.H && gx < p.W;
+        const unsigned voff = ok ? (unsigned)((gy * p.W + gx) * p.res_pitch + p.res_coff) * 2u + part * 16u : OOB;
+        dma_buf16(smem_lds + (unsigned)(OFF_RES + slot * RSTAGE + (wv * RPW + i) * 1024), voff, make_rsrc(p.res + (size_t)(valid ? n : 0) * res_bytes, res_bytes), 0u);
+    };
+
+    int n, x0, y0;
+    {
+        const int t0 = tile_index(0);
+        if (t0 < 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+        tile_coords(t0, n, x0, y0);
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) dma_in(i, true, n, x0, y0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                wr[c][q][t] = *reinterpret_cast<const i32x4*>(smem + OFF_RES + ((c * PAIRS + q) * NT + t) * 1024 + lane * 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // every wave holds its fragments: the residual stages may be written
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) dma_res(i, true, n, x0, y0, 0);             // the first tile's residual (its wait: the first tile's end)
+
+    int b_off[PAIRS];
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+        const int tap = min(2 * q + (kq >> 1), 8);
+        b_off[q] = ((wv * RW + tap / 3) * TH + px + tap % 3) * PIXB + (kq & 1) * 16;
+    }
+    const int r_off = ((wv * RW) * 16 + px) * PIXB + kq * 8;                 // residual of row 0 of the wave: channels 16 t + 4 kq .. at + 32 t
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 {
+        const u32x2 a = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
+        const u32x2 b = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
+        return i32x4{(int)a.x, (int)b.x, (int)a.y, (int)b.y};
+    };
+    auto hilo = [&](f32x4 v) __attribute__((always_inline)) -> i32x4 {
+        const unsigned h0 = pack2<BF16>(v.x, v.y), h1 = pack2<BF16>(v.z, v.w);
+        if (!BF16) return i32x4{(int)h0, (int)h1, 0, 0};
+        float a, b, c, d;
+        unpack2<BF16>(h0, a, b);
+        unpack2<BF16>(h1, c, d);
+        return i32x4{(int)h0, (int)h1, (int)pack2<BF16>(v.x - a, v.y - b), (int)pack2<BF16>(v.z - c, v.w - d)};
+    };
+    const float slope = p.slope, p1s = p.p1_slope;
+    const size_t p1_img = (size_t)p.H * p.W * p.py1_pitch * 2, p2_img = (size_t)p.H * p.W * p.py2_pitch * 2;
+    const unsigned rowb1 = (unsigned)p.W * (unsigned)p.py1_pitch * 2u, rowb2 = (unsigned)p.W * (unsigned)p.py2_pitch * 2u;
+
+    f32x4 acc[2][NT][2];
+    // the finished pair's fp32 values (act(conv) + residual, then c5's result) live in ITS accumulators -- free until the pair after next
+    // starts; the rounded post results in named registers
+    uint2 q00, q01, q10, q11, q20, q21, z0, z1;
+    auto PK1 = [&](int t, int e) __attribute__((always_inline)) -> uint2& { return t == 0 ? (e ? q01 : q00) : (t == 1 ? (e ? q11 : q10) : (e ? q21 : q20)); };
+    auto PK2 = [&](int e) __attribute__((always_inline)) -> uint2& { return e ? z1 : z0; };
+    unsigned e_vA = OOB, e_vB = OOB, e_v2 = OOB;
+    int e_n = 0, e_slot = 0;             // image / residual stage of the tile whose epilogue is in flight
+    auto epi_res = [&](int par, int f, int r) __attribute__((always_inline)) {   // fragment f = 2 t + e of the finished pair (first row r)
+        const int t = f >> 1, e = f & 1;
+        f32x4 v = acc[par][t][e];
+        const f32x4 rf = unpack4<BF16>(*reinterpret_cast<const uint2*>(smem + OFF_RES + e_slot * RSTAGE + r_off + t * 32 + (r + e) * (16 * PIXB)));
+        if (!res_post) v += rf;
+        v.x = act1(v.x, slope); v.y = act1(v.y, slope); v.z = act1(v.z, slope); v.w = act1(v.w, slope);
+        if (res_post) v += rf;
+        acc[par][t][e] = v;
+    };
+    auto epi_post1 = [&](int par, int e) __attribute__((always_inline)) {                 // c5 on row e: d1 stays in u[.][e] (fp32) for post 2
+        f32x4 d1[PNT1];
+#pragma unroll
+        for (int ot = 0; ot < PNT1; ++ot) d1[ot] = pb1[ot];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const i32x4 bsv = hilo(acc[par][kt][e]);
+#pragma unroll
+            for (int ot = 0; ot < PNT1; ++ot) {
+                d1[ot] = mfma32<BF16>(*reinterpret_cast<const i32x4*>(img1 + (kt * PNT1 + ot) * 1024), bsv, d1[ot]);
+                if (plo) d1[ot] = mfma32<BF16>(*reinterpret_cast<const i32x4*>(img1 + P1_IMG + (kt * PNT1 + ot) * 1024), bsv, d1[ot]);
+            }
+        }
+#pragma unroll
+        for (int ot = 0; ot < PNT1; ++ot) {
+            f32x4 v = d1[ot];
+            v.x = act1(v.x, p1s); v.y = act1(v.y, p1s); v.z = act1(v.z, p1s); v.w = act1(v.w, p1s);
+            acc[par][ot][e] = v;
+            PK1(ot, e).x = pack2<BF16>(v.x, v.y);
+            PK1(ot, e).y = pack2<BF16>(v.z, v.w);
+        }
+    };
+    auto epi_post2 = [&](int par, int e) __attribute__((always_inline)) {                 // esa.conv1 on c5's fp32 result of row e
+        f32x4 d2 = pb2;
+#pragma unroll
+        for (int kt = 0; kt < PNT1; ++kt) {
+            const i32x4 bsv = hilo(acc[par][kt][e]);
+            d2 = mfma32<BF16>(*reinterpret_cast<const i32x4*>(img2 + kt * 1024), bsv, d2);
+            if (plo) d2 = mfma32<BF16>(*reinterpret_cast<const i32x4*>(img2 + P2_IMG + kt * 1024), bsv, d2);
+        }
+        PK2(e).x = pack2<BF16>(d2.x, d2.y);
+        PK2(e).y = pack2<BF16>(d2.z, d2.w);
+    };
+    auto epi_store = [&](int i, int r) __attribute__((always_inline)) {           // the pair's four stores
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(p.py1 + (size_t)e_n * p1_img, 0, (int)p1_img, 0x00020000);
+        if (i == 0) __builtin_amdgcn_raw_buffer_store_b128(swap16(q00, q10), r1, e_vA + (unsigned)r * rowb1, 0, 0);
+        else if (i == 1) __builtin_amdgcn_raw_buffer_store_b128(swap16(q01, q11), r1, e_vA + (unsigned)(r + 1) * rowb1, 0, 0);
+        else if (i == 2) __builtin_amdgcn_raw_buffer_store_b128(swap16(q20, q21), r1, e_vB + (unsigned)r * rowb1, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(swap16(z0, z1), __builtin_amdgcn_make_buffer_rsrc(p.py2 + (size_t)e_n * p2_img, 0, (int)p2_img, 0x00020000),
+                                                    e_v2 + (unsigned)r * rowb2, 0, 0);
+    };
+    auto store_offsets = [&](int nn_, int x0_, int y0_, int slot_) __attribute__((always_inline)) {
+        const bool inx = x0_ + px < p.W;
+        const unsigned pix = (unsigned)((y0_ + wv * RW) * p.W + x0_ + px);
+        const unsigned b1 = (pix * (unsigned)p.py1_pitch + (unsigned)p.py1_coff) * 2u, b2 = (pix * (unsigned)p.py2_pitch + (unsigned)p.py2_coff) * 2u;
+        const int chA = (kq & 1) * 16 + (kq >> 1) * 8, chB = 32 + (kq >> 1) * 8, ch2 = (kq >> 1) * 8;
+        e_vA = (inx && chA < p.p1_cout8) ? b1 + (unsigned)chA * 2u : OOB;
+        e_vB = (inx && chB < p.p1_cout8) ? b1 + (unsigned)chB * 2u + ((kq & 1) ? rowb1 : 0u) : OOB;
+        e_v2 = (inx && ch2 < p.p2_cout8) ? b2 + (unsigned)ch2 * 2u + ((kq & 1) ? rowb2 : 0u) : OOB;
+        e_n = nn_; e_slot = slot_;
+    };
+    bool pend = false;
+    for (int k = 0;; ++k) {
+        const int tn = tile_index(k + 1);
+        const bool more = tn >= 0;
+        int nn = 0, nx0 = 0, ny0 = 0;
+        if (more) tile_coords(tn, nn, nx0, ny0);
+        const char* sb = smem + (k & 1) * STAGE;
+        constexpr int AHEAD = 3;
+        i32x4 b[4][2];
+        auto read_b = [&](int L) __attribute__((always_inline)) {
+            const int rp_ = L / NG, g_ = L % NG, c_ = g_ / PAIRS, q_ = g_ % PAIRS;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) b[L & 3][e] = *reinterpret_cast<const i32x4*>(sb + b_off[q_] + c_ * 32 + (2 * rp_ + e) * (TH * PIXB));
+        };
+#pragma unroll
+        for (int L = 0; L < AHEAD; ++L) read_b(L);
+        // (one lambda instance per row pair: as ONE doubly unrolled loop the body exceeded hipcc's full-unroll budget, the loops stayed
+        // rolled and accumulators / fragment ring were indexed dynamically -- through scratch)
+        auto run_pair = [&](auto rp_tag) __attribute__((always_inline)) {
+            constexpr int rp = decltype(rp_tag)::value;
+            constexpr int par = rp & 1;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int c = g / PAIRS, q = g % PAIRS, L = rp * NG + g, cs = L & 3;
+                if (L + AHEAD < (RW / 2) * NG) read_b(L + AHEAD);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if (g == 0) {
+                            if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=v"(acc[par][t][e]) : "a"(wr[c][q][t]), "v"(b[cs][e]), "v"(bia[t]));
+                            else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=v"(acc[par][t][e]) : "a"(wr[c][q][t]), "v"(b[cs][e]), "v"(bia[t]));
+                        } else {
+                            if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "a"(wr[c][q][t]), "v"(b[cs][e]));
+                            else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "a"(wr[c][q][t]), "v"(b[cs][e]));
+                        }
+                    }
+                // the next tile's DMA in the first pair: input pieces first, the wave's residual rows behind the groups (1 .. 6) in which the
+                // carried epilogue reads the residual stage they overwrite
+                if (rp == 0 && g < IPW) dma_in(g, more, nn, nx0, ny0, (k + 1) & 1);
+                if (rp == 0 && g >= IPW && g < IPW + RPW) dma_res(g - IPW, more, nn, nx0, ny0, (k + 1) & 1);
+                if (rp > 0 || pend) {
+                    const int r_prev = rp == 0 ? RW - 2 : 2 * rp - 2;
+                    if (g >= 1 && g <= 6) epi_res(par ^ 1, g - 1, r_prev);
+                    if (g == 7) epi_post1(par ^ 1, 0);
+                    if (g == 8) epi_post2(par ^ 1, 0);
+                    if (g == 9) epi_post1(par ^ 1, 1);
+                    if (g == 10) epi_post2(par ^ 1, 1);
+                    if (g >= 11) epi_store(g - 11, r_prev);
+                }
+                if (rp == 1 && g == 0) store_offsets(n, x0, y0, k & 1);            // (behind the carried epilogue's last store, ahead of this tile's first)
+            }
+        };
+        run_pair(std::integral_constant<int, 0>{});
+        run_pair(std::integral_constant<int, 1>{});
+        // the next tile's stages have landed: younger than their last DMA piece (group 13 of the first pair) are the carried epilogue's
+        // stores of groups 13, 14 and the four stores of this tile's first pair
+        if (pend) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        pend = true;
+        if (!more) break;
+        n = nn; x0 = nx0; y0 = ny0;
+    }
+    // the last tile's last pair (its residual stage: e_slot)
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+#pragma unroll
+    for (int f = 0; f < 2 * NT; ++f) epi_res(1, f, RW - 2);
+    epi_post1(1, 0); epi_post2(1, 0); epi_post1(1, 1); epi_post2(1, 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) epi_store(i, RW - 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool BF16>
+int launch_conv48rp(const S16K& k, hipStream_t st)
+{
+    constexpr int LDS = 2 * 31 * 1024 + 2 * 24576 + 2 * 9 * 1024 + 2 * 3 * 1024;
+    static std::atomic<unsigned> attr_set[MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
+    if (!attr_set[dev].load(std::memory_order_relaxed)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv48rp_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            esr_set_err("hipFuncSetAttribute(conv48rp_kernel, MaxDynamicSharedMemorySize)", e);
+            return ESR_ERR_LAUNCH;
+        }
+        attr_set[dev].store(1u, std::memory_order_relaxed);
+    }
+    const int ntiles = k.N * k.tiles_x * k.tiles_y;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    esr_note_kernel("conv48rp_kernel<%s>", esr_tf(BF16));
+    hipLaunchKernelGGL((conv48rp_kernel<BF16>), dim3(grid), dim3(256), LDS, st, k);
+    return esr_check_launch("conv48rp_kernel launch");
+}
+
 template <bool BF16, int NT, int PNT1, bool EXT>
 int launch_conv48r(const S16K& k, hipStream_t st)
 {
@@ -1360,11 +1667,30 @@ static bool conv48r_takes(const esr_conv_desc* d)
     return (long)d->n * ((d->w + TILE - 1) / TILE) * ((d->h + 31) / 32) >= 256;
 }
 
-// 1: conv48r_kernel (one 4-wave block per CU, weights in registers), 4: conv_s16_kernel's two-blocks-per-CU shape (4 waves, 16 x 16
-// tiles), 8: one 8-wave block per CU on 16 x 32 tiles
+int s16_post_plan(const esr_conv_desc* d, int nt, int nchunks, int* pnt1, int* pnt2, int* post_lo, int* ring, size_t* lds);
+
+// conv48rp_kernel's descriptors: RLFB's c3_r -- 48 -> 48 (3 chunks, 3 tiles) with a residual from HBM that is not the input, the conv's
+// own result not stored, a post chain of 3 + 1 tiles without GELU -- on SMALL launches: between 256 tiles of 16 x 16 and 1024 of 16 x 32.
+// Measured (tools/gpu_c48p.sh): one 339 x 510 image 30.7 against conv_s16_kernel's 38.6 us, but 0.287 against 0.270 ms at 32 x 256 x 256.
+static bool conv48rp_takes(const esr_conv_desc* d)
+{
+    const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
+    if (d->ksize != 3 || nchunks != 3 || nt != 3 || d->out_layout != ESR_NHWC || d->in_seg_stride != 0 || !d->post_wpacked || !d->post2_wpacked) return false;
+    if (d->out0.ptr || d->border_bias || d->act == ESR_ACT_GELU || d->post_act == ESR_ACT_GELU) return false;
+    if (d->res_mode == ESR_RES_NONE || s16_res_is_input(d)) return false;
+    int pnt1 = 0, pnt2 = 0, post_lo = 0, ring = 0;
+    size_t lds = 0;
+    if (s16_post_plan(d, nt, nchunks, &pnt1, &pnt2, &post_lo, &ring, &lds) != ESR_OK) return false;
+    if (pnt1 != 3 || pnt2 != 1 || post_lo != (d->storage == ESR_STORE_BF16 ? 1 : 0)) return false;
+    const long tx = (d->w + TILE - 1) / TILE;
+    return (long)d->n * tx * ((d->h + 15) / 16) >= 256 && (long)d->n * tx * ((d->h + 31) / 32) < 1024;
+}
+
+// 1: conv48r_kernel / conv48rp_kernel (one 4-wave block per CU, weights in registers), 4: conv_s16_kernel's two-blocks-per-CU shape (4
+// waves, 16 x 16 tiles), 8: one 8-wave block per CU on 16 x 32 tiles
 int s16_block_waves(const esr_conv_desc* d)
 {
-    if (conv48r_takes(d)) return 1;
+    if (conv48r_takes(d) || conv48rp_takes(d)) return 1;
     const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
     const bool res_hbm = d->res_mode != ESR_RES_NONE && !s16_res_is_input(d);
     if (d->ksize != 3 || nt != 3 || d->border_bias || d->post_wpacked || res_hbm || d->out_layout != ESR_NHWC || d->in_seg_stride != 0) return 8;
@@ -1734,6 +2060,15 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     k.seg_chunks = segmented ? d->in_seg_chunks : nchunks;
     k.seg_stride = segmented ? d->in_seg_stride : 0;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (conv48rp_takes(d)) {
+        // RLFB c3_r (+ block input) -> c5 -> esa.conv1 on 16 x 16 tiles
+        S16K kp = k;
+        kp.tiles_y = (d->h + 15) / 16;
+        kp.magic_y = kp.tiles_y > 1 ? (unsigned)((0x100000000ull + kp.tiles_y - 1) / kp.tiles_y) : 0u;
+        const double nt_all = (double)d->n * kp.tiles_x * kp.tiles_y;
+        if (nt_all * (kp.tiles_x > kp.tiles_y ? kp.tiles_x : kp.tiles_y) < 4294967296.0)
+            return bf16 ? launch_conv48rp<true>(kp, st) : launch_conv48rp<false>(kp, st);
+    }
     if (conv48r_takes(d)) {
         // (a post chain stays on conv_s16_kernel: the PNT1 = 2 instantiation -- ESDB c{j}_r + the next distillation 1x1, two GELUs per
         // pixel -- measured 0.396 against 0.368 ms at 32 x 270 x 480: with ONE wave per SIMD the ~380 VALU instructions of a row pair's

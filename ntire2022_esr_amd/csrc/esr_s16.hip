@@ -946,21 +946,25 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
 // its chunk's groups, the border-bias table and GELU; PNT1 = 2 the distillation 1x1 (+ GELU) of the finished rows (esr_conv_desc.post_*).
 // Same packed weights, fragment maps, operation order and rounding as conv_s16_kernel: results are bit-identical (a batch takes this
 // kernel, a single small image conv_s16_kernel: test_16bit_batch_equals_per_image).
-template <bool BF16, int NT, int PNT1, bool EXT>
+template <bool BF16, int NT, int PNT1, bool EXT, int RW = 8>
 __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
 {
-    constexpr int NCH = 3, PAIRS = 5, TH = 18, THY = 34, RW = 8;
+    // RW = rows per wave: 8 (16 x 32 tiles) or 4 (16 x 16 tiles: small launches -- one DIV2K image is 352 large tiles on 256 CUs, two rounds of
+    // which the second fills 37 % of the chip, but 704 small ones; the next tile's DMA then has less time to land, which is why batches keep 8)
+    constexpr int NCH = 3, PAIRS = 5, TH = 18, THY = 4 * RW + 2;
     constexpr int PIXB = NCH * 32;                 // 96 bytes per staged pixel
     constexpr int NSLOT = TH * THY * (PIXB / 16);  // 3672 16-byte slots
-    constexpr int NPIECES = (NSLOT + 63) / 64;     // 58 DMA pieces of 1 KB
+    constexpr int NPIECES = (NSLOT + 63) / 64;     // 58 (RW = 4: 31) DMA pieces of 1 KB
     constexpr int STAGE = NPIECES * 1024;
-    constexpr int PPW = (NPIECES + 3) / 4;         // 15 per wave (waves 2, 3: 14)
+    constexpr int PPW = (NPIECES + 3) / 4;         // 15 (8) per wave, the last waves one fewer
     constexpr int NG = NCH * PAIRS;                // tap-pair groups per row pair
     constexpr int MAIN_ST = NT == 3 ? 3 : 2, POST_ST = PNT1 > 0 ? 2 : 0, SPP = MAIN_ST + POST_ST;   // stores per row pair
-    static_assert(PPW == NG, "one DMA piece per tap-pair group");
+    static_assert(PPW <= NG && (RW == 8 || RW == 4), "at most one DMA piece per tap-pair group of the first row pair");
     static_assert((NT == 2 || NT == 3) && (PNT1 == 0 || PNT1 == 2), "shapes");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    float* const btab = reinterpret_cast<float*>(smem + 2 * STAGE);          // border bias table [16][NT * 16] (EXT && p.border)
+    constexpr int WSTAGE = RW == 8 ? STAGE : 2 * STAGE;                        // where the weight blob (<= 45 KB) is staged before the first tile
+    constexpr int BT_OFF = RW == 8 ? 2 * STAGE : 2 * STAGE + NCH * PAIRS * NT * 1024;   // RW = 8: the blob is staged in input stage 1; RW = 4: behind both stages
+    float* const btab = reinterpret_cast<float*>(smem + BT_OFF);               // border bias table [16][NT * 16] (EXT && p.border)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -975,7 +979,7 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
 #pragma unroll
     for (int i = 0; i < (WPIECES + 3) / 4; ++i) {
         const int pc = wv + 4 * i;
-        if (pc < WPIECES) dma_glb16(smem_lds + (unsigned)(STAGE + pc * 1024), p.wp + (size_t)pc * 1024 + lane * 16);
+        if (pc < WPIECES) dma_glb16(smem_lds + (unsigned)(WSTAGE + pc * 1024), p.wp + (size_t)pc * 1024 + lane * 16);
     }
     i32x4 wr[NCH][PAIRS][NT];
     f32x4 bia[NT];
@@ -1018,7 +1022,7 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
         n = my ? (int)__umulhi((unsigned)tq, my) : tq;
         const int ty = tq - n * p.tiles_y;
         x0 = tx * TILE;
-        y0 = ty * 32;
+        y0 = ty * (4 * RW);
     };
     const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 2;
     // piece i of this wave of the tile (n, x0, y0) into stage `slot`; nothing valid (behind the last tile): zeros
@@ -1051,7 +1055,7 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
         for (int q = 0; q < PAIRS; ++q)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                wr[c][q][t] = *reinterpret_cast<const i32x4*>(smem + STAGE + ((c * PAIRS + q) * NT + t) * 1024 + lane * 16);
+                wr[c][q][t] = *reinterpret_cast<const i32x4*>(smem + WSTAGE + ((c * PAIRS + q) * NT + t) * 1024 + lane * 16);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                 // every wave holds its fragments: stage 1 may be overwritten
 
@@ -1149,7 +1153,7 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
         int nn = 0, nx0 = 0, ny0 = 0;
         if (more) tile_coords(tn, nn, nx0, ny0);
         const char* sb = smem + (k & 1) * STAGE;
-        const bool on_border = has_border && (x0 == 0 || x0 + TILE >= p.W || y0 == 0 || y0 + 32 >= p.H);
+        const bool on_border = has_border && (x0 == 0 || x0 + TILE >= p.W || y0 == 0 || y0 + 4 * RW >= p.H);
         // B fragments: a ring of four (two rows each), read THREE groups ahead of their MFMAs (a group is 2 NT MFMAs = ~100 cycles, an
         // LDS read returns after ~130): linear group index L = 15 rp + g over the tile's 60 groups
         constexpr int AHEAD = 3;
@@ -1188,7 +1192,7 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
                             else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "a"(wr[c][q][t]), "v"(b[cs][e]));
                         }
                     }
-                if (rp == 0) dma_piece(g, more, nn, nx0, ny0, (k + 1) & 1);      // the next tile's DMA, in the shadow of the matrix pipe
+                if (rp == 0 && g < PPW) dma_piece(g, more, nn, nx0, ny0, (k + 1) & 1);      // the next tile's DMA, in the shadow of the matrix pipe
                 // the previous row pair's epilogue (rp == 0: the previous TILE's last pair), one piece per group: its accumulators were
                 // last written 15 groups ago
                 if (rp > 0 || pend) {
@@ -1222,8 +1226,8 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
                 }
             }
         }
-        // the next tile has landed: younger than its DMA are the stores of this tile's first three row pairs
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * SPP) : "memory");
+        // the next tile has landed: younger than its DMA are the stores of this tile's row pairs but the last
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RW / 2 - 1) * SPP) : "memory");
         __builtin_amdgcn_s_barrier();
         pend = true;
         if (!more) break;
@@ -1546,15 +1550,17 @@ int launch_conv48rp(const S16K& k, hipStream_t st)
     return esr_check_launch("conv48rp_kernel launch");
 }
 
-template <bool BF16, int NT, int PNT1, bool EXT>
+template <bool BF16, int NT, int PNT1, bool EXT, int RW = 8>
 int launch_conv48r(const S16K& k, hipStream_t st)
 {
-    const int LDS = 2 * 58 * 1024 + ((EXT && k.border) ? NT * 1024 : 0);
+    // [two input stages][RW = 4: 45 KB where the weight blob is staged][border table]
+    constexpr int STAGES = RW == 8 ? 2 * 58 * 1024 : 2 * 31 * 1024 + 15 * NT * 1024;
+    const int LDS = STAGES + ((EXT && k.border) ? NT * 1024 : 0);
     static std::atomic<unsigned> attr_set[MAX_DEVICES];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
     if (!attr_set[dev].load(std::memory_order_relaxed)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv48r_kernel<BF16, NT, PNT1, EXT>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 58 * 1024 + NT * 1024);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv48r_kernel<BF16, NT, PNT1, EXT, RW>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGES + NT * 1024);
         if (e != hipSuccess) {
             esr_set_err("hipFuncSetAttribute(conv48r_kernel, MaxDynamicSharedMemorySize)", e);
             return ESR_ERR_LAUNCH;
@@ -1563,8 +1569,8 @@ int launch_conv48r(const S16K& k, hipStream_t st)
     }
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int grid = ntiles < 256 ? ntiles : 256;
-    esr_note_kernel("conv48r_kernel<%s, %d, %d, %s>", esr_tf(BF16), NT, PNT1, esr_tf(EXT));
-    hipLaunchKernelGGL((conv48r_kernel<BF16, NT, PNT1, EXT>), dim3(grid), dim3(256), LDS, st, k);
+    esr_note_kernel("conv48r_kernel<%s, %d, %d, %s, %d>", esr_tf(BF16), NT, PNT1, esr_tf(EXT), RW);
+    hipLaunchKernelGGL((conv48r_kernel<BF16, NT, PNT1, EXT, RW>), dim3(grid), dim3(256), LDS, st, k);
     return esr_check_launch("conv48r_kernel launch");
 }
 
@@ -2074,6 +2080,15 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         // pixel -- measured 0.396 against 0.368 ms at 32 x 270 x 480: with ONE wave per SIMD the ~380 VALU instructions of a row pair's
         // epilogue have to fit the shadow of its 102 MFMAs exactly, conv_s16_kernel's second wave absorbs them)
         const bool ext = k.border != nullptr || k.res_in || d->act == ESR_ACT_GELU;
+        if ((long)d->n * k.tiles_x * k.tiles_y < 1024) {
+            // small launches (single images): 16 x 16 tiles
+            S16K k4 = k;
+            k4.tiles_y = (d->h + 15) / 16;
+            k4.magic_y = k4.tiles_y > 1 ? (unsigned)((0x100000000ull + k4.tiles_y - 1) / k4.tiles_y) : 0u;
+            if (nt == 2) return bf16 ? launch_conv48r<true, 2, 0, true, 4>(k4, st) : launch_conv48r<false, 2, 0, true, 4>(k4, st);
+            if (ext) return bf16 ? launch_conv48r<true, 3, 0, true, 4>(k4, st) : launch_conv48r<false, 3, 0, true, 4>(k4, st);
+            return bf16 ? launch_conv48r<true, 3, 0, false, 4>(k4, st) : launch_conv48r<false, 3, 0, false, 4>(k4, st);
+        }
         if (nt == 2) return bf16 ? launch_conv48r<true, 2, 0, true>(k, st) : launch_conv48r<false, 2, 0, true>(k, st);
         if (ext) return bf16 ? launch_conv48r<true, 3, 0, true>(k, st) : launch_conv48r<false, 3, 0, true>(k, st);
         return bf16 ? launch_conv48r<true, 3, 0, false>(k, st) : launch_conv48r<false, 3, 0, false>(k, st);

@@ -294,7 +294,9 @@ def test_network_psnr_shift(mid, compute, max_dpsnr):
     (48, 48, 3, True, True, (128, 128), 8),        # ESDB c{j}_r as a dense BSConvU: + input, border table, GELU
     (48, 48, 3, True, True, (90, 130), 12),
     (48, 24, 3, False, True, (128, 128), 8),       # ESDB c4: two output tiles
-    (48, 48, 0, True, False, (128, 128), 8)])      # residual == input without activation
+    (48, 48, 0, True, False, (128, 128), 8),       # residual == input without activation
+    (48, 48, 1, False, False, (128, 128), 32),     # >= 1024 tiles of 16 x 32: the 8-rows-per-wave shape (the others: 16 x 16 tiles)
+    (48, 48, 3, True, True, (128, 120), 33)])
 def test_conv48r_equals_conv_s16(compute, cin, cout, act, res_in, border, hw, n):
     """conv48r_kernel (3x3 over 48 physical input channels, >= 256 tiles of 16 x 32: weights in registers, one wave per SIMD, row pairs
     as the outer loop) against conv_s16_kernel: the batch takes the new kernel (esr_conv_block_waves == 1), each image alone the old

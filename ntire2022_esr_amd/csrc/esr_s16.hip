@@ -943,7 +943,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
 //     nothing of the epilogue is exposed; (b) the next tile's 58 DMA pieces are all issued during the FIRST pair, three quarters of a
 //     tile ahead of their wait; (c) B fragments (one ds_read_b128 feeds NT MFMAs) are read three groups ahead through a ring of four.
 // EXT adds what ESDB's dense BSConvU needs, in conv_s16_kernel's order of operations: the residual == input from the staged tile behind
-// its chunk's groups, the border-bias table and GELU; PNT1 = 2 the distillation 1x1 (+ GELU) of the finished rows (esr_conv_desc.post_*).
+// its chunk's groups, the border-bias table and GELU; PNT1 = 2 the distillation 1x1 (+ GELU) of the finished rows (esr_conv_desc.post_*) -- written,
+// measured slower than conv_s16_kernel at every size (0.396 against 0.368 ms at 32 x 270 x 480, 32.3 against 31.4 us on one image) and NOT
+// instantiated: launches with a 2-tile post chain stay on conv_s16_kernel.
 // Same packed weights, fragment maps, operation order and rounding as conv_s16_kernel: results are bit-identical (a batch takes this
 // kernel, a single small image conv_s16_kernel: test_16bit_batch_equals_per_image).
 template <bool BF16, int NT, int PNT1, bool EXT, int RW = 8>

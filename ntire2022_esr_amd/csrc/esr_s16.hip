@@ -1404,38 +1404,69 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
         if (res_post) v += rf;
         acc[par][t][e] = v;
     };
-    auto epi_post1 = [&](int par, int e) __attribute__((always_inline)) {                 // c5 on row e: d1 stays in u[.][e] (fp32) for post 2
-        f32x4 d1[PNT1];
-#pragma unroll
-        for (int ot = 0; ot < PNT1; ++ot) d1[ot] = pb1[ot];
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            const i32x4 bsv = hilo(acc[par][kt][e]);
-#pragma unroll
-            for (int ot = 0; ot < PNT1; ++ot) {
-                d1[ot] = mfma32<BF16>(*reinterpret_cast<const i32x4*>(img1 + (kt * PNT1 + ot) * 1024), bsv, d1[ot]);
-                if (plo) d1[ot] = mfma32<BF16>(*reinterpret_cast<const i32x4*>(img1 + P1_IMG + (kt * PNT1 + ot) * 1024), bsv, d1[ot]);
-            }
-        }
+    // The post chain of a finished pair, BOTH rows at once and one k tile per MFMA group: the A fragments (LDS) of k tile kt + 1 are read
+    // while k tile kt is multiplied and serve both rows.  (First version: row by row, every fragment read right in front of its MFMA --
+    // with one wave per SIMD nothing hides the ~130 cycles of an LDS read: the chain's 48 MFMAs cost 0.15 ms of a 0.28 ms launch, more than
+    // the convolution's 90.)  Per accumulator the order of MFMAs is conv_s16_kernel's: k tiles ascending, hi then lo.
+    i32x4 pa[2][6];                      // [buffer][2 ot + lo] (post 1) / [lo][kt] (post 2)
+    f32x4 d1[PNT1][2];
+    auto load_p1 = [&](int kt, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int ot = 0; ot < PNT1; ++ot) {
-            f32x4 v = d1[ot];
-            v.x = act1(v.x, p1s); v.y = act1(v.y, p1s); v.z = act1(v.z, p1s); v.w = act1(v.w, p1s);
-            acc[par][ot][e] = v;
-            PK1(ot, e).x = pack2<BF16>(v.x, v.y);
-            PK1(ot, e).y = pack2<BF16>(v.z, v.w);
+            pa[buf][2 * ot] = *reinterpret_cast<const i32x4*>(img1 + (kt * PNT1 + ot) * 1024);
+            if (plo) pa[buf][2 * ot + 1] = *reinterpret_cast<const i32x4*>(img1 + P1_IMG + (kt * PNT1 + ot) * 1024);
         }
     };
-    auto epi_post2 = [&](int par, int e) __attribute__((always_inline)) {                 // esa.conv1 on c5's fp32 result of row e
-        f32x4 d2 = pb2;
+    auto post1_step = [&](int par, int kt, int buf) __attribute__((always_inline)) {
+        i32x4 bsv[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) bsv[e] = hilo(acc[par][kt][e]);
+        // (the six hi MFMAs, then the six lo ones: a lo MFMA depends on the hi one of its accumulator)
+#pragma unroll
+        for (int ot = 0; ot < PNT1; ++ot)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) d1[ot][e] = mfma32<BF16>(pa[buf][2 * ot], bsv[e], kt == 0 ? pb1[ot] : d1[ot][e]);
+        if (plo) {
+#pragma unroll
+            for (int ot = 0; ot < PNT1; ++ot)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) d1[ot][e] = mfma32<BF16>(pa[buf][2 * ot + 1], bsv[e], d1[ot][e]);
+        }
+    };
+    auto post1_fin = [&](int par) __attribute__((always_inline)) {              // c5's result: fp32 back into the pair's accumulators, rounded into PK1
+#pragma unroll
+        for (int ot = 0; ot < PNT1; ++ot)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                f32x4 v = d1[ot][e];
+                v.x = act1(v.x, p1s); v.y = act1(v.y, p1s); v.z = act1(v.z, p1s); v.w = act1(v.w, p1s);
+                acc[par][ot][e] = v;
+                PK1(ot, e).x = pack2<BF16>(v.x, v.y);
+                PK1(ot, e).y = pack2<BF16>(v.z, v.w);
+            }
+    };
+    auto load_p2 = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int kt = 0; kt < PNT1; ++kt) {
-            const i32x4 bsv = hilo(acc[par][kt][e]);
-            d2 = mfma32<BF16>(*reinterpret_cast<const i32x4*>(img2 + kt * 1024), bsv, d2);
-            if (plo) d2 = mfma32<BF16>(*reinterpret_cast<const i32x4*>(img2 + P2_IMG + kt * 1024), bsv, d2);
+            pa[0][kt] = *reinterpret_cast<const i32x4*>(img2 + kt * 1024);
+            if (plo) pa[1][kt] = *reinterpret_cast<const i32x4*>(img2 + P2_IMG + kt * 1024);
         }
-        PK2(e).x = pack2<BF16>(d2.x, d2.y);
-        PK2(e).y = pack2<BF16>(d2.z, d2.w);
+    };
+    auto post2_both = [&](int par) __attribute__((always_inline)) {             // esa.conv1 on c5's fp32 result, both rows
+        f32x4 d2[2] = {pb2, pb2};
+#pragma unroll
+        for (int kt = 0; kt < PNT1; ++kt)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const i32x4 bsv = hilo(acc[par][kt][e]);
+                d2[e] = mfma32<BF16>(pa[0][kt], bsv, d2[e]);
+                if (plo) d2[e] = mfma32<BF16>(pa[1][kt], bsv, d2[e]);
+            }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            PK2(e).x = pack2<BF16>(d2[e].x, d2[e].y);
+            PK2(e).y = pack2<BF16>(d2[e].z, d2[e].w);
+        }
     };
     auto epi_store = [&](int i, int r) __attribute__((always_inline)) {           // the pair's four stores
         const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(p.py1 + (size_t)e_n * p1_img, 0, (int)p1_img, 0x00020000);
@@ -1495,25 +1526,32 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
                     }
                 // the next tile's DMA in the first pair: input pieces first, the wave's residual rows behind the groups (1 .. 6) in which the
                 // carried epilogue reads the residual stage they overwrite
-                if (rp == 0 && g < IPW) dma_in(g, more, nn, nx0, ny0, (k + 1) & 1);
-                if (rp == 0 && g >= IPW && g < IPW + RPW) dma_res(g - IPW, more, nn, nx0, ny0, (k + 1) & 1);
+                if (rp == 0 && 2 * g < IPW) {
+                    dma_in(2 * g, more, nn, nx0, ny0, (k + 1) & 1);
+                    if (2 * g + 1 < IPW) dma_in(2 * g + 1, more, nn, nx0, ny0, (k + 1) & 1);
+                }
+                if (rp == 0 && g >= 7 && g < 7 + RPW) dma_res(g - 7, more, nn, nx0, ny0, (k + 1) & 1);
                 if (rp > 0 || pend) {
                     const int r_prev = rp == 0 ? RW - 2 : 2 * rp - 2;
                     if (g >= 1 && g <= 6) epi_res(par ^ 1, g - 1, r_prev);
-                    if (g == 7) epi_post1(par ^ 1, 0);
-                    if (g == 8) epi_post2(par ^ 1, 0);
-                    if (g == 9) epi_post1(par ^ 1, 1);
-                    if (g == 10) epi_post2(par ^ 1, 1);
-                    if (g >= 11) epi_store(g - 11, r_prev);
+                    if (g == 6) load_p1(0, 0);
+                    if (g >= 7 && g <= 9) {
+                        if (g < 9) load_p1(g - 6, (g - 6) & 1);
+                        post1_step(par ^ 1, g - 7, (g - 7) & 1);
+                    }
+                    if (g == 10) { post1_fin(par ^ 1); load_p2(); }
+                    if (g == 11) post2_both(par ^ 1);
+                    if (g == 12) { epi_store(0, r_prev); epi_store(1, r_prev); }
+                    if (g >= 13) epi_store(g - 11, r_prev);
                 }
                 if (rp == 1 && g == 0) store_offsets(n, x0, y0, k & 1);            // (behind the carried epilogue's last store, ahead of this tile's first)
             }
         };
         run_pair(std::integral_constant<int, 0>{});
         run_pair(std::integral_constant<int, 1>{});
-        // the next tile's stages have landed: younger than their last DMA piece (group 13 of the first pair) are the carried epilogue's
-        // stores of groups 13, 14 and the four stores of this tile's first pair
-        if (pend) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // the next tile's stages have landed: younger than their last DMA piece (group 12 of the first pair) are the carried epilogue's
+        // four stores (groups 12 - 14) and the four stores of this tile's first pair
+        if (pend) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         pend = true;
@@ -1524,7 +1562,15 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
 #pragma unroll
     for (int f = 0; f < 2 * NT; ++f) epi_res(1, f, RW - 2);
-    epi_post1(1, 0); epi_post2(1, 0); epi_post1(1, 1); epi_post2(1, 1);
+    load_p1(0, 0);
+#pragma unroll
+    for (int kt = 0; kt < PNT1; ++kt) {
+        if (kt + 1 < PNT1) load_p1(kt + 1, (kt + 1) & 1);
+        post1_step(1, kt, kt & 1);
+    }
+    post1_fin(1);
+    load_p2();
+    post2_both(1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) epi_store(i, RW - 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1678,8 +1724,8 @@ static bool conv48r_takes(const esr_conv_desc* d)
 int s16_post_plan(const esr_conv_desc* d, int nt, int nchunks, int* pnt1, int* pnt2, int* post_lo, int* ring, size_t* lds);
 
 // conv48rp_kernel's descriptors: RLFB's c3_r -- 48 -> 48 (3 chunks, 3 tiles) with a residual from HBM that is not the input, the conv's
-// own result not stored, a post chain of 3 + 1 tiles without GELU -- on SMALL launches: between 256 tiles of 16 x 16 and 1024 of 16 x 32.
-// Measured (tools/gpu_c48p.sh): one 339 x 510 image 30.7 against conv_s16_kernel's 38.6 us, but 0.287 against 0.270 ms at 32 x 256 x 256.
+// own result not stored, a post chain of 3 + 1 tiles without GELU -- from 256 tiles of 16 x 16.  Measured (tools/gpu_c48p.sh): one
+// 339 x 510 image 26 against conv_s16_kernel's 38.6 us, 0.219 against 0.265 ms at 32 x 256 x 256.
 static bool conv48rp_takes(const esr_conv_desc* d)
 {
     const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
@@ -1691,7 +1737,7 @@ static bool conv48rp_takes(const esr_conv_desc* d)
     if (s16_post_plan(d, nt, nchunks, &pnt1, &pnt2, &post_lo, &ring, &lds) != ESR_OK) return false;
     if (pnt1 != 3 || pnt2 != 1 || post_lo != (d->storage == ESR_STORE_BF16 ? 1 : 0)) return false;
     const long tx = (d->w + TILE - 1) / TILE;
-    return (long)d->n * tx * ((d->h + 15) / 16) >= 256 && (long)d->n * tx * ((d->h + 31) / 32) < 1024;
+    return (long)d->n * tx * ((d->h + 15) / 16) >= 256;
 }
 
 // 1: conv48r_kernel / conv48rp_kernel (one 4-wave block per CU, weights in registers), 4: conv_s16_kernel's two-blocks-per-CU shape (4

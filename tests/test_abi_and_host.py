@@ -275,6 +275,12 @@ def test_block_shape_query_cpu():
     assert waves(32, 256, 256, 48, 48, k=1, store="bf16") == 8
     assert waves(32, 256, 256, 48, 48, store="bf16", res_mode=L.RES_POST_ACT) == 8          # residual from HBM
     assert waves(32, 256, 256, 48, 48, store="bf16", out_layout=L.NCHW_SHUFFLE4) == 8
+    # RLFB's c3_r (residual from HBM, own result not stored, c5 -> esa.conv1 in the epilogue): conv48rp_kernel from 256 tiles of 16 x 16
+    fake = lambda a: ctypes.c_void_p(a)
+    c3r = dict(store="bf16", compute=L.COMPUTE["bf16"], res_mode=L.RES_POST_ACT, res=L.View(fake(0x1000), 48, 0), inp=L.View(fake(0x2000), 48, 0),
+               post_wpacked=fake(0x3000), post2_wpacked=fake(0x4000), post_cout=46, post2_cout=16)
+    assert waves(32, 256, 256, 48, 46, **c3r) == 1 and waves(1, 339, 510, 48, 46, **c3r) == 1 and waves(1, 128, 128, 48, 46, **c3r) == 8
+    assert waves(1, 339, 510, 48, 46, out0=L.View(fake(0x5000), 48, 0), **c3r) == 8          # its own result stored too: conv_s16_kernel
     assert lib.esr_conv_block_waves(None) == 0
 
 

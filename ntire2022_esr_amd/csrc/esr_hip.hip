@@ -883,7 +883,7 @@ size_t esr_sizeof(int which)
     }
 }
 
-const char* esr_build_info(void) { return "gfx950 f32:v_mfma_f32_16x16x4_f32 (tiles 16x16/16x32, chunk 8) s16:v_mfma_f32_16x16x32_{bf16,f16} (16-bit storage, LDS-DMA ring, chunk 16) persistent"; }
+const char* esr_build_info(void) { return "gfx950 f32:v_mfma_f32_16x16x4_f32 (Winograd F(2x2,3x3) / direct, tiles 16x16/16x32, chunk 8) s16:v_mfma_f32_16x16x32_{bf16,f16} (16-bit storage: conv_s16 LDS-DMA ring, chunk 16; conv48r / conv48rp weights in registers, whole-pixel stages) persistent"; }
 
 size_t esr_packed_conv_bytes(int cin_phys, int cout, int ksize)
 {

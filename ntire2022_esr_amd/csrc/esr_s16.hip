@@ -1269,7 +1269,7 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
     constexpr int IPW = (NPIECES + 3) / 4;         // 8 input pieces per wave (wave 3: 7)
     constexpr int NG = NCH * PAIRS;
     constexpr int P1_IMG = NT * PNT1 * 1024, P2_IMG = PNT1 * 1024;
-    constexpr int OFF_RES = 2 * STAGE, OFF_POST = OFF_RES + 2 * RSTAGE;       // LDS map: [input x 2][residual x 2][P1 hi, lo][P2 hi, lo]
+    constexpr int SLOT = STAGE + RSTAGE, OFF_POST = 2 * SLOT;                 // LDS map: [input 0][residual 0][input 1][residual 1][P1 hi, lo][P2 hi, lo]
     static_assert(IPW + RPW <= NG - 1, "DMA pieces fit the first pair's groups");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
@@ -1281,11 +1281,12 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
     const bool res_post = p.res_mode == ESR_RES_POST_ACT;
 
     // ---- prologue: conv weights through the (still unused) residual stages into registers, post images to their place ----------
-    constexpr int WPIECES = NCH * PAIRS * NT;      // 45 <= 48 KB of residual stages
+    constexpr int WPIECES = NCH * PAIRS * NT;      // 45 KB <= slot 1 (55 KB), free until the first tile's DMA issue for the second tile
+    static_assert(WPIECES * 1024 <= SLOT, "weights fit slot 1");
 #pragma unroll
     for (int i = 0; i < (WPIECES + 3) / 4; ++i) {
         const int pc = wv + 4 * i;
-        if (pc < WPIECES) dma_glb16(smem_lds + (unsigned)(OFF_RES + pc * 1024), p.wp + (size_t)pc * 1024 + lane * 16);
+        if (pc < WPIECES) dma_glb16(smem_lds + (unsigned)(SLOT + pc * 1024), p.wp + (size_t)pc * 1024 + lane * 16);
     }
     for (int pc = wv; pc < 2 * (P1_IMG / 1024); pc += 4) dma_glb16(smem_lds + (unsigned)(OFF_POST + pc * 1024), p.pw1 + (size_t)pc * 1024 + lane * 16);
     for (int pc = wv; pc < 2 * (P2_IMG / 1024); pc += 4) dma_glb16(smem_lds + (unsigned)(OFF_POST + 2 * P1_IMG + pc * 1024), p.pw2 + (size_t)pc * 1024 + lane * 16);
@@ -1328,7 +1329,7 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
             const int gy = y0 - 1 + (int)ly, gx = x0 - 1 + (int)lx;
             const bool ok = valid && sl < (unsigned)NSLOT && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             const unsigned voff = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff) * 2u + part * 16u : OOB;
-            dma_buf16(smem_lds + (unsigned)(slot * STAGE + pc * 1024), voff, make_rsrc(p.x + (size_t)(valid ? n : 0) * img_bytes, img_bytes), 0u);
+            dma_buf16(smem_lds + (unsigned)(slot * SLOT + pc * 1024), voff, make_rsrc(p.x + (size_t)(valid ? n : 0) * img_bytes, img_bytes), 0u);
         }
     };
     auto dma_res = [&](int i, bool valid, int n, int x0, int y0, int slot) __attribute__((always_inline)) {      // piece i (< 6) of this wave's own rows
@@ -1337,7 +1338,7 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
         const int gy = y0 + (int)(pixel >> 4), gx = x0 + (int)(pixel & 15u);
         const bool ok = valid && gy < p.H && gx < p.W;
         const unsigned voff = ok ? (unsigned)((gy * p.W + gx) * p.res_pitch + p.res_coff) * 2u + part * 16u : OOB;
-        dma_buf16(smem_lds + (unsigned)(OFF_RES + slot * RSTAGE + (wv * RPW + i) * 1024), voff, make_rsrc(p.res + (size_t)(valid ? n : 0) * res_bytes, res_bytes), 0u);
+        dma_buf16(smem_lds + (unsigned)(slot * SLOT + STAGE + (wv * RPW + i) * 1024), voff, make_rsrc(p.res + (size_t)(valid ? n : 0) * res_bytes, res_bytes), 0u);
     };
 
     int n, x0, y0;
@@ -1347,6 +1348,8 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
         tile_coords(t0, n, x0, y0);
 #pragma unroll
         for (int i = 0; i < IPW; ++i) dma_in(i, true, n, x0, y0, 0);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) dma_res(i, true, n, x0, y0, 0);         // the first tile's residual too: nothing else waits for it before its first use
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1356,11 +1359,9 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
         for (int q = 0; q < PAIRS; ++q)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                wr[c][q][t] = *reinterpret_cast<const i32x4*>(smem + OFF_RES + ((c * PAIRS + q) * NT + t) * 1024 + lane * 16);
+                wr[c][q][t] = *reinterpret_cast<const i32x4*>(smem + SLOT + ((c * PAIRS + q) * NT + t) * 1024 + lane * 16);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                 // every wave holds its fragments: the residual stages may be written
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) dma_res(i, true, n, x0, y0, 0);             // the first tile's residual (its wait: the first tile's end)
+    __builtin_amdgcn_s_barrier();                 // every wave holds its fragments: slot 1 may be written
 
     int b_off[PAIRS];
 #pragma unroll
@@ -1398,7 +1399,7 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
     auto epi_res = [&](int par, int f, int r) __attribute__((always_inline)) {   // fragment f = 2 t + e of the finished pair (first row r)
         const int t = f >> 1, e = f & 1;
         f32x4 v = acc[par][t][e];
-        const f32x4 rf = unpack4<BF16>(*reinterpret_cast<const uint2*>(smem + OFF_RES + e_slot * RSTAGE + r_off + t * 32 + (r + e) * (16 * PIXB)));
+        const f32x4 rf = unpack4<BF16>(*reinterpret_cast<const uint2*>(smem + e_slot * SLOT + STAGE + r_off + t * 32 + (r + e) * (16 * PIXB)));
         if (!res_post) v += rf;
         v.x = act1(v.x, slope); v.y = act1(v.y, slope); v.z = act1(v.z, slope); v.w = act1(v.w, slope);
         if (res_post) v += rf;
@@ -1492,7 +1493,7 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
         const bool more = tn >= 0;
         int nn = 0, nx0 = 0, ny0 = 0;
         if (more) tile_coords(tn, nn, nx0, ny0);
-        const char* sb = smem + (k & 1) * STAGE;
+        const char* sb = smem + (k & 1) * SLOT;
         constexpr int AHEAD = 3;
         i32x4 b[4][2];
         auto read_b = [&](int L) __attribute__((always_inline)) {

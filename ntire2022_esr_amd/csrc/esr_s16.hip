@@ -943,12 +943,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
 //     nothing of the epilogue is exposed; (b) the next tile's 58 DMA pieces are all issued during the FIRST pair, three quarters of a
 //     tile ahead of their wait; (c) B fragments (one ds_read_b128 feeds NT MFMAs) are read three groups ahead through a ring of four.
 // EXT adds what ESDB's dense BSConvU needs, in conv_s16_kernel's order of operations: the residual == input from the staged tile behind
-// its chunk's groups, the border-bias table and GELU; PNT1 = 2 the distillation 1x1 (+ GELU) of the finished rows (esr_conv_desc.post_*) -- written,
-// measured slower than conv_s16_kernel at every size (0.396 against 0.368 ms at 32 x 270 x 480, 32.3 against 31.4 us on one image) and NOT
-// instantiated: launches with a 2-tile post chain stay on conv_s16_kernel.
+// its chunk's groups, the border-bias table and GELU.  (A post-chain instantiation -- ESDB c{j}_r + the next distillation 1x1, two GELUs per
+// pixel -- was written and measured slower than conv_s16_kernel at every size: 0.396 against 0.368 ms at 32 x 270 x 480, 32.3 against 31.4 us on
+// one image; it is not part of the kernel any more and those launches stay on conv_s16_kernel.)
 // Same packed weights, fragment maps, operation order and rounding as conv_s16_kernel: results are bit-identical (a batch takes this
 // kernel, a single small image conv_s16_kernel: test_16bit_batch_equals_per_image).
-template <bool BF16, int NT, int PNT1, bool EXT, int RW = 8>
+template <bool BF16, int NT, bool EXT, int RW = 8>
 __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
 {
     // RW = rows per wave: 8 (16 x 32 tiles) or 4 (16 x 16 tiles: small launches -- one DIV2K image is 352 large tiles on 256 CUs, two rounds of
@@ -960,9 +960,9 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
     constexpr int STAGE = NPIECES * 1024;
     constexpr int PPW = (NPIECES + 3) / 4;         // 15 (8) per wave, the last waves one fewer
     constexpr int NG = NCH * PAIRS;                // tap-pair groups per row pair
-    constexpr int MAIN_ST = NT == 3 ? 3 : 2, POST_ST = PNT1 > 0 ? 2 : 0, SPP = MAIN_ST + POST_ST;   // stores per row pair
+    constexpr int SPP = NT == 3 ? 3 : 2;             // stores per row pair
     static_assert(PPW <= NG && (RW == 8 || RW == 4), "at most one DMA piece per tap-pair group of the first row pair");
-    static_assert((NT == 2 || NT == 3) && (PNT1 == 0 || PNT1 == 2), "shapes");
+    static_assert(NT == 2 || NT == 3, "shapes");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int WSTAGE = RW == 8 ? STAGE : 2 * STAGE;                        // where the weight blob (<= 45 KB) is staged before the first tile
     constexpr int BT_OFF = RW == 8 ? 2 * STAGE : 2 * STAGE + NCH * PAIRS * NT * 1024;   // RW = 8: the blob is staged in input stage 1; RW = 4: behind both stages
@@ -987,23 +987,6 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
     f32x4 bia[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bia[t] = *reinterpret_cast<const f32x4*>(p.bias + t * 16 + kq * 4);
-    // post 1x1 (esr_pack_post_s16 blob: hi images [k tile][out tile], lo images, fp32 bias)
-    constexpr int P1N = PNT1 > 0 ? PNT1 : 1;
-    i32x4 pw_hi[NT][P1N], pw_lo[NT][P1N];
-    f32x4 pb[P1N];
-    const bool plo = PNT1 > 0 && BF16 && p.post_lo != 0;
-    if (PNT1 > 0) {
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-            for (int ot = 0; ot < P1N; ++ot) {
-                pw_hi[kt][ot] = *reinterpret_cast<const i32x4*>(p.pw1 + (size_t)(kt * PNT1 + ot) * 1024 + lane * 16);
-                pw_lo[kt][ot] = i32x4{0, 0, 0, 0};
-                if (plo) pw_lo[kt][ot] = *reinterpret_cast<const i32x4*>(p.pw1 + (size_t)(NT * PNT1 + kt * PNT1 + ot) * 1024 + lane * 16);
-            }
-#pragma unroll
-        for (int ot = 0; ot < P1N; ++ot) pb[ot] = *reinterpret_cast<const f32x4*>(p.pw1 + (size_t)2 * NT * PNT1 * 1024 + (ot * 16 + kq * 4) * 4);
-    }
     if (has_border)
         for (int i = tid; i < 16 * NT * 16; i += 256) btab[i] = p.border[i];
 
@@ -1075,23 +1058,13 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
         const u32x2 b = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
         return i32x4{(int)a.x, (int)b.x, (int)a.y, (int)b.y};
     };
-    auto hilo = [&](f32x4 v) __attribute__((always_inline)) -> i32x4 {     // fp32 fragment -> B operand of the post 1x1 (as conv_s16_kernel)
-        const unsigned h0 = pack2<BF16>(v.x, v.y), h1 = pack2<BF16>(v.z, v.w);
-        if (!BF16) return i32x4{(int)h0, (int)h1, 0, 0};
-        float a, b, c, d;
-        unpack2<BF16>(h0, a, b);
-        unpack2<BF16>(h1, c, d);
-        return i32x4{(int)h0, (int)h1, (int)pack2<BF16>(v.x - a, v.y - b), (int)pack2<BF16>(v.z - c, v.w - d)};
-    };
     const float slope = gelu ? 1.f : p.slope;
-    const size_t y_img = (size_t)p.H * p.W * p.y0_pitch * 2, p1_img = (size_t)p.H * p.W * p.py1_pitch * 2;
-    const unsigned rowb = (unsigned)p.W * (unsigned)p.y0_pitch * 2u, rowbp = (unsigned)p.W * (unsigned)p.py1_pitch * 2u;
+    const size_t y_img = (size_t)p.H * p.W * p.y0_pitch * 2;
+    const unsigned rowb = (unsigned)p.W * (unsigned)p.y0_pitch * 2u;
 
     f32x4 acc[2][NT][2];                 // [row pair & 1][channel tile][row of the pair]
     uint2 pk[NT][2];                     // the finished row pair, rounded
-    f32x4 u[PNT1 > 0 ? NT : 1][2];       // ... its fp32 values (the post 1x1 reads them unrounded)
-    uint2 pk1[P1N][2];
-    unsigned e_vA = OOB, e_vB = OOB, e_vP = OOB;     // store offsets (row 0 of the wave) of the tile whose epilogue is in flight
+    unsigned e_vA = OOB, e_vB = OOB;     // store offsets (row 0 of the wave) of the tile whose epilogue is in flight
     int e_n = 0;
     auto epi_pack = [&](int par, int f) __attribute__((always_inline)) {          // fragment f = 2 t + e of the finished pair
         const int t = f >> 1, e = f & 1;
@@ -1100,43 +1073,12 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
         else { v.x = act1(v.x, slope); v.y = act1(v.y, slope); v.z = act1(v.z, slope); v.w = act1(v.w, slope); }
         pk[t][e].x = pack2<BF16>(v.x, v.y);
         pk[t][e].y = pack2<BF16>(v.z, v.w);
-        if (PNT1 > 0) u[PNT1 > 0 ? t : 0][e] = v;
-    };
-    auto epi_post = [&](int e) __attribute__((always_inline)) {                    // the post 1x1 of row e of the finished pair
-        if constexpr (PNT1 > 0) {
-            f32x4 d1[PNT1];
-#pragma unroll
-            for (int ot = 0; ot < PNT1; ++ot) d1[ot] = pb[ot];
-#pragma unroll
-            for (int kt = 0; kt < NT; ++kt) {
-                const i32x4 bsv = hilo(u[kt][e]);
-#pragma unroll
-                for (int ot = 0; ot < PNT1; ++ot) {
-                    d1[ot] = mfma32<BF16>(pw_hi[kt][ot], bsv, d1[ot]);
-                    if (plo) d1[ot] = mfma32<BF16>(pw_lo[kt][ot], bsv, d1[ot]);
-                }
-            }
-#pragma unroll
-            for (int ot = 0; ot < PNT1; ++ot) {
-                f32x4 v = d1[ot];
-                if (p.p1_gelu) v = gelu16x4(v);
-                else { v.x = act1(v.x, p.p1_slope); v.y = act1(v.y, p.p1_slope); v.z = act1(v.z, p.p1_slope); v.w = act1(v.w, p.p1_slope); }
-                pk1[ot][e].x = pack2<BF16>(v.x, v.y);
-                pk1[ot][e].y = pack2<BF16>(v.z, v.w);
-            }
-        }
     };
     auto epi_store = [&](int i, int r) __attribute__((always_inline)) {           // store i of the pair whose first row is r
-        if (i < MAIN_ST) {
-            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)e_n * y_img, 0, (int)y_img, 0x00020000);
-            if (i == 0) __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[0][0], pk[1][0]), yr, e_vA + (unsigned)r * rowb, 0, 0);
-            else if (i == 1) __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[0][1], pk[1][1]), yr, e_vA + (unsigned)(r + 1) * rowb, 0, 0);
-            else __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[NT - 1][0], pk[NT - 1][1]), yr, e_vB + (unsigned)r * rowb, 0, 0);
-        } else if constexpr (PNT1 > 0) {
-            const int e = i - MAIN_ST;
-            const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(p.py1 + (size_t)e_n * p1_img, 0, (int)p1_img, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(swap16(pk1[0][e], pk1[1][e]), pr, e_vP + (unsigned)(r + e) * rowbp, 0, 0);
-        }
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)e_n * y_img, 0, (int)y_img, 0x00020000);
+        if (i == 0) __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[0][0], pk[1][0]), yr, e_vA + (unsigned)r * rowb, 0, 0);
+        else if (i == 1) __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[0][1], pk[1][1]), yr, e_vA + (unsigned)(r + 1) * rowb, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[NT - 1][0], pk[NT - 1][1]), yr, e_vB + (unsigned)r * rowb, 0, 0);
     };
     auto store_offsets = [&](int nn_, int x0_, int y0_) __attribute__((always_inline)) {
         const bool inx = x0_ + px < p.W;
@@ -1145,7 +1087,6 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
         const int chA = (kq & 1) * 16 + (kq >> 1) * 8, chB = 32 + (kq >> 1) * 8;
         e_vA = (inx && chA < p.cout_store) ? base + (unsigned)chA * 2u : OOB;
         e_vB = (inx && chB < p.cout_store) ? base + (unsigned)chB * 2u + ((kq & 1) ? rowb : 0u) : OOB;
-        if (PNT1 > 0) e_vP = (inx && chA < p.p1_cout8) ? (pix * (unsigned)p.py1_pitch + (unsigned)p.py1_coff) * 2u + (unsigned)chA * 2u : OOB;
         e_n = nn_;
     };
     bool pend = false;                   // a finished tile's last row pair waits for its epilogue
@@ -1200,7 +1141,6 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
                 if (rp > 0 || pend) {
                     const int r_prev = rp == 0 ? RW - 2 : 2 * rp - 2;
                     if (g >= 1 && g <= 2 * NT) epi_pack(par ^ 1, g - 1);
-                    if (PNT1 > 0 && (g == 7 || g == 8)) epi_post(g - 7);
                     if (g >= 9 && g < 9 + SPP) epi_store(g - 9, r_prev);
                 }
                 if (rp == 0 && g == NG - 1) store_offsets(n, x0, y0);              // (behind the previous tile's last store)
@@ -1239,7 +1179,6 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // (asm MFMAs: hipcc does not pad MFMA -> VALU reads of their results)
 #pragma unroll
     for (int f = 0; f < 2 * NT; ++f) epi_pack(1, f);
-    if (PNT1 > 0) { epi_post(0); epi_post(1); }
 #pragma unroll
     for (int i = 0; i < SPP; ++i) epi_store(i, RW - 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the trailing zero-fill DMA must not outlive the block)
@@ -1599,7 +1538,7 @@ int launch_conv48rp(const S16K& k, hipStream_t st)
     return esr_check_launch("conv48rp_kernel launch");
 }
 
-template <bool BF16, int NT, int PNT1, bool EXT, int RW = 8>
+template <bool BF16, int NT, bool EXT, int RW = 8>
 int launch_conv48r(const S16K& k, hipStream_t st)
 {
     // [two input stages][RW = 4: 45 KB where the weight blob is staged][border table]
@@ -1609,7 +1548,7 @@ int launch_conv48r(const S16K& k, hipStream_t st)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
     if (!attr_set[dev].load(std::memory_order_relaxed)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv48r_kernel<BF16, NT, PNT1, EXT, RW>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGES + NT * 1024);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv48r_kernel<BF16, NT, EXT, RW>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGES + NT * 1024);
         if (e != hipSuccess) {
             esr_set_err("hipFuncSetAttribute(conv48r_kernel, MaxDynamicSharedMemorySize)", e);
             return ESR_ERR_LAUNCH;
@@ -1618,8 +1557,8 @@ int launch_conv48r(const S16K& k, hipStream_t st)
     }
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int grid = ntiles < 256 ? ntiles : 256;
-    esr_note_kernel("conv48r_kernel<%s, %d, %d, %s, %d>", esr_tf(BF16), NT, PNT1, esr_tf(EXT), RW);
-    hipLaunchKernelGGL((conv48r_kernel<BF16, NT, PNT1, EXT, RW>), dim3(grid), dim3(256), LDS, st, k);
+    esr_note_kernel("conv48r_kernel<%s, %d, %s, %d>", esr_tf(BF16), NT, esr_tf(EXT), RW);
+    hipLaunchKernelGGL((conv48r_kernel<BF16, NT, EXT, RW>), dim3(grid), dim3(256), LDS, st, k);
     return esr_check_launch("conv48r_kernel launch");
 }
 
@@ -2134,13 +2073,13 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
             S16K k4 = k;
             k4.tiles_y = (d->h + 15) / 16;
             k4.magic_y = k4.tiles_y > 1 ? (unsigned)((0x100000000ull + k4.tiles_y - 1) / k4.tiles_y) : 0u;
-            if (nt == 2) return bf16 ? launch_conv48r<true, 2, 0, true, 4>(k4, st) : launch_conv48r<false, 2, 0, true, 4>(k4, st);
-            if (ext) return bf16 ? launch_conv48r<true, 3, 0, true, 4>(k4, st) : launch_conv48r<false, 3, 0, true, 4>(k4, st);
-            return bf16 ? launch_conv48r<true, 3, 0, false, 4>(k4, st) : launch_conv48r<false, 3, 0, false, 4>(k4, st);
+            if (nt == 2) return bf16 ? launch_conv48r<true, 2, true, 4>(k4, st) : launch_conv48r<false, 2, true, 4>(k4, st);
+            if (ext) return bf16 ? launch_conv48r<true, 3, true, 4>(k4, st) : launch_conv48r<false, 3, true, 4>(k4, st);
+            return bf16 ? launch_conv48r<true, 3, false, 4>(k4, st) : launch_conv48r<false, 3, false, 4>(k4, st);
         }
-        if (nt == 2) return bf16 ? launch_conv48r<true, 2, 0, true>(k, st) : launch_conv48r<false, 2, 0, true>(k, st);
-        if (ext) return bf16 ? launch_conv48r<true, 3, 0, true>(k, st) : launch_conv48r<false, 3, 0, true>(k, st);
-        return bf16 ? launch_conv48r<true, 3, 0, false>(k, st) : launch_conv48r<false, 3, 0, false>(k, st);
+        if (nt == 2) return bf16 ? launch_conv48r<true, 2, true>(k, st) : launch_conv48r<false, 2, true>(k, st);
+        if (ext) return bf16 ? launch_conv48r<true, 3, true>(k, st) : launch_conv48r<false, 3, true>(k, st);
+        return bf16 ? launch_conv48r<true, 3, false>(k, st) : launch_conv48r<false, 3, false>(k, st);
     }
     if (post) {
         const bool gres = k.res_mode != ESR_RES_NONE;

@@ -341,3 +341,27 @@ def test_conv48r_equals_conv_s16(compute, cin, cout, act, res_in, border, hw, n)
         eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
         tol = ref.abs() * eps * 1.01 + (3e-4 if act == 3 else 5e-5) * max(1.0, float(ref.abs().max()))
         assert int(((got - ref).abs() > tol).sum()) == 0
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
+@pytest.mark.parametrize("hw,n", [((128, 128), 8), ((100, 77), 9)])
+def test_conv48rp_equals_conv_s16(compute, hw, n):
+    """conv48rp_kernel (RLFB c3_r + block input -> c5 -> esa.conv1: weights in registers, 16 x 16 tiles, the residual staged by each wave
+    for its own rows, post images in LDS, the chain on both rows of a pair) against conv_s16_kernel: the batch takes the new kernel
+    (>= 256 tiles of 16 x 16), each image alone the old one -- both outputs bit-identical, ragged edges included."""
+    from ntire2022_esr_amd import ops, _lib as L
+    dt = DT[compute]
+    g = torch.Generator().manual_seed(hw[0] + n)
+    x = _nhwc(torch.randn(n, 48, *hw, generator=g).to(dt)).to(DEV)
+    r = F.pad(_nhwc(torch.randn(n, 46, *hw, generator=g).to(dt)), (0, 2)).to(DEV)
+    w, b = torch.randn(46, 48, 3, 3, generator=g) * 0.1, torch.randn(46, generator=g)
+    w5, b5 = torch.randn(46, 46, generator=g) * 0.2, torch.randn(46, generator=g)
+    w1, b1 = torch.randn(16, 46, generator=g) * 0.2, torch.randn(16, generator=g)
+    kw = dict(act=1, res_mode=2, post_weight=w5, post_bias=b5, post2_weight=w1, post2_bias=b1, store_main=False)
+    tiles16 = lambda nn: nn * ((hw[1] + 15) // 16) * ((hw[0] + 15) // 16)
+    assert tiles16(n) >= 256 and tiles16(1) < 256
+    y, yv, yc = ops.conv2d(x, w, b, res=r, **kw)
+    assert y is None
+    for i in range(n):
+        _, v1, c1 = ops.conv2d(x[i:i + 1].contiguous(), w, b, res=r[i:i + 1].contiguous(), **kw)
+        assert torch.equal(yv[i:i + 1], v1) and torch.equal(yc[i:i + 1], c1), i

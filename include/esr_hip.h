@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESR_ABI_VERSION 8
+#define ESR_ABI_VERSION 9
 
 typedef enum esr_status {
     ESR_OK = 0,
@@ -337,6 +337,21 @@ int    esr_dwconv3x3_f32(const esr_conv_desc* d, void* hip_stream);
 int esr_tensor2uint_u8(const float* x_chw, uint8_t* y_hwc, int c, int h, int w, float data_range, void* hip_stream);
 int esr_sqerr_u8(const uint8_t* a_hwc, const uint8_t* b_hwc, int h, int w, int c, int border,
                  unsigned long long* sum_out /* device, zeroed by the call */, void* hip_stream);
+/*
+ * ABI v9 (csrc/esr_metrics.hip):
+ *   esr_tensor2uint_u8_chk  esr_tensor2uint_u8 that also ORs 1 into *nonfinite (device int, caller-zeroed) when the fp32 image holds an
+ *                           Inf or NaN: the harness learns about overflowed 16-bit activations without a full-size isfinite pass.
+ *   esr_ssim_u8             calculate_ssim (utils/utils_image.py:509-554) for two HWC uint8 images (c = 1 or 3) already on the device:
+ *                           crop `border`, 11x11 Gaussian window (sigma 1.5) as two separable float64 passes, 'valid' region, the SSIM
+ *                           map summed per block into partials[esr_ssim_partials(h, w, c, border)] (device doubles, every entry
+ *                           written); the caller adds them up in order and divides by (h - 2 border - 10)(w - 2 border - 10) c.  For c = 3
+ *                           that is the reference's result: its loop evaluates ssim() on the whole HxWx3 array three times
+ *                           (:521-527).  ESR_ERR_BAD_ARG when the cropped image is smaller than the 11x11 window.
+ */
+int    esr_tensor2uint_u8_chk(const float* x_chw, uint8_t* y_hwc, int c, int h, int w, float data_range, int* nonfinite, void* hip_stream);
+size_t esr_ssim_partials(int h, int w, int c, int border);
+int    esr_ssim_u8(const uint8_t* a_hwc, const uint8_t* b_hwc, int h, int w, int c, int border, double* partials, size_t n_partials,
+                   void* hip_stream);
 
 /*
  * A forward pass is a flat list of ops executed in order on one stream: the native
@@ -444,6 +459,10 @@ const char* esr_last_hip_error(void);     /* thread-local, "" if none */
  * reference has no counterpart: its boundary is Python objects). */
 size_t      esr_sizeof(int which);
 const char* esr_build_info(void);         /* e.g. "gfx950 f32-mfma16x16x4 tile16x16 chunk8" */
+/* ABI v9: SHA-256 (hex) over the library's sources (every .hip / .inc / .h under csrc + this header) as __graft_entry__.build() saw them, or
+ * "unknown" for a library compiled by hand.  Measurements stored next to the code (profiles/pmc_traffic.json) carry it, and bench.py
+ * refuses to replay PMC traffic recorded for another build. */
+const char* esr_source_hash(void);
 
 #ifdef __cplusplus
 }

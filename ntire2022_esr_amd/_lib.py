@@ -110,7 +110,7 @@ class Op(ctypes.Structure):
 
 # every symbol include/esr_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "esr_abi_version", "esr_last_hip_error", "esr_build_info", "esr_sizeof",
+    "esr_abi_version", "esr_last_hip_error", "esr_build_info", "esr_source_hash", "esr_sizeof",
     "esr_packed_conv_bytes", "esr_pack_conv_f32", "esr_unpack_conv_f32",
     "esr_packed_conv_s16_bytes", "esr_pack_conv_s16", "esr_unpack_conv_s16",
     "esr_packed_post_s16_bytes", "esr_pack_post_s16", "esr_conv_post_supported",
@@ -122,6 +122,7 @@ EXPORTS = [
     "esr_esa_apply_post_supported", "esr_packed_apply_post_bytes", "esr_pack_apply_post",
     "esr_packed_dw_bytes", "esr_pack_dw_f32", "esr_dwconv3x3_f32", "esr_bsconv_f32",
     "esr_tensor2uint_u8", "esr_sqerr_u8", "esr_channel_attention_f32",
+    "esr_tensor2uint_u8_chk", "esr_ssim_partials", "esr_ssim_u8",
 ]
 
 _lib = None
@@ -199,6 +200,13 @@ def lib():
     L.esr_tensor2uint_u8.restype = ci
     L.esr_sqerr_u8.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
     L.esr_sqerr_u8.restype = ci
+    L.esr_tensor2uint_u8_chk.argtypes = [vp, vp, ci, ci, ci, ctypes.c_float, vp, vp]
+    L.esr_tensor2uint_u8_chk.restype = ci
+    L.esr_ssim_partials.argtypes = [ci, ci, ci, ci]
+    L.esr_ssim_partials.restype = sz
+    L.esr_ssim_u8.argtypes = [vp, vp, ci, ci, ci, ci, vp, sz, vp]
+    L.esr_ssim_u8.restype = ci
+    L.esr_source_hash.restype = ctypes.c_char_p
     L.esr_prof_create.argtypes = [ci, ci, ctypes.POINTER(vp)]
     L.esr_prof_create.restype = ci
     L.esr_run_ops_profiled.argtypes = [ctypes.POINTER(Op), ci, vp, vp]
@@ -215,7 +223,7 @@ def lib():
     L.esr_packed_apply_post_bytes.restype = sz
     L.esr_pack_apply_post.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, sz]
     L.esr_pack_apply_post.restype = ci
-    if L.esr_abi_version() != 8:
+    if L.esr_abi_version() != 9:
         raise EsrError("libesr_hip.so ABI version mismatch")
     L.esr_sizeof.argtypes = [ci]
     L.esr_sizeof.restype = ctypes.c_size_t

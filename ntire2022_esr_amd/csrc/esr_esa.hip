@@ -86,10 +86,10 @@ __global__ __launch_bounds__(256) void conv3x3s2_kernel(const void* __restrict__
 #pragma unroll
             for (int cq = 0; cq < FP / 4; ++cq) {
                 const f32x4 xv = ld4<ST>(x, xi + cq * 4);
-                acc += xv.x * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 0) * FP);
-                acc += xv.y * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 1) * FP);
-                acc += xv.z * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 2) * FP);
-                acc += xv.w * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 3) * FP);
+                acc += esr_lone(xv.x) * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 0) * FP);     // esr_lone: see esr_internal.h
+                acc += esr_lone(xv.y) * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 1) * FP);
+                acc += esr_lone(xv.z) * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 2) * FP);
+                acc += esr_lone(xv.w) * *reinterpret_cast<const f32x4*>(wt + (cq * 4 + 3) * FP);
             }
         }
     *reinterpret_cast<f32x4*>(y + (size_t)pix * FP + q * 4) = acc;
@@ -203,10 +203,10 @@ __global__ __launch_bounds__(256) void esa_apply_kernel(const EsaK p)
 #pragma unroll
     for (int iq = 0; iq < FP / 4; ++iq) {
         const f32x4 sv = *reinterpret_cast<const f32x4*>(sx + pl * FP + iq * 4);
-        m += sv.x * *reinterpret_cast<const f32x4*>(w4 + (iq * 4 + 0) * p.cp + g * 4);
-        m += sv.y * *reinterpret_cast<const f32x4*>(w4 + (iq * 4 + 1) * p.cp + g * 4);
-        m += sv.z * *reinterpret_cast<const f32x4*>(w4 + (iq * 4 + 2) * p.cp + g * 4);
-        m += sv.w * *reinterpret_cast<const f32x4*>(w4 + (iq * 4 + 3) * p.cp + g * 4);
+        m += esr_lone(sv.x) * *reinterpret_cast<const f32x4*>(w4 + (iq * 4 + 0) * p.cp + g * 4);     // esr_lone: see esr_internal.h
+        m += esr_lone(sv.y) * *reinterpret_cast<const f32x4*>(w4 + (iq * 4 + 1) * p.cp + g * 4);
+        m += esr_lone(sv.z) * *reinterpret_cast<const f32x4*>(w4 + (iq * 4 + 2) * p.cp + g * 4);
+        m += esr_lone(sv.w) * *reinterpret_cast<const f32x4*>(w4 + (iq * 4 + 3) * p.cp + g * 4);
     }
     const f32x4 xv = ld4<ST>(p.x, (size_t)pix * p.x_pitch + p.x_coff + g * 4);
     f32x4 o;
@@ -386,8 +386,13 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
         return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * m));
     };
     auto finish = [&](const Grp& g) __attribute__((always_inline)) {
-        const float hy = 1.f - g.ly, hx = 1.f - g.lx;
-        f32x4 sacc = hy * (hx * g.ta + g.lx * g.tb) + g.ly * (hx * g.tc + g.lx * g.td) + bf4;      // same evaluation order as the VALU kernel
+        // The four interpolation weights in registers of their own (esr_lone, esr_internal.h): when lx and ly travel as a register PAIR
+        // (every loop shape that carried a fetched group into the next iteration did that) hipcc encodes `lx * tb` as v_pk_mul_f32 ...
+        // op_sel:[0,1], the encoding that returns 0 in lanes 48..63 beside another kernel's MFMAs -- the overlapped-forward defect of
+        // round 3 (LAB_NOTES.md).
+        const float ly_ = esr_lone(g.ly), lx_ = esr_lone(g.lx);
+        const float hy = esr_lone(1.f - ly_), hx = esr_lone(1.f - lx_);
+        f32x4 sacc = hy * (hx * g.ta + lx_ * g.tb) + ly_ * (hx * g.tc + lx_ * g.td) + bf4;        // same evaluation order as the VALU kernel
         sacc = mfma_k32<ST>(a_f, g.bc1, sacc);
         // s -> B operand of conv4: high parts in k slots 0..3, low parts in 4..7
         unsigned short h[4], l[4];

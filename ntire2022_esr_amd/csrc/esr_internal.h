@@ -19,6 +19,19 @@ int esr_s16_block_waves(const esr_conv_desc* d);      // 4: two 4-wave blocks pe
 int esr_conv2d_wino(const esr_conv_desc* d, void* hip_stream);
 
 #ifdef __HIPCC__
+// gfx950 erratum found in round 4 (LAB_NOTES.md "packed fp32 op_sel"; tools/dbg/pk_opsel_probe.hip reproduces it in isolation): a
+// packed fp32 VALU instruction whose op_sel makes a result half read the HIGH dword of a 64-bit source pair (v_pk_mul_f32 ...
+// op_sel:[0,1]) returns 0 in lanes 48..63 when a wave of ANOTHER kernel issues MFMAs on the same SIMD -- forwards overlapping on
+// several HIP streams differed from serial ones.  hipcc picks that encoding when a scalar factor happens to live in the odd
+// register of a pair (an .y / .w element of a loaded vector, or lx next to ly in a struct).  esr_lone() gives the factor a register
+// of its own, so the broadcast is encoded with op_sel_hi (both halves read the LOW dword: the form that never failed);
+// tools/lint_isa.py (a CPU test) fails the build if the bad encoding shows up in any kernel of the library.
+__device__ __forceinline__ float esr_lone(float v)
+{
+    asm("" : "+v"(v));
+    return v;
+}
+
 // GELU of the 16-bit storage modes (the scalar definition conv_s16_kernel's packed version follows bit for bit; accuracy and
 // derivation: esr_s16.hip, tools/fit_gelu.py)
 __device__ __forceinline__ float esr_gelu16(float x)

@@ -1,0 +1,149 @@
+// esr_metrics.hip -- run()'s per-image metrics on the device: SSIM and the checked tensor2uint.
+// Interface: include/esr_hip.h (ABI v9).  Reference: utils/utils_image.py:509-554 (calculate_ssim / ssim), :204-208 (tensor2uint).
+//
+// calculate_ssim crops `border` pixels, then ssim() filters img1, img2, img1^2, img2^2, img1*img2 (float64) with the 11x11 Gaussian
+// window outer(k, k), k = cv2.getGaussianKernel(11, 1.5), keeps the 'valid' region [5:-5, 5:-5] and averages
+//     ((2 mu1 mu2 + C1)(2 s12 + C2)) / ((mu1^2 + mu2^2 + C1)(s1 + s2 + C2)),   C1 = (0.01*255)^2, C2 = (0.03*255)^2
+// over it.  For an HxWx3 input the reference runs ssim() on the WHOLE array three times (its loop index is unused, :521-527):
+// cv2.filter2D filters every channel, the crop is spatial, so the result is the mean of the map over all three channels.
+// This kernel does exactly that: separable 11-tap passes (vertical, then horizontal: the order of ntire2022_esr_amd/image_util._ssim)
+// in float64 on the uint8 images already on the device, one partial sum per block; the host adds the partials (a fixed-order float64
+// sum) and divides -- one scalar leaves the GPU.  Parity: UNPINNED against the reference (its SSIM needs cv2, absent here); pinned to
+// image_util.calculate_ssim (<= 1e-9, tests/test_gpu_harness.py).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "esr_hip.h"
+#include "esr_internal.h"
+
+namespace {
+
+constexpr int SS_TY = 16, SS_TX = 32;                 // output tile of a block (one channel)
+constexpr int SS_R = 5;                               // window radius
+constexpr int SS_PY = SS_TY + 2 * SS_R, SS_PX = SS_TX + 2 * SS_R;
+
+struct SsimK {
+    const uint8_t* a; const uint8_t* b;
+    int W, C, border;
+    int vh, vw;                                       // valid output region (per channel)
+    int tiles_x, tiles_y;
+    double k[11];
+    double* partials;
+};
+
+__global__ __launch_bounds__(256) void ssim_u8_kernel(const SsimK p)
+{
+    __shared__ uint8_t pa[SS_PY][SS_PX], pb[SS_PY][SS_PX];
+    __shared__ double v[5][SS_TY][SS_PX];            // vertical pass: a, b, a^2, b^2, a b
+    __shared__ double red[4];
+    const int c = blockIdx.z;
+    const int oy0 = blockIdx.y * SS_TY, ox0 = blockIdx.x * SS_TX;       // tile origin in the valid-output frame
+    const int tid = threadIdx.x;
+    // patch rows oy0 .. oy0 + TY + 9, columns ox0 .. ox0 + TX + 9 of the border-cropped image (clamped: only feeds masked outputs)
+    const int ch = p.vh + 2 * SS_R, cw = p.vw + 2 * SS_R;               // cropped image size
+    for (int e = tid; e < SS_PY * SS_PX; e += 256) {
+        const int py = e / SS_PX, px = e - py * SS_PX;
+        const int y = min(oy0 + py, ch - 1) + p.border, x = min(ox0 + px, cw - 1) + p.border;
+        const size_t idx = ((size_t)y * p.W + x) * p.C + c;
+        pa[py][px] = p.a[idx];
+        pb[py][px] = p.b[idx];
+    }
+    __syncthreads();
+    for (int e = tid; e < SS_TY * SS_PX; e += 256) {
+        const int ty = e / SS_PX, px = e - ty * SS_PX;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+#pragma unroll
+        for (int t = 0; t < 11; ++t) {
+            const double x = (double)pa[ty + t][px], y = (double)pb[ty + t][px], w = p.k[t];
+            s0 += w * x; s1 += w * y; s2 += w * (x * x); s3 += w * (y * y); s4 += w * (x * y);
+        }
+        v[0][ty][px] = s0; v[1][ty][px] = s1; v[2][ty][px] = s2; v[3][ty][px] = s3; v[4][ty][px] = s4;
+    }
+    __syncthreads();
+    const double C1 = (0.01 * 255) * (0.01 * 255), C2 = (0.03 * 255) * (0.03 * 255);
+    double acc = 0;
+    for (int e = tid; e < SS_TY * SS_TX; e += 256) {
+        const int ty = e / SS_TX, tx = e - ty * SS_TX;
+        if (oy0 + ty >= p.vh || ox0 + tx >= p.vw) continue;
+        double m[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 11; ++t) {
+            const double w = p.k[t];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) m[q] += w * v[q][ty][tx + t];
+        }
+        const double mu1 = m[0], mu2 = m[1];
+        const double mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const double s1 = m[2] - mu1_sq, s2 = m[3] - mu2_sq, s12 = m[4] - mu12;
+        acc += ((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2));
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) p.partials[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void tensor2uint_chk_kernel(const float* __restrict__ x, uint8_t* __restrict__ y, int C, int H,
+                                                              int W, float dr, float scale, int* __restrict__ nonfinite)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;        // output element index (HWC)
+    const long long n = (long long)H * W * C;
+    bool bad = false;
+    if (i < n) {
+        const int c = (int)(i % C);
+        const long long hw = i / C;
+        float v = x[(size_t)c * H * W + hw];
+        bad = !(fabsf(v) <= 3.402823466e38f);                             // Inf or NaN
+        v = v < 0.f ? 0.f : (v > dr ? dr : v);
+        y[i] = (uint8_t)__float2int_rn(__fmul_rn(v, scale));
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(nonfinite, 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+static bool ssim_geometry(int h, int w, int c, int border, int* vh, int* vw)
+{
+    if (h <= 0 || w <= 0 || (c != 1 && c != 3) || border < 0) return false;
+    *vh = h - 2 * border - 2 * SS_R;
+    *vw = w - 2 * border - 2 * SS_R;
+    return *vh > 0 && *vw > 0;
+}
+
+size_t esr_ssim_partials(int h, int w, int c, int border)
+{
+    int vh, vw;
+    if (!ssim_geometry(h, w, c, border, &vh, &vw)) return 0;
+    return (size_t)((vh + SS_TY - 1) / SS_TY) * ((vw + SS_TX - 1) / SS_TX) * c;
+}
+
+int esr_ssim_u8(const uint8_t* a, const uint8_t* b, int h, int w, int c, int border, double* partials, size_t n_partials, void* hip_stream)
+{
+    int vh, vw;
+    if (!a || !b || !partials || !ssim_geometry(h, w, c, border, &vh, &vw)) return ESR_ERR_BAD_ARG;
+    if (n_partials < esr_ssim_partials(h, w, c, border)) return ESR_ERR_BAD_ARG;
+    SsimK k;
+    k.a = a; k.b = b; k.W = w; k.C = c; k.border = border; k.vh = vh; k.vw = vw;
+    k.tiles_y = (vh + SS_TY - 1) / SS_TY; k.tiles_x = (vw + SS_TX - 1) / SS_TX;
+    if (k.tiles_y > 65535) return ESR_ERR_UNSUPPORTED;
+    double s = 0;                                       // cv2.getGaussianKernel(11, 1.5)
+    for (int i = 0; i < 11; ++i) { const double x = i - 5.0; k.k[i] = exp(-(x * x) / (2.0 * 1.5 * 1.5)); s += k.k[i]; }
+    for (int i = 0; i < 11; ++i) k.k[i] /= s;
+    k.partials = partials;
+    hipLaunchKernelGGL(ssim_u8_kernel, dim3(k.tiles_x, k.tiles_y, c), dim3(256), 0, static_cast<hipStream_t>(hip_stream), k);
+    return esr_check_launch("ssim_u8_kernel launch");
+}
+
+int esr_tensor2uint_u8_chk(const float* x, uint8_t* y, int c, int h, int w, float data_range, int* nonfinite, void* hip_stream)
+{
+    if (!x || !y || !nonfinite || c <= 0 || h <= 0 || w <= 0 || !(data_range > 0.f)) return ESR_ERR_BAD_ARG;
+    const long long n = (long long)c * h * w;
+    hipLaunchKernelGGL(tensor2uint_chk_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                       x, y, c, h, w, data_range, 255.0f / data_range, nonfinite);
+    return esr_check_launch("tensor2uint_chk_kernel launch");
+}
+
+}  // extern "C"

@@ -10,6 +10,7 @@ and the stream handle.
 import collections
 import ctypes
 import itertools
+import threading
 import weakref
 
 import numpy as np
@@ -565,6 +566,25 @@ def _sr_forward_fake(x, handle):
     return x.new_empty((x.shape[0], m.out_nc, x.shape[2] * m.upscale, x.shape[3] * m.upscale), dtype=torch.float32)
 
 
+class _ModelLock:
+    """threading.RLock that survives copy.deepcopy / pickling of the module that owns it (a copy gets a lock of its own)."""
+
+    def __init__(self):
+        self._l = threading.RLock()
+
+    def __enter__(self):
+        return self._l.__enter__()
+
+    def __exit__(self, *a):
+        return self._l.__exit__(*a)
+
+    def __deepcopy__(self, memo):
+        return _ModelLock()
+
+    def __reduce__(self):
+        return (_ModelLock, ())
+
+
 class _Entry:
     """One cached shape: the Plan, and its esr_op array finalized against workspace base `base`."""
     __slots__ = ("plan", "arr", "in_idx", "out_idx", "base")
@@ -601,8 +621,9 @@ class HipSRModel(nn.Module):
         self._dirty = True         # parameters may have changed since the last repack (load_state_dict / .to() / repack())
         self._ctxs = {}            # (device, HIP stream handle) -> _StreamCtx: workspace + plans of the forwards enqueued on that stream
         self.compute = "f32"       # "f32" | "bf16" | "f16": MFMA operand format of the full-resolution 3x3 convs
-        self.fuse_esa_lowres = True   # ESA's low-resolution branch as one esr_esa_lowres_f32 op (two launches) instead of 3 .. 8 launches
-        self.winograd = True       # fp32 plans: 3x3 convs whose shape qualifies run as Winograd F(2x2, 3x3) (esr_conv_desc.wino_wpacked)
+        self._fuse_esa_lowres = True  # ESA's low-resolution branch as one esr_esa_lowres_f32 op (two launches) instead of 3 .. 8 launches
+        self._winograd = True      # fp32 plans: 3x3 convs whose shape qualifies run as Winograd F(2x2, 3x3) (esr_conv_desc.wino_wpacked)
+        self._lock = _ModelLock()       # plan / workspace bookkeeping and the pointer patch + enqueue of one forward (see _forward_impl)
         self._prof_passes = 0      # >0: record HIP events around every op (bench roofline leg)
         self.handle = next(_HANDLES)       # the `handle` argument of esr::sr_forward
         _LIVE[self.handle] = self
@@ -642,6 +663,18 @@ class HipSRModel(nn.Module):
         for p in path.split("."):
             mod = mod._modules[p]
         return mod
+
+    # Plan-shaping switches: which blobs repack() builds and which ops _build_plan emits depend on them, so a change re-packs and drops
+    # the cached plans exactly like set_compute() (as plain attributes a late change was ignored or raised KeyError).
+    def _set_flag(self, name, value):
+        value = bool(value)
+        if getattr(self, name) != value:
+            setattr(self, name, value)
+            self._dirty = True
+            self._drop_plans()
+
+    fuse_esa_lowres = property(lambda self: self._fuse_esa_lowres, lambda self, v: self._set_flag("_fuse_esa_lowres", v))
+    winograd = property(lambda self: self._winograd, lambda self, v: self._set_flag("_winograd", v))
 
     def set_compute(self, mode):
         """'f32': exact fp32 MFMA, fp32 activations.  'bf16' / 'f16' (BASELINE.json configs [2]-[4]): the full-resolution
@@ -856,9 +889,10 @@ class HipSRModel(nn.Module):
             raise L.EsrError(f"{type(self).__name__}.prepare: device {device} -- this engine only runs on an MI355X")
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        self._ensure_packed(device)
         n, c, h, w = (int(v) for v in shape)
-        return self._entry((n, c, h, w, device))
+        with self._lock:
+            self._ensure_packed(device)
+            return self._entry((n, c, h, w, device))
 
     def forward(self, x):
         """NCHW fp32 [N, in_nc, H, W] on the GPU -> NCHW fp32 [N, out_nc, 4H, 4W]: one esr::sr_forward call."""
@@ -875,27 +909,32 @@ class HipSRModel(nn.Module):
             raise L.EsrError("expected a 4-D float32 NCHW tensor (uint2tensor4 output)")
         lib = L.lib()
         x = x.contiguous()
-        self._ensure_packed(x.device)
         n, c, h, w = x.shape
         key = (n, c, h, w, x.device)
-        ctx = self._ctx(x.device)
-        ent = self._entry(key, ctx)
-        arr = ent.arr
         y = torch.empty((n, self.out_nc, h * self.upscale, w * self.upscale), dtype=torch.float32, device=x.device)
-        for i in ent.in_idx:
-            arr[i].conv.inp.ptr = x.data_ptr()
-        for i in ent.out_idx:
-            arr[i].conv.out0.ptr = y.data_ptr()
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        if self._prof_passes > 0:
-            prof = ctx.profs.get(key)
-            if prof is None:
-                prof = ctypes.c_void_p()
-                L.check(lib.esr_prof_create(len(arr), self._prof_passes, ctypes.byref(prof)), "esr_prof_create")
-                ctx.profs[key] = prof
-            rc = lib.esr_run_ops_profiled(arr, len(arr), ctypes.c_void_p(stream), prof)
-        else:
-            rc = lib.esr_run_ops(arr, len(arr), ctypes.c_void_p(stream))
+        # One lock per model around the host-side bookkeeping AND the enqueue: the cached esr_op array of a (stream, shape) carries
+        # this call's x / y pointers from the patch below until esr_run_ops has read it (it only enqueues: ~0.1-0.25 ms of host
+        # time, no device wait), and plan / workspace creation mutates dicts.  Two Python threads calling one model therefore
+        # enqueue their forwards one after the other -- on their own streams the forwards still overlap on the GPU.
+        with self._lock:
+            self._ensure_packed(x.device)
+            ctx = self._ctx(x.device)
+            ent = self._entry(key, ctx)
+            arr = ent.arr
+            for i in ent.in_idx:
+                arr[i].conv.inp.ptr = x.data_ptr()
+            for i in ent.out_idx:
+                arr[i].conv.out0.ptr = y.data_ptr()
+            if self._prof_passes > 0:
+                prof = ctx.profs.get(key)
+                if prof is None:
+                    prof = ctypes.c_void_p()
+                    L.check(lib.esr_prof_create(len(arr), self._prof_passes, ctypes.byref(prof)), "esr_prof_create")
+                    ctx.profs[key] = prof
+                rc = lib.esr_run_ops_profiled(arr, len(arr), ctypes.c_void_p(stream), prof)
+            else:
+                rc = lib.esr_run_ops(arr, len(arr), ctypes.c_void_p(stream))
         L.check(rc, f"{type(self).__name__}.forward")
         return y
 
@@ -923,9 +962,9 @@ class HipSRModel(nn.Module):
             npix = plan.npix if hw is None else plan.n * hw[0] * hw[1]
             e_act = es if hw is None else 4                       # low-resolution maps are fp32
             wino = False
-            if kind == "pack":                      # the network input, read once (fp32 NCHW); its 16-bit copy is an intermediate
+            if kind == "pack":                      # the network input read once (fp32 NCHW), its 16 16-bit slots per pixel written once
                 out.append(dict(name="pack_input", kernel="pack_input_kernel", cin=o["cin"], cout=16, k=0, flops=0.0, flops_exec=0.0,
-                                read_bytes=float(npix * o["cin"] * 4), write_bytes=0.0))
+                                read_bytes=float(npix * o["cin"] * 4), write_bytes=float(npix * 16 * 2)))
                 continue
             if kind == "conv":
                 nt = (o["cout"] + 15) // 16
@@ -947,14 +986,14 @@ class HipSRModel(nn.Module):
                 ca = o["cin_alg"]
                 rd = npix * (ca * e_in + (o["cout"] * e_act if o["res"] is not None else 0)) + 4.0 * ca * o["cout"] * o["k"] ** 2
                 if o.get("head"):
-                    rd -= npix * ca * e_in            # (counted with the pack op)
+                    rd += npix * (16 * 2 - ca * e_in)  # the head reads the packed 16-slot copy (esr_pack_input_s16), not the fp32 input
                 wr = float(npix * o["cout"] * e_out) if o["dst"] is not None else 0.0
                 flops = 2.0 * npix * ca * o["cout"] * o["k"] * o["k"]
                 if o.get("bs_of") is not None:      # the BSConvU it stands for: pointwise GEMM + depthwise 3x3
                     flops = 2.0 * npix * (ca * o["cout"] + 9 * o["cout"])
                     rd = npix * (ca * e_in + (o["cout"] * e_act if (o["res"] is not None and o["res"] is not o["src"]) else 0)) + 4.0 * (ca * o["cout"] + 10 * o["cout"])
                     if o.get("head"):
-                        rd -= npix * ca * e_in
+                        rd += npix * (16 * 2 - ca * e_in)
                 t = o.get("tail")
                 if t is not None:                   # 3x3 -> 1x1 in one kernel: both GEMMs' flops, the 1x1's traffic
                     kern = f"conv_f32_kernel<NT={nt},KS=3,NCHW_IN=0,NW=4,TAIL={(t['cout'] + 15) // 16}>"
@@ -981,7 +1020,7 @@ class HipSRModel(nn.Module):
                 npl = plan.n * dst.h * dst.w
                 h2, w2 = (src.h - 3) // 2 + 1, (src.w - 3) // 2 + 1
                 f = o["f"]
-                kern = f"esa_s2pool{'16' if plan.store else ''}_kernel<{L.STORE[plan.store]}> + esa_chain_kernel"
+                kern = f"esa_s2pool{'16' if plan.esize == 2 else ''}_kernel<{L.STORE[plan.store]}> + esa_chain_kernel"
                 flops = 2.0 * 9 * f * f * plan.n * h2 * w2
                 for ly in o["layers"]:
                     flops += 2.0 * npl * (9 * f * f if ly["kind"] == 0 else f * f + 9 * f)

@@ -106,10 +106,11 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
         lr_path, hr_path = data_path[i]
         return util.imread_uint(lr_path, n_channels=3), util.modcrop(util.imread_uint(hr_path, n_channels=3).squeeze(), sf)
 
-    def log_row(i, ms, psnr, img_sr_u8, img_hr):
+    def log_row(i, ms, psnr, img_sr_u8, img_hr, ssim=None):
         img_name, ext = os.path.splitext(os.path.basename(data_path[i][1]))
         if want_ssim:
-            ssim = util.calculate_ssim(img_sr_u8, img_hr, border=border)
+            if ssim is None:                     # serial loop: host evaluation; the pipeline passes the device result (ops.ssim_sum_device)
+                ssim = util.calculate_ssim(img_sr_u8, img_hr, border=border)
             logger.info("{:s} - PSNR: {:.2f} dB; SSIM: {:.4f}.".format(img_name + ext, psnr, ssim))
         else:
             ssim = float("nan")
@@ -162,26 +163,9 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
 
         prep_ms = []
 
-        def retire():
-            i, start, end, done, sr_host, se_dev, count, img_hr, fin_dev = inflight.pop(0)
-            done.synchronize()                                   # this image's D2H (and everything before it) has finished
-            ms = start.elapsed_time(end)
-            if not bool(fin_dev.item()) and hasattr(model, "invalidate_workspaces"):
-                # Inf / NaN in this output (activations overflowed, 16-bit modes): the workspaces are shared between shapes without
-                # re-zeroing, so isolate the following images from whatever this one left in other shapes' pad slots
-                logger.warning("non-finite values in the output of image %d: workspaces will be cleared", i)
-                model.invalidate_workspaces()
-            se = int(se_dev.item())
-            psnr = float("inf") if se == 0 else 20 * math.log10(255.0 / math.sqrt(se / count))
-            img_sr = sr_host.numpy()
-            writes.append(writers.submit(util.imsave, img_sr, log_row(i, ms, psnr, img_sr, img_hr)))
-
-        for k, i in enumerate(mine):
-            lr, img_hr = ahead[k].result()
-            ahead[k] = None
-            if nxt < len(mine):
-                ahead.append(readers.submit(load_pair, mine[nxt]))
-                nxt += 1
+        def enqueue(k, i, lr, img_hr):
+            """H2D, prepare(), the event-bracketed forward and the device-side metrics of image i on compute stream k % ngs; returns
+            its in-flight record.  Nothing here waits for the GPU."""
             with torch.cuda.stream(compute_streams[k % ngs]):
                 img_lr = util.uint2tensor4(lr, data_range).to(device, non_blocking=True)
                 hr_dev = torch.from_numpy(np.ascontiguousarray(img_hr)).to(device, non_blocking=True)
@@ -197,11 +181,13 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
                 start.record()
                 img_sr = forward(img_lr, model, tile)
                 end.record()
-                fin_dev = torch.isfinite(img_sr).all()
-                sr_dev = ops.tensor2uint_device(img_sr, data_range)
+                # Inf / NaN check folded into tensor2uint (esr_tensor2uint_u8_chk): one int on the device, no full-size isfinite pass
+                bad_dev = torch.zeros(1, dtype=torch.int32, device=device)
+                sr_dev = ops.tensor2uint_device(img_sr, data_range, nonfinite=bad_dev)
                 if sr_dev.shape != hr_dev.shape:
                     raise ValueError('Input images must have the same dimensions.')
                 se_dev = ops.sqerr_device(sr_dev, hr_dev, border=border)
+                ssim_dev = ops.ssim_sum_device(sr_dev, hr_dev, border=border) if want_ssim else None     # (device scalar, count)
                 ready = torch.cuda.Event()
                 ready.record()
                 sr_host = torch.empty(sr_dev.shape, dtype=torch.uint8, pin_memory=True)
@@ -212,7 +198,37 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
                     done = torch.cuda.Event()
                     done.record()
             hh, ww = sr_dev.shape[:2]
-            inflight.append((i, start, end, done, sr_host, se_dev, (hh - 2 * border) * (ww - 2 * border) * sr_dev.shape[2], img_hr, fin_dev))
+            return dict(k=k, i=i, lr=lr, hr=img_hr, start=start, end=end, done=done, sr_host=sr_host, se=se_dev, ssim=ssim_dev, bad=bad_dev,
+                        count=(hh - 2 * border) * (ww - 2 * border) * sr_dev.shape[2])
+
+        def retire():
+            r = inflight.pop(0)
+            r["done"].synchronize()                              # this image's D2H (and everything before it) has finished
+            ms = r["start"].elapsed_time(r["end"])
+            if bool(r["bad"].item()) and hasattr(model, "invalidate_workspaces"):
+                # Inf / NaN in this output (activations overflowed, 16-bit modes).  The workspaces are shared between shapes without
+                # re-zeroing, so whatever this image left in other shapes' pad slots must not reach another image: clear the
+                # workspaces and RUN AGAIN the images that were enqueued behind it in the meantime (the check is read
+                # when the image retires, up to `window` images late).  Their records are replaced in place: order, log lines
+                # and files stay those of the serial loop.
+                logger.warning("non-finite values in the output of image %d: workspaces cleared, %d image(s) in flight run again", r["i"], len(inflight))
+                torch.cuda.synchronize(device)
+                model.invalidate_workspaces()
+                for j, q in enumerate(inflight):
+                    inflight[j] = enqueue(q["k"], q["i"], q["lr"], q["hr"])
+            se = int(r["se"].item())
+            psnr = float("inf") if se == 0 else 20 * math.log10(255.0 / math.sqrt(se / r["count"]))
+            ssim = float(r["ssim"][0].item()) / r["ssim"][1] if r["ssim"] is not None else None
+            img_sr = r["sr_host"].numpy()
+            writes.append(writers.submit(util.imsave, img_sr, log_row(r["i"], ms, psnr, img_sr, r["hr"], ssim)))
+
+        for k, i in enumerate(mine):
+            lr, img_hr = ahead[k].result()
+            ahead[k] = None
+            if nxt < len(mine):
+                ahead.append(readers.submit(load_pair, mine[nxt]))
+                nxt += 1
+            inflight.append(enqueue(k, i, lr, img_hr))
             if len(inflight) > window:
                 retire()
         while inflight:
@@ -337,8 +353,10 @@ def main(args):
 
 def build_parser():
     p = argparse.ArgumentParser("NTIRE2022-EfficientSR")
-    p.add_argument("--data_dir", default="/cluster/work/cvl/yawli/data/NTIRE2022_Challenge", type=str)
-    p.add_argument("--save_dir", default="/cluster/work/cvl/yawli/data/NTIRE2022_Challenge/results", type=str)
+    # (the reference's defaults are its author's cluster paths, test_demo.py:570-571; neutral ones here)
+    p.add_argument("--data_dir", default="./data/NTIRE2022_Challenge", type=str,
+                   help="root holding DIV2K_valid_LR / DIV2K_valid_HR (/ DIV2K_test_LR), test_demo.py:344-361")
+    p.add_argument("--save_dir", default="./results", type=str)
     p.add_argument("--model_id", default=0, type=int)
     p.add_argument("--include_test", action="store_true", help="Inference on the DIV2K test set")
     p.add_argument("--ssim", action="store_true", help="Calculate SSIM")

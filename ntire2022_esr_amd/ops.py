@@ -142,8 +142,10 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
     return (y, yp) if yp2 is None else (y, yp, yp2)
 
 
-def tensor2uint_device(img_sr, data_range):
-    """utils_image.tensor2uint on the GPU: [1,C,H,W] (or [C,H,W]) fp32 -> HWC uint8 tensor on the same device."""
+def tensor2uint_device(img_sr, data_range, nonfinite=None):
+    """utils_image.tensor2uint on the GPU: [1,C,H,W] (or [C,H,W]) fp32 -> HWC uint8 tensor on the same device.
+    nonfinite: optional 1-element int32 DEVICE tensor (caller-zeroed) that the kernel ORs 1 into when the image holds an Inf / NaN
+    (esr_tensor2uint_u8_chk) -- the harness's overflow check without a full-size isfinite pass."""
     if not img_sr.is_cuda:
         raise L.EsrError("tensor2uint_device: tensor must live on the GPU")
     t = img_sr.detach()
@@ -154,9 +156,42 @@ def tensor2uint_device(img_sr, data_range):
     c, h, w = t.shape
     out = torch.empty((h, w, c), dtype=torch.uint8, device=t.device)
     stream = torch.cuda.current_stream(t.device).cuda_stream
+    if nonfinite is not None:
+        assert nonfinite.is_cuda and nonfinite.dtype == torch.int32 and nonfinite.numel() == 1
+        L.check(L.lib().esr_tensor2uint_u8_chk(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(out.data_ptr()), c, h, w, ctypes.c_float(data_range),
+                                               ctypes.c_void_p(nonfinite.data_ptr()), ctypes.c_void_p(stream)), "esr_tensor2uint_u8_chk")
+        return out
     L.check(L.lib().esr_tensor2uint_u8(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(out.data_ptr()), c, h, w,
                                        ctypes.c_float(data_range), ctypes.c_void_p(stream)), "esr_tensor2uint_u8")
     return out
+
+
+def ssim_sum_device(a_u8, b_u8, border=0):
+    """calculate_ssim's numerator on the GPU (utils/utils_image.py:509-554, esr_ssim_u8): the SSIM map of two HWC (or HW) uint8 CUDA
+    tensors summed over the 'valid' region of the border-cropped image and all channels, as a 0-dim float64 DEVICE tensor (no host
+    synchronisation), and the number of map elements it was summed over.  ssim = sum / count."""
+    if a_u8.shape != b_u8.shape:
+        raise ValueError('Input images must have the same dimensions.')
+    a, b = a_u8.contiguous(), b_u8.contiguous()
+    h, w = a.shape[:2]
+    c = a.shape[2] if a.dim() == 3 else 1
+    if a.dim() not in (2, 3) or c not in (1, 3):
+        raise ValueError('Wrong input image dimensions.')
+    n = int(L.lib().esr_ssim_partials(h, w, c, border))
+    if n == 0:
+        raise L.EsrError(f"ssim_device: a {h}x{w} image cropped by {border} is smaller than the 11x11 window")
+    partials = torch.empty(n, dtype=torch.float64, device=a.device)
+    stream = torch.cuda.current_stream(a.device).cuda_stream
+    L.check(L.lib().esr_ssim_u8(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), h, w, c, border,
+                                ctypes.c_void_p(partials.data_ptr()), n, ctypes.c_void_p(stream)), "esr_ssim_u8")
+    return partials.sum(), (h - 2 * border - 10) * (w - 2 * border - 10) * c
+
+
+def ssim_device(a_u8, b_u8, border=0):
+    """calculate_ssim for two uint8 CUDA tensors: one scalar D2H.  Parity: pinned to image_util.calculate_ssim (the reference's needs
+    cv2, absent in the authoring container: PARITY-UNPINNED against the reference itself)."""
+    s, count = ssim_sum_device(a_u8, b_u8, border)
+    return float(s.item()) / count
 
 
 def sqerr_device(a_u8, b_u8, border=0):

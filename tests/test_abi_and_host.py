@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libesr_hip.so does not export {s}"
     assert set(L.EXPORTS) == set(syms), (set(L.EXPORTS) ^ set(syms))
-    assert lib.esr_abi_version() == 8
+    assert lib.esr_abi_version() == 9
     # the ctypes mirrors of the ABI structs have the library's sizes (also checked by _lib.lib() at load time)
     for which, st in enumerate((L.View, L.ConvDesc, L.EsaDesc, L.BsDesc, L.CaDesc, L.Op, L.EsaLowresDesc)):
         assert lib.esr_sizeof(which) == ctypes.sizeof(st) > 0, st.__name__
@@ -185,14 +185,39 @@ def test_s16_packer_layout_diffusion_and_split():
     assert lib.esr_packed_conv_s16_bytes(64, 64, 2) == 0
 
 
-def test_conv_s16_isa_lint():
-    """tools/lint_s16_isa.py: no scratch access / VGPR spill in any conv_s16_kernel variant (its vmcnt arithmetic counts every
-    vector-memory instruction) and no copy out of a register an in-flight residual load writes.  Cross-compiles esr_s16.hip to
-    assembly (about a minute and a half, no GPU)."""
+def test_isa_lint():
+    """tools/lint_isa.py over EVERY translation unit of the library (cross-compiled to gfx950 assembly, cached under build/isa; about a
+    minute, no GPU): (1) no packed-fp32 instruction with an op_sel that reads a high dword -- the gfx950 erratum behind round 3's
+    overlapped-forward defect (LAB_NOTES.md); (2) tools/lint_s16_isa.py: no scratch access / VGPR spill in any conv_s16_kernel variant
+    (its vmcnt arithmetic counts every vector-memory instruction) and no copy out of a register an in-flight residual load writes."""
     import subprocess, sys
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lint_s16_isa.py")],
-                       capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lint_isa.py")],
+                       capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_isa_lint_flags_the_round3_apply_loop():
+    """The lint catches the defect it was written for: esr_esa.hip with the round-3 group loop (a fetched group carried over the back
+    edge, lx / ly travelling as a register pair, no esr_lone) compiles to `v_pk_mul_f32 ... op_sel:[0,1]` in every
+    esa_apply_mfma_kernel instantiation -- the encoding that returned 0 in lanes 48..63 beside another kernel's MFMAs; the same loop
+    WITH esr_lone() is clean."""
+    import subprocess, sys, tempfile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(repo, "tools"))
+    sys.path.insert(0, os.path.join(repo, "tools", "dbg"))
+    import lint_isa
+    import race_dump
+    d = tempfile.mkdtemp(prefix="esr_lint_old_")
+    counts = {}
+    for tag, exps in (("round3", ("nolone",)), ("fixed", ())):
+        src, asm = os.path.join(d, f"esr_esa_{tag}.hip"), os.path.join(d, f"esr_esa_{tag}.s")
+        open(src, "w").write(race_dump.patched("old", dump=False, exps=exps))
+        subprocess.check_call([lint_isa.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(repo, "include"), "-I", lint_isa.CSRC,
+                               "-S", "--cuda-device-only", src, "-o", asm], stderr=subprocess.DEVNULL)
+        counts[tag] = [k for k, _ in lint_isa.lint_opsel(asm)]
+    assert counts["round3"] and all("esa_apply_mfma_kernel" in k for k in counts["round3"]), counts["round3"][:3]
+    assert len({k for k in counts["round3"]}) >= 10            # every instantiation (5 shapes x 2 storages)
+    assert counts["fixed"] == []
 
 
 def test_merged_bsconv_algebra_cpu():

@@ -78,6 +78,10 @@ def test_harness_ssim_flag(tmp_path):
                 pairs=H.select_dataset(args.data_dir, "valid")[:3])
     assert len(res["valid_ssim"]) == 3 and all(0.5 < v < 1.0 for v in res["valid_ssim"])
     assert res["valid_ave_ssim"] == sum(res["valid_ssim"]) / 3
+    # the pipeline computed them on the device (ops.ssim_sum_device); the serial loop computes them on the host: same numbers
+    a2 = types.SimpleNamespace(data_dir=args.data_dir, save_dir=str(tmp_path / "serial"), rank=0, world=1, ssim=True, device_metrics=False)
+    res2 = H.run(model, name, data_range, tile, logging.getLogger("gpu"), dev, a2, mode="valid", pairs=H.select_dataset(args.data_dir, "valid")[:3])
+    assert res["valid_ssim"] == pytest.approx(res2["valid_ssim"], abs=1e-9)
 
 
 def test_device_tensor2uint_and_psnr_match_host():
@@ -101,6 +105,90 @@ def test_device_tensor2uint_and_psnr_match_host():
     big2 = (big.int() + torch.randint(-5, 6, big.shape, generator=g)).clamp(0, 255).to(torch.uint8)
     assert ops.psnr_device(big.to("cuda:0"), big2.to("cuda:0"), 4) == pytest.approx(
         util.calculate_psnr(big.numpy(), big2.numpy(), 4), abs=1e-10)
+
+
+def test_device_ssim_matches_host():
+    """esr_ssim_u8 (metrics on the device, one scalar D2H) against image_util.calculate_ssim -- the host restatement of
+    utils/utils_image.py:509-554, itself parity-unpinned against the reference (cv2 absent) -- to 1e-9: 3-channel (the reference's
+    "whole HxWx3 array three times" quirk = the mean over all channels), single channel, borders, a ragged size that leaves partial
+    tiles, a DIV2K-sized pair, and the smallest image the 11x11 window fits."""
+    import numpy as np
+    from ntire2022_esr_amd import image_util as util, ops, _lib as L
+    g = torch.Generator().manual_seed(5)
+    cases = [((64, 80, 3), 4), ((37, 53, 3), 0), ((45, 41), 4), ((11, 11, 3), 0), ((19, 30, 1), 4), ((1356, 2040, 3), 4)]
+    for shape, border in cases:
+        a = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
+        noise = torch.randint(-12, 13, shape, generator=g)
+        b = (a.int() + noise).clamp(0, 255).to(torch.uint8)
+        if len(shape) == 3 and shape[0] > 100:                  # structured content: smooth gradients + noise
+            yy, xx = torch.meshgrid(torch.arange(shape[0]), torch.arange(shape[1]), indexing="ij")
+            base = ((yy * 0.11 + xx * 0.07) % 256).to(torch.uint8)
+            a = (base[..., None].int() + torch.randint(-3, 4, shape, generator=g)).clamp(0, 255).to(torch.uint8)
+            b = (a.int() + torch.randint(-6, 7, shape, generator=g)).clamp(0, 255).to(torch.uint8)
+        want = util.calculate_ssim(a.numpy(), b.numpy(), border=border)
+        got = ops.ssim_device(a.to("cuda:0"), b.to("cuda:0"), border=border)
+        assert abs(got - want) <= 1e-9, (shape, border, got, want)
+    same = torch.randint(0, 256, (40, 40, 3), dtype=torch.uint8, generator=g).to("cuda:0")
+    assert ops.ssim_device(same, same, 4) == pytest.approx(1.0, abs=1e-12)
+    with pytest.raises(L.EsrError):
+        ops.ssim_device(same[:14, :14], same[:14, :14], 4)          # 6 x 6 after the crop: no 11 x 11 window fits
+    with pytest.raises(ValueError):
+        ops.ssim_device(same, same[:, :39], 0)
+
+
+def test_checked_tensor2uint_flags_nonfinite():
+    """esr_tensor2uint_u8_chk: the same uint8 image as esr_tensor2uint_u8 and a device flag that is set exactly when an Inf / NaN is present"""
+    import numpy as np
+    from ntire2022_esr_amd import image_util as util, ops
+    g = torch.Generator().manual_seed(2)
+    y = (torch.rand(1, 3, 61, 47, generator=g) * 1.4 - 0.2)
+    for poison in (None, float("inf"), float("-inf"), float("nan")):
+        t = y.clone()
+        if poison is not None:
+            t[0, 1, 60, 46] = poison
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+        got = ops.tensor2uint_device(t.to("cuda:0"), 1.0, nonfinite=flag).cpu().numpy()
+        assert int(flag.item()) == (0 if poison is None else 1)
+        if poison is None:
+            assert np.array_equal(got, util.tensor2uint(t, 1.0))
+        else:
+            assert np.array_equal(got[:60], util.tensor2uint(t, 1.0)[:60])
+
+
+def test_pipeline_reruns_images_behind_a_nonfinite_one(tmp_path, monkeypatch):
+    """An image whose output holds Inf / NaN makes the pipeline clear the workspaces AND run again the images that were enqueued behind
+    it: results of all other images equal the clean run's, the warning is logged once."""
+    from ntire2022_esr_amd import harness as H, ops
+    from ntire2022_esr_amd.registry import select_model
+    dev = torch.device("cuda:0")
+    model, name, data_range, tile = select_model(4, dev)
+    pairs = H.select_dataset(os.path.join(GOLD, "mini_div2k"), "valid")[:3] * 2           # six images in flight
+    log = logging.getLogger("gpu")
+    a0 = types.SimpleNamespace(save_dir=str(tmp_path / "clean"), rank=0, world=1, io_workers=2, inflight=3)
+    r0 = H.run(model, name, data_range, tile, log, dev, a0, mode="valid", pairs=pairs)
+    calls = {"n": 0, "invalidated": 0}
+    real_fwd, real_inv = H.forward, model.invalidate_workspaces
+
+    def poisoned_forward(img_lq, mdl, tile=None, **kw):
+        y = real_fwd(img_lq, mdl, tile, **kw)
+        calls["n"] += 1
+        if calls["n"] == 2:                                      # the second image overflows
+            y = y.clone()
+            y[0, 0, 0, 0] = float("inf")
+        return y
+
+    def counting_invalidate():
+        calls["invalidated"] += 1
+        return real_inv()
+
+    monkeypatch.setattr(H, "forward", poisoned_forward)
+    monkeypatch.setattr(model, "invalidate_workspaces", counting_invalidate)
+    a1 = types.SimpleNamespace(save_dir=str(tmp_path / "poisoned"), rank=0, world=1, io_workers=2, inflight=3)
+    r1 = H.run(model, name, data_range, tile, log, dev, a1, mode="valid", pairs=pairs)
+    assert calls["invalidated"] == 1 and calls["n"] > len(pairs)          # some images ran twice
+    for j in range(len(pairs)):
+        if j != 1:
+            assert r1["valid_psnr"][j] == r0["valid_psnr"][j], j
 
 
 def test_pipeline_equals_serial_loop(tmp_path):

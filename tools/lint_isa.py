@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""ISA lint of every kernel of libesr_hip.so (hipcc cross-compiles each translation unit to gfx950 assembly; no GPU needed).
+
+Rule 1 -- the packed-fp32 op_sel erratum (round 4, LAB_NOTES.md; reproduced in isolation by tools/dbg/pk_opsel_probe.hip):
+    a v_pk_{mul,add,fma}_f32 / v_pk_mov_b32 whose `op_sel:[...]` has a 1 -- a LOW result half reading the HIGH dword of a 64-bit source
+    pair -- returns 0 in lanes 48..63 when a wave of another kernel issues MFMAs on the same SIMD (forwards on several HIP streams).
+    hipcc emits that encoding whenever a scalar factor happens to sit in the odd register of a pair; the sources route such factors
+    through esr_lone() (csrc/esr_internal.h).  No kernel of the library may contain the encoding.
+Rule 2 -- conv_s16_kernel's wait-count arithmetic (tools/lint_s16_isa.py, unchanged): no scratch / spills, no copies out of registers an
+    in-flight asm load writes.
+
+usage: lint_isa.py [--src FILE.hip ...]      exit status 0 = clean.   Assemblies are cached under build/isa/ by source hash."""
+import hashlib, os, re, subprocess, sys
+from concurrent.futures import ThreadPoolExecutor
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(REPO, "ntire2022_esr_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+BAD_OPSEL = re.compile(r"^\s+(v_pk_(?:mul|add|fma)_f32|v_pk_mov_b32)\b.*\bop_sel:\[([01,]+)\]", re.M)
+
+
+def _deps_hash(src):
+    h = hashlib.sha256(open(src, "rb").read())
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".inc", ".h")) and not f.endswith(".gen.h"):
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(REPO, "include", "esr_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def assemble(src):
+    """src (.hip) -> path of its gfx950 assembly (cached)."""
+    d = os.path.join(REPO, "build", "isa")
+    os.makedirs(d, exist_ok=True)
+    out = os.path.join(d, f"{os.path.basename(src)[:-4]}.{_deps_hash(src)}.s")
+    if not os.path.exists(out):
+        tmp = out + f".tmp{os.getpid()}"
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(REPO, "include"), "-I", CSRC,
+                               "-S", "--cuda-device-only", src, "-o", tmp], stderr=subprocess.DEVNULL)
+        os.replace(tmp, out)
+        for f in os.listdir(d):                                   # older assemblies of the same unit
+            if f.startswith(os.path.basename(src)[:-4] + ".") and f.endswith(".s") and os.path.join(d, f) != out:
+                os.remove(os.path.join(d, f))
+    return out
+
+
+def lint_opsel(path):
+    """[(kernel symbol, instruction text)] for every packed-fp32 instruction with a 1 in op_sel."""
+    txt = open(path).read()
+    labels = [(m.start(), m.group(1)) for m in re.finditer(r"^(_Z\w+):", txt, re.M)]
+    out = []
+    for m in BAD_OPSEL.finditer(txt):
+        if "1" not in m.group(2):
+            continue
+        name = "?"
+        for pos, lab in labels:
+            if pos > m.start():
+                break
+            name = lab
+        out.append((name, " ".join(m.group(0).split())))
+    return out
+
+
+def main(argv):
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    if "--src" in argv:
+        srcs = argv[argv.index("--src") + 1:]
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
+        asms = list(ex.map(assemble, srcs))
+    problems = []
+    for src, a in zip(srcs, asms):
+        hits = lint_opsel(a)
+        by_kernel = {}
+        for k, ins in hits:
+            by_kernel.setdefault(k, []).append(ins)
+        for k, v in by_kernel.items():
+            problems.append(f"{os.path.basename(src)}: {k}: {len(v)} packed-fp32 instruction(s) with op_sel reading a high dword, e.g. `{v[0]}`")
+        if os.path.basename(src) == "esr_s16.hip":
+            sys.path.insert(0, os.path.join(REPO, "tools"))
+            import lint_s16_isa
+            n, p2 = lint_s16_isa.lint(a)
+            print(f"{n} conv_s16_kernel variants checked (tools/lint_s16_isa.py)")
+            if n == 0:
+                p2 = p2 + ["no conv_s16_kernel variant found in esr_s16.s"]
+            problems += p2
+    print(f"{len(srcs)} translation units, {len(problems)} problems")
+    for p in problems:
+        print("  ", p)
+    return 1 if problems else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

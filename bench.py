@@ -116,6 +116,161 @@ def cpu_baseline(name, shape, budget_s=16.0):
                       f"{phys} physical cores); oracle/torch_port.py = the reference's ATen op sequence on oneDNN"}
 
 
+def library_build():
+    """esr_source_hash() of the libesr_hip.so this process runs (include/esr_hip.h, ABI v9)"""
+    from ntire2022_esr_amd import _lib as L
+    return L.lib().esr_source_hash().decode()
+
+
+def roofline_from_profile(prof, peak, traffic_key, events_desc):
+    """The roofline object of a JSON line from per-op event times (HipSRModel.collect_profile): dominant kernel symbol = largest share
+    of the timed kernel time; ALGORITHMIC flops / bytes per launch over its average launch duration against the dense MFMA peak of its
+    operand type and the HBM peak.  Returns (roofline dict, executed flops per step)."""
+    by_kernel = {}
+    for o in prof:
+        by_kernel[o["kernel"]] = by_kernel.get(o["kernel"], 0.0) + o["ms_sum"]
+    dom_name = max(by_kernel, key=by_kernel.get)
+    dom = [o for o in prof if o["kernel"] == dom_name]
+    launches = sum(o["passes"] for o in dom)
+    ms = sum(o["ms_sum"] for o in dom)
+    flops = sum(o["flops"] * o["passes"] for o in dom) / launches                 # algorithmic = direct-convolution flops (SURVEY 8d)
+    flops_exec = sum(o["flops_exec"] * o["passes"] for o in dom) / launches       # what the matrix cores execute (Winograd: 16/36)
+    nbytes = sum((o["read_bytes"] + o["write_bytes"]) * o["passes"] for o in dom) / launches
+    total_ms = sum(o["ms_sum"] for o in prof)
+    avg_s = ms / launches * 1e-3
+    tflops, gbs = flops_exec / avg_s / 1e12, nbytes / avg_s / 1e9
+    tflops_direct = flops / avg_s / 1e12
+    # 16-bit modes: conv_s16 / bsconv / esa kernels multiply on v_mfma_f32_16x16x32; the NCHW head and the ESA low-resolution
+    # convs (conv_f32_kernel) stay on the fp32 MFMA in every mode
+    kpeak = peak if not dom_name.startswith(("conv_f32", "wino_f32", "wino8_f32")) else PEAK_TFLOPS["f32"]
+    f_mfma, f_hbm = tflops / kpeak, gbs / HBM_PEAK_GBS
+    # PMC traffic: replayed from profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.py)
+    # ONLY when it was recorded for the library build that is running (esr_source_hash); a stale file gives traffic = null
+    traffic, traffic_src = None, None
+    tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            ent = json.load(open(tpath)).get(traffic_key, {})
+            have, want = ent.get("_build"), library_build()
+            if ent and have != want:
+                traffic_src = (f"profiles/pmc_traffic.json holds {traffic_key} for library build {str(have)[:12]}, this run is build {want[:12]}: "
+                               "not replayed (re-collect: tools/profile_r04.sh)")
+            else:
+                traffic = ent.get(dom_name, {}).get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic_src = (f"profiles/pmc_traffic.json, {ent.get('_round', '?')}, library build {want[:12]} (= this run's): separate "
+                                   "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an EARLIER run (tools/pmc_traffic.py), "
+                                   "not measured in this run")
+        except Exception:
+            traffic = None
+    if f_mfma >= f_hbm:
+        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(tflops, 2), "peak": kpeak, "unit": "TFLOP/s",
+                    "frac": round(f_mfma, 4), "traffic": traffic}
+    else:
+        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(f_hbm, 4), "traffic": traffic}
+    roofline.update({"traffic_source": traffic_src, "launches": launches, "avg_launch_ms": round(ms / launches, 4),
+                     "algorithmic_gflop_per_launch": round(flops / 1e9, 3),
+                     "executed_gflop_per_launch": round(flops_exec / 1e9, 3),
+                     "direct_equivalent_tflops": round(tflops_direct, 2),
+                     # both definitions side by side (VERDICT r03): frac prices EXECUTED flops (<= 1 by construction), frac_algorithmic
+                     # prices SURVEY 8d's algorithmic (direct-convolution) flops over the same time -- above 1 for a Winograd kernel
+                     "frac_algorithmic": round(tflops_direct / kpeak, 4),
+                     "flops_accounting": ("achieved / frac price the flops the matrix cores EXECUTE (Winograd F(2x2,3x3): 16 products per 2x2 "
+                                          "outputs and (cin, cout) where the direct convolution has 36); direct_equivalent_tflops / "
+                                          "frac_algorithmic = the algorithmic (direct) flops of SURVEY 8d over the same time"),
+                     "algorithmic_mb_per_launch": round(nbytes / 1e6, 2),
+                     "frac_of_mfma_peak": round(f_mfma, 4), "frac_of_hbm_peak": round(f_hbm, 4),
+                     "share_of_kernel_time": round(ms / total_ms, 4)})
+    # every kernel symbol: share of the step, achieved TFLOP/s and GB/s on algorithmic work
+    table = []
+    for kn, kms in sorted(by_kernel.items(), key=lambda kv: -kv[1]):
+        ops = [o for o in prof if o["kernel"] == kn]
+        n = sum(o["passes"] for o in ops)
+        fl = sum(o["flops_exec"] * o["passes"] for o in ops)
+        fd = sum(o["flops"] * o["passes"] for o in ops)
+        by = sum((o["read_bytes"] + o["write_bytes"]) * o["passes"] for o in ops)
+        table.append({"kernel": kn, "share": round(kms / total_ms, 4), "avg_ms": round(kms / n, 4),
+                      "tflops": round(fl / (kms * 1e-3) / 1e12, 2), "tflops_direct_equivalent": round(fd / (kms * 1e-3) / 1e12, 2),
+                      "gbs": round(by / (kms * 1e-3) / 1e9, 1)})
+    exec_per_step = sum(o["flops_exec"] * o["passes"] for o in prof) / max(1, max(o["passes"] for o in prof))
+    roofline["kernels"] = table
+    roofline["events"] = events_desc
+    roofline["library_build"] = library_build()
+    return roofline, exec_per_step
+
+
+# What the driver's fixed command also reports (VERDICT r03 #4): the other BASELINE.json configs, measured right behind the headline's
+# timed region in the same process, a second or two each.  (model, compute, sizes, tile, batch, streams)
+OTHER_CONFIGS = [
+    ("rfdn_baseline", "bf16", "div2k", None, 1, 4),          # config [2]
+    ("team04_rlfn", "bf16", "div2k", None, 1, 1),            # config [3], the reference's strictly serial loop
+    ("team04_rlfn", "bf16", "div2k", None, 1, 4),            # config [3], four HIP streams
+    ("team18_bsrn", "f16", "tile", (270, 480), 32, 1),       # config [4]
+]
+
+
+def measure_other_config(spec, device, budget_s=1.2):
+    """One entry of `other_configs`: un-instrumented timed steps (the number that fits ~budget_s after 2 warm-up steps), then a replay of
+    a few steps on one stream with a HIP event pair around every launch for the dominant kernel's roofline."""
+    import torch
+    name, compute, sizes, tile, B, nstreams = spec
+    _, dr, gflop256 = MODELS[name]
+    model, _ = build_model(name, device, compute)
+    shapes = DIV2K_LR_SHAPES if sizes == "div2k" else [tile]
+    gen = torch.Generator().manual_seed(0)
+    xs = [(torch.rand(B, 3, h, w, generator=gen) * dr).to(device) for h, w in shapes]
+    streams = [torch.cuda.Stream(device) for _ in range(nstreams)] if nstreams > 1 else None
+
+    def step(spread=True):
+        if streams is None or not spread:
+            for x in xs:
+                model(x)
+        else:
+            for k, x in enumerate(xs):
+                with torch.cuda.stream(streams[k % nstreams]):
+                    model(x)
+
+    with torch.no_grad():
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize(device)
+        one = max(time.perf_counter() - t0, 1e-4)
+        steps = int(min(200, max(5, budget_s / one)))
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(device)
+        elapsed = time.perf_counter() - t0
+        psteps = 3
+        step(False)
+        model.enable_profiling(psteps)
+        step(False)
+        torch.cuda.synchronize(device)
+        model.collect_profile()
+        for _ in range(psteps):
+            step(False)
+        torch.cuda.synchronize(device)
+        prof = model.collect_profile()
+        model.disable_profiling()
+    imgs = B * len(xs) * steps
+    if sizes == "div2k":
+        wl = f"{name} x4 {compute}, DIV2K-val-shaped LR images (10 per step, B = {B} per forward, {nstreams} HIP stream(s))"
+        tkey = f"{name}:{compute}:div2k"
+    else:
+        wl = f"{name} x4 {compute}, {B}x3x{tile[0]}x{tile[1]} LR batch -> {B}x3x{4 * tile[0]}x{4 * tile[1]}"
+        tkey = f"{name}:{compute}:{B}x{tile[0]}x{tile[1]}"
+    r, _ = roofline_from_profile(prof, PEAK_TFLOPS[compute], tkey, f"replay of {psteps} steps on one stream with a HIP event pair around every launch")
+    del model
+    return {"workload": wl, "dtype": compute, "value": round(imgs / elapsed, 2), "unit": "images/s", "steps": steps,
+            "ms_per_step": round(elapsed / steps * 1e3, 3), "ms_per_image": round(elapsed / imgs * 1e3, 4), "streams": nstreams,
+            "roofline": {k: r[k] for k in ("kernel", "bound", "frac", "avg_launch_ms", "achieved", "peak", "unit", "traffic", "share_of_kernel_time")}}
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -147,6 +302,8 @@ def parse_args():
                          "runtimes gathered once after the timed region (dist.gather_rows): BASELINE.json config [3] with N = 200 "
                          "(DIV2K valid + test).  The total work is fixed, so the line says \"scaling\": \"strong\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default headline run only: skip the `other_configs` leg (BASELINE.json configs [2]-[4] measured behind the timed region)")
     ap.add_argument("--b1-latency", action="store_true",
                     help="also report the latency of a single-image forward (extra launches after the timed region: "
                          "keep it off when the run is profiled, the B=1 launches would enter the per-kernel averages)")
@@ -337,74 +494,15 @@ def main():
                      "how": "one event pair per forward in an extra pass on one stream (test_demo.py:429-433), rows gathered with one "
                             "all_gather_into_tensor and averaged in index order in float64 (ntire2022_esr_amd/dist.py)"}
 
-    roofline = None
+    roofline, exec_per_step = None, 0.0
     if not args.no_kernel_events:
         prof = model.collect_profile()
         model.disable_profiling()
-        # dominant kernel = the kernel symbol with the largest share of the timed kernel time
-        by_kernel = {}
-        for o in prof:
-            by_kernel[o["kernel"]] = by_kernel.get(o["kernel"], 0.0) + o["ms_sum"]
-        dom_name = max(by_kernel, key=by_kernel.get)
-        dom = [o for o in prof if o["kernel"] == dom_name]
-        launches = sum(o["passes"] for o in dom)
-        ms = sum(o["ms_sum"] for o in dom)
-        flops = sum(o["flops"] * o["passes"] for o in dom) / launches                 # algorithmic = direct-convolution flops
-        flops_exec = sum(o["flops_exec"] * o["passes"] for o in dom) / launches       # what the matrix cores execute (Winograd: 16/36)
-        nbytes = sum((o["read_bytes"] + o["write_bytes"]) * o["passes"] for o in dom) / launches
-        total_ms = sum(o["ms_sum"] for o in prof)
-        avg_s = ms / launches * 1e-3
-        # the MFMA fraction is priced on EXECUTED flops (<= 1 by construction); the direct-equivalent rate is reported next to it
-        tflops, gbs = flops_exec / avg_s / 1e12, nbytes / avg_s / 1e9
-        tflops_direct = flops / avg_s / 1e12
-        # 16-bit modes: conv_s16 / bsconv / esa kernels multiply on v_mfma_f32_16x16x32; the NCHW head and the ESA low-resolution
-        # convs (conv_f32_kernel) stay on the fp32 MFMA in every mode
-        kpeak = peak if not dom_name.startswith(("conv_f32", "wino_f32")) else PEAK_TFLOPS["f32"]
-        f_mfma, f_hbm = tflops / kpeak, gbs / HBM_PEAK_GBS
-        traffic, traffic_src = None, None
-        tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tkey = f"{args.model}:{args.compute}:div2k" if args.sizes == "div2k" else f"{args.model}:{args.compute}:{B}x{th}x{tw}"
-                ent = json.load(open(tpath)).get(tkey, {})
-                traffic = ent.get(dom_name, {}).get("hbm_bytes_per_launch")
-                if traffic is not None:
-                    traffic_src = (f"profiles/pmc_traffic.json, {ent.get('_round', '?')}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                   "passes of this command on an EARLIER run (tools/pmc_traffic.py), not measured in this run")
-            except Exception:
-                traffic = None
-        if f_mfma >= f_hbm:
-            roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(tflops, 2), "peak": kpeak, "unit": "TFLOP/s",
-                        "frac": round(f_mfma, 4), "traffic": traffic}
-        else:
-            roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(f_hbm, 4), "traffic": traffic}
-        roofline.update({"traffic_source": traffic_src, "launches": launches, "avg_launch_ms": round(ms / launches, 4),
-                         "algorithmic_gflop_per_launch": round(flops / 1e9, 3),
-                         "executed_gflop_per_launch": round(flops_exec / 1e9, 3),
-                         "direct_equivalent_tflops": round(tflops_direct, 2),
-                         "flops_accounting": ("achieved / frac price the flops the matrix cores EXECUTE (Winograd F(2x2,3x3): 16 products per 2x2 "
-                                              "outputs and (cin, cout) where the direct convolution has 36); direct_equivalent_tflops = the "
-                                              "algorithmic (direct) flops of SURVEY 8d over the same time"),
-                         "algorithmic_mb_per_launch": round(nbytes / 1e6, 2),
-                         "frac_of_mfma_peak": round(f_mfma, 4), "frac_of_hbm_peak": round(f_hbm, 4),
-                         "share_of_kernel_time": round(ms / total_ms, 4)})
-        # every kernel symbol: share of the step, achieved TFLOP/s and GB/s on algorithmic work
-        table = []
-        for kn, kms in sorted(by_kernel.items(), key=lambda kv: -kv[1]):
-            ops = [o for o in prof if o["kernel"] == kn]
-            n = sum(o["passes"] for o in ops)
-            fl = sum(o["flops_exec"] * o["passes"] for o in ops)
-            fd = sum(o["flops"] * o["passes"] for o in ops)
-            by = sum((o["read_bytes"] + o["write_bytes"]) * o["passes"] for o in ops)
-            table.append({"kernel": kn, "share": round(kms / total_ms, 4), "avg_ms": round(kms / n, 4),
-                          "tflops": round(fl / (kms * 1e-3) / 1e12, 2), "tflops_direct_equivalent": round(fd / (kms * 1e-3) / 1e12, 2),
-                          "gbs": round(by / (kms * 1e-3) / 1e9, 1)})
-        exec_per_step = sum(o["flops_exec"] * o["passes"] for o in prof) / max(1, max(o["passes"] for o in prof))
-        roofline["kernels"] = table
-        roofline["events"] = (f"HIP event pair around every launch, inside the timed region (its first {prof_steps} of {args.steps} steps)" if events_in_region else
-                              f"HIP event pair around every launch in a replay of the same {args.steps} steps on ONE stream after the "
-                              f"timed region ({instrumented_ms:.3f} ms/step with the events; the timed region carries none)")
+        tkey = f"{args.model}:{args.compute}:div2k" if args.sizes == "div2k" else f"{args.model}:{args.compute}:{B}x{th}x{tw}"
+        events_desc = (f"HIP event pair around every launch, inside the timed region (its first {prof_steps} of {args.steps} steps)" if events_in_region else
+                       f"HIP event pair around every launch in a replay of the same {args.steps} steps on ONE stream after the "
+                       f"timed region ({instrumented_ms:.3f} ms/step with the events; the timed region carries none)")
+        roofline, exec_per_step = roofline_from_profile(prof, peak, tkey, events_desc)
 
     if rank == 0:
         imgs = sum(r["images"] for r in recs)
@@ -451,6 +549,13 @@ def main():
                     model(x1)
                 torch.cuda.synchronize(device)
             out["b1_latency_ms"] = round((time.perf_counter() - t1) / 50 * 1e3, 3)
+        headline = (args.model == "imdn_baseline" and args.compute == "f32" and args.sizes == "tile" and (th, tw) == (256, 256)
+                    and args.batch is None and nstreams == 1)
+        if world == 1 and headline and not args.no_other_configs and not args.no_kernel_events:
+            # BASELINE.json configs [2]-[4] in front of the driver: same process, behind the headline's timed region (not part of `value`)
+            del model, xs
+            torch.cuda.empty_cache()
+            out["other_configs"] = [measure_other_config(spec, device) for spec in OTHER_CONFIGS]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, shapes[0])
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)

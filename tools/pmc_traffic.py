@@ -86,7 +86,7 @@ def main():
         t[0] += fkb; t[1] += write.get(sym, (0.0, 0))[0]; t[2] += n
     res = json.load(open(out)) if os.path.exists(out) else {}
     res["_how"] = __doc__.split("usage:")[1].strip()
-    cur = {"_round": tag}
+    cur = {"_round": tag, "_build": bench.library_build()}       # esr_source_hash(): bench.py replays an entry only for the build it was recorded on
     for lab, (fkb, wkb, n) in tot.items():
         ar, aw, na = algo[lab]
         hbm = (2.0 * fkb + wkb) * 1024 / n

@@ -80,6 +80,10 @@ struct WinoK {
     unsigned magic_x, magic_y;   // floor(2^32 / d) + 1 (0 for d == 1): n / d == umulhi(n, magic) for n * d < 2^32 (host-checked)
     int y1_blk;
     int first_share;             // 1/16ths of the items the first-dispatched half of the blocks takes (8 = even split)
+    // wino8_f32_kernel: input addressing for NHWC and for channel-blocked [n][C/8][h][w][8] inputs (esr_conv_desc.blocked8 & ESR_BLOCKED_IN)
+    unsigned pix_floats;         // floats from one pixel to the next inside a chunk: in_pitch (NHWC) | 8 (blocked)
+    unsigned in_base;            // byte offset of the first input channel inside an image: in_coff * 4 | (in_coff / 8) * H * W * 32
+    unsigned chunk_stride;       // bytes from one 8-channel chunk to the next: 32 | H * W * 32
 };
 
 __device__ __forceinline__ unsigned wn_div(unsigned n, unsigned d, unsigned magic) { return d == 1 ? n : __umulhi(n, magic); }
@@ -469,6 +473,380 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the out-of-range DMAs issued behind the last item
 }
 
+
+// ==================================================================================================================================
+// wino8_f32_kernel<ACT, OUT, NCH> -- the same arithmetic for layers of NCH <= 6 input chunks (cin <= 48: IMDBlock conv2 / conv3), organised
+// around what round 4's counters said bounds wino_f32_kernel (profiles/r04_c1_sq_counters.md, LAB_NOTES.md 9.2): the length of a wave's
+// own instruction stream per MFMA -- 7 LDS-DMA pieces (~100 cycles of issue each) and a block barrier per 64 MFMAs.
+//
+//   block     8 waves, ONE block per CU.  The U of the block's cout half for ALL input chunks is RESIDENT in LDS (NCH x 16 KB, loaded once
+//             per block): no U DMA in the loop.
+//   wave      autonomous: it walks its own list of STRIPS (4 output rows x 16 columns = 2 x 8 Winograd tiles = the N side of the MFMA,
+//             all 16 positions, 2 cout tiles -- the accumulator shape of wino_f32_kernel) and stages its own 6 x 18-pixel halo, one 8-channel
+//             chunk at a time, into a PRIVATE ring of two slots (4 DMA pieces per chunk instead of 7).  No wave ever reads what another wave
+//             staged, so the loop has NO barrier: the two waves of a SIMD drift apart, one's epilogue and DMA issue run under the other's MFMAs.
+//   stage     chunk c of a strip: 64 MFMAs (A fragments two positions ahead from the resident U); between them, from position W8_TP on: s_waitcnt
+//             vmcnt(4 (+ 8 stores of an epilogue in between)), the transform of chunk c + 1 from slot (c + 1) & 1, and -- as soon as its four
+//             rows have been read -- the DMA of chunk c + 3 into the same slot: 1.75 stages ahead of the transform that reads it.
+//             Chunks run on across strip boundaries (the last stages of a strip stage and transform the next strip's first chunks).
+//   epilogue  stores as unconditional buffer stores (invalid lanes: out-of-range offsets), so the vmcnt arithmetic is exact.
+// Shapes: RES_NONE only (conv2 / conv3 have no residual), NHWC split or channel-blocked second output.
+constexpr int W8_THREADS = 512;
+constexpr int W8_PLANE = 3 * WN_PAIR;                  // 6 halo rows = 3 row pairs of 37 slots, per channel-half plane
+constexpr int W8_SLOTS = 2 * W8_PLANE;                 // 222 slots of 16 B = 3 full DMA pieces + one of 30 lanes
+constexpr int W8_SLOT_BYTES = W8_SLOTS * 16;           // 3552
+constexpr int W8_LAST_LANES = W8_SLOTS - 192;
+constexpr int W8_EPI_STORES = 8;                       // buffer stores per wave and strip (2 cout tiles x 2 x 2 pixels)
+constexpr int W8_MAX_BLOCKS = 256;
+#ifndef W8_TP
+#define W8_TP 2
+#endif
+#ifndef W8_DMA_TOP
+#define W8_DMA_TOP 0
+#endif
+// ablation switches of tools/wino/w8_variants.sh (research builds only; results are WRONG with any of them set)
+#ifndef W8_STAGGER
+#define W8_STAGGER 0          // s_sleep units (64 cycles) the second wave of every SIMD waits before its first stage
+#endif
+#ifndef W8_ABL_NODMA
+#define W8_ABL_NODMA 0
+#endif
+#ifndef W8_ABL_NOXF
+#define W8_ABL_NOXF 0
+#endif
+#ifndef W8_ABL_NOA
+#define W8_ABL_NOA 0
+#endif
+#ifndef W8_ABL_NOEPI
+#define W8_ABL_NOEPI 0
+#endif
+#ifndef W8_ABL_NOMFMA
+#define W8_ABL_NOMFMA 0
+#endif
+#ifndef W8_ABL_OOBST
+#define W8_ABL_OOBST 0          // every store out of range (issued, dropped: no write traffic)
+#endif
+#ifndef W8_ABL_OOBDMA
+#define W8_ABL_OOBDMA 0         // every halo piece out of range (issued, zero fill: no read traffic)
+#endif
+
+template <int NCH> struct W8L {
+    static constexpr int U_BYTES = NCH * WN_U_BYTES;
+    static constexpr int RAW_OFF = U_BYTES;
+    static constexpr int BIAS_OFF = RAW_OFF + 8 * 2 * W8_SLOT_BYTES;
+    static constexpr int TOTAL = BIAS_OFF + 256;
+    static_assert(TOTAL <= 160 * 1024, "one block per CU");
+};
+
+// s_nop 1: a store of more than 64 bits reads its data registers AFTER it has issued, and a VALU write to them needs 2 wait states behind
+// it on gfx940+ (LLVM: checkVALUHazardsHelper / VmemStoreHazard).  hipcc inserts them for its own stores but cannot see into an asm:
+// without the nop the next output's arithmetic landed in v.x of lanes 12..15 of every row before the store had read it (r04f).
+__device__ __forceinline__ void wn_store16(f32x4 v, unsigned voff, wn_i32x4 rsrc)
+{
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(rsrc) : "memory");
+}
+
+template <int ACT, int OUT, int NCH>
+__global__ __launch_bounds__(W8_THREADS, 1) void wino8_f32_kernel(const WinoK p)
+{
+    typedef W8L<NCH> LY;
+    __shared__ __attribute__((aligned(16))) char smem[LY::TOTAL];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int tx = j & 7, ty = j >> 3;
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    // ---- which strips: blocks b and b + 8 (same XCD) take the two cout halves of the same strips; a block owns a contiguous run of
+    // strips and its 8 waves take 8 consecutive ones (horizontal neighbours) per step
+    const int nh = p.nhalves;
+    const int half = nh == 2 ? ((int)blockIdx.x >> 3) & 1 : 0;
+    const int pidx = nh == 2 ? (((int)blockIdx.x >> 4) << 3) + ((int)blockIdx.x & 7) : (int)blockIdx.x;
+    const int npair = nh == 2 ? (int)gridDim.x >> 1 : (int)gridDim.x;
+    const int nstrips = p.N * p.tiles_y * p.tiles_x;                       // tiles_x = strips per row (16 px), tiles_y = strips per column (4 px)
+    const int per_block = (nstrips + npair - 1) / npair;
+    const int s_end = min((pidx + 1) * per_block, nstrips);
+    auto strip_index = [&](int k) -> int {
+        const int s = pidx * per_block + k * 8 + wv;
+        return s < s_end ? s : -1;
+    };
+
+    // Two cursors: `cur` (image, origin of the strip whose MFMAs run: wave-uniform, SGPRs) and the DMA cursor `dvoff` / `dn` (per-lane
+    // offsets of the 4 halo pieces and the image of the strip whose chunks are being STAGED) -- it runs two chunks ahead and moves to
+    // the next strip in stage NCH - 2, so only one set of offsets is live
+    struct Ctx { int n, x0, y0; };
+    unsigned dvoff[4];
+    int dn = 0;
+    auto locate = [&](int strip, Ctx& c) {
+        if (strip < 0) { c.n = 0; c.x0 = 0; c.y0 = 0; return; }
+        const unsigned sq = wn_div((unsigned)strip, (unsigned)p.tiles_x, p.magic_x);
+        const unsigned sxi = (unsigned)strip - sq * p.tiles_x;
+        c.n = (int)wn_div(sq, (unsigned)p.tiles_y, p.magic_y);
+        const unsigned syi = sq - (unsigned)c.n * p.tiles_y;
+        c.x0 = (int)sxi * 16;
+        c.y0 = (int)syi * 4;
+    };
+    auto dma_to = [&](int strip, const Ctx& c) {
+        dn = c.n;
+        if (strip < 0) {                             // behind the last strip: the pieces still issue (uniform counts), all lanes out of range
+            dvoff[0] = dvoff[1] = dvoff[2] = dvoff[3] = WN_OOB;
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int item = i * 64 + lane;
+            const int plane = item >= W8_PLANE ? 1 : 0;
+            const int slot = item - plane * W8_PLANE;
+            const int pr = slot / WN_PAIR, rem = slot - pr * WN_PAIR;
+            const int odd = rem >= WN_HALO ? 1 : 0;
+            const int ly = 2 * pr + odd, lx = rem - odd * WN_HALO;
+            const int gy = c.y0 - 1 + ly, gx = c.x0 - 1 + lx;
+            const bool ok = item < W8_SLOTS && rem < 2 * WN_HALO && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            dvoff[i] = ((ok && !W8_ABL_OOBDMA) ? ((unsigned)(gy * p.W + gx) * p.pix_floats + 4u * plane) * 4u + p.in_base : WN_OOB) - (unsigned)(i * 1024);
+        }
+    };
+    const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 4;
+    auto image_rsrc = [&](int n) { return wn_rsrc(p.x + (size_t)n * (img_bytes / 4), img_bytes); };
+    const unsigned ring_m0 = smem_lds + (unsigned)(LY::RAW_OFF + wv * 2 * W8_SLOT_BYTES);
+    const bool live3 = lane < W8_LAST_LANES;
+    // the 4 pieces of chunk `chunk` of an image (rsrc xr, per-lane offsets v[]) -> this wave's ring slot `par`
+    auto issue_raw = [&](int par, int chunk) __attribute__((always_inline)) {
+        const wn_i32x4 xr = image_rsrc(dn);
+        const unsigned soff = (unsigned)chunk * p.chunk_stride;
+        const unsigned m = ring_m0 + (unsigned)(par * W8_SLOT_BYTES);
+        wn_dma16<0>(m, dvoff[0], xr, soff);
+        wn_dma16<1024>(m, dvoff[1], xr, soff);
+        wn_dma16<2048>(m, dvoff[2], xr, soff);
+        if (live3) wn_dma16<3072>(m, dvoff[3], xr, soff);      // 30 lanes: the others would write into the next slot
+    };
+
+    int work = strip_index(0);
+    // ---- resident U of this block's cout half + bias (every wave takes part, also one without strips: the barrier below is the only one)
+    {
+        const wn_i32x4 ursrc = wn_rsrc(p.up, p.up_bytes);
+#pragma unroll 1
+        for (int pc = wv; pc < NCH * 16; pc += 8) {
+            const int chunk = pc >> 4, piece = pc & 15;
+            wn_dma16<0>(smem_lds + (unsigned)(chunk * WN_U_BYTES + piece * 1024), (unsigned)lane * 16u, ursrc,
+                        (unsigned)((chunk * nh + half) * WN_U_BYTES + piece * 1024));
+        }
+        if (tid < nh * 8) *reinterpret_cast<f32x4*>(smem + LY::BIAS_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(p.bias + tid * 4);
+    }
+    Ctx cur, nxt;
+    locate(work, cur);
+    int wn = strip_index(1);
+    locate(wn, nxt);
+    if (work >= 0) {
+        dma_to(work, cur);
+        issue_raw(0, 0);
+        issue_raw(1, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (work < 0) return;
+
+    const int raw_lane = (g >> 1) * (W8_PLANE * 16) + wn_slot(2 * ty, 2 * tx) * 16 + (g & 1) * 8;
+    const int u_lane = lane * 16;
+    auto raw_row = [&](unsigned rb, int r, f32x2 (&d)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx)
+            d[dx] = wn_lds_b64(rb + ((r >> 1) * WN_PAIR + (r & 1) * WN_HALO + dx) * 16);
+    };
+    auto row_pass = [&](f32x2 (&V)[16], int r, const f32x2 (&d)[4]) __attribute__((always_inline)) {
+        V[4 * r + 0] = wn_sub2(d[0], d[2]);
+        V[4 * r + 1] = d[1] + d[2];
+        V[4 * r + 2] = wn_sub2(d[2], d[1]);
+        V[4 * r + 3] = wn_sub2(d[1], d[3]);
+    };
+    auto col_pass = [&](f32x2 (&V)[16], int c) __attribute__((always_inline)) {
+        const f32x2 w0 = V[c], w1 = V[4 + c], w2 = V[8 + c], w3 = V[12 + c];
+        V[c] = wn_sub2(w0, w2);
+        V[4 + c] = w1 + w2;
+        V[8 + c] = wn_sub2(w2, w1);
+        V[12 + c] = wn_sub2(w1, w3);
+    };
+
+    // V of chunk 0 of the first strip, alone
+    f32x2 V0[16], V1[16];
+    {
+        unsigned rs = ring_m0 + raw_lane;
+        asm volatile("" : "+v"(rs));
+        f32x2 d[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { raw_row(rs, r, d); row_pass(V0, r, d); }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) col_pass(V0, c);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // slot 0 is free: chunk 2 goes there
+    if (!W8_DMA_TOP) issue_raw(0, 2);
+    f32x4 a[4];
+    a[0] = *reinterpret_cast<const f32x4*>(smem + u_lane);
+    a[1] = *reinterpret_cast<const f32x4*>(smem + u_lane + 1024);
+
+    // The two waves of a SIMD (w and w + 4) run the same instruction stream on equal work: left alone they stay in step, reach their
+    // epilogues (~350 instructions without an MFMA) and their DMA issue together, and the matrix pipe idles -- the ablations of r04 put
+    // 14 % + 15 % of the launch there.  Half a strip of head start for one of them keeps one wave's epilogue under the other's MFMAs.
+    if (W8_STAGGER > 0 && wv >= 4) {
+#pragma unroll
+        for (int i = 0; i < (W8_STAGGER + 126) / 127; ++i) __builtin_amdgcn_s_sleep(W8_STAGGER < 127 ? W8_STAGGER : 127);
+    }
+    int k = 0;
+    f32x4 acc[16][2];
+    if (W8_ABL_NOXF) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) V1[q] = V0[q];
+    }
+    if (W8_ABL_NOA) { a[2] = a[0]; a[3] = a[1]; }
+    const char* const bias_lds = smem + LY::BIAS_OFF + (half * 32 + g * 4) * 4;
+    for (;;) {
+        const bool has_next = wn >= 0;
+        // stage of chunk c: DMA of chunk c + 2 into slot c & 1 (the slot the previous stage's transform has finished reading), transform of
+        // chunk c + 1 (slot (c + 1) & 1), 64 MFMAs.  AFTER_EPI: the first stage of a strip other than the wave's first -- the previous
+        // strip's W8_EPI_STORES stores were issued between the DMA this stage waits for and the DMA it issues.
+        auto stage = [&](auto first_tag, int c, f32x2 (&Vc)[16], f32x2 (&Vn)[16]) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            if (W8_DMA_TOP) {                                               // research variant: chunk c + 2 at the top of stage c (1 stage + W8_TP positions of lead)
+                if (c + 2 == NCH) dma_to(wn, nxt);
+                issue_raw(c & 1, c + 2 < NCH ? c + 2 : c + 2 - NCH);
+            }
+            f32x4 biasv0, biasv1;
+            const int cn = c + 1 < NCH ? c + 1 : 0;                       // U chunk of the next stage (position look-ahead)
+            const char* ust = smem + c * WN_U_BYTES + u_lane;
+            const char* ust1 = smem + cn * WN_U_BYTES + u_lane;
+            unsigned rs = ring_m0 + (unsigned)(((c + 1) & 1) * W8_SLOT_BYTES) + raw_lane;
+            asm volatile("" : "+v"(rs));
+            // chunk c + 1 has landed when only this stage's 3 or 4 pieces (+ the epilogue's stores) are still in flight.  A wave with lanes
+            // >= 30 ... every wave issues the 4th piece (lanes < 30 exist in every wave), so the count is 4
+            f32x2 d[2][4];
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos) {
+                if (!W8_ABL_NOA) {
+                if (pos + 2 < 16) a[(pos + 2) & 3] = *reinterpret_cast<const f32x4*>(ust + (pos + 2) * 1024);
+                else a[(pos + 2) & 3] = *reinterpret_cast<const f32x4*>(ust1 + (pos + 2 - 16) * 1024);
+                }
+                // the transform of the NEXT chunk sits in positions W8_TP .. W8_TP + 8: with a ring of two slots its DMA was issued only
+                // one stage ago, so the wait comes as late as the stage allows
+                if (pos == W8_TP) {
+                    // chunk c + 1 has landed when only the 4 pieces of chunk c + 2 are younger -- and, in the first two stages of a strip
+                    // that is not the wave's first, the 8 stores of the epilogue in between (every wave issues all 4 pieces and all 8 stores)
+                    if (c < (W8_DMA_TOP ? 1 : 2) && k > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + W8_EPI_STORES) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                }
+                if (!W8_DMA_TOP && pos == W8_TP + 5) {
+                    // the four rows of chunk c + 1 have been read (row_pass has consumed them): its slot takes chunk c + 3, two stages ahead
+                    // of the transform that will read it
+                    if (c + 3 == NCH) dma_to(wn, nxt);                        // the DMA cursor moves on to the next strip
+                    if (!W8_ABL_NODMA) issue_raw((c + 1) & 1, c + 3 < NCH ? c + 3 : c + 3 - NCH);
+                }
+                if (!W8_ABL_NOXF && pos >= W8_TP && pos < W8_TP + 4) raw_row(rs, pos - W8_TP, d[(pos - W8_TP) & 1]);
+                if (!W8_ABL_NOXF && pos >= W8_TP + 1 && pos < W8_TP + 5) {
+                    row_pass(Vn, pos - W8_TP - 1, d[(pos - W8_TP - 1) & 1]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) WN_PIN(Vn[4 * (pos - W8_TP - 1) + q]);
+                }
+                if (!W8_ABL_NOXF && pos >= W8_TP + 5 && pos < W8_TP + 9) {
+                    col_pass(Vn, pos - W8_TP - 5);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) WN_PIN(Vn[4 * q + pos - W8_TP - 5]);
+                }
+                if (FIRST && pos == 3) {                                     // the bias enters at position 5 (see wino_f32_kernel)
+                    biasv0 = *reinterpret_cast<const f32x4*>(bias_lds);
+                    biasv1 = *reinterpret_cast<const f32x4*>(bias_lds + 64);
+                }
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 c0 = FIRST ? (pos == 5 ? biasv0 : zero) : acc[pos][0];
+                const f32x4 c1 = FIRST ? (pos == 5 ? biasv1 : zero) : acc[pos][1];
+                const f32x4 af = a[pos & 3];
+                if (W8_ABL_NOMFMA) {
+                    acc[pos][0] = c0; acc[pos][1] = c1;
+                    acc[pos][0].x += af.x * Vc[pos].x + af.y * Vc[pos].y; acc[pos][1].x += af.z * Vc[pos].x + af.w * Vc[pos].y;
+                } else {
+                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, Vc[pos].x, c0, 0, 0, 0);
+                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, Vc[pos].x, c1, 0, 0, 0);
+                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, Vc[pos].y, acc[pos][0], 0, 0, 0);
+                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, Vc[pos].y, acc[pos][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        stage(std::true_type{}, 0, V0, V1);
+        stage(std::false_type{}, 1, V1, V0);
+#pragma unroll
+        for (int c = 2; c < NCH; c += 2) {
+            stage(std::false_type{}, c, V0, V1);
+            stage(std::false_type{}, c + 1, V1, V0);
+        }
+
+        if (W8_ABL_NOEPI) {
+            if (p.N < 0) {                        // never true: keeps the accumulators alive
+                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sum += acc[q][0] + acc[q][1];
+                *reinterpret_cast<f32x4*>(p.y0 + lane * 4) = sum;
+            }
+        } else
+        // ---- output transform Y = A^T M A, activation, 8 unconditional buffer stores (out-of-range offset = dropped)
+        {
+            const int ybase = cur.y0 + 2 * ty, xbase = cur.x0 + 2 * tx;
+            const size_t hw = (size_t)p.H * p.W;
+            unsigned pix[2][2];
+            bool pok[2][2];
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    pok[aa][b] = ybase + aa < p.H && xbase + b < p.W;
+                    pix[aa][b] = (unsigned)((ybase + aa) * p.W + xbase + b);
+                }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int cg = half * 32 + ct * 16 + g * 4;
+                const bool to0 = half * 32 + ct * 16 < p.split;
+                const bool cok = cg < p.cout_store;
+                const int ch = to0 ? p.y0_coff + cg : p.y1_coff + cg - p.split;
+                const bool blk = OUT == 1 && !to0;
+                const unsigned pitch_b = (unsigned)((to0 ? p.y0_pitch : p.y1_pitch) * 4);
+                const size_t ibytes = hw * pitch_b;
+                const wn_i32x4 yr = wn_rsrc(reinterpret_cast<const char*>(to0 ? p.y0 : p.y1) + (size_t)cur.n * ibytes, ibytes);
+                const unsigned dps = blk ? 32u : pitch_b;
+                const unsigned dlane = blk ? (unsigned)(ch >> 3) * (unsigned)(hw * 32) + (unsigned)(ch & 7) * 4u : (unsigned)ch * 4u;
+                f32x4 Y[2][2];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const f32x4 m0 = acc[jj][ct], m1 = acc[4 + jj][ct], m2 = acc[8 + jj][ct], m3 = acc[12 + jj][ct];
+                    const f32x4 t0 = m0 + m1 + m2, t1 = m1 - m2 - m3;
+                    if (jj == 0) { Y[0][0] = t0; Y[1][0] = t1; }
+                    else if (jj == 1) { Y[0][0] += t0; Y[1][0] += t1; Y[0][1] = t0; Y[1][1] = t1; }
+                    else if (jj == 2) { Y[0][0] += t0; Y[1][0] += t1; Y[0][1] -= t0; Y[1][1] -= t1; }
+                    else { Y[0][1] -= t0; Y[1][1] -= t1; }
+                }
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const f32x4 v = wn_act4<ACT>(Y[aa][b], p.act, p.slope);
+                        wn_store16(v, (pok[aa][b] && cok && !W8_ABL_OOBST) ? dlane + pix[aa][b] * dps : WN_OOB, yr);
+                    }
+            }
+        }
+        if (!has_next) break;
+        cur = nxt;
+        ++k;
+        wn = strip_index(k + 1);
+        locate(wn, nxt);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the out-of-range DMAs issued behind the last strip
+}
+
+template <int ACT, int OUT, int NCH>
+int w8_launch(const WinoK& k, int grid, hipStream_t st)
+{
+    esr_note_kernel("wino8_f32_kernel<%d, %d, %d>", ACT, OUT, NCH);
+    hipLaunchKernelGGL((wino8_f32_kernel<ACT, OUT, NCH>), dim3(grid), dim3(W8_THREADS), 0, st, k);
+    return esr_check_launch("wino8_f32_kernel launch");
+}
+
 template <int ACT, int RES, int OUT>
 int wn_launch(const WinoK& k, int grid, hipStream_t st)
 {
@@ -476,6 +854,8 @@ int wn_launch(const WinoK& k, int grid, hipStream_t st)
     hipLaunchKernelGGL((wino_f32_kernel<ACT, RES, OUT>), dim3(grid), dim3(WN_THREADS), 0, st, k);
     return esr_check_launch("wino_f32_kernel launch");
 }
+
+bool g_wino8_enabled = true;          // research switch (esr_dbg_wino8): A/B of the two Winograd kernels inside one process
 
 // G of F(2x2, 3x3)
 const double WN_G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
@@ -499,12 +879,14 @@ int esr_wino_supported(const esr_conv_desc* d)
     } else if (d->out_layout != ESR_NHWC) return 0;
     if (d->storage != ESR_STORE_F32 || d->compute != ESR_COMPUTE_F32) return 0;
     if (d->tail_wpacked || d->post_wpacked || d->border_bias || d->in_seg_stride) return 0;
-    if (d->blocked8 & ESR_BLOCKED_IN) return 0;
     if ((d->blocked8 & ESR_BLOCKED_OUT1) && d->res_mode != ESR_RES_NONE) return 0;
     if (d->cin <= 0 || d->cout <= 0 || d->cout > 64) return 0;
     const int cin_phys = esr_round_up(d->cin, 8);
     const int nchunks = cin_phys / 8;
     if (nchunks < 4 || (nchunks & 1)) return 0;                  // raw ring looks 3 chunks ahead; stages are unrolled in pairs
+    // a channel-blocked INPUT only where wino8_f32_kernel runs (it takes every such descriptor, of any size): 4 or 6 chunks, no residual
+    if ((d->blocked8 & ESR_BLOCKED_IN) && !((nchunks == 4 || nchunks == 6) && d->res_mode == ESR_RES_NONE && d->out_layout == ESR_NHWC && (d->in.coff & 7) == 0))
+        return 0;
     const int cout4 = esr_round_up(d->cout, 4);
     int split = d->split <= 0 ? cout4 : d->split;
     if (split >= d->cout) split = cout4;
@@ -577,6 +959,9 @@ int esr_unpack_wino_f32(const void* packed, size_t bytes, int cin, int cout, con
     return ESR_OK;
 }
 
+/* research switch, not part of the ABI header: 0 = every Winograd launch on wino_f32_kernel */
+void esr_dbg_wino8(int on) { g_wino8_enabled = on != 0; }
+
 }  // extern "C"
 
 // Called by esr_conv2d_f32 after its argument checks when d->wino_wpacked is set and esr_wino_supported(d).
@@ -617,6 +1002,34 @@ int esr_conv2d_wino(const esr_conv_desc* d, void* hip_stream)
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     // instantiations: the activation is a template constant for LeakyReLU / none (the networks' cases), read at run time otherwise
     const int a = d->act;
+    // wino8_f32_kernel (resident U, wave-private halo rings, no barrier): 4 or 6 input chunks, no residual, NHWC / blocked outputs, and enough
+    // strips (4 rows x 16 columns) that each of the 2048 waves walks several; both per-image byte ranges behind 31-bit buffer offsets
+    const bool blocked_in = (d->blocked8 & ESR_BLOCKED_IN) != 0;
+    if ((k.nchunks == 4 || k.nchunks == 6) && d->res_mode == ESR_RES_NONE && d->out_layout == ESR_NHWC && (g_wino8_enabled || blocked_in)) {
+        const long sx = (d->w + 15) / 16, sy = (d->h + 3) / 4;
+        const long nstrips = (long)k.N * sx * sy;
+        const double out_bytes = (double)d->h * d->w * 4.0 * (d->out0.pitch > d->out1.pitch ? d->out0.pitch : d->out1.pitch);
+        const bool fits = (double)k.N * sx * sy * (sx > sy ? sx : sy) < 4294967296.0 && out_bytes < 2147482624.0;
+        if (blocked_in && !fits) return ESR_ERR_UNSUPPORTED;
+        if (fits && (blocked_in || nstrips >= 4L * 8 * W8_MAX_BLOCKS / k.nhalves)) {
+            WinoK w = k;
+            w.pix_floats = blocked_in ? 8u : (unsigned)d->in.pitch;
+            w.in_base = blocked_in ? (unsigned)(d->in.coff / 8) * (unsigned)(d->h * d->w * 32) : (unsigned)d->in.coff * 4u;
+            w.chunk_stride = blocked_in ? (unsigned)(d->h * d->w * 32) : 32u;
+            w.tiles_x = (int)sx; w.tiles_y = (int)sy;
+            w.magic_x = sx == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)sx) + 1u;
+            w.magic_y = sy == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)sy) + 1u;
+            const int grid8 = W8_MAX_BLOCKS;
+            const bool blk = k.y1_blk != 0;
+            const bool lr = a == ESR_ACT_LRELU;
+            if (k.nchunks == 6) {
+                if (blk) return lr ? w8_launch<ESR_ACT_LRELU, 1, 6>(w, grid8, st) : w8_launch<-1, 1, 6>(w, grid8, st);
+                return lr ? w8_launch<ESR_ACT_LRELU, 0, 6>(w, grid8, st) : w8_launch<-1, 0, 6>(w, grid8, st);
+            }
+            if (blk) return lr ? w8_launch<ESR_ACT_LRELU, 1, 4>(w, grid8, st) : w8_launch<-1, 1, 4>(w, grid8, st);
+            return lr ? w8_launch<ESR_ACT_LRELU, 0, 4>(w, grid8, st) : w8_launch<-1, 0, 4>(w, grid8, st);
+        }
+    }
     if (d->out_layout == ESR_NCHW_SHUFFLE4)
         return a == ESR_ACT_NONE ? wn_launch<ESR_ACT_NONE, ESR_RES_NONE, 2>(k, grid, st) : wn_launch<-1, ESR_RES_NONE, 2>(k, grid, st);
     if (k.y1_blk)

@@ -59,11 +59,14 @@ class IMDN(HipSRModel):
         cat = plan.planar('cat', 4, d) if planar else plan.buffer('cat', plan.cpad(3 * d if fused else 4 * d))
         cs = (lambda j: cat.seg(j)) if planar else (lambda j: cat[j * d:(j + 1) * d])
         # pitches are whole K chunks of the plan's storage type (8 fp32 / 16 16-bit channels): r = 24 (nc = 32) needs 32 slots in bf16 / fp16
-        r1, r2 = plan.buffer('r1', plan.cpad(r)), plan.buffer('r2', plan.cpad(r))
         # fused tail: its 3x3 input (conv3's remaining channels) is stored channel-blocked [n][r/8][h][w][8] -- imdb_tail_kernel
         # stages one 8-channel K chunk at a time, and in NHWC every 128-byte line of a 192-byte pixel would be fetched by four
-        # stages microseconds apart (esr_conv_desc.blocked8)
+        # stages microseconds apart (esr_conv_desc.blocked8).  Round 4: the same for r1 / r2, the inputs of conv2 / conv3 on
+        # wino8_f32_kernel (its ablations put 15 % of a launch into the read traffic of 32-byte pieces of 192-byte pixels; the
+        # direct kernel cannot read a blocked input, so only with the Winograd path on)
         blk = fused and r == 48 and nc == 64
+        blk12 = blk and self.winograd
+        r1, r2 = plan.buffer('r1', plan.cpad(r), blocked=blk12), plan.buffer('r2', plan.cpad(r), blocked=blk12)
         r3 = plan.buffer('r3', r, blocked=True) if blk else r1
         act = dict(act=self.act, slope=self.slope)
         plan.conv('model.0', INPUT, fea, self.in_nc, nc)

@@ -161,3 +161,99 @@ def test_wino_pixelshuffle_output(hw):
     out = ops.conv2d(_nhwc(t).to(dev), w2, b2, shuffle_out=True, wino=True).cpu()
     assert out.shape == ref.shape
     assert float((out - ref).abs().max()) / max(1.0, float(ref.abs().max())) < 2e-5
+
+
+# ---- wino8_f32_kernel (round 4): resident U, wave-private halo rings, no barrier -- taken for 4 / 6 input chunks, no residual, when every
+# one of the 2048 waves gets at least four 4 x 16-pixel strips
+def _w8_on(on):
+    import ctypes
+    from ntire2022_esr_amd import _lib as L
+    L.lib().esr_dbg_wino8(ctypes.c_int(1 if on else 0))
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w,act", [(48, 64, 4, 256, 256, 1), (48, 64, 5, 250, 251, 0), (32, 32, 9, 255, 258, 3),
+                                                 (48, 48, 6, 253, 244, 1), (32, 64, 3, 300, 301, 2), (46, 64, 7, 203, 190, 1)])
+def test_wino8_plain(cin, cout, n, h, w, act):
+    """strip-autonomous kernel vs ATen fp32 on ragged sizes (partial strips on the right / bottom edge, several strips per wave, strips
+    that straddle image boundaries of the batch), and vs wino_f32_kernel: the same fp32 operations per output -> bit-identical"""
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    ref = ACTS[act](F.conv2d(x, wt, b, padding=1))
+    xd = _nhwc(x).to(dev)
+    if cin % 8:
+        xd = F.pad(xd, (0, 8 - cin % 8))
+    _w8_on(True)
+    y8 = ops.conv2d(xd, wt, b, act=act, cin=cin, wino=True)
+    _w8_on(False)
+    y4 = ops.conv2d(xd, wt, b, act=act, cin=cin, wino=True)
+    _w8_on(True)
+    _check(y8, ref)
+    assert torch.equal(y8, y4)
+
+
+def test_wino8_split_and_blocked_stores():
+    """IMDBlock conv2 / conv3 at batch size: 16 / 48 split into a concat slice + the remaining channels dense or channel-blocked"""
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    n, h, w = 4, 256, 250
+    big = torch.randn(n, 64, h, w, generator=g)
+    wt = torch.randn(64, 48, 3, 3, generator=g) * 0.1
+    b = torch.randn(64, generator=g)
+    ref = F.leaky_relu(F.conv2d(big[:, 16:], wt, b, padding=1), 0.05)
+    cat = torch.full((n, h, w, 64), 7.0, device=dev)
+    rem = torch.full((n, h, w, 48), 9.0, device=dev)
+    ops.conv2d(_nhwc(big).to(dev), wt, b, act=1, in_coff=16, cin=48, split=16, out=cat, out_coff=32, out1=rem, out1_coff=0, wino=True)
+    cat_c, rem_c = cat.cpu(), rem.cpu()
+    assert torch.all(cat_c[..., :32] == 7.0) and torch.all(cat_c[..., 48:] == 7.0)
+    _check(cat_c[..., 32:48], ref[:, :16])
+    _check(rem_c, ref[:, 16:])
+    x = big[:, :48].contiguous()
+    ref = F.leaky_relu(F.conv2d(x, wt, b, padding=1), 0.05)
+    cat = torch.zeros((n, h, w, 48), device=dev)
+    remb = torch.full((n, 6, h, w, 8), 9.0, device=dev)
+    ops.conv2d(_nhwc(x).to(dev), wt, b, act=1, split=16, out=cat, out_coff=16, out1=remb, blocked_out1=True, wino=True)
+    _check(cat.cpu()[..., 16:32], ref[:, :16])
+    r = remb.cpu().permute(0, 1, 4, 2, 3).reshape(n, 48, h, w)
+    assert float((r - ref[:, 16:]).abs().max()) / max(1.0, float(ref.abs().max())) < 2e-5
+    assert torch.all(cat.cpu()[..., :16] == 0) and torch.all(cat.cpu()[..., 32:] == 0)
+
+
+def test_wino8_is_the_kernel_that_ran():
+    """the profiled op list names wino8_f32_kernel for IMDN's conv2 / conv3 at batch 32 and wino_f32_kernel for the 64-channel layers"""
+    from ntire2022_esr_amd.registry import select_model
+    dev = _dev()
+    m, _, dr, _ = select_model(-1, dev)
+    m.enable_profiling(1)
+    m(torch.rand(8, 3, 256, 256, device=dev) * dr)
+    torch.cuda.synchronize()
+    names = [o["kernel"] for o in m.collect_profile()]
+    m.disable_profiling()
+    assert sum(k.startswith("wino8_f32_kernel") for k in names) == 16, sorted(set(names))
+    assert sum(k.startswith("wino_f32_kernel") for k in names) == 10, sorted(set(names))      # conv1 x 8, LR conv, last conv
+
+
+@pytest.mark.parametrize("n,h,w", [(4, 256, 256), (1, 37, 29), (2, 5, 3), (3, 130, 70)])
+def test_wino8_blocked_input(n, h, w):
+    """channel-blocked INPUT [N, C/8, H, W, 8] (esr_conv_desc.blocked8 & ESR_BLOCKED_IN: IMDBlock's r1 / r2 since round 4) -- every size goes
+    to wino8_f32_kernel (wino_f32_kernel cannot read it); bit-identical to the NHWC input through the same kernel family"""
+    from ntire2022_esr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(31 + h)
+    x = torch.randn(n, 48, h, w, generator=g)
+    wt = torch.randn(64, 48, 3, 3, generator=g) * 0.1
+    b = torch.randn(64, generator=g)
+    ref = F.leaky_relu(F.conv2d(x, wt, b, padding=1), 0.05)
+    xb = x.view(n, 6, 8, h, w).permute(0, 1, 3, 4, 2).contiguous().to(dev)
+    cat = torch.zeros((n, h, w, 16), device=dev)
+    remb = torch.full((n, 6, h, w, 8), 9.0, device=dev)
+    ops.conv2d(xb, wt, b, act=1, blocked_in=True, split=16, out=cat, out1=remb, blocked_out1=True, wino=True)
+    _check(cat.cpu(), ref[:, :16])
+    r = remb.cpu().permute(0, 1, 4, 2, 3).reshape(n, 48, h, w)
+    assert float((r - ref[:, 16:]).abs().max()) / max(1.0, float(ref.abs().max())) < 2e-5
+    y_nhwc = ops.conv2d(_nhwc(x).to(dev), wt, b, act=1, wino=True)
+    assert torch.equal(y_nhwc[..., :16], cat) and torch.equal(y_nhwc[..., 16:].cpu(), r.permute(0, 2, 3, 1))

@@ -158,6 +158,23 @@ __device__ __forceinline__ f32x2 wn_sub2(f32x2 a, f32x2 b)
     return r;
 }
 
+// Channel-blocked stores as whole lines.  A lane (tile j, cout group g) holds 4 channels of the pixels b = 0 / 1 of its tile; stored as they
+// are, an instruction writes 32 bytes (lanes g, g + 1: one 8-channel plane) of every other pixel.  v_permlane32_swap on the b = 0 / b = 1
+// registers moves the upper half-wave's b = 0 data down and the lower half-wave's b = 1 data up: afterwards `lo` holds, for plane A
+// (channels 0..7 of the cout tile), rows g = 0, 1: pixel b = 0 and rows g = 2, 3: pixel b = 1 -- 64 contiguous bytes per tile, 512 per
+// row of 8 tiles -- and `hi` the same for plane B (channels 8..15).  Pixel of a lane: b = g >> 1, 16-byte slot g & 1.
+__device__ __forceinline__ void wn_pair_planes(f32x4& v0, f32x4& v1)
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a = v0[e], b = v1[e];          // (hipcc: __builtin_bit_cast on an ext-vector ELEMENT reads element 0 -- copy to a scalar first)
+        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        v0[e] = __builtin_bit_cast(float, r0);
+        v1[e] = __builtin_bit_cast(float, r1);
+    }
+}
+
 // keeps a value's computation where it is written: without it hipcc sinks the whole input transform (it is only consumed by the
 // NEXT stage's MFMAs) out of this stage's MFMA stream into the top of the next stage
 #define WN_PIN(x) asm volatile("" : "+v"(x))
@@ -447,6 +464,21 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
                     else if (jj == 2) { Y[0][0] += t0; Y[1][0] += t1; Y[0][1] -= t0; Y[1][1] -= t1; }
                     else { Y[0][1] -= t0; Y[1][1] -= t1; }
                 }
+                if (blk) {
+                    // RES_NONE by construction (esr_wino_supported); whole-line stores of the tile's two 8-channel planes (wn_pair_planes)
+                    char* const pa = dbase + (size_t)((p.y1_coff + cur.half * 32 + ct * 16 - p.split) >> 3) * hw * 32 + (size_t)(g & 1) * 16;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        f32x4 v0 = wn_act4<ACT>(Y[a][0], p.act, p.slope), v1 = wn_act4<ACT>(Y[a][1], p.act, p.slope);
+                        wn_pair_planes(v0, v1);
+                        const bool ok = (g >> 1) ? pok[a][1] : pok[a][0];
+                        char* const q = pa + (size_t)((g >> 1) ? pix[a][1] : pix[a][0]) * 32;
+                        if (ok) {
+                            *reinterpret_cast<f32x4*>(q) = v0;
+                            *reinterpret_cast<f32x4*>(q + hw * 32) = v1;
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -522,6 +554,9 @@ constexpr int W8_MAX_BLOCKS = 256;
 #endif
 #ifndef W8_ABL_NOMFMA
 #define W8_ABL_NOMFMA 0
+#endif
+#ifndef W8_ABL_LAXWAIT
+#define W8_ABL_LAXWAIT 0        // timing probe (wrong results possible): stages 2 and 3 also leave the epilogue's stores outstanding
 #endif
 #ifndef W8_ABL_OOBST
 #define W8_ABL_OOBST 0          // every store out of range (issued, dropped: no write traffic)
@@ -730,7 +765,7 @@ __global__ __launch_bounds__(W8_THREADS, 1) void wino8_f32_kernel(const WinoK p)
                 if (pos == W8_TP) {
                     // chunk c + 1 has landed when only the 4 pieces of chunk c + 2 are younger -- and, in the first two stages of a strip
                     // that is not the wave's first, the 8 stores of the epilogue in between (every wave issues all 4 pieces and all 8 stores)
-                    if (c < (W8_DMA_TOP ? 1 : 2) && k > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + W8_EPI_STORES) : "memory");
+                    if (c < (W8_DMA_TOP ? 1 : 2) + 2 * W8_ABL_LAXWAIT && k > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + W8_EPI_STORES) : "memory");
                     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 }
                 if (!W8_DMA_TOP && pos == W8_TP + 5) {
@@ -821,6 +856,19 @@ __global__ __launch_bounds__(W8_THREADS, 1) void wino8_f32_kernel(const WinoK p)
                     else if (jj == 2) { Y[0][0] += t0; Y[1][0] += t1; Y[0][1] -= t0; Y[1][1] -= t1; }
                     else { Y[0][1] -= t0; Y[1][1] -= t1; }
                 }
+                if (blk) {
+                    // whole-line stores of the two 8-channel planes of this cout tile (wn_pair_planes)
+                    const unsigned plane_a = (unsigned)((p.y1_coff + half * 32 + ct * 16 - p.split) >> 3) * (unsigned)(hw * 32) + (unsigned)(g & 1) * 16u;
+#pragma unroll
+                    for (int aa = 0; aa < 2; ++aa) {
+                        f32x4 v0 = wn_act4<ACT>(Y[aa][0], p.act, p.slope), v1 = wn_act4<ACT>(Y[aa][1], p.act, p.slope);
+                        wn_pair_planes(v0, v1);
+                        const bool ok = (g >> 1) ? pok[aa][1] : pok[aa][0];
+                        const unsigned po = plane_a + ((g >> 1) ? pix[aa][1] : pix[aa][0]) * 32u;
+                        wn_store16(v0, (ok && !W8_ABL_OOBST) ? po : WN_OOB, yr);
+                        wn_store16(v1, (ok && !W8_ABL_OOBST) ? po + (unsigned)(hw * 32) : WN_OOB, yr);
+                    }
+                } else {
 #pragma unroll
                 for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
@@ -828,6 +876,7 @@ __global__ __launch_bounds__(W8_THREADS, 1) void wino8_f32_kernel(const WinoK p)
                         const f32x4 v = wn_act4<ACT>(Y[aa][b], p.act, p.slope);
                         wn_store16(v, (pok[aa][b] && cok && !W8_ABL_OOBST) ? dlane + pix[aa][b] * dps : WN_OOB, yr);
                     }
+                }
             }
         }
         if (!has_next) break;

@@ -175,6 +175,23 @@ __device__ __forceinline__ void wn_pair_planes(f32x4& v0, f32x4& v1)
     }
 }
 
+__device__ __forceinline__ f32x2 wn_add2(f32x2 a, f32x2 b)          // (hipcc makes two scalar v_add_f32 of a plain f32x2 sum here)
+{
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// acc += a * b on v_mfma_f32_16x16x4_f32, IN PLACE.  With the builtin hipcc unties vdst from srcC, rotates every accumulator through
+// temporaries, reuses the freed registers for the next A fragment and pads the resulting WAR hazard (an LDS load into a register an
+// MFMA still reads as srcC) with four to six s_nop 7 per stage.  An asm keeps vdst == srcC.  What hipcc's hazard recognizer then no
+// longer sees: the VALU read of an MFMA result (epilogue) -- wn_mfma_drain() in front of the first one.
+__device__ __forceinline__ void wn_mfma(f32x4& acc, float a, float b)
+{
+    asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void wn_mfma_drain(f32x4& acc) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc)); }   // >= 18 wait states: an 8-pass XDL write -> VALU read needs 11 (+1 on gfx950)
+
 // keeps a value's computation where it is written: without it hipcc sinks the whole input transform (it is only consumed by the
 // NEXT stage's MFMAs) out of this stage's MFMA stream into the top of the next stage
 #define WN_PIN(x) asm volatile("" : "+v"(x))
@@ -291,14 +308,14 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
     };
     auto row_pass = [&](f32x2 (&V)[16], int r, const f32x2 (&d)[4]) __attribute__((always_inline)) {
         V[4 * r + 0] = wn_sub2(d[0], d[2]);
-        V[4 * r + 1] = d[1] + d[2];
+        V[4 * r + 1] = wn_add2(d[1], d[2]);
         V[4 * r + 2] = wn_sub2(d[2], d[1]);
         V[4 * r + 3] = wn_sub2(d[1], d[3]);
     };
     auto col_pass = [&](f32x2 (&V)[16], int c) __attribute__((always_inline)) {
         const f32x2 w0 = V[c], w1 = V[4 + c], w2 = V[8 + c], w3 = V[12 + c];
         V[c] = wn_sub2(w0, w2);
-        V[4 + c] = w1 + w2;
+        V[4 + c] = wn_add2(w1, w2);
         V[8 + c] = wn_sub2(w2, w1);
         V[12 + c] = wn_sub2(w1, w3);
     };
@@ -405,10 +422,15 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
                 const f32x4 c0 = FIRST ? (pos == 5 ? biasv[0] : zero) : acc[pos][0];
                 const f32x4 c1 = FIRST ? (pos == 5 ? biasv[1] : zero) : acc[pos][1];
                 const f32x4 af = a[pos & 3];
-                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, Vc[pos].x, c0, 0, 0, 0);
-                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, Vc[pos].x, c1, 0, 0, 0);
-                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, Vc[pos].y, acc[pos][0], 0, 0, 0);
-                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, Vc[pos].y, acc[pos][1], 0, 0, 0);
+                if (FIRST) {
+                    acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, Vc[pos].x, c0, 0, 0, 0);
+                    acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, Vc[pos].x, c1, 0, 0, 0);
+                } else {                                       // in place (wn_mfma): no accumulator rotation, no WAR padding
+                    wn_mfma(acc[pos][0], af.x, Vc[pos].x);
+                    wn_mfma(acc[pos][1], af.z, Vc[pos].x);
+                }
+                wn_mfma(acc[pos][0], af.y, Vc[pos].y);
+                wn_mfma(acc[pos][1], af.w, Vc[pos].y);
                 __builtin_amdgcn_sched_barrier(0);
             }
             us = us1;
@@ -423,6 +445,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
 
         // ---- output transform  Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1], then residual / activation / store
         {
+            wn_mfma_drain(acc[15][1]);
             const int ybase = cur.y0 + 4 * wv + 2 * ty, xbase = cur.x0 + 2 * tx;
             unsigned pix[2][2];
             bool pok[2][2];
@@ -690,14 +713,14 @@ __global__ __launch_bounds__(W8_THREADS, 1) void wino8_f32_kernel(const WinoK p)
     };
     auto row_pass = [&](f32x2 (&V)[16], int r, const f32x2 (&d)[4]) __attribute__((always_inline)) {
         V[4 * r + 0] = wn_sub2(d[0], d[2]);
-        V[4 * r + 1] = d[1] + d[2];
+        V[4 * r + 1] = wn_add2(d[1], d[2]);
         V[4 * r + 2] = wn_sub2(d[2], d[1]);
         V[4 * r + 3] = wn_sub2(d[1], d[3]);
     };
     auto col_pass = [&](f32x2 (&V)[16], int c) __attribute__((always_inline)) {
         const f32x2 w0 = V[c], w1 = V[4 + c], w2 = V[8 + c], w3 = V[12 + c];
         V[c] = wn_sub2(w0, w2);
-        V[4 + c] = w1 + w2;
+        V[4 + c] = wn_add2(w1, w2);
         V[8 + c] = wn_sub2(w2, w1);
         V[12 + c] = wn_sub2(w1, w3);
     };
@@ -796,11 +819,16 @@ __global__ __launch_bounds__(W8_THREADS, 1) void wino8_f32_kernel(const WinoK p)
                 if (W8_ABL_NOMFMA) {
                     acc[pos][0] = c0; acc[pos][1] = c1;
                     acc[pos][0].x += af.x * Vc[pos].x + af.y * Vc[pos].y; acc[pos][1].x += af.z * Vc[pos].x + af.w * Vc[pos].y;
-                } else {
+                } else if (FIRST) {
                 acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, Vc[pos].x, c0, 0, 0, 0);
                 acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, Vc[pos].x, c1, 0, 0, 0);
-                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, Vc[pos].y, acc[pos][0], 0, 0, 0);
-                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, Vc[pos].y, acc[pos][1], 0, 0, 0);
+                wn_mfma(acc[pos][0], af.y, Vc[pos].y);
+                wn_mfma(acc[pos][1], af.w, Vc[pos].y);
+                } else {
+                wn_mfma(acc[pos][0], af.x, Vc[pos].x);
+                wn_mfma(acc[pos][1], af.z, Vc[pos].x);
+                wn_mfma(acc[pos][0], af.y, Vc[pos].y);
+                wn_mfma(acc[pos][1], af.w, Vc[pos].y);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -823,6 +851,7 @@ __global__ __launch_bounds__(W8_THREADS, 1) void wino8_f32_kernel(const WinoK p)
         } else
         // ---- output transform Y = A^T M A, activation, 8 unconditional buffer stores (out-of-range offset = dropped)
         {
+            wn_mfma_drain(acc[15][1]);
             const int ybase = cur.y0 + 2 * ty, xbase = cur.x0 + 2 * tx;
             const size_t hw = (size_t)p.H * p.W;
             unsigned pix[2][2];

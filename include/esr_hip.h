@@ -157,8 +157,10 @@ typedef struct esr_conv_desc {
      * [.., 48]-channel NHWC pixel is touched by four stages microseconds apart and is re-fetched when the L2 has dropped it in
      * between (PMC: 1.33x the algorithmic reads for the memory-bound IMDB tail); in the blocked layout a stage reads whole lines
      * and every line exactly once.  Supported: ESR_BLOCKED_OUT1 for fp32 NHWC convolutions with a split store (the "remaining"
-     * channels of IMDBlock's conv3), ESR_BLOCKED_IN for the fused IMDB tail at the network's shape (imdb_tail_kernel); any
-     * other use returns ESR_ERR_UNSUPPORTED. */
+     * channels of IMDBlock's conv3), ESR_BLOCKED_IN for the fused IMDB tail at the network's shape (imdb_tail_kernel) and -- ABI v9 --
+     * for every Winograd descriptor (both kernels read a chunk as a plane); ABI v9 also: bit 2 (ESR_BLOCKED_OUT0) `out0` and bit 3
+     * (ESR_BLOCKED_RES) `res` of the fused IMDB tail (IMDBlock's input / output x: the 64-input-channel Winograd layers then read
+     * whole lines too); any other use returns ESR_ERR_UNSUPPORTED. */
     int32_t blocked8;
     int32_t reserved4;
     /* ABI v7 -- Winograd F(2x2, 3x3) weights (esr_pack_wino_f32) of the SAME convolution; NULL = none.  When set and
@@ -171,6 +173,8 @@ typedef struct esr_conv_desc {
 } esr_conv_desc;
 #define ESR_BLOCKED_IN   1
 #define ESR_BLOCKED_OUT1 2
+#define ESR_BLOCKED_OUT0 4
+#define ESR_BLOCKED_RES  8
 
 /* Host-side weight packer (the K10 "weight packer" of SURVEY 7.2): OIHW fp32 (the layout of every
  * Conv2d in the reference state_dicts; nn.Linear [out,in] is the k=1 case) + bias -> the MFMA-tiled,

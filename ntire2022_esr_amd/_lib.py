@@ -16,7 +16,7 @@ STATUS = {0: "ESR_OK", -1: "ESR_ERR_BAD_ARG", -2: "ESR_ERR_UNSUPPORTED", -3: "ES
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
 RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
 NHWC, NCHW_IN, NCHW_SHUFFLE4 = 0, 1, 2
-BLOCKED_IN, BLOCKED_OUT1 = 1, 2          # esr_conv_desc.blocked8 bits (ABI v6)
+BLOCKED_IN, BLOCKED_OUT1, BLOCKED_OUT0, BLOCKED_RES = 1, 2, 4, 8          # esr_conv_desc.blocked8 bits (ABI v6 / v9)
 OP_CONV, OP_CONV3X3S2, OP_MAXPOOL7S3, OP_ESA_APPLY, OP_DWCONV, OP_BSCONV, OP_PACK_INPUT, OP_ESA_LOWRES = 0, 1, 2, 3, 4, 5, 6, 7
 ESA_MAX_LAYERS = 3
 ESA_FP = 16

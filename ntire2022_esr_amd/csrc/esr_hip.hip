@@ -74,6 +74,7 @@ struct ConvK {
     int out16;            // NCHW head only: the NHWC output is stored as bf16 (1) / fp16 (2) (esr_storage), 0 = fp32
     int y1_blk;           // esr_conv_desc.blocked8 & ESR_BLOCKED_OUT1: y1 is [n][y1_pitch / 8][H][W][8]
     int in_blk;           // ... & ESR_BLOCKED_IN (imdb_tail_kernel only): x is [n][in_pitch / 8][H][W][8]
+    int y0_blk, res_blk;  // ... & ESR_BLOCKED_OUT0 / ESR_BLOCKED_RES (imdb_tail_kernel only, ABI v9): y0 / res are [n][pitch / 8][H][W][8]
 };
 
 __device__ __forceinline__ float act_any(float v, int act, float slope)
@@ -229,6 +230,57 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvK& p, f32x4 (&acc)[NT][4
     else if (inside && p.act == ESR_ACT_GELU && p.res_mode == ESR_RES_NONE)
         epilogue_nhwc_fast<ESR_ACT_GELU, ESR_RES_NONE, NT, Y1BLK>(p, acc, scr, n, x0, y0, wv, lane);
     else epilogue_nhwc_checked<NT, Y1BLK>(p, acc, scr, n, x0, y0, wv, lane);
+}
+
+// Channel-blocked out0 ([n][y0_pitch / 8][H][W][8], ESR_BLOCKED_OUT0: the fused IMDB tail's output since round 4), NT = 4, no residual
+// (folded into the accumulators), any activation.  Same transposition through the wave's scratch as above; lane (chunk ch, pixel
+// prow + 4 i) then writes 16 bytes of plane ch / 2: the four prow lanes of a chunk cover 4 consecutive pixels x 32 bytes = one whole
+// 128-byte line per plane and instruction.
+template <int NT>
+__device__ __forceinline__ void epilogue_blk8(const ConvK& p, f32x4 (&acc)[NT][4], float* scr, int n, int x0, int y0, int wv, int lane, int tile_h)
+{
+    const int px = lane & 15, kq = lane >> 4;
+    const int ch = lane & 15, prow = lane >> 4;
+    const int cb = ch * 4;
+    const int c0 = p.y0_coff + cb;
+    const size_t hw8 = (size_t)p.H * p.W * 8;
+    float* const ylane = p.y0 + (size_t)n * hw8 * (p.y0_pitch / 8) + (size_t)(c0 >> 3) * hw8 + (c0 & 7) + prow * 8;
+    const bool inside = x0 + TILE <= p.W && y0 + tile_h <= p.H && p.cout_store == 64 && NT == 4;        // uniform
+    if (inside && (p.act == ESR_ACT_NONE || p.act == ESR_ACT_LRELU)) {
+        // fast path: no bounds checks, one uniform pixel base per row, the activation decided once
+        const float slope = p.act == ESR_ACT_NONE ? 1.f : p.slope;
+        const int pix00 = __builtin_amdgcn_readfirstlane((y0 + wv * 4) * p.W + x0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(scr + px * EPI_PITCH + t * 16 + kq * 4) = acc[t][r];
+            f32x4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(scr + (4 * i + prow) * EPI_PITCH + cb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 o = v[i];
+                o.x = fmaxf(o.x, slope * o.x); o.y = fmaxf(o.y, slope * o.y); o.z = fmaxf(o.z, slope * o.z); o.w = fmaxf(o.w, slope * o.w);
+                *reinterpret_cast<f32x4*>(ylane + (size_t)(pix00 + r * p.W + 4 * i) * 8) = o;
+            }
+        }
+        return;
+    }
+    const bool ch_ok = cb < p.cout_store;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gy = y0 + wv * 4 + r;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(scr + px * EPI_PITCH + t * 16 + kq * 4) = acc[t][r];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gx = x0 + 4 * i + prow;
+            f32x4 v = *reinterpret_cast<const f32x4*>(scr + (4 * i + prow) * EPI_PITCH + min(cb, NT * 16 - 4));
+            v.x = act_any(v.x, p.act, p.slope); v.y = act_any(v.y, p.act, p.slope);
+            v.z = act_any(v.z, p.act, p.slope); v.w = act_any(v.w, p.act, p.slope);
+            if (ch_ok && gy < p.H && gx < p.W) *reinterpret_cast<f32x4*>(ylane + ((size_t)gy * p.W + 4 * i + x0) * 8) = v;
+        }
+    }
 }
 
 // NCHW head of a 16-bit-storage network: the native fragment (4 channels of one pixel per lane) goes out as 8 bytes per lane.
@@ -1069,7 +1121,13 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
     // channel-blocked views (ABI v6): out1 of an fp32 NHWC split store; in of the fused IMDB tail at the network's shape
     k.y1_blk = (d->blocked8 & ESR_BLOCKED_OUT1) ? 1 : 0;
     k.in_blk = (d->blocked8 & ESR_BLOCKED_IN) ? 1 : 0;
-    if (d->blocked8 & ~(ESR_BLOCKED_IN | ESR_BLOCKED_OUT1)) return ESR_ERR_BAD_ARG;
+    k.y0_blk = (d->blocked8 & ESR_BLOCKED_OUT0) ? 1 : 0;
+    k.res_blk = (d->blocked8 & ESR_BLOCKED_RES) ? 1 : 0;
+    if (d->blocked8 & ~(ESR_BLOCKED_IN | ESR_BLOCKED_OUT1 | ESR_BLOCKED_OUT0 | ESR_BLOCKED_RES)) return ESR_ERR_BAD_ARG;
+    // blocked out0 / res: only the fused IMDB tail (checked again where the tail shape is known), whole planes
+    if ((k.y0_blk || k.res_blk) && (!tail || store16)) return ESR_ERR_UNSUPPORTED;
+    if (k.y0_blk && ((d->out0.pitch & 7) || (d->out0.coff & 7) || (double)d->h * d->w * d->out0.pitch * 4.0 >= 2147483647.0)) return ESR_ERR_UNSUPPORTED;
+    if (k.res_blk && (d->res_mode != ESR_RES_PRE_ACT || (d->res.pitch & 7) || (d->res.coff & 7))) return ESR_ERR_UNSUPPORTED;
     if (k.y1_blk) {
         if (d->out_layout != ESR_NHWC || tail || post || store16 || split >= cout4 || d->ksize != 3 || in_nchw || d->cout <= 48 || d->cout > 64 || (d->out1.pitch & 7) || (d->out1.coff & 7) || (split & 7) ||
             (double)d->h * d->w * d->out1.pitch * 4.0 >= 2147483647.0)
@@ -1121,7 +1179,7 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
             const double px_all = (double)d->n * d->h * d->w;
             if (px_all * d->tail_cat.pitch >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
         }
-        if (k.in_blk && !imdb_tail_shape(k)) return ESR_ERR_UNSUPPORTED;      // only imdb_tail_kernel reads the blocked layout
+        if ((k.in_blk || k.y0_blk || k.res_blk) && !imdb_tail_shape(k)) return ESR_ERR_UNSUPPORTED;      // only imdb_tail_kernel knows the blocked layouts
         return launch_conv_tail(k, st);
     }
     if (in_nchw) return launch_conv_nt<3, true>(nt, k, st);

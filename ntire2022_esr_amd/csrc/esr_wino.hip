@@ -261,7 +261,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
             const int ly = 2 * pr + odd, lx = rem - odd * WN_HALO;
             const int gy = c.y0 - 1 + ly, gx = c.x0 - 1 + lx;
             const bool ok = item < WN_RAW_SLOTS && rem < 2 * WN_HALO && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            c.voff[i] = (ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff + 4 * half) * 4u : WN_OOB) - (i == 1 ? 1024u : 0u);
+            c.voff[i] = (ok ? ((unsigned)(gy * p.W + gx) * p.pix_floats + 4u * half) * 4u + p.in_base : WN_OOB) - (i == 1 ? 1024u : 0u);
         }
     };
     const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 4;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_f32_kernel(const WinoK p)
 
     // piece i of the raw halo of chunk `chunk` of an item (image rsrc xr, per-lane offset v) -> raw ring slot `rs`
     auto issue_raw = [&](int i, int rs, wn_i32x4 xr, int chunk, unsigned v) __attribute__((always_inline)) {
-        const unsigned soff = (unsigned)chunk * 32u;
+        const unsigned soff = (unsigned)chunk * p.chunk_stride;
         const unsigned ro = (unsigned)(rs * WN_RAW_BYTES);
         if (i == 0) wn_dma16<0>(raw_m0 + ro, v, xr, soff);
         else if (i == 1) { if (live1) wn_dma16<1024>(raw_m0 + ro, v, xr, soff); }
@@ -962,9 +962,8 @@ int esr_wino_supported(const esr_conv_desc* d)
     const int cin_phys = esr_round_up(d->cin, 8);
     const int nchunks = cin_phys / 8;
     if (nchunks < 4 || (nchunks & 1)) return 0;                  // raw ring looks 3 chunks ahead; stages are unrolled in pairs
-    // a channel-blocked INPUT only where wino8_f32_kernel runs (it takes every such descriptor, of any size): 4 or 6 chunks, no residual
-    if ((d->blocked8 & ESR_BLOCKED_IN) && !((nchunks == 4 || nchunks == 6) && d->res_mode == ESR_RES_NONE && d->out_layout == ESR_NHWC && (d->in.coff & 7) == 0))
-        return 0;
+    // a channel-blocked INPUT [n][C/8][h][w][8] (both Winograd kernels read it: a chunk is a plane): whole planes only
+    if ((d->blocked8 & ESR_BLOCKED_IN) && (d->in.coff & 7)) return 0;
     const int cout4 = esr_round_up(d->cout, 4);
     int split = d->split <= 0 ? cout4 : d->split;
     if (split >= d->cout) split = cout4;
@@ -1083,17 +1082,16 @@ int esr_conv2d_wino(const esr_conv_desc* d, void* hip_stream)
     // wino8_f32_kernel (resident U, wave-private halo rings, no barrier): 4 or 6 input chunks, no residual, NHWC / blocked outputs, and enough
     // strips (4 rows x 16 columns) that each of the 2048 waves walks several; both per-image byte ranges behind 31-bit buffer offsets
     const bool blocked_in = (d->blocked8 & ESR_BLOCKED_IN) != 0;
-    if ((k.nchunks == 4 || k.nchunks == 6) && d->res_mode == ESR_RES_NONE && d->out_layout == ESR_NHWC && (g_wino8_enabled || blocked_in)) {
+    k.pix_floats = blocked_in ? 8u : (unsigned)d->in.pitch;
+    k.in_base = blocked_in ? (unsigned)(d->in.coff / 8) * (unsigned)(d->h * d->w * 32) : (unsigned)d->in.coff * 4u;
+    k.chunk_stride = blocked_in ? (unsigned)(d->h * d->w * 32) : 32u;
+    if ((k.nchunks == 4 || k.nchunks == 6) && d->res_mode == ESR_RES_NONE && d->out_layout == ESR_NHWC && g_wino8_enabled) {
         const long sx = (d->w + 15) / 16, sy = (d->h + 3) / 4;
         const long nstrips = (long)k.N * sx * sy;
         const double out_bytes = (double)d->h * d->w * 4.0 * (d->out0.pitch > d->out1.pitch ? d->out0.pitch : d->out1.pitch);
         const bool fits = (double)k.N * sx * sy * (sx > sy ? sx : sy) < 4294967296.0 && out_bytes < 2147482624.0;
-        if (blocked_in && !fits) return ESR_ERR_UNSUPPORTED;
-        if (fits && (blocked_in || nstrips >= 4L * 8 * W8_MAX_BLOCKS / k.nhalves)) {
+        if (fits && nstrips >= 4L * 8 * W8_MAX_BLOCKS / k.nhalves) {
             WinoK w = k;
-            w.pix_floats = blocked_in ? 8u : (unsigned)d->in.pitch;
-            w.in_base = blocked_in ? (unsigned)(d->in.coff / 8) * (unsigned)(d->h * d->w * 32) : (unsigned)d->in.coff * 4u;
-            w.chunk_stride = blocked_in ? (unsigned)(d->h * d->w * 32) : 32u;
             w.tiles_x = (int)sx; w.tiles_y = (int)sy;
             w.magic_x = sx == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)sx) + 1u;
             w.magic_y = sy == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)sy) + 1u;

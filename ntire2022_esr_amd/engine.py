@@ -490,8 +490,10 @@ class Plan:
                 d.out1 = self._view(o["dst1"], base)
             def _blk(v):
                 return v is not None and v is not INPUT and v is not OUTPUT and not isinstance(v, Planar) and (v if isinstance(v, Buffer) else v[0]).blocked
-            assert not _blk(o["dst"]) and not _blk(o["res"]), "blocked buffers: dst1 of a split store / input of the fused tail only"
-            d.blocked8 = (L.BLOCKED_IN if _blk(o["src"]) else 0) | (L.BLOCKED_OUT1 if _blk(o["dst1"]) else 0)
+            assert o.get("tail") is not None or (not _blk(o["dst"]) and not _blk(o["res"])), \
+                "blocked buffers: input of a Winograd conv / the fused tail, dst1 of a split store, dst / res of the fused tail"
+            d.blocked8 = (L.BLOCKED_IN if _blk(o["src"]) else 0) | (L.BLOCKED_OUT1 if _blk(o["dst1"]) else 0) | \
+                (L.BLOCKED_OUT0 if _blk(o["dst"]) else 0) | (L.BLOCKED_RES if _blk(o["res"]) else 0)
             if o["res"] is not None:
                 d.res = self._view(o["res"], base)
             lowres = o["hw"] is not None

@@ -51,7 +51,6 @@ class IMDN(HipSRModel):
             raise L.EsrError(f'IMDN expects {self.in_nc} input channels, got {c}')
         nc, d, r = self.nc, self.d_nc, self.r_nc
         fea = plan.buffer('fea', nc)
-        xa, xb = plan.buffer('xa', nc), plan.buffer('xb', nc)
         fused = d == 16 and 48 < nc <= 64 and self.compute == 'f32'    # conv4 + 1x1 in one launch (16-bit modes keep conv4 on the 16-bit kernel)
         # fused: conv4's slot never reaches memory.  16-bit storage (d a multiple of 16): four dense tensors (engine.Planar) instead
         # of 32-byte slices of a 128-byte pixel -- partial-line stores cost 2.3x a dense one
@@ -66,6 +65,11 @@ class IMDN(HipSRModel):
         # direct kernel cannot read a blocked input, so only with the Winograd path on)
         blk = fused and r == 48 and nc == 64
         blk12 = blk and self.winograd
+        # ... and for the block input / output x (xa / xb: written and read as a residual by the fused tail, read by conv1 and the LR conv
+        # on wino_f32_kernel): a standalone 64 -> 64 layer reads a blocked input 7-9 % faster (tools/wino/blk_probe.py).  `fea` stays NHWC:
+        # the NCHW head writes it, block 0 and the LR conv's residual read it
+        xa, xb = plan.buffer('xa', nc, blocked=blk12), plan.buffer('xb', nc, blocked=blk12)
+        lr = plan.buffer('lr', nc) if blk12 else None
         r1, r2 = plan.buffer('r1', plan.cpad(r), blocked=blk12), plan.buffer('r2', plan.cpad(r), blocked=blk12)
         r3 = plan.buffer('r3', r, blocked=True) if blk else r1
         act = dict(act=self.act, slope=self.slope)
@@ -86,5 +90,7 @@ class IMDN(HipSRModel):
                 plan.conv(p + 'conv1x1', cat, nxt, 4 * d, nc, k=1, res=cur, res_mode=L.RES_PRE_ACT)
             cur = nxt
             nxt = xb if cur is xa else xa
+        if lr is not None:
+            nxt = lr                                   # the LR conv's epilogue (residual add) stores NHWC
         plan.conv(f'model.1.sub.{self.nb}', cur, nxt, nc, nc, res=fea, res_mode=L.RES_PRE_ACT)
         plan.conv('model.2', nxt, OUTPUT, nc, self.out_nc * 16)

@@ -125,10 +125,19 @@ def test_imdn_plan_shape():
     m._build_plan(plan, 3)
     assert len(plan.ops) == 3 + 4 * 8
     assert sum(o.get("tail") is not None for o in plan.ops) == 8
-    assert plan.total == 4 * 2 * 40 * 56 * (64 * 3 + 48 * 4)                  # bytes: fea, xa, xb | cat (d1 d2 d3), r1, r2, r3
+    assert plan.total == 4 * 2 * 40 * 56 * (64 * 4 + 48 * 4)                  # bytes: fea, xa, xb, lr | cat (d1 d2 d3), r1, r2, r3
     blk = [bf for bf in plan.buffers if bf.blocked]
-    assert [bf.name for bf in blk] == ["r3"]                                  # conv3's remaining channels, channel-blocked for the tail
-    assert all((o["dst1"] is blk[0]) == o["w"].endswith("conv3.0") and (o["src"] is blk[0]) == (o.get("tail") is not None) for o in plan.ops)
+    # channel-blocked [n][c/8][h][w][8]: the IMDBlocks' x (ping-pong) and every "remaining" slice; fea, lr and cat stay NHWC
+    assert [bf.name for bf in blk] == ["xa", "xb", "r1", "r2", "r3"]
+    r3 = blk[-1]
+    assert all((o["dst1"] is r3) == o["w"].endswith("conv3.0") and (o["src"] is r3) == (o.get("tail") is not None) for o in plan.ops)
+    m.winograd = False                                                          # the direct kernels read NHWC: only r3 stays blocked
+    plan = Plan(2, 40, 56)
+    m._build_plan(plan, 3)
+    assert [bf.name for bf in plan.buffers if bf.blocked] == ["r3"]
+    m.winograd = True
+    plan = Plan(2, 40, 56)
+    m._build_plan(plan, 3)
     assert m.workspace_bytes(2, 40, 56) == plan.total
     total_macs = sum(cin * cout * k * k for o in plan.ops for (cin, cout, k, _, _) in m._counted_convs(plan, o))
     assert total_macs == 891584                                                # MAC per LR pixel

@@ -52,11 +52,15 @@ DIV2K_LR_SHAPES = [(339, 510), (339, 510), (384, 510), (339, 510), (510, 339), (
                    (510, 384), (339, 510)]
 
 
+NO_HILO_SKIP = False           # --no-hilo-skip: bf16 plans keep the long skip in single bf16 numbers (A/B of the hi + lo pairs)
+
+
 def build_model(name, device, compute):
     """Registry model with the exported reference checkpoint (weights/<name>.safetensors)."""
     from ntire2022_esr_amd.registry import select_model
     m, _, _, _ = select_model(MODELS[name][0], device)
     m.set_compute(compute)
+    m.hilo_skip = not NO_HILO_SKIP
     return m, "checkpoint"
 
 
@@ -302,6 +306,7 @@ def parse_args():
                          "runtimes gathered once after the timed region (dist.gather_rows): BASELINE.json config [3] with N = 200 "
                          "(DIV2K valid + test).  The total work is fixed, so the line says \"scaling\": \"strong\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hilo-skip", action="store_true", help="bf16: single-bf16 long skip instead of hi + lo pairs (A/B; model.hilo_skip = False)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default headline run only: skip the `other_configs` leg (BASELINE.json configs [2]-[4] measured behind the timed region)")
     ap.add_argument("--b1-latency", action="store_true",
@@ -317,6 +322,8 @@ def parse_args():
 
 def main():
     args = parse_args()
+    global NO_HILO_SKIP
+    NO_HILO_SKIP = bool(args.no_hilo_skip)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

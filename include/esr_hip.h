@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESR_ABI_VERSION 9
+#define ESR_ABI_VERSION 10
 
 typedef enum esr_status {
     ESR_OK = 0,
@@ -162,7 +162,15 @@ typedef struct esr_conv_desc {
      * (ESR_BLOCKED_RES) `res` of the fused IMDB tail (IMDBlock's input / output x: the 64-input-channel Winograd layers then read
      * whole lines too); any other use returns ESR_ERR_UNSUPPORTED. */
     int32_t blocked8;
-    int32_t reserved4;
+    /* ABI v10 -- hi + lo tensors (bf16 storage, plain 3x3 with 33..64 output channels): a value is kept as the SUM of two bf16 numbers in two
+     * dense NHWC tensors of the same shape -- the high parts bf16(v) where the view points, the low parts bf16(v - hi) `hilo_stride` bytes
+     * behind them (the field at the end of this struct; a multiple of 16) -- 16 significant bits instead of 8.  Bits: ESR_HILO_IN -- `in` is
+     * such a pair (the K loop runs over both tensors against the same weights: w (hi + lo) = w hi + w lo); ESR_HILO_RES -- `res` is one (both
+     * are added in fp32); ESR_HILO_OUT -- `out0` becomes one (NHWC only; `out1` unused).  For the long skip of the x4 networks,
+     * `upsampler(LR_conv(body) + fea)` (team04_rlfn.py:149-150; rfdn_baseline/RFDN.py:44-47): the image itself travels through `fea` and
+     * `out_lr`, and two bf16 roundings of it cost 0.03-0.09 dB on near-detail-free content (LAB_NOTES.md 9.4).  Anything else returns
+     * ESR_ERR_UNSUPPORTED. */
+    int32_t hilo;
     /* ABI v7 -- Winograd F(2x2, 3x3) weights (esr_pack_wino_f32) of the SAME convolution; NULL = none.  When set and
      * esr_wino_supported(d) (fp32 storage and compute, ksize 3, NHWC in / NHWC out, round_up(cin, 8) / 8 even and >= 4, no tail /
      * post / border table / segmented or blocked input, a split store only at a multiple of 16 channels), esr_conv2d_f32 runs
@@ -170,11 +178,15 @@ typedef struct esr_conv_desc {
      * fp32 throughout (its rounding differs from the direct sum's by ~1e-6 relative, inside the 2e-5 budget of SURVEY 8c).
      * Otherwise the descriptor takes conv_f32_kernel with `wpacked`, which must always be valid. */
     const void* wino_wpacked;
+    int64_t hilo_stride;        /* ABI v10: bytes from the high-part tensor to the low-part tensor of every hi + lo pair of this descriptor (`hilo`) */
 } esr_conv_desc;
 #define ESR_BLOCKED_IN   1
 #define ESR_BLOCKED_OUT1 2
 #define ESR_BLOCKED_OUT0 4
 #define ESR_BLOCKED_RES  8
+#define ESR_HILO_IN 1
+#define ESR_HILO_RES 2
+#define ESR_HILO_OUT 4
 
 /* Host-side weight packer (the K10 "weight packer" of SURVEY 7.2): OIHW fp32 (the layout of every
  * Conv2d in the reference state_dicts; nn.Linear [out,in] is the k=1 case) + bias -> the MFMA-tiled,

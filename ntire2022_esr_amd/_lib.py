@@ -17,6 +17,7 @@ ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
 RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
 NHWC, NCHW_IN, NCHW_SHUFFLE4 = 0, 1, 2
 BLOCKED_IN, BLOCKED_OUT1, BLOCKED_OUT0, BLOCKED_RES = 1, 2, 4, 8          # esr_conv_desc.blocked8 bits (ABI v6 / v9)
+HILO_IN, HILO_RES, HILO_OUT = 1, 2, 4                                     # esr_conv_desc.hilo bits (ABI v10)
 OP_CONV, OP_CONV3X3S2, OP_MAXPOOL7S3, OP_ESA_APPLY, OP_DWCONV, OP_BSCONV, OP_PACK_INPUT, OP_ESA_LOWRES = 0, 1, 2, 3, 4, 5, 6, 7
 ESA_MAX_LAYERS = 3
 ESA_FP = 16
@@ -46,7 +47,8 @@ class ConvDesc(ctypes.Structure):
         ("post_cout", ctypes.c_int32), ("post_act", ctypes.c_int32),
         ("post2_wpacked", ctypes.c_void_p), ("post2_out", View),
         ("post2_cout", ctypes.c_int32), ("reserved3", ctypes.c_int32), ("border_bias", ctypes.c_void_p), ("in_seg_stride", ctypes.c_int64), ("in_seg_chunks", ctypes.c_int32), ("blocked8", ctypes.c_int32),
-        ("reserved4", ctypes.c_int32), ("wino_wpacked", ctypes.c_void_p),      # ABI v7
+        ("hilo", ctypes.c_int32), ("wino_wpacked", ctypes.c_void_p),           # ABI v10 / v7
+        ("hilo_stride", ctypes.c_int64),                                       # ABI v10
     ]
 
 
@@ -223,7 +225,7 @@ def lib():
     L.esr_packed_apply_post_bytes.restype = sz
     L.esr_pack_apply_post.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, sz]
     L.esr_pack_apply_post.restype = ci
-    if L.esr_abi_version() != 9:
+    if L.esr_abi_version() != 10:
         raise EsrError("libesr_hip.so ABI version mismatch")
     L.esr_sizeof.argtypes = [ci]
     L.esr_sizeof.restype = ctypes.c_size_t

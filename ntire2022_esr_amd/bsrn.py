@@ -143,7 +143,11 @@ class BSRN(HipSRModel):
 
         def bs3(path, src, dst, cin, cout, **kw):
             plan.conv(path + '#bs3', src, dst, cin, cout, k=3, border=path + '#bs3#border', bs_of=path, **kw)
-        fea = plan.buffer('fea', C)
+        # bf16: `fea` and `out_lr` -- the long skip, team18_bsrn.py:231-234 -- are hi + lo pairs (Plan.pair: two dense tensors)
+        hl = merged and self._skip_hilo(plan, C)
+        fea2 = plan.pair('fea', plan.cpad(C)) if hl else None
+        out_lr2 = plan.pair('out_lr', plan.cpad(C)) if hl else None
+        fea = fea2.seg(0) if hl else plan.buffer('fea', C)
         # block outputs, team18_bsrn.py:226.  16-bit storage: nb dense tensors (engine.Planar) -- as C-channel slices of one [.., nb C]
         # buffer every block wrote 96 of 384 bytes per pixel (partial lines) and the next block's first convolutions read them back
         # at 1.7x their algorithmic bytes (profiles/pmc_traffic.json, r03b)
@@ -165,7 +169,11 @@ class BSRN(HipSRModel):
         apply_out = fuse_d and bplanar and bool(L.lib().esr_esa_apply_post_supported(C, C, dc))
         def first_d(k):
             return dict(w=f'B{k}.c1_d', dst=cs(0), cout=dc, act=L.ACT_GELU) if fuse_d else None
-        if merged:
+        if hl:                  # (the hi + lo store has no post-chain variant: block 1's c1_d is its own launch)
+            plan.conv('fea_conv#bs3', INPUT, fea2, self.in_nc, C, k=3, border='fea_conv#bs3#border', bs_of='fea_conv', hilo=L.HILO_OUT)
+            if fuse_d:
+                plan.conv('B1.c1_d', fea, cs(0), C, dc, k=1, counted=False, **g)
+        elif merged:
             plan.conv('fea_conv#bs3', INPUT, fea, self.in_nc, C, k=3, border='fea_conv#bs3#border', bs_of='fea_conv', post=first_d(1))
         else:
             plan.conv('fea_conv.pw', INPUT, t, self.in_nc, C, counted=False)
@@ -230,6 +238,10 @@ class BSRN(HipSRModel):
                           post=first_d(k + 1) if (merged and k < nb) else None)
             cur = out
         plan.conv('c1', bcat, v, nb * C, C, k=1, counted=False, **g)
+        if hl:
+            bs3('c2', v, out_lr2, C, C, res=fea2, res_mode=L.RES_PRE_ACT, hilo=L.HILO_RES | L.HILO_OUT)
+            plan.conv('upsampler.upsampleOneStep.0', out_lr2, OUTPUT, C, self.out_nc * 16, hilo=L.HILO_IN)
+            return
         if merged:
             bs3('c2', v, u, C, C, res=fea, res_mode=L.RES_PRE_ACT)
         else:

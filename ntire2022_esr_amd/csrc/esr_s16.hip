@@ -82,6 +82,12 @@ struct S16K {
     const float* border;                   // esr_conv_desc.border_bias, or NULL
     long long seg_stride;                  // segmented input: bytes between the tensors of the concat (else 0)
     int seg_chunks;                        // chunks per input segment (one tensor: nchunks)
+    // hi + lo tensors (esr_conv_desc.hilo, HILO kernels): a value is the sum of two 16-bit numbers kept in two dense tensors of the same
+    // shape, the low parts `hilo_stride` bytes behind the high parts
+    int w_chunks;                          // resident weight chunks: input chunk c multiplies weight chunk c mod w_chunks (hi + lo INPUT: nchunks / 2;
+                                           // the input is then a two-segment concat: seg_stride = hilo_stride, seg_chunks = w_chunks)
+    int hilo_out;                          // the epilogue stores the low parts too (through y1 = y0 + hilo_stride)
+    long long res_lo_stride;               // hi + lo RESIDUAL: 2 NT residual stages per tile, the second NT from res + this many bytes (else 0)
 };
 
 template <bool BF16>
@@ -250,10 +256,14 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, size_t bytes)
 // producing GEMM (lane (px, kq): 4 channels of one pixel, fp32) becomes the B operand of the next WITHOUT leaving the lane and
 // without being rounded: k slots (kq, 0..3) carry the 16-bit high parts of the four values, (kq, 4..7) their low parts, so the
 // intermediate tensor (RLFB's u, which nothing else reads) is neither stored nor quantised.
-template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 = 0>
+// HILO (bf16, the long skip head -> (+) -> upsampler; LAB_NOTES 9.4): tensors stored as hi + lo pairs.  Input: the K loop runs over both
+// halves of the pixel against the same resident weights (w (hi + lo) = w hi + w lo); residual: 2 NT staged chunks, both added; output:
+// a second set of stores with the low parts bf16(v - hi).
+template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 = 0, bool HILO = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(const S16K p)
 {
     static_assert(PNT2 == 0 || PNT1 > 0, "post 2 needs post 1");
+    static_assert(!HILO || (PNT1 == 0 && !GRES && KS == 3), "hi + lo tensors: the plain 3x3");
     constexpr int HALO = KS / 2;
     constexpr int TH = TILE + 2 * HALO;          // halo tile width = LDS row pitch in pixels
     // NW = 4: 16 x 16 tiles and TWO independent blocks per CU (each with its own copy of the weights: only where that fits 80 KB) --
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
         return q;
     };
     const int R = p.ring;
-    const int w_main = p.nchunks * W_CHUNK_BYTES;
+    const int w_main = (HILO ? p.w_chunks : p.nchunks) * W_CHUNK_BYTES;
     // post images: [post 1: NT k-tiles x PNT1 tiles, hi (then lo)][post 2: PNT1 k-tiles x PNT2 tiles, hi (then lo)][biases, 1 KB]
     constexpr int P1_IMG = NT * PNT1 * 1024, P2_IMG = PNT1 * PNT2 * 1024;
     const int plo = (PNT1 > 0 && p.post_lo) ? 2 : 1;
@@ -386,8 +396,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
         const int pc = OWN_PIECES ? wv * PPW + i : wv + NW * i;
         if (NPIECES % NW == 0 || i < PPW - 1 || pc < NPIECES) {         // wave-uniform
             const unsigned dst = ring_lds + (unsigned)(lslot * STAGE_BYTES) + (unsigned)pc * 1024u;
-            if (lc >= p.nchunks) dma_buf16(dst, LVR(i), lrsrcr, (unsigned)(lc - p.nchunks) * 32u);     // a residual chunk
-            else dma_buf16(dst, lvoff[i], lrsrc, lsoff);
+            if (lc >= p.nchunks) {                                      // a residual chunk
+                int rc = lc - p.nchunks;
+                i32x4 rs = lrsrcr;
+                if (HILO && rc >= NT) {                                  // ... of the low-part tensor: the buffer base moves on (see cursor_advance)
+                    rc -= NT;
+                    const unsigned long long b = ((unsigned long long)(unsigned)rs.x | ((unsigned long long)((unsigned)rs.y & 0xffffu) << 32)) + (unsigned long long)p.res_lo_stride;
+                    rs.x = (int)(unsigned)b;
+                    rs.y = (int)(((unsigned)rs.y & 0xffff0000u) | ((unsigned)(b >> 32) & 0xffffu));
+                }
+                dma_buf16(dst, LVR(i), rs, (unsigned)rc * 32u);
+            } else {
+                dma_buf16(dst, lvoff[i], lrsrc, lsoff);
+            }
         }
     };
     auto cursor_advance = [&]() __attribute__((always_inline)) {
@@ -465,7 +486,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
     constexpr int P1_STORES = (PNT1 / 2) * RW + (PNT1 & 1) * (RW / 2), P2_STORES = PNT2 > 0 ? RW / 2 : 0;
     static_assert(PNT2 <= 1, "post 2: one tile");
     const int epi_stores = p.out_layout == ESR_NCHW_SHUFFLE4 ? RW * NT
-                           : ((PNT1 == 0 || p.store_main) ? (p.split < p.cout_store ? 2 : 1) * SWAP_STORES : 0) + P1_STORES + P2_STORES;   // stores per wave and tile
+                           : ((PNT1 == 0 || p.store_main) ? ((p.split < p.cout_store || (HILO && p.hilo_out)) ? 2 : 1) * SWAP_STORES : 0) + P1_STORES + P2_STORES;   // stores per wave and tile
     const unsigned hmask = (1u << (R - 2)) - 1u;
     unsigned hist_rs = 0, hist_st = 0;   // bit i: stage s - i was a tile's first stage (residual loads) / carried an epilogue's stores
 
@@ -602,7 +623,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
     int e_y0n = 0, e_y1n = 0;
     float e_slope = 0.f;
     int e_res_mode = 0;
-    bool e_split = false, e_main = true;
+    bool e_split = false, e_main = true, e_hilo = false;
     // post outputs: post 1 = PNT1 tiles (pairs + an odd last tile), post 2 = one tile (rows paired)
     constexpr int NPAIR1 = PNT1 / 2;
     unsigned vp1A[NPAIR1 > 0 ? NPAIR1 : 1], vp1B = OOB, vp2B = OOB, e_rowbp1 = 0, e_rowbp2 = 0;
@@ -617,6 +638,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
         e_slope = (act_gelu || (q->nres > 0 && q->res_mode == ESR_RES_POST_ACT)) ? 1.f : q->slope;     // applied in place already
         e_res_mode = q->res_mode;
         e_split = qsplit < qcs;
+        e_hilo = HILO && q->hilo_out != 0;
         const size_t y0_img = (size_t)qH * qW * qy0p * 2, y1_img = (size_t)qH * qW * qy1p * 2;
         e_y0 = q->y0 + (size_t)pn * y0_img; e_y0n = (int)y0_img;
         e_y1 = q->y1 + (size_t)pn * y1_img; e_y1n = (int)y1_img;
@@ -632,11 +654,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
             const int ch = (2 * j + (kq & 1)) * 16 + (kq >> 1) * 8;
             vbA0[j] = (inx && ch < qsplit) ? s0 + l0 + (unsigned)ch * 2u : OOB;
             vbA1[j] = (inx && ch >= qsplit && ch < qcs) ? s1 + l1 + (unsigned)ch * 2u : OOB;
+            if (HILO && e_hilo) vbA1[j] = (inx && ch < qcs) ? s1 + l1 + (unsigned)ch * 2u : OOB;        // (split == cout_store: l1 counts from y1_coff - cout_store)
         }
         if (NT & 1) {
             const int ch = (NT - 1) * 16 + (kq >> 1) * 8;
             vbB0 = (inx && ch < qsplit) ? s0 + l0 + (unsigned)ch * 2u + ((kq & 1) ? e_rowb0 : 0u) : OOB;
             vbB1 = (inx && ch >= qsplit && ch < qcs) ? s1 + l1 + (unsigned)ch * 2u + ((kq & 1) ? e_rowb1 : 0u) : OOB;
+            if (HILO && e_hilo) vbB1 = (inx && ch < qcs) ? s1 + l1 + (unsigned)ch * 2u + ((kq & 1) ? e_rowb1 : 0u) : OOB;
         }
         if (PNT1 > 0) {
             e_main = q->store_main != 0;
@@ -667,6 +691,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
         }
     };
     uint2 pk[NT][2];                     // rounded rows r - 1 (even), r (odd) of the finished tile
+    uint2 pkl[HILO ? NT : 1][2];         // HILO: their low parts
     uint2 pk1[PNT1 > 0 ? PNT1 : 1][2], pk2[2];          // ... of the post chain's results
     auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 {
         const u32x2 a = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
@@ -677,6 +702,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
         const i32x4 o = swap16(X, Y);
         __builtin_amdgcn_raw_buffer_store_b128(o, __builtin_amdgcn_make_buffer_rsrc(e_y0, 0, e_y0n, 0x00020000), v0 + (unsigned)r * e_rowb0, 0, 0);
         if (e_split) __builtin_amdgcn_raw_buffer_store_b128(o, __builtin_amdgcn_make_buffer_rsrc(e_y1, 0, e_y1n, 0x00020000), v1 + (unsigned)r * e_rowb1, 0, 0);
+    };
+    auto store16lo = [&](uint2 X, uint2 Y, unsigned v1, int r) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_buffer_store_b128(swap16(X, Y), __builtin_amdgcn_make_buffer_rsrc(e_y1, 0, e_y1n, 0x00020000), v1 + (unsigned)r * e_rowb1, 0, 0);
     };
     // the fp32 fragment as the B operand of the post 1x1: k slots 0..3 = the 16-bit high parts, 4..7 = the low parts
     auto hilo = [&](f32x4 v) __attribute__((always_inline)) -> i32x4 {
@@ -700,6 +728,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
             if (GRES && e_res_mode == ESR_RES_POST_ACT) v += rf;
             pk[tt][r & 1].x = pack2<BF16>(v.x, v.y);
             pk[tt][r & 1].y = pack2<BF16>(v.z, v.w);
+            if (HILO) {
+                float a, b, c, d;
+                unpack2<BF16>(pk[tt][r & 1].x, a, b);
+                unpack2<BF16>(pk[tt][r & 1].y, c, d);
+                pkl[HILO ? tt : 0][r & 1].x = pack2<BF16>(v.x - a, v.y - b);
+                pkl[HILO ? tt : 0][r & 1].y = pack2<BF16>(v.z - c, v.w - d);
+            }
             if (PNT1 > 0) u[tt] = v;
         }
         if constexpr (PNT1 > 0) {
@@ -747,6 +782,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
                 store16(pk[2 * j][1], pk[2 * j + 1][1], vbA0[j], vbA1[j], r);
             }
             if (NT & 1) store16(pk[NT - 1][0], pk[NT - 1][1], vbB0, vbB1, r - 1);
+            if (HILO && e_hilo) {
+#pragma unroll
+                for (int j = 0; j < NPAIR; ++j) {
+                    store16lo(pkl[HILO ? 2 * j : 0][0], pkl[HILO ? 2 * j + 1 : 0][0], vbA1[j], r - 1);
+                    store16lo(pkl[HILO ? 2 * j : 0][1], pkl[HILO ? 2 * j + 1 : 0][1], vbA1[j], r);
+                }
+                if (NT & 1) store16lo(pkl[HILO ? NT - 1 : 0][0], pkl[HILO ? NT - 1 : 0][1], vbB1, r - 1);
+            }
         }
         if constexpr (PNT1 > 0) {
             const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(e_p1, 0, e_p1n, 0x00020000);
@@ -768,7 +811,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
         constexpr bool EPI = decltype(epi_tag)::value;           // first stage of a tile with the swap epilogue inside
         const bool first = EPI || c == 0;
         const char* sb = ring + slot * STAGE_BYTES;
-        const char* wc = smem + c * W_CHUNK_BYTES + a_off;
+        const char* wc = smem + ((HILO && c >= p.w_chunks) ? c - p.w_chunks : c) * W_CHUNK_BYTES + a_off;      // HILO input: the low half meets the same weights
 
         constexpr int NBUF = NW == 16 ? 1 : 2;          // fragment sets: the read of pair q+1 runs under the MFMAs of pair q
         i32x4 a[NBUF][NT], b[NBUF][RW];
@@ -865,7 +908,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
         for (int tt = 0; tt < NT; ++tt) {
             int cc = c - p.nchunks;
             asm volatile("" : "+s"(cc));      // opaque per tile (see the res_in block of compute)
-            if (tt == cc) {
+            if (tt == cc || (HILO && tt + NT == cc)) {             // HILO: stages NT .. 2 NT - 1 carry the residual's low parts
 #pragma unroll
                 for (int r = 0; r < RW; ++r)
                     acc[tt][r] += unpack4<BF16>(*reinterpret_cast<const uint2*>(sb + c_off + r * (TH * 32)));
@@ -1562,7 +1605,7 @@ int launch_conv48r(const S16K& k, hipStream_t st)
     return esr_check_launch("conv48r_kernel launch");
 }
 
-template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 = 0>
+template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 = 0, bool HILO = false>
 int launch_s16(const S16K& k, size_t lds, hipStream_t st)
 {
     // the attribute belongs to the (device, instantiation) pair: one process may drive several GPUs (engine contexts are keyed by
@@ -1571,7 +1614,7 @@ int launch_s16(const S16K& k, size_t lds, hipStream_t st)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
     if (!attr_set[dev].load(std::memory_order_relaxed)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<NT, KS, NW, BF16, GRES, PNT1, PNT2>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s16_kernel<NT, KS, NW, BF16, GRES, PNT1, PNT2, HILO>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
         if (e != hipSuccess) {
             esr_set_err("hipFuncSetAttribute(conv_s16_kernel, MaxDynamicSharedMemorySize)", e);
@@ -1582,8 +1625,9 @@ int launch_s16(const S16K& k, size_t lds, hipStream_t st)
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int cap = NW == 4 ? 512 : 256;                   // one block per CU (LDS; NW = 4: two), persistent over the tiles
     const int grid = ntiles < cap ? ntiles : cap;
-    esr_note_kernel("conv_s16_kernel<%d, %d, %d, %s, %s, %d, %d>", NT, KS, NW, esr_tf(BF16), esr_tf(GRES), PNT1, PNT2);
-    hipLaunchKernelGGL((conv_s16_kernel<NT, KS, NW, BF16, GRES, PNT1, PNT2>), dim3(grid), dim3(64 * NW), lds, st, k);
+    if (HILO) esr_note_kernel("conv_s16_kernel<%d, %d, %d, %s, %s, %d, %d, true>", NT, KS, NW, esr_tf(BF16), esr_tf(GRES), PNT1, PNT2);
+    else esr_note_kernel("conv_s16_kernel<%d, %d, %d, %s, %s, %d, %d>", NT, KS, NW, esr_tf(BF16), esr_tf(GRES), PNT1, PNT2);
+    hipLaunchKernelGGL((conv_s16_kernel<NT, KS, NW, BF16, GRES, PNT1, PNT2, HILO>), dim3(grid), dim3(64 * NW), lds, st, k);
     return esr_check_launch("conv_s16_kernel launch");
 }
 
@@ -1655,7 +1699,7 @@ static bool s16_res_is_input(const esr_conv_desc* d)
 static bool conv48r_takes(const esr_conv_desc* d)
 {
     const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
-    if (d->ksize != 3 || nchunks != 3 || (nt != 2 && nt != 3) || d->out_layout != ESR_NHWC || d->in_seg_stride != 0 || d->post_wpacked) return false;
+    if (d->ksize != 3 || nchunks != 3 || (nt != 2 && nt != 3) || d->out_layout != ESR_NHWC || d->in_seg_stride != 0 || d->post_wpacked || d->hilo) return false;
     if (d->res_mode != ESR_RES_NONE && !s16_res_is_input(d)) return false;
     if (d->split > 0 && d->split < d->cout) return false;
     return (long)d->n * ((d->w + TILE - 1) / TILE) * ((d->h + 31) / 32) >= 256;
@@ -1687,7 +1731,7 @@ int s16_block_waves(const esr_conv_desc* d)
     if (conv48r_takes(d) || conv48rp_takes(d)) return 1;
     const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
     const bool res_hbm = d->res_mode != ESR_RES_NONE && !s16_res_is_input(d);
-    if (d->ksize != 3 || nt != 3 || d->border_bias || d->post_wpacked || res_hbm || d->out_layout != ESR_NHWC || d->in_seg_stride != 0) return 8;
+    if (d->ksize != 3 || nt != 3 || d->border_bias || d->post_wpacked || res_hbm || d->out_layout != ESR_NHWC || d->in_seg_stride != 0 || d->hilo) return 8;
     if ((long)d->n * ((d->w + TILE - 1) / TILE) * ((d->h + 15) / 16) < 512) return 8;           // fewer tiles than resident blocks
     return s16_lds_bytes(nchunks, nt, 3, 4, RING_MIN, 1024) <= (size_t)LDS_LIMIT / 2 ? 4 : 8;
 }
@@ -1958,6 +2002,15 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     const int nt = esr_round_up(d->cout, 16) / 16;
     const bool shuffle = d->out_layout == ESR_NCHW_SHUFFLE4;
     const int cout8 = esr_round_up(d->cout, 8);
+    // hi + lo tensors (ABI v10): two dense tensors of the same shape, the low parts d->hilo_stride bytes behind the high parts
+    const int hilo = d->hilo;
+    if (hilo & ~(ESR_HILO_IN | ESR_HILO_RES | ESR_HILO_OUT)) return ESR_ERR_BAD_ARG;
+    if (hilo) {
+        if (!bf16 || d->ksize != 3 || post || segmented || (d->border_bias && (hilo & ESR_HILO_IN)) || (nt != 3 && nt != 4) || (d->split > 0 && d->split < d->cout)) return ESR_ERR_UNSUPPORTED;
+        if (d->hilo_stride <= 0 || (d->hilo_stride & 15)) return ESR_ERR_BAD_ARG;
+        if ((hilo & ESR_HILO_RES) && d->res_mode == ESR_RES_NONE) return ESR_ERR_BAD_ARG;
+        if ((hilo & ESR_HILO_OUT) && (shuffle || !d->out0.ptr)) return ESR_ERR_BAD_ARG;
+    }
     int split = d->split <= 0 ? cout8 : d->split;
     if (split >= d->cout) split = cout8;
     if (split & 7) return ESR_ERR_BAD_ARG;
@@ -1976,7 +2029,8 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     if (d->res_mode != ESR_RES_NONE && (!d->res.ptr || (d->res.pitch & 7) || (d->res.coff & 7) || d->res.coff + cout8 > d->res.pitch))
         return ESR_ERR_BAD_ARG;
     if ((double)d->h * d->w * d->in.pitch * 2.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;   // per-image raw buffer < 2 GiB
-    const int nchunks = cin_phys / 16;
+    const int wchunks = cin_phys / 16;                       // resident weight chunks
+    const int nchunks = (hilo & ESR_HILO_IN) ? 2 * wchunks : wchunks;     // input stages per tile
     int ring = RING_MAX;                                     // as many input stages as fit next to the resident weights
     size_t lds = 0;
     int pnt1 = 0, pnt2 = 0, post_lo = 0;
@@ -1994,8 +2048,8 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         if (d->post_act != ESR_ACT_NONE && d->post_act != ESR_ACT_LRELU && d->post_act != ESR_ACT_RELU && d->post_act != ESR_ACT_GELU) return ESR_ERR_UNSUPPORTED;
     } else {
         const size_t extra = (d->border_bias ? (size_t)nt * 1024 : 0) + 1024;      // border table, the bias KB
-        while (ring > RING_MIN && s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, ring, extra) > (size_t)LDS_LIMIT) --ring;
-        lds = s16_lds_bytes(nchunks, nt, d->ksize, S16_NW, ring, extra);
+        while (ring > RING_MIN && s16_lds_bytes(wchunks, nt, d->ksize, S16_NW, ring, extra) > (size_t)LDS_LIMIT) --ring;
+        lds = s16_lds_bytes(wchunks, nt, d->ksize, S16_NW, ring, extra);
     }
     if (lds > (size_t)LDS_LIMIT) return ESR_ERR_UNSUPPORTED;                                     // weight set too large to stay resident
     if (!shuffle && d->out0.ptr) {
@@ -2010,7 +2064,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     S16K k;
     k.x = static_cast<const char*>(d->in.ptr);
     k.wp = static_cast<const char*>(d->wpacked);
-    k.bias = reinterpret_cast<const float*>(k.wp + (size_t)nchunks * pairs * nt * 1024);
+    k.bias = reinterpret_cast<const float*>(k.wp + (size_t)wchunks * pairs * nt * 1024);
     k.res = static_cast<const char*>(d->res.ptr);
     k.y0 = static_cast<char*>(d->out0.ptr);
     k.y1 = static_cast<char*>(d->out1.ptr);
@@ -2032,7 +2086,15 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         k.res_in = 1;                               // residual == input: added from the staged tile, no residual loads
         k.res_mode = ESR_RES_NONE;
     }
-    if (k.res_mode != ESR_RES_NONE) k.nres = nt;                   // residual from HBM: staged as nt extra chunks per tile
+    if (k.res_mode != ESR_RES_NONE) k.nres = (hilo & ESR_HILO_RES) ? 2 * nt : nt;      // residual from HBM: staged as extra chunks per tile
+    k.w_chunks = wchunks;
+    k.hilo_out = (hilo & ESR_HILO_OUT) ? 1 : 0;
+    k.res_lo_stride = (hilo & ESR_HILO_RES) ? d->hilo_stride : 0;
+    if (k.hilo_out) {                                              // the low parts leave through the y1 stores
+        k.y1 = k.y0 + d->hilo_stride;
+        k.y1_pitch = k.y0_pitch;
+        k.y1_coff = k.y0_coff + split;                             // (the kernel subtracts `split` from y1's channel offsets)
+    }
     k.out_layout = d->out_layout;
     k.tiles_x = (d->w + TILE - 1) / TILE;
     k.tiles_y = (d->h + 31) / 32;
@@ -2053,7 +2115,15 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     k.border = d->border_bias;
     k.seg_chunks = segmented ? d->in_seg_chunks : nchunks;
     k.seg_stride = segmented ? d->in_seg_stride : 0;
+    if (hilo & ESR_HILO_IN) {                                      // [hi tensor, lo tensor]: a two-segment concat that meets the same weights twice
+        k.seg_chunks = wchunks;
+        k.seg_stride = d->hilo_stride;
+    }
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (hilo) {
+        if (nt == 3) return launch_s16<3, 3, S16_NW, true, false, 0, 0, true>(k, lds, st);
+        return launch_s16<4, 3, S16_NW, true, false, 0, 0, true>(k, lds, st);
+    }
     if (conv48rp_takes(d)) {
         // RLFB c3_r (+ block input) -> c5 -> esa.conv1 on 16 x 16 tiles
         S16K kp = k;

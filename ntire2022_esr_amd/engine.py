@@ -307,9 +307,13 @@ class Plan:
         assert self.esize == 2 and seg_pitch % 16 == 0
         return Planar([self.buffer(f"{name}.{j}", seg_pitch) for j in range(nseg)])
 
+    def pair(self, name, pitch):
+        """a hi + lo pair (esr_conv_desc.hilo): value = seg(0) + seg(1), two dense bf16 tensors `stride` bytes apart"""
+        return self.planar(name, 2, pitch)
+
     def conv(self, wname, src, dst, cin, cout, k=3, act=L.ACT_NONE, slope=0.05,
              res=None, res_mode=L.RES_NONE, dst1=None, split=0, hw=None, counted=True, tail=None, post=None, cin_alg=None,
-             border=None, bs_of=None):
+             border=None, bs_of=None, hilo=0):
         """src/dst/res: INPUT | OUTPUT | Buffer | (Buffer, coff, channels).  hw: spatial dims if not full-res.
         counted=False marks launches that are not an nn.Conv2d call of the reference (complexity counters).
         tail = dict(w=<1x1 weight name>, cat=<view of its other input channels>, cat_c, cout, mid_act): the 3x3 result
@@ -318,7 +322,8 @@ class Plan:
         by the same launch (esr_conv_desc.post_*).  cin_alg: logical input channels when `cin` counts the pad slots of a
         padded concat buffer (algorithmic flops / bytes).  border: name of an esr_conv_desc.border_bias table.  bs_of: this
         dense 3x3 stands for a BSConvU (pointwise 1x1 + depthwise 3x3 with merged weights): its algorithmic flops and its
-        complexity-counter terms are the BSConvU's."""
+        complexity-counter terms are the BSConvU's.  hilo: L.HILO_IN | HILO_RES | HILO_OUT -- src / res / dst are hi + lo pairs
+        (esr_conv_desc.hilo, bf16 plans): `Plan.pair(name, pitch)` objects, two dense tensors [high parts, low parts] one stride apart."""
         head = None
         if src is INPUT and self.esize == 2 and k == 3 and dst is not OUTPUT:
             # 16-bit plans: the NCHW fp32 input is first packed to 16-bit hi / lo slots (esr_pack_input_s16), the head convolution
@@ -328,7 +333,7 @@ class Plan:
             src, head, wname = x16, cin, wname + '#head'
         self.ops.append(dict(kind="conv", w=wname, src=src, dst=dst, dst1=dst1, cin=cin, cout=cout, k=k, act=act,
                              slope=slope, res=res, res_mode=res_mode, split=split, hw=hw, counted=counted, tail=tail,
-                             post=post, cin_alg=cin if cin_alg is None else cin_alg, border=border, bs_of=bs_of, head=head))
+                             post=post, cin_alg=cin if cin_alg is None else cin_alg, border=border, bs_of=bs_of, head=head, hilo=hilo))
 
     def dwconv(self, wname, src, dst, c, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.RES_NONE, hw=None):
         """depthwise 3x3 + bias (+res) (+act): the dw half of BSConvU."""
@@ -464,6 +469,12 @@ class Plan:
             d.n, d.h, d.w = self.n, self.h, self.w
             if o["hw"] is not None:
                 d.h, d.w = o["hw"]
+            if o.get("hilo", 0):                                  # hi + lo pairs (Plan.pair): the descriptor's views are the high-part tensors
+                o = dict(o)
+                for bit, key in ((L.HILO_IN, "src"), (L.HILO_RES, "res"), (L.HILO_OUT, "dst")):
+                    if o["hilo"] & bit:
+                        assert isinstance(o[key], Planar) and len(o[key].segs) == 2, "hilo: Plan.pair() buffers"
+                        o[key + "_pair"], o[key] = o[key], o[key].seg(0)
             d.cin, d.cout, d.ksize = (3 * o["head"] if o.get("head") else o["cin"]), o["cout"], o["k"]
             d.act, d.slope, d.res_mode = o["act"], o["slope"], o["res_mode"]
             d.split = o["split"]
@@ -496,6 +507,11 @@ class Plan:
                 (L.BLOCKED_OUT0 if _blk(o["dst"]) else 0) | (L.BLOCKED_RES if _blk(o["res"]) else 0)
             if o["res"] is not None:
                 d.res = self._view(o["res"], base)
+            d.hilo = o.get("hilo", 0)
+            if d.hilo:                                            # one stride for all pairs of the descriptor
+                strides = {o[key + "_pair"].stride for bit, key in ((L.HILO_IN, "src"), (L.HILO_RES, "res"), (L.HILO_OUT, "dst")) if d.hilo & bit}
+                assert len(strides) == 1, "hilo: pairs of one shape"
+                d.hilo_stride = strides.pop()
             lowres = o["hw"] is not None
             d.storage = 0 if lowres else st                       # ESA low-resolution maps: fp32
 
@@ -625,6 +641,7 @@ class HipSRModel(nn.Module):
         self.compute = "f32"       # "f32" | "bf16" | "f16": MFMA operand format of the full-resolution 3x3 convs
         self._fuse_esa_lowres = True  # ESA's low-resolution branch as one esr_esa_lowres_f32 op (two launches) instead of 3 .. 8 launches
         self._winograd = True      # fp32 plans: 3x3 convs whose shape qualifies run as Winograd F(2x2, 3x3) (esr_conv_desc.wino_wpacked)
+        self._hilo_skip = True     # bf16 plans: the long skip's tensors (`fea`, `out_lr`) as hi + lo pairs (esr_conv_desc.hilo; Plan.hilo_skip)
         self._lock = _ModelLock()       # plan / workspace bookkeeping and the pointer patch + enqueue of one forward (see _forward_impl)
         self._prof_passes = 0      # >0: record HIP events around every op (bench roofline leg)
         self.handle = next(_HANDLES)       # the `handle` argument of esr::sr_forward
@@ -677,6 +694,13 @@ class HipSRModel(nn.Module):
 
     fuse_esa_lowres = property(lambda self: self._fuse_esa_lowres, lambda self, v: self._set_flag("_fuse_esa_lowres", v))
     winograd = property(lambda self: self._winograd, lambda self, v: self._set_flag("_winograd", v))
+    hilo_skip = property(lambda self: self._hilo_skip, lambda self, v: self._set_flag("_hilo_skip", v))
+
+    def _skip_hilo(self, plan, c):
+        """bf16 plans: keep the long skip `upsampler(LR_conv(body) + fea)` in hi + lo pairs?  (c = its channel count; the hi + lo kernels
+        exist for 3 and 4 output tiles.)  Two bf16 roundings of the image itself cost 0.03-0.09 dB on near-detail-free content, the pairs
+        bring that to <= 0.003 dB (LAB_NOTES 9.4; tools/emulate_skip.py)."""
+        return bool(self._hilo_skip) and plan.store == "bf16" and (c + 15) // 16 in (3, 4)
 
     def set_compute(self, mode):
         """'f32': exact fp32 MFMA, fp32 activations.  'bf16' / 'f16' (BASELINE.json configs [2]-[4]): the full-resolution
@@ -990,6 +1014,11 @@ class HipSRModel(nn.Module):
                 if o.get("head"):
                     rd += npix * (16 * 2 - ca * e_in)  # the head reads the packed 16-slot copy (esr_pack_input_s16), not the fp32 input
                 wr = float(npix * o["cout"] * e_out) if o["dst"] is not None else 0.0
+                hl = o.get("hilo", 0)                # hi + lo tensors: twice the 16-bit bytes
+                rd += npix * e_act * ((ca if hl & L.HILO_IN else 0) + (o["cout"] if hl & L.HILO_RES else 0))
+                wr += npix * e_act * o["cout"] if hl & L.HILO_OUT else 0.0
+                if hl:
+                    kern = kern[:-1] + ",HILO>"
                 flops = 2.0 * npix * ca * o["cout"] * o["k"] * o["k"]
                 if o.get("bs_of") is not None:      # the BSConvU it stands for: pointwise GEMM + depthwise 3x3
                     flops = 2.0 * npix * (ca * o["cout"] + 9 * o["cout"])
@@ -1065,6 +1094,8 @@ class HipSRModel(nn.Module):
             # flops = ALGORITHMIC (direct-convolution) flops; flops_exec = what the matrix cores execute: Winograd F(2x2,3x3) does 16
             # multiplications per 2x2 outputs where the direct form does 36
             fexec = flops * (16.0 / 36.0) if (kind == "conv" and wino) else flops
+            if kind == "conv" and o.get("hilo", 0) & L.HILO_IN:
+                fexec = 2.0 * flops               # both halves of a hi + lo input meet the weights
             out.append(dict(name=o.get("w", kind), kernel=kern, cin=o.get("cin", 0), cout=o.get("cout", 0), k=o.get("k", 0),
                             flops=flops, flops_exec=fexec, read_bytes=rd, write_bytes=wr))
         return out

@@ -50,7 +50,11 @@ class IMDN(HipSRModel):
         if c != self.in_nc:
             raise L.EsrError(f'IMDN expects {self.in_nc} input channels, got {c}')
         nc, d, r = self.nc, self.d_nc, self.r_nc
-        fea = plan.buffer('fea', nc)
+        # bf16: `fea` and the LR conv's output -- the long skip of the ShortcutBlock, models/imdn_baseline.py:61, basicblock.py:191-205 -- are hi + lo pairs (Plan.pair)
+        hl = self._skip_hilo(plan, nc)
+        fea2 = plan.pair('fea', plan.cpad(nc)) if hl else None
+        out_lr2 = plan.pair('out_lr', plan.cpad(nc)) if hl else None
+        fea = fea2.seg(0) if hl else plan.buffer('fea', nc)
         fused = d == 16 and 48 < nc <= 64 and self.compute == 'f32'    # conv4 + 1x1 in one launch (16-bit modes keep conv4 on the 16-bit kernel)
         # fused: conv4's slot never reaches memory.  16-bit storage (d a multiple of 16): four dense tensors (engine.Planar) instead
         # of 32-byte slices of a 128-byte pixel -- partial-line stores cost 2.3x a dense one
@@ -73,7 +77,7 @@ class IMDN(HipSRModel):
         r1, r2 = plan.buffer('r1', plan.cpad(r), blocked=blk12), plan.buffer('r2', plan.cpad(r), blocked=blk12)
         r3 = plan.buffer('r3', r, blocked=True) if blk else r1
         act = dict(act=self.act, slope=self.slope)
-        plan.conv('model.0', INPUT, fea, self.in_nc, nc)
+        plan.conv('model.0', INPUT, fea2 if hl else fea, self.in_nc, nc, hilo=L.HILO_OUT if hl else 0)
         cur, nxt = fea, xa
         for i in range(self.nb):
             p = f'model.1.sub.{i}.'
@@ -92,5 +96,9 @@ class IMDN(HipSRModel):
             nxt = xb if cur is xa else xa
         if lr is not None:
             nxt = lr                                   # the LR conv's epilogue (residual add) stores NHWC
-        plan.conv(f'model.1.sub.{self.nb}', cur, nxt, nc, nc, res=fea, res_mode=L.RES_PRE_ACT)
-        plan.conv('model.2', nxt, OUTPUT, nc, self.out_nc * 16)
+        if hl:
+            plan.conv(f'model.1.sub.{self.nb}', cur, out_lr2, nc, nc, res=fea2, res_mode=L.RES_PRE_ACT, hilo=L.HILO_RES | L.HILO_OUT)
+            plan.conv('model.2', out_lr2, OUTPUT, nc, self.out_nc * 16, hilo=L.HILO_IN)
+        else:
+            plan.conv(f'model.1.sub.{self.nb}', cur, nxt, nc, nc, res=fea, res_mode=L.RES_PRE_ACT)
+            plan.conv('model.2', nxt, OUTPUT, nc, self.out_nc * 16)

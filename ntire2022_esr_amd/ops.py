@@ -22,7 +22,7 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
            split=0, out1=None, out1_coff=0, res_coff=0, packed=None, cin_map=None, store=None,
            tail_weight=None, tail_bias=None, tail_cat=None, tail_cat_coff=0, tail_mid_act=L.ACT_NONE,
            post_weight=None, post_bias=None, post_act=L.ACT_NONE, post2_weight=None, post2_bias=None, store_main=True,
-           border=None, blocked_in=False, blocked_out1=False, wino=False):
+           border=None, blocked_in=False, blocked_out1=False, wino=False, hilo=0):
     """Fused conv (k=1|3, stride 1, same padding) on the current stream.
 
     x       NHWC [N,H,W,pitch] (channels [in_coff, in_coff+cin) are read) or NCHW fp32 if in_nchw.  The dtype of an NHWC
@@ -35,6 +35,9 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
             on the first (returns (y, post, post2)); store_main=False does not store y (returns None in its place)
     border  esr_conv_desc.border_bias: fp32 [16, round_up(cout, 16)] table added by outside-mask (16-bit storage only)
     blocked_in / blocked_out1   esr_conv_desc.blocked8: x / out1 is a channel-blocked fp32 tensor [N, C/8, H, W, 8]
+    hilo    esr_conv_desc.hilo (bf16, 3x3, 33..64 output channels): L.HILO_IN -- x is a contiguous [2, N, H, W, P] pair (value = x[0] + x[1]:
+            high parts, low parts); L.HILO_RES -- so is res; L.HILO_OUT -- so will y be ([2, N, H, W, round_up(cout, 16)]); all pairs of one
+            call must have the same x.stride(0)
     wino    fp32 3x3: also pass Winograd F(2x2, 3x3) weights (esr_conv_desc.wino_wpacked); raises if the shape does not qualify
     tail_*  fused 1x1 (esr_conv_desc.tail_*): tail_weight [cout1, cat_c + 16(, 1, 1)] over concat(tail_cat slice,
             mid_act(this 3x3 conv)); act / res / out then apply to the 1x1, whose output is returned
@@ -65,6 +68,14 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
         d.in_layout = L.NHWC
         d.inp = L.View(ctypes.c_void_p(x.data_ptr()), pl * 8, in_coff)
         d.blocked8 |= L.BLOCKED_IN
+    elif hilo & L.HILO_IN:
+        if x.dim() != 5 or x.shape[0] != 2 or not x.is_contiguous():
+            raise L.EsrError("conv2d: a hi + lo input is a contiguous [2, N, H, W, P] pair")
+        _, n, h, w, _ = x.shape
+        cin = wcin if cin is None else cin
+        d.in_layout = L.NHWC
+        d.inp = _view(x[0], in_coff)
+        d.hilo_stride = x.stride(0) * x.element_size()
     elif x.dim() == 5:
         # planar concat [S, N, H, W, P]: S dense tensors one stride apart (esr_conv_desc.in_seg_stride / in_seg_chunks)
         if not s16 or not x.is_contiguous() or x.shape[-1] % 16:
@@ -104,10 +115,17 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
         else:
             if out is None:
                 c_store = (min(split, cout) if split else cout)
-                y = torch.zeros((n, h, w, (c_store + gran - 1) // gran * gran), dtype=odt, device=x.device)
+                y = torch.zeros(((2,) if hilo & L.HILO_OUT else ()) + (n, h, w, (c_store + gran - 1) // gran * gran if not hilo & L.HILO_OUT else (cout + 15) // 16 * 16),
+                                dtype=odt, device=x.device)
             else:
                 y = out
-            d.out0 = _view(y, out_coff)
+            if hilo & L.HILO_OUT:
+                if y.dim() != 5 or y.shape[0] != 2 or not y.is_contiguous():
+                    raise L.EsrError("conv2d: a hi + lo output is a contiguous [2, N, H, W, P] pair")
+                d.out0 = _view(y[0], out_coff)
+                d.hilo_stride = y.stride(0) * y.element_size()
+            else:
+                d.out0 = _view(y, out_coff)
         if out1 is not None:
             if blocked_out1:
                 if out1.dim() != 5 or out1.shape[-1] != 8 or out1.dtype != torch.float32 or not out1.is_contiguous():
@@ -116,8 +134,14 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
                 d.blocked8 |= L.BLOCKED_OUT1
             else:
                 d.out1 = _view(out1, out1_coff)
-    if res is not None:
+    if res is not None and hilo & L.HILO_RES:
+        if res.dim() != 5 or res.shape[0] != 2 or not res.is_contiguous():
+            raise L.EsrError("conv2d: a hi + lo residual is a contiguous [2, N, H, W, P] pair")
+        d.res = _view(res[0], res_coff)
+        d.hilo_stride = res.stride(0) * res.element_size()
+    elif res is not None:
         d.res = _view(res, res_coff)
+    d.hilo = hilo
     d.wpacked = ctypes.c_void_p(packed.data_ptr())
     if wino:
         keepw = pack_wino(w4, bias, cin_map=cin_map).to(x.device)

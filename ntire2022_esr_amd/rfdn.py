@@ -69,7 +69,11 @@ class RFDN(HipSRModel):
         nf, dc, f, DP = self.nf, self.dc, self.f, self.DP
         P = plan.cpad(nf)                                 # 56 fp32 channels / 64 16-bit channels: whole K chunks
         h2, w2, h3, w3 = _lowres(plan.h, plan.w)
-        fea = plan.buffer('fea', P)
+        # bf16: `fea` and `out_lr` -- the long skip, RFDN.py:44-47 -- are hi + lo pairs (Plan.pair: two dense tensors)
+        hl = self._skip_hilo(plan, nf)
+        fea2 = plan.pair('fea', P) if hl else None
+        fea = fea2.seg(0) if hl else plan.buffer('fea', P)
+        out_lr2 = plan.pair('out_lr', P) if hl else None
         # the four block outputs, RFDN.py:36: four dense tensors in the 16-bit modes (engine.Planar; same slot order as the padded
         # [.., 4 P] buffer, so c.0's weight blob does not change)
         bplanar = plan.esize == 2
@@ -89,10 +93,11 @@ class RFDN(HipSRModel):
         res = (lambda v: dict(res=v, res_mode=L.RES_PRE_ACT)) if self.block_residual else (lambda v: {})
         fused_post = (48 < nf <= 64 and 16 < dc <= 32) if plan.esize == 4 else ((nf + 15) // 16 in (3, 4) and 16 < dc <= 32)
         # 16-bit modes: block 1's first distillation conv (c1_d of fea) rides in the head convolution's epilogue
-        head_d = plan.esize == 2 and fused_post
-        plan.conv('fea_conv', INPUT, fea, self.in_nc, nf, post=dict(w='B1.c1_d', dst=cs(0), cout=dc, act=L.ACT_LRELU) if head_d else None)
+        head_d = plan.esize == 2 and fused_post and not hl        # (the hi + lo store has no post-chain variant: block 1's c1_d is its own launch)
+        plan.conv('fea_conv', INPUT, fea2 if hl else fea, self.in_nc, nf, post=dict(w='B1.c1_d', dst=cs(0), cout=dc, act=L.ACT_LRELU) if head_d else None,
+                  hilo=L.HILO_OUT if hl else 0)
         # ... and the other blocks' in the ESA apply launch that produces their input (esr_esa_desc.post[])
-        apply_d = head_d and bool(L.lib().esr_esa_apply_post_supported(nf, dc, 0))
+        apply_d = plan.esize == 2 and fused_post and bool(L.lib().esr_esa_apply_post_supported(nf, dc, 0))
         cur = fea
         for k in range(1, 5):
             b = f'B{k}.'
@@ -133,8 +138,12 @@ class RFDN(HipSRModel):
             plan.esa_apply(b + 'esa.conv_f', b + 'esa.conv4', v, c1, lb, out, nf, f, post=nxt_d)
             cur = out
         plan.conv('c.0', bcat, v, 4 * P, nf, k=1, cin_alg=4 * nf, **act)
-        plan.conv('LR_conv', v, r1, nf, nf, res=fea, res_mode=L.RES_PRE_ACT)
-        plan.conv('upsampler.0', r1, OUTPUT, nf, self.out_nc * 16)
+        if hl:
+            plan.conv('LR_conv', v, out_lr2, nf, nf, res=fea2, res_mode=L.RES_PRE_ACT, hilo=L.HILO_RES | L.HILO_OUT)
+            plan.conv('upsampler.0', out_lr2, OUTPUT, nf, self.out_nc * 16, hilo=L.HILO_IN)
+        else:
+            plan.conv('LR_conv', v, r1, nf, nf, res=fea, res_mode=L.RES_PRE_ACT)
+            plan.conv('upsampler.0', r1, OUTPUT, nf, self.out_nc * 16)
 
     def _cin_map(self, path, cin_map, store):
         if path == 'c.0':                                 # the block-output slices are as wide as the storage type's K chunks

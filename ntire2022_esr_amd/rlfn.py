@@ -57,7 +57,11 @@ class RLFN_cut(HipSRModel):
         nf, mf, f = self.nf, self.mf, self.esa_channels
         P, M = plan.cpad(nf), plan.cpad(mf)
         h2, w2, h3, w3 = _lowres(plan.h, plan.w)
-        fea = plan.buffer('fea', P)
+        # bf16: `fea` and `out_lr` -- the long skip, team04_rlfn.py:149-150 -- are hi + lo pairs (Plan.pair: two dense tensors)
+        hl = self._skip_hilo(plan, nf)
+        fea2 = plan.pair('fea', P) if hl else None
+        fea = fea2.seg(0) if hl else plan.buffer('fea', P)
+        out_lr2 = plan.pair('out_lr', P) if hl else None
         xa, xb = plan.buffer('xa', P), plan.buffer('xb', P)
         t1, t2 = plan.buffer('t1', M), plan.buffer('t2', M)
         u, v = plan.buffer('u', P), plan.buffer('v', P)
@@ -66,7 +70,7 @@ class RLFN_cut(HipSRModel):
         lo3 = plan.buffer('esa_pool', FP, h3, w3)
         lo4 = plan.buffer('esa_c3', FP, h3, w3)
         act = dict(act=L.ACT_LRELU, slope=0.05)
-        plan.conv('fea_conv', INPUT, fea, self.in_nc, nf)
+        plan.conv('fea_conv', INPUT, fea2 if hl else fea, self.in_nc, nf, hilo=L.HILO_OUT if hl else 0)
         cur, nxt = fea, xa
         for k in range(1, 5):
             b = f'B{k}.'
@@ -92,5 +96,9 @@ class RLFN_cut(HipSRModel):
             plan.esa_apply(b + 'esa.conv_f', b + 'esa.conv4', v, c1, lo4, nxt, nf, f)
             cur = nxt
             nxt = xb if cur is xa else xa
-        plan.conv('LR_conv', cur, u, nf, nf, res=fea, res_mode=L.RES_PRE_ACT)
-        plan.conv('upsampler.0', u, OUTPUT, nf, self.out_nc * 16)
+        if hl:
+            plan.conv('LR_conv', cur, out_lr2, nf, nf, res=fea2, res_mode=L.RES_PRE_ACT, hilo=L.HILO_RES | L.HILO_OUT)
+            plan.conv('upsampler.0', out_lr2, OUTPUT, nf, self.out_nc * 16, hilo=L.HILO_IN)
+        else:
+            plan.conv('LR_conv', cur, u, nf, nf, res=fea, res_mode=L.RES_PRE_ACT)
+            plan.conv('upsampler.0', u, OUTPUT, nf, self.out_nc * 16)

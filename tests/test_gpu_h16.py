@@ -279,10 +279,9 @@ def test_network_psnr_shift(mid, compute, max_dpsnr):
     p16 = util.calculate_psnr(util.tensor2uint(y16, dr), hr, border=4)
     rel = float((y16 - y32).abs().max()) / dr
     print(f"{name} {compute}: PSNR {p32:.4f} -> {p16:.4f} dB (d = {p16 - p32:+.4f}), max|dy|/data_range = {rel:.2e}")
-    # the budget is a DATASET-MEAN budget (100 DIV2K images of ~173 k LR pixels); ONE image of 4 k LR pixels scatters around
-    # it (measured: RLFN bf16 -0.005 .. -0.007 dB on the 65 k .. 173 k-pixel images, -0.011 here): 1.5 x for the single
-    # small image, the budget itself is asserted on the stated-size images and on the set mean in test_gpu_big.py
-    assert abs(p16 - p32) < 1.5 * max_dpsnr
+    # (rounds 2-3 allowed this single 4 k-pixel image 1.5 x the dataset-mean budget: RLFN bf16 sat at -0.011 dB; with the long skip in
+    # hi + lo pairs -- round 4 -- it is -0.005 dB and the budget itself holds)
+    assert abs(p16 - p32) < max_dpsnr
     model.set_compute("f32")
     assert torch.equal(model(x), y32)                       # switching back restores the exact fp32 path
 
@@ -365,3 +364,84 @@ def test_conv48rp_equals_conv_s16(compute, hw, n):
     for i in range(n):
         _, v1, c1 = ops.conv2d(x[i:i + 1].contiguous(), w, b, res=r[i:i + 1].contiguous(), **kw)
         assert torch.equal(yv[i:i + 1], v1) and torch.equal(yc[i:i + 1], c1), i
+
+
+def _hilo(t, cp):
+    """NCHW fp32 -> bf16 pair [2, N, H, W, cp]: high parts, low parts (value = hi + lo; pad channels zero)"""
+    t = F.pad(_nhwc(t), (0, cp - t.shape[1]))
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo]).contiguous()
+
+
+@pytest.mark.parametrize("n,c,hw", [(2, 46, (37, 29)), (1, 50, (64, 80)), (3, 48, (100, 77)), (1, 64, (339, 510))])
+def test_s16_hilo_skip_convs(n, c, hw):
+    """esr_conv_desc.hilo (ABI v10): the three convolutions of the long skip on hi + lo tensors.
+    head:       y = conv(x16)              -> hi + lo out: the high parts ARE the plain kernel's output (bit-identical), hi + lo is
+                                              the fp64 result to 2^-16 relative (two bf16 numbers) instead of 2^-8
+    LR_conv:    y = conv(x16) + (r_hi + r_lo)  -> hi + lo out, same bound
+    upsampler:  y = shuffle(conv(x_hi + x_lo))  against the fp64 convolution of the SUM with the blob's effective weights"""
+    from ntire2022_esr_amd import _lib as L, ops
+    from ntire2022_esr_amd.engine import pack_conv_s16, unpack_conv_s16
+    g = torch.Generator().manual_seed(n * 1000 + c + hw[0])
+    cp = (c + 15) // 16 * 16
+    x = torch.randn(n, c, *hw, generator=g).to(torch.bfloat16)
+    r32 = torch.randn(n, c, *hw, generator=g) * 3.0
+    w = torch.randn(c, c, 3, 3, generator=g) * 0.1
+    b = torch.randn(c, generator=g)
+    blob = pack_conv_s16(w, b, "bf16", cin_phys=cp)
+    weff, _ = unpack_conv_s16(blob, c, c, 3, "bf16", cin_phys=cp)
+    xin = F.pad(_nhwc(x), (0, cp - c)).to(DEV)
+    conv = F.conv2d(x.double(), weff.double(), b.double(), padding=1)
+
+    def check(y, ref, what):
+        assert y.dtype == torch.bfloat16 and tuple(y.shape) == (2, n, *hw, cp)
+        hi, lo = y[0].float().cpu(), y[1].float().cpu()
+        got = (hi.double() + lo.double()).permute(0, 3, 1, 2)[:, :c]
+        tol = ref.abs() * 2.0 ** -15 + 3e-5 * max(1.0, float(ref.abs().max()))           # fp32 accumulation noise dominates
+        assert bool(((got - ref).abs() <= tol).all()), (what, float(((got - ref).abs() - tol).max()))
+        assert float((lo.abs() > hi.abs() * 2.0 ** -7 + 1e-30).float().mean()) < 1e-3, what         # the low parts are remainders of the high ones
+        return hi
+
+    plain = ops.conv2d(xin, w, b, cin=c, packed=blob.to(DEV))
+    y = ops.conv2d(xin, w, b, cin=c, packed=blob.to(DEV), hilo=L.HILO_OUT)
+    hi = check(y, conv, "head")
+    assert torch.equal(hi[..., :plain.shape[-1]], plain.float().cpu()), "the high parts are the plain kernel's output"
+    rin = _hilo(r32, cp).to(DEV)
+    rsum = (rin[0].double() + rin[1].double()).cpu().permute(0, 3, 1, 2)[:, :c]
+    y = ops.conv2d(xin, w, b, cin=c, packed=blob.to(DEV), res=rin, res_mode=1, hilo=L.HILO_RES | L.HILO_OUT)
+    check(y, conv + rsum, "LR_conv")
+    # upsampler: 48 output channels, pixel shuffle, hi + lo input
+    wu = torch.randn(48, c, 3, 3, generator=g) * 0.1
+    bu = torch.randn(48, generator=g)
+    blobu = pack_conv_s16(wu, bu, "bf16", cin_phys=cp)
+    weffu, _ = unpack_conv_s16(blobu, c, 48, 3, "bf16", cin_phys=cp)
+    x32 = torch.randn(n, c, *hw, generator=g) * 2.0
+    xh = _hilo(x32, cp).to(DEV)
+    xsum = (xh[0].double() + xh[1].double()).cpu().permute(0, 3, 1, 2)[:, :c]
+    ref = F.pixel_shuffle(F.conv2d(xsum, weffu.double(), bu.double(), padding=1), 4)
+    yu = ops.conv2d(xh, wu, bu, cin=c, packed=blobu.to(DEV), shuffle_out=True, hilo=L.HILO_IN)
+    assert yu.dtype == torch.float32 and tuple(yu.shape) == (n, 3, 4 * hw[0], 4 * hw[1])
+    err = float((yu.double().cpu() - ref).abs().max())
+    assert err <= 3e-5 * max(1.0, float(ref.abs().max())), err
+    # and the same input WITHOUT its low parts is off by the bf16 rounding of x: the low half is really read
+    y0 = ops.conv2d(xh[0], wu, bu, cin=c, packed=blobu.to(DEV), shuffle_out=True)
+    assert float((y0.double().cpu() - ref).abs().max()) > 20 * err
+
+
+def test_s16_hilo_rejects_what_it_does_not_cover():
+    from ntire2022_esr_amd import _lib as L, ops
+    x = torch.zeros(1, 20, 20, 32, dtype=torch.bfloat16, device=DEV)
+    w, b = torch.zeros(32, 32, 3, 3), torch.zeros(32)
+    with pytest.raises(L.EsrError):                      # two output tiles: no hi + lo kernel
+        ops.conv2d(x, w, b, hilo=L.HILO_OUT)
+    x = torch.zeros(1, 20, 20, 48, dtype=torch.float16, device=DEV)
+    w, b = torch.zeros(48, 48, 3, 3), torch.zeros(48)
+    with pytest.raises(L.EsrError):                      # fp16 storage: 11 bits already
+        ops.conv2d(x, w, b, hilo=L.HILO_OUT)
+    x = torch.zeros(1, 20, 20, 48, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(L.EsrError):                      # the input is not a pair
+        ops.conv2d(x, w, b, hilo=L.HILO_IN)
+    x = torch.zeros(2, 1, 20, 20, 48, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(L.EsrError):                      # 1x1: not covered
+        ops.conv2d(x, torch.zeros(48, 48, 1, 1), b, hilo=L.HILO_IN)

@@ -4,9 +4,11 @@ flipped / shifted, two noise tiles with 1/f and 1/f^2 spectra -- mirror-tiled to
 Asserted: fp32 -- every image's SR sample <= 2e-5 * data_range from the reference's and
 |dPSNR| <= 0.002 dB; 16-bit modes -- the MEAN |dPSNR| against the REFERENCE's PSNR <= 0.01 dB (bf16) / 0.005 dB (fp16) over the
 seven images of photographic PSNR (19 - 29 dB; DIV2K-val's mean is 29 dB), no single one of them beyond the budget itself.
-Image 6 (the 1/f^2 tile: almost no detail, reference PSNR 44.6 dB) is the stress case and is asserted on its own: the rounding
-noise of bf16 storage sits ~61 dB below full scale whatever the image, which is invisible next to a 29 dB reconstruction error
-and worth -0.03 ... -0.09 dB next to a 44.6 dB one (fp16: 8x finer, inside its budget there too)."""
+Image 6 (the 1/f^2 tile: almost no detail, reference PSNR 44.6 dB) is the stress case: the rounding noise of bf16 storage sits ~61 dB below
+full scale whatever the image, invisible next to a 29 dB reconstruction error and worth -0.03 ... -0.09 dB next to a 44.6 dB one when the
+long skip `upsampler(LR_conv(body) + fea)` carries the image through two bf16 roundings (rounds 2-3).  Round 4: the skip's tensors are hi + lo
+bf16 pairs (esr_conv_desc.hilo, LAB_NOTES 9.4) and the tile is inside the budget like every other image (BSRN bf16, an extra pairing: -0.05 dB);
+`model.hilo_skip = False` restores the single-bf16 skip (asserted below to be what made the difference)."""
 import os
 
 import numpy as np
@@ -79,5 +81,29 @@ def test_16bit_mean_psnr_budget_over_eight_textures(name, compute, budget):
     # single images: inside the budget for the BASELINE.json pairings (RLFN / RFDN bf16, BSRN fp16), twice that for the extra ones
     config_pair = (name, compute) in (("team04_rlfn", "bf16"), ("rfdn_baseline", "bf16"), ("team18_bsrn", "f16"))
     assert max(abs(d) for d in photo) <= (budget if config_pair else 2 * budget), ds
-    # the near-detail-free tile (reference PSNR 44.6 dB): fp16 stays inside its budget, bf16 within 0.12 dB (see the module docstring)
-    assert abs(ds[SMOOTH]) <= (0.12 if compute == "bf16" else budget), ds[SMOOTH]
+    # the near-detail-free tile (reference PSNR 44.6 dB): inside the budget too (bf16: with the hi + lo skip, see the module docstring)
+    # BSRN bf16 (not a BASELINE pairing) keeps -0.05 dB there: its ESDBs add their input to their output (team18_bsrn.py:172), so the image also
+    # travels through eight single-bf16 block outputs; was -0.085 before the skip's pairs
+    smooth_budget = budget if config_pair else (0.06 if (name, compute) == ("team18_bsrn", "bf16") else 2 * budget)
+    assert abs(ds[SMOOTH]) <= smooth_budget, ds[SMOOTH]
+
+
+@pytest.mark.parametrize("name", ["team04_rlfn", "rfdn_baseline"])
+def test_bf16_hilo_skip_is_what_keeps_the_smooth_tile_in_budget(name):
+    """model.hilo_skip = False: the same bf16 network with `fea` / `out_lr` as single bf16 tensors -- the smooth tile leaves the budget
+    (RLFN -0.09 dB, RFDN -0.03 dB), the photographic images hardly move; switching back restores the hi + lo plans bit for bit."""
+    from ntire2022_esr_amd import image_util as util
+    m, dr = _model(name, "bf16")
+    g = np.load(os.path.join(GOLD, "multi", f"multi_{SMOOTH}.npz"))
+    x = util.uint2tensor4(g["lr"], dr).to(DEV)
+    ref = float(g[f"{name}_psnr"])
+    y_on = m(x).clone()
+    d_on = util.calculate_psnr(util.tensor2uint(y_on, dr), hr_source(SMOOTH), border=4) - ref
+    m.hilo_skip = False
+    try:
+        d_off = util.calculate_psnr(util.tensor2uint(m(x), dr), hr_source(SMOOTH), border=4) - ref
+    finally:
+        m.hilo_skip = True
+    print(name, "bf16 smooth tile dPSNR: hi + lo skip", round(d_on, 5), " single-bf16 skip", round(d_off, 5))
+    assert abs(d_on) <= 0.01 and abs(d_off) >= 2.5 * abs(d_on) and d_off < -0.02
+    assert torch.equal(m(x), y_on)

@@ -1109,19 +1109,43 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
     uint2 pk[NT][2];                     // the finished row pair, rounded
     unsigned e_vA = OOB, e_vB = OOB;     // store offsets (row 0 of the wave) of the tile whose epilogue is in flight
     int e_n = 0;
-    auto epi_pack = [&](int par, int f) __attribute__((always_inline)) {          // fragment f = 2 t + e of the finished pair
+    // The epilogue of a finished row pair runs in MICRO-STEPS, one behind each MFMA of the next pair's groups (round 4): the wave is alone on
+    // its SIMD and issues in order, so VALU work placed as a clump behind a group's last MFMA runs while the matrix pipe idles (an MFMA
+    // occupies the pipe for 16 cycles, an independent VALU instruction issues in 4).  Step m of group g: fragment f = g - 1 (g = 1 .. 2 NT)
+    // is activated in steps 0 / 1 and rounded in 2 / 3; store i = g - 9 swaps in steps 0 / 1 and leaves in step 2.
+    f32x4 ev = {0.f, 0.f, 0.f, 0.f};
+    u32x2 es0 = {0u, 0u}, es1 = {0u, 0u};
+    auto epi_pack_step = [&](int par, int f, int m) __attribute__((always_inline)) {          // fragment f = 2 t + e of the finished pair
         const int t = f >> 1, e = f & 1;
-        f32x4 v = acc[par][t][e];
-        if (gelu) v = gelu16x4(v);
-        else { v.x = act1(v.x, slope); v.y = act1(v.y, slope); v.z = act1(v.z, slope); v.w = act1(v.w, slope); }
-        pk[t][e].x = pack2<BF16>(v.x, v.y);
-        pk[t][e].y = pack2<BF16>(v.z, v.w);
+        if (m == 0) {
+            ev = acc[par][t][e];
+            if (gelu) ev = gelu16x4(ev);
+            else { ev.x = act1(ev.x, slope); ev.y = act1(ev.y, slope); }
+        } else if (m == 1) {
+            if (!gelu) { ev.z = act1(ev.z, slope); ev.w = act1(ev.w, slope); }
+        } else if (m == 2) {
+            pk[t][e].x = pack2<BF16>(ev.x, ev.y);
+        } else if (m == 3) {
+            pk[t][e].y = pack2<BF16>(ev.z, ev.w);
+        }
     };
-    auto epi_store = [&](int i, int r) __attribute__((always_inline)) {           // store i of the pair whose first row is r
-        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)e_n * y_img, 0, (int)y_img, 0x00020000);
-        if (i == 0) __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[0][0], pk[1][0]), yr, e_vA + (unsigned)r * rowb, 0, 0);
-        else if (i == 1) __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[0][1], pk[1][1]), yr, e_vA + (unsigned)(r + 1) * rowb, 0, 0);
-        else __builtin_amdgcn_raw_buffer_store_b128(swap16(pk[NT - 1][0], pk[NT - 1][1]), yr, e_vB + (unsigned)r * rowb, 0, 0);
+    auto epi_store_step = [&](int i, int r, int m) __attribute__((always_inline)) {           // store i of the pair whose first row is r
+        // i = 0 / 1: tiles 0, 1 of row r / r + 1 (64 bytes per pixel); i = 2: the odd last tile of both rows (32 bytes per pixel and row)
+        const int ta = i < 2 ? 0 : NT - 1, tb = i < 2 ? 1 : NT - 1, ea = i < 2 ? i : 0, eb = i < 2 ? i : 1;
+        if (m == 0) es0 = __builtin_amdgcn_permlane16_swap(pk[ta][ea].x, pk[tb][eb].x, false, false);
+        else if (m == 1) es1 = __builtin_amdgcn_permlane16_swap(pk[ta][ea].y, pk[tb][eb].y, false, false);
+        else if (m == 2) {
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)e_n * y_img, 0, (int)y_img, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)es0.x, (int)es1.x, (int)es0.y, (int)es1.y}, yr, (i < 2 ? e_vA + (unsigned)(r + i) * rowb : e_vB + (unsigned)r * rowb), 0, 0);
+        }
+    };
+    auto epi_pack = [&](int par, int f) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) epi_pack_step(par, f, m);
+    };
+    auto epi_store = [&](int i, int r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) epi_store_step(i, r, m);
     };
     auto store_offsets = [&](int nn_, int x0_, int y0_) __attribute__((always_inline)) {
         const bool inx = x0_ + px < p.W;
@@ -1132,7 +1156,6 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
         e_vB = (inx && chB < p.cout_store) ? base + (unsigned)chB * 2u + ((kq & 1) ? rowb : 0u) : OOB;
         e_n = nn_;
     };
-    bool pend = false;                   // a finished tile's last row pair waits for its epilogue
     for (int k = 0;; ++k) {
         const int tn = tile_index(k + 1);
         const bool more = tn >= 0;
@@ -1177,15 +1200,17 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
                             if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "a"(wr[c][q][t]), "v"(b[cs][e]));
                             else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "a"(wr[c][q][t]), "v"(b[cs][e]));
                         }
+                        // the previous row pair's epilogue (rp == 0: the previous TILE's last pair), one micro-step behind each MFMA: its
+                        // accumulators were last written 15 groups ago.  (The block's first tile: nothing is waiting, the steps run on
+                        // whatever the registers hold and their stores are out of range.)
+                        {
+                            const int m = 2 * t + e, r_prev = rp == 0 ? RW - 2 : 2 * rp - 2;
+                            if (g >= 1 && g <= 2 * NT) epi_pack_step(par ^ 1, g - 1, m);
+                            if (g >= 9 && g < 9 + SPP) epi_store_step(g - 9, r_prev, m);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 if (rp == 0 && g < PPW) dma_piece(g, more, nn, nx0, ny0, (k + 1) & 1);      // the next tile's DMA, in the shadow of the matrix pipe
-                // the previous row pair's epilogue (rp == 0: the previous TILE's last pair), one piece per group: its accumulators were
-                // last written 15 groups ago
-                if (rp > 0 || pend) {
-                    const int r_prev = rp == 0 ? RW - 2 : 2 * rp - 2;
-                    if (g >= 1 && g <= 2 * NT) epi_pack(par ^ 1, g - 1);
-                    if (g >= 9 && g < 9 + SPP) epi_store(g - 9, r_prev);
-                }
                 if (rp == 0 && g == NG - 1) store_offsets(n, x0, y0);              // (behind the previous tile's last store)
                 if (EXT && q == PAIRS - 1 && (res_in || (on_border && c == NCH - 1))) {
                     // conv_s16_kernel's order: act(conv(x) + x) adds the centre pixels of chunk c to channel tile c BEHIND chunk c's
@@ -1214,7 +1239,282 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
         // the next tile has landed: younger than its DMA are the stores of this tile's row pairs but the last
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RW / 2 - 1) * SPP) : "memory");
         __builtin_amdgcn_s_barrier();
-        pend = true;
+        if (!more) break;
+        n = nn; x0 = nx0; y0 = ny0;
+    }
+    // the last tile's last row pair
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // (asm MFMAs: hipcc does not pad MFMA -> VALU reads of their results)
+#pragma unroll
+    for (int f = 0; f < 2 * NT; ++f) epi_pack(1, f);
+#pragma unroll
+    for (int i = 0; i < SPP; ++i) epi_store(i, RW - 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the trailing zero-fill DMA must not outlive the block)
+}
+
+// ---- conv64r_kernel: conv48r_kernel's plan for 64 physical input channels (round 4) ------------------------------------------------
+// RFDB's c3_r / c4 (rfdn_baseline/block.py:157-161) and every other plain 3x3 over 49..64 channels with 2 or 4 output tiles ran on
+// conv_s16_kernel at 0.32-0.38 of the HBM peak: a wave issues one ds_read_b128 per two MFMAs there (four weight + four pixel fragments per
+// 16 MFMAs) and the eight waves ask for them in lockstep -- the LDS pipe and the matrix pipe each need a stage's whole time.  What changes
+// against conv48r_kernel:
+//   * the layer's weights are 80 fragments x 4 registers = 320 for NT = 4: more than the 256 accumulation registers.  Chunks 0..2 (240)
+//     stay there; chunk 3 (20 KB) stays in LDS where the blob was staged and its fragments are read one group ahead through a ring of two
+//     -- on average 3 LDS reads per 8 MFMAs instead of 4 per 8.  NT = 2: all 160 in registers;
+//   * a staged pixel is 128 bytes in memory and 160 in LDS (two unused 16-byte slots).  A ds_read_b128 is served in four groups of 16
+//     lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 (MI355X_MICROARCH.md, LDS): half of a group reads channel half
+//     0 of eight pixels, the other half channel half 1 of the other eight.  With a 128-byte pitch the 16 lanes meet in 2 of the 16 slot
+//     columns, with 144 bytes (9 px mod 16) the two halves of a group collide in 7; 10 px mod 16 puts half 0 on the even and half 1 on
+//     the odd columns, eight different ones each: conflict-free.  The pad slots are part of the DMA pieces (their lanes fetch nothing:
+//     out-of-range offset), 51 pieces of 1 KB per 18 x 18 tile;
+//   * 16 x 16 tiles only (a 16 x 32 tile's two stages would not fit); LDS: two stages + the blob behind stage 0 = 131 KB.
+// Same packed weights, fragment maps, operation order and rounding as conv_s16_kernel: results are bit-identical.
+template <bool BF16, int NT, bool EXT>
+__global__ __launch_bounds__(256, 1) void conv64r_kernel(const S16K p)
+{
+    constexpr int NCH = 4, PAIRS = 5, TH = 18, RW = 4, THY = 4 * RW + 2;
+    constexpr int GSL = NCH * 2;                   // 16-byte slots of a pixel in memory
+    constexpr int LSL = GSL + 2;                   // ... in LDS
+    constexpr int PIXB = LSL * 16;                 // 160
+    constexpr int NSLOT = TH * THY * LSL;          // 3240
+    constexpr int NPIECES = (NSLOT + 63) / 64;     // 51
+    constexpr int STAGE = NPIECES * 1024;
+    constexpr int PPW = (NPIECES + 3) / 4;         // 13 per wave, the last wave one fewer
+    constexpr int NG = NCH * PAIRS;                // 20 tap-pair groups per row pair
+    constexpr int NCR = NT == 4 ? 3 : 4;           // chunks whose weights live in registers
+    constexpr int SPP = NT;                        // stores per row pair: NT / 2 tile pairs x 2 rows
+    constexpr int WSTAGE = STAGE;                  // the blob is staged behind stage 0 (stage 1 is free until the second tile's DMA) ...
+    constexpr int W3 = WSTAGE + NCR * PAIRS * NT * 1024;      // ... and chunk 3 stays where it landed
+    static_assert(PPW <= NG, "at most one DMA piece per tap-pair group of the first row pair");
+    static_assert(NT == 2 || NT == 4, "shapes");
+    static_assert(NCR == NCH || W3 >= 2 * STAGE, "the resident chunk lies behind stage 1");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, kq = lane >> 4;
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const bool res_in = EXT && p.res_in != 0;       // (no GELU here: the 64-channel layers of the path are RFDN's, LeakyReLU)
+
+    constexpr int WPIECES = NCH * PAIRS * NT;      // 1 KB fragments
+#pragma unroll
+    for (int i = 0; i < (WPIECES + 3) / 4; ++i) {
+        const int pc = wv + 4 * i;
+        if (pc < WPIECES) dma_glb16(smem_lds + (unsigned)(WSTAGE + pc * 1024), p.wp + (size_t)pc * 1024 + lane * 16);
+    }
+    i32x4 wr[NCR][PAIRS][NT];
+    f32x4 bia[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bia[t] = *reinterpret_cast<const f32x4*>(p.bias + t * 16 + kq * 4);
+
+    const int ntiles = p.N * p.tiles_y * p.tiles_x;
+    const int G = gridDim.x;
+    auto tile_index = [&](int k) -> int {
+        const int base = k * G;
+        if (base >= ntiles) return -1;
+        int off = blockIdx.x;
+        if ((G & 7) == 0 && base + G <= ntiles) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+        const int t = base + off;
+        return t < ntiles ? t : -1;
+    };
+    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) {
+        const unsigned mx = p.magic_x, my = p.magic_y;
+        const int tq = mx ? (int)__umulhi((unsigned)t, mx) : t;
+        const int tx = t - tq * p.tiles_x;
+        n = my ? (int)__umulhi((unsigned)tq, my) : tq;
+        const int ty = tq - n * p.tiles_y;
+        x0 = tx * TILE;
+        y0 = ty * (4 * RW);
+    };
+    const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 2;
+    // piece i of this wave of the tile (n, x0, y0) into stage `slot`; nothing valid (behind the last tile): zeros
+    auto dma_piece = [&](int i, bool valid, int n, int x0, int y0, int slot) __attribute__((always_inline)) {
+        const int pc = wv + 4 * i;
+        if (i < PPW - 1 || pc < NPIECES) {                             // wave-uniform
+            const unsigned sl = (unsigned)(pc * 64 + lane);             // 16-byte slot of the stage: pixel sl / 10, part sl % 10 (parts 8, 9: the pad)
+            const unsigned pixel = sl / (unsigned)LSL, part = sl - pixel * (unsigned)LSL;
+            const unsigned ly = pixel / (unsigned)TH, lx = pixel - ly * (unsigned)TH;
+            const int gy = y0 - 1 + (int)ly, gx = x0 - 1 + (int)lx;
+            const bool ok = valid && part < (unsigned)GSL && sl < (unsigned)NSLOT && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const unsigned voff = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff) * 2u + part * 16u : OOB;
+            dma_buf16(smem_lds + (unsigned)(slot * STAGE + pc * 1024), voff, make_rsrc(p.x + (size_t)(valid ? n : 0) * img_bytes, img_bytes), 0u);
+        }
+    };
+
+    int n, x0, y0;
+    {
+        const int t0 = tile_index(0);
+        if (t0 < 0) return;
+        tile_coords(t0, n, x0, y0);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma_piece(i, true, n, x0, y0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int c = 0; c < NCR; ++c)
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                wr[c][q][t] = *reinterpret_cast<const i32x4*>(smem + WSTAGE + ((c * PAIRS + q) * NT + t) * 1024 + lane * 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // every wave holds its fragments: stage 1 may be overwritten
+
+    // lane-constant offsets of the B fragments: pair q reads tap min(2q + (kq >> 1), 8), channel half kq & 1 of the chunk
+    int b_off[PAIRS];
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+        const int tap = min(2 * q + (kq >> 1), 8);
+        b_off[q] = ((wv * RW + tap / 3) * TH + px + tap % 3) * PIXB + (kq & 1) * 16;
+    }
+    const int c_off = ((wv * RW + 1) * TH + px + 1) * PIXB + kq * 8;      // centre pixel of row 0 of the wave: channels 16 c + 4 kq .. +3 at + 32 c
+    const char* const w3 = smem + W3 + lane * 16;                           // chunk 3's fragments: + (q * NT + t) KB
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 {
+        const u32x2 a = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
+        const u32x2 b = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
+        return i32x4{(int)a.x, (int)b.x, (int)a.y, (int)b.y};
+    };
+    const float slope = p.slope;
+    const size_t y_img = (size_t)p.H * p.W * p.y0_pitch * 2;
+    const unsigned rowb = (unsigned)p.W * (unsigned)p.y0_pitch * 2u;
+
+    f32x4 acc[2][NT][2];                 // [row pair & 1][channel tile][row of the pair]
+    uint2 pk[NT][2];                     // the finished row pair, rounded
+    unsigned e_v[NT / 2];                // store offsets (row 0 of the wave, tile pair j) of the tile whose epilogue is in flight
+#pragma unroll
+    for (int j = 0; j < NT / 2; ++j) e_v[j] = OOB;
+    int e_n = 0;
+    // The epilogue of a finished row pair runs in MICRO-STEPS, one behind each MFMA of the next pair's groups: this wave is alone on its
+    // SIMD and issues in order, so VALU work placed behind a group's last MFMA runs while the matrix pipe idles (an MFMA occupies the pipe
+    // for 16 cycles, a dependent-free VALU instruction issues in 4) -- as a clump behind each group the epilogue cost a third of the launch
+    // (tools/abl/c64_abl.py: 128 us without it, 213 us with).  step m of group g: fragment f = g - 1 (g = 1 .. 2 NT) is activated in steps
+    // 0 / 1 and rounded in 2 / 3; store i = g - 2 NT - 1 swaps in steps 0 / 1 and leaves in step 2.
+    f32x4 ev = {0.f, 0.f, 0.f, 0.f};
+    u32x2 es0 = {0u, 0u}, es1 = {0u, 0u};
+    auto epi_pack_step = [&](int par, int f, int m) __attribute__((always_inline)) {          // fragment f = 2 t + e of the finished pair
+        const int t = f >> 1, e = f & 1;
+        if (m == 0) {
+            ev = acc[par][t][e];
+            ev.x = act1(ev.x, slope); ev.y = act1(ev.y, slope);
+        } else if (m == 1) {
+            ev.z = act1(ev.z, slope); ev.w = act1(ev.w, slope);
+        } else if (m == 2) {
+            pk[t][e].x = pack2<BF16>(ev.x, ev.y);
+        } else if (m == 3) {
+            pk[t][e].y = pack2<BF16>(ev.z, ev.w);
+        }
+    };
+    auto epi_store_step = [&](int i, int r, int m) __attribute__((always_inline)) {           // store i = 2 j + e of the pair whose first row is r
+        const int j = i >> 1, e = i & 1;
+        if (m == 0) es0 = __builtin_amdgcn_permlane16_swap(pk[2 * j][e].x, pk[2 * j + 1][e].x, false, false);
+        else if (m == 1) es1 = __builtin_amdgcn_permlane16_swap(pk[2 * j][e].y, pk[2 * j + 1][e].y, false, false);
+        else if (m == 2) {
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)e_n * y_img, 0, (int)y_img, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)es0.x, (int)es1.x, (int)es0.y, (int)es1.y}, yr, e_v[j] + (unsigned)(r + e) * rowb, 0, 0);
+        }
+    };
+    auto epi_pack = [&](int par, int f) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) epi_pack_step(par, f, m);
+    };
+    auto epi_store = [&](int i, int r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) epi_store_step(i, r, m);
+    };
+    auto store_offsets = [&](int nn_, int x0_, int y0_) __attribute__((always_inline)) {
+        const bool inx = x0_ + px < p.W;
+        const unsigned pix = (unsigned)((y0_ + wv * RW) * p.W + x0_ + px);
+        const unsigned base = (pix * (unsigned)p.y0_pitch + (unsigned)p.y0_coff) * 2u;
+#pragma unroll
+        for (int j = 0; j < NT / 2; ++j) {
+            const int ch = (2 * j + (kq & 1)) * 16 + (kq >> 1) * 8;
+            e_v[j] = (inx && ch < p.cout_store) ? base + (unsigned)ch * 2u : OOB;
+        }
+        e_n = nn_;
+    };
+    for (int k = 0;; ++k) {
+        const int tn = tile_index(k + 1);
+        const bool more = tn >= 0;
+        int nn = 0, nx0 = 0, ny0 = 0;
+        if (more) tile_coords(tn, nn, nx0, ny0);
+        const char* sb = smem + (k & 1) * STAGE;
+        // B fragments: a ring of four (two rows each), read THREE groups ahead of their MFMAs; chunk 3's A fragments (NT = 4): a ring of two,
+        // read ONE group ahead.  Linear group index L = 20 rp + g over the tile's 40 groups
+        constexpr int AHEAD = 3;
+        i32x4 b[4][2];
+        i32x4 a3[2][NCR == NCH ? 1 : NT];
+        auto read_b = [&](int L) __attribute__((always_inline)) {
+            const int rp_ = L / NG, g_ = L % NG, c_ = g_ / PAIRS, q_ = g_ % PAIRS;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) b[L & 3][e] = *reinterpret_cast<const i32x4*>(sb + b_off[q_] + c_ * 32 + (2 * rp_ + e) * (TH * PIXB));
+        };
+        auto read_a = [&](int L) __attribute__((always_inline)) {
+            const int g_ = L % NG, c_ = g_ / PAIRS, q_ = g_ % PAIRS;
+            if (NCR < NCH && c_ >= NCR) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) a3[L & 1][NCR == NCH ? 0 : t] = *reinterpret_cast<const i32x4*>(w3 + (q_ * NT + t) * 1024);
+            }
+        };
+#pragma unroll
+        for (int L = 0; L < AHEAD; ++L) read_b(L);
+#pragma unroll
+        for (int rp = 0; rp < RW / 2; ++rp) {
+            const int par = rp & 1;
+            uint2 cen[NT][2];            // residual == input: the centre pixels of this pair's rows, 4 channels per tile
+            if (EXT && res_in) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) cen[t][e] = *reinterpret_cast<const uint2*>(sb + c_off + t * 32 + (2 * rp + e) * (TH * PIXB));
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int c = g / PAIRS, q = g % PAIRS, L = rp * NG + g, cs = L & 3;
+                if (L + AHEAD < (RW / 2) * NG) read_b(L + AHEAD);
+                if (L + 1 < (RW / 2) * NG) read_a(L + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if (c < NCR) {
+                            if (g == 0) {
+                                if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=v"(acc[par][t][e]) : "a"(wr[c < NCR ? c : 0][q][t]), "v"(b[cs][e]), "v"(bia[t]));
+                                else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=v"(acc[par][t][e]) : "a"(wr[c < NCR ? c : 0][q][t]), "v"(b[cs][e]), "v"(bia[t]));
+                            } else {
+                                if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "a"(wr[c < NCR ? c : 0][q][t]), "v"(b[cs][e]));
+                                else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "a"(wr[c < NCR ? c : 0][q][t]), "v"(b[cs][e]));
+                            }
+                        } else {
+                            if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "v"(a3[L & 1][NCR == NCH ? 0 : t]), "v"(b[cs][e]));
+                            else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "v"(a3[L & 1][NCR == NCH ? 0 : t]), "v"(b[cs][e]));
+                        }
+                        // the previous row pair's epilogue (rp == 0: the previous TILE's last pair), one micro-step behind each MFMA: its
+                        // accumulators were last written 20 groups ago
+                        // (the block's first tile: nothing is waiting, the steps run on whatever the registers hold and their stores are out of range)
+                        {
+                            const int m = 2 * t + e, r_prev = rp == 0 ? RW - 2 : 2 * rp - 2;
+                            if (g >= 1 && g <= 2 * NT) epi_pack_step(par ^ 1, g - 1, m);
+                            if (g >= 2 * NT + 1 && g < 2 * NT + 1 + SPP) epi_store_step(g - 2 * NT - 1, r_prev, m);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                if (rp == 0 && g < PPW) dma_piece(g, more, nn, nx0, ny0, (k + 1) & 1);      // the next tile's DMA, in the shadow of the matrix pipe
+                if (rp == 0 && g == NG - 1) store_offsets(n, x0, y0);              // (behind the previous tile's last store)
+                if (EXT && q == PAIRS - 1 && res_in && c < NT) {
+                    // conv_s16_kernel's order: act(conv(x) + x) adds the centre pixels of chunk c to channel tile c BEHIND chunk c's
+                    // groups.  The MFMAs above are asm: hipcc pads neither the read of their results (XDL write -> VALU read) nor the
+                    // next group's read of what is written here
+                    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) acc[par][c < NT ? c : 0][e] += unpack4<BF16>(cen[c < NT ? c : 0][e]);
+                    asm volatile("s_nop 3" ::: "memory");
+                }
+            }
+        }
+        // the next tile has landed: younger than its DMA are the stores of this tile's row pairs but the last
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RW / 2 - 1) * SPP) : "memory");
+        __builtin_amdgcn_s_barrier();
         if (!more) break;
         n = nn; x0 = nx0; y0 = ny0;
     }
@@ -1605,6 +1905,30 @@ int launch_conv48r(const S16K& k, hipStream_t st)
     return esr_check_launch("conv48r_kernel launch");
 }
 
+template <bool BF16, int NT, bool EXT>
+int launch_conv64r(const S16K& k, hipStream_t st)
+{
+    // [stage 0][stage 1 | the weight blob as staged, chunk 3 (NT = 4) resident behind stage 1]
+    constexpr int STAGE = 51 * 1024, BLOB = 4 * 5 * NT * 1024;
+    constexpr int LDS = STAGE + (BLOB > STAGE ? BLOB : STAGE);
+    static std::atomic<unsigned> attr_set[MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
+    if (!attr_set[dev].load(std::memory_order_relaxed)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64r_kernel<BF16, NT, EXT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            esr_set_err("hipFuncSetAttribute(conv64r_kernel, MaxDynamicSharedMemorySize)", e);
+            return ESR_ERR_LAUNCH;
+        }
+        attr_set[dev].store(1u, std::memory_order_relaxed);
+    }
+    const int ntiles = k.N * k.tiles_x * k.tiles_y;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    esr_note_kernel("conv64r_kernel<%s, %d, %s>", esr_tf(BF16), NT, esr_tf(EXT));
+    hipLaunchKernelGGL((conv64r_kernel<BF16, NT, EXT>), dim3(grid), dim3(256), LDS, st, k);
+    return esr_check_launch("conv64r_kernel launch");
+}
+
 template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 = 0, bool HILO = false>
 int launch_s16(const S16K& k, size_t lds, hipStream_t st)
 {
@@ -1705,6 +2029,18 @@ static bool conv48r_takes(const esr_conv_desc* d)
     return (long)d->n * ((d->w + TILE - 1) / TILE) * ((d->h + 31) / 32) >= 256;
 }
 
+// conv64r_kernel's descriptors: a 3x3 over 64 physical input channels with 2 or 4 output tiles, at least one 16 x 16 tile per CU, no
+// residual from HBM, no split, no post chain, no border table, NHWC, one input tensor
+static bool conv64r_takes(const esr_conv_desc* d)
+{
+    const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
+    if (d->ksize != 3 || nchunks != 4 || (nt != 2 && nt != 4) || d->out_layout != ESR_NHWC || d->in_seg_stride != 0 || d->post_wpacked || d->hilo || d->border_bias) return false;
+    if (d->act == ESR_ACT_GELU) return false;
+    if (d->res_mode != ESR_RES_NONE && !s16_res_is_input(d)) return false;
+    if (d->split > 0 && d->split < d->cout) return false;
+    return (long)d->n * ((d->w + TILE - 1) / TILE) * ((d->h + 15) / 16) >= 256;
+}
+
 int s16_post_plan(const esr_conv_desc* d, int nt, int nchunks, int* pnt1, int* pnt2, int* post_lo, int* ring, size_t* lds);
 
 // conv48rp_kernel's descriptors: RLFB's c3_r -- 48 -> 48 (3 chunks, 3 tiles) with a residual from HBM that is not the input, the conv's
@@ -1728,7 +2064,7 @@ static bool conv48rp_takes(const esr_conv_desc* d)
 // waves, 16 x 16 tiles), 8: one 8-wave block per CU on 16 x 32 tiles
 int s16_block_waves(const esr_conv_desc* d)
 {
-    if (conv48r_takes(d) || conv48rp_takes(d)) return 1;
+    if (conv48r_takes(d) || conv48rp_takes(d) || conv64r_takes(d)) return 1;
     const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
     const bool res_hbm = d->res_mode != ESR_RES_NONE && !s16_res_is_input(d);
     if (d->ksize != 3 || nt != 3 || d->border_bias || d->post_wpacked || res_hbm || d->out_layout != ESR_NHWC || d->in_seg_stride != 0 || d->hilo) return 8;
@@ -2132,6 +2468,18 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         const double nt_all = (double)d->n * kp.tiles_x * kp.tiles_y;
         if (nt_all * (kp.tiles_x > kp.tiles_y ? kp.tiles_x : kp.tiles_y) < 4294967296.0)
             return bf16 ? launch_conv48rp<true>(kp, st) : launch_conv48rp<false>(kp, st);
+    }
+    if (conv64r_takes(d)) {
+        S16K k4 = k;
+        k4.tiles_y = (d->h + 15) / 16;
+        k4.magic_y = k4.tiles_y > 1 ? (unsigned)((0x100000000ull + k4.tiles_y - 1) / k4.tiles_y) : 0u;
+        const double nt_all = (double)d->n * k4.tiles_x * k4.tiles_y;
+        if (nt_all * (k4.tiles_x > k4.tiles_y ? k4.tiles_x : k4.tiles_y) < 4294967296.0) {
+            const bool ext = k.res_in != 0;
+            if (nt == 2) return bf16 ? launch_conv64r<true, 2, true>(k4, st) : launch_conv64r<false, 2, true>(k4, st);
+            if (ext) return bf16 ? launch_conv64r<true, 4, true>(k4, st) : launch_conv64r<false, 4, true>(k4, st);
+            return bf16 ? launch_conv64r<true, 4, false>(k4, st) : launch_conv64r<false, 4, false>(k4, st);
+        }
     }
     if (conv48r_takes(d)) {
         // (a post chain stays on conv_s16_kernel: the PNT1 = 2 instantiation -- ESDB c{j}_r + the next distillation 1x1, two GELUs per

@@ -445,3 +445,53 @@ def test_s16_hilo_rejects_what_it_does_not_cover():
     x = torch.zeros(2, 1, 20, 20, 48, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(L.EsrError):                      # 1x1: not covered
         ops.conv2d(x, torch.zeros(48, 48, 1, 1), b, hilo=L.HILO_IN)
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,act,res_in,hw,n", [
+    (64, 64, 1, False, (128, 128), 4),       # plain, LeakyReLU
+    (50, 50, 1, True, (100, 77), 9),         # RFDB c{j}_r: lrelu(conv(x) + x), 50 logical channels in 64, ragged edges
+    (64, 32, 1, False, (128, 128), 5),       # RFDB c4: two output tiles
+    (50, 25, 1, False, (64, 250), 7),
+    (64, 64, 0, True, (128, 128), 4)])       # residual == input without activation
+def test_conv64r_equals_conv_s16(compute, cin, cout, act, res_in, hw, n):
+    """conv64r_kernel (3x3 over 64 physical input channels, >= 256 tiles of 16 x 16: 240 weight registers + chunk 3 from LDS, one wave per
+    SIMD, row pairs as the outer loop, 144-byte LDS pixels) against conv_s16_kernel: the batch takes the new kernel
+    (esr_conv_block_waves == 1), each image alone the old one (< 256 tiles), same packed weights -- bit-identical results, and both within
+    storage precision of the fp64 convolution."""
+    from ntire2022_esr_amd import ops, _lib as L
+    from ntire2022_esr_amd.engine import pack_conv_s16, unpack_conv_s16
+    dt = DT[compute]
+    g = torch.Generator().manual_seed(cin + cout + act + hw[0] + n)
+    cp = 64
+    x = torch.randn(n, cin, *hw, generator=g).to(dt)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    blob = pack_conv_s16(w, b, compute, cin_phys=cp).to(DEV)
+    xin = F.pad(_nhwc(x), (0, cp - cin)).to(DEV)
+    kw = dict(act=act, cin=cin, packed=blob)
+    if res_in:
+        kw.update(res=xin, res_mode=L.RES_PRE_ACT)
+    d = L.ConvDesc()
+    d.n, d.h, d.w, d.cin, d.cout, d.ksize = n, hw[0], hw[1], cin, cout, 3
+    d.in_layout = d.out_layout = L.NHWC
+    d.storage = L.STORE[compute]
+    assert L.lib().esr_conv_block_waves(ctypes.byref(d)) == 1
+    d.n = 1
+    assert L.lib().esr_conv_block_waves(ctypes.byref(d)) != 1
+    y = ops.conv2d(xin, w, b, **kw)
+    for i in range(n):
+        kw1 = dict(kw)
+        if res_in:
+            kw1["res"] = xin[i:i + 1]
+        y1 = ops.conv2d(xin[i:i + 1].contiguous(), w, b, **kw1)
+        assert torch.equal(y[i:i + 1], y1), i
+    weff, _ = unpack_conv_s16(blob.cpu(), cin, cout, 3, compute, cin_phys=cp)
+    conv = F.conv2d(x.double().to(DEV), weff.double().to(DEV), b.double().to(DEV), padding=1)
+    if res_in:
+        conv = conv + x.double().to(DEV)[:, :cout]
+    ref = ACTS[act](conv)
+    got = y.permute(0, 3, 1, 2)[:, :cout].double()
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    tol = ref.abs() * eps * 1.01 + (3e-4 if act == 3 else 5e-5) * max(1.0, float(ref.abs().max()))
+    assert int(((got - ref).abs() > tol).sum()) == 0

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
+#include <utility>
 #include <type_traits>
 
 #include "esr_internal.h"
@@ -39,6 +40,13 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
+
+// compile-time loops: the body sees its index as a constant expression (std::integral_constant) -- schedules written as `if constexpr`
+// chains do not depend on hipcc's unrolling heuristics (a loop it leaves rolled indexes registers dynamically: scratch)
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 constexpr int TILE = 16;            // output tile width (pixels) = one MFMA's pixel dimension
 constexpr int RING_MIN = 3, RING_MAX = 8;   // input stages in LDS (as many as fit next to the resident weights)
@@ -1438,11 +1446,11 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(const S16K p)
         int nn = 0, nx0 = 0, ny0 = 0;
         if (more) tile_coords(tn, nn, nx0, ny0);
         const char* sb = smem + (k & 1) * STAGE;
-        // B fragments: a ring of four (two rows each), read THREE groups ahead of their MFMAs; chunk 3's A fragments (NT = 4): a ring of two,
-        // read ONE group ahead.  Linear group index L = 20 rp + g over the tile's 40 groups
+        // B fragments: a ring of four (two rows each), read THREE groups ahead of their MFMAs; chunk 3's A fragments (NT = 4): a ring of three,
+        // read TWO groups ahead.  Linear group index L = 20 rp + g over the tile's 40 groups
         constexpr int AHEAD = 3;
         i32x4 b[4][2];
-        i32x4 a3[2][NCR == NCH ? 1 : NT];
+        i32x4 a3[3][NCR == NCH ? 1 : NT];
         auto read_b = [&](int L) __attribute__((always_inline)) {
             const int rp_ = L / NG, g_ = L % NG, c_ = g_ / PAIRS, q_ = g_ % PAIRS;
 #pragma unroll
@@ -1452,11 +1460,12 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(const S16K p)
             const int g_ = L % NG, c_ = g_ / PAIRS, q_ = g_ % PAIRS;
             if (NCR < NCH && c_ >= NCR) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) a3[L & 1][NCR == NCH ? 0 : t] = *reinterpret_cast<const i32x4*>(w3 + (q_ * NT + t) * 1024);
+                for (int t = 0; t < NT; ++t) a3[L % 3][NCR == NCH ? 0 : t] = *reinterpret_cast<const i32x4*>(w3 + (q_ * NT + t) * 1024);
             }
         };
 #pragma unroll
         for (int L = 0; L < AHEAD; ++L) read_b(L);
+        read_a(0); read_a(1);                  // (no-ops: the first chunk-3 group is L = 15)
 #pragma unroll
         for (int rp = 0; rp < RW / 2; ++rp) {
             const int par = rp & 1;
@@ -1471,7 +1480,7 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(const S16K p)
             for (int g = 0; g < NG; ++g) {
                 const int c = g / PAIRS, q = g % PAIRS, L = rp * NG + g, cs = L & 3;
                 if (L + AHEAD < (RW / 2) * NG) read_b(L + AHEAD);
-                if (L + 1 < (RW / 2) * NG) read_a(L + 1);
+                if (L + 2 < (RW / 2) * NG) read_a(L + 2);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
@@ -1486,8 +1495,8 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(const S16K p)
                                 else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "a"(wr[c < NCR ? c : 0][q][t]), "v"(b[cs][e]));
                             }
                         } else {
-                            if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "v"(a3[L & 1][NCR == NCH ? 0 : t]), "v"(b[cs][e]));
-                            else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "v"(a3[L & 1][NCR == NCH ? 0 : t]), "v"(b[cs][e]));
+                            if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "v"(a3[L % 3][NCR == NCH ? 0 : t]), "v"(b[cs][e]));
+                            else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "v"(a3[L % 3][NCR == NCH ? 0 : t]), "v"(b[cs][e]));
                         }
                         // the previous row pair's epilogue (rp == 0: the previous TILE's last pair), one micro-step behind each MFMA: its
                         // accumulators were last written 20 groups ago
@@ -1560,7 +1569,7 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
     const int px = lane & 15, kq = lane >> 4;
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     constexpr bool plo = BF16;                    // bf16: hi + lo post images (the host takes this kernel only when conv_s16_kernel would use them too)
-    const bool res_post = p.res_mode == ESR_RES_POST_ACT;
+    constexpr bool res_post = true;               // act(conv) + residual: the only order the host sends here (RLFB, team04_rlfn.py:117-119)
 
     // ---- prologue: conv weights through the (still unused) residual stages into registers, post images to their place ----------
     constexpr int WPIECES = NCH * PAIRS * NT;      // 45 KB <= slot 1 (55 KB), free until the first tile's DMA issue for the second tile
@@ -1652,20 +1661,6 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
         b_off[q] = ((wv * RW + tap / 3) * TH + px + tap % 3) * PIXB + (kq & 1) * 16;
     }
     const int r_off = ((wv * RW) * 16 + px) * PIXB + kq * 8;                 // residual of row 0 of the wave: channels 16 t + 4 kq .. at + 32 t
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 {
-        const u32x2 a = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
-        const u32x2 b = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
-        return i32x4{(int)a.x, (int)b.x, (int)a.y, (int)b.y};
-    };
-    auto hilo = [&](f32x4 v) __attribute__((always_inline)) -> i32x4 {
-        const unsigned h0 = pack2<BF16>(v.x, v.y), h1 = pack2<BF16>(v.z, v.w);
-        if (!BF16) return i32x4{(int)h0, (int)h1, 0, 0};
-        float a, b, c, d;
-        unpack2<BF16>(h0, a, b);
-        unpack2<BF16>(h1, c, d);
-        return i32x4{(int)h0, (int)h1, (int)pack2<BF16>(v.x - a, v.y - b), (int)pack2<BF16>(v.z - c, v.w - d)};
-    };
     const float slope = p.slope, p1s = p.p1_slope;
     const size_t p1_img = (size_t)p.H * p.W * p.py1_pitch * 2, p2_img = (size_t)p.H * p.W * p.py2_pitch * 2;
     const unsigned rowb1 = (unsigned)p.W * (unsigned)p.py1_pitch * 2u, rowb2 = (unsigned)p.W * (unsigned)p.py2_pitch * 2u;
@@ -1678,21 +1673,41 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
     auto PK2 = [&](int e) __attribute__((always_inline)) -> uint2& { return e ? z1 : z0; };
     unsigned e_vA = OOB, e_vB = OOB, e_v2 = OOB;
     int e_n = 0, e_slot = 0;             // image / residual stage of the tile whose epilogue is in flight
-    auto epi_res = [&](int par, int f, int r) __attribute__((always_inline)) {   // fragment f = 2 t + e of the finished pair (first row r)
+    // ---- the finished pair's epilogue as MICRO-STEPS (round 4) ---------------------------------------------------------------------
+    // One wave per SIMD issues in order: VALU work placed as a clump behind a group's MFMAs runs while the matrix pipe idles, and this
+    // epilogue is ~350 VALU instructions + 36 (fp16: 18) post MFMAs per row pair against the pair's 90 convolution MFMAs.  It is cut
+    // into steps of <= ~10 VALU instructions (or one LDS read set, or one post MFMA), one or two behind EACH convolution MFMA of the next
+    // pair (slot s = 6 g + 2 t + e, 0 .. 89): an MFMA occupies the pipe for 16 cycles, an independent VALU instruction issues in 4.
+    // Per accumulator the order of operations is unchanged (conv_s16_kernel's: k tiles ascending, hi then lo): results stay bit-identical.
+    uint2 rraw[4];                       // residual fragments on their way from LDS (ring of four: fragment f + 3 is read while f is applied)
+    i32x4 bsv[2][2];                     // [k tile & 1][row]: the fp32 fragment as the post 1x1's B operand (hi parts | lo parts)
+    i32x4 pa[2][6];                      // post A fragments: [buffer][2 ot + lo] (post 1) / [lo][kt] (post 2)
+    f32x4 d1[PNT1][2], d2[2];
+    auto rd = [&](int f, int r) __attribute__((always_inline)) {
         const int t = f >> 1, e = f & 1;
-        f32x4 v = acc[par][t][e];
-        const f32x4 rf = unpack4<BF16>(*reinterpret_cast<const uint2*>(smem + e_slot * SLOT + STAGE + r_off + t * 32 + (r + e) * (16 * PIXB)));
-        if (!res_post) v += rf;
-        v.x = act1(v.x, slope); v.y = act1(v.y, slope); v.z = act1(v.z, slope); v.w = act1(v.w, slope);
-        if (res_post) v += rf;
-        acc[par][t][e] = v;
+        rraw[f & 3] = *reinterpret_cast<const uint2*>(smem + e_slot * SLOT + STAGE + r_off + t * 32 + (r + e) * (16 * PIXB));
     };
-    // The post chain of a finished pair, BOTH rows at once and one k tile per MFMA group: the A fragments (LDS) of k tile kt + 1 are read
-    // while k tile kt is multiplied and serve both rows.  (First version: row by row, every fragment read right in front of its MFMA --
-    // with one wave per SIMD nothing hides the ~130 cycles of an LDS read: the chain's 48 MFMAs cost 0.15 ms of a 0.28 ms launch, more than
-    // the convolution's 90.)  Per accumulator the order of MFMAs is conv_s16_kernel's: k tiles ascending, hi then lo.
-    i32x4 pa[2][6];                      // [buffer][2 ot + lo] (post 1) / [lo][kt] (post 2)
-    f32x4 d1[PNT1][2];
+    auto ra = [&](int par, int f, int h) __attribute__((always_inline)) {        // half h of fragment f: + residual, activation (in the pair's accumulators)
+        const int t = f >> 1, e = f & 1;
+        float ra_, rb_;
+        unpack2<BF16>(h ? rraw[f & 3].y : rraw[f & 3].x, ra_, rb_);
+        float va = h ? acc[par][t][e].z : acc[par][t][e].x, vb = h ? acc[par][t][e].w : acc[par][t][e].y;
+        if (!res_post) { va += ra_; vb += rb_; }
+        va = act1(va, slope); vb = act1(vb, slope);
+        if (res_post) { va += ra_; vb += rb_; }
+        if (h) { acc[par][t][e].z = va; acc[par][t][e].w = vb; } else { acc[par][t][e].x = va; acc[par][t][e].y = vb; }
+    };
+    auto hl = [&](i32x4& o, f32x4 v, int h) __attribute__((always_inline)) {     // the fp32 fragment as a B operand: h = 0 high parts, h = 1 low parts (bf16)
+        if (h == 0) {
+            o.x = (int)pack2<BF16>(v.x, v.y); o.y = (int)pack2<BF16>(v.z, v.w);
+            if (!BF16) { o.z = 0; o.w = 0; }
+        } else if (BF16) {
+            float a, b, c, d;
+            unpack2<BF16>((unsigned)o.x, a, b);
+            unpack2<BF16>((unsigned)o.y, c, d);
+            o.z = (int)pack2<BF16>(v.x - a, v.y - b); o.w = (int)pack2<BF16>(v.z - c, v.w - d);
+        }
+    };
     auto load_p1 = [&](int kt, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int ot = 0; ot < PNT1; ++ot) {
@@ -1700,33 +1715,21 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
             if (plo) pa[buf][2 * ot + 1] = *reinterpret_cast<const i32x4*>(img1 + P1_IMG + (kt * PNT1 + ot) * 1024);
         }
     };
-    auto post1_step = [&](int par, int kt, int buf) __attribute__((always_inline)) {
-        i32x4 bsv[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) bsv[e] = hilo(acc[par][kt][e]);
-        // (the six hi MFMAs, then the six lo ones: a lo MFMA depends on the hi one of its accumulator)
-#pragma unroll
-        for (int ot = 0; ot < PNT1; ++ot)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) d1[ot][e] = mfma32<BF16>(pa[buf][2 * ot], bsv[e], kt == 0 ? pb1[ot] : d1[ot][e]);
-        if (plo) {
-#pragma unroll
-            for (int ot = 0; ot < PNT1; ++ot)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) d1[ot][e] = mfma32<BF16>(pa[buf][2 * ot + 1], bsv[e], d1[ot][e]);
-        }
+    auto pm1 = [&](int kt, int i) __attribute__((always_inline)) {               // post-1 MFMA i of k tile kt: i = 0 .. 5 high images (ot, e), 6 .. 11 low images
+        const int lo = i / 6, ot = (i % 6) >> 1, e = i & 1;
+        if (lo && !plo) return;
+        d1[ot][e] = mfma32<BF16>(pa[kt & 1][2 * ot + lo], bsv[kt & 1][e], (kt == 0 && !lo) ? pb1[ot] : d1[ot][e]);
     };
-    auto post1_fin = [&](int par) __attribute__((always_inline)) {              // c5's result: fp32 back into the pair's accumulators, rounded into PK1
-#pragma unroll
-        for (int ot = 0; ot < PNT1; ++ot)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                f32x4 v = d1[ot][e];
-                v.x = act1(v.x, p1s); v.y = act1(v.y, p1s); v.z = act1(v.z, p1s); v.w = act1(v.w, p1s);
-                acc[par][ot][e] = v;
-                PK1(ot, e).x = pack2<BF16>(v.x, v.y);
-                PK1(ot, e).y = pack2<BF16>(v.z, v.w);
-            }
+    auto fin = [&](int par, int ot, int e, int h) __attribute__((always_inline)) {   // c5's result: activation, fp32 back into the pair's accumulators, rounded into PK1
+        if (h == 0) {
+            f32x4 v = d1[ot][e];
+            v.x = act1(v.x, p1s); v.y = act1(v.y, p1s); v.z = act1(v.z, p1s); v.w = act1(v.w, p1s);
+            acc[par][ot][e] = v;
+        } else {
+            const f32x4 v = acc[par][ot][e];
+            PK1(ot, e).x = pack2<BF16>(v.x, v.y);
+            PK1(ot, e).y = pack2<BF16>(v.z, v.w);
+        }
     };
     auto load_p2 = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -1735,29 +1738,62 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
             if (plo) pa[1][kt] = *reinterpret_cast<const i32x4*>(img2 + P2_IMG + kt * 1024);
         }
     };
-    auto post2_both = [&](int par) __attribute__((always_inline)) {             // esa.conv1 on c5's fp32 result, both rows
-        f32x4 d2[2] = {pb2, pb2};
-#pragma unroll
-        for (int kt = 0; kt < PNT1; ++kt)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const i32x4 bsv = hilo(acc[par][kt][e]);
-                d2[e] = mfma32<BF16>(pa[0][kt], bsv, d2[e]);
-                if (plo) d2[e] = mfma32<BF16>(pa[1][kt], bsv, d2[e]);
+    auto pm2 = [&](int kt, int i) __attribute__((always_inline)) {               // post-2 MFMA i of k tile kt: (e, lo) = (i >> 1, i & 1)
+        const int e = i >> 1, lo = i & 1;
+        if (lo && !plo) return;
+        d2[e] = mfma32<BF16>(pa[lo][kt], bsv[kt & 1][e], (kt == 0 && !lo) ? pb2 : d2[e]);
+    };
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 es0 = {0u, 0u}, es1 = {0u, 0u};
+    auto st = [&](int i, int r, int h) __attribute__((always_inline)) {          // store i of the pair (first row r): two swaps, then the store
+        uint2 X = i == 0 ? q00 : (i == 1 ? q01 : (i == 2 ? q20 : z0)), Y = i == 0 ? q10 : (i == 1 ? q11 : (i == 2 ? q21 : z1));
+        if (h == 0) es0 = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
+        else if (h == 1) es1 = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
+        else {
+            const i32x4 o = i32x4{(int)es0.x, (int)es1.x, (int)es0.y, (int)es1.y};
+            if (i < 3) {
+                const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(p.py1 + (size_t)e_n * p1_img, 0, (int)p1_img, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(o, r1, (i < 2 ? e_vA + (unsigned)(r + i) * rowb1 : e_vB + (unsigned)r * rowb1), 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(o, __builtin_amdgcn_make_buffer_rsrc(p.py2 + (size_t)e_n * p2_img, 0, (int)p2_img, 0x00020000),
+                                                       e_v2 + (unsigned)r * rowb2, 0, 0);
             }
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            PK2(e).x = pack2<BF16>(d2[e].x, d2[e].y);
-            PK2(e).y = pack2<BF16>(d2[e].z, d2[e].w);
         }
     };
-    auto epi_store = [&](int i, int r) __attribute__((always_inline)) {           // the pair's four stores
-        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(p.py1 + (size_t)e_n * p1_img, 0, (int)p1_img, 0x00020000);
-        if (i == 0) __builtin_amdgcn_raw_buffer_store_b128(swap16(q00, q10), r1, e_vA + (unsigned)r * rowb1, 0, 0);
-        else if (i == 1) __builtin_amdgcn_raw_buffer_store_b128(swap16(q01, q11), r1, e_vA + (unsigned)(r + 1) * rowb1, 0, 0);
-        else if (i == 2) __builtin_amdgcn_raw_buffer_store_b128(swap16(q20, q21), r1, e_vB + (unsigned)r * rowb1, 0, 0);
-        else __builtin_amdgcn_raw_buffer_store_b128(swap16(z0, z1), __builtin_amdgcn_make_buffer_rsrc(p.py2 + (size_t)e_n * p2_img, 0, (int)p2_img, 0x00020000),
-                                                    e_v2 + (unsigned)r * rowb2, 0, 0);
+    // the schedule: what runs behind convolution MFMA s of the next pair (par = the FINISHED pair's accumulators, first row r)
+    auto micro = [&](auto par_, auto r_, auto s_) __attribute__((always_inline)) {
+        constexpr int par = decltype(par_)::value, r = decltype(r_)::value, s = decltype(s_)::value;
+        // 0 .. 17: the residual: fragment f is read at slot 2 f and applied in slots 2 f + 6, 2 f + 7
+        if constexpr (s >= 6 && s < 18) ra(par, (s - 6) >> 1, (s - 6) & 1);
+        if constexpr (s < 12 && (s & 1) == 0) rd(s >> 1, r);
+        if constexpr (s == 12) load_p1(0, 0);
+        // 18 .. 59: post 1: the B operands of k tile 0 in slots 18 .. 21, of k tile kt > 0 beside the MFMAs of k tile kt - 1 (26 + 12 (kt - 1) ..);
+        // the 12 MFMAs of k tile kt in slots 24 + 12 kt ..
+        static_for<PNT1>([&](auto kt_) __attribute__((always_inline)) {
+            constexpr int kt = decltype(kt_)::value;
+            constexpr int h0 = kt == 0 ? 18 : 24 + 12 * (kt - 1) + 2;
+            if constexpr (s >= h0 && s < h0 + 4) hl(bsv[kt & 1][(s - h0) >> 1], acc[par][kt][(s - h0) >> 1], (s - h0) & 1);
+            constexpr int m0 = 24 + 12 * kt;
+            if constexpr (s >= m0 && s < m0 + 12) pm1(kt, s - m0);
+            if constexpr (kt + 1 < PNT1 && s == m0 + 6) load_p1(kt + 1, (kt + 1) & 1);     // (buffer (kt + 1) & 1 was last read by k tile kt - 1)
+        });
+        if constexpr (s == 60) load_p2();
+        // 60 .. 71: c5's result (ot, e) in slots 60 + 4 ot + 2 e, + 1;  its B operand for post 2 one out tile later;  post 2's MFMAs
+        // (k tile kt, 4 each) in 72 + 4 kt ..;  stores: PK1's from slot 76 on (three slots each), PK2's at the end
+        if constexpr (s >= 60 && s < 72) fin(par, (s - 60) >> 2, ((s - 60) >> 1) & 1, (s - 60) & 1);
+        // (k tile 2 shares its B buffer with k tile 0: its operands follow k tile 0's MFMAs, slots 76 .. 79)
+        if constexpr (s >= 64 && s < 72) hl(bsv[((s - 64) >> 2) & 1][((s - 64) >> 1) & 1], acc[par][(s - 64) >> 2][((s - 64) >> 1) & 1], (s - 64) & 1);
+        if constexpr (s >= 76 && s < 80) hl(bsv[0][((s - 76) >> 1) & 1], acc[par][2][((s - 76) >> 1) & 1], (s - 76) & 1);
+        if constexpr (s >= 72 && s < 84) pm2((s - 72) >> 2, (s - 72) & 3);
+        if constexpr (s >= 76 && s < 85) st((s - 76) / 3, r, (s - 76) % 3);
+        if constexpr (s == 85) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                PK2(e).x = pack2<BF16>(d2[e].x, d2[e].y);
+                PK2(e).y = pack2<BF16>(d2[e].z, d2[e].w);
+            }
+        }
+        if constexpr (s >= 87 && s < 90) st(3, r, s - 87);
     };
     auto store_offsets = [&](int nn_, int x0_, int y0_, int slot_) __attribute__((always_inline)) {
         const bool inx = x0_ + px < p.W;
@@ -1769,7 +1805,6 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
         e_v2 = (inx && ch2 < p.p2_cout8) ? b2 + (unsigned)ch2 * 2u + ((kq & 1) ? rowb2 : 0u) : OOB;
         e_n = nn_; e_slot = slot_;
     };
-    bool pend = false;
     for (int k = 0;; ++k) {
         const int tn = tile_index(k + 1);
         const bool more = tn >= 0;
@@ -1790,15 +1825,17 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
         auto run_pair = [&](auto rp_tag) __attribute__((always_inline)) {
             constexpr int rp = decltype(rp_tag)::value;
             constexpr int par = rp & 1;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int c = g / PAIRS, q = g % PAIRS, L = rp * NG + g, cs = L & 3;
-                if (L + AHEAD < (RW / 2) * NG) read_b(L + AHEAD);
+            // this tile's store offsets and residual stage: behind the carried epilogue's last store (first pair, slot 89), ahead of the
+            // first step of this tile's own epilogue (the residual reads of slot 0)
+            if constexpr (rp == 1) store_offsets(n, x0, y0, k & 1);
+            static_for<NG>([&](auto g_) __attribute__((always_inline)) {
+                constexpr int g = decltype(g_)::value;
+                constexpr int c = g / PAIRS, q = g % PAIRS, L = rp * NG + g, cs = L & 3;
+                if constexpr (L + AHEAD < (RW / 2) * NG) read_b(L + AHEAD);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
+                static_for<2 * NT>([&](auto m_) __attribute__((always_inline)) {
+                    constexpr int t = decltype(m_)::value >> 1, e = decltype(m_)::value & 1;
+                    {
                         if (g == 0) {
                             if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=v"(acc[par][t][e]) : "a"(wr[c][q][t]), "v"(b[cs][e]), "v"(bia[t]));
                             else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=v"(acc[par][t][e]) : "a"(wr[c][q][t]), "v"(b[cs][e]), "v"(bia[t]));
@@ -1806,7 +1843,12 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
                             if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "a"(wr[c][q][t]), "v"(b[cs][e]));
                             else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "a"(wr[c][q][t]), "v"(b[cs][e]));
                         }
+                        // the finished pair's epilogue (rp == 0: the previous TILE's last pair), one step behind each MFMA.  (The block's first
+                        // tile: nothing is waiting, the steps run on whatever the registers hold and their stores are out of range.)
+                        micro(std::integral_constant<int, par ^ 1>{}, std::integral_constant<int, (rp == 0 ? RW - 2 : 2 * rp - 2)>{}, std::integral_constant<int, 6 * g + 2 * t + e>{});
+                        __builtin_amdgcn_sched_barrier(0);
                     }
+                });
                 // the next tile's DMA in the first pair: input pieces first, the wave's residual rows behind the groups (1 .. 6) in which the
                 // carried epilogue reads the residual stage they overwrite
                 if (rp == 0 && 2 * g < IPW) {
@@ -1814,48 +1856,20 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
                     if (2 * g + 1 < IPW) dma_in(2 * g + 1, more, nn, nx0, ny0, (k + 1) & 1);
                 }
                 if (rp == 0 && g >= 7 && g < 7 + RPW) dma_res(g - 7, more, nn, nx0, ny0, (k + 1) & 1);
-                if (rp > 0 || pend) {
-                    const int r_prev = rp == 0 ? RW - 2 : 2 * rp - 2;
-                    if (g >= 1 && g <= 6) epi_res(par ^ 1, g - 1, r_prev);
-                    if (g == 6) load_p1(0, 0);
-                    if (g >= 7 && g <= 9) {
-                        if (g < 9) load_p1(g - 6, (g - 6) & 1);
-                        post1_step(par ^ 1, g - 7, (g - 7) & 1);
-                    }
-                    if (g == 10) { post1_fin(par ^ 1); load_p2(); }
-                    if (g == 11) post2_both(par ^ 1);
-                    if (g == 12) { epi_store(0, r_prev); epi_store(1, r_prev); }
-                    if (g >= 13) epi_store(g - 11, r_prev);
-                }
-                if (rp == 1 && g == 0) store_offsets(n, x0, y0, k & 1);            // (behind the carried epilogue's last store, ahead of this tile's first)
-            }
+            });
         };
         run_pair(std::integral_constant<int, 0>{});
         run_pair(std::integral_constant<int, 1>{});
         // the next tile's stages have landed: younger than their last DMA piece (group 12 of the first pair) are the carried epilogue's
         // four stores (groups 12 - 14) and the four stores of this tile's first pair
-        if (pend) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        pend = true;
         if (!more) break;
         n = nn; x0 = nx0; y0 = ny0;
     }
-    // the last tile's last pair (its residual stage: e_slot)
+    // the last tile's last pair (its residual stage: e_slot): the same steps, back to back
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-#pragma unroll
-    for (int f = 0; f < 2 * NT; ++f) epi_res(1, f, RW - 2);
-    load_p1(0, 0);
-#pragma unroll
-    for (int kt = 0; kt < PNT1; ++kt) {
-        if (kt + 1 < PNT1) load_p1(kt + 1, (kt + 1) & 1);
-        post1_step(1, kt, kt & 1);
-    }
-    post1_fin(1);
-    load_p2();
-    post2_both(1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) epi_store(i, RW - 2);
+    static_for<90>([&](auto s_) __attribute__((always_inline)) { micro(std::integral_constant<int, 1>{}, std::integral_constant<int, RW - 2>{}, s_); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -2051,7 +2065,7 @@ static bool conv48rp_takes(const esr_conv_desc* d)
     const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
     if (d->ksize != 3 || nchunks != 3 || nt != 3 || d->out_layout != ESR_NHWC || d->in_seg_stride != 0 || !d->post_wpacked || !d->post2_wpacked) return false;
     if (d->out0.ptr || d->border_bias || d->act == ESR_ACT_GELU || d->post_act == ESR_ACT_GELU) return false;
-    if (d->res_mode == ESR_RES_NONE || s16_res_is_input(d)) return false;
+    if (d->res_mode != ESR_RES_POST_ACT || s16_res_is_input(d)) return false;
     int pnt1 = 0, pnt2 = 0, post_lo = 0, ring = 0;
     size_t lds = 0;
     if (s16_post_plan(d, nt, nchunks, &pnt1, &pnt2, &post_lo, &ring, &lds) != ESR_OK) return false;

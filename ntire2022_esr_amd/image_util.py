@@ -31,11 +31,30 @@ def mkdirs(paths):
 
 
 def imread_uint(path, n_channels=3):
-    """HxWx3 uint8 RGB (gray images become GGG), or HxWx1 for n_channels=1."""
+    """utils_image.imread_uint (utils/utils_image.py:122-134) with PIL in place of cv2.
+
+    n_channels = 3: `cv2.imread(path, IMREAD_UNCHANGED)`, then GRAY2RGB for a 2-D result, BGR2RGB otherwise -- HxWx3 RGB; a gray image
+    becomes GGG; a palette is expanded; an alpha channel (RGBA, gray + alpha, palette + tRNS) is DROPPED, not composited (cvtColor's
+    4 -> 3 channel form); a 1-bit image is 0 / 255; a 16-bit gray image stays uint16 (IMREAD_UNCHANGED keeps the depth, the reference then
+    divides by 255 like any other input -- restated, not fixed).  16-bit RGB(A) PNGs would come back as uint16 from cv2; PIL can only
+    decode them to 8 bits, so they raise instead of silently differing.
+    n_channels = 1: `cv2.imread(path, 0)` -- HxWx1 gray (colour images: PIL's ITU-R 601 luma; libpng's conversion inside cv2 may differ
+    by one level on some pixels: PARITY-UNPINNED, the path never takes this branch, test_demo.py:419)."""
     img = Image.open(path)
+    raw = img.tile[0][3] if getattr(img, "tile", None) and isinstance(img.tile[0][3], str) else ""
     if n_channels == 1:
         return np.expand_dims(np.array(img.convert("L")), axis=2)
-    if img.mode in ("L", "1", "I;16", "I"):
+    if n_channels != 3:
+        raise ValueError("n_channels must be 1 or 3")
+    if img.mode in ("I;16", "I;16B", "I;16L", "I"):
+        g = np.array(img)
+        if g.min() < 0 or g.max() > 65535:
+            raise NotImplementedError(f"{path}: 32-bit integer image")
+        g = g.astype(np.uint16)
+        return np.stack([g, g, g], axis=2)
+    if "16" in raw and img.mode in ("RGB", "RGBA"):
+        raise NotImplementedError(f"{path}: 16-bit RGB PNG (cv2.IMREAD_UNCHANGED returns uint16; PIL decodes 8 bits only)")
+    if img.mode in ("L", "1"):
         g = np.array(img.convert("L"))
         return np.stack([g, g, g], axis=2)
     return np.array(img.convert("RGB"))

@@ -38,6 +38,54 @@ def test_image_util_matches_reference_pins():
         util.modcrop(np.zeros((2, 2, 2, 2)), 4)
 
 
+def test_imread_uint_cv2_edge_cases(tmp_path):
+    """imread_uint's restatement of cv2.imread(IMREAD_UNCHANGED) + cvtColor (utils/utils_image.py:122-134) on the inputs a DIV2K-style
+    folder can contain besides 8-bit RGB: palette, alpha, gray + alpha, 1-bit, 16-bit gray (depth kept), 16-bit RGB (refused)."""
+    from PIL import Image
+    from ntire2022_esr_amd import image_util as util
+    rng = np.random.default_rng(5)
+    rgb = rng.integers(0, 256, (9, 11, 3), dtype=np.uint8)
+    # palette (with and without tRNS): expanded to RGB, transparency ignored
+    pal = Image.fromarray(rgb).quantize(16)
+    pal.save(tmp_path / "p.png")
+    assert np.array_equal(util.imread_uint(str(tmp_path / "p.png")), np.array(pal.convert("RGB")))
+    pal.save(tmp_path / "pt.png", transparency=3)
+    assert np.array_equal(util.imread_uint(str(tmp_path / "pt.png")), np.array(pal.convert("RGB")))
+    # RGBA: alpha dropped, colours NOT composited
+    a = rng.integers(0, 256, (9, 11, 1), dtype=np.uint8)
+    Image.fromarray(np.concatenate([rgb, a], axis=2), "RGBA").save(tmp_path / "rgba.png")
+    assert np.array_equal(util.imread_uint(str(tmp_path / "rgba.png")), rgb)
+    # gray + alpha: GGG
+    g = rng.integers(0, 256, (9, 11), dtype=np.uint8)
+    Image.fromarray(np.stack([g, a[..., 0]], axis=2), "LA").save(tmp_path / "la.png")
+    assert np.array_equal(util.imread_uint(str(tmp_path / "la.png")), np.stack([g, g, g], axis=2))
+    # 1-bit: 0 / 255
+    b = (g > 127)
+    Image.fromarray(b).save(tmp_path / "b.png")
+    assert Image.open(tmp_path / "b.png").mode == "1"
+    assert np.array_equal(util.imread_uint(str(tmp_path / "b.png")), np.stack([b * np.uint8(255)] * 3, axis=2))
+    # 16-bit gray: uint16 kept (IMREAD_UNCHANGED), GGG
+    g16 = rng.integers(0, 65536, (9, 11), dtype=np.uint16)
+    Image.fromarray(g16).save(tmp_path / "g16.png")
+    r = util.imread_uint(str(tmp_path / "g16.png"))
+    assert r.dtype == np.uint16 and np.array_equal(r, np.stack([g16, g16, g16], axis=2))
+    assert util.imread_uint(str(tmp_path / "g16.png"), 1).shape == (9, 11, 1)
+    # 16-bit RGB: cv2 would return uint16; refused rather than truncated (a hand-made 2 x 1 PNG: PIL cannot write the format)
+    import struct, zlib
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    raw = b"".join(b"\x00" + struct.pack(">6H", 1000, 2000, 3000, 40000, 50000, 60000) for _ in range(1))
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 2, 1, 16, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+    (tmp_path / "rgb16.png").write_bytes(png)
+    with pytest.raises(NotImplementedError):
+        util.imread_uint(str(tmp_path / "rgb16.png"))
+    with pytest.raises(ValueError):
+        util.imread_uint(str(tmp_path / "p.png"), 4)
+    # imsave: squeezes HxWx1, writes what imread_uint reads back (utils_image.py:137-141)
+    util.imsave(g[..., None], str(tmp_path / "sub" / "g.png"))
+    assert np.array_equal(util.imread_uint(str(tmp_path / "sub" / "g.png"), 1)[..., 0], g)
+
+
 def test_imread_imsave_roundtrip(tmp_path):
     img = np.random.RandomState(0).randint(0, 256, (13, 17, 3)).astype(np.uint8)
     p = str(tmp_path / "sub" / "x.png")

@@ -305,7 +305,12 @@ def test_block_shape_query_cpu():
     assert waves(32, 256, 256, 48, 24, store="bf16") == 1 and waves(2, 256, 256, 48, 48, store="f16") == 1     # two output tiles; exactly 256 tiles
     assert waves(1, 256, 256, 48, 48, store="bf16") == 8 and waves(32, 256, 256, 32, 48, store="bf16") == 4     # 128 tiles; two input chunks (the two-blocks-per-CU shape)
     assert waves(1, 128, 128, 48, 48, store="bf16") == 8                        # 64 tiles: fewer than resident blocks
-    assert waves(32, 256, 256, 64, 64, store="bf16") == 8                        # 74 KB of weights: one block per CU
+    # round 4: the plain 64-channel 3x3 with 2 or 4 output tiles and >= 256 tiles of 16 x 16 takes conv64r_kernel (1); GELU, a split store,
+    # three output tiles or fewer tiles stay on conv_s16_kernel's 8-wave block (74 KB of weights: one block per CU)
+    assert waves(32, 256, 256, 64, 64, store="bf16") == 1 and waves(1, 339, 510, 50, 25, store="f16") == 1
+    assert waves(32, 256, 256, 64, 64, store="bf16", act=L.ACT_GELU) == 8 and waves(32, 256, 256, 64, 64, store="bf16", split=16) == 8
+    assert waves(32, 256, 256, 64, 48, store="bf16") == 8 and waves(1, 128, 128, 64, 64, store="bf16") == 8
+    assert waves(32, 256, 256, 48, 48, store="bf16", hilo=L.HILO_OUT) == 8      # hi + lo pairs: conv_s16_kernel's HILO instantiation
     assert waves(32, 256, 256, 48, 48, k=1, store="bf16") == 8
     assert waves(32, 256, 256, 48, 48, store="bf16", res_mode=L.RES_POST_ACT) == 8          # residual from HBM
     assert waves(32, 256, 256, 48, 48, store="bf16", out_layout=L.NCHW_SHUFFLE4) == 8

@@ -1547,7 +1547,12 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(const S16K p)
 //   * the post images (18 + 6 KB, hi + lo for bf16) are resident in LDS; the chain runs row by row on the fp32 values exactly as
 //     conv_s16_kernel's swap_epi_act does (same order of MFMAs: results are bit-identical);
 //   * per tile and wave 8 + 6 DMA pieces in the first pair's groups, four stores per pair; the tile closes with ONE counted wait.
-template <bool BF16>
+// LRS (round 4): the same kernel as the LR conv of a 48-channel network in bf16 -- `out_lr = LR_conv(body) + out_fea` (team04_rlfn.py:149) with
+// `out_fea` and `out_lr` as hi + lo pairs (esr_conv_desc.hilo = RES | OUT): the residual stage holds the wave's own rows of BOTH tensors
+// (2 x 24 KB, 12 pieces per wave), (conv + hi) + lo in conv_s16_kernel's order, then the activation, the result rounded to hi and
+// bf16(v - hi) and stored as six stores per row pair; no post chain.  On conv_s16_kernel the residual pair was six extra stages per tile
+// (0.26 ms at batch 32, 42 us on one image -- more than any other launch of RLFN).
+template <bool BF16, bool LRS = false>
 __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
 {
     constexpr int NT = 3, NCH = 3, PAIRS = 5, TH = 18, THY = 18, RW = 4, PNT1 = 3;
@@ -1555,13 +1560,15 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
     constexpr int NSLOT = TH * THY * (PIXB / 16);  // 1944
     constexpr int NPIECES = (NSLOT + 63) / 64;     // 31
     constexpr int STAGE = NPIECES * 1024;          // 31 744
-    constexpr int RSTAGE = 16 * 16 * PIXB;         // 24 576: the tile's own pixels of the residual, [row][px][96 B]
-    constexpr int RPW = RSTAGE / 4 / 1024;         // 6 pieces per wave: its own four rows
+    constexpr int RTEN = 16 * 16 * PIXB;           // 24 576: the tile's own pixels of a residual tensor, [row][px][96 B]
+    constexpr int RSTAGE = LRS ? 2 * RTEN : RTEN;  // LRS: high parts, then low parts
+    constexpr int RPT = RTEN / 4 / 1024;           // 6 pieces per wave and tensor: its own four rows
+    constexpr int RPW = LRS ? 2 * RPT : RPT;
     constexpr int IPW = (NPIECES + 3) / 4;         // 8 input pieces per wave (wave 3: 7)
     constexpr int NG = NCH * PAIRS;
     constexpr int P1_IMG = NT * PNT1 * 1024, P2_IMG = PNT1 * 1024;
     constexpr int SLOT = STAGE + RSTAGE, OFF_POST = 2 * SLOT;                 // LDS map: [input 0][residual 0][input 1][residual 1][P1 hi, lo][P2 hi, lo]
-    static_assert(IPW + RPW <= NG - 1, "DMA pieces fit the first pair's groups");
+    static_assert(IPW / 2 <= 7 && 7 + RPT <= NG, "DMA pieces fit the first pair's groups");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1569,7 +1576,7 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
     const int px = lane & 15, kq = lane >> 4;
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     constexpr bool plo = BF16;                    // bf16: hi + lo post images (the host takes this kernel only when conv_s16_kernel would use them too)
-    constexpr bool res_post = true;               // act(conv) + residual: the only order the host sends here (RLFB, team04_rlfn.py:117-119)
+    constexpr bool res_post = !LRS;               // RLFB: act(conv) + residual (team04_rlfn.py:117-119); LRS: act(conv + residual)
 
     // ---- prologue: conv weights through the (still unused) residual stages into registers, post images to their place ----------
     constexpr int WPIECES = NCH * PAIRS * NT;      // 45 KB <= slot 1 (55 KB), free until the first tile's DMA issue for the second tile
@@ -1579,15 +1586,19 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
         const int pc = wv + 4 * i;
         if (pc < WPIECES) dma_glb16(smem_lds + (unsigned)(SLOT + pc * 1024), p.wp + (size_t)pc * 1024 + lane * 16);
     }
-    for (int pc = wv; pc < 2 * (P1_IMG / 1024); pc += 4) dma_glb16(smem_lds + (unsigned)(OFF_POST + pc * 1024), p.pw1 + (size_t)pc * 1024 + lane * 16);
-    for (int pc = wv; pc < 2 * (P2_IMG / 1024); pc += 4) dma_glb16(smem_lds + (unsigned)(OFF_POST + 2 * P1_IMG + pc * 1024), p.pw2 + (size_t)pc * 1024 + lane * 16);
+    if (!LRS) {
+        for (int pc = wv; pc < 2 * (P1_IMG / 1024); pc += 4) dma_glb16(smem_lds + (unsigned)(OFF_POST + pc * 1024), p.pw1 + (size_t)pc * 1024 + lane * 16);
+        for (int pc = wv; pc < 2 * (P2_IMG / 1024); pc += 4) dma_glb16(smem_lds + (unsigned)(OFF_POST + 2 * P1_IMG + pc * 1024), p.pw2 + (size_t)pc * 1024 + lane * 16);
+    }
     i32x4 wr[NCH][PAIRS][NT];
     f32x4 bia[NT], pb1[PNT1], pb2;
 #pragma unroll
     for (int t = 0; t < NT; ++t) bia[t] = *reinterpret_cast<const f32x4*>(p.bias + t * 16 + kq * 4);
+    if (!LRS) {
 #pragma unroll
-    for (int t = 0; t < PNT1; ++t) pb1[t] = *reinterpret_cast<const f32x4*>(p.pw1 + (size_t)2 * P1_IMG + (t * 16 + kq * 4) * 4);
-    pb2 = *reinterpret_cast<const f32x4*>(p.pw2 + (size_t)2 * P2_IMG + (kq * 4) * 4);
+        for (int t = 0; t < PNT1; ++t) pb1[t] = *reinterpret_cast<const f32x4*>(p.pw1 + (size_t)2 * P1_IMG + (t * 16 + kq * 4) * 4);
+        pb2 = *reinterpret_cast<const f32x4*>(p.pw2 + (size_t)2 * P2_IMG + (kq * 4) * 4);
+    }
     const char* const img1 = smem + OFF_POST + lane * 16;                     // hi [k tile][out tile], lo at + P1_IMG
     const char* const img2 = smem + OFF_POST + 2 * P1_IMG + lane * 16;        // hi [k tile], lo at + P2_IMG
 
@@ -1623,13 +1634,15 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
             dma_buf16(smem_lds + (unsigned)(slot * SLOT + pc * 1024), voff, make_rsrc(p.x + (size_t)(valid ? n : 0) * img_bytes, img_bytes), 0u);
         }
     };
-    auto dma_res = [&](int i, bool valid, int n, int x0, int y0, int slot) __attribute__((always_inline)) {      // piece i (< 6) of this wave's own rows
-        const unsigned sl = (unsigned)((wv * RPW + i) * 64 + lane);     // slot of the residual stage: pixel sl / 6 = 16 row + col
+    auto dma_res = [&](int i, bool valid, int n, int x0, int y0, int slot) __attribute__((always_inline)) {      // piece i of this wave's own rows (LRS: 6 .. 11 = the low parts)
+        const int ten = i / RPT, j = i - ten * RPT;
+        const unsigned sl = (unsigned)((wv * RPT + j) * 64 + lane);     // slot of the residual stage: pixel sl / 6 = 16 row + col
         const unsigned pixel = sl / 6u, part = sl - pixel * 6u;
         const int gy = y0 + (int)(pixel >> 4), gx = x0 + (int)(pixel & 15u);
         const bool ok = valid && gy < p.H && gx < p.W;
         const unsigned voff = ok ? (unsigned)((gy * p.W + gx) * p.res_pitch + p.res_coff) * 2u + part * 16u : OOB;
-        dma_buf16(smem_lds + (unsigned)(slot * SLOT + STAGE + (wv * RPW + i) * 1024), voff, make_rsrc(p.res + (size_t)(valid ? n : 0) * res_bytes, res_bytes), 0u);
+        dma_buf16(smem_lds + (unsigned)(slot * SLOT + STAGE + ten * RTEN + (wv * RPT + j) * 1024), voff,
+                  make_rsrc(p.res + (size_t)(ten ? p.res_lo_stride : 0) + (size_t)(valid ? n : 0) * res_bytes, res_bytes), 0u);
     };
 
     int n, x0, y0;
@@ -1662,13 +1675,16 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
     }
     const int r_off = ((wv * RW) * 16 + px) * PIXB + kq * 8;                 // residual of row 0 of the wave: channels 16 t + 4 kq .. at + 32 t
     const float slope = p.slope, p1s = p.p1_slope;
-    const size_t p1_img = (size_t)p.H * p.W * p.py1_pitch * 2, p2_img = (size_t)p.H * p.W * p.py2_pitch * 2;
-    const unsigned rowb1 = (unsigned)p.W * (unsigned)p.py1_pitch * 2u, rowb2 = (unsigned)p.W * (unsigned)p.py2_pitch * 2u;
+    // (LRS: the "post 1" output is the conv's own hi + lo pair: y0 and y0 + the pair's stride)
+    const size_t p1_img = (size_t)p.H * p.W * (LRS ? p.y0_pitch : p.py1_pitch) * 2, p2_img = (size_t)p.H * p.W * p.py2_pitch * 2;
+    const unsigned rowb1 = (unsigned)p.W * (unsigned)(LRS ? p.y0_pitch : p.py1_pitch) * 2u, rowb2 = (unsigned)p.W * (unsigned)p.py2_pitch * 2u;
 
     f32x4 acc[2][NT][2];
     // the finished pair's fp32 values (act(conv) + residual, then c5's result) live in ITS accumulators -- free until the pair after next
     // starts; the rounded post results in named registers
     uint2 q00, q01, q10, q11, q20, q21, z0, z1;
+    uint2 l00, l01, l10, l11, l20, l21;      // LRS: the low parts of the rounded pair
+    auto PKL = [&](int t, int e) __attribute__((always_inline)) -> uint2& { return t == 0 ? (e ? l01 : l00) : (t == 1 ? (e ? l11 : l10) : (e ? l21 : l20)); };
     auto PK1 = [&](int t, int e) __attribute__((always_inline)) -> uint2& { return t == 0 ? (e ? q01 : q00) : (t == 1 ? (e ? q11 : q10) : (e ? q21 : q20)); };
     auto PK2 = [&](int e) __attribute__((always_inline)) -> uint2& { return e ? z1 : z0; };
     unsigned e_vA = OOB, e_vB = OOB, e_v2 = OOB;
@@ -1679,13 +1695,14 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
     // into steps of <= ~10 VALU instructions (or one LDS read set, or one post MFMA), one or two behind EACH convolution MFMA of the next
     // pair (slot s = 6 g + 2 t + e, 0 .. 89): an MFMA occupies the pipe for 16 cycles, an independent VALU instruction issues in 4.
     // Per accumulator the order of operations is unchanged (conv_s16_kernel's: k tiles ascending, hi then lo): results stay bit-identical.
-    uint2 rraw[4];                       // residual fragments on their way from LDS (ring of four: fragment f + 3 is read while f is applied)
+    uint2 rraw[4], rlo[4];               // residual fragments on their way from LDS (ring of four: fragment f + 3 is read while f is applied); LRS: their low parts
     i32x4 bsv[2][2];                     // [k tile & 1][row]: the fp32 fragment as the post 1x1's B operand (hi parts | lo parts)
     i32x4 pa[2][6];                      // post A fragments: [buffer][2 ot + lo] (post 1) / [lo][kt] (post 2)
     f32x4 d1[PNT1][2], d2[2];
     auto rd = [&](int f, int r) __attribute__((always_inline)) {
         const int t = f >> 1, e = f & 1;
         rraw[f & 3] = *reinterpret_cast<const uint2*>(smem + e_slot * SLOT + STAGE + r_off + t * 32 + (r + e) * (16 * PIXB));
+        if (LRS) rlo[f & 3] = *reinterpret_cast<const uint2*>(smem + e_slot * SLOT + STAGE + RTEN + r_off + t * 32 + (r + e) * (16 * PIXB));
     };
     auto ra = [&](int par, int f, int h) __attribute__((always_inline)) {        // half h of fragment f: + residual, activation (in the pair's accumulators)
         const int t = f >> 1, e = f & 1;
@@ -1693,6 +1710,11 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
         unpack2<BF16>(h ? rraw[f & 3].y : rraw[f & 3].x, ra_, rb_);
         float va = h ? acc[par][t][e].z : acc[par][t][e].x, vb = h ? acc[par][t][e].w : acc[par][t][e].y;
         if (!res_post) { va += ra_; vb += rb_; }
+        if (LRS) {                                                               // (conv + hi) + lo: conv_s16_kernel's order (its residual stages NT .. 2 NT - 1)
+            float la_, lb_;
+            unpack2<BF16>(h ? rlo[f & 3].y : rlo[f & 3].x, la_, lb_);
+            va += la_; vb += lb_;
+        }
         va = act1(va, slope); vb = act1(vb, slope);
         if (res_post) { va += ra_; vb += rb_; }
         if (h) { acc[par][t][e].z = va; acc[par][t][e].w = vb; } else { acc[par][t][e].x = va; acc[par][t][e].y = vb; }
@@ -1760,9 +1782,44 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
             }
         }
     };
+    auto pkl = [&](int par, int f, int h) __attribute__((always_inline)) {      // LRS: fragment f rounded to its high (h = 0) and low (h = 1) parts
+        const int t = f >> 1, e = f & 1;
+        const f32x4 v = acc[par][t][e];
+        if (h == 0) {
+            PK1(t, e).x = pack2<BF16>(v.x, v.y);
+            PK1(t, e).y = pack2<BF16>(v.z, v.w);
+        } else {
+            float a, b, c, d;
+            unpack2<BF16>(PK1(t, e).x, a, b);
+            unpack2<BF16>(PK1(t, e).y, c, d);
+            PKL(t, e).x = pack2<BF16>(v.x - a, v.y - b);
+            PKL(t, e).y = pack2<BF16>(v.z - c, v.w - d);
+        }
+    };
+    auto stl = [&](int i, int r, int h) __attribute__((always_inline)) {         // LRS: store i = 0 .. 2 of the high parts, 3 .. 5 of the low parts
+        const int lo = i / 3, k3 = i - 3 * lo;
+        uint2 X, Y;
+        if (lo == 0) { X = k3 == 0 ? q00 : (k3 == 1 ? q01 : q20); Y = k3 == 0 ? q10 : (k3 == 1 ? q11 : q21); }
+        else { X = k3 == 0 ? l00 : (k3 == 1 ? l01 : l20); Y = k3 == 0 ? l10 : (k3 == 1 ? l11 : l21); }
+        if (h == 0) es0 = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
+        else if (h == 1) es1 = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
+        else {
+            const i32x4 o = i32x4{(int)es0.x, (int)es1.x, (int)es0.y, (int)es1.y};
+            const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)(lo ? p.res_lo_stride : 0) + (size_t)e_n * p1_img, 0, (int)p1_img, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(o, r1, (k3 < 2 ? e_vA + (unsigned)(r + k3) * rowb1 : e_vB + (unsigned)r * rowb1), 0, 0);
+        }
+    };
     // the schedule: what runs behind convolution MFMA s of the next pair (par = the FINISHED pair's accumulators, first row r)
     auto micro = [&](auto par_, auto r_, auto s_) __attribute__((always_inline)) {
         constexpr int par = decltype(par_)::value, r = decltype(r_)::value, s = decltype(s_)::value;
+        if constexpr (LRS) {
+            // residual as below (slots 0 .. 17); rounding of fragment f in slots 18 + 2 f, + 1; the six stores from slot 30 on, three slots each
+            if constexpr (s >= 6 && s < 18) ra(par, (s - 6) >> 1, (s - 6) & 1);
+            if constexpr (s < 12 && (s & 1) == 0) rd(s >> 1, r);
+            if constexpr (s >= 18 && s < 30) pkl(par, (s - 18) >> 1, (s - 18) & 1);
+            if constexpr (s >= 30 && s < 48) stl((s - 30) / 3, r, (s - 30) % 3);
+            return;
+        }
         // 0 .. 17: the residual: fragment f is read at slot 2 f and applied in slots 2 f + 6, 2 f + 7
         if constexpr (s >= 6 && s < 18) ra(par, (s - 6) >> 1, (s - 6) & 1);
         if constexpr (s < 12 && (s & 1) == 0) rd(s >> 1, r);
@@ -1798,11 +1855,13 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
     auto store_offsets = [&](int nn_, int x0_, int y0_, int slot_) __attribute__((always_inline)) {
         const bool inx = x0_ + px < p.W;
         const unsigned pix = (unsigned)((y0_ + wv * RW) * p.W + x0_ + px);
-        const unsigned b1 = (pix * (unsigned)p.py1_pitch + (unsigned)p.py1_coff) * 2u, b2 = (pix * (unsigned)p.py2_pitch + (unsigned)p.py2_coff) * 2u;
+        const unsigned b1 = (pix * (unsigned)(LRS ? p.y0_pitch : p.py1_pitch) + (unsigned)(LRS ? p.y0_coff : p.py1_coff)) * 2u;
+        const unsigned b2 = (pix * (unsigned)p.py2_pitch + (unsigned)p.py2_coff) * 2u;
         const int chA = (kq & 1) * 16 + (kq >> 1) * 8, chB = 32 + (kq >> 1) * 8, ch2 = (kq >> 1) * 8;
-        e_vA = (inx && chA < p.p1_cout8) ? b1 + (unsigned)chA * 2u : OOB;
-        e_vB = (inx && chB < p.p1_cout8) ? b1 + (unsigned)chB * 2u + ((kq & 1) ? rowb1 : 0u) : OOB;
-        e_v2 = (inx && ch2 < p.p2_cout8) ? b2 + (unsigned)ch2 * 2u + ((kq & 1) ? rowb2 : 0u) : OOB;
+        const int c1max = LRS ? p.cout_store : p.p1_cout8;
+        e_vA = (inx && chA < c1max) ? b1 + (unsigned)chA * 2u : OOB;
+        e_vB = (inx && chB < c1max) ? b1 + (unsigned)chB * 2u + ((kq & 1) ? rowb1 : 0u) : OOB;
+        e_v2 = (!LRS && inx && ch2 < p.p2_cout8) ? b2 + (unsigned)ch2 * 2u + ((kq & 1) ? rowb2 : 0u) : OOB;
         e_n = nn_; e_slot = slot_;
     };
     for (int k = 0;; ++k) {
@@ -1855,14 +1914,18 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
                     dma_in(2 * g, more, nn, nx0, ny0, (k + 1) & 1);
                     if (2 * g + 1 < IPW) dma_in(2 * g + 1, more, nn, nx0, ny0, (k + 1) & 1);
                 }
-                if (rp == 0 && g >= 7 && g < 7 + RPW) dma_res(g - 7, more, nn, nx0, ny0, (k + 1) & 1);
+                if (rp == 0 && g >= 7 && g < 7 + RPT) {
+                    dma_res(g - 7, more, nn, nx0, ny0, (k + 1) & 1);
+                    if (LRS) dma_res(g - 7 + RPT, more, nn, nx0, ny0, (k + 1) & 1);
+                }
             });
         };
         run_pair(std::integral_constant<int, 0>{});
         run_pair(std::integral_constant<int, 1>{});
         // the next tile's stages have landed: younger than their last DMA piece (group 12 of the first pair) are the carried epilogue's
         // four stores (groups 12 - 14) and the four stores of this tile's first pair
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // (LRS: the carried epilogue's stores leave in groups 5 - 7, AHEAD of the last DMA piece: only the first pair's six stores are younger)
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LRS ? 6 : 8) : "memory");
         __builtin_amdgcn_s_barrier();
         if (!more) break;
         n = nn; x0 = nx0; y0 = ny0;
@@ -1873,15 +1936,15 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <bool BF16>
+template <bool BF16, bool LRS = false>
 int launch_conv48rp(const S16K& k, hipStream_t st)
 {
-    constexpr int LDS = 2 * 31 * 1024 + 2 * 24576 + 2 * 9 * 1024 + 2 * 3 * 1024;
+    constexpr int LDS = LRS ? 2 * (31 * 1024 + 2 * 24576) : 2 * 31 * 1024 + 2 * 24576 + 2 * 9 * 1024 + 2 * 3 * 1024;
     static std::atomic<unsigned> attr_set[MAX_DEVICES];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
     if (!attr_set[dev].load(std::memory_order_relaxed)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv48rp_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv48rp_kernel<BF16, LRS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             esr_set_err("hipFuncSetAttribute(conv48rp_kernel, MaxDynamicSharedMemorySize)", e);
             return ESR_ERR_LAUNCH;
@@ -1890,8 +1953,9 @@ int launch_conv48rp(const S16K& k, hipStream_t st)
     }
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int grid = ntiles < 256 ? ntiles : 256;
-    esr_note_kernel("conv48rp_kernel<%s>", esr_tf(BF16));
-    hipLaunchKernelGGL((conv48rp_kernel<BF16>), dim3(grid), dim3(256), LDS, st, k);
+    if (LRS) esr_note_kernel("conv48rp_kernel<%s, true>", esr_tf(BF16));
+    else esr_note_kernel("conv48rp_kernel<%s>", esr_tf(BF16));
+    hipLaunchKernelGGL((conv48rp_kernel<BF16, LRS>), dim3(grid), dim3(256), LDS, st, k);
     return esr_check_launch("conv48rp_kernel launch");
 }
 
@@ -2074,11 +2138,22 @@ static bool conv48rp_takes(const esr_conv_desc* d)
     return (long)d->n * tx * ((d->h + 15) / 16) >= 256;
 }
 
+// conv48rp_kernel<bf16, LRS>'s descriptors: the LR conv of a 48-channel network on hi + lo pairs -- 48 -> 48 (3 chunks, 3 tiles), residual pair
+// from HBM added before the activation, output pair, no post chain -- from 256 tiles of 16 x 16
+static bool conv48rl_takes(const esr_conv_desc* d)
+{
+    const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
+    if (d->storage != ESR_STORE_BF16 || d->hilo != (ESR_HILO_RES | ESR_HILO_OUT) || d->hilo_stride <= 0) return false;
+    if (d->ksize != 3 || nchunks != 3 || nt != 3 || d->out_layout != ESR_NHWC || d->in_seg_stride != 0 || d->post_wpacked || d->border_bias) return false;
+    if (d->res_mode != ESR_RES_PRE_ACT || d->act == ESR_ACT_GELU || (d->split > 0 && d->split < d->cout)) return false;
+    return (long)d->n * ((d->w + TILE - 1) / TILE) * ((d->h + 15) / 16) >= 256;
+}
+
 // 1: conv48r_kernel / conv48rp_kernel (one 4-wave block per CU, weights in registers), 4: conv_s16_kernel's two-blocks-per-CU shape (4
 // waves, 16 x 16 tiles), 8: one 8-wave block per CU on 16 x 32 tiles
 int s16_block_waves(const esr_conv_desc* d)
 {
-    if (conv48r_takes(d) || conv48rp_takes(d) || conv64r_takes(d)) return 1;
+    if (conv48r_takes(d) || conv48rp_takes(d) || conv64r_takes(d) || conv48rl_takes(d)) return 1;
     const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
     const bool res_hbm = d->res_mode != ESR_RES_NONE && !s16_res_is_input(d);
     if (d->ksize != 3 || nt != 3 || d->border_bias || d->post_wpacked || res_hbm || d->out_layout != ESR_NHWC || d->in_seg_stride != 0) return 8;
@@ -2471,6 +2546,13 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         k.seg_stride = d->hilo_stride;
     }
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (hilo && conv48rl_takes(d)) {
+        S16K kp = k;
+        kp.tiles_y = (d->h + 15) / 16;
+        kp.magic_y = kp.tiles_y > 1 ? (unsigned)((0x100000000ull + kp.tiles_y - 1) / kp.tiles_y) : 0u;
+        const double nt_all = (double)d->n * kp.tiles_x * kp.tiles_y;
+        if (nt_all * (kp.tiles_x > kp.tiles_y ? kp.tiles_x : kp.tiles_y) < 4294967296.0) return launch_conv48rp<true, true>(kp, st);
+    }
     if (hilo) {
         const long t16 = (long)d->n * k.tiles_x * ((d->h + 15) / 16);
         if (nt == 3 && hilo == ESR_HILO_OUT && wchunks == 1 && t16 >= 512 && t16 < 4096) {

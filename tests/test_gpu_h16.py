@@ -495,3 +495,42 @@ def test_conv64r_equals_conv_s16(compute, cin, cout, act, res_in, hw, n):
     eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
     tol = ref.abs() * eps * 1.01 + (3e-4 if act == 3 else 5e-5) * max(1.0, float(ref.abs().max()))
     assert int(((got - ref).abs() > tol).sum()) == 0
+
+
+@pytest.mark.parametrize("hw,n,c,act", [((128, 128), 8, 48, 0), ((100, 77), 9, 46, 0), ((64, 250), 5, 46, 1)])
+def test_conv48rl_equals_conv_s16(hw, n, c, act):
+    """conv48rp_kernel<bf16, LRS> (the LR conv of a 48-channel network on hi + lo pairs: residual pair staged by each wave for its own rows,
+    (conv + hi) + lo, hi / lo stores) against conv_s16_kernel's HILO instantiation: the batch takes the new kernel (>= 256 tiles of
+    16 x 16, esr_conv_block_waves == 1), each image alone the old one -- both tensors of the output pair bit-identical, ragged edges
+    included; and hi + lo is the fp64 result to two bf16 numbers."""
+    from ntire2022_esr_amd import _lib as L, ops
+    from ntire2022_esr_amd.engine import pack_conv_s16, unpack_conv_s16
+    g = torch.Generator().manual_seed(n * 100 + c + hw[0])
+    cp = 48
+    x = torch.randn(n, c, *hw, generator=g).to(torch.bfloat16)
+    r32 = torch.randn(n, c, *hw, generator=g) * 3.0
+    w = torch.randn(c, c, 3, 3, generator=g) * 0.1
+    b = torch.randn(c, generator=g)
+    blob = pack_conv_s16(w, b, "bf16", cin_phys=cp).to(DEV)
+    weff, _ = unpack_conv_s16(blob.cpu(), c, c, 3, "bf16", cin_phys=cp)
+    xin = F.pad(_nhwc(x), (0, cp - c)).to(DEV)
+    rin = _hilo(r32, cp).to(DEV)
+    d = L.ConvDesc()
+    d.n, d.h, d.w, d.cin, d.cout, d.ksize = n, hw[0], hw[1], c, c, 3
+    d.in_layout = d.out_layout = L.NHWC
+    d.storage, d.act, d.res_mode, d.hilo, d.hilo_stride = L.STORE["bf16"], act, L.RES_PRE_ACT, L.HILO_RES | L.HILO_OUT, 4096
+    d.res = L.View(ctypes.c_void_p(rin.data_ptr()), cp, 0)
+    assert L.lib().esr_conv_block_waves(ctypes.byref(d)) == 1
+    d.n = 1
+    assert L.lib().esr_conv_block_waves(ctypes.byref(d)) == 8
+    kw = dict(cin=c, packed=blob, act=act, res_mode=L.RES_PRE_ACT, hilo=L.HILO_RES | L.HILO_OUT)
+    y = ops.conv2d(xin, w, b, res=rin, **kw)
+    assert tuple(y.shape) == (2, n, *hw, cp)
+    for i in range(n):
+        y1 = ops.conv2d(xin[i:i + 1].contiguous(), w, b, res=rin[:, i:i + 1].contiguous(), **kw)
+        assert torch.equal(y[:, i:i + 1], y1), i
+    rsum = (rin[0].double() + rin[1].double()).permute(0, 3, 1, 2)[:, :c]
+    ref = ACTS[act](F.conv2d(x.double().to(DEV), weff.double().to(DEV), b.double().to(DEV), padding=1) + rsum)
+    got = (y[0].double() + y[1].double()).permute(0, 3, 1, 2)[:, :c]
+    tol = ref.abs() * 2.0 ** -15 + 3e-5 * max(1.0, float(ref.abs().max()))
+    assert int(((got - ref).abs() > tol).sum()) == 0

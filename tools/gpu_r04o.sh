@@ -1,0 +1,20 @@
+#!/bin/bash
+# round 4: the LR conv on conv48rp_kernel<bf16, LRS> -- kernel tests, RLFN model tests, per-op times, benches
+O=$GRAFT_REPO_ROOT/gpurun_out/r04o; mkdir -p $O; cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_h16.py -q -x -k "conv48rl or hilo or conv48rp or batch" 2>&1 | tail -4 > $O/t.txt
+timeout 900 python -m pytest tests/test_gpu_esa_models.py tests/test_gpu_multi.py tests/test_gpu_big.py -q -x -k "rlfn" 2>&1 | tail -3 >> $O/t.txt
+python tools/per_op.py 4 bf16 2>&1 | grep -E "kernels per forward|head|LR_conv|upsampler" >> $O/t.txt
+python tools/per_op.py 4 bf16 1 339x510 2>&1 | grep -E "kernels per forward|head|LR_conv|upsampler|pack" >> $O/t.txt
+for rep in 1 2; do
+timeout 300 python bench.py --model team04_rlfn --compute bf16 --no-cpu-baseline --no-other-configs > $O/b32_rlfn_$rep.json 2> $O/b32.err
+timeout 300 python bench.py --model team04_rlfn --compute bf16 --sizes div2k --streams 1 --no-cpu-baseline --no-other-configs > $O/div2k_rlfn_$rep.json 2> $O/div2k.err
+done
+python - <<'PY' > $O/summary.txt
+import json,glob,os
+for f in sorted(glob.glob(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/r04o/*.json")):
+    try:
+        j=json.loads(open(f).read().strip().splitlines()[-1]); r=j["roofline"]
+        print(os.path.basename(f), j["value"], j["ms_per_step"], [(k["kernel"],k["avg_ms"]) for k in r["kernels"][:7]])
+    except Exception as e: print(f, "ERR", e)
+PY
+cat $O/t.txt $O/summary.txt

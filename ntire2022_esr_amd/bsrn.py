@@ -169,10 +169,8 @@ class BSRN(HipSRModel):
         apply_out = fuse_d and bplanar and bool(L.lib().esr_esa_apply_post_supported(C, C, dc))
         def first_d(k):
             return dict(w=f'B{k}.c1_d', dst=cs(0), cout=dc, act=L.ACT_GELU) if fuse_d else None
-        if hl:                  # (the hi + lo store has no post-chain variant: block 1's c1_d is its own launch)
-            plan.conv('fea_conv#bs3', INPUT, fea2, self.in_nc, C, k=3, border='fea_conv#bs3#border', bs_of='fea_conv', hilo=L.HILO_OUT)
-            if fuse_d:
-                plan.conv('B1.c1_d', fea, cs(0), C, dc, k=1, counted=False, **g)
+        if hl:
+            plan.conv('fea_conv#bs3', INPUT, fea2, self.in_nc, C, k=3, border='fea_conv#bs3#border', bs_of='fea_conv', post=first_d(1), hilo=L.HILO_OUT)
         elif merged:
             plan.conv('fea_conv#bs3', INPUT, fea, self.in_nc, C, k=3, border='fea_conv#bs3#border', bs_of='fea_conv', post=first_d(1))
         else:

@@ -271,7 +271,7 @@ template <int NT, int KS, int NW, bool BF16, bool GRES, int PNT1 = 0, int PNT2 =
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(const S16K p)
 {
     static_assert(PNT2 == 0 || PNT1 > 0, "post 2 needs post 1");
-    static_assert(!HILO || (PNT1 == 0 && !GRES && KS == 3), "hi + lo tensors: the plain 3x3");
+    static_assert(!HILO || (PNT2 == 0 && !GRES && KS == 3), "hi + lo tensors: the 3x3, at most one post 1x1 (the head of RFDN / BSRN with block 1's first distillation conv)");
     constexpr int HALO = KS / 2;
     constexpr int TH = TILE + 2 * HALO;          // halo tile width = LDS row pitch in pixels
     // NW = 4: 16 x 16 tiles and TWO independent blocks per CU (each with its own copy of the weights: only where that fits 80 KB) --
@@ -2432,7 +2432,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     const int hilo = d->hilo;
     if (hilo & ~(ESR_HILO_IN | ESR_HILO_RES | ESR_HILO_OUT)) return ESR_ERR_BAD_ARG;
     if (hilo) {
-        if (!bf16 || d->ksize != 3 || post || segmented || (d->border_bias && (hilo & ESR_HILO_IN)) || (nt != 3 && nt != 4) || (d->split > 0 && d->split < d->cout)) return ESR_ERR_UNSUPPORTED;
+        if (!bf16 || d->ksize != 3 || (post && (hilo != ESR_HILO_OUT || d->post2_wpacked)) || segmented || (d->border_bias && (hilo & ESR_HILO_IN)) || (nt != 3 && nt != 4) || (d->split > 0 && d->split < d->cout)) return ESR_ERR_UNSUPPORTED;
         if (d->hilo_stride <= 0 || (d->hilo_stride & 15)) return ESR_ERR_BAD_ARG;
         if ((hilo & ESR_HILO_RES) && d->res_mode == ESR_RES_NONE) return ESR_ERR_BAD_ARG;
         if ((hilo & ESR_HILO_OUT) && (shuffle || !d->out0.ptr)) return ESR_ERR_BAD_ARG;
@@ -2552,6 +2552,12 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         kp.magic_y = kp.tiles_y > 1 ? (unsigned)((0x100000000ull + kp.tiles_y - 1) / kp.tiles_y) : 0u;
         const double nt_all = (double)d->n * kp.tiles_x * kp.tiles_y;
         if (nt_all * (kp.tiles_x > kp.tiles_y ? kp.tiles_x : kp.tiles_y) < 4294967296.0) return launch_conv48rp<true, true>(kp, st);
+    }
+    if (hilo && post) {
+        // the head with block 1's first distillation 1x1 in its epilogue (RFDN: 4 main tiles, BSRN: 3; 2 post tiles) + the hi + lo store
+        if (pnt2 != 0 || pnt1 != 2 || (nt != 3 && nt != 4)) return ESR_ERR_UNSUPPORTED;
+        if (nt == 3) return launch_s16<3, 3, S16_NW, true, false, 2, 0, true>(k, lds, st);
+        return launch_s16<4, 3, S16_NW, true, false, 2, 0, true>(k, lds, st);
     }
     if (hilo) {
         const long t16 = (long)d->n * k.tiles_x * ((d->h + 15) / 16);

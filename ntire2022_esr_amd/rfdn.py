@@ -93,7 +93,7 @@ class RFDN(HipSRModel):
         res = (lambda v: dict(res=v, res_mode=L.RES_PRE_ACT)) if self.block_residual else (lambda v: {})
         fused_post = (48 < nf <= 64 and 16 < dc <= 32) if plan.esize == 4 else ((nf + 15) // 16 in (3, 4) and 16 < dc <= 32)
         # 16-bit modes: block 1's first distillation conv (c1_d of fea) rides in the head convolution's epilogue
-        head_d = plan.esize == 2 and fused_post and not hl        # (the hi + lo store has no post-chain variant: block 1's c1_d is its own launch)
+        head_d = plan.esize == 2 and fused_post
         plan.conv('fea_conv', INPUT, fea2 if hl else fea, self.in_nc, nf, post=dict(w='B1.c1_d', dst=cs(0), cout=dc, act=L.ACT_LRELU) if head_d else None,
                   hilo=L.HILO_OUT if hl else 0)
         # ... and the other blocks' in the ESA apply launch that produces their input (esr_esa_desc.post[])

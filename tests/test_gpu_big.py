@@ -169,6 +169,29 @@ def test_forwards_on_several_streams_equal_serial(name, compute):
     m.set_compute("f32")
 
 
+@pytest.mark.parametrize("name,compute", [("team04_rlfn", "bf16"), ("rfdn_baseline", "bf16")])
+def test_full_size_forwards_on_several_streams_equal_serial(name, compute):
+    """the same with DIV2K-val-sized images (>= 256 tiles of 16 x 16): these launches take the one-wave-per-SIMD kernels (conv48r / conv48rp /
+    conv64r_kernel, the LR conv on hi + lo pairs), whose bf16 MFMAs run beside the other streams' packed-fp32 epilogues -- the partner
+    pattern of the round-3 defect (LAB_NOTES 9.1); 12 rounds = 120 overlapped forwards per network (tools/dbg/streams_race.py ... big: 6000 clean)"""
+    m, dr = _model(name, compute)
+    g = torch.Generator().manual_seed(5)
+    shapes = [(339, 510), (339, 510), (384, 510), (339, 510), (510, 339), (294, 510), (339, 510), (345, 510), (510, 384), (339, 510)]
+    xs = [(torch.rand(1, 3, h, w, generator=g) * dr).to(DEV) for h, w in shapes]
+    want = [m(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(DEV) for _ in range(4)]
+    for rnd in range(12):
+        got = []
+        for i, x in enumerate(xs):
+            with torch.cuda.stream(streams[(i + rnd) % 4]):
+                got.append(m(x))
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert torch.equal(a, b), (rnd, i)
+    m.set_compute("f32")
+
+
 @pytest.mark.parametrize("compute", ["bf16", "f16"])
 @pytest.mark.parametrize("name", ["imdn_baseline", "rfdn_baseline", "team04_rlfn", "team18_bsrn"])
 def test_16bit_batch_equals_per_image(name, compute):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """repeat tests/test_gpu_big.py::test_forwards_on_several_streams_equal_serial and report WHERE serial and overlapped forwards differ
-usage: streams_race.py <model> <compute> [rounds] [so path] [nolowres]"""
+usage: streams_race.py <model> <compute> [rounds] [so path | -] [nolowres] [big]"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -17,6 +17,8 @@ if "nolowres" in sys.argv:
 DEV = "cuda:0"
 g = torch.Generator().manual_seed(3)
 shapes = [(85, 128), (96, 128), (128, 85), (74, 128), (85, 128), (87, 128), (128, 96), (85, 128), (85, 128), (64, 64)]
+if "big" in sys.argv:          # DIV2K-val-shaped images: >= 256 tiles of 16 x 16, the launches take conv48r / conv48rp / conv64r_kernel
+    shapes = [(339, 510), (339, 510), (384, 510), (339, 510), (510, 339), (294, 510), (339, 510), (345, 510), (510, 384), (339, 510)]
 xs = [(torch.rand(1, 3, h, w, generator=g) * dr).to(DEV) for h, w in shapes]
 want = [m(x).clone() for x in xs]
 torch.cuda.synchronize()

@@ -1953,8 +1953,7 @@ int launch_conv48rp(const S16K& k, hipStream_t st)
     }
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int grid = ntiles < 256 ? ntiles : 256;
-    if (LRS) esr_note_kernel("conv48rp_kernel<%s, true>", esr_tf(BF16));
-    else esr_note_kernel("conv48rp_kernel<%s>", esr_tf(BF16));
+    esr_note_kernel("conv48rp_kernel<%s, %s>", esr_tf(BF16), esr_tf(LRS));
     hipLaunchKernelGGL((conv48rp_kernel<BF16, LRS>), dim3(grid), dim3(256), LDS, st, k);
     return esr_check_launch("conv48rp_kernel launch");
 }
@@ -2027,8 +2026,8 @@ int launch_s16(const S16K& k, size_t lds, hipStream_t st)
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int cap = NW == 4 ? 512 : 256;                   // one block per CU (LDS; NW = 4: two), persistent over the tiles
     const int grid = ntiles < cap ? ntiles : cap;
-    if (HILO) esr_note_kernel("conv_s16_kernel<%d, %d, %d, %s, %s, %d, %d, true>", NT, KS, NW, esr_tf(BF16), esr_tf(GRES), PNT1, PNT2);
-    else esr_note_kernel("conv_s16_kernel<%d, %d, %d, %s, %s, %d, %d>", NT, KS, NW, esr_tf(BF16), esr_tf(GRES), PNT1, PNT2);
+    // (rocprofv3 prints every template argument, defaulted ones included)
+    esr_note_kernel("conv_s16_kernel<%d, %d, %d, %s, %s, %d, %d, %s>", NT, KS, NW, esr_tf(BF16), esr_tf(GRES), PNT1, PNT2, esr_tf(HILO));
     hipLaunchKernelGGL((conv_s16_kernel<NT, KS, NW, BF16, GRES, PNT1, PNT2, HILO>), dim3(grid), dim3(64 * NW), lds, st, k);
     return esr_check_launch("conv_s16_kernel launch");
 }

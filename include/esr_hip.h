@@ -168,8 +168,9 @@ typedef struct esr_conv_desc {
      * such a pair (the K loop runs over both tensors against the same weights: w (hi + lo) = w hi + w lo); ESR_HILO_RES -- `res` is one (both
      * are added in fp32); ESR_HILO_OUT -- `out0` becomes one (NHWC only; `out1` unused).  For the long skip of the x4 networks,
      * `upsampler(LR_conv(body) + fea)` (team04_rlfn.py:149-150; rfdn_baseline/RFDN.py:44-47): the image itself travels through `fea` and
-     * `out_lr`, and two bf16 roundings of it cost 0.03-0.09 dB on near-detail-free content (LAB_NOTES.md 9.4).  Anything else returns
-     * ESR_ERR_UNSUPPORTED. */
+     * `out_lr`, and two bf16 roundings of it cost 0.03-0.09 dB on near-detail-free content (LAB_NOTES.md 9.4).  ESR_HILO_OUT alone may carry one
+     * post 1x1 of two output tiles (`post_*`) and a border table -- the head of RFDN / BSRN with block 1's first distillation conv in its
+     * epilogue.  Anything else returns ESR_ERR_UNSUPPORTED. */
     int32_t hilo;
     /* ABI v7 -- Winograd F(2x2, 3x3) weights (esr_pack_wino_f32) of the SAME convolution; NULL = none.  When set and
      * esr_wino_supported(d) (fp32 storage and compute, ksize 3, NHWC in / NHWC out, round_up(cin, 8) / 8 even and >= 4, no tail /

@@ -21,6 +21,15 @@
 // 16-bit), so 1x1 layers see effectively fp32-accurate weights at no cost.  3x3 weights are rounded with error
 // diffusion over the 9 taps of each (cout, cin) filter (esr_pack_conv_s16): the filter's DC gain, which dominates the
 // response to natural features, keeps fp32 accuracy.  Measured effect on RLFN bf16: tools/emulate_s16.py, DESIGN.md.
+//
+// Kernels of this file (all share the packed weights, fragment maps, order of operations and rounding: their results are bit-identical
+// where their shapes overlap, which the tests use -- a batch and its single images take different kernels):
+//   conv_s16_kernel<NT, KS, NW, bf16|f16, GRES, PNT1, PNT2, HILO>   the general one (ring of 16-channel stages, weights in LDS, 2 waves per SIMD);
+//       PNT1 / PNT2: 1x1 post chain on the fp32 tile; HILO (bf16): hi + lo pairs for the long skip (esr_conv_desc.hilo, LAB_NOTES 9.4)
+//   conv48r_kernel<bf16|f16, NT, EXT, RW>        3x3 over 48 channels, weights in registers, one wave per SIMD, whole-pixel stages, row pairs
+//   conv48rp_kernel<bf16|f16, LRS>               ... + residual from HBM staged per wave + RLFB's 1x1 chain; LRS: the LR conv on hi + lo pairs
+//   conv64r_kernel<bf16|f16, NT, EXT>            ... over 64 channels (240 weight registers + one chunk from LDS, 160-byte LDS pixels)
+// The one-wave-per-SIMD kernels run a finished row pair's epilogue as micro-steps behind each MFMA of the next pair (LAB_NOTES 9.5).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>

@@ -534,3 +534,19 @@ def test_conv48rl_equals_conv_s16(hw, n, c, act):
     got = (y[0].double() + y[1].double()).permute(0, 3, 1, 2)[:, :c]
     tol = ref.abs() * 2.0 ** -15 + 3e-5 * max(1.0, float(ref.abs().max()))
     assert int(((got - ref).abs() > tol).sum()) == 0
+
+
+@pytest.mark.parametrize("c,pc,hw", [(50, 25, (40, 56)), (48, 24, (64, 80))])
+def test_s16_hilo_head_with_post(c, pc, hw):
+    """ESR_HILO_OUT + one post 1x1 (the head of RFDN / BSRN in bf16: block 1's first distillation conv in its epilogue): the pair's high
+    parts and the post output are the plain post-chain kernel's, bit for bit; hi + lo carries the fp32 result."""
+    from ntire2022_esr_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(c + hw[0])
+    x = torch.randn(2, hw[0], hw[1], 16, generator=g).to(torch.bfloat16).to(DEV)
+    w, b = torch.randn(c, 9, 3, 3, generator=g) * 0.2, torch.randn(c, generator=g)
+    wp, bp = torch.randn(pc, c, generator=g) * 0.2, torch.randn(pc, generator=g)
+    y0, p0 = ops.conv2d(x, w, b, cin=9, post_weight=wp, post_bias=bp, post_act=1)
+    y1, p1 = ops.conv2d(x, w, b, cin=9, post_weight=wp, post_bias=bp, post_act=1, hilo=L.HILO_OUT)
+    assert y1.dim() == 5 and torch.equal(y1[0][..., :y0.shape[-1]], y0) and torch.equal(p1, p0)
+    lo = y1[1].float()
+    assert float(lo.abs().max()) > 0 and bool((lo.abs() <= y1[0].float().abs() * 2.0 ** -7 + 1e-30).all())

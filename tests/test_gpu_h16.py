@@ -550,3 +550,40 @@ def test_s16_hilo_head_with_post(c, pc, hw):
     assert y1.dim() == 5 and torch.equal(y1[0][..., :y0.shape[-1]], y0) and torch.equal(p1, p0)
     lo = y1[1].float()
     assert float(lo.abs().max()) > 0 and bool((lo.abs() <= y1[0].float().abs() * 2.0 ** -7 + 1e-30).all())
+
+
+@pytest.mark.parametrize("hw,n,border,act,pact", [((128, 128), 8, True, 3, 3), ((100, 77), 9, False, 3, 3), ((64, 250), 5, True, 1, 1)])
+def test_conv48rq_equals_conv_s16(hw, n, border, act, pact):
+    """conv48rq_kernel (fp16: ESDB c{j}_r as a dense BSConvU + input + GELU, stored, with the next distillation 1x1 + GELU as 87 micro-operations
+    behind the next row pair's MFMAs) against conv_s16_kernel<3, 3, 8, .., 2, 0>: the batch takes the new kernel (>= 256 tiles of 16 x 16,
+    esr_conv_block_waves == 1), each image alone the old one -- both outputs bit-identical, ragged edges and the border table included."""
+    from ntire2022_esr_amd import ops, _lib as L
+    from ntire2022_esr_amd.engine import pack_conv_s16
+    g = torch.Generator().manual_seed(n * 10 + hw[0])
+    c, pc = 48, 24
+    x = torch.randn(n, *hw, c, generator=g).to(torch.float16).to(DEV)
+    w, b = torch.randn(c, c, 3, 3, generator=g) * 0.1, torch.randn(c, generator=g)
+    wp, bp = torch.randn(pc, c, generator=g) * 0.2, torch.randn(pc, generator=g)
+    table = None
+    if border:
+        table = torch.randn(16, 48, generator=g) * 0.2
+        table[0] = 0
+        table = table.to(DEV)
+    blob = pack_conv_s16(w, b, "f16").to(DEV)
+    kw = dict(act=act, packed=blob, border=table, res_mode=L.RES_PRE_ACT, post_weight=wp, post_bias=bp, post_act=pact)
+    y, yp = ops.conv2d(x, w, b, res=x, **kw)
+    d = L.ConvDesc()
+    d.n, d.h, d.w, d.cin, d.cout, d.ksize = n, hw[0], hw[1], c, c, 3
+    d.in_layout = d.out_layout = L.NHWC
+    d.storage, d.act, d.res_mode, d.post_cout = L.STORE["f16"], act, L.RES_PRE_ACT, pc
+    d.inp = d.res = L.View(ctypes.c_void_p(x.data_ptr()), c, 0)
+    d.out0 = L.View(ctypes.c_void_p(y.data_ptr()), y.shape[-1], 0)
+    d.post_wpacked = ctypes.c_void_p(blob.data_ptr())                  # (any non-null pointer: the query does not read it)
+    assert L.lib().esr_conv_block_waves(ctypes.byref(d)) == 1
+    d.n = 1
+    assert L.lib().esr_conv_block_waves(ctypes.byref(d)) == 8
+    for i in range(n):
+        xi = x[i:i + 1].contiguous()
+        y1, p1 = ops.conv2d(xi, w, b, res=xi, **kw)
+        assert torch.equal(y[i:i + 1], y1) and torch.equal(yp[i:i + 1], p1), i
+    assert bool(torch.isfinite(y.float()).all()) and float(yp.float().abs().max()) > 0

@@ -228,7 +228,7 @@ def test_pipeline_equals_serial_loop(tmp_path):
 @pytest.mark.parametrize("extra,streams,events", [
     (["--batch", "4"], 1, "inside the timed region"),
     (["--batch", "4", "--streams", "2"], 2, "replay"),
-    (["--model", "team04_rlfn", "--compute", "bf16", "--sizes", "div2k"], 4, "replay"),
+    (["--model", "team04_rlfn", "--compute", "bf16", "--sizes", "div2k"], 8, "replay"),
     (["--model", "team04_rlfn", "--compute", "bf16", "--sizes", "div2k", "--streams", "1"], 1, "replay"),
 ])
 def test_bench_json_contract(extra, streams, events):

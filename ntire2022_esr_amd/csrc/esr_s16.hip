@@ -28,6 +28,7 @@
 //       PNT1 / PNT2: 1x1 post chain on the fp32 tile; HILO (bf16): hi + lo pairs for the long skip (esr_conv_desc.hilo, LAB_NOTES 9.4)
 //   conv48r_kernel<bf16|f16, NT, EXT, RW>        3x3 over 48 channels, weights in registers, one wave per SIMD, whole-pixel stages, row pairs
 //   conv48rp_kernel<bf16|f16, LRS>               ... + residual from HBM staged per wave + RLFB's 1x1 chain; LRS: the LR conv on hi + lo pairs
+//   conv48rq_kernel<f16>                         ... + residual == input, border table, GELU and ONE post 1x1 (ESDB c{j}_r + the next distillation conv)
 //   conv64r_kernel<bf16|f16, NT, EXT>            ... over 64 channels (240 weight registers + one chunk from LDS, 160-byte LDS pixels)
 // The one-wave-per-SIMD kernels run a finished row pair's epilogue as micro-steps behind each MFMA of the next pair (LAB_NOTES 9.5).
 #include <hip/hip_runtime.h>

@@ -96,6 +96,36 @@ def test_descriptor_validation_without_gpu():
     assert lib.esr_packed_conv_bytes(64, 64, 2) == 0
 
 
+def test_hilo_descriptor_validation_without_gpu():
+    """esr_conv_desc.hilo (ABI v10) is validated before anything is launched: unknown bits, a missing stride, fp16 storage, a 1x1, two output
+    tiles, a segmented input and a post chain next to the input / residual flags are refused on a CPU-only host as on a GPU box."""
+    from ntire2022_esr_amd import _lib as L
+    lib = L.lib()
+    buf = (ctypes.c_float * 64)()
+    a = ctypes.addressof(buf)
+
+    def desc(**kw):
+        d = L.ConvDesc()
+        d.n, d.h, d.w, d.cin, d.cout, d.ksize = 1, 32, 32, 48, 48, 3
+        d.in_layout = d.out_layout = L.NHWC
+        d.storage = d.compute = L.STORE["bf16"]
+        d.inp, d.out0, d.res = L.View(a, 48, 0), L.View(a, 48, 0), L.View(a, 48, 0)
+        d.wpacked = a
+        d.hilo, d.hilo_stride = L.HILO_OUT, 4096
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return lib.esr_conv2d_f32(ctypes.byref(d), None)
+
+    assert desc(hilo=8) == -1                                              # unknown bit
+    assert desc(hilo_stride=0) == -1 and desc(hilo_stride=24) == -1        # no stride / not a multiple of 16
+    assert desc(storage=L.STORE["f16"], compute=L.STORE["f16"]) == -2      # fp16: 11 bits already
+    assert desc(ksize=1) == -2 and desc(cout=32) == -2                      # 1x1; two output tiles
+    assert desc(hilo=L.HILO_RES) == -1                                     # a residual pair without a residual
+    assert desc(out_layout=L.NCHW_SHUFFLE4) == -1                          # the output pair is NHWC
+    assert desc(hilo=L.HILO_IN | L.HILO_OUT, post_wpacked=a, post_cout=24, post_out=L.View(a, 32, 0)) == -2    # a post 1x1 rides with HILO_OUT alone
+    assert desc(split=16, out1=L.View(a, 48, 0)) == -2                     # no split store
+
+
 def test_module_surface_and_no_cpu_fallback():
     from ntire2022_esr_amd import IMDN, _lib as L
     m = IMDN(in_nc=3, out_nc=3, nc=64, nb=8, upscale=4, act_mode='L', upsample_mode='pixelshuffle', negative_slope=0.05)

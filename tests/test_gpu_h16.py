@@ -587,3 +587,40 @@ def test_conv48rq_equals_conv_s16(hw, n, border, act, pact):
         y1, p1 = ops.conv2d(xi, w, b, res=xi, **kw)
         assert torch.equal(y[i:i + 1], y1) and torch.equal(yp[i:i + 1], p1), i
     assert bool(torch.isfinite(y.float()).all()) and float(yp.float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
+@pytest.mark.parametrize("hw,n,c,pc,res_in", [((128, 128), 8, 50, 25, True), ((100, 77), 9, 64, 32, True), ((64, 250), 5, 50, 25, False)])
+def test_conv64rq_equals_conv_s16(compute, hw, n, c, pc, res_in):
+    """conv64rq_kernel (RFDB c{j}_r = lrelu(conv(x) + x), stored, with c{j+1}_d + LeakyReLU as 110 micro-operations behind the next row pair's
+    MFMAs; two weight chunks in registers, two in LDS) against conv_s16_kernel<4, 3, 8, .., 2, 0>: the batch takes the new kernel (>= 256 tiles
+    of 16 x 16), each image alone the old one -- both outputs bit-identical, ragged edges included."""
+    from ntire2022_esr_amd import ops, _lib as L
+    from ntire2022_esr_amd.engine import pack_conv_s16
+    dt = DT[compute]
+    g = torch.Generator().manual_seed(n * 10 + hw[0] + c)
+    x = F.pad(torch.randn(n, *hw, c, generator=g), (0, 64 - c)).to(dt).to(DEV)
+    w, b = torch.randn(c, c, 3, 3, generator=g) * 0.1, torch.randn(c, generator=g)
+    wp, bp = torch.randn(pc, c, generator=g) * 0.2, torch.randn(pc, generator=g)
+    blob = pack_conv_s16(w, b, compute, cin_phys=64).to(DEV)
+    kw = dict(act=1, cin=c, packed=blob, post_weight=wp, post_bias=bp, post_act=1)
+    if res_in:
+        kw.update(res_mode=L.RES_PRE_ACT)
+    y, yp = ops.conv2d(x, w, b, **(dict(res=x) if res_in else {}), **kw)
+    d = L.ConvDesc()
+    d.n, d.h, d.w, d.cin, d.cout, d.ksize = n, hw[0], hw[1], c, c, 3
+    d.in_layout = d.out_layout = L.NHWC
+    d.storage, d.act, d.post_cout, d.post_act = L.STORE[compute], 1, pc, 1
+    d.inp = L.View(ctypes.c_void_p(x.data_ptr()), 64, 0)
+    if res_in:
+        d.res_mode, d.res = L.RES_PRE_ACT, d.inp
+    d.out0 = L.View(ctypes.c_void_p(y.data_ptr()), y.shape[-1], 0)
+    d.post_wpacked = ctypes.c_void_p(blob.data_ptr())
+    assert L.lib().esr_conv_block_waves(ctypes.byref(d)) == 1
+    d.n = 1
+    assert L.lib().esr_conv_block_waves(ctypes.byref(d)) == 8
+    for i in range(n):
+        xi = x[i:i + 1].contiguous()
+        y1, p1 = ops.conv2d(xi, w, b, **(dict(res=xi) if res_in else {}), **kw)
+        assert torch.equal(y[i:i + 1], y1) and torch.equal(yp[i:i + 1], p1), i
+    assert bool(torch.isfinite(y.float()).all()) and float(yp.float().abs().max()) > 0

@@ -1028,6 +1028,7 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
     if (store16 && !in_nchw) return esr_conv2d_s16(d, hip_stream);         // 16-bit storage: esr_s16.hip
     if (d->compute != ESR_COMPUTE_F32) return ESR_ERR_BAD_ARG;              // fp32 MFMA from here on (incl. the NCHW head)
     if (d->border_bias) return ESR_ERR_UNSUPPORTED;                        // border table: conv_s16_kernel only
+    if (d->hilo) return ESR_ERR_UNSUPPORTED;                               // hi + lo pairs: esr_conv2d_s16 only (a low tensor would be silently ignored here)
     if (d->in_seg_stride != 0) return ESR_ERR_UNSUPPORTED;                 // segmented input: conv_s16_kernel only
     if (store16) {
         // the network head with 16-bit activations downstream: fp32 NCHW input (exact), fp32 MFMA, 16-bit NHWC store
@@ -1095,6 +1096,10 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
         if (px_img * (in_nchw ? d->cin : d->in.pitch) * 4.0 >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
     }
 
+    // channel-blocked views: the bits are validated BEFORE the Winograd dispatch (which knows IN / OUT1 only: anything else would run
+    // on NHWC addressing where the caller declared a blocked tensor)
+    if (d->blocked8 & ~(ESR_BLOCKED_IN | ESR_BLOCKED_OUT1 | ESR_BLOCKED_OUT0 | ESR_BLOCKED_RES)) return ESR_ERR_BAD_ARG;
+    if ((d->blocked8 & (ESR_BLOCKED_OUT0 | ESR_BLOCKED_RES)) && (!tail || store16)) return ESR_ERR_UNSUPPORTED;
     if (d->wino_wpacked && !store16 && esr_wino_supported(d)) return esr_conv2d_wino(d, hip_stream);
 
     const int nt = round_up(d->cout, 16) / 16;

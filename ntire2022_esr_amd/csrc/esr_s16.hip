@@ -3150,6 +3150,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         if (!bf16 || d->ksize != 3 || (post && (hilo != ESR_HILO_OUT || d->post2_wpacked)) || segmented || (d->border_bias && (hilo & ESR_HILO_IN)) || (nt != 3 && nt != 4) || (d->split > 0 && d->split < d->cout)) return ESR_ERR_UNSUPPORTED;
         if (d->hilo_stride <= 0 || (d->hilo_stride & 15)) return ESR_ERR_BAD_ARG;
         if ((hilo & ESR_HILO_RES) && d->res_mode == ESR_RES_NONE) return ESR_ERR_BAD_ARG;
+        if ((hilo & ESR_HILO_RES) && s16_res_is_input(d)) return ESR_ERR_UNSUPPORTED;      // residual == input is added from the staged tile: the low tensor would be dropped
         if ((hilo & ESR_HILO_OUT) && (shuffle || !d->out0.ptr)) return ESR_ERR_BAD_ARG;
     }
     int split = d->split <= 0 ? cout8 : d->split;

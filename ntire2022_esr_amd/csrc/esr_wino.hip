@@ -963,7 +963,9 @@ int esr_wino_supported(const esr_conv_desc* d)
     const int nchunks = cin_phys / 8;
     if (nchunks < 4 || (nchunks & 1)) return 0;                  // raw ring looks 3 chunks ahead; stages are unrolled in pairs
     // a channel-blocked INPUT [n][C/8][h][w][8] (both Winograd kernels read it: a chunk is a plane): whole planes only
-    if ((d->blocked8 & ESR_BLOCKED_IN) && (d->in.coff & 7)) return 0;
+    if ((d->blocked8 & ESR_BLOCKED_IN) && ((d->in.coff & 7) || (d->in.pitch & 7))) return 0;
+    if (d->blocked8 & ~(ESR_BLOCKED_IN | ESR_BLOCKED_OUT1)) return 0;   // blocked out0 / res: the fused IMDB tail only
+    if (d->hilo) return 0;
     const int cout4 = esr_round_up(d->cout, 4);
     int split = d->split <= 0 ? cout4 : d->split;
     if (split >= d->cout) split = cout4;

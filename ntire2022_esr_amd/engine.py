@@ -687,10 +687,11 @@ class HipSRModel(nn.Module):
     # the cached plans exactly like set_compute() (as plain attributes a late change was ignored or raised KeyError).
     def _set_flag(self, name, value):
         value = bool(value)
-        if getattr(self, name) != value:
-            setattr(self, name, value)
-            self._dirty = True
-            self._drop_plans()
+        with self._lock:               # (another thread may be inside forward(): plans / profiler handles must not vanish under it)
+            if getattr(self, name) != value:
+                setattr(self, name, value)
+                self._dirty = True
+                self._drop_plans()
 
     fuse_esa_lowres = property(lambda self: self._fuse_esa_lowres, lambda self, v: self._set_flag("_fuse_esa_lowres", v))
     winograd = property(lambda self: self._winograd, lambda self, v: self._set_flag("_winograd", v))
@@ -709,9 +710,10 @@ class HipSRModel(nn.Module):
         low-resolution branch stay fp32."""
         if mode not in L.COMPUTE:
             raise ValueError(f"compute must be one of {sorted(L.COMPUTE)}")
-        if mode != self.compute:
-            self.compute = mode
-            self._dirty = True
+        with self._lock:
+            if mode != self.compute:
+                self.compute = mode
+                self._dirty = True
         return self
 
     def _store(self):
@@ -749,8 +751,9 @@ class HipSRModel(nn.Module):
         """Forget what the per-stream workspaces hold: the next forward on each stream zero-fills before it runs.  For callers that
         saw a non-finite output (overflowing activations in a 16-bit mode): with rezero_on_switch = False another shape's pad
         channels may lie where Inf / NaN were stored, and 0 * Inf = NaN would reach its results."""
-        for ctx in self._ctxs.values():
-            ctx.ws_owner = None
+        with self._lock:
+            for ctx in self._ctxs.values():
+                ctx.ws_owner = None
 
     def _apply(self, fn, *args, **kwargs):          # .to() / .cuda() / .float(): parameters move or change
         self._dirty = True
@@ -760,25 +763,28 @@ class HipSRModel(nn.Module):
         return tuple((p.data_ptr(), p._version, p.device) for p in self.parameters())
 
     def _drop_plans(self):
-        for ctx in self._ctxs.values():
-            for prof in ctx.profs.values():
-                L.lib().esr_prof_destroy(prof)
-            ctx.profs = {}
-            ctx.plans.clear()
-            ctx.ws_owner = None
+        with self._lock:
+            for ctx in self._ctxs.values():
+                for prof in ctx.profs.values():
+                    L.lib().esr_prof_destroy(prof)
+                ctx.profs = {}
+                ctx.plans.clear()
+                ctx.ws_owner = None
 
-    MAX_STREAMS = 8                # contexts kept; the least recently created one beyond that is dropped (its workspace is freed)
+    MAX_STREAMS = 16               # contexts kept (LRU): bench.py's DIV2K mode uses 8 streams + the default stream of the replay leg; the
+                                   # least recently USED context beyond that is dropped (its workspace is freed, its plans are rebuilt on return)
 
     def _ctx(self, device):
         """The context of the CURRENT HIP stream of `device` (torch.cuda.stream(...) selects it, like every torch op)."""
         key = (device, torch.cuda.current_stream(device).cuda_stream)
-        ctx = self._ctxs.get(key)
+        ctx = self._ctxs.pop(key, None)
         if ctx is None:
-            ctx = self._ctxs[key] = _StreamCtx()
-            while len(self._ctxs) > self.MAX_STREAMS:
-                old = next(iter(self._ctxs))
-                for prof in self._ctxs.pop(old).profs.values():
-                    L.lib().esr_prof_destroy(prof)
+            ctx = _StreamCtx()
+        self._ctxs[key] = ctx          # (re)inserted at the end: dict order = least recently used first
+        while len(self._ctxs) > self.MAX_STREAMS:
+            old = next(iter(self._ctxs))
+            for prof in self._ctxs.pop(old).profs.values():
+                L.lib().esr_prof_destroy(prof)
         return ctx
 
     # the default-stream context under its historical names (tests, tools)
@@ -820,6 +826,10 @@ class HipSRModel(nn.Module):
         return cin_map
 
     def repack(self, device):
+        with self._lock:
+            self._repack(device)
+
+    def _repack(self, device):
         packed = {}
         s16 = self._s16_convs() if self._store() != "f32" else set()
         for path, (cin, cout, k, cin_map) in self._conv_specs.items():
@@ -970,11 +980,12 @@ class HipSRModel(nn.Module):
         self._prof_passes = int(max_passes)
 
     def disable_profiling(self):
-        for ctx in self._ctxs.values():
-            for prof in ctx.profs.values():
-                L.lib().esr_prof_destroy(prof)
-            ctx.profs = {}
-        self._prof_passes = 0
+        with self._lock:
+            for ctx in self._ctxs.values():
+                for prof in ctx.profs.values():
+                    L.lib().esr_prof_destroy(prof)
+                ctx.profs = {}
+            self._prof_passes = 0
 
     def op_costs(self, plan, arr=None):
         """Per op of `plan`: device kernel symbol, ALGORITHMIC flops (2 x MACs of the matrix products the op stands

@@ -163,9 +163,10 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
 
         prep_ms = []
 
-        def enqueue(k, i, lr, img_hr):
+        def enqueue(k, i, lr, img_hr, again=False):
             """H2D, prepare(), the event-bracketed forward and the device-side metrics of image i on compute stream k % ngs; returns
-            its in-flight record.  Nothing here waits for the GPU."""
+            its in-flight record.  Nothing here waits for the GPU.  again: the image is re-enqueued after a non-finite output ahead of
+            it -- its prepare() time was recorded the first time."""
             with torch.cuda.stream(compute_streams[k % ngs]):
                 img_lr = util.uint2tensor4(lr, data_range).to(device, non_blocking=True)
                 hr_dev = torch.from_numpy(np.ascontiguousarray(img_hr)).to(device, non_blocking=True)
@@ -176,7 +177,8 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
                     t = None if tile is None else min(tile, h, w)
                     tp = time.perf_counter()
                     model.prepare((b, c, h, w) if t is None else (b, c, t, t), device)
-                    prep_ms.append((time.perf_counter() - tp) * 1e3)
+                    if not again:
+                        prep_ms.append((time.perf_counter() - tp) * 1e3)
                 start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 start.record()
                 img_sr = forward(img_lr, model, tile)
@@ -187,7 +189,12 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
                 if sr_dev.shape != hr_dev.shape:
                     raise ValueError('Input images must have the same dimensions.')
                 se_dev = ops.sqerr_device(sr_dev, hr_dev, border=border)
-                ssim_dev = ops.ssim_sum_device(sr_dev, hr_dev, border=border) if want_ssim else None     # (device scalar, count)
+                # (device scalar, count); an image whose border-cropped area is smaller than the 11x11 window has no device SSIM
+                # (esr_ssim_partials == 0): the host restatement then evaluates it when the image retires, like the serial loop
+                ssim_dev = None
+                ssim_host = want_ssim and ops.L.lib().esr_ssim_partials(sr_dev.shape[0], sr_dev.shape[1], sr_dev.shape[2], border) == 0
+                if want_ssim and not ssim_host:
+                    ssim_dev = ops.ssim_sum_device(sr_dev, hr_dev, border=border)
                 ready = torch.cuda.Event()
                 ready.record()
                 sr_host = torch.empty(sr_dev.shape, dtype=torch.uint8, pin_memory=True)
@@ -198,7 +205,7 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
                     done = torch.cuda.Event()
                     done.record()
             hh, ww = sr_dev.shape[:2]
-            return dict(k=k, i=i, lr=lr, hr=img_hr, start=start, end=end, done=done, sr_host=sr_host, se=se_dev, ssim=ssim_dev, bad=bad_dev,
+            return dict(k=k, i=i, lr=lr, hr=img_hr, start=start, end=end, done=done, sr_host=sr_host, se=se_dev, ssim=ssim_dev, ssim_host=ssim_host, bad=bad_dev,
                         count=(hh - 2 * border) * (ww - 2 * border) * sr_dev.shape[2])
 
         def retire():
@@ -215,11 +222,13 @@ def run(model, model_name, data_range, tile, logger, device, args, mode="test", 
                 torch.cuda.synchronize(device)
                 model.invalidate_workspaces()
                 for j, q in enumerate(inflight):
-                    inflight[j] = enqueue(q["k"], q["i"], q["lr"], q["hr"])
+                    inflight[j] = enqueue(q["k"], q["i"], q["lr"], q["hr"], again=True)
             se = int(r["se"].item())
             psnr = float("inf") if se == 0 else 20 * math.log10(255.0 / math.sqrt(se / r["count"]))
             ssim = float(r["ssim"][0].item()) / r["ssim"][1] if r["ssim"] is not None else None
             img_sr = r["sr_host"].numpy()
+            if r["ssim_host"]:
+                ssim = util.calculate_ssim(img_sr, r["hr"], border=border)
             writes.append(writers.submit(util.imsave, img_sr, log_row(r["i"], ms, psnr, img_sr, r["hr"], ssim)))
 
         for k, i in enumerate(mine):

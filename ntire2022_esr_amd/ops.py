@@ -56,6 +56,7 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
     d = L.ConvDesc()
     d.storage = L.STORE[st]
     d.compute = L.COMPUTE[st] if s16 else 0
+    hilo_strides = []
     if in_nchw:
         n, c, h, w = x.shape
         d.in_layout, cin = L.NCHW_IN, c
@@ -75,7 +76,7 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
         cin = wcin if cin is None else cin
         d.in_layout = L.NHWC
         d.inp = _view(x[0], in_coff)
-        d.hilo_stride = x.stride(0) * x.element_size()
+        _hilo_pair(x, "input", hilo_strides)
     elif x.dim() == 5:
         # planar concat [S, N, H, W, P]: S dense tensors one stride apart (esr_conv_desc.in_seg_stride / in_seg_chunks)
         if not s16 or not x.is_contiguous() or x.shape[-1] % 16:
@@ -123,7 +124,7 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
                 if y.dim() != 5 or y.shape[0] != 2 or not y.is_contiguous():
                     raise L.EsrError("conv2d: a hi + lo output is a contiguous [2, N, H, W, P] pair")
                 d.out0 = _view(y[0], out_coff)
-                d.hilo_stride = y.stride(0) * y.element_size()
+                _hilo_pair(y, "output", hilo_strides)
             else:
                 d.out0 = _view(y, out_coff)
         if out1 is not None:
@@ -138,10 +139,16 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
         if res.dim() != 5 or res.shape[0] != 2 or not res.is_contiguous():
             raise L.EsrError("conv2d: a hi + lo residual is a contiguous [2, N, H, W, P] pair")
         d.res = _view(res[0], res_coff)
-        d.hilo_stride = res.stride(0) * res.element_size()
+        _hilo_pair(res, "residual", hilo_strides)
     elif res is not None:
         d.res = _view(res, res_coff)
     d.hilo = hilo
+    if hilo_strides:
+        # ONE stride field serves every pair of the descriptor (esr_conv_desc.hilo_stride): pairs of different geometry would make the
+        # kernel address a low tensor at the wrong place
+        if len(set(hilo_strides)) != 1:
+            raise L.EsrError(f"conv2d: the hi + lo pairs of one call must have the same stride between their halves, got {sorted(set(hilo_strides))}")
+        d.hilo_stride = hilo_strides[0]
     d.wpacked = ctypes.c_void_p(packed.data_ptr())
     if wino:
         keepw = pack_wino(w4, bias, cin_map=cin_map).to(x.device)
@@ -164,6 +171,13 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
     if yp is None:
         return y
     return (y, yp) if yp2 is None else (y, yp, yp2)
+
+
+def _hilo_pair(t, what, strides):
+    """checks a hi + lo pair [2, N, H, W, P] (bf16, P a multiple of 16) and records the byte stride between its halves"""
+    if t.dtype != torch.bfloat16 or t.shape[-1] % 16:
+        raise L.EsrError(f"conv2d: a hi + lo {what} is a bf16 pair with a pixel pitch that is a multiple of 16 channels")
+    strides.append(t.stride(0) * t.element_size())
 
 
 def tensor2uint_device(img_sr, data_range, nonfinite=None):

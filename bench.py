@@ -53,6 +53,7 @@ DIV2K_LR_SHAPES = [(339, 510), (339, 510), (384, 510), (339, 510), (510, 339), (
 
 
 NO_HILO_SKIP = False           # --no-hilo-skip: bf16 plans keep the long skip in single bf16 numbers (A/B of the hi + lo pairs)
+NO_FUSE_CHAIN = False          # --no-fuse-chain: a block's 3x3 chain as separate launches (A/B of esr_conv_chain_s16; model.fuse_chain = False)
 
 
 def build_model(name, device, compute):
@@ -61,6 +62,7 @@ def build_model(name, device, compute):
     m, _, _, _ = select_model(MODELS[name][0], device)
     m.set_compute(compute)
     m.hilo_skip = not NO_HILO_SKIP
+    m.fuse_chain = not NO_FUSE_CHAIN
     return m, "checkpoint"
 
 
@@ -311,6 +313,7 @@ def parse_args():
                          "(DIV2K valid + test).  The total work is fixed, so the line says \"scaling\": \"strong\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hilo-skip", action="store_true", help="bf16: single-bf16 long skip instead of hi + lo pairs (A/B; model.hilo_skip = False)")
+    ap.add_argument("--no-fuse-chain", action="store_true", help="16-bit plans: the 3x3 chain of a block as separate launches (A/B; model.fuse_chain = False)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default headline run only: skip the `other_configs` leg (BASELINE.json configs [2]-[4] measured behind the timed region)")
     ap.add_argument("--b1-latency", action="store_true",
@@ -326,8 +329,9 @@ def parse_args():
 
 def main():
     args = parse_args()
-    global NO_HILO_SKIP
+    global NO_HILO_SKIP, NO_FUSE_CHAIN
     NO_HILO_SKIP = bool(args.no_hilo_skip)
+    NO_FUSE_CHAIN = bool(args.no_fuse_chain)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESR_ABI_VERSION 10
+#define ESR_ABI_VERSION 11
 
 typedef enum esr_status {
     ESR_OK = 0,
@@ -379,7 +379,8 @@ typedef enum esr_op_kind {
     ESR_OP_CONV = 0, ESR_OP_CONV3X3S2 = 1, ESR_OP_MAXPOOL7S3 = 2, ESR_OP_ESA_APPLY = 3, ESR_OP_DWCONV = 4,
     ESR_OP_BSCONV = 5,
     ESR_OP_PACK_INPUT = 6,      /* esr_pack_input_s16 on esr_op.conv (ABI v5) */
-    ESR_OP_ESA_LOWRES = 7       /* esr_esa_lowres_f32 on esr_op.lo (ABI v7) */
+    ESR_OP_ESA_LOWRES = 7,      /* esr_esa_lowres_f32 on esr_op.lo (ABI v7) */
+    ESR_OP_CONV_CHAIN = 8       /* esr_conv_chain_s16 on esr_op.chain (ABI v11) */
 } esr_op_kind;
 
 /*
@@ -434,6 +435,42 @@ typedef struct esr_ca_desc {
 
 int esr_channel_attention_f32(const esr_ca_desc* d, void* hip_stream);
 
+/*
+ * ABI v11 -- esr_conv_chain_s16: a residual block's chain of 3x3 convolutions as ONE launch (16-bit storage):
+ *     t_0 = in;  t_i = act(conv3x3_i(t_{i-1}))  (i = 1 .. n_layers - 1);
+ *     u   = act(conv3x3_n(t_{n-1})) + in                        (res_mode ESR_RES_POST_ACT: the chain's input, after the activation)
+ *     post_out = post_act(W_p . u + b_p);  post2_out = W_q . post_out_fp32 + b_q
+ * RLFB.forward (models/team04_rlfn.py:109-122, 76): c1_r -> c2_r -> c3_r (+ x) -> c5 -> esa.conv1.  The intermediate tensors never reach
+ * memory: they travel as 16-bit pixels (t_i, rounded exactly as esr_conv2d_f32 would store them) or fp32 (u, the post chain's input as in
+ * esr_conv_desc.post_*) through LDS, one image row at a time, between the waves of a block that each own one layer and keep its weights in
+ * registers (rlfb_chain_kernel, csrc/esr_chain.hip).  Results are bit-identical to the three esr_conv2d_f32 launches it replaces.
+ * wpacked[i] = esr_pack_conv_s16 (ksize 3) of layer i, post_wpacked / post2_wpacked = esr_pack_post_s16.  esr_conv_chain_supported() tells
+ * whether a descriptor's shape has a kernel (today: three layers over 33..48 channels, a first 1x1 of 33..48 and a second of <= 16 outputs).
+ */
+#define ESR_CHAIN_MAX_LAYERS 4
+typedef struct esr_chain_desc {
+    int32_t n, h, w;
+    int32_t n_layers;
+    int32_t cin, cmid, cout;    /* logical channels: in -> cmid -> ... -> cmid -> cout */
+    int32_t act;                /* esr_act of every 3x3 layer */
+    float   slope;
+    int32_t res_mode;           /* esr_res of the LAST layer (residual = `in`) */
+    int32_t storage;            /* esr_storage of in / post_out / post2_out */
+    int32_t compute;            /* esr_compute: the storage's type */
+    esr_view in;
+    const void* wpacked[ESR_CHAIN_MAX_LAYERS];
+    const void* post_wpacked;
+    esr_view post_out;
+    int32_t post_cout;
+    int32_t post_act;
+    const void* post2_wpacked;
+    esr_view post2_out;
+    int32_t post2_cout;
+    int32_t reserved;
+} esr_chain_desc;
+int esr_conv_chain_supported(const esr_chain_desc* d);   /* 1: esr_conv_chain_s16 has a kernel for this shape */
+int esr_conv_chain_s16(const esr_chain_desc* d, void* hip_stream);
+
 typedef struct esr_op {
     int32_t kind;               /* esr_op_kind */
     int32_t reserved;
@@ -441,6 +478,7 @@ typedef struct esr_op {
     esr_esa_desc esa;           /* the three ESA kinds */
     esr_bsconv_desc bs;         /* ESR_OP_BSCONV (ABI v3) */
     esr_esa_lowres_desc lo;     /* ESR_OP_ESA_LOWRES (ABI v7) */
+    esr_chain_desc chain;       /* ESR_OP_CONV_CHAIN (ABI v11) */
 } esr_op;
 
 /* ABI v5 -- the network input for the 16-bit plans: NCHW fp32 [n, cin <= 4, h, w] (d->in.ptr) -> NHWC 16-bit (d->out0, pitch >= 16,
@@ -472,7 +510,7 @@ int  esr_prof_kernel_symbol(esr_profiler* prof, int op, char* buf, size_t n);
 int         esr_abi_version(void);
 const char* esr_last_hip_error(void);     /* thread-local, "" if none */
 /* sizeof of the ABI structs as this library was compiled -- 0: esr_view, 1: esr_conv_desc, 2: esr_esa_desc, 3: esr_bsconv_desc,
- * 4: esr_ca_desc, 5: esr_op, 6: esr_esa_lowres_desc; anything else: 0.  A binding checks its own struct definitions against these once at load time (the
+ * 4: esr_ca_desc, 5: esr_op, 6: esr_esa_lowres_desc, 7: esr_chain_desc; anything else: 0.  A binding checks its own struct definitions against these once at load time (the
  * reference has no counterpart: its boundary is Python objects). */
 size_t      esr_sizeof(int which);
 const char* esr_build_info(void);         /* e.g. "gfx950 f32-mfma16x16x4 tile16x16 chunk8" */

@@ -18,7 +18,8 @@ RES_NONE, RES_PRE_ACT, RES_POST_ACT = 0, 1, 2
 NHWC, NCHW_IN, NCHW_SHUFFLE4 = 0, 1, 2
 BLOCKED_IN, BLOCKED_OUT1, BLOCKED_OUT0, BLOCKED_RES = 1, 2, 4, 8          # esr_conv_desc.blocked8 bits (ABI v6 / v9)
 HILO_IN, HILO_RES, HILO_OUT = 1, 2, 4                                     # esr_conv_desc.hilo bits (ABI v10)
-OP_CONV, OP_CONV3X3S2, OP_MAXPOOL7S3, OP_ESA_APPLY, OP_DWCONV, OP_BSCONV, OP_PACK_INPUT, OP_ESA_LOWRES = 0, 1, 2, 3, 4, 5, 6, 7
+OP_CONV, OP_CONV3X3S2, OP_MAXPOOL7S3, OP_ESA_APPLY, OP_DWCONV, OP_BSCONV, OP_PACK_INPUT, OP_ESA_LOWRES, OP_CONV_CHAIN = 0, 1, 2, 3, 4, 5, 6, 7, 8
+CHAIN_MAX_LAYERS = 4
 ESA_MAX_LAYERS = 3
 ESA_FP = 16
 COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2
@@ -105,9 +106,21 @@ class EsaLowresDesc(ctypes.Structure):
     ]
 
 
+class ChainDesc(ctypes.Structure):          # esr_chain_desc (ABI v11)
+    _fields_ = [
+        ("n", ctypes.c_int32), ("h", ctypes.c_int32), ("w", ctypes.c_int32), ("n_layers", ctypes.c_int32),
+        ("cin", ctypes.c_int32), ("cmid", ctypes.c_int32), ("cout", ctypes.c_int32),
+        ("act", ctypes.c_int32), ("slope", ctypes.c_float), ("res_mode", ctypes.c_int32),
+        ("storage", ctypes.c_int32), ("compute", ctypes.c_int32),
+        ("inp", View), ("wpacked", ctypes.c_void_p * CHAIN_MAX_LAYERS),
+        ("post_wpacked", ctypes.c_void_p), ("post_out", View), ("post_cout", ctypes.c_int32), ("post_act", ctypes.c_int32),
+        ("post2_wpacked", ctypes.c_void_p), ("post2_out", View), ("post2_cout", ctypes.c_int32), ("reserved", ctypes.c_int32),
+    ]
+
+
 class Op(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("conv", ConvDesc), ("esa", EsaDesc),
-                ("bs", BsDesc), ("lo", EsaLowresDesc)]
+                ("bs", BsDesc), ("lo", EsaLowresDesc), ("chain", ChainDesc)]
 
 
 # every symbol include/esr_hip.h declares (tests check the .so exports all of them)
@@ -125,6 +138,7 @@ EXPORTS = [
     "esr_packed_dw_bytes", "esr_pack_dw_f32", "esr_dwconv3x3_f32", "esr_bsconv_f32",
     "esr_tensor2uint_u8", "esr_sqerr_u8", "esr_channel_attention_f32",
     "esr_tensor2uint_u8_chk", "esr_ssim_partials", "esr_ssim_u8",
+    "esr_conv_chain_supported", "esr_conv_chain_s16",
 ]
 
 _lib = None
@@ -225,11 +239,15 @@ def lib():
     L.esr_packed_apply_post_bytes.restype = sz
     L.esr_pack_apply_post.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, sz]
     L.esr_pack_apply_post.restype = ci
-    if L.esr_abi_version() != 10:
+    L.esr_conv_chain_supported.argtypes = [ctypes.POINTER(ChainDesc)]
+    L.esr_conv_chain_supported.restype = ci
+    L.esr_conv_chain_s16.argtypes = [ctypes.POINTER(ChainDesc), vp]
+    L.esr_conv_chain_s16.restype = ci
+    if L.esr_abi_version() != 11:
         raise EsrError("libesr_hip.so ABI version mismatch")
     L.esr_sizeof.argtypes = [ci]
     L.esr_sizeof.restype = ctypes.c_size_t
-    for which, st in enumerate((View, ConvDesc, EsaDesc, BsDesc, CaDesc, Op, EsaLowresDesc)):
+    for which, st in enumerate((View, ConvDesc, EsaDesc, BsDesc, CaDesc, Op, EsaLowresDesc, ChainDesc)):
         if L.esr_sizeof(which) != ctypes.sizeof(st):
             raise EsrError(f"libesr_hip.so: sizeof({st.__name__}) is {L.esr_sizeof(which)} in the library, {ctypes.sizeof(st)} in the binding")
     _lib = L

@@ -931,6 +931,7 @@ size_t esr_sizeof(int which)
         case 4: return sizeof(esr_ca_desc);
         case 5: return sizeof(esr_op);
         case 6: return sizeof(esr_esa_lowres_desc);
+        case 7: return sizeof(esr_chain_desc);
         default: return 0;
     }
 }
@@ -1203,6 +1204,7 @@ static int run_one(const esr_op& op, void* hip_stream)
         case ESR_OP_BSCONV: return esr_bsconv_f32(&op.bs, hip_stream);
         case ESR_OP_PACK_INPUT: return esr_pack_input_s16(&op.conv, hip_stream);
         case ESR_OP_ESA_LOWRES: return esr_esa_lowres_f32(&op.lo, hip_stream);
+        case ESR_OP_CONV_CHAIN: return esr_conv_chain_s16(&op.chain, hip_stream);
         default: return ESR_ERR_BAD_ARG;
     }
 }

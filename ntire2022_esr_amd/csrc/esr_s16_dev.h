@@ -1,0 +1,184 @@
+// esr_s16_dev.h -- device-side primitives shared by the 16-bit-storage kernels (esr_s16.hip, esr_chain.hip): vector typedefs, compile-time
+// loops, MFMA / rounding wrappers, the packed GELU, LDS-DMA issue and counted waits.  Everything is force-inlined and lives in an anonymous
+// namespace: a translation unit that includes this header gets its own copies.  Design notes: esr_s16.hip (file header), DESIGN.md section 4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <utility>
+#include <type_traits>
+
+#include "esr_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+// compile-time loops: the body sees its index as a constant expression (std::integral_constant) -- schedules written as `if constexpr`
+// chains do not depend on hipcc's unrolling heuristics (a loop it leaves rolled indexes registers dynamically: scratch)
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+constexpr int TILE = 16;            // output tile width (pixels) = one MFMA's pixel dimension
+constexpr int RING_MIN = 3, RING_MAX = 8;   // input stages in LDS (as many as fit next to the resident weights)
+constexpr unsigned OOB = 0x80000000u;
+constexpr int LDS_LIMIT = 160 * 1024;
+constexpr int MAX_DEVICES = 64;     // per-device launch attributes (launch_s16)
+constexpr int S16_NW = 8;           // waves per tile
+
+template <bool BF16>
+__device__ __forceinline__ f32x4 mfma32(i32x4 a, i32x4 b, f32x4 c)
+{
+    if (BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// two fp32 -> one dword of two 16-bit values (RNE), and back
+template <bool BF16>
+__device__ __forceinline__ unsigned pack2(float a, float b)
+{
+    if (BF16) {
+        bf16x2 v;
+        v[0] = (__bf16)a; v[1] = (__bf16)b;
+        return __builtin_bit_cast(unsigned, v);
+    }
+    f16x2 v;
+    v[0] = (_Float16)a; v[1] = (_Float16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <bool BF16>
+__device__ __forceinline__ void unpack2(unsigned u, float& a, float& b)
+{
+    if (BF16) {
+        a = __builtin_bit_cast(float, u << 16);
+        b = __builtin_bit_cast(float, u & 0xffff0000u);
+    } else {
+        const f16x2 v = __builtin_bit_cast(f16x2, u);
+        a = (float)v[0]; b = (float)v[1];
+    }
+}
+
+template <bool BF16>
+__device__ __forceinline__ f32x4 unpack4(uint2 u)
+{
+    float a, b, c, d;
+    unpack2<BF16>(u.x, a, b);
+    unpack2<BF16>(u.y, c, d);
+    return f32x4{a, b, c, d};
+}
+
+// GELU for the 16-bit storage modes: x * Phi(x) with Phi(x) - 0.5 = x * P(x^2), P a degree-7 minimax polynomial on |x| <= 4
+// (|error| of Phi <= 2.1e-5, tools/fit_gelu.py), the argument clamped to [-4, 4] and the factor x to [-4, inf): |gelu error| <=
+// 1.3e-4 for x <= 4 and 5.3e-5 x beyond, about one fp16 step of the values that matter, far below a bf16 step -- and 11 plain VALU instructions
+// (packable two values at a time) instead of libm erff's ~40 or the 16 + v_rcp + v_exp of an erf approximation.  The fp32
+// path keeps erff.
+__device__ __forceinline__ __attribute__((unused)) float gelu16(float x)       // the scalar definition (esr_bsconv.hip uses it as is)
+{
+    const float xc = fminf(fmaxf(x, -4.f), 4.f);
+    const float t = xc * xc;
+    float p = -1.580786198e-09f;
+    p = fmaf(p, t, 1.217111051e-07f);
+    p = fmaf(p, t, -4.100866386e-06f);
+    p = fmaf(p, t, 8.066739505e-05f);
+    p = fmaf(p, t, -1.048204400e-03f);
+    p = fmaf(p, t, 9.664874174e-03f);
+    p = fmaf(p, t, -6.617537882e-02f);
+    p = fmaf(p, t, 3.988475079e-01f);
+    return fmaxf(x, -4.f) * fmaf(xc, p, 0.5f);
+}
+
+// the same arithmetic (bit for bit) on a D fragment with packed fp32 instructions: 16 v_pk_fma + 4 v_pk_mul + 4 v_med3 + 4 v_max
+// = 7 VALU instructions per value instead of 13
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu16x2(f32x2 x)
+{
+    f32x2 xc, xm;
+    xc.x = __builtin_amdgcn_fmed3f(x.x, -4.f, 4.f); xc.y = __builtin_amdgcn_fmed3f(x.y, -4.f, 4.f);
+    const f32x2 t = xc * xc;
+    f32x2 p = {-1.580786198e-09f, -1.580786198e-09f};
+    p = __builtin_elementwise_fma(p, t, f32x2{1.217111051e-07f, 1.217111051e-07f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-4.100866386e-06f, -4.100866386e-06f});
+    p = __builtin_elementwise_fma(p, t, f32x2{8.066739505e-05f, 8.066739505e-05f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-1.048204400e-03f, -1.048204400e-03f});
+    p = __builtin_elementwise_fma(p, t, f32x2{9.664874174e-03f, 9.664874174e-03f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-6.617537882e-02f, -6.617537882e-02f});
+    p = __builtin_elementwise_fma(p, t, f32x2{3.988475079e-01f, 3.988475079e-01f});
+    const float m4 = -4.f;
+    asm("v_max_f32 %0, %1, %2" : "=v"(xm.x) : "v"(x.x), "v"(m4));
+    asm("v_max_f32 %0, %1, %2" : "=v"(xm.y) : "v"(x.y), "v"(m4));
+    return xm * __builtin_elementwise_fma(xc, p, f32x2{0.5f, 0.5f});
+}
+__device__ __forceinline__ f32x4 gelu16x4(f32x4 v)
+{
+    const f32x2 a = gelu16x2(f32x2{v.x, v.y}), b = gelu16x2(f32x2{v.z, v.w});
+    return f32x4{a.x, a.y, b.x, b.y};
+}
+
+// Epilogue activation: max(v, slope * v); slope carries none (1) / LeakyReLU (s) / ReLU (0).  GELU is applied IN PLACE to the
+// accumulators at the end of a tile's last stage (gelu_inplace below), after which the epilogue runs with slope = 1: as a
+// second body of the epilogue its polynomials cost every variant ~50 VGPRs (or spills) for an activation only a few
+// launches use.  asm: fmaxf() on an MFMA result costs a second v_max (hipcc canonicalises the operand first).
+__device__ __forceinline__ float act1(float v, float slope)
+{
+    float r;
+    const float sv = slope * v;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(sv));
+    return r;
+}
+
+// LDS-DMA: every lane moves 16 bytes from (buffer base + voff + soff) to LDS byte (lds_dst + lane * 16); an out-of-range
+// voff writes zeros.  Issued from inline asm so that hipcc does not put vmcnt(0) in front of later ds_reads (it cannot see
+// which LDS bytes the DMA touches); completion is tracked by the counted waits of the stage loop.
+__device__ __forceinline__ void dma_buf16(unsigned lds_dst, unsigned voff, i32x4 rsrc, unsigned soff)
+{
+    // wave-uniform by construction; readfirstlane pins them to SGPRs where hipcc's uniformity analysis gives up
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    rsrc.x = __builtin_amdgcn_readfirstlane(rsrc.x); rsrc.y = __builtin_amdgcn_readfirstlane(rsrc.y);
+    rsrc.z = __builtin_amdgcn_readfirstlane(rsrc.z); rsrc.w = __builtin_amdgcn_readfirstlane(rsrc.w);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+__device__ __forceinline__ void dma_glb16(unsigned lds_dst, const void* g)
+{
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(g) : "memory");
+}
+
+// s_waitcnt vmcnt(cnt) for a wave-uniform runtime cnt (the immediate has to be a constant): a branch tree over the values
+// the stage loop produces; rounding DOWN is always safe (waits for more).
+__device__ __forceinline__ void wait_vm_dyn(int cnt)
+{
+#define ESR_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (cnt < 0 ? 0 : (cnt > 47 ? 47 : cnt)) {
+        ESR_W(0) ESR_W(1) ESR_W(2) ESR_W(3) ESR_W(4) ESR_W(5) ESR_W(6) ESR_W(7) ESR_W(8) ESR_W(9) ESR_W(10) ESR_W(11)
+        ESR_W(12) ESR_W(13) ESR_W(14) ESR_W(15) ESR_W(16) ESR_W(17) ESR_W(18) ESR_W(19) ESR_W(20) ESR_W(21) ESR_W(22) ESR_W(23)
+        ESR_W(24) ESR_W(25) ESR_W(26) ESR_W(27) ESR_W(28) ESR_W(29) ESR_W(30) ESR_W(31) ESR_W(32) ESR_W(33) ESR_W(34) ESR_W(35)
+        ESR_W(36) ESR_W(37) ESR_W(38) ESR_W(39) ESR_W(40) ESR_W(41) ESR_W(42) ESR_W(43) ESR_W(44) ESR_W(45) ESR_W(46) ESR_W(47)
+    }
+#undef ESR_W
+}
+
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, size_t bytes)
+{
+    i32x4 r;
+    r.x = (int)(size_t)base;
+    r.y = (int)(((size_t)base >> 32) & 0xffff);
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+
+}  // namespace

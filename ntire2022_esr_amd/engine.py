@@ -225,6 +225,15 @@ def unpack_conv(blob, cin, cout, k, cin_map=None, cin_phys=None):
     return w, b
 
 
+def _flat_ops(ops):
+    """the op dicts with every `chain` op replaced by the convolutions it stands for (their weights are the chain's)"""
+    for o in ops:
+        if o["kind"] == "chain":
+            yield from o["replaces"]
+        else:
+            yield o
+
+
 class Buffer:
     """An NHWC activation buffer inside the workspace: [n][h][w][pitch] elements of `esize` bytes
     (4 = fp32; 2 = bf16 / fp16 for the full-resolution buffers of a 16-bit-storage plan)."""
@@ -363,6 +372,20 @@ class Plan:
         self.ops.append(dict(kind="lowres", src=c1, pooled=pooled, dst=dst, f=f, w=s2, layers=layers, replaces=sub,
                              cin=f, cout=f, k=3))
 
+    def chain(self, mark):
+        """The 3x3 convolutions appended since `mark = len(plan.ops)` -- a residual block's chain src -> t1 -> ... -> (+ src) -> post 1x1 ->
+        post2 1x1, RLFB's c1_r -> c2_r -> c3_r -> c5 -> esa.conv1 (team04_rlfn.py:109-122) -- as ONE esr_conv_chain_s16 op (16-bit plans):
+        the intermediate tensors stay in LDS (rlfb_chain_kernel).  The conv op dicts stay attached as `replaces`: weights, complexity
+        counters and algorithmic costs are theirs; the result is bit-identical to running them one by one."""
+        sub = self.ops[mark:]
+        assert self.esize == 2 and len(sub) >= 2 and all(o["kind"] == "conv" and o["k"] == 3 for o in sub)
+        for a, b in zip(sub[:-1], sub[1:]):
+            assert b["src"] is a["dst"] and a["res"] is None and a.get("post") is None
+        last = sub[-1]
+        assert last["dst"] is None and last["res"] is sub[0]["src"] and last.get("post") is not None and last["post"].get("post2") is not None
+        del self.ops[mark:]
+        self.ops.append(dict(kind="chain", replaces=sub, w=sub[0]["w"], cin=sub[0]["cin"], cout=last["cout"], k=3))
+
     def esa_apply(self, wf, w4, x, c1, c3, dst, c, f, post=None, skip_y=False):
         """y = x * sigmoid(conv4(bilinear(c3) + conv_f(c1)));  two nn.Conv2d calls of the reference.
         post (16-bit plans): [dict(w=<1x1 path>, dst=<view>, cout, act, slope, res=<view>|None, linear=bool), ...] -- one or two 1x1
@@ -431,6 +454,28 @@ class Plan:
                     d.layer[l].w = ctypes.c_void_p(weights[ly["w"] + "#dense"].data_ptr())
                     if ly["kind"] == 1:
                         d.layer[l].w_dw = ctypes.c_void_p(weights[ly["w_dw"]].data_ptr())
+                continue
+            if o["kind"] == "chain":
+                op.kind = L.OP_CONV_CHAIN
+                d = op.chain
+                sub = o["replaces"]
+                first, last = sub[0], sub[-1]
+                d.n, d.h, d.w, d.n_layers = self.n, self.h, self.w, len(sub)
+                d.cin, d.cmid, d.cout = first["cin"], first["cout"], last["cout"]
+                d.act, d.slope, d.res_mode = first["act"], first["slope"], last["res_mode"]
+                d.storage = d.compute = st
+                d.inp = self._view(first["src"], base)
+                for l, so in enumerate(sub):
+                    d.wpacked[l] = weights[so["w"] + "#s16"].data_ptr()
+                t = last["post"]
+                t2 = t["post2"]
+                pc = min((t["cout"] + 15) // 16 * 16, t["dst"].pitch) if isinstance(t["dst"], Buffer) else t["cout"]    # (whole dense buffer: pad channels too)
+                d.post_wpacked, d.post_out = ctypes.c_void_p(weights[t["w"] + "#post"].data_ptr()), self._view(t["dst"], base)
+                d.post_cout, d.post_act = pc, t.get("act", L.ACT_NONE)
+                d.post2_wpacked, d.post2_out = ctypes.c_void_p(weights[t2["w"] + "#post"].data_ptr()), self._view(t2["dst"], base)
+                d.post2_cout = t2["cout"]
+                if not L.lib().esr_conv_chain_supported(ctypes.byref(d)):
+                    raise L.EsrError(f"{o['w']}: no chain kernel for this shape (the plan should have kept separate ops)")
                 continue
             if o["kind"] not in ("conv", "dw"):
                 e = op.esa
@@ -642,6 +687,7 @@ class HipSRModel(nn.Module):
         self._fuse_esa_lowres = True  # ESA's low-resolution branch as one esr_esa_lowres_f32 op (two launches) instead of 3 .. 8 launches
         self._winograd = True      # fp32 plans: 3x3 convs whose shape qualifies run as Winograd F(2x2, 3x3) (esr_conv_desc.wino_wpacked)
         self._hilo_skip = True     # bf16 plans: the long skip's tensors (`fea`, `out_lr`) as hi + lo pairs (esr_conv_desc.hilo; Plan.hilo_skip)
+        self._fuse_chain = True    # 16-bit plans: a block's 3x3 chain as one esr_conv_chain_s16 launch where a kernel exists (Plan.chain)
         self._lock = _ModelLock()       # plan / workspace bookkeeping and the pointer patch + enqueue of one forward (see _forward_impl)
         self._prof_passes = 0      # >0: record HIP events around every op (bench roofline leg)
         self.handle = next(_HANDLES)       # the `handle` argument of esr::sr_forward
@@ -696,6 +742,7 @@ class HipSRModel(nn.Module):
     fuse_esa_lowres = property(lambda self: self._fuse_esa_lowres, lambda self, v: self._set_flag("_fuse_esa_lowres", v))
     winograd = property(lambda self: self._winograd, lambda self, v: self._set_flag("_winograd", v))
     hilo_skip = property(lambda self: self._hilo_skip, lambda self, v: self._set_flag("_hilo_skip", v))
+    fuse_chain = property(lambda self: self._fuse_chain, lambda self, v: self._set_flag("_fuse_chain", v))
 
     def _skip_hilo(self, plan, c):
         """bf16 plans: keep the long skip `upsampler(LR_conv(body) + fea)` in hi + lo pairs?  (c = its channel count; the hi + lo kernels
@@ -724,7 +771,7 @@ class HipSRModel(nn.Module):
         """paths of the convolutions conv_s16_kernel runs in the 16-bit modes: every full-resolution NHWC conv"""
         plan = Plan(1, 32, 32, self._store())
         self._build_plan(plan, self.in_nc)
-        paths = {o["w"] for o in plan.ops if o["kind"] == "conv" and o["hw"] is None and o["src"] is not INPUT and not o.get("head")}
+        paths = {o["w"] for o in _flat_ops(plan.ops) if o["kind"] == "conv" and o["hw"] is None and o["src"] is not INPUT and not o.get("head")}
         for o in plan.ops:
             if o["kind"] == "bs":                        # BSConvU: pointwise + distillation 1x1 weights as hi + lo blobs
                 paths.add(o["pw"])
@@ -800,7 +847,7 @@ class HipSRModel(nn.Module):
         plan = Plan(1, 32, 32, self._store())
         self._build_plan(plan, self.in_nc)
         out = set()
-        for o in plan.ops:
+        for o in _flat_ops(plan.ops):
             t = o.get("post") if o["kind"] == "conv" else None
             if t is not None:
                 out.add(t["w"])
@@ -1057,6 +1104,15 @@ class HipSRModel(nn.Module):
                         kern = kern[:-1] + f"+{(t2['cout'] + 15) // 16}>"
                         flops += 2.0 * npix * t["cout"] * t2["cout"]
                         wr += npix * e_act * t2["cout"]
+            elif kind == "chain":                   # the block's 3x3 chain + its two 1x1s in one launch: the input read once, only the 1x1 results written
+                sub = o["replaces"]
+                kern = f"rlfb_chain_kernel<{plan.store}>"
+                flops = sum(2.0 * npix * so["cin_alg"] * so["cout"] * 9 for so in sub)
+                t = sub[-1]["post"]
+                t2 = t["post2"]
+                flops += 2.0 * npix * (sub[-1]["cout"] * t["cout"] + t["cout"] * t2["cout"])
+                rd = float(npix * sub[0]["cin_alg"] * es) + 4.0 * (sum(so["cin_alg"] * so["cout"] * 9 for so in sub) + sub[-1]["cout"] * t["cout"] + t["cout"] * t2["cout"])
+                wr = float(npix * es * (t["cout"] + t2["cout"]))
             elif kind == "lowres":                  # conv2 (s2) + pooling + the 3x3 layers behind it: two launches, only the pooled map in between
                 src, dst = o["src"], o["dst"]
                 npl = plan.n * dst.h * dst.w
@@ -1136,7 +1192,7 @@ class HipSRModel(nn.Module):
     def _complexity_terms(self, plan, o):
         """(flops, activations, n_conv) that the reference's model_summary hooks would count for op `o`."""
         flops = acts = nconv = 0
-        if o["kind"] == "lowres":                   # the fused ESA branch counts as the nn.Conv2d / nn.Linear calls it replaces
+        if o["kind"] in ("lowres", "chain"):        # the fused ESA branch / 3x3 chain counts as the nn.Conv2d / nn.Linear calls it replaces
             for sub in o["replaces"]:
                 f_, a_, n_ = self._complexity_terms(plan, sub)
                 flops, acts, nconv = flops + f_, acts + a_, nconv + n_

@@ -173,6 +173,45 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
     return (y, yp) if yp2 is None else (y, yp, yp2)
 
 
+def conv_chain(x, weights, biases, post_weight, post_bias, post2_weight, post2_bias, *, act=L.ACT_LRELU, slope=0.05,
+               res_mode=L.RES_POST_ACT, post_act=L.ACT_NONE, cin=None):
+    """esr_conv_chain_s16 (ABI v11): a residual block's chain of 3x3 convolutions in ONE launch on a 16-bit NHWC tensor x [N, H, W, P]
+    (RLFB.forward, team04_rlfn.py:109-122): t = x; t = act(conv_i(t)) for all but the last 3x3; u = act(conv_n(t)) + x;
+    v = post_act(post_weight . u + post_bias) -> stored; c1 = post2_weight . v_fp32 + post2_bias -> stored.  Returns (v, c1).
+    weights: list of OIHW fp32 3x3 weights, biases: list of fp32 biases (or None)."""
+    if not x.is_cuda:
+        raise L.EsrError("conv_chain: tensors must live on the GPU; there is no CPU fallback")
+    st = _STORE_OF[x.dtype]
+    if st == "f32":
+        raise L.EsrError("conv_chain: 16-bit storage only")
+    lib = L.lib()
+    n, h, w, _ = x.shape
+    d = L.ChainDesc()
+    d.n, d.h, d.w, d.n_layers = n, h, w, len(weights)
+    d.cin = weights[0].shape[1] if cin is None else cin
+    d.cmid, d.cout = weights[0].shape[0], weights[-1].shape[0]
+    d.act, d.slope, d.res_mode = act, slope, res_mode
+    d.storage = d.compute = L.STORE[st]
+    d.inp = _view(x)
+    keep = []
+    for i, (wt, b) in enumerate(zip(weights, biases)):
+        blob = pack_conv_s16(wt, b, st, cin_phys=(wt.shape[1] + 15) // 16 * 16).to(x.device)
+        keep.append(blob)
+        d.wpacked[i] = blob.data_ptr()
+    pw = post_weight if post_weight.dim() == 4 else post_weight[:, :, None, None]
+    p1 = pack_post_s16(pw, post_bias, st).to(x.device)
+    p2 = pack_post_s16(post2_weight, post2_bias, st).to(x.device)
+    v = torch.zeros((n, h, w, (pw.shape[0] + 15) // 16 * 16), dtype=x.dtype, device=x.device)
+    c1 = torch.zeros((n, h, w, (post2_weight.shape[0] + 7) // 8 * 8), dtype=x.dtype, device=x.device)
+    d.post_wpacked, d.post_out, d.post_cout, d.post_act = ctypes.c_void_p(p1.data_ptr()), _view(v), pw.shape[0], post_act
+    d.post2_wpacked, d.post2_out, d.post2_cout = ctypes.c_void_p(p2.data_ptr()), _view(c1), post2_weight.shape[0]
+    if not lib.esr_conv_chain_supported(ctypes.byref(d)):
+        raise L.EsrError("conv_chain: no kernel for this shape (esr_conv_chain_supported)")
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    L.check(lib.esr_conv_chain_s16(ctypes.byref(d), ctypes.c_void_p(stream)), "esr_conv_chain_s16")
+    return v, c1
+
+
 def _hilo_pair(t, what, strides):
     """checks a hi + lo pair [2, N, H, W, P] (bf16, P a multiple of 16) and records the byte stride between its halves"""
     if t.dtype != torch.bfloat16 or t.shape[-1] % 16:

@@ -74,6 +74,7 @@ class RLFN_cut(HipSRModel):
         cur, nxt = fea, xa
         for k in range(1, 5):
             b = f'B{k}.'
+            mark_c = len(plan.ops)
             plan.conv(b + 'c1_r', cur, t1, nf, mf, **act)
             plan.conv(b + 'c2_r', t1, t2, mf, mf, **act)
             if plan.esize == 2 and (nf + 15) // 16 == 3 and f <= 16:
@@ -83,6 +84,9 @@ class RLFN_cut(HipSRModel):
                 plan.conv(b + 'c3_r', t2, None, mf, nf, res=cur, res_mode=L.RES_POST_ACT, **act,
                           post=dict(w=b + 'c5', dst=v, cout=nf, act=L.ACT_NONE,
                                     post2=dict(w=b + 'esa.conv1', dst=c1, cout=f)))
+                if self.fuse_chain and (mf + 15) // 16 == 3:
+                    # ... and the three 3x3s as ONE launch: a layer-per-SIMD pipeline with t1 / t2 / u in LDS (esr_conv_chain_s16, round 5)
+                    plan.chain(mark_c)
             else:
                 plan.conv(b + 'c3_r', t2, u, mf, nf, res=cur, res_mode=L.RES_POST_ACT, **act)
                 plan.conv(b + 'c5', u, v, nf, nf, k=1)

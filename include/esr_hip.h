@@ -491,6 +491,21 @@ int esr_pack_input_s16(const esr_conv_desc* d, void* hip_stream);
 int esr_run_ops(const esr_op* ops, int n_ops, void* hip_stream);
 
 /*
+ * ABI v11 -- an op list as ONE HIP graph launch (csrc/esr_graph.hip).  test_demo.py runs one image per forward (:416-433); esr_run_ops then
+ * costs the host 20-35 kernel launches (5-8 us each).  esr_graph_create captures the launches of `ops` once (nothing executes; `x` / `y` are
+ * the network input / output pointers the ops currently hold: the ops that read ESR_NCHW_IN / esr_pack_input_s16's source and the op that
+ * writes ESR_NCHW_SHUFFLE4); esr_graph_launch patches the two pointers in the captured kernel arguments when they changed and enqueues the
+ * whole forward with one hipGraphLaunch on the caller's stream.  Same kernels, same order, same results as esr_run_ops; the graph must be
+ * rebuilt when anything else in the op list changes (workspace address, weights, shape).  Every launch of a graph must be enqueued on a
+ * stream that orders it behind the previous launch of the SAME graph (its ops share one workspace).
+ */
+typedef struct esr_graph esr_graph;
+int  esr_graph_create(const esr_op* ops, int n_ops, const void* x, void* y, esr_graph** out);
+int  esr_graph_launch(esr_graph* g, const void* x, void* y, void* hip_stream);
+int  esr_graph_nodes(const esr_graph* g);      /* diagnostics: nodes of the captured graph */
+void esr_graph_destroy(esr_graph* g);
+
+/*
  * In-stream per-op timing (what test_demo.py:413-433 does per image with a CUDA event pair, done
  * per kernel): esr_run_ops_profiled records a HIP event pair around every op ON THE LAUNCH STREAM
  * and never synchronises; esr_prof_collect (call after the stream is idle) adds each op's elapsed
@@ -505,6 +520,13 @@ void esr_prof_destroy(esr_profiler* prof);
  * "conv_s16_kernel<4, 3, 8, true, false, 2, 0>", ...; "a + b" when an op was lowered to two launches): what a profiler matches its
  * kernel trace against (the reference has torch.profiler for that). */
 int  esr_prof_kernel_symbol(esr_profiler* prof, int op, char* buf, size_t n);
+
+/* ABI v11 -- measurement helpers of bench.py (csrc/esr_metrics.hip): esr_event_pair_ms = the elapsed time an EMPTY hipEvent pair reports on
+ * the stream (median of n): what esr_run_ops_profiled's per-launch brackets add to a kernel's own duration; esr_bw_probe = read + write GB/s a
+ * plain copy kernel reaches inside `buf` (2 x bytes, device memory) when it repeats the pass `reps` times in one launch: the ceiling of a
+ * streaming kernel at that working set (a tensor the previous launch wrote is Infinity-Cache resident at single-image sizes). */
+int esr_event_pair_ms(void* hip_stream, int n, double* ms_out);
+int esr_bw_probe(void* buf, size_t bytes, int reps, void* hip_stream, double* gbs_out);
 
 /* diagnostics */
 int         esr_abi_version(void);

@@ -139,6 +139,8 @@ EXPORTS = [
     "esr_tensor2uint_u8", "esr_sqerr_u8", "esr_channel_attention_f32",
     "esr_tensor2uint_u8_chk", "esr_ssim_partials", "esr_ssim_u8",
     "esr_conv_chain_supported", "esr_conv_chain_s16",
+    "esr_graph_create", "esr_graph_launch", "esr_graph_nodes", "esr_graph_destroy",
+    "esr_event_pair_ms", "esr_bw_probe",
 ]
 
 _lib = None
@@ -243,6 +245,18 @@ def lib():
     L.esr_conv_chain_supported.restype = ci
     L.esr_conv_chain_s16.argtypes = [ctypes.POINTER(ChainDesc), vp]
     L.esr_conv_chain_s16.restype = ci
+    L.esr_graph_create.argtypes = [ctypes.POINTER(Op), ci, vp, vp, ctypes.POINTER(vp)]
+    L.esr_graph_create.restype = ci
+    L.esr_graph_launch.argtypes = [vp, vp, vp, vp]
+    L.esr_graph_launch.restype = ci
+    L.esr_graph_nodes.argtypes = [vp]
+    L.esr_graph_nodes.restype = ci
+    L.esr_graph_destroy.argtypes = [vp]
+    L.esr_graph_destroy.restype = None
+    L.esr_event_pair_ms.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double)]
+    L.esr_event_pair_ms.restype = ci
+    L.esr_bw_probe.argtypes = [vp, sz, ci, vp, ctypes.POINTER(ctypes.c_double)]
+    L.esr_bw_probe.restype = ci
     if L.esr_abi_version() != 11:
         raise EsrError("libesr_hip.so ABI version mismatch")
     L.esr_sizeof.argtypes = [ci]

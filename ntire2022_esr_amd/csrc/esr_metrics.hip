@@ -147,3 +147,74 @@ int esr_tensor2uint_u8_chk(const float* x, uint8_t* y, int c, int h, int w, floa
 }
 
 }  // extern "C"
+
+
+// ---- measurement helpers of bench.py (ABI v11) ---------------------------------------------------------------------------------------------
+// esr_bw_probe: what a plain streaming kernel reaches on THIS device at a given working set -- one launch copies `bytes` from the first half
+// of `buf` to the second half `reps` times (grid-stride, 16 bytes per lane), timed by one event pair.  bench.py divides the B = 1 kernels'
+// algorithmic bytes by this (a 16.6 MB tensor that the previous launch wrote sits in the 256 MB Infinity Cache: 8 TB/s of HBM is not the roof).
+namespace {
+__global__ __launch_bounds__(256) void bw_probe_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, int reps)
+{
+    for (int r = 0; r < reps; ++r) {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+            uint4 v = src[i];
+            v.x += (unsigned)r;                 // (a pass must not be optimised into the previous one)
+            dst[i] = v;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int esr_bw_probe(void* buf, size_t bytes, int reps, void* hip_stream, double* gbs_out)
+{
+    if (!buf || bytes < 4096 || reps <= 0 || !gbs_out) return ESR_ERR_BAD_ARG;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const size_t n16 = bytes / 16;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return ESR_ERR_LAUNCH;
+    const uint4* src = static_cast<const uint4*>(buf);
+    uint4* dst = static_cast<uint4*>(buf) + n16;
+    hipLaunchKernelGGL(bw_probe_kernel, dim3(2048), dim3(256), 0, st, src, dst, n16, 2);        // warm the caches
+    (void)hipEventRecord(e0, st);
+    hipLaunchKernelGGL(bw_probe_kernel, dim3(2048), dim3(256), 0, st, src, dst, n16, reps);
+    (void)hipEventRecord(e1, st);
+    int rc = esr_check_launch("bw_probe_kernel launch");
+    if (rc == ESR_OK && hipEventSynchronize(e1) != hipSuccess) rc = ESR_ERR_LAUNCH;
+    float ms = 0.f;
+    if (rc == ESR_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = ESR_ERR_LAUNCH;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc != ESR_OK) return rc;
+    *gbs_out = 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9;
+    return ESR_OK;
+}
+
+// esr_event_pair_ms: the elapsed time an EMPTY hipEvent pair reports on `hip_stream` (median of n pairs): what esr_run_ops_profiled's
+// per-launch brackets add to a kernel's own duration (~2.5 us: a fifth of a 13 us single-image launch)
+extern "C" int esr_event_pair_ms(void* hip_stream, int n, double* ms_out)
+{
+    if (n <= 0 || n > 4096 || !ms_out) return ESR_ERR_BAD_ARG;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipEvent_t* ev = new hipEvent_t[2 * n];
+    int made = 0;
+    for (; made < 2 * n; ++made)
+        if (hipEventCreate(&ev[made]) != hipSuccess) break;
+    int rc = made == 2 * n ? ESR_OK : ESR_ERR_LAUNCH;
+    if (rc == ESR_OK) {
+        for (int i = 0; i < n; ++i) { (void)hipEventRecord(ev[2 * i], st); (void)hipEventRecord(ev[2 * i + 1], st); }
+        if (hipEventSynchronize(ev[2 * n - 1]) != hipSuccess) rc = ESR_ERR_LAUNCH;
+    }
+    if (rc == ESR_OK) {
+        float* v = new float[n];
+        for (int i = 0; i < n && rc == ESR_OK; ++i)
+            if (hipEventElapsedTime(&v[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = ESR_ERR_LAUNCH;
+        if (rc == ESR_OK) {
+            for (int i = 1; i < n; ++i) { const float x = v[i]; int j = i - 1; while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; --j; } v[j + 1] = x; }
+            *ms_out = v[n / 2];
+        }
+        delete[] v;
+    }
+    for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+    delete[] ev;
+    return rc;
+}

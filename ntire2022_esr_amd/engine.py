@@ -649,11 +649,25 @@ class _ModelLock:
 
 
 class _Entry:
-    """One cached shape: the Plan, and its esr_op array finalized against workspace base `base`."""
-    __slots__ = ("plan", "arr", "in_idx", "out_idx", "base")
+    """One cached shape: the Plan, its esr_op array finalized against workspace base `base`, and (after the second forward of the
+    shape on this stream) the HIP graph of its launches (esr_graph_create)."""
+    __slots__ = ("plan", "arr", "in_idx", "out_idx", "base", "graph", "uses")
 
     def __init__(self, plan):
         self.plan, self.arr, self.in_idx, self.out_idx, self.base = plan, None, (), (), None
+        self.graph, self.uses = None, 0
+
+    def drop_graph(self):
+        if self.graph is not None:
+            L.lib().esr_graph_destroy(self.graph)
+            self.graph = None
+        self.uses = 0
+
+    def __del__(self):
+        try:
+            self.drop_graph()
+        except Exception:          # interpreter shutdown: the library may be gone
+            pass
 
 
 class _StreamCtx:
@@ -688,6 +702,7 @@ class HipSRModel(nn.Module):
         self._winograd = True      # fp32 plans: 3x3 convs whose shape qualifies run as Winograd F(2x2, 3x3) (esr_conv_desc.wino_wpacked)
         self._hilo_skip = True     # bf16 plans: the long skip's tensors (`fea`, `out_lr`) as hi + lo pairs (esr_conv_desc.hilo; Plan.hilo_skip)
         self._fuse_chain = True    # 16-bit plans: a block's 3x3 chain as one esr_conv_chain_s16 launch where a kernel exists (Plan.chain)
+        self.use_graphs = True     # forwards of at most GRAPH_MAX_PIXELS input pixels replay a captured HIP graph (esr_graph_launch)
         self._lock = _ModelLock()       # plan / workspace bookkeeping and the pointer patch + enqueue of one forward (see _forward_impl)
         self._prof_passes = 0      # >0: record HIP events around every op (bench roofline leg)
         self.handle = next(_HANDLES)       # the `handle` argument of esr::sr_forward
@@ -780,6 +795,7 @@ class HipSRModel(nn.Module):
         return paths
 
     # -- packing ------------------------------------------------------------------------------
+    GRAPH_MAX_PIXELS = 4 * 512 * 512   # larger forwards are GPU-bound by a wide margin: esr_run_ops
     MAX_PLANS = 128                # DIV2K has ~100 distinct LR shapes; a plan is a few tens of KB of host memory
     # Plans of different shapes lay their buffers out in ONE workspace, so after a shape switch another shape's activations lie where
     # this plan keeps its pad channels.  That is harmless: every pad slot is only ever multiplied by a zero weight (packers), added
@@ -815,6 +831,8 @@ class HipSRModel(nn.Module):
                 for prof in ctx.profs.values():
                     L.lib().esr_prof_destroy(prof)
                 ctx.profs = {}
+                for ent in ctx.plans.values():
+                    ent.drop_graph()
                 ctx.plans.clear()
                 ctx.ws_owner = None
 
@@ -953,6 +971,7 @@ class HipSRModel(nn.Module):
             ctx.ws_owner = key                                          # fresh zeros: this plan's pad channels are 0
         base = (ctx.ws.data_ptr(), ctx.lo_cap)
         if ent.base != base:
+            ent.drop_graph()                        # (the captured launches hold the old workspace addresses)
             ent.arr, ent.in_idx, ent.out_idx = ent.plan.finalize(base, self._packed)
             ent.base = base
         if ctx.ws_owner is None:
@@ -979,6 +998,10 @@ class HipSRModel(nn.Module):
 
     def forward(self, x):
         """NCHW fp32 [N, in_nc, H, W] on the GPU -> NCHW fp32 [N, out_nc, 4H, 4W]: one esr::sr_forward call."""
+        if type(x) is torch.Tensor and x.is_cuda and not torch.compiler.is_compiling():
+            # plain eager call on a real tensor: straight to the C ABI (the registered operator costs ~8 us of dispatch per call -- a
+            # fifth of a graph-launched forward's host time); tracing, FakeTensor and torch.compile go through esr::sr_forward below
+            return self._forward_impl(x)
         if _LIVE.get(self.handle) is not self:          # a copy.deepcopy of a module carries its source's handle: take a fresh one
             self.handle = next(_HANDLES)
             _LIVE[self.handle] = self
@@ -1016,6 +1039,21 @@ class HipSRModel(nn.Module):
                     L.check(lib.esr_prof_create(len(arr), self._prof_passes, ctypes.byref(prof)), "esr_prof_create")
                     ctx.profs[key] = prof
                 rc = lib.esr_run_ops_profiled(arr, len(arr), ctypes.c_void_p(stream), prof)
+            elif self.use_graphs and n * h * w <= self.GRAPH_MAX_PIXELS:
+                # small forwards (one image: test_demo.py:416-433) are host-bound -- 20-35 launches at 5-8 us each: from the second
+                # forward of a (stream, shape) on, the launches are replayed as ONE hipGraphLaunch with x / y patched (esr_graph_launch)
+                ent.uses += 1
+                if ent.graph is None and ent.uses >= 2:
+                    gh = ctypes.c_void_p()
+                    rc = lib.esr_graph_create(arr, len(arr), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), ctypes.byref(gh))
+                    if rc == L.ESR_OK:
+                        ent.graph = gh
+                    else:
+                        ent.uses = -(1 << 30)      # this plan's launches cannot be captured: stay on esr_run_ops
+                if ent.graph is not None:
+                    rc = lib.esr_graph_launch(ent.graph, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(stream))
+                else:
+                    rc = lib.esr_run_ops(arr, len(arr), ctypes.c_void_p(stream))
             else:
                 rc = lib.esr_run_ops(arr, len(arr), ctypes.c_void_p(stream))
         L.check(rc, f"{type(self).__name__}.forward")

@@ -55,6 +55,19 @@ def test_fp32_matches_reference_at_stated_size(name, h, w):
     assert d.max() <= 1 and (d != 0).mean() <= 2e-4
     psnr = util.calculate_psnr(y8, _hr(4 * h, 4 * w), border=4)
     assert abs(psnr - float(g["psnr"])) <= BUDGET["f32"], (psnr, float(g["psnr"]))
+    # FULL-tensor checksums of the reference's output (tools/gen_golden_r5.py): the fp64 sum, sum of squares and a 4 x 4 grid of tile sums per
+    # channel -- the ::9 sample above sees 1/81 of the pixels, these see all of them (a tile holds ~86 000 values of O(data_range))
+    c = np.load(os.path.join(GOLD, "big_checks.npz"))
+    key = f"{name}_{h}x{w}"
+    yd = y[0].double()
+    npx = 16.0 * h * w
+    assert abs(float(yd.sum()) - float(c[key + "_sum"])) <= 2e-6 * dr * 3 * npx
+    assert abs(float((yd * yd).sum()) - float(c[key + "_sumsq"])) <= 4e-6 * dr * dr * 3 * npx
+    hh, ww = 4 * h, 4 * w
+    ys = [round(i * hh / 4) for i in range(5)]
+    xs = [round(i * ww / 4) for i in range(5)]
+    tiles = np.array([[[float(yd[k, ys[i]:ys[i + 1], xs[j]:xs[j + 1]].sum()) for j in range(4)] for i in range(4)] for k in range(3)])
+    assert np.abs(tiles - c[key + "_tiles"]).max() <= 2e-6 * dr * npx / 16, np.abs(tiles - c[key + "_tiles"]).max()
 
 
 @pytest.mark.parametrize("compute", ["bf16", "f16"])

@@ -21,7 +21,21 @@ print(f"{name} {comp} 1x{h}x{w}: wall per forward (back to back): {s.elapsed_tim
 t0 = time.perf_counter()
 for _ in range(200): y = m(x)
 t1 = time.perf_counter(); torch.cuda.synchronize()
-print("host enqueue time per forward: %.3f ms" % ((t1 - t0) / 200 * 1e3))
+print("host enqueue time per forward (back-pressured queue): %.3f ms" % ((t1 - t0) / 200 * 1e3))
+# against an IDLE queue: one forward at a time, the device drained in between -- what the host alone costs
+for graphs in (True, False):
+    m.use_graphs = graphs
+    for _ in range(3): m(x)
+    torch.cuda.synchronize()
+    tot = 0.0
+    for _ in range(100):
+        t0 = time.perf_counter(); y = m(x); tot += time.perf_counter() - t0
+        torch.cuda.synchronize()
+    s.record()
+    for _ in range(200): y = m(x)
+    e.record(); torch.cuda.synchronize()
+    print(f"use_graphs={graphs}: host time per forward, idle queue: {tot / 100 * 1e6:.1f} us; wall per forward back to back: {s.elapsed_time(e) / 200:.3f} ms")
+m.use_graphs = True
 m.enable_profiling(5)
 for _ in range(5): m(x)
 torch.cuda.synchronize()

@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libesr_hip.so")
+# (ESR_HIP_LIB: research builds of the SAME library -- compile-time A/B switches, tools/r05 -- loaded in place of the product's; never set in production)
+SO_PATH = os.environ.get("ESR_HIP_LIB") or os.path.join(_HERE, "libesr_hip.so")
 
 ESR_OK = 0
 STATUS = {0: "ESR_OK", -1: "ESR_ERR_BAD_ARG", -2: "ESR_ERR_UNSUPPORTED", -3: "ESR_ERR_LAUNCH", -4: "ESR_ERR_TOO_SMALL"}

@@ -28,6 +28,7 @@
 // bit-identical to the three separate launches (tests/test_gpu_chain.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <atomic>
 
@@ -58,27 +59,35 @@ struct ChainK {
 #endif
 };
 
-constexpr int CH_G = 2;                       // MFMA pixel groups per row
 constexpr int CH_NW = 4;                      // waves per block: one per SIMD
-constexpr int CH_COLS = 16 * CH_G + 2;        // pixels of a ring row
-constexpr int CH_WS = 16 * CH_G - 4;          // valid output columns of a strip
-constexpr int CH_IN_PITCH = 4096;             // input ring row: 34 pixels x 96 B = 3264 B, staged as four 1 KB DMA pieces
-constexpr int CH_NR_IN = 16;
-constexpr int CH_T_PITCH = 3328;              // t1 / t2 ring row (>= 34 x 96)
-constexpr int CH_NR_T = 4;
-constexpr int CH_U_ROW = 3 * CH_G * 1024;     // u ring row: [tile][group] 1 KB B-operand fragments
-constexpr int CH_NR_U = 2;
-constexpr int CH_OFF_IN = 0;
-constexpr int CH_OFF_T1 = CH_NR_IN * CH_IN_PITCH;
-constexpr int CH_OFF_T2 = CH_OFF_T1 + CH_NR_T * CH_T_PITCH;
-constexpr int CH_OFF_U = CH_OFF_T2 + CH_NR_T * CH_T_PITCH;
-constexpr int CH_LDS = CH_OFF_U + CH_NR_U * CH_U_ROW;
-constexpr int CH_D = 8;                       // the input DMA runs this many rows ahead of layer 1
+// Geometry of a block that computes G MFMA pixel groups (16 G columns) per row: strips of 16 G - 4 valid output columns.  G = 2 for single
+// images (more, smaller jobs: 339 x 510 = 247 jobs on 256 CUs), G = 3 for batches (44 of 48 columns valid instead of 28 of 32, and the
+// per-step overhead -- barrier, bookkeeping -- spread over 135 instead of 90 MFMAs per wave).
+template <int G>
+struct ChGeo {
+    static constexpr int COLS = 16 * G + 2;                     // pixels of a ring row
+    static constexpr int WS = 16 * G - 4;                       // valid output columns of a strip
+    static constexpr int PIECES = (COLS * 6 + 63) / 64;         // 1 KB DMA pieces of an input row (COLS pixels x 96 B)
+    static constexpr int IN_PITCH = PIECES * 1024;
+    static constexpr int NR_IN = 16;
+    static constexpr int T_PITCH = (COLS * 96 + 255) / 256 * 256;   // t1 / t2 ring row
+    static constexpr int NR_T = 4;
+    static constexpr int U_ROW = 3 * G * 1024;                  // u ring row: [tile][group] 1 KB B-operand fragments
+    static constexpr int NR_U = 2;
+    static constexpr int OFF_IN = 0;
+    static constexpr int OFF_T1 = NR_IN * IN_PITCH;
+    static constexpr int OFF_T2 = OFF_T1 + NR_T * T_PITCH;
+    static constexpr int OFF_U = OFF_T2 + NR_T * T_PITCH;
+    static constexpr int LDS = OFF_U + NR_U * U_ROW;
+    static constexpr int STORES = G + 2 * ((G + 1) / 2);        // stores per row of the post wave: tiles 0 | 1 per group, tile 2 and conv1's tile per group PAIR
+    // the input DMA runs D rows ahead of layer 1; the post wave's counted wait (PIECES + STORES) (D - 2) + STORES must fit vmcnt's 6 bits
+    static constexpr int D = (PIECES + STORES) * 6 + STORES <= 63 ? 8 : 6;
+    static_assert((PIECES + STORES) * (D - 2) + STORES <= 63 && D + 8 <= NR_IN, "vmcnt range / input ring depth");
+};
 constexpr int CH_LAG = 3;                     // a layer lags its producer by this many steps
 constexpr int CH_LAGP = 2 * CH_LAG + 2;       // wave 3 (post chain) lags layer 1 by this many steps
 constexpr int CH_HALO = 3;                    // row slot r of a job is image row Y0 - 3 + r; RS + 6 slots per job
 constexpr int CH_WIMG = 45 * 1024;            // 3 chunks x 5 tap pairs x 3 tiles
-constexpr int CH_DMA_STORES = 4;              // stores per step of the wave that also issues the DMA (its vmcnt arithmetic)
 // Out-of-range markers of the per-lane / per-row byte offsets that are ADDED to form a buffer offset: a lane that must not touch memory
 // carries CH_LOOB, a row that must not the (wave-uniform) CH_ROOB; images are < 1 GiB (checked by the host), so any sum with a marker in it
 // is >= the buffer's num_records (hardware: loads return zero -- the zero padding --, stores are dropped) and no sum wraps to a valid offset
@@ -150,7 +159,7 @@ constexpr int CH_TRACE_W = 6;             // stamps per step: before / after the
 #endif
 
 __device__ __forceinline__ void chain_barrier(char* const smem = nullptr, int wv = 0, int step = -1, unsigned long long m0 = 0, unsigned long long m1 = 0,
-                                              unsigned long long m2 = 0, unsigned long long m3 = 0)
+                                              unsigned long long m2 = 0, unsigned long long m3 = 0, int lds_end = 0)
 {
     // every LDS access of the step has completed (writes visible, ring slots released); the "memory" clobber keeps hipcc from moving
     // LDS accesses across it
@@ -158,7 +167,7 @@ __device__ __forceinline__ void chain_barrier(char* const smem = nullptr, int wv
     unsigned long long t0, t1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1) :: "memory");
     if (smem && step >= 0 && step < CH_TRACE_STEPS && (threadIdx.x & 63) == 0) {
-        unsigned long long* tr = reinterpret_cast<unsigned long long*>(smem + CH_LDS) + (wv * CH_TRACE_STEPS + step) * CH_TRACE_W;
+        unsigned long long* tr = reinterpret_cast<unsigned long long*>(smem + lds_end) + (wv * CH_TRACE_STEPS + step) * CH_TRACE_W;
         tr[0] = t0; tr[1] = t1; tr[2] = m0; tr[3] = m1; tr[4] = m2; tr[5] = m3;
     }
 #else
@@ -177,15 +186,16 @@ __device__ __forceinline__ void mul2(float& a, float& b, float x, float y, float
 // ---- waves 0 .. 2: one 3x3 layer each -------------------------------------------------------------------------------------------------
 // LAST = false: act(conv) rounded into the next layer's ring (zeros outside the image).  LAST = true (c3_r): act(conv) + x (the block input
 // from the input ring), kept in fp32 and handed to wave 3 as the post chain's B operands (16-bit high parts | low parts).
-template <bool BF16, bool LAST>
+template <bool BF16, bool LAST, int G>
 __device__ __forceinline__ void chain_layer_wave(const ChainK& p, char* const smem, const int layer, const int nsteps, const int RJ)
 {
-    constexpr int G = CH_G, NCH = 3, PAIRS = 5, NT = 3, NG = NCH * PAIRS;
+    typedef ChGeo<G> Geo;
+    constexpr int NCH = 3, PAIRS = 5, NT = 3, NG = NCH * PAIRS, NF = NT * G;      // NF: fragments (MFMAs of a group) per row
     const int lane = threadIdx.x & 63, px = lane & 15, kq = lane >> 4;
-    const int src_base = layer == 0 ? CH_OFF_IN : (layer == 1 ? CH_OFF_T1 : CH_OFF_T2);
-    const int src_pitch = layer == 0 ? CH_IN_PITCH : CH_T_PITCH;
-    const int src_mask = layer == 0 ? CH_NR_IN - 1 : CH_NR_T - 1;
-    const int dst_base = layer == 0 ? CH_OFF_T1 : CH_OFF_T2;
+    const int src_base = layer == 0 ? Geo::OFF_IN : (layer == 1 ? Geo::OFF_T1 : Geo::OFF_T2);
+    const int src_pitch = layer == 0 ? Geo::IN_PITCH : Geo::T_PITCH;
+    const int src_mask = layer == 0 ? Geo::NR_IN - 1 : Geo::NR_T - 1;
+    const int dst_base = layer == 0 ? Geo::OFF_T1 : Geo::OFF_T2;
     const char* const wp = layer == 0 ? p.w0 : (layer == 1 ? p.w1 : p.w2);
 
     // ---- the layer's weights: registers for the life of the block ----------------------------------------------------------------------
@@ -217,7 +227,9 @@ __device__ __forceinline__ void chain_layer_wave(const ChainK& p, char* const sm
     auto rowaddr = [&](int v) __attribute__((always_inline)) -> int { return src_base + (v & src_mask) * src_pitch; };
 
     ChainCur cur = chain_cursor(CH_LAG * layer, RJ);
-    unsigned cm0 = 0u, cm1 = 0u;                // this job's column masks (the layer's output column 16 e + px lies inside the image)
+    unsigned cm[G];                             // this job's column masks (the layer's output column 16 e + px lies inside the image)
+#pragma unroll
+    for (int e = 0; e < G; ++e) cm[e] = 0u;
     int baddr[2][PAIRS];
     {
         const int ra0 = rowaddr(cur.V), ra1 = rowaddr(cur.V + 1), ra2 = rowaddr(cur.V + 2);
@@ -226,9 +238,15 @@ __device__ __forceinline__ void chain_layer_wave(const ChainK& p, char* const sm
     }
 
     // epilogue parameters of a row, stashed by the step that computes it for the step that finishes it
-    struct Epi { int wa; unsigned m0, m1; int ra; };
-    Epi ep[2] = {{dst_base + lane_w, 0u, 0u, CH_OFF_IN + lane_r}, {dst_base + lane_w, 0u, 0u, CH_OFF_IN + lane_r}};
-    if (LAST) { ep[0].wa = CH_OFF_U + lane * 16; ep[1].wa = CH_OFF_U + lane * 16; }
+    struct Epi { int wa; unsigned m[G]; int ra; };
+    Epi ep[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ep[i].wa = LAST ? Geo::OFF_U + lane * 16 : dst_base + lane_w;
+        ep[i].ra = Geo::OFF_IN + lane_r;
+#pragma unroll
+        for (int e = 0; e < G; ++e) ep[i].m[e] = 0u;
+    }
 
     f32x4 acc[2][NT][G];
     i32x4 b[5][G];                              // B fragments: ring of five, read three groups ahead
@@ -262,27 +280,27 @@ __device__ __forceinline__ void chain_layer_wave(const ChainK& p, char* const sm
         if constexpr (!LAST) {
             // fragment f = 2 t + e in bundles 2 + 7 f ..: slope products, maxima (x, y | z, w), rounding, mask, store
             constexpr int S0 = 2, PER = 7;
-            if constexpr (s >= S0 && s < S0 + PER * NT * G) {
-                constexpr int f = (s - S0) / PER, m = (s - S0) % PER, t = f >> 1, e = f & 1;
+            if constexpr (s >= S0 && s < S0 + PER * NF) {
+                constexpr int f = (s - S0) / PER, m = (s - S0) % PER, t = f / G, e = f % G;
                 f32x4& A = acc[pp][t][e];
                 if constexpr (m == 0) mul2(ta, tb, A.x, A.y, slope);
                 else if constexpr (m == 1) CH_MAX2(A.x, A.y, ta, tb);
                 else if constexpr (m == 2) mul2(ta, tb, A.z, A.w, slope);
                 else if constexpr (m == 3) CH_MAX2(A.z, A.w, ta, tb);
                 else if constexpr (m == 4) { pk.x = pack2<BF16>(A.x, A.y); pk.y = pack2<BF16>(A.z, A.w); }
-                else if constexpr (m == 5) { const unsigned msk = e ? E.m1 : E.m0; pk.x &= msk; pk.y &= msk; }
+                else if constexpr (m == 5) { const unsigned msk = E.m[e]; pk.x &= msk; pk.y &= msk; }
                 else *reinterpret_cast<uint2*>(smem + E.wa + e * (16 * 96) + t * 32) = pk;
             }
         } else {
             // fragment f in bundles 15 f .. 15 f + 14 (all 90): lrelu(conv) + x (team04_rlfn.py:117-119), the fp32 value as high parts | low
             // parts; its residual is read five bundles ahead (fragment 0's: behind the previous row's last bundles is too early -- bundle 0)
             constexpr int PER = 15;
-            constexpr int f = s / PER, m = s % PER, t = f >> 1, e = f & 1;
+            constexpr int f = s / PER, m = s % PER, t = f / G, e = f % G;
             f32x4& A = acc[pp][t][e];
             // residual of fragment f + 1 (of fragment 0 in bundle 1 of fragment 0: its first use is bundle 4)
-            if constexpr (m == 9 && f + 1 < NT * G) {
+            if constexpr (m == 9 && f + 1 < NF) {
                 constexpr int f1 = f + 1;
-                rraw[f1 & 1] = *reinterpret_cast<const uint2*>(smem + E.ra + (f1 & 1) * (16 * 96) + (f1 >> 1) * 32);
+                rraw[f1 & 1] = *reinterpret_cast<const uint2*>(smem + E.ra + (f1 % G) * (16 * 96) + (f1 / G) * 32);
             }
             if constexpr (s == 0) rraw[0] = *reinterpret_cast<const uint2*>(smem + E.ra);
             if constexpr (m == 0) mul2(ta, tb, A.x, A.y, slope);
@@ -311,19 +329,19 @@ __device__ __forceinline__ void chain_layer_wave(const ChainK& p, char* const sm
         unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
         if (chain_advance(p, cur, RJ) && !LAST) {
             const int gx = cur.X0 - 2 + layer + px;
-            cm0 = (cur.ok && (unsigned)gx < (unsigned)p.W) ? 0xffffffffu : 0u;
-            cm1 = (cur.ok && (unsigned)(gx + 16) < (unsigned)p.W) ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int e = 0; e < G; ++e) cm[e] = (cur.ok && (unsigned)(gx + 16 * e) < (unsigned)p.W) ? 0xffffffffu : 0u;
         }
         {
             // this row's epilogue parameters (used one step later)
             if (!LAST) {
                 const bool rowok = (unsigned)(cur.Y0 - CH_HALO + cur.r) < (unsigned)p.H;
-                ep[par].wa = dst_base + (cur.V & (CH_NR_T - 1)) * CH_T_PITCH + lane_w;
-                ep[par].m0 = rowok ? cm0 : 0u;
-                ep[par].m1 = rowok ? cm1 : 0u;
+                ep[par].wa = dst_base + (cur.V & (Geo::NR_T - 1)) * Geo::T_PITCH + lane_w;
+#pragma unroll
+                for (int e = 0; e < G; ++e) ep[par].m[e] = rowok ? cm[e] : 0u;
             } else {
-                ep[par].wa = CH_OFF_U + (cur.V & (CH_NR_U - 1)) * CH_U_ROW + lane * 16;
-                ep[par].ra = CH_OFF_IN + (cur.V & (CH_NR_IN - 1)) * CH_IN_PITCH + lane_r;
+                ep[par].wa = Geo::OFF_U + (cur.V & (Geo::NR_U - 1)) * Geo::U_ROW + lane * 16;
+                ep[par].ra = Geo::OFF_IN + (cur.V & (Geo::NR_IN - 1)) * Geo::IN_PITCH + lane_r;
             }
         }
         // the next step's row addresses (its window = rows V, V + 1, V + 2 of the producer)
@@ -335,8 +353,8 @@ __device__ __forceinline__ void chain_layer_wave(const ChainK& p, char* const sm
         static_for<NG>([&](auto g_) __attribute__((always_inline)) {
             constexpr int g = decltype(g_)::value;
             constexpr int c = g / PAIRS, q = g % PAIRS;
-            static_for<NT * G>([&](auto m_) __attribute__((always_inline)) {
-                constexpr int mi = decltype(m_)::value, t = mi >> 1, e = mi & 1;
+            static_for<NF>([&](auto m_) __attribute__((always_inline)) {
+                constexpr int mi = decltype(m_)::value, t = mi / G, e = mi % G;
                 // groups 0 .. 2 take the fragments read during the previous step; they are consumed before group 8 overwrites them
                 const i32x4 bf = g < 3 ? pb[g < 3 ? g : 0][e] : b[g % 5][e];
 #ifndef CH_ABL_NOMFMA
@@ -357,23 +375,23 @@ __device__ __forceinline__ void chain_layer_wave(const ChainK& p, char* const sm
                     b[g3 % 5][mi] = *reinterpret_cast<const i32x4*>(smem + ba[g3 % PAIRS] + (g3 / PAIRS) * 32 + mi * (16 * 96));
                 }
                 // the next step's groups 0 .. 2 (taps 0 .. 5: the two older rows of its window, complete since the last barrier)
-                if constexpr (mi >= 2 && mi < 2 + G && g >= 8 && g < 11)
-                    pb[g - 8][mi - 2] = *reinterpret_cast<const i32x4*>(smem + nb[g - 8] + (mi - 2) * (16 * 96));
+                if constexpr (mi >= G && mi < 2 * G && g >= 8 && g < 11)
+                    pb[g - 8][mi - G] = *reinterpret_cast<const i32x4*>(smem + nb[g - 8] + (mi - G) * (16 * 96));
 #endif
                 // the next step's B addresses, one VALU instruction at a time (groups 5 .. 7: ahead of their first use in group 8)
-                if constexpr (g == 5 && mi == 4) nb[0] = na0 + laneoff[0];
-                if constexpr (g == 5 && mi == 5) nb[1] = (hi_tap ? na1 : na0) + laneoff[1];
-                if constexpr (g == 6 && mi == 4) nb[2] = na1 + laneoff[2];
-                if constexpr (g == 6 && mi == 5) nb[3] = na2 + laneoff[3];
-                if constexpr (g == 7 && mi == 4) nb[4] = na2 + laneoff[4];
-                micro(std::integral_constant<int, par ^ 1>{}, std::integral_constant<int, 6 * g + mi>{});
-                if constexpr (mi == 5 && g == 4) CH_STAMP(m1);
-                if constexpr (mi == 5 && g == 9) CH_STAMP(m2);
-                if constexpr (mi == 5 && g == 14) CH_STAMP(m3);
+                if constexpr (g == 5 && mi == NF - 2) nb[0] = na0 + laneoff[0];
+                if constexpr (g == 5 && mi == NF - 1) nb[1] = (hi_tap ? na1 : na0) + laneoff[1];
+                if constexpr (g == 6 && mi == NF - 2) nb[2] = na1 + laneoff[2];
+                if constexpr (g == 6 && mi == NF - 1) nb[3] = na2 + laneoff[3];
+                if constexpr (g == 7 && mi == NF - 2) nb[4] = na2 + laneoff[4];
+                micro(std::integral_constant<int, par ^ 1>{}, std::integral_constant<int, NF * g + mi>{});
+                if constexpr (mi == NF - 1 && g == 4) CH_STAMP(m1);
+                if constexpr (mi == NF - 1 && g == 9) CH_STAMP(m2);
+                if constexpr (mi == NF - 1 && g == 14) CH_STAMP(m3);
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
-        chain_barrier(smem, layer, step_no++, m0, m1, m2, m3);
+        chain_barrier(smem, layer, step_no++, m0, m1, m2, m3, Geo::LDS);
     };
     for (int it = 0; it < nsteps; it += 2) {
         run_step(std::integral_constant<int, 0>{});
@@ -382,30 +400,33 @@ __device__ __forceinline__ void chain_layer_wave(const ChainK& p, char* const sm
 }
 
 // ---- wave 3: the input DMA, c5 and esa.conv1 on the fp32 rows of u, the stores ---------------------------------------------------------------
-template <bool BF16>
+template <bool BF16, int G>
 __device__ __forceinline__ void chain_post_wave(const ChainK& p, char* const smem, const int nsteps, const int RJ)
 {
-    constexpr int G = CH_G, NT = 3, PNT1 = 3;
+    typedef ChGeo<G> Geo;
+    constexpr int NT = 3, PNT1 = 3, NPAIR = G / 2, ODD = G & 1;
     constexpr int P1_IMG = NT * PNT1 * 1024, P2_IMG = PNT1 * 1024;
     constexpr bool plo = BF16;
     const int lane = threadIdx.x & 63, px = lane & 15, kq = lane >> 4;
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
-    // ---- input DMA: row V of the input ring = 34 pixels x 6 sixteen-byte parts, four pieces of 64 lanes.  Per job: the buffer resource
+    // ---- input DMA: row V of the input ring = COLS pixels x 6 sixteen-byte parts, PIECES pieces of 64 lanes.  Per job: the buffer resource
     // of the image and every lane's byte offset in image row 0 (CH_LOOB: a pixel outside the strip's window or the image: zero fill);
     // per row: ONE v_add per piece with the row's (wave-uniform) offset or CH_ROOB
     const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 2;
     const unsigned rowb_in = (unsigned)p.W * (unsigned)p.in_pitch * 2u;
-    ChainCur dc = chain_cursor(0, RJ);          // runs CH_D rows ahead of layer 1 after the prologue
-    unsigned dbase[4] = {CH_LOOB, CH_LOOB, CH_LOOB, CH_LOOB};
+    ChainCur dc = chain_cursor(0, RJ);          // runs Geo::D rows ahead of layer 1 after the prologue
+    unsigned dbase[Geo::PIECES];
+#pragma unroll
+    for (int i = 0; i < Geo::PIECES; ++i) dbase[i] = CH_LOOB;
     i32x4 drs = make_rsrc(p.x, img_bytes);
     auto dma_job = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < Geo::PIECES; ++i) {
             const unsigned sl = (unsigned)(i * 64 + lane);
             const unsigned pixel = sl / 6u, part = sl - pixel * 6u;
             const int gx = dc.X0 - CH_HALO + (int)pixel;
-            const bool ok = dc.ok && pixel < (unsigned)CH_COLS && (unsigned)gx < (unsigned)p.W;
+            const bool ok = dc.ok && pixel < (unsigned)Geo::COLS && (unsigned)gx < (unsigned)p.W;
             dbase[i] = ok ? (unsigned)(gx * p.in_pitch + p.in_coff) * 2u + part * 16u : CH_LOOB;
         }
         drs = make_rsrc(p.x + (size_t)dc.n * img_bytes, img_bytes);
@@ -415,17 +436,28 @@ __device__ __forceinline__ void chain_post_wave(const ChainK& p, char* const sme
     auto dma_row = [&]() __attribute__((always_inline)) {
         const int gy = dc.Y0 - CH_HALO + dc.r;
         const unsigned roff = (dc.ok && (unsigned)gy < (unsigned)p.H) ? (unsigned)gy * rowb_in : CH_ROOB;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(CH_OFF_IN + (dc.V & (CH_NR_IN - 1)) * CH_IN_PITCH));
-        const unsigned v0 = dbase[0] + roff, v1 = dbase[1] + roff, v2 = dbase[2] + roff, v3 = dbase[3] + roff;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(Geo::OFF_IN + (dc.V & (Geo::NR_IN - 1)) * Geo::IN_PITCH));
+        unsigned v[Geo::PIECES];
+#pragma unroll
+        for (int i = 0; i < Geo::PIECES; ++i) v[i] = dbase[i] + roff;
         unsigned keep;
-        // four 1 KB pieces, M0 (the LDS destination) stepped between them
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %6, 0 offen lds\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %6, 0 offen lds\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %6, 0 offen lds\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %6, 0 offen lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "s"(dst), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(drs) : "memory", "scc");
+        // 1 KB pieces, M0 (the LDS destination) stepped between them
+        if constexpr (Geo::PIECES == 4)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %6, 0 offen lds\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %6, 0 offen lds\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %6, 0 offen lds\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %6, 0 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(dst), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(drs) : "memory", "scc");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %7, 0 offen lds\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %7, 0 offen lds\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %7, 0 offen lds\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %7, 0 offen lds\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %7, 0 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(dst), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[Geo::PIECES - 1]), "s"(drs) : "memory", "scc");
     };
-    for (int i = 0; i < CH_D; ++i) {
+    static_assert(Geo::PIECES == 4 || Geo::PIECES == 5, "DMA asm blocks");
+    for (int i = 0; i < Geo::D; ++i) {
         if (chain_advance(p, dc, RJ)) dma_job();
         dma_row();
     }
@@ -450,28 +482,45 @@ __device__ __forceinline__ void chain_post_wave(const ChainK& p, char* const sme
     const bool p1act = p1s != 1.f;              // (wave-uniform: RLFB's c5 has no activation)
 
     // ---- stores: per job the images' buffer resources and the lane's byte offsets in row 0 (CH_LOOB: column outside the strip / image,
-    // channel not stored); per row one v_add per store
+    // channel not stored); per row one v_add per store.  Tiles 0 | 1 of a pixel group leave as one 16-byte store per lane
+    // (v_permlane16_swap pairs the tiles: 64 contiguous bytes per pixel); tile 2 and conv1's tile of a group PAIR likewise (the swap pairs
+    // the groups); an odd last group stores them as 8 bytes per lane
     const size_t y1_img = (size_t)p.H * p.W * p.y1_pitch * 2, y2_img = (size_t)p.H * p.W * p.y2_pitch * 2;
     const unsigned rowb1 = (unsigned)p.W * (unsigned)p.y1_pitch * 2u, rowb2 = (unsigned)p.W * (unsigned)p.y2_pitch * 2u;
     ChainCur cur = chain_cursor(CH_LAGP, RJ);
-    unsigned sA0 = CH_LOOB, sA1 = CH_LOOB, sB = CH_LOOB, sC = CH_LOOB;
+    unsigned sA[G], sB[NPAIR + ODD], sC[NPAIR + ODD];
+#pragma unroll
+    for (int e = 0; e < G; ++e) sA[e] = CH_LOOB;
+#pragma unroll
+    for (int i = 0; i < NPAIR + ODD; ++i) { sB[i] = CH_LOOB; sC[i] = CH_LOOB; }
     __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(p.y1, 0, (int)y1_img, 0x00020000);
     __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(p.y2, 0, (int)y2_img, 0x00020000);
     auto store_job = [&]() __attribute__((always_inline)) {
         const int wsj = min(p.WS, p.W - cur.X0);                       // valid output columns of this strip
         const int chA = (kq & 1) * 16 + (kq >> 1) * 8, chB = 32 + (kq >> 1) * 8, ch2 = (kq >> 1) * 8;
-        const int colB = (kq & 1) * 16 + px;
         auto off1 = [&](int col, int ch) -> unsigned {
             return (cur.ok && col < wsj && ch < p.p1_cout8) ? (unsigned)((cur.X0 + col) * p.y1_pitch + p.y1_coff + ch) * 2u : CH_LOOB;
         };
-        sA0 = off1(px, chA);
-        sA1 = off1(16 + px, chA);
-        sB = off1(colB, chB);
-        sC = (cur.ok && colB < wsj && ch2 < p.p2_cout8) ? (unsigned)((cur.X0 + colB) * p.y2_pitch + p.y2_coff + ch2) * 2u : CH_LOOB;
+        auto off2 = [&](int col, int ch) -> unsigned {
+            return (cur.ok && col < wsj && ch < p.p2_cout8) ? (unsigned)((cur.X0 + col) * p.y2_pitch + p.y2_coff + ch) * 2u : CH_LOOB;
+        };
+#pragma unroll
+        for (int e = 0; e < G; ++e) sA[e] = off1(16 * e + px, chA);
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) {
+            const int colB = 32 * i + (kq & 1) * 16 + px;               // the swap gives lanes kq & 1 the pixel of group 2 i + (kq & 1)
+            sB[i] = off1(colB, chB);
+            sC[i] = off2(colB, ch2);
+        }
+        if (ODD) {
+            sB[NPAIR] = off1(16 * (G - 1) + px, 32 + kq * 4);           // 8 bytes per lane: channels 4 kq .. of the tile
+            sC[NPAIR] = off2(16 * (G - 1) + px, kq * 4);
+        }
         r1 = __builtin_amdgcn_make_buffer_rsrc(p.y1 + (size_t)cur.n * y1_img, 0, (int)y1_img, 0x00020000);
         r2 = __builtin_amdgcn_make_buffer_rsrc(p.y2 + (size_t)cur.n * y2_img, 0, (int)y2_img, 0x00020000);
     };
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
     auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 {
         const u32x2 a = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
         const u32x2 bq = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
@@ -491,15 +540,15 @@ __device__ __forceinline__ void chain_post_wave(const ChainK& p, char* const sme
         return o;
     };
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the first CH_D input rows have landed (and the weights)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the first Geo::D input rows have landed (and the weights)
     chain_barrier();                                        // (pairs with the barrier in front of the layer waves' loops)
 
     for (int S = 0; S < nsteps; ++S) {
-        // the input row CH_D ahead of layer 1, into the slot layer 3's epilogue released a step ago
+        // the input row Geo::D ahead of layer 1, into the slot layer 3's epilogue released a step ago
         if (chain_advance(p, dc, RJ)) dma_job();
         dma_row();
         if (chain_advance(p, cur, RJ)) store_job();
-        const char* const ub = smem + CH_OFF_U + (cur.V & (CH_NR_U - 1)) * CH_U_ROW + lane * 16;
+        const char* const ub = smem + Geo::OFF_U + (cur.V & (Geo::NR_U - 1)) * Geo::U_ROW + lane * 16;
         i32x4 bs[NT][G];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -551,25 +600,31 @@ __device__ __forceinline__ void chain_post_wave(const ChainK& p, char* const sme
             pk2[e].x = pack2<BF16>(d2[e].x, d2[e].y);
             pk2[e].y = pack2<BF16>(d2[e].z, d2[e].w);
         }
-        // four stores per row: tiles 0 | 1 of each pixel group (64 B per pixel), tile 2 of both groups, conv1's tile of both groups
         {
             const int gy = cur.Y0 - CH_HALO + cur.r;
             const bool rowok = cur.ok && cur.r >= CH_HALO && cur.r < RJ - CH_HALO && gy < p.H;
             const unsigned ro1 = rowok ? (unsigned)gy * rowb1 : CH_ROOB, ro2 = rowok ? (unsigned)gy * rowb2 : CH_ROOB;
-            __builtin_amdgcn_raw_buffer_store_b128(swap16(pk1[0][0], pk1[1][0]), r1, sA0 + ro1, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(swap16(pk1[0][1], pk1[1][1]), r1, sA1 + ro1, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(swap16(pk1[2][0], pk1[2][1]), r1, sB + ro1, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(swap16(pk2[0], pk2[1]), r2, sC + ro2, 0, 0);
+#pragma unroll
+            for (int e = 0; e < G; ++e) __builtin_amdgcn_raw_buffer_store_b128(swap16(pk1[0][e], pk1[1][e]), r1, sA[e] + ro1, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NPAIR; ++i) {
+                __builtin_amdgcn_raw_buffer_store_b128(swap16(pk1[2][2 * i], pk1[2][2 * i + 1]), r1, sB[i] + ro1, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(swap16(pk2[2 * i], pk2[2 * i + 1]), r2, sC[i] + ro2, 0, 0);
+            }
+            if (ODD) {
+                __builtin_amdgcn_raw_buffer_store_b64(i32x2{(int)pk1[2][G - 1].x, (int)pk1[2][G - 1].y}, r1, sB[NPAIR] + ro1, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(i32x2{(int)pk2[G - 1].x, (int)pk2[G - 1].y}, r2, sC[NPAIR] + ro2, 0, 0);
+            }
         }
-        // Layer 1 reads input row S + 2 in the next step: it was requested in step S - 6 (or by the prologue, which waited for everything);
-        // younger than its four pieces are the four stores of step S - 6, and four pieces + four stores of each of the steps S - 5 .. S
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((4 + CH_DMA_STORES) * (CH_D - 2) + CH_DMA_STORES) : "memory");
-        chain_barrier(smem, 3, S);
+        // Layer 1 reads input row S + 2 in the next step: it was requested in step S + 2 - D (or by the prologue, which waited for
+        // everything); younger than its pieces are the stores of that step, and the pieces + stores of each of the D - 2 steps since
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((Geo::PIECES + Geo::STORES) * (Geo::D - 2) + Geo::STORES) : "memory");
+        chain_barrier(smem, 3, S, 0, 0, 0, 0, Geo::LDS);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the trailing zero-fill DMA must not outlive the block)
 }
 
-template <bool BF16>
+template <bool BF16, int G>
 __global__ __launch_bounds__(64 * CH_NW, 1) void rlfb_chain_kernel(const ChainK p)
 {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -579,14 +634,14 @@ __global__ __launch_bounds__(64 * CH_NW, 1) void rlfb_chain_kernel(const ChainK 
     int nj = 0;
     while (chain_job_index(p, nj) >= 0) ++nj;
     const int nsteps = (nj * RJ + CH_LAGP + 1) & ~1;
-    if (wv == 3) chain_post_wave<BF16>(p, smem, nsteps, RJ);
-    else if (wv == 2) chain_layer_wave<BF16, true>(p, smem, 2, nsteps, RJ);
-    else chain_layer_wave<BF16, false>(p, smem, wv, nsteps, RJ);
+    if (wv == 3) chain_post_wave<BF16, G>(p, smem, nsteps, RJ);
+    else if (wv == 2) chain_layer_wave<BF16, true, G>(p, smem, 2, nsteps, RJ);
+    else chain_layer_wave<BF16, false, G>(p, smem, wv, nsteps, RJ);
 #ifdef ESR_CHAIN_TRACE
     __syncthreads();
     if (p.trace && blockIdx.x < 4)
         for (int i = threadIdx.x; i < CH_NW * CH_TRACE_STEPS * CH_TRACE_W; i += 64 * CH_NW)
-            p.trace[(size_t)blockIdx.x * CH_NW * CH_TRACE_STEPS * CH_TRACE_W + i] = reinterpret_cast<const unsigned long long*>(smem + CH_LDS)[i];
+            p.trace[(size_t)blockIdx.x * CH_NW * CH_TRACE_STEPS * CH_TRACE_W + i] = reinterpret_cast<const unsigned long long*>(smem + ChGeo<G>::LDS)[i];
 #endif
 }
 
@@ -596,19 +651,21 @@ namespace {
 
 #ifdef ESR_CHAIN_TRACE
 unsigned long long* g_chain_trace = nullptr;
-constexpr int CH_LDS_LAUNCH = CH_LDS + CH_NW * CH_TRACE_STEPS * CH_TRACE_W * 8;
+constexpr int CH_TRACE_LDS = CH_NW * CH_TRACE_STEPS * CH_TRACE_W * 8;
 #else
-constexpr int CH_LDS_LAUNCH = CH_LDS;
+constexpr int CH_TRACE_LDS = 0;
 #endif
 
-template <bool BF16>
+template <bool BF16, int G>
 int launch_rlfb_chain(const ChainK& k, hipStream_t st)
 {
+    constexpr int LDS = ChGeo<G>::LDS + CH_TRACE_LDS;
+    static_assert(LDS <= LDS_LIMIT, "rings fit the LDS");
     static std::atomic<unsigned> attr_set[MAX_DEVICES];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
     if (!attr_set[dev].load(std::memory_order_relaxed)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rlfb_chain_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_LAUNCH);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rlfb_chain_kernel<BF16, G>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             esr_set_err("hipFuncSetAttribute(rlfb_chain_kernel, MaxDynamicSharedMemorySize)", e);
             return ESR_ERR_LAUNCH;
@@ -616,16 +673,17 @@ int launch_rlfb_chain(const ChainK& k, hipStream_t st)
         attr_set[dev].store(1u, std::memory_order_relaxed);
     }
     const int grid = k.njobs < 256 ? k.njobs : 256;
-    esr_note_kernel("rlfb_chain_kernel<%s>", esr_tf(BF16));
-    hipLaunchKernelGGL((rlfb_chain_kernel<BF16>), dim3(grid), dim3(64 * CH_NW), CH_LDS_LAUNCH, st, k);
+    esr_note_kernel("rlfb_chain_kernel<%s, %d>", esr_tf(BF16), G);
+    hipLaunchKernelGGL((rlfb_chain_kernel<BF16, G>), dim3(grid), dim3(64 * CH_NW), LDS, st, k);
     return esr_check_launch("rlfb_chain_kernel launch");
 }
 
-// Row segments per image: a block's cost is (jobs per block) x (RS + 6) + 9 steps, a step is the same work whatever the job -- take the
-// segment count with the cheapest slowest block on 256 CUs (ties: fewer, longer segments = less halo traffic).
-void chain_geometry(int n, int h, int w, int* sx, int* sy, int* rs)
+// Strip width and row segments: a block's cost is (jobs per block) x (RS + 6) + 9 steps, a step costs about the same whatever the job --
+// for each strip width take the segment count with the cheapest slowest block on 256 CUs (ties: fewer, longer segments = less halo traffic),
+// then the width whose steps x (cycles per step) is smaller.  Relative step cost measured at 32 x 256 x 256 (0.404 ms / 359 steps against 0.364 ms / 219 steps): G = 3 : G = 2 = 1.48.
+long chain_geometry_g(int n, int h, int w, int ws, int* sx, int* sy, int* rs)
 {
-    const int SX = (w + CH_WS - 1) / CH_WS;
+    const int SX = (w + ws - 1) / ws;
     long best = -1;
     int best_sy = 1;
     const int sy_max = h / 4 > 0 ? h / 4 : 1;                // RS >= 4
@@ -641,7 +699,10 @@ void chain_geometry(int n, int h, int w, int* sx, int* sy, int* rs)
     *sx = SX;
     *sy = best_sy;
     *rs = (h + best_sy - 1) / best_sy;
+    return best;
 }
+
+constexpr long CH_STEP_CYCLES_G2 = 2200, CH_STEP_CYCLES_G3 = 3250;
 
 }  // namespace
 
@@ -688,8 +749,16 @@ int esr_conv_chain_s16(const esr_chain_desc* d, void* hip_stream)
     k.p1_cout8 = p1c8; k.p2_cout8 = p2c8;
     k.slope = d->act == ESR_ACT_LRELU ? d->slope : (d->act == ESR_ACT_RELU ? 0.f : 1.f);
     k.p1_slope = d->post_act == ESR_ACT_LRELU ? d->slope : (d->post_act == ESR_ACT_RELU ? 0.f : 1.f);
-    k.WS = CH_WS;
-    chain_geometry(d->n, d->h, d->w, &k.SX, &k.SY, &k.RS);
+    int g = 2;
+    {
+        int sx2, sy2, rs2, sx3, sy3, rs3;
+        const long c2 = chain_geometry_g(d->n, d->h, d->w, ChGeo<2>::WS, &sx2, &sy2, &rs2) * CH_STEP_CYCLES_G2;
+        const long c3 = chain_geometry_g(d->n, d->h, d->w, ChGeo<3>::WS, &sx3, &sy3, &rs3) * CH_STEP_CYCLES_G3;
+        const char* force = getenv("ESR_CHAIN_G");          // (research: force a strip width)
+        if (force ? force[0] == '3' : c3 < c2) { g = 3; k.SX = sx3; k.SY = sy3; k.RS = rs3; }
+        else { k.SX = sx2; k.SY = sy2; k.RS = rs2; }
+    }
+    k.WS = g == 3 ? ChGeo<3>::WS : ChGeo<2>::WS;
     const double jobs = (double)d->n * k.SX * k.SY;
     if (jobs >= 2147483647.0) return ESR_ERR_UNSUPPORTED;
     k.njobs = (int)jobs;
@@ -697,7 +766,8 @@ int esr_conv_chain_s16(const esr_chain_desc* d, void* hip_stream)
     k.trace = g_chain_trace;
 #endif
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    return d->storage == ESR_STORE_BF16 ? launch_rlfb_chain<true>(k, st) : launch_rlfb_chain<false>(k, st);
+    if (g == 3) return d->storage == ESR_STORE_BF16 ? launch_rlfb_chain<true, 3>(k, st) : launch_rlfb_chain<false, 3>(k, st);
+    return d->storage == ESR_STORE_BF16 ? launch_rlfb_chain<true, 2>(k, st) : launch_rlfb_chain<false, 2>(k, st);
 }
 
 #ifdef ESR_CHAIN_TRACE

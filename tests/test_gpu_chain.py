@@ -34,10 +34,23 @@ def _separate(x, ws, bs, w5, b5, w1, b1, nf):
     return v, c1
 
 
+@pytest.fixture(params=["2", "3"])
+def strip_groups(request):
+    """both strip widths of the kernel (G = 2: 28 columns, G = 3: 44), forced through the research switch ESR_CHAIN_G"""
+    import os
+    old = os.environ.get("ESR_CHAIN_G")
+    os.environ["ESR_CHAIN_G"] = request.param
+    yield request.param
+    if old is None:
+        del os.environ["ESR_CHAIN_G"]
+    else:
+        os.environ["ESR_CHAIN_G"] = old
+
+
 @pytest.mark.parametrize("compute", ["bf16", "f16"])
-@pytest.mark.parametrize("n,h,w", [(1, 40, 56), (2, 23, 37), (1, 17, 15), (1, 64, 28), (3, 33, 29), (1, 5, 90), (1, 96, 61)])
-def test_chain_equals_separate_launches(compute, n, h, w):
-    """ragged strips (w not a multiple of 28), one-strip and one-segment images, several jobs per block: v and c1 bit for bit"""
+@pytest.mark.parametrize("n,h,w", [(1, 40, 56), (2, 23, 37), (1, 17, 15), (1, 64, 28), (3, 33, 29), (1, 5, 90), (1, 96, 61), (2, 50, 44), (1, 30, 133)])
+def test_chain_equals_separate_launches(compute, n, h, w, strip_groups):
+    """ragged strips (w not a multiple of the strip width), one-strip and one-segment images, several jobs per block: v and c1 bit for bit"""
     from ntire2022_esr_amd import ops
     dt = DT[compute]
     nf = 46
@@ -57,7 +70,7 @@ def test_chain_equals_separate_launches(compute, n, h, w):
 
 
 @pytest.mark.parametrize("compute", ["bf16", "f16"])
-def test_chain_matches_fp64_reference(compute):
+def test_chain_matches_fp64_reference(compute, strip_groups):
     """... and directly against ATen in fp64 on the blobs' effective weights (one rounding per stored tensor: t1, t2, v, c1)"""
     import torch.nn.functional as F
     from ntire2022_esr_amd import ops
@@ -91,7 +104,7 @@ def test_chain_matches_fp64_reference(compute):
 
 
 @pytest.mark.parametrize("compute,shape", [("bf16", (1, 3, 64, 80)), ("bf16", (2, 3, 40, 56)), ("f16", (1, 3, 45, 61))])
-def test_rlfn_with_chain_equals_without(compute, shape):
+def test_rlfn_with_chain_equals_without(compute, shape, strip_groups):
     """the whole network: fuse_chain on / off give bit-identical outputs (the checkpoint's weights)"""
     from ntire2022_esr_amd import RLFN_cut
     sd = load_sd_torch("team04_rlfn")

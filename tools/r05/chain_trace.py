@@ -99,3 +99,5 @@ if __name__ == "__main__":
         run(*a)
         if len(sys.argv) < 5:
             run(32, 256, 256)
+            os.environ["ESR_CHAIN_G"] = "3"
+            run(32, 256, 256)

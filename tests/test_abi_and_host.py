@@ -375,3 +375,61 @@ def test_wino_packer_is_G_g_Gt_rounded_once():
     assert torch.equal(u2, U2) and float(b2.abs().max()) == 0.0
     # everything that is not a (slot, cout) of the logical tensor is zero: total mass matches
     assert abs(float(blob2.double().abs().sum()) - float(U2.double().abs().sum())) < 1e-6 * float(U2.double().abs().sum())
+
+
+def test_chain_descriptor_validation_and_rlfn_plan_without_gpu():
+    """esr_conv_chain_s16 (ABI v11) validates before it launches; RLFN's 16-bit plans hold one chain op per RLFB whose sub-ops keep the
+    complexity counters of the reference's five convolutions; fp32 plans and fuse_chain = False keep separate ops; graphs: argument checks."""
+    import torch
+    from ntire2022_esr_amd import RLFN_cut, _lib as L
+    from ntire2022_esr_amd.engine import Plan
+    from ntire2022_esr_amd.summary import model_complexity
+    lib = L.lib()
+    buf = (ctypes.c_float * 64)()
+    a = ctypes.addressof(buf)
+
+    def desc(**kw):
+        d = L.ChainDesc()
+        d.n, d.h, d.w, d.n_layers, d.cin, d.cmid, d.cout = 1, 32, 40, 3, 46, 48, 46
+        d.act, d.slope, d.res_mode = L.ACT_LRELU, 0.05, L.RES_POST_ACT
+        d.storage = d.compute = L.STORE["bf16"]
+        d.inp, d.post_out, d.post2_out = L.View(a, 48, 0), L.View(a, 48, 0), L.View(a, 16, 0)
+        for i in range(3):
+            d.wpacked[i] = a
+        d.post_wpacked, d.post2_wpacked, d.post_cout, d.post2_cout = a, a, 46, 16
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+
+    assert lib.esr_conv_chain_supported(ctypes.byref(desc())) == 1
+    assert lib.esr_conv_chain_supported(ctypes.byref(desc(storage=0, compute=0))) == 0            # 16-bit storage only
+    assert lib.esr_conv_chain_supported(ctypes.byref(desc(n_layers=2))) == 0
+    assert lib.esr_conv_chain_supported(ctypes.byref(desc(cmid=64))) == 0                          # three K chunks per layer
+    assert lib.esr_conv_chain_supported(ctypes.byref(desc(res_mode=L.RES_PRE_ACT))) == 0
+    assert lib.esr_conv_chain_supported(ctypes.byref(desc(act=L.ACT_GELU))) == 0
+    assert lib.esr_conv_chain_supported(ctypes.byref(desc(post2_cout=24))) == 0
+    assert lib.esr_conv_chain_s16(None, None) == -1
+    assert lib.esr_conv_chain_s16(ctypes.byref(desc(post_out=L.View(None, 48, 0))), None) == -1     # null output
+    assert lib.esr_conv_chain_s16(ctypes.byref(desc(cmid=64)), None) == -2
+    assert lib.esr_conv_chain_s16(ctypes.byref(desc(inp=L.View(a, 48, 8))), None) == -1            # the 48 channels would leave the pixel
+    assert lib.esr_graph_create(None, 0, None, None, None) == -1 and lib.esr_graph_launch(None, None, None, None) == -1
+    assert lib.esr_graph_nodes(None) == 0
+    lib.esr_graph_destroy(None)
+
+    m = RLFN_cut()
+    ref = model_complexity(m, (3, 64, 64))
+    for store, fuse, nchain in (("bf16", True, 4), ("f16", True, 4), ("bf16", False, 0), ("f32", True, 0)):
+        m.fuse_chain = fuse
+        plan = Plan(1, 64, 64, store)
+        m._build_plan(plan, 3)
+        assert sum(o["kind"] == "chain" for o in plan.ops) == nchain, (store, fuse)
+        for o in plan.ops:
+            if o["kind"] == "chain":
+                assert [s["w"].split(".")[-1] for s in o["replaces"]] == ["c1_r", "c2_r", "c3_r"] and o["replaces"][-1]["post"]["post2"] is not None
+        terms = [m._complexity_terms(plan, o) for o in plan.ops]
+        flops, acts, nconv = (sum(t[i] for t in terms) for i in range(3))
+        assert (float(flops), float(acts), int(nconv)) == (ref["flops"], ref["activations"], ref["num_conv"]), (store, fuse)
+    m.fuse_chain = True
+    assert {"B1.c1_r", "B2.c2_r", "B4.c3_r"} <= m._s16_convs() if m.set_compute("bf16") else False
+    assert {"B1.c5", "B3.esa.conv1"} <= m._post_convs()
+    m.set_compute("f32")

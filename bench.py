@@ -132,8 +132,9 @@ _CAL = {}
 
 
 def calibration(device):
-    """Measured on this device, once per process: (a) what an EMPTY HIP event pair reports (esr_event_pair_ms) -- esr_run_ops_profiled brackets
-    every launch with one, which adds ~2.5 us to a 13 us single-image kernel: the per-launch averages below have it subtracted; (b) the
+    """Measured on this device, once per process: (a) what per-launch HIP event brackets add to a launch (esr_event_pair_ms: a probe kernel
+    launched n times inside one pair and n times with a pair each) -- esr_run_ops_profiled brackets every launch, which adds ~2.5 us
+    to a 13 us single-image kernel: the per-launch averages below have it subtracted; (b) the
     read + write rate of a plain copy kernel at a 2 x 16 MiB working set (esr_bw_probe) -- what a streaming kernel can reach on tensors the
     previous launch left in the 256 MB Infinity Cache; single-image launches are priced against THIS, not against 8 TB/s of HBM."""
     import ctypes
@@ -144,7 +145,7 @@ def calibration(device):
         lib = L.lib()
         st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
         pair = ctypes.c_double(0.0)
-        L.check(lib.esr_event_pair_ms(st, 200, ctypes.byref(pair)), "esr_event_pair_ms")
+        L.check(lib.esr_event_pair_ms(st, 100, ctypes.byref(pair)), "esr_event_pair_ms")
         buf = torch.empty(2 * (16 << 20), dtype=torch.uint8, device=device)
         gbs = ctypes.c_double(0.0)
         L.check(lib.esr_bw_probe(ctypes.c_void_p(buf.data_ptr()), 16 << 20, 64, st, ctypes.byref(gbs)), "esr_bw_probe")

@@ -521,9 +521,10 @@ void esr_prof_destroy(esr_profiler* prof);
  * kernel trace against (the reference has torch.profiler for that). */
 int  esr_prof_kernel_symbol(esr_profiler* prof, int op, char* buf, size_t n);
 
-/* ABI v11 -- measurement helpers of bench.py (csrc/esr_metrics.hip): esr_event_pair_ms = the elapsed time an EMPTY hipEvent pair reports on
- * the stream (median of n): what esr_run_ops_profiled's per-launch brackets add to a kernel's own duration; esr_bw_probe = read + write GB/s a
- * plain copy kernel reaches inside `buf` (2 x bytes, device memory) when it repeats the pass `reps` times in one launch: the ceiling of a
+/* ABI v11 -- measurement helpers of bench.py (csrc/esr_metrics.hip; they allocate and synchronise: NOT for a timed region).
+ * esr_event_pair_ms = what per-launch hipEvent brackets add to a launch: n launches of a probe kernel timed by one pair around all of them
+ * and by a pair around each, (sum - whole) / n -- the inflation of esr_run_ops_profiled's per-op numbers; esr_bw_probe = read + write
+ * GB/s a plain copy kernel reaches inside `buf` (2 x bytes, device memory) when it repeats the pass `reps` times in one launch: the ceiling of a
  * streaming kernel at that working set (a tensor the previous launch wrote is Infinity-Cache resident at single-image sizes). */
 int esr_event_pair_ms(void* hip_stream, int n, double* ms_out);
 int esr_bw_probe(void* buf, size_t bytes, int reps, void* hip_stream, double* gbs_out);

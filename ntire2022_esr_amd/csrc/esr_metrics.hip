@@ -189,32 +189,59 @@ extern "C" int esr_bw_probe(void* buf, size_t bytes, int reps, void* hip_stream,
     return ESR_OK;
 }
 
-// esr_event_pair_ms: the elapsed time an EMPTY hipEvent pair reports on `hip_stream` (median of n pairs): what esr_run_ops_profiled's
-// per-launch brackets add to a kernel's own duration (~2.5 us: a fifth of a 13 us single-image launch)
+// esr_event_pair_ms: what per-launch hipEvent brackets add to a launch -- n launches of a ~15 us copy kernel timed (a) by ONE pair around all
+// of them and (b) by a pair around each: (sum of (b) - (a)) / n.  That is the inflation of esr_run_ops_profiled's per-op numbers relative to
+// the kernels running back to back (~2.5 us: a fifth of a 13 us single-image launch; it agrees with rocprofv3's kernel durations to a few
+// tenths of a microsecond, where an EMPTY pair -- 4.8 us -- or a device-stamped probe -- 11 us, it also sees the dispatch latency -- do not).
+namespace {
+__global__ __launch_bounds__(256) void event_probe_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+}  // namespace
+
 extern "C" int esr_event_pair_ms(void* hip_stream, int n, double* ms_out)
 {
-    if (n <= 0 || n > 4096 || !ms_out) return ESR_ERR_BAD_ARG;
+    if (n <= 0 || n > 1024 || !ms_out) return ESR_ERR_BAD_ARG;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    hipEvent_t* ev = new hipEvent_t[2 * n];
+    const size_t bytes = 24u << 20;
+    char* buf = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&buf), 2 * bytes) != hipSuccess) return ESR_ERR_LAUNCH;
+    hipEvent_t* ev = new hipEvent_t[2 * n + 2];
     int made = 0;
-    for (; made < 2 * n; ++made)
+    for (; made < 2 * n + 2; ++made)
         if (hipEventCreate(&ev[made]) != hipSuccess) break;
-    int rc = made == 2 * n ? ESR_OK : ESR_ERR_LAUNCH;
+    int rc = made == 2 * n + 2 ? ESR_OK : ESR_ERR_LAUNCH;
+    auto launch = [&]() {
+        hipLaunchKernelGGL(event_probe_kernel, dim3(1024), dim3(256), 0, st, reinterpret_cast<const uint4*>(buf), reinterpret_cast<uint4*>(buf + bytes), bytes / 16);
+    };
+    double together = 0.0, apart = 0.0;
     if (rc == ESR_OK) {
-        for (int i = 0; i < n; ++i) { (void)hipEventRecord(ev[2 * i], st); (void)hipEventRecord(ev[2 * i + 1], st); }
-        if (hipEventSynchronize(ev[2 * n - 1]) != hipSuccess) rc = ESR_ERR_LAUNCH;
+        (void)hipMemsetAsync(buf, 0, 2 * bytes, st);
+        for (int i = 0; i < 4; ++i) launch();
+        (void)hipEventRecord(ev[2 * n], st);
+        for (int i = 0; i < n; ++i) launch();
+        (void)hipEventRecord(ev[2 * n + 1], st);
+        for (int i = 0; i < n; ++i) {
+            (void)hipEventRecord(ev[2 * i], st);
+            launch();
+            (void)hipEventRecord(ev[2 * i + 1], st);
+        }
+        rc = esr_check_launch("event_probe_kernel launch");
+        if (rc == ESR_OK && hipStreamSynchronize(st) != hipSuccess) rc = ESR_ERR_LAUNCH;
     }
     if (rc == ESR_OK) {
-        float* v = new float[n];
-        for (int i = 0; i < n && rc == ESR_OK; ++i)
-            if (hipEventElapsedTime(&v[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = ESR_ERR_LAUNCH;
-        if (rc == ESR_OK) {
-            for (int i = 1; i < n; ++i) { const float x = v[i]; int j = i - 1; while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; --j; } v[j + 1] = x; }
-            *ms_out = v[n / 2];
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev[2 * n], ev[2 * n + 1]) != hipSuccess) rc = ESR_ERR_LAUNCH;
+        together = ms;
+        for (int i = 0; i < n && rc == ESR_OK; ++i) {
+            if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = ESR_ERR_LAUNCH;
+            apart += ms;
         }
-        delete[] v;
+        if (rc == ESR_OK) *ms_out = apart > together ? (apart - together) / n : 0.0;
     }
     for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
     delete[] ev;
+    (void)hipFree(buf);
     return rc;
 }

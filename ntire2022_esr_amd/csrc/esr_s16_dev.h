@@ -121,6 +121,8 @@ __device__ __forceinline__ f32x4 gelu16x4(f32x4 v)
     // (round 5: the same polynomial as 12 PLAIN VALU instructions per value -- v_pk_fma_f32 costs a wave ~4x a plain instruction beside MFMAs,
     // tools/r05/mfma_valu_probe.hip -- was measured and LOST: 48 live scalars per fragment push conv48r / conv48rq into scratch (BSRN fp16
     // 2710 -> 1600 images/s), tools/r05/f_gelu.sh)
+    // (also measured: the scalar C++ form under -fno-slp-vectorize, conv48rq 0.35 -> 0.39-0.41 ms; -fno-slp-vectorize alone: no difference,
+    // tools/r05/h_slp.sh)
     const f32x2 a = gelu16x2(f32x2{v.x, v.y}), b = gelu16x2(f32x2{v.z, v.w});
     return f32x4{a.x, a.y, b.x, b.y};
 }

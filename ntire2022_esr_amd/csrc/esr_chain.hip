@@ -104,13 +104,7 @@ struct ChainCur {
 
 __device__ __forceinline__ int chain_job_index(const ChainK& p, int k)
 {
-    const int G = gridDim.x;
-    const int base = k * G;
-    if (k < 0 || base >= p.njobs) return -1;
-    int off = blockIdx.x;
-    if ((G & 7) == 0 && base + G <= p.njobs) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);      // neighbouring strips on one XCD
-    const int t = base + off;
-    return t < p.njobs ? t : -1;
+    return k < 0 ? -1 : s16_tile_index(k, p.njobs);          // (the kernels' common walk: neighbouring strips on one XCD)
 }
 
 __device__ __forceinline__ void chain_decode(const ChainK& p, ChainCur& c)
@@ -519,13 +513,8 @@ __device__ __forceinline__ void chain_post_wave(const ChainK& p, char* const sme
         r1 = __builtin_amdgcn_make_buffer_rsrc(p.y1 + (size_t)cur.n * y1_img, 0, (int)y1_img, 0x00020000);
         r2 = __builtin_amdgcn_make_buffer_rsrc(p.y2 + (size_t)cur.n * y2_img, 0, (int)y2_img, 0x00020000);
     };
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     typedef int i32x2 __attribute__((ext_vector_type(2)));
-    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 {
-        const u32x2 a = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
-        const u32x2 bq = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
-        return i32x4{(int)a.x, (int)bq.x, (int)a.y, (int)bq.y};
-    };
+    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 { return s16_swap16(X, Y); };
     auto hl = [&](f32x4 v) __attribute__((always_inline)) -> i32x4 {      // an fp32 fragment as a B operand: 16-bit high parts | low parts
         i32x4 o;
         o.x = (int)pack2<BF16>(v.x, v.y); o.y = (int)pack2<BF16>(v.z, v.w);

@@ -175,14 +175,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
     // ---- tile walk (persistent; XCD-aware order as in conv_f32_kernel) ---------------------------------------------
     const int ntiles = p.N * p.tiles_y * p.tiles_x;
     const int G = gridDim.x;
-    auto tile_index = [&](int k) -> int {
-        const int base = k * G;
-        if (base >= ntiles) return -1;
-        int off = blockIdx.x;
-        if ((G & 7) == 0 && base + G <= ntiles) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-        const int t = base + off;
-        return t < ntiles ? t : -1;
-    };
+    auto tile_index = [&](int k) -> int { return s16_tile_index(k, ntiles); };
     auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) {
         const kparg_t q = KP();
         const unsigned mx = q->magic_x, my = q->magic_y;
@@ -546,11 +539,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
     uint2 pk[NT][2];                     // rounded rows r - 1 (even), r (odd) of the finished tile
     uint2 pkl[HILO ? NT : 1][2];         // HILO: their low parts
     uint2 pk1[PNT1 > 0 ? PNT1 : 1][2], pk2[2];          // ... of the post chain's results
-    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 {
-        const u32x2 a = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
-        const u32x2 b = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
-        return i32x4{(int)a.x, (int)b.x, (int)a.y, (int)b.y};
-    };
+    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 { return s16_swap16(X, Y); };
     auto store16 = [&](uint2 X, uint2 Y, unsigned v0, unsigned v1, int r) __attribute__((always_inline)) {
         const i32x4 o = swap16(X, Y);
         __builtin_amdgcn_raw_buffer_store_b128(o, __builtin_amdgcn_make_buffer_rsrc(e_y0, 0, e_y0n, 0x00020000), v0 + (unsigned)r * e_rowb0, 0, 0);
@@ -888,23 +877,8 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
 
     const int ntiles = p.N * p.tiles_y * p.tiles_x;
     const int G = gridDim.x;
-    auto tile_index = [&](int k) -> int {
-        const int base = k * G;
-        if (base >= ntiles) return -1;
-        int off = blockIdx.x;
-        if ((G & 7) == 0 && base + G <= ntiles) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-        const int t = base + off;
-        return t < ntiles ? t : -1;
-    };
-    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) {
-        const unsigned mx = p.magic_x, my = p.magic_y;
-        const int tq = mx ? (int)__umulhi((unsigned)t, mx) : t;
-        const int tx = t - tq * p.tiles_x;
-        n = my ? (int)__umulhi((unsigned)tq, my) : tq;
-        const int ty = tq - n * p.tiles_y;
-        x0 = tx * TILE;
-        y0 = ty * (4 * RW);
-    };
+    auto tile_index = [&](int k) -> int { return s16_tile_index(k, ntiles); };
+    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) { s16_tile_coords(t, p.magic_x, p.magic_y, p.tiles_x, p.tiles_y, (4 * RW), n, x0, y0); };
     const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 2;
     // piece i of this wave of the tile (n, x0, y0) into stage `slot`; nothing valid (behind the last tile): zeros
     auto dma_piece = [&](int i, bool valid, int n, int x0, int y0, int slot) __attribute__((always_inline)) {
@@ -949,11 +923,7 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
     }
     const int c_off = ((wv * RW + 1) * TH + px + 1) * PIXB + kq * 8;      // centre pixel of row 0 of the wave: channels 16 c + 4 kq .. +3 at + 32 c
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 {
-        const u32x2 a = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
-        const u32x2 b = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
-        return i32x4{(int)a.x, (int)b.x, (int)a.y, (int)b.y};
-    };
+    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 { return s16_swap16(X, Y); };
     const float slope = gelu ? 1.f : p.slope;
     const size_t y_img = (size_t)p.H * p.W * p.y0_pitch * 2;
     const unsigned rowb = (unsigned)p.W * (unsigned)p.y0_pitch * 2u;
@@ -1163,23 +1133,8 @@ __global__ __launch_bounds__(256, 1) void conv48rq_kernel(const S16K p)
 
     const int ntiles = p.N * p.tiles_y * p.tiles_x;
     const int G = gridDim.x;
-    auto tile_index = [&](int k) -> int {
-        const int base = k * G;
-        if (base >= ntiles) return -1;
-        int off = blockIdx.x;
-        if ((G & 7) == 0 && base + G <= ntiles) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-        const int t = base + off;
-        return t < ntiles ? t : -1;
-    };
-    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) {
-        const unsigned mx = p.magic_x, my = p.magic_y;
-        const int tq = mx ? (int)__umulhi((unsigned)t, mx) : t;
-        const int tx = t - tq * p.tiles_x;
-        n = my ? (int)__umulhi((unsigned)tq, my) : tq;
-        const int ty = tq - n * p.tiles_y;
-        x0 = tx * TILE;
-        y0 = ty * (4 * RW);
-    };
+    auto tile_index = [&](int k) -> int { return s16_tile_index(k, ntiles); };
+    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) { s16_tile_coords(t, p.magic_x, p.magic_y, p.tiles_x, p.tiles_y, (4 * RW), n, x0, y0); };
     const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 2;
     // piece i of this wave of the tile (n, x0, y0) into stage `slot`; nothing valid (behind the last tile): zeros
     auto dma_piece = [&](int i, bool valid, int n, int x0, int y0, int slot) __attribute__((always_inline)) {
@@ -1224,11 +1179,7 @@ __global__ __launch_bounds__(256, 1) void conv48rq_kernel(const S16K p)
     }
     const int c_off = ((wv * RW + 1) * TH + px + 1) * PIXB + kq * 8;      // centre pixel of row 0 of the wave: channels 16 c + 4 kq .. +3 at + 32 c
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 {
-        const u32x2 a = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
-        const u32x2 b = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
-        return i32x4{(int)a.x, (int)b.x, (int)a.y, (int)b.y};
-    };
+    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 { return s16_swap16(X, Y); };
     const float slope = gelu ? 1.f : p.slope;
     const size_t y_img = (size_t)p.H * p.W * p.y0_pitch * 2;
     const unsigned rowb = (unsigned)p.W * (unsigned)p.y0_pitch * 2u;
@@ -1475,23 +1426,8 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(const S16K p)
 
     const int ntiles = p.N * p.tiles_y * p.tiles_x;
     const int G = gridDim.x;
-    auto tile_index = [&](int k) -> int {
-        const int base = k * G;
-        if (base >= ntiles) return -1;
-        int off = blockIdx.x;
-        if ((G & 7) == 0 && base + G <= ntiles) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-        const int t = base + off;
-        return t < ntiles ? t : -1;
-    };
-    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) {
-        const unsigned mx = p.magic_x, my = p.magic_y;
-        const int tq = mx ? (int)__umulhi((unsigned)t, mx) : t;
-        const int tx = t - tq * p.tiles_x;
-        n = my ? (int)__umulhi((unsigned)tq, my) : tq;
-        const int ty = tq - n * p.tiles_y;
-        x0 = tx * TILE;
-        y0 = ty * (4 * RW);
-    };
+    auto tile_index = [&](int k) -> int { return s16_tile_index(k, ntiles); };
+    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) { s16_tile_coords(t, p.magic_x, p.magic_y, p.tiles_x, p.tiles_y, (4 * RW), n, x0, y0); };
     const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 2;
     // piece i of this wave of the tile (n, x0, y0) into stage `slot`; nothing valid (behind the last tile): zeros
     auto dma_piece = [&](int i, bool valid, int n, int x0, int y0, int slot) __attribute__((always_inline)) {
@@ -1537,11 +1473,7 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(const S16K p)
     const int c_off = ((wv * RW + 1) * TH + px + 1) * PIXB + kq * 8;      // centre pixel of row 0 of the wave: channels 16 c + 4 kq .. +3 at + 32 c
     const char* const w3 = smem + W3 + lane * 16;                           // chunk 3's fragments: + (q * NT + t) KB
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 {
-        const u32x2 a = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
-        const u32x2 b = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
-        return i32x4{(int)a.x, (int)b.x, (int)a.y, (int)b.y};
-    };
+    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 { return s16_swap16(X, Y); };
     const float slope = p.slope;
     const size_t y_img = (size_t)p.H * p.W * p.y0_pitch * 2;
     const unsigned rowb = (unsigned)p.W * (unsigned)p.y0_pitch * 2u;
@@ -1751,23 +1683,8 @@ __global__ __launch_bounds__(256, 1) void conv64rq_kernel(const S16K p)
 
     const int ntiles = p.N * p.tiles_y * p.tiles_x;
     const int G = gridDim.x;
-    auto tile_index = [&](int k) -> int {
-        const int base = k * G;
-        if (base >= ntiles) return -1;
-        int off = blockIdx.x;
-        if ((G & 7) == 0 && base + G <= ntiles) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-        const int t = base + off;
-        return t < ntiles ? t : -1;
-    };
-    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) {
-        const unsigned mx = p.magic_x, my = p.magic_y;
-        const int tq = mx ? (int)__umulhi((unsigned)t, mx) : t;
-        const int tx = t - tq * p.tiles_x;
-        n = my ? (int)__umulhi((unsigned)tq, my) : tq;
-        const int ty = tq - n * p.tiles_y;
-        x0 = tx * TILE;
-        y0 = ty * (4 * RW);
-    };
+    auto tile_index = [&](int k) -> int { return s16_tile_index(k, ntiles); };
+    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) { s16_tile_coords(t, p.magic_x, p.magic_y, p.tiles_x, p.tiles_y, (4 * RW), n, x0, y0); };
     const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 2;
     // piece i of this wave of the tile (n, x0, y0) into stage `slot`; nothing valid (behind the last tile): zeros
     auto dma_piece = [&](int i, bool valid, int n, int x0, int y0, int slot) __attribute__((always_inline)) {
@@ -1813,11 +1730,7 @@ __global__ __launch_bounds__(256, 1) void conv64rq_kernel(const S16K p)
     const int c_off = ((wv * RW + 1) * TH + px + 1) * PIXB + kq * 8;      // centre pixel of row 0 of the wave: channels 16 c + 4 kq .. +3 at + 32 c
     const char* const w3 = smem + W3 + lane * 16;                           // chunk 3's fragments: + (q * NT + t) KB
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 {
-        const u32x2 a = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
-        const u32x2 b = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
-        return i32x4{(int)a.x, (int)b.x, (int)a.y, (int)b.y};
-    };
+    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 { return s16_swap16(X, Y); };
     const float slope = p.slope;
     const size_t y_img = (size_t)p.H * p.W * p.y0_pitch * 2;
     const unsigned rowb = (unsigned)p.W * (unsigned)p.y0_pitch * 2u;
@@ -2076,23 +1989,8 @@ __global__ __launch_bounds__(256, 1) void conv48rp_kernel(const S16K p)
 
     const int ntiles = p.N * p.tiles_y * p.tiles_x;
     const int G = gridDim.x;
-    auto tile_index = [&](int k) -> int {
-        const int base = k * G;
-        if (base >= ntiles) return -1;
-        int off = blockIdx.x;
-        if ((G & 7) == 0 && base + G <= ntiles) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-        const int t = base + off;
-        return t < ntiles ? t : -1;
-    };
-    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) {
-        const unsigned mx = p.magic_x, my = p.magic_y;
-        const int tq = mx ? (int)__umulhi((unsigned)t, mx) : t;
-        const int tx = t - tq * p.tiles_x;
-        n = my ? (int)__umulhi((unsigned)tq, my) : tq;
-        const int ty = tq - n * p.tiles_y;
-        x0 = tx * TILE;
-        y0 = ty * 16;
-    };
+    auto tile_index = [&](int k) -> int { return s16_tile_index(k, ntiles); };
+    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) { s16_tile_coords(t, p.magic_x, p.magic_y, p.tiles_x, p.tiles_y, 16, n, x0, y0); };
     const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 2, res_bytes = (size_t)p.H * p.W * p.res_pitch * 2;
     auto dma_in = [&](int i, bool valid, int n, int x0, int y0, int slot) __attribute__((always_inline)) {
         const int pc = wv + 4 * i;

@@ -186,4 +186,36 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, size_t bytes)
     return r;
 }
 
+// ---- shared by every persistent 16-bit kernel (esr_s16.hip; round 5: one definition instead of one lambda per kernel) ---------------------
+// the k-th tile of this block: XCD-aware order (blocks are dealt round-robin to the 8 XCDs: the eight blocks of an XCD take neighbouring tiles,
+// whose halos then meet in that XCD's L2), -1 behind the last tile
+__device__ __forceinline__ int s16_tile_index(int k, int ntiles)
+{
+    const int G = gridDim.x;
+    const int base = k * G;
+    if (base >= ntiles) return -1;
+    int off = blockIdx.x;
+    if ((G & 7) == 0 && base + G <= ntiles) off = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int t = base + off;
+    return t < ntiles ? t : -1;
+}
+// tile t -> image n, origin (x0, y0): t / tiles by multiplication (magic = ceil(2^32 / tiles), 0 for tiles == 1: the host checks the range)
+__device__ __forceinline__ void s16_tile_coords(int t, unsigned mx, unsigned my, int tiles_x, int tiles_y, int tile_h, int& n, int& x0, int& y0)
+{
+    const int tq = mx ? (int)__umulhi((unsigned)t, mx) : t;
+    const int tx = t - tq * tiles_x;
+    n = my ? (int)__umulhi((unsigned)tq, my) : tq;
+    const int ty = tq - n * tiles_y;
+    x0 = tx * TILE;
+    y0 = ty * tile_h;
+}
+// two D-fragment halves (tiles a | b: 4 channels per lane each) -> 8 consecutive channels per lane: the store epilogues' 16-byte pieces
+__device__ __forceinline__ i32x4 s16_swap16(uint2 X, uint2 Y)
+{
+    typedef unsigned s16_u32x2 __attribute__((ext_vector_type(2)));
+    const s16_u32x2 a = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
+    const s16_u32x2 b = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
+    return i32x4{(int)a.x, (int)b.x, (int)a.y, (int)b.y};
+}
+
 }  // namespace

@@ -365,12 +365,14 @@ __device__ __forceinline__ void chain_layer_wave(const ChainK& p, char* const sm
                 // lgkmcnt(0) in front of the first use of a fragment read before it: nothing is outstanding there yet)
 #ifndef CH_ABL_NOBREAD
                 if constexpr (mi < G && g + 3 < NG) {
-                    constexpr int g3 = g + 3;
-                    b[g3 % 5][mi] = *reinterpret_cast<const i32x4*>(smem + ba[g3 % PAIRS] + (g3 / PAIRS) * 32 + mi * (16 * 96));
+                    // (pixel group G - 1 first: the group's first MFMA uses group 0's fragment, the YOUNGEST read -- LDS returns in order, so the one
+                    // s_waitcnt in front of it covers the others and hipcc emits no second one: 11 instructions less per step)
+                    constexpr int g3 = g + 3, e3 = G - 1 - mi;
+                    b[g3 % 5][e3] = *reinterpret_cast<const i32x4*>(smem + ba[g3 % PAIRS] + (g3 / PAIRS) * 32 + e3 * (16 * 96));
                 }
                 // the next step's groups 0 .. 2 (taps 0 .. 5: the two older rows of its window, complete since the last barrier)
                 if constexpr (mi >= G && mi < 2 * G && g >= 8 && g < 11)
-                    pb[g - 8][mi - G] = *reinterpret_cast<const i32x4*>(smem + nb[g - 8] + (mi - G) * (16 * 96));
+                    pb[g - 8][2 * G - 1 - mi] = *reinterpret_cast<const i32x4*>(smem + nb[g - 8] + (2 * G - 1 - mi) * (16 * 96));
 #endif
                 // the next step's B addresses, one VALU instruction at a time (groups 5 .. 7: ahead of their first use in group 8)
                 if constexpr (g == 5 && mi == NF - 2) nb[0] = na0 + laneoff[0];

@@ -267,41 +267,80 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
     constexpr int P0_IMGS = 2 * NT0 * NP, P1_IMGS = LO1 * NT1 * NT0;
     __shared__ __attribute__((aligned(16))) unsigned short spimg[(P0_IMGS + P1_IMGS > 0 ? P0_IMGS + P1_IMGS : 1) * 512];
     __shared__ __attribute__((aligned(16))) float spbias[(NT0 + NT1 > 0 ? NT0 + NT1 : 1) * 16];
+    // Prologue (round 5): every global load of the block's weight images is issued BEFORE the first one is waited for.  As plain loops
+    // (for e = tid; e < n; e += 256) hipcc kept one load in flight -- 18 + 6 dependent L2 round trips, 3-7 us in front of a block whose
+    // waves then work for 8-16 us: a fifth of a single image's launch.  The trip counts are compile-time constants, the image index of
+    // a pass too (512 elements per image, 256 threads: pass i builds half of image i / 2).
+    constexpr int PCOPY = ((P0_IMGS + P1_IMGS) * 64 + 255) / 256;
+    i32x4_t pcp[PCOPY > 0 ? PCOPY : 1];
+    float pbias = 0.f;
     if (NP0 > 0) {
         // esr_pack_apply_post blob: the images in this order, then the biases
         const i32x4_t* src = reinterpret_cast<const i32x4_t*>(p.pimg);
-        for (int e = threadIdx.x; e < (P0_IMGS + P1_IMGS) * 64; e += 256) reinterpret_cast<i32x4_t*>(spimg)[e] = src[e];
+#pragma unroll
+        for (int i = 0; i < PCOPY; ++i) {
+            const int e = (int)threadIdx.x + 256 * i;
+            pcp[i] = src[e < (P0_IMGS + P1_IMGS) * 64 ? e : 0];
+        }
         const float* bsrc = reinterpret_cast<const float*>(p.pimg + (size_t)(P0_IMGS + P1_IMGS) * 512);
-        for (int e = threadIdx.x; e < (NT0 + NT1) * 16; e += 256) spbias[e] = bsrc[e];
+        static_assert((NT0 + NT1) * 16 <= 256, "one bias per thread");
+        pbias = bsrc[(int)threadIdx.x < (NT0 + NT1) * 16 ? threadIdx.x : 0];
     }
     // LDS: A images, lane-linear 16 bytes per lane: [Wf][W4 hi x NT][W4 lo x NT], then bf[16] and b4[NT*16] as floats
     __shared__ __attribute__((aligned(16))) unsigned short simg[(1 + 2 * NT) * 64 * 8];
     __shared__ __attribute__((aligned(16))) float sbias[16 + NT * 16];
     const int tid = threadIdx.x;
-    for (int e = tid; e < (1 + 2 * NT) * 512; e += 256) {
-        const int img = e >> 9, l = (e >> 3) & 63, j = e & 7;
+    constexpr int NPASS = (1 + 2 * NT) * 2;
+    float wraw[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int e = tid + 256 * ps;
+        const int img = ps >> 1, l = (e >> 3) & 63, j = e & 7;
         const int i = l & 15, kq = l >> 4;
-        float v = 0.f;
         if (img == 0) {
             // conv_f: k slot (kq, j) = input channel 8 (kq & 1) + j, high part for kq < 2, low part for kq >= 2
-            const float w = p.wf[(8 * (kq & 1) + j) * FP + i];
-            const float hi = from16<ST>(to16<ST>(w));
-            v = kq < 2 ? hi : w - hi;
+            wraw[ps] = p.wf[(8 * (kq & 1) + j) * FP + i];
         } else {
-            const int t = (img - 1) % NT, lo = (img - 1) / NT;
+            const int t = (img - 1) % NT;
             const int oc = 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3);
-            const float w = oc < p.cp ? p.w4[(4 * kq + (j & 3)) * p.cp + oc] : 0.f;
-            const float hi = from16<ST>(to16<ST>(w));
+            // (clamped address + select: a load under a lane mask is a branch, and hipcc drains the load queue in front of each)
+            const float w = p.w4[(4 * kq + (j & 3)) * p.cp + (oc < p.cp ? oc : p.cp - 1)];
+            wraw[ps] = oc < p.cp ? w : 0.f;
+        }
+    }
+    static_assert(NT * 16 <= 240, "one bias per thread");
+    float braw = 0.f;
+    {
+        const int e = tid < 16 ? 0 : (tid < 16 + NT * 16 ? tid - 16 : 0), t = e >> 4, i = e & 15;
+        const int oc = 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3);
+        const float* const src = tid < 16 ? p.wf + FP * FP + tid : p.w4 + FP * p.cp + (oc < p.cp ? oc : p.cp - 1);
+        braw = *src;
+        braw = (tid < 16 || oc < p.cp) ? braw : 0.f;
+    }
+    if (NP0 > 0) {
+#pragma unroll
+        for (int i = 0; i < PCOPY; ++i) {
+            const int e = tid + 256 * i;
+            if (e < (P0_IMGS + P1_IMGS) * 64) reinterpret_cast<i32x4_t*>(spimg)[e] = pcp[i];
+        }
+        if (tid < (NT0 + NT1) * 16) spbias[tid] = pbias;
+    }
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int e = tid + 256 * ps;
+        const int img = ps >> 1, l = (e >> 3) & 63, j = e & 7;
+        const int kq = l >> 4;
+        const float w = wraw[ps];
+        const float hi = from16<ST>(to16<ST>(w));
+        float v;
+        if (img == 0) v = kq < 2 ? hi : w - hi;
+        else {
+            const int lo = (img - 1) / NT;
             v = lo ? (j < 4 ? w - hi : 0.f) : hi;           // hi image: against s_hi (j < 4) and s_lo (j >= 4); lo image: against s_hi only
         }
         simg[e] = to16<ST>(v);
     }
-    if (tid < 16) sbias[tid] = p.wf[FP * FP + tid];
-    for (int e = tid; e < NT * 16; e += 256) {
-        const int t = e >> 4, i = e & 15;
-        const int oc = 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3);
-        sbias[16 + e] = oc < p.cp ? p.w4[FP * p.cp + oc] : 0.f;
-    }
+    if (tid < 16 + NT * 16) sbias[tid] = braw;
     __syncthreads();
 
     const int lane = tid & 63, wv = tid >> 6;
@@ -534,7 +573,7 @@ int launch_esa_mfma(const EsaK& k, int np0, int np1, hipStream_t st)
     // at least ~4 (8) pixel groups of work
     const long long ngroups = (npix + 15) / 16;
     long long nwg = np0 > 0 ? (ngroups + 31) / 32 : (ngroups + 15) / 16;
-    nwg = nwg < 1 ? 1 : (nwg > 4096 ? 4096 : nwg);
+    nwg = nwg < 1 ? 1 : (nwg > 4096 ? 4096 : nwg);      // (round 5 A/B of the cap, 512 .. 4096 blocks: 2048 / 4096 best, within 1.5 % of each other)
     const unsigned grid = (unsigned)nwg;
     const int np = (k.Cp4 + 31) / 32;
     if (np0 > 0) {

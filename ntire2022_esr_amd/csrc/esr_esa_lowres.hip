@@ -43,6 +43,15 @@ constexpr int PMAX = OT + 2 * ML;              // 12
 // 4g .. 4g+3 of pixel j (one float4 of an NHWC pixel).  The weights of a layer sit in REGISTERS (9 taps x float4 per lane) for the
 // life of the block.  (As VALU kernels with per-lane or scalar weight loads these were LDS-return- or latency-bound: 50 - 90 us per
 // ESA block on one image, no better than the five launches they replace.)
+// tile of this block.  Blocks are dealt round-robin to the 8 XCDs (XCD = blockIdx & 7), each with its own L2: XCD k takes the k-th eighth of
+// the tiles in raster order, so that the halo a tile shares with its right and lower neighbours (s2pool: 33 x 33 input pixels per 24 x 24
+// of the tile, 1.9x) is fetched by the SAME L2 shortly after (round 5; before: blockIdx = tile, every neighbour on another XCD)
+__device__ __forceinline__ int lo_xcd_tile()
+{
+    const int G8 = (int)gridDim.x & ~7, b = (int)blockIdx.x;
+    return b < G8 ? (b & 7) * (G8 >> 3) + (b >> 3) : b;
+}
+
 template <int TAPS>
 __device__ __forceinline__ void lo_load_weights(const float* __restrict__ wp, f32x4 (&wr)[TAPS], f32x4& bias, int lane)
 {
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(256) void esa_s2pool_kernel(const void* __restrict_
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4;
-    int t = blockIdx.x;
+    int t = lo_xcd_tile();
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int n = t / tiles_y;
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(256) void esa_s2pool16_kernel(const void* __restric
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, kq = lane >> 4;
-    int t = blockIdx.x;
+    int t = lo_xcd_tile();
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int n = t / tiles_y;
@@ -259,6 +268,14 @@ __global__ __launch_bounds__(256) void esa_s2pool16_kernel(const void* __restric
             for (int dw = 0; dw < 4; ++dw) wa[q][pp][dw] = (int)((unsigned)part[pp][2 * dw] | ((unsigned)part[pp][2 * dw + 1] << 16));
     }
     const f32x4 bias = *reinterpret_cast<const f32x4*>(wp + 9 * FP * FP + 4 * kq);
+    // (an opaque use of every piece: without it hipcc SINKS the loads whose only use is a predicated LDS store below into that store's
+    // branch -- pieces 5 .. 8 became four dependent round trips, load, vmcnt(0), store, in an 8 us kernel; round 5)
+#pragma unroll
+    for (int i = 0; i < S16_PER; ++i) {
+        i32x4 t = {(int)v[i].x, (int)v[i].y, (int)v[i].z, (int)v[i].w};
+        asm volatile("" : "+v"(t));
+        v[i] = uint4{(unsigned)t.x, (unsigned)t.y, (unsigned)t.z, (unsigned)t.w};
+    }
 #pragma unroll
     for (int i = 0; i < S16_PER; ++i) {
         const int it = threadIdx.x + 256 * i;
@@ -338,7 +355,7 @@ __global__ __launch_bounds__(256) void esa_chain_kernel(const ChainK p)
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4;
     const int L = p.n_layers;
-    int t = blockIdx.x;
+    int t = lo_xcd_tile();
     const int tx = t % p.tiles_x; t /= p.tiles_x;
     const int ty = t % p.tiles_y;
     const int n = t / p.tiles_y;

@@ -291,13 +291,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
                 dma_glb16(smem_lds + (unsigned)(w_main + pc * 1024), p.pw1 + (size_t)pc * 1024 + lane * 16);
             for (int pc = wv; pc < n2; pc += NW)
                 dma_glb16(smem_lds + (unsigned)(w_main + plo * P1_IMG + pc * 1024), p.pw2 + (size_t)pc * 1024 + lane * 16);
-            if (tid < PNT1 * 16) pbias[tid] = reinterpret_cast<const float*>(p.pw1 + 2 * P1_IMG)[tid];
-            if (PNT2 > 0 && tid < PNT2 * 16) pbias[PNT1 * 16 + tid] = reinterpret_cast<const float*>(p.pw2 + 2 * P2_IMG)[tid];
         }
+        // The biases and the border table travel as LDS-DMA pieces too (16 bytes per lane, lanes past the end masked off).  As per-thread loads +
+        // LDS writes (until round 5) each of them was a dependent round trip -- load, s_waitcnt vmcnt(0), ds_write -- that also drained the
+        // weights' DMA queue in front of the first tile's requests: three to four L2 latencies, 10 % of a single image's 1x1 launch.
+        if (wv == 0) {
+            const unsigned pb_lds = smem_lds + (unsigned)(w_main + plo * (P1_IMG + P2_IMG));
+            if (PNT1 > 0 && lane < PNT1 * 4) dma_glb16(pb_lds, p.pw1 + 2 * P1_IMG + lane * 16);
+            if (PNT2 > 0 && lane < PNT2 * 4) dma_glb16(pb_lds + PNT1 * 64, p.pw2 + 2 * P2_IMG + lane * 16);
+            if (lane < NT * 4) dma_glb16(smem_lds + (unsigned)(bias_at + 512), reinterpret_cast<const char*>(p.bias) + lane * 16);
+        }
+        if (p.border)
+            for (int pc = wv; pc < NT; pc += NW)
+                dma_glb16(smem_lds + (unsigned)(bias_at + 1024 + pc * 1024), reinterpret_cast<const char*>(p.border) + (size_t)pc * 1024 + lane * 16);
     }
-    if (p.border)
-        for (int i = tid; i < 16 * NT * 16; i += 64 * NW) btab[i] = p.border[i];
-    if (tid < NT * 16) sbias[tid] = p.bias[tid];
     cursor_tile();
     if (!lvalid) return;                 // block without tiles (grid <= ntiles: does not happen)
     for (int i = 0; i < R - 1; ++i) {
@@ -872,8 +879,9 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
     f32x4 bia[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bia[t] = *reinterpret_cast<const f32x4*>(p.bias + t * 16 + kq * 4);
-    if (has_border)
-        for (int i = tid; i < 16 * NT * 16; i += 256) btab[i] = p.border[i];
+    if (has_border)             // (LDS-DMA, NT pieces of 1 KB: as a load / wait / ds_write loop it was three dependent round trips in front of the first tile's DMA)
+        for (int pc = wv; pc < NT; pc += 4)
+            dma_glb16(smem_lds + (unsigned)(BT_OFF + pc * 1024), reinterpret_cast<const char*>(p.border) + (size_t)pc * 1024 + lane * 16);
 
     const int ntiles = p.N * p.tiles_y * p.tiles_x;
     const int G = gridDim.x;
@@ -1128,8 +1136,9 @@ __global__ __launch_bounds__(256, 1) void conv48rq_kernel(const S16K p)
     const char* const img1 = smem + OFF_POST + lane * 16;
 #pragma unroll
     for (int t = 0; t < NT; ++t) bia[t] = *reinterpret_cast<const f32x4*>(p.bias + t * 16 + kq * 4);
-    if (has_border)
-        for (int i = tid; i < 16 * NT * 16; i += 256) btab[i] = p.border[i];
+    if (has_border)             // (LDS-DMA, NT pieces of 1 KB: as a load / wait / ds_write loop it was three dependent round trips in front of the first tile's DMA)
+        for (int pc = wv; pc < NT; pc += 4)
+            dma_glb16(smem_lds + (unsigned)(BT_OFF + pc * 1024), reinterpret_cast<const char*>(p.border) + (size_t)pc * 1024 + lane * 16);
 
     const int ntiles = p.N * p.tiles_y * p.tiles_x;
     const int G = gridDim.x;
@@ -2814,10 +2823,13 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
         unsigned short v[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = 0;
+        float fin[4];               // (every plane's load in flight before the first use: a load inside `if (c < C)` is a branch with its own wait)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fin[c] = x[(n * C + (c < C ? c : C - 1)) * hw + s];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (c < C) {
-                const float f = x[(n * C + c) * hw + s];
+                const float f = fin[c];
                 const unsigned h = pack2<BF16>(f, 0.f) & 0xffffu;
                 float fh, dummy;
                 unpack2<BF16>(h, fh, dummy);
@@ -2861,6 +2873,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     if (d->tail_wpacked || d->blocked8) return ESR_ERR_UNSUPPORTED;                            // fp32 features
     const bool post = d->post_wpacked != nullptr;
     if (d->border_bias && d->out_layout != ESR_NHWC) return ESR_ERR_UNSUPPORTED;
+    if (d->border_bias && ((uintptr_t)d->border_bias & 15)) return ESR_ERR_BAD_ARG;       // (staged by 16-byte LDS-DMA pieces, as the packed weights)
     if (!post && d->post2_wpacked) return ESR_ERR_BAD_ARG;
     if ((d->in.pitch & 7) || (d->in.coff & 7)) return ESR_ERR_BAD_ARG;                         // 16-byte granules
     const int cin_phys = esr_round_up(d->cin, 16);

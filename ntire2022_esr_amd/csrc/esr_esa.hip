@@ -258,7 +258,13 @@ __device__ __forceinline__ f32x4 mfma_k32(i32x4_t a, i32x4_t b, f32x4 c)
 // map, so again 8 consecutive channels per lane and tile pair) feed post 1 as fp32 high + low parts.  RFDN: y + the next block's
 // c1_d; BSRN: conv_out (+ block input) and the next block's c1_d, the attention output itself never reaches memory.
 template <int ST, int NP, int NP0 = 0, int NP1 = 0>     // NP = channel pairs of tiles = ceil(C / 32)
-__global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
+// Occupancy target: four waves per SIMD (<= 128 registers).  Without it hipcc takes 132 for the plain kernel once both groups' loads are
+// unconditional -- three waves -- and the launch is 5-10 % slower (round 5 A/B, tools/r05/l_esa_fetch.sh: targets none / 3 / 4).  The variant
+// with two post stages on bf16 needs 160 whatever the target (hipcc says so); fp16's meets it with two spilled registers.
+#ifndef ESA_APPLY_WAVES
+#define ESA_APPLY_WAVES 4
+#endif
+__global__ __launch_bounds__(256, ESA_APPLY_WAVES) void esa_apply_mfma_kernel(const EsaK p)
 {
 #pragma clang fp contract(off)
     constexpr int NT = 2 * NP;
@@ -394,15 +400,17 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
         g.bc1 = *reinterpret_cast<const i32x4_t*>(c1 + (size_t)g.pix * FP + 8 * (kq & 1));
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            g.xv[q] = i32x4_t{0, 0, 0, 0};
-            if (chan_ok[q]) g.xv[q] = *reinterpret_cast<const i32x4_t*>(xs + (size_t)g.pix * p.x_pitch + p.x_coff + 32 * q + 8 * kq);
+            // UNCONDITIONAL (round 5): a lane past the last channel reads the pixel's first 16 bytes instead and finish() zeroes what it got.
+            // As `zero; if (chan_ok) load` each load sat in a branch of its own, and hipcc waited for the group's FIRST loads before it issued
+            // the second group's -- the two groups of an iteration were fetched one after the other, not together.
+            g.xv[q] = *reinterpret_cast<const i32x4_t*>(xs + (size_t)g.pix * p.x_pitch + p.x_coff + (chan_ok[q] ? 32 * q + 8 * kq : 0));
         }
         if (NP0 > 0) {
 #pragma unroll
             for (int q = 0; q < (NP0 > 0 ? NP0 : 1); ++q) {
-                g.rv[q] = i32x4_t{0, 0, 0, 0};
-                if (p.p0_res && 32 * q + 8 * kq < p.p0_c8)
-                    g.rv[q] = *reinterpret_cast<const i32x4_t*>(rs + (size_t)g.pix * p.pres_pitch + p.pres_coff + 32 * q + 8 * kq);
+                // (the residual likewise: without one, rs = the block input x -- any readable address, the value is dropped in finish())
+                const bool rok = 32 * q + 8 * kq < p.p0_c8;
+                g.rv[q] = *reinterpret_cast<const i32x4_t*>((p.p0_res ? rs + (size_t)g.pix * p.pres_pitch + p.pres_coff : xs + (size_t)g.pix * p.x_pitch + p.x_coff) + (rok ? 32 * q + 8 * kq : 0));
             }
         }
         // bilinear source coordinates: ATen area_pixel_compute_source_index, fused multiply-add (see oracle)
@@ -462,7 +470,8 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
                 m0 = mfma_k32<ST>(*reinterpret_cast<const i32x4_t*>(sim + (1 + NT + 2 * q) * 512), bs, m0);
                 m1 = mfma_k32<ST>(*reinterpret_cast<const i32x4_t*>(sim + (1 + NT + 2 * q + 1) * 512), bs, m1);
             }
-            const unsigned xw[4] = {(unsigned)g.xv[q].x, (unsigned)g.xv[q].y, (unsigned)g.xv[q].z, (unsigned)g.xv[q].w};
+            const i32x4_t xq = chan_ok[q] ? g.xv[q] : i32x4_t{0, 0, 0, 0};
+            const unsigned xw[4] = {(unsigned)xq.x, (unsigned)xq.y, (unsigned)xq.z, (unsigned)xq.w};
             const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
             unsigned ow[4];
 #pragma unroll
@@ -501,7 +510,8 @@ __global__ __launch_bounds__(256) void esa_apply_mfma_kernel(const EsaK p)
             }
 #pragma unroll
             for (int q = 0; q < NP0; ++q) {
-                const unsigned rw[4] = {(unsigned)g.rv[q].x, (unsigned)g.rv[q].y, (unsigned)g.rv[q].z, (unsigned)g.rv[q].w};
+                const i32x4_t rq = (p.p0_res && 32 * q + 8 * kq < p.p0_c8) ? g.rv[q] : i32x4_t{0, 0, 0, 0};
+                const unsigned rw[4] = {(unsigned)rq.x, (unsigned)rq.y, (unsigned)rq.z, (unsigned)rq.w};
                 f32x4 ra, rb;          // (zeros when there is no residual)
                 ra.x = from16<ST>((unsigned short)(rw[0] & 0xffffu)); ra.y = from16<ST>((unsigned short)(rw[0] >> 16));
                 ra.z = from16<ST>((unsigned short)(rw[1] & 0xffffu)); ra.w = from16<ST>((unsigned short)(rw[1] >> 16));

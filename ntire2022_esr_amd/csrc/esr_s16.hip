@@ -840,7 +840,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_s16_kernel(cons
 // one image; it is not part of the kernel any more and those launches stay on conv_s16_kernel.)
 // Same packed weights, fragment maps, operation order and rounding as conv_s16_kernel: results are bit-identical (a batch takes this
 // kernel, a single small image conv_s16_kernel: test_16bit_batch_equals_per_image).
-template <bool BF16, int NT, bool EXT, int RW = 8>
+// FX >= 0 (round 5): the kernel's three run-time switches as COMPILE-TIME constants -- bit 0 GELU, bit 1 border table, bit 2 residual == input.
+// As wave-uniform branches inside the micro-step schedule they cost the EXT instantiation 120 s_cbranch + 140 v_mov (phi copies) per tile on top of
+// the work itself (4231 against 2427 instructions for the same 360 MFMAs), and a wave that is alone on its SIMD pays ~4 cycles for every one of
+// them (profiles/r05_instruction_census.txt).  The host launches the specialisation when a descriptor's switches match one that exists (ESDB:
+// 7 = c{j}_r, 3 = c4), FX = -1 (run-time switches) otherwise.
+template <bool BF16, int NT, bool EXT, int RW = 8, int FX = -1>
 __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
 {
     // RW = rows per wave: 8 (16 x 32 tiles) or 4 (16 x 16 tiles: small launches -- one DIV2K image is 352 large tiles on 256 CUs, two rounds of
@@ -864,7 +869,8 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15, kq = lane >> 4;
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const bool has_border = EXT && p.border != nullptr, res_in = EXT && p.res_in != 0, gelu = EXT && p.act == ESR_ACT_GELU;
+    const bool has_border = FX >= 0 ? (FX & 2) != 0 : (EXT && p.border != nullptr), res_in = FX >= 0 ? (FX & 4) != 0 : (EXT && p.res_in != 0),
+               gelu = FX >= 0 ? (FX & 1) != 0 : (EXT && p.act == ESR_ACT_GELU);
 
     // ---- the weights: registers for the life of the block ---------------------------------------------------------------------
     // (the blob goes global -> LDS ONCE per block -- stage 1 is free until the first tile's DMA issue -- and from there into each wave's
@@ -1091,7 +1097,8 @@ __global__ __launch_bounds__(256, 1) void conv48r_kernel(const S16K p)
 // activated main result go back into the pair's accumulators, where the 1x1 reads them (conv_s16_kernel: the post chain sees the unrounded tile).
 // Same order of operations per accumulator as conv_s16_kernel: bit-identical.  Post images: high parts only (the host sends fp16 plans here,
 // post_lo == 0) or high + low (bf16).
-template <bool BF16>
+// FX: as conv48r_kernel's, + bit 3 = the post 1x1's activation is GELU (ESDB: 15)
+template <bool BF16, int FX = -1>
 __global__ __launch_bounds__(256, 1) void conv48rq_kernel(const S16K p)
 {
     constexpr int NT = 3, RW = 4, PNT1 = 2;
@@ -1117,7 +1124,8 @@ __global__ __launch_bounds__(256, 1) void conv48rq_kernel(const S16K p)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15, kq = lane >> 4;
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const bool has_border = EXT && p.border != nullptr, res_in = EXT && p.res_in != 0, gelu = EXT && p.act == ESR_ACT_GELU;
+    const bool has_border = FX >= 0 ? (FX & 2) != 0 : (EXT && p.border != nullptr), res_in = FX >= 0 ? (FX & 4) != 0 : (EXT && p.res_in != 0),
+               gelu = FX >= 0 ? (FX & 1) != 0 : (EXT && p.act == ESR_ACT_GELU);
 
     // ---- the weights: registers for the life of the block ---------------------------------------------------------------------
     // (the blob goes global -> LDS ONCE per block -- stage 1 is free until the first tile's DMA issue -- and from there into each wave's
@@ -1198,7 +1206,7 @@ __global__ __launch_bounds__(256, 1) void conv48rq_kernel(const S16K p)
     unsigned e_vA = OOB, e_vB = OOB, e_vP = OOB;     // store offsets (row 0 of the wave) of the tile whose epilogue is in flight
     int e_n = 0;
     const float p1s = p.p1_slope;
-    const bool g1 = p.p1_gelu != 0;
+    const bool g1 = FX >= 0 ? (FX & 8) != 0 : p.p1_gelu != 0;
     const size_t p1_img = (size_t)p.H * p.W * p.py1_pitch * 2;
     const unsigned rowb1 = (unsigned)p.W * (unsigned)p.py1_pitch * 2u;
     f32x4 ev = {0.f, 0.f, 0.f, 0.f};
@@ -2337,8 +2345,8 @@ int launch_conv48rp(const S16K& k, hipStream_t st)
     return esr_check_launch("conv48rp_kernel launch");
 }
 
-template <bool BF16, int NT, bool EXT, int RW = 8>
-int launch_conv48r(const S16K& k, hipStream_t st)
+template <bool BF16, int NT, bool EXT, int RW = 8, int FX = -1>
+int launch_conv48r_fx(const S16K& k, hipStream_t st)
 {
     // [two input stages][RW = 4: 45 KB where the weight blob is staged][border table]
     constexpr int STAGES = RW == 8 ? 2 * 58 * 1024 : 2 * 31 * 1024 + 15 * NT * 1024;
@@ -2347,7 +2355,7 @@ int launch_conv48r(const S16K& k, hipStream_t st)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
     if (!attr_set[dev].load(std::memory_order_relaxed)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv48r_kernel<BF16, NT, EXT, RW>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGES + NT * 1024);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv48r_kernel<BF16, NT, EXT, RW, FX>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGES + NT * 1024);
         if (e != hipSuccess) {
             esr_set_err("hipFuncSetAttribute(conv48r_kernel, MaxDynamicSharedMemorySize)", e);
             return ESR_ERR_LAUNCH;
@@ -2356,9 +2364,21 @@ int launch_conv48r(const S16K& k, hipStream_t st)
     }
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int grid = ntiles < 256 ? ntiles : 256;
-    esr_note_kernel("conv48r_kernel<%s, %d, %s, %d>", esr_tf(BF16), NT, esr_tf(EXT), RW);
-    hipLaunchKernelGGL((conv48r_kernel<BF16, NT, EXT, RW>), dim3(grid), dim3(256), LDS, st, k);
+    esr_note_kernel("conv48r_kernel<%s, %d, %s, %d, %d>", esr_tf(BF16), NT, esr_tf(EXT), RW, FX);
+    hipLaunchKernelGGL((conv48r_kernel<BF16, NT, EXT, RW, FX>), dim3(grid), dim3(256), LDS, st, k);
     return esr_check_launch("conv48r_kernel launch");
+}
+
+// the descriptor's switches -> the specialisation that has them compiled in, if there is one (ESDB's two shapes), else the run-time kernel
+template <bool BF16, int NT, bool EXT, int RW = 8>
+int launch_conv48r(const S16K& k, hipStream_t st)
+{
+    if constexpr (EXT) {
+        const int fx = (k.act == ESR_ACT_GELU ? 1 : 0) | (k.border != nullptr ? 2 : 0) | (k.res_in ? 4 : 0);
+        if (NT == 3 && fx == 7) return launch_conv48r_fx<BF16, NT, EXT, RW, (NT == 3 ? 7 : -1)>(k, st);
+        if (NT == 2 && fx == 3) return launch_conv48r_fx<BF16, NT, EXT, RW, (NT == 2 ? 3 : -1)>(k, st);
+    }
+    return launch_conv48r_fx<BF16, NT, EXT, RW, -1>(k, st);
 }
 
 template <bool BF16>
@@ -2384,8 +2404,8 @@ int launch_conv64rq(const S16K& k, hipStream_t st)
     return esr_check_launch("conv64rq_kernel launch");
 }
 
-template <bool BF16>
-int launch_conv48rq(const S16K& k, hipStream_t st)
+template <bool BF16, int FX = -1>
+int launch_conv48rq_fx(const S16K& k, hipStream_t st)
 {
     // [two input stages][45 KB where the weight blob is staged][border table][post images: hi (+ lo)]
     constexpr int LDS = 2 * 31 * 1024 + 45 * 1024 + 3 * 1024 + (BF16 ? 2 : 1) * 6 * 1024;
@@ -2393,7 +2413,7 @@ int launch_conv48rq(const S16K& k, hipStream_t st)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
     if (!attr_set[dev].load(std::memory_order_relaxed)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv48rq_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv48rq_kernel<BF16, FX>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             esr_set_err("hipFuncSetAttribute(conv48rq_kernel, MaxDynamicSharedMemorySize)", e);
             return ESR_ERR_LAUNCH;
@@ -2402,9 +2422,17 @@ int launch_conv48rq(const S16K& k, hipStream_t st)
     }
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int grid = ntiles < 256 ? ntiles : 256;
-    esr_note_kernel("conv48rq_kernel<%s>", esr_tf(BF16));
-    hipLaunchKernelGGL((conv48rq_kernel<BF16>), dim3(grid), dim3(256), LDS, st, k);
+    esr_note_kernel("conv48rq_kernel<%s, %d>", esr_tf(BF16), FX);
+    hipLaunchKernelGGL((conv48rq_kernel<BF16, FX>), dim3(grid), dim3(256), LDS, st, k);
     return esr_check_launch("conv48rq_kernel launch");
+}
+
+template <bool BF16>
+int launch_conv48rq(const S16K& k, hipStream_t st)
+{
+    const int fx = (k.act == ESR_ACT_GELU ? 1 : 0) | (k.border != nullptr ? 2 : 0) | (k.res_in ? 4 : 0) | (k.p1_gelu ? 8 : 0);
+    if (fx == 15) return launch_conv48rq_fx<BF16, 15>(k, st);
+    return launch_conv48rq_fx<BF16, -1>(k, st);
 }
 
 template <bool BF16, int NT, bool EXT>

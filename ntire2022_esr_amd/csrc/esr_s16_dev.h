@@ -123,8 +123,27 @@ __device__ __forceinline__ f32x4 gelu16x4(f32x4 v)
     // 2710 -> 1600 images/s), tools/r05/f_gelu.sh)
     // (also measured: the scalar C++ form under -fno-slp-vectorize, conv48rq 0.35 -> 0.39-0.41 ms; -fno-slp-vectorize alone: no difference,
     // tools/r05/h_slp.sh)
-    const f32x2 a = gelu16x2(f32x2{v.x, v.y}), b = gelu16x2(f32x2{v.z, v.w});
-    return f32x4{a.x, a.y, b.x, b.y};
+    // The two halves' Horner chains INTERLEAVED, instruction by instruction (round 5).  A v_pk_fma_f32 that reads the previous one's result needs a
+    // wait state, and as gelu16x2(lo) followed by gelu16x2(hi) hipcc filled every one of them with an s_nop 0: 510 s_nop per tile of
+    // conv48r_kernel<.., 3, EXT, 8>, each an issue slot of a wave that is bound by exactly those (profiles/r05_instruction_census.txt).
+    // Same operations on the same values: bit-identical to gelu16x2 / gelu16.
+    f32x2 xa = {v.x, v.y}, xb = {v.z, v.w}, ca, cb, ma, mb;
+    ca.x = __builtin_amdgcn_fmed3f(xa.x, -4.f, 4.f); ca.y = __builtin_amdgcn_fmed3f(xa.y, -4.f, 4.f);
+    cb.x = __builtin_amdgcn_fmed3f(xb.x, -4.f, 4.f); cb.y = __builtin_amdgcn_fmed3f(xb.y, -4.f, 4.f);
+    const f32x2 ta = ca * ca, tb = cb * cb;
+    f32x2 pa = {-1.580786198e-09f, -1.580786198e-09f}, pb = pa;
+#define ESR_G16_STEP(c) pa = __builtin_elementwise_fma(pa, ta, f32x2{c, c}); pb = __builtin_elementwise_fma(pb, tb, f32x2{c, c});
+    ESR_G16_STEP(1.217111051e-07f) ESR_G16_STEP(-4.100866386e-06f) ESR_G16_STEP(8.066739505e-05f) ESR_G16_STEP(-1.048204400e-03f)
+    ESR_G16_STEP(9.664874174e-03f) ESR_G16_STEP(-6.617537882e-02f) ESR_G16_STEP(3.988475079e-01f)
+#undef ESR_G16_STEP
+    const float m4 = -4.f;
+    asm("v_max_f32 %0, %1, %2" : "=v"(ma.x) : "v"(xa.x), "v"(m4));
+    asm("v_max_f32 %0, %1, %2" : "=v"(ma.y) : "v"(xa.y), "v"(m4));
+    asm("v_max_f32 %0, %1, %2" : "=v"(mb.x) : "v"(xb.x), "v"(m4));
+    asm("v_max_f32 %0, %1, %2" : "=v"(mb.y) : "v"(xb.y), "v"(m4));
+    const f32x2 qa = __builtin_elementwise_fma(ca, pa, f32x2{0.5f, 0.5f}), qb = __builtin_elementwise_fma(cb, pb, f32x2{0.5f, 0.5f});
+    const f32x2 ra = ma * qa, rb = mb * qb;
+    return f32x4{ra.x, ra.y, rb.x, rb.y};
 }
 
 // Epilogue activation: max(v, slope * v); slope carries none (1) / LeakyReLU (s) / ReLU (0).  GELU is applied IN PLACE to the

@@ -140,7 +140,8 @@ typedef struct esr_conv_desc {
      * (models/team18_bsrn.py:82-88: depthwise 3x3 over the ZERO-PADDED pointwise output pw(x) + b) run as ONE dense 3x3 with
      * the merged weights dw[c,tap] * pw[c,k]: in the interior the pointwise bias contributes b[c] * sum_tap dw[c,tap] (folded
      * into the bias), at the border the taps that fall outside the image contribute nothing -- row m holds
-     * -b[c] * sum over the taps outside for mask m of dw[c,tap]. */
+     * -b[c] * sum over the taps outside for mask m of dw[c,tap].  The table must be 16-byte aligned (it is staged by 16-byte
+     * LDS-DMA pieces like the packed weights; ESR_ERR_BAD_ARG otherwise). */
     const float* border_bias;
     /* ABI v5 -- segmented (planar) input for the 1x1 over a channel concat (16-bit storage): the input channels come from
      * `cin_phys / (16 * in_seg_chunks)` tensors of identical geometry (pitch / coff as given by `in`) that lie in_seg_stride bytes

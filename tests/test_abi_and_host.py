@@ -124,6 +124,8 @@ def test_hilo_descriptor_validation_without_gpu():
     assert desc(out_layout=L.NCHW_SHUFFLE4) == -1                          # the output pair is NHWC
     assert desc(hilo=L.HILO_IN | L.HILO_OUT, post_wpacked=a, post_cout=24, post_out=L.View(a, 32, 0)) == -2    # a post 1x1 rides with HILO_OUT alone
     assert desc(split=16, out1=L.View(a, 48, 0)) == -2                     # no split store
+    # (round 5) the border table is staged by 16-byte LDS-DMA pieces: a misaligned one is refused before anything is launched
+    assert desc(hilo=0, hilo_stride=0, border_bias=a + 4) == -1
 
 
 def test_module_surface_and_no_cpu_fallback():

@@ -48,6 +48,8 @@ timeout 300 python bench.py --model team04_rlfn --compute bf16 --sizes div2k --s
 for a in "4 bf16 339x510" "0 bf16 339x510" "18 f16 270x480" "-1 f32 256x256"; do timeout 200 python tools/b1_latency.py $a 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_host_latency.txt; done
 timeout 100 tools/r05/mfma_pair_probe > $O/${TAG}_mfma_pair_probe.txt 2>&1
 timeout 100 tools/r05/mfma_valu_probe > $O/${TAG}_mfma_valu_probe.txt 2>&1
+for pr in valu_cost_probe valu_cost_probe2 pk_block_probe dot2_probe; do [ -x tools/r05/$pr ] && timeout 200 tools/r05/$pr > $O/${TAG}_$pr.txt 2>&1; done
+timeout 300 bash -c 'for a in "4 bf16 32 256x256" "4 bf16 1 339x510" "0 bf16 32 256x256" "0 bf16 1 339x510" "18 f16 32 270x480" "18 f16 1 339x510" "-1 f32 32 256x256"; do python tools/per_op.py $a 2>&1 | grep -v amdgpu.ids; done' > $O/${TAG}_per_op.txt
 for g in 2 3; do ESR_CHAIN_G=$g timeout 100 python tools/r05/chain_trace.py run 32 256 256 2>&1 | grep -v amdgpu.ids | head -8 >> $O/${TAG}_chain_step_trace.txt; done
 python bench.py --b1-latency --no-cpu-baseline --no-kernel-events > $O/b1_imdn_f32.json 2>/dev/null
 python bench.py --streams 2 --no-cpu-baseline --no-kernel-events > $O/bench_c1_imdn_f32_2streams.json 2>/dev/null

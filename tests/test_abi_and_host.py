@@ -261,6 +261,30 @@ def test_isa_lint_flags_the_round3_apply_loop():
     assert counts["fixed"] == []
 
 
+def test_isa_lint_flags_sunk_patch_loads():
+    """rule 3 of the lint catches what it was written for: esa_s2pool16_kernel WITHOUT the opaque use of its nine patch loads compiles to
+    four loads sunk into the predicated LDS stores (load, vmcnt(0), store -- round 5, LAB_NOTES 10.8); the product source is clean."""
+    import subprocess, sys, tempfile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(repo, "tools"))
+    import lint_isa
+    src = open(os.path.join(lint_isa.CSRC, "esr_esa_lowres.hip")).read()
+    start = src.index("    // (an opaque use of every piece")
+    end = src.index("#pragma unroll", src.index("asm volatile(\"\" : \"+v\"(t));"))
+    old = src[:start] + src[end:]
+    assert "asm volatile(\"\" : \"+v\"(t))" not in old
+    d = tempfile.mkdtemp(prefix="esr_lint_sunk_")
+    res = {}
+    for tag, text in (("sunk", old), ("product", src)):
+        f, asm = os.path.join(d, f"lowres_{tag}.hip"), os.path.join(d, f"lowres_{tag}.s")
+        open(f, "w").write(text)
+        subprocess.check_call([lint_isa.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(repo, "include"), "-I", lint_isa.CSRC,
+                               "-S", "--cuda-device-only", f, "-o", asm], stderr=subprocess.DEVNULL)
+        res[tag] = lint_isa.lint_prologues(asm, "esr_esa_lowres.hip")
+    assert len(res["sunk"]) == 2 and all("esa_s2pool16_kernel" in r for r in res["sunk"]), res["sunk"]          # both storage types
+    assert res["product"] == []
+
+
 def test_merged_bsconv_algebra_cpu():
     """BSRN._merged_bsconv (host arithmetic, no GPU): dense 3x3 with weights dw[c,tap] * pw[c,k] + interior bias + the 16-row border
     table == the reference's BSConvU (pointwise Linear -> depthwise 3x3 over the zero-padded pointwise OUTPUT, team18_bsrn.py:82-88),

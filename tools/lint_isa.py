@@ -6,6 +6,10 @@ Rule 1 -- the packed-fp32 op_sel erratum (round 4, LAB_NOTES.md; reproduced in i
     pair -- returns 0 in lanes 48..63 when a wave of another kernel issues MFMAs on the same SIMD (forwards on several HIP streams).
     hipcc emits that encoding whenever a scalar factor happens to sit in the odd register of a pair; the sources route such factors
     through esr_lone() (csrc/esr_internal.h).  No kernel of the library may contain the encoding.
+Rule 3 -- prologues and wait states (round 5, LAB_NOTES.md 10.8): hipcc keeps ONE load in flight in a `for (e = tid; ..)` staging loop, sinks a
+    load into the predicated store that uses it, and pads every dependent v_pk_fma_f32 with an s_nop.  Guards for the kernels that were fixed:
+    esa_apply_mfma_kernel -- at most 3 waits for an empty load queue in front of the first barrier (24 before); esa_s2pool16_kernel -- every
+    16-byte patch load in front of the first LDS store of the patch; conv48r / conv48rq_kernel with the GELU compiled in -- < 160 s_nop (510).
 Rule 2 -- conv_s16_kernel's wait-count arithmetic (tools/lint_s16_isa.py, unchanged): no scratch / spills, no copies out of registers an
     in-flight asm load writes.
 
@@ -61,6 +65,48 @@ def lint_opsel(path):
     return out
 
 
+def _kernels(path):
+    """[(symbol, [instruction lines])] of an assembly file (labels, directives and comments dropped)."""
+    out, cur = [], None
+    for l in open(path):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            cur = (m.group(1), [])
+            out.append(cur)
+            continue
+        if cur is None:
+            continue
+        if l.startswith(".Lfunc_end"):
+            cur = None
+            continue
+        t = l.strip()
+        if t and not t.startswith((";", ".")):
+            cur[1].append(t)
+    return out
+
+
+def lint_prologues(path, unit):
+    """rule 3 (see the module docstring): [problem strings]"""
+    problems = []
+    for name, ins in _kernels(path):
+        if unit == "esr_esa.hip" and "esa_apply_mfma_kernel" in name:
+            end = next((i for i, t in enumerate(ins) if t.startswith("s_barrier")), len(ins))
+            drains = sum(1 for t in ins[:end] if t.startswith("s_waitcnt") and "vmcnt(0)" in t)
+            if drains > 3:
+                problems.append(f"{unit}: {name}: {drains} s_waitcnt vmcnt(0) in the prologue (weight-image loads serialised again)")
+        if unit == "esr_esa_lowres.hip" and "esa_s2pool16_kernel" in name:
+            end = next((i for i, t in enumerate(ins) if t.startswith("s_barrier")), len(ins))
+            first_store = next((i for i, t in enumerate(ins[:end]) if t.startswith("ds_write_b128")), end)
+            late = sum(1 for t in ins[first_store:end] if t.startswith("global_load_dwordx4") and "offset:1024" not in t)
+            if late:
+                problems.append(f"{unit}: {name}: {late} patch load(s) behind the first LDS store (sunk into the predicated stores again)")
+        if unit == "esr_s16.hip" and re.search(r"conv48r_kernelILb[01]ELi[23]ELb1ELi[48]ELi[37]E|conv48rq_kernelILb[01]ELi15E", name):
+            nops = sum(1 for t in ins if t.startswith("s_nop"))
+            if nops >= 160:
+                problems.append(f"{unit}: {name}: {nops} s_nop (the GELU's Horner chains are serial again)")
+    return problems
+
+
 def main(argv):
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
     if "--src" in argv:
@@ -75,6 +121,7 @@ def main(argv):
             by_kernel.setdefault(k, []).append(ins)
         for k, v in by_kernel.items():
             problems.append(f"{os.path.basename(src)}: {k}: {len(v)} packed-fp32 instruction(s) with op_sel reading a high dword, e.g. `{v[0]}`")
+        problems += lint_prologues(a, os.path.basename(src))
         if os.path.basename(src) == "esr_s16.hip":
             sys.path.insert(0, os.path.join(REPO, "tools"))
             import lint_s16_isa

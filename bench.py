@@ -149,7 +149,16 @@ def calibration(device):
         buf = torch.empty(2 * (16 << 20), dtype=torch.uint8, device=device)
         gbs = ctypes.c_double(0.0)
         L.check(lib.esr_bw_probe(ctypes.c_void_p(buf.data_ptr()), 16 << 20, 64, st, ctypes.byref(gbs)), "esr_bw_probe")
-        _CAL[key] = {"event_pair_ms": pair.value, "l3_copy_gbs": gbs.value}
+        # (c) the same copy kernel at a 2 x 1 GiB working set: what "HBM-bound" can mean on this device (4.7-5.0 TB/s of the nominal 8)
+        big = ctypes.c_double(0.0)
+        try:
+            buf2 = torch.empty(2 * (1 << 30), dtype=torch.uint8, device=device)
+            for _ in range(2):
+                L.check(lib.esr_bw_probe(ctypes.c_void_p(buf2.data_ptr()), 1 << 30, 1, st, ctypes.byref(big)), "esr_bw_probe")
+            del buf2
+        except Exception:
+            big = ctypes.c_double(0.0)
+        _CAL[key] = {"event_pair_ms": pair.value, "l3_copy_gbs": gbs.value, "hbm_copy_gbs": big.value}
     return _CAL[key]
 
 
@@ -229,6 +238,8 @@ def roofline_from_profile(prof, peak, traffic_key, events_desc, cal=None):
                                           "frac_algorithmic = the algorithmic (direct) flops of SURVEY 8d over the same time"),
                      "algorithmic_mb_per_launch": round(nbytes / 1e6, 2),
                      "frac_of_mfma_peak": round(f_mfma, 4), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                     # the measured read + write rate of a plain copy kernel over 2 x 1 GiB on this device: the practical memory roof
+                     "hbm_copy_kernel_gbs": round((cal or {}).get("hbm_copy_gbs", 0.0), 1) or None,
                      "share_of_kernel_time": round(ms / total_ms, 4)})
     # every kernel symbol: share of the step, achieved TFLOP/s and GB/s on algorithmic work
     table = []

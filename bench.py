@@ -179,6 +179,7 @@ def roofline_from_profile(prof, peak, traffic_key, events_desc, cal=None):
     flops = sum(o["flops"] * o["passes"] for o in dom) / launches                 # algorithmic = direct-convolution flops
     flops_exec = sum(o["flops_exec"] * o["passes"] for o in dom) / launches       # what the matrix cores execute (Winograd: 16/36)
     nbytes = sum((o["read_bytes"] + o["write_bytes"]) * o["passes"] for o in dom) / launches
+    stored = sum(o.get("stored_bytes", o["read_bytes"] + o["write_bytes"]) * o["passes"] for o in dom) / launches
     # the event pair's own time is not the kernel's (15.5 us by events against rocprofv3's 12.8 us)
     pair_ms = cal["event_pair_ms"] if cal else 0.0
     raw_ms = ms
@@ -237,6 +238,8 @@ def roofline_from_profile(prof, peak, traffic_key, events_desc, cal=None):
                                           "outputs and (cin, cout) where the direct convolution has 36); direct_equivalent_tflops / "
                                           "frac_algorithmic = the algorithmic (direct) flops of SURVEY 8d over the same time"),
                      "algorithmic_mb_per_launch": round(nbytes / 1e6, 2),
+                     # the bytes the launch moves with its tensors' pad channels (nf = 50 at pitch 64, ...): stored / algorithmic = padding waste
+                     "stored_mb_per_launch": round(stored / 1e6, 2),
                      "frac_of_mfma_peak": round(f_mfma, 4), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
                      # the measured read + write rate of a plain copy kernel over 2 x 1 GiB on this device: the practical memory roof
                      "hbm_copy_kernel_gbs": round((cal or {}).get("hbm_copy_gbs", 0.0), 1) or None,
@@ -249,10 +252,11 @@ def roofline_from_profile(prof, peak, traffic_key, events_desc, cal=None):
         fl = sum(o["flops_exec"] * o["passes"] for o in ops)
         fd = sum(o["flops"] * o["passes"] for o in ops)
         by = sum((o["read_bytes"] + o["write_bytes"]) * o["passes"] for o in ops)
+        sb = sum(o.get("stored_bytes", o["read_bytes"] + o["write_bytes"]) * o["passes"] for o in ops)
         kms = max(kms - pair_ms * n, 0.25 * kms)
         table.append({"kernel": kn, "share": round(kms / total_ms, 4), "avg_ms": round(kms / n, 4),
                       "tflops": round(fl / (kms * 1e-3) / 1e12, 2), "tflops_direct_equivalent": round(fd / (kms * 1e-3) / 1e12, 2),
-                      "gbs": round(by / (kms * 1e-3) / 1e9, 1)})
+                      "gbs": round(by / (kms * 1e-3) / 1e9, 1), "stored_over_algorithmic": round(sb / by, 3) if by else None})
     exec_per_step = sum(o["flops_exec"] * o["passes"] for o in prof) / max(1, max(o["passes"] for o in prof))
     roofline["kernels"] = table
     roofline["events"] = events_desc
@@ -334,7 +338,8 @@ def measure_other_config(spec, device, budget_s=1.2):
     return {"workload": wl, "dtype": compute, "value": round(imgs / elapsed, 2), "unit": "images/s", "steps": steps,
             "ms_per_step": round(elapsed / steps * 1e3, 3), "ms_per_image": round(elapsed / imgs * 1e3, 4), "streams": nstreams,
             "roofline": {k: r[k] for k in ("kernel", "bound", "frac", "frac_algorithmic", "avg_launch_ms", "avg_launch_ms_with_event_pair", "achieved",
-                                           "peak", "unit", "traffic", "share_of_kernel_time", "frac_of_mfma_peak", "frac_of_hbm_peak") if k in r}}
+                                           "peak", "unit", "traffic", "algorithmic_mb_per_launch", "stored_mb_per_launch", "share_of_kernel_time", "frac_of_mfma_peak",
+                                           "frac_of_hbm_peak", "hbm_copy_kernel_gbs") if k in r}}
 
 
 def free_port():
@@ -494,11 +499,10 @@ def main():
             raise SystemExit(f"--streams {nstreams} does not divide the batch {B}")
         xs = [c.contiguous() for c in xs[0].chunk(nstreams)]
         my_items = list(range(len(xs)))           # (imgs_per_step stays B: the same batch, in sub-batches)
-    # Per-kernel HIP events bracket every launch.  At B = 32 that is < 1 % of a step and they are recorded inside the timed
-    # region; one image per forward (20 us kernels) they cost 20 % and, with several streams, would time overlapping kernels:
-    # there the timed region runs un-instrumented and the SAME steps are replayed on one stream with events for the roofline leg.
-    events_in_region = not args.no_kernel_events and args.sizes == "tile" and nstreams == 1
-    events_after = not args.no_kernel_events and not events_in_region
+    # Per-kernel HIP events bracket every launch of the roofline leg.  Since round 6 the timed region carries NO event pairs in any
+    # mode (86 event records per instrumented step were work inside the number); the SAME steps are replayed on one
+    # stream with events right behind the timed region (one image per forward with several streams would time overlapping kernels anyway).
+    events_after = not args.no_kernel_events
 
     def step(spread=True):
         y = None
@@ -514,14 +518,6 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             y = step()
-        # batch mode: the event pairs cost 1.2 % of a step (86 event records between 43 back-to-back launches), so only the FIRST
-        # QUARTER of the timed steps is instrumented (the profiler runs un-instrumented once its passes are used up): 0.3 %
-        prof_steps = max(1, (args.steps + 3) // 4)
-        if events_in_region:
-            model.enable_profiling(prof_steps)
-            step()                         # creates the events outside the timed region
-            torch.cuda.synchronize(device)
-            model.collect_profile()        # discard
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -570,8 +566,7 @@ def main():
         prof = model.collect_profile()
         model.disable_profiling()
         tkey = f"{args.model}:{args.compute}:div2k" if args.sizes == "div2k" else f"{args.model}:{args.compute}:{B}x{th}x{tw}"
-        events_desc = (f"HIP event pair around every launch, inside the timed region (its first {prof_steps} of {args.steps} steps)" if events_in_region else
-                       f"HIP event pair around every launch in a replay of the same {args.steps} steps on ONE stream after the "
+        events_desc = (f"HIP event pair around every launch in a replay of the same {args.steps} steps on ONE stream after the "
                        f"timed region ({instrumented_ms:.3f} ms/step with the events; the timed region carries none)")
         roofline, exec_per_step = roofline_from_profile(prof, peak, tkey, events_desc, cal=calibration(device))
 

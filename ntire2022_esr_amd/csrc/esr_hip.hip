@@ -20,6 +20,7 @@
 //                a lane (p, kq) reads channels c0+2kq+{0,1}: k-slot kq of MFMA j <-> channel c0+2kq+j,
 //                identical on the A and B side by construction of the packer below.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -816,6 +817,7 @@ int launch_conv(const ConvK& k, hipStream_t st)
             hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, CAN_TALL ? 8 : 4, 0, 0, CAN_TALL && NT == 4>), dim3(grid), dim3(512), 0, st, kk);
         else
             hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, CAN_TALL ? 8 : 4>), dim3(grid), dim3(512), 0, st, kk);
+        esr_graph_note_io(st, kk.x, offsetof(ConvK, x), kk.y0, offsetof(ConvK, y0));
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             set_err("conv_f32_kernel (tall) launch", e);
@@ -827,6 +829,7 @@ int launch_conv(const ConvK& k, hipStream_t st)
     esr_note_kernel("conv_f32_kernel<%d, %d, %s, 4, 0, 0, %s>", NT, KS, esr_tf(IN_NCHW), esr_tf(CAN_TALL && NT == 4 && k.y1_blk));
     if (CAN_TALL && NT == 4 && k.y1_blk) hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, 4, 0, 0, CAN_TALL && NT == 4>), dim3(grid), dim3(THREADS), 0, st, k);
     else hipLaunchKernelGGL((conv_f32_kernel<NT, KS, IN_NCHW, 4>), dim3(grid), dim3(THREADS), 0, st, k);
+    esr_graph_note_io(st, k.x, offsetof(ConvK, x), k.y0, offsetof(ConvK, y0));
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_err("conv_f32_kernel launch", e);

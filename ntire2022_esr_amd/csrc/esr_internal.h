@@ -18,6 +18,11 @@ int esr_s16_block_waves(const esr_conv_desc* d);      // 4: two 4-wave blocks pe
 // esr_wino.hip: Winograd F(2x2, 3x3) fp32 convolution (called by esr_conv2d_f32 when d->wino_wpacked is set and the shape qualifies)
 int esr_conv2d_wino(const esr_conv_desc* d, void* hip_stream);
 
+// esr_graph.hip: while esr_graph_create captures an op list, a launcher whose kernel can read the network input or write the network
+// output reports the launch it has JUST enqueued on `st`: the pointer values it passed and their byte offsets inside the kernel's first
+// argument (offsetof in the parameter struct; 0 for a leading scalar pointer argument).  No-op outside a capture.
+void esr_graph_note_io(hipStream_t st, const void* in_ptr, size_t in_off, const void* out_ptr, size_t out_off);
+
 #ifdef __HIPCC__
 // gfx950 erratum found in round 4 (LAB_NOTES.md "packed fp32 op_sel"; tools/dbg/pk_opsel_probe.hip reproduces it in isolation): a
 // packed fp32 VALU instruction whose op_sel makes a result half read the HIGH dword of a 64-bit source pair (v_pk_mul_f32 ...

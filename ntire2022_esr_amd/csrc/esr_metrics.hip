@@ -10,6 +10,8 @@
 // in float64 on the uint8 images already on the device, one partial sum per block; the host adds the partials (a fixed-order float64
 // sum) and divides -- one scalar leaves the GPU.  Parity: UNPINNED against the reference (its SSIM needs cv2, absent here); pinned to
 // image_util.calculate_ssim (<= 1e-9, tests/test_gpu_harness.py).
+#include <cstdio>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -151,19 +153,41 @@ int esr_tensor2uint_u8_chk(const float* x, uint8_t* y, int c, int h, int w, floa
 
 // ---- measurement helpers of bench.py (ABI v11) ---------------------------------------------------------------------------------------------
 // esr_bw_probe: what a plain streaming kernel reaches on THIS device at a given working set -- one launch copies `bytes` from the first half
-// of `buf` to the second half `reps` times (grid-stride, 16 bytes per lane), timed by one event pair.  bench.py divides the B = 1 kernels'
-// algorithmic bytes by this (a 16.6 MB tensor that the previous launch wrote sits in the 256 MB Infinity Cache: 8 TB/s of HBM is not the roof).
+// of `buf` to the second half `reps` times, timed by one event pair.  bench.py divides the B = 1 kernels' algorithmic bytes by this (a
+// 16.6 MB tensor that the previous launch wrote sits in the 256 MB Infinity Cache: 8 TB/s of HBM is not the roof) and reports the 2 x 1 GiB
+// rate as the practical HBM roof.  Round 6: the round-5 probe was one 16-byte load per lane and iteration (4.98 TB/s at
+// 2 x 1 GiB, where MI355X_MICROARCH.md measures 6.29 with a float4 copy); the probe now times a small family -- U independent 16-byte loads in
+// flight per lane before the first store (U = 1, 4, 8), plain or nontemporal stores, 8 / 16 / 32 blocks per CU -- and reports the BEST: a roof
+// must not depend on one kernel's shape.
 namespace {
-__global__ __launch_bounds__(256) void bw_probe_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, int reps)
+typedef unsigned bw_u4 __attribute__((ext_vector_type(4)));
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void bw_probe_kernel(const bw_u4* __restrict__ src, bw_u4* __restrict__ dst, size_t n16, int reps)
 {
+    const size_t stride = (size_t)gridDim.x * 256;
     for (int r = 0; r < reps; ++r) {
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
-            uint4 v = src[i];
-            v.x += (unsigned)r;                 // (a pass must not be optimised into the previous one)
+        size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+        for (; i + (U - 1) * stride < n16; i += U * stride) {
+            bw_u4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(&src[i + u * stride]) : src[i + u * stride];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                v[u].x += (unsigned)r;          // (a pass must not be optimised into the previous one)
+                if (NT) __builtin_nontemporal_store(v[u], &dst[i + u * stride]);
+                else dst[i + u * stride] = v[u];
+            }
+        }
+        for (; i < n16; i += stride) {
+            bw_u4 v = src[i];
+            v.x += (unsigned)r;
             dst[i] = v;
         }
     }
 }
+
+using bw_fn = void (*)(const bw_u4*, bw_u4*, size_t, int);
+struct bw_variant { bw_fn fn; int blocks; };
 }  // namespace
 
 extern "C" int esr_bw_probe(void* buf, size_t bytes, int reps, void* hip_stream, double* gbs_out)
@@ -171,21 +195,38 @@ extern "C" int esr_bw_probe(void* buf, size_t bytes, int reps, void* hip_stream,
     if (!buf || bytes < 4096 || reps <= 0 || !gbs_out) return ESR_ERR_BAD_ARG;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const size_t n16 = bytes / 16;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return ESR_ERR_LAUNCH;
-    const uint4* src = static_cast<const uint4*>(buf);
-    uint4* dst = static_cast<uint4*>(buf) + n16;
-    hipLaunchKernelGGL(bw_probe_kernel, dim3(2048), dim3(256), 0, st, src, dst, n16, 2);        // warm the caches
-    (void)hipEventRecord(e0, st);
-    hipLaunchKernelGGL(bw_probe_kernel, dim3(2048), dim3(256), 0, st, src, dst, n16, reps);
-    (void)hipEventRecord(e1, st);
-    int rc = esr_check_launch("bw_probe_kernel launch");
-    if (rc == ESR_OK && hipEventSynchronize(e1) != hipSuccess) rc = ESR_ERR_LAUNCH;
-    float ms = 0.f;
-    if (rc == ESR_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = ESR_ERR_LAUNCH;
+    const bw_u4* src = static_cast<const bw_u4*>(buf);
+    bw_u4* dst = static_cast<bw_u4*>(buf) + n16;
+    const bw_variant variants[] = {
+        {bw_probe_kernel<1, false>, 8 * cus}, {bw_probe_kernel<4, false>, 8 * cus}, {bw_probe_kernel<4, true>, 8 * cus},
+        {bw_probe_kernel<8, false>, 8 * cus}, {bw_probe_kernel<8, true>, 8 * cus}, {bw_probe_kernel<4, false>, 16 * cus},
+        {bw_probe_kernel<4, true>, 16 * cus}, {bw_probe_kernel<4, true>, 32 * cus}, {bw_probe_kernel<8, true>, 4 * cus},
+    };
+    int rc = ESR_OK;
+    double best = 0.0;
+    const bool verbose = std::getenv("ESR_BW_PROBE_VERBOSE") != nullptr;
+    hipLaunchKernelGGL(variants[0].fn, dim3(variants[0].blocks), dim3(256), 0, st, src, dst, n16, 2);        // warm the caches
+    for (const bw_variant& v : variants) {
+        (void)hipEventRecord(e0, st);
+        hipLaunchKernelGGL(v.fn, dim3(v.blocks), dim3(256), 0, st, src, dst, n16, reps);
+        (void)hipEventRecord(e1, st);
+        rc = esr_check_launch("bw_probe_kernel launch");
+        if (rc == ESR_OK && hipEventSynchronize(e1) != hipSuccess) rc = ESR_ERR_LAUNCH;
+        float ms = 0.f;
+        if (rc == ESR_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = ESR_ERR_LAUNCH;
+        if (rc != ESR_OK) break;
+        const double gbs = 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9;
+        if (gbs > best) best = gbs;
+        if (verbose) std::fprintf(stderr, "esr_bw_probe: %zu B x %d, variant %d (%d blocks): %.1f GB/s\n", n16 * 16, reps, (int)(&v - variants), v.blocks, gbs);
+    }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (rc != ESR_OK) return rc;
-    *gbs_out = 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9;
+    *gbs_out = best;
     return ESR_OK;
 }
 

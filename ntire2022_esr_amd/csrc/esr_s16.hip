@@ -33,6 +33,7 @@
 //   conv64rq_kernel<bf16|f16>                    ... + ONE post 1x1 (RFDB c{j}_r + c{j+1}_d): two chunks in registers, two in LDS
 // The one-wave-per-SIMD kernels run a finished row pair's epilogue as micro-steps behind each MFMA of the next pair (LAB_NOTES 9.5).
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -2482,6 +2483,7 @@ int launch_s16(const S16K& k, size_t lds, hipStream_t st)
     // (rocprofv3 prints every template argument, defaulted ones included)
     esr_note_kernel("conv_s16_kernel<%d, %d, %d, %s, %s, %d, %d, %s>", NT, KS, NW, esr_tf(BF16), esr_tf(GRES), PNT1, PNT2, esr_tf(HILO));
     hipLaunchKernelGGL((conv_s16_kernel<NT, KS, NW, BF16, GRES, PNT1, PNT2, HILO>), dim3(grid), dim3(64 * NW), lds, st, k);
+    esr_graph_note_io(st, k.x, offsetof(S16K, x), k.y0, offsetof(S16K, y0));
     return esr_check_launch("conv_s16_kernel launch");
 }
 
@@ -2886,6 +2888,7 @@ extern "C" int esr_pack_input_s16(const esr_conv_desc* d, void* hip_stream)
         hipLaunchKernelGGL(pack_input_kernel<true>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(d->in.ptr), static_cast<char*>(d->out0.ptr), d->cin, hw, npix, d->out0.pitch, d->out0.coff);
     else
         hipLaunchKernelGGL(pack_input_kernel<false>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(d->in.ptr), static_cast<char*>(d->out0.ptr), d->cin, hw, npix, d->out0.pitch, d->out0.coff);
+    esr_graph_note_io(st, d->in.ptr, 0, nullptr, 0);
     return esr_check_launch("pack_input_kernel launch");
 }
 

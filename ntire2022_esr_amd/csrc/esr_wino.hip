@@ -26,6 +26,7 @@
 //               offset moves the LDS destination AND the global address: tools/wino/m0_offset_probe.hip).
 //   LDS reads   per wave and chunk: 16 ds_read_b128 (A) + 16 ds_read_b64 (raw) for 64 MFMAs
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
@@ -922,6 +923,7 @@ int w8_launch(const WinoK& k, int grid, hipStream_t st)
 {
     esr_note_kernel("wino8_f32_kernel<%d, %d, %d>", ACT, OUT, NCH);
     hipLaunchKernelGGL((wino8_f32_kernel<ACT, OUT, NCH>), dim3(grid), dim3(W8_THREADS), 0, st, k);
+    esr_graph_note_io(st, k.x, offsetof(WinoK, x), k.y0, offsetof(WinoK, y0));
     return esr_check_launch("wino8_f32_kernel launch");
 }
 
@@ -930,6 +932,7 @@ int wn_launch(const WinoK& k, int grid, hipStream_t st)
 {
     esr_note_kernel("wino_f32_kernel<%d, %d, %d>", ACT, RES, OUT);
     hipLaunchKernelGGL((wino_f32_kernel<ACT, RES, OUT>), dim3(grid), dim3(WN_THREADS), 0, st, k);
+    esr_graph_note_io(st, k.x, offsetof(WinoK, x), k.y0, offsetof(WinoK, y0));
     return esr_check_launch("wino_f32_kernel launch");
 }
 

@@ -66,3 +66,48 @@ def test_graphs_on_several_streams_and_after_workspace_growth():
     assert torch.equal(yb1, ref_b) and torch.equal(yb2, ref_b)
     for y, r in zip(ys_again + ys_again2, ref_s + ref_s):
         assert torch.equal(y, r)
+
+
+def test_many_graph_launches_rotate_instances():
+    """ESR_GRAPH_EXECS = 4 executable instances per captured graph, used round-robin with x / y re-patched per launch: 14 forwards back to back"""
+    m = _model("team04_rlfn", "bf16")
+    g = torch.Generator().manual_seed(11)
+    xs = [(torch.rand(1, 3, 40, 52, generator=g) * 255.0).to(DEV) for _ in range(14)]
+    m.use_graphs = False
+    ref = [m(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    m.use_graphs = True
+    ys = [m(x) for x in xs]
+    ys2 = [m(x) for x in xs[::-1]]
+    torch.cuda.synchronize()
+    for y, r in zip(ys + ys2, ref + ref[::-1]):
+        assert torch.equal(y, r)
+
+
+def test_tracers_and_dispatch_modes_see_the_operator():
+    """the eager fast path (straight to the C ABI) is only for plain eager calls; torch.jit.trace, make_fx(real) and any active
+    TorchDispatchMode must go through esr::sr_forward, or a traced graph bakes the output in as an unwritten constant"""
+    from torch.fx.experimental.proxy_tensor import make_fx
+    from torch.utils._python_dispatch import TorchDispatchMode
+    m = _model("imdn_baseline", "f32")
+    x = torch.rand(1, 3, 24, 32, device=DEV)
+    want = m(x).clone()
+
+    seen = []
+
+    class Log(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            seen.append(str(func))
+            return func(*args, **(kwargs or {}))
+
+    with Log():
+        y = m(x)
+    assert any("sr_forward" in s for s in seen), seen
+    assert torch.equal(y, want)
+    gm = make_fx(lambda t: m(t), tracing_mode="real")(x)
+    assert any("sr_forward" in str(n.target) for n in gm.graph.nodes), gm.graph
+    x2 = torch.rand(1, 3, 24, 32, device=DEV)
+    assert torch.equal(gm(x2), m(x2))
+    tr = torch.jit.trace(m, x, check_trace=False)
+    assert "sr_forward" in str(tr.graph)
+    assert torch.equal(tr(x2), m(x2))

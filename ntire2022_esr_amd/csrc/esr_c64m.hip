@@ -1,0 +1,442 @@
+// esr_c64m.hip -- the 3x3 convolutions over 64 physical channels with 64 outputs on v_mfma_f32_32x32x16_{bf16,f16} (round 6).
+// Interface: esr_conv2d_f32 with 16-bit storage (include/esr_hip.h) -> esr_conv2d_s16 (esr_s16.hip) -> esr_launch_conv64m.
+// Reference semantics: RFDB's c1_r / c2_r / c3_r = lrelu(conv3x3(x) + x) (rfdn_baseline/block.py:150-158) and, POST, the next distillation
+// conv c{j+1}_d + LeakyReLU of the activated result in the same launch (:152-156).
+//
+// Why a second kernel family (tools/r06/mfma_shape_probe.hip): conv64r / conv64rq_kernel issue 3.3-3.8 non-MFMA
+// instructions per v_mfma_f32_16x16x32 from ONE wave per SIMD; that MFMA occupies the pipe for 16 cycles = 4 issue slots, two fillers are
+// free and every further one costs ~4.5 cycles: 27 ns per 16384 MACs measured at that mix.  v_mfma_f32_32x32x16 holds the pipe 32 cycles
+// for the same 16384 MACs, hides five fillers (16.9 ns at 5, 21.2 ns at 8 per MFMA) and even alone runs 15.7 ns against 2 x 9.3.
+//
+// GEMM view: D[cout][pixel] as everywhere in the library; A = weights (32 output channels x 16 k), B = 32 pixels x 16 k, k = the 16
+// channels of ONE chunk at ONE tap (nine taps, no tenth tap slot: 10 % fewer MACs than the tap-pair form).  Lane l: A row / B column
+// l & 31, k = 8 (l >> 5) + j.  A block = 4 waves = one 16 x 16 pixel tile, a wave = 4 rows = two row PAIRS; the 32 pixels of an MFMA are
+// a row pair (pixel n = l & 31: row n >> 4, column n & 15).  Per row pair: 4 chunks x 9 taps x 2 output halves = 72 MFMAs, + 2 that
+// load the bias (A = [b_hi b_mid b_lo 0 ..], B = ones: C-operand registers would cost 32 VGPRs) + 4 that add the residual == input
+// (A = a 0 / 1 selection matrix against the centre tap's B fragment, which is exact: no centre-pixel reads, no VALU adds).
+// D fragment: register r of lane l holds output channel 32 half + 8 (r >> 2) + 4 (l >> 5) + (r & 3) of pixel l & 31; two 4-channel
+// blocks of lanes l and l ^ 32 become one 16-byte store through v_permlane32_swap.
+//   * input halo tile global -> LDS by DMA into two stages (18 x 18 pixels, 160-byte pixels: conv64r_kernel's conflict-free pitch) with a
+//     row pitch of 181 slots: the two rows of an MFMA's pixel set then fall on even / odd 16-byte columns (a ds_read_b128 is served in
+//     groups of 16 lanes that hold eight pixels of each row);
+//   * weights: 72 fragments of 1 KB.  Plain kernel: all in registers (64 in accumulation registers + 8 in VGPRs); POST: chunks 0 .. 2 in
+//     accumulation registers, chunk 3 through a ring from LDS next to the post images;
+//   * B fragments: one ds_read_b128 per tap and chunk with an immediate offset (no address arithmetic), a ring of four read three steps ahead;
+//   * the finished row pair's epilogue (activation, rounding, hi | lo split for the post 1x1, its MFMAs, swaps, stores) as micro-operations
+//     of ~4 instructions behind each MFMA of the next pair, as conv64rq_kernel.
+// Same packed 16-bit weights (error-diffused taps) as conv_s16_kernel, laid out for this MFMA (esr_pack_conv_s16 appends the image);
+// results agree with conv_s16_kernel to fp32 accumulation order (tests: tests/test_gpu_c64m.py against the fp64 reference).
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <atomic>
+#include <utility>
+#include <type_traits>
+
+#include "esr_internal.h"
+#include "esr_s16_dev.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int M_NCH = 4, M_TAPS = 9, M_TH = 18, M_RW = 4, M_THY = 4 * M_RW + 2;
+constexpr int M_LSL = 10;                                 // 16-byte slots of a pixel in LDS (8 + 2 pad)
+constexpr int M_PIXB = M_LSL * 16;                        // 160
+constexpr int M_ROWSL = M_TH * M_LSL + 1;                 // 181 slots per staged row: odd, see the file header
+constexpr int M_ROWB = M_ROWSL * 16;                      // 2896
+constexpr int M_NSLOT = M_THY * M_ROWSL;                  // 3258
+constexpr int M_NPIECES = (M_NSLOT + 63) / 64;            // 51
+constexpr int M_STAGE = M_NPIECES * 1024;                 // 52224
+constexpr int M_PPW = (M_NPIECES + 3) / 4;                // 13 pieces per wave, the last wave one fewer
+constexpr int M_NG = M_NCH * M_TAPS;                      // 36 k steps per row pair
+constexpr int M_NFRAG = M_NG * 2;                         // 72 weight fragments
+constexpr int M_SLOTS = 2 + 2 * M_NG + M_NCH;             // 78 MFMAs per row pair
+constexpr int M_W3 = 2 * M_STAGE;                         // POST: chunk 3's 18 fragments
+constexpr int M_OFF_POST = M_W3 + M_TAPS * 2 * 1024;      // POST: the post images, 8 steps x (hi, lo)
+constexpr int M_POST_IMG = 16 * 1024;
+constexpr int M_LDS_PLAIN = 2 * M_STAGE;
+constexpr int M_LDS_POST = M_OFF_POST + M_POST_IMG;
+static_assert(M_LDS_POST <= LDS_LIMIT, "LDS map");
+static_assert(M_PPW <= M_NG, "one DMA piece per k step of the first row pair");
+
+template <bool BF16, bool AG>
+__device__ __forceinline__ void mfma_m(f32x16& acc, const i32x4& a, const i32x4& b)
+{
+    if (BF16) {
+        if (AG) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b));
+        else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    } else {
+        if (AG) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b));
+        else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    }
+}
+// acc = A B (C = 0): the first MFMA of a row pair's chain
+template <bool BF16>
+__device__ __forceinline__ void mfma_m0(f32x16& acc, const i32x4& a, const i32x4& b)
+{
+    if (BF16) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+}
+template <bool BF16>
+__device__ __forceinline__ f32x16 mfma_b(i32x4 a, i32x4 b, f32x16 c)
+{
+    if (BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// fp32 -> three 16-bit parts (b = hi + mid + lo to 24 bits): the bias as k slots 0 .. 2 of an A fragment against a B fragment of ones
+template <bool BF16>
+__device__ __forceinline__ i32x4 bias_frag(float b, bool first_half)
+{
+    float h0, m0, dummy;
+    unpack2<BF16>(pack2<BF16>(b, 0.f), h0, dummy);
+    const float r1 = b - h0;
+    unpack2<BF16>(pack2<BF16>(r1, 0.f), m0, dummy);
+    const float r2 = r1 - m0;
+    const unsigned x = pack2<BF16>(h0, m0), y = pack2<BF16>(r2, 0.f);
+    return first_half ? i32x4{(int)x, (int)y, 0, 0} : i32x4{0, 0, 0, 0};
+}
+
+template <bool BF16, bool POST>
+__global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
+{
+    constexpr int RW = M_RW, NG = M_NG, TAPS = M_TAPS, STAGE = M_STAGE, ROWB = M_ROWB, PIXB = M_PIXB, PPW = M_PPW;
+    constexpr int NREG = POST ? 3 * TAPS * 2 : M_NFRAG;    // fragments in registers; the first min(NREG, 64) in accumulation registers
+    constexpr int NAG = NREG < 64 ? NREG : 64;
+    constexpr int NVG = NREG - NAG;
+    constexpr int SPP = POST ? 6 : 4;                      // stores per row pair
+    constexpr unsigned ONE = BF16 ? 0x3f80u : 0x3c00u;
+    constexpr bool PLO = BF16;                             // the post 1x1 sees hi + lo activations and weights (bf16), hi only (fp16)
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pn = lane & 31, hh = lane >> 5;              // MFMA column (pixel of the row pair) / k half
+    const int px = pn & 15, pe = pn >> 4;
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    // ---- prologue: weights.  POST: chunk 3's fragments and the post images go to LDS by DMA; everything else straight into registers
+    if (POST) {
+        for (int pc = wv; pc < TAPS * 2; pc += 4) dma_glb16(smem_lds + (unsigned)(M_W3 + pc * 1024), p.wm32 + (size_t)(NREG + pc) * 1024 + lane * 16);
+        for (int pc = wv; pc < M_POST_IMG / 1024; pc += 4) dma_glb16(smem_lds + (unsigned)(M_OFF_POST + pc * 1024), p.pm32 + (size_t)pc * 1024 + lane * 16);
+    }
+    i32x4 wa[NAG];
+    i32x4 wx[NVG > 0 ? NVG : 1];
+#pragma unroll
+    for (int f = 0; f < NAG; ++f) wa[f] = *reinterpret_cast<const i32x4*>(p.wm32 + (size_t)f * 1024 + lane * 16);
+#pragma unroll
+    for (int f = 0; f < NVG; ++f) wx[f] = *reinterpret_cast<const i32x4*>(p.wm32 + (size_t)(NAG + f) * 1024 + lane * 16);
+    // bias fragments (A) against a fragment of ones (B); the residual's selection matrices
+    i32x4 a_bias[2], a_id[2], a_pb = {0, 0, 0, 0};
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) a_bias[hf] = bias_frag<BF16>(p.bias[32 * hf + pn], hh == 0);
+    if (POST) a_pb = bias_frag<BF16>(p.pbias1[pn], hh == 0);
+    const i32x4 b_ones = hh == 0 ? i32x4{(int)(ONE | (ONE << 16)), (int)ONE, 0, 0} : i32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int j0 = pn - 16 * q - 8 * hh;               // k slot of this lane's half that carries output row pn
+        const bool on = p.res_in != 0 && j0 >= 0 && j0 < 8;
+        const unsigned v = ONE << ((j0 & 1) * 16);
+        a_id[q] = i32x4{(on && (j0 >> 1) == 0) ? (int)v : 0, (on && (j0 >> 1) == 1) ? (int)v : 0, (on && (j0 >> 1) == 2) ? (int)v : 0, (on && (j0 >> 1) == 3) ? (int)v : 0};
+    }
+
+    const int ntiles = p.N * p.tiles_y * p.tiles_x;
+    auto tile_index = [&](int k) -> int { return s16_tile_index(k, ntiles); };
+    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) { s16_tile_coords(t, p.magic_x, p.magic_y, p.tiles_x, p.tiles_y, (4 * RW), n, x0, y0); };
+    const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 2;
+    // piece i of this wave of the tile (n, x0, y0) into stage `slot`; nothing valid (behind the last tile): zeros
+    auto dma_piece = [&](int i, bool valid, int n, int x0, int y0, int slot) __attribute__((always_inline)) {
+        const int pc = wv + 4 * i;
+        if (i < PPW - 1 || pc < M_NPIECES) {                             // wave-uniform
+            const unsigned sl = (unsigned)(pc * 64 + lane);               // 16-byte slot of the stage: row sl / 181, then pixel / part of the row
+            const unsigned row = sl / (unsigned)M_ROWSL, rem = sl - row * (unsigned)M_ROWSL;
+            const unsigned lx = rem / (unsigned)M_LSL, part = rem - lx * (unsigned)M_LSL;
+            const int gy = y0 - 1 + (int)row, gx = x0 - 1 + (int)lx;
+            const bool ok = valid && part < 8u && lx < (unsigned)M_TH && row < (unsigned)M_THY && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const unsigned voff = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff) * 2u + part * 16u : OOB;
+            dma_buf16(smem_lds + (unsigned)(slot * STAGE + pc * 1024), voff, make_rsrc(p.x + (size_t)(valid ? n : 0) * img_bytes, img_bytes), 0u);
+        }
+    };
+
+    int n, x0, y0;
+    {
+        const int t0 = tile_index(0);
+        if (t0 < 0) return;
+        tile_coords(t0, n, x0, y0);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma_piece(i, true, n, x0, y0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const unsigned b_base = (unsigned)((wv * RW + pe) * ROWB + px * PIXB + hh * 16);       // this lane's B fragments: + stage, + row / tap / chunk immediates
+    const char* const w3 = smem + M_W3 + lane * 16;
+    const char* const img1 = smem + M_OFF_POST + lane * 16;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const float slope = p.slope, p1s = p.p1_slope;
+    const size_t y_img = (size_t)p.H * p.W * p.y0_pitch * 2;
+    const unsigned rowb = (unsigned)p.W * (unsigned)p.y0_pitch * 2u;
+    const size_t p1_img = POST ? (size_t)p.H * p.W * p.py1_pitch * 2 : 0;
+    const unsigned rowb1 = POST ? (unsigned)p.W * (unsigned)p.py1_pitch * 2u : 0u;
+
+    f32x16 acc[2][2];                    // [row pair & 1][output half]
+    f32x16 d1;                           // the post 1x1's accumulators (32 outputs x the pair's 32 pixels)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { d1[j] = 0.f; acc[0][0][j] = 0.f; acc[0][1][j] = 0.f; acc[1][0][j] = 0.f; acc[1][1][j] = 0.f; }
+    i32x4 bs[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};     // [block & 1]: the block's four values rounded (x, y) and their low parts (z, w)
+    i32x4 pa[2][2];                      // post images of a block: [block & 1][hi, lo]
+    uint2 pq[4];                         // the post result rounded, per 4-channel block
+    float tv0 = 0.f, tv1 = 0.f, tv2 = 0.f, tv3 = 0.f, lv0 = 0.f, lv1 = 0.f, lv2 = 0.f, lv3 = 0.f;
+    unsigned e_v[4], e_vP[2];            // store offsets of the tile whose epilogue is in flight: (half, block pair) / post block pair
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e_v[j] = OOB;
+    e_vP[0] = e_vP[1] = OOB;
+    int e_n = 0;
+    auto store_offsets = [&](int nn_, int x0_, int y0_) __attribute__((always_inline)) {
+        const bool inx = x0_ + px < p.W;
+        const unsigned pix = (unsigned)((y0_ + wv * RW + pe) * p.W + x0_ + px);
+        const unsigned base = (pix * (unsigned)p.y0_pitch + (unsigned)p.y0_coff) * 2u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = 16 * j + 8 * hh;               // (half, block pair) j = 2 half + bp: channels 32 half + 16 bp + 8 h .. + 7
+            e_v[j] = (inx && ch < p.cout_store) ? base + (unsigned)ch * 2u : OOB;
+        }
+        if (POST) {
+            const unsigned base1 = (pix * (unsigned)p.py1_pitch + (unsigned)p.py1_coff) * 2u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ch = 16 * j + 8 * hh;
+                e_vP[j] = (inx && ch < p.p1_cout8) ? base1 + (unsigned)ch * 2u : OOB;
+            }
+        }
+        e_n = nn_;
+    };
+    auto load_pa = [&](int blk) __attribute__((always_inline)) {
+        pa[blk & 1][0] = *reinterpret_cast<const i32x4*>(img1 + (blk * 2) * 1024);
+        if (PLO) pa[blk & 1][1] = *reinterpret_cast<const i32x4*>(img1 + (blk * 2 + 1) * 1024);
+    };
+    // one block (4 channels of the lane's pixel) of the finished pair: step u of its list
+    auto block_op = [&](auto par_, auto blk_, auto u_) __attribute__((always_inline)) {
+        constexpr int par = decltype(par_)::value, blk = decltype(blk_)::value, u = decltype(u_)::value;
+        constexpr int hf = blk >> 2, b = blk & 3, sl = blk & 1;
+        f32x16& A = acc[par][hf];
+        if constexpr (u == 0) {
+            A[4 * b] = act1(A[4 * b], slope); A[4 * b + 1] = act1(A[4 * b + 1], slope);
+            if constexpr (POST && blk == 0) load_pa(0);
+        } else if constexpr (u == 1) {
+            A[4 * b + 2] = act1(A[4 * b + 2], slope); A[4 * b + 3] = act1(A[4 * b + 3], slope);
+            if constexpr (POST && blk == 0) d1 = mfma_b<BF16>(a_pb, b_ones, f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
+        } else if constexpr (u == 2) {
+            bs[sl].x = (int)pack2<BF16>(A[4 * b], A[4 * b + 1]); bs[sl].y = (int)pack2<BF16>(A[4 * b + 2], A[4 * b + 3]);
+            if constexpr (POST && PLO) unpack2<BF16>((unsigned)bs[sl].x, tv0, tv1);
+            if constexpr (POST && !PLO) { bs[sl].z = 0; bs[sl].w = 0; }
+        } else if constexpr (u == 3) {
+            if constexpr (PLO) {
+                unpack2<BF16>((unsigned)bs[sl].y, tv2, tv3);
+                lv0 = A[4 * b] - tv0; lv1 = A[4 * b + 1] - tv1;
+            }
+        } else if constexpr (u == 4) {
+            if constexpr (PLO) {
+                lv2 = A[4 * b + 2] - tv2; lv3 = A[4 * b + 3] - tv3;
+                bs[sl].z = (int)pack2<BF16>(lv0, lv1); bs[sl].w = (int)pack2<BF16>(lv2, lv3);
+            }
+        } else if constexpr (u == 5) {
+            d1 = mfma_b<BF16>(pa[sl][0], bs[sl], d1);
+            if constexpr (blk < 7) load_pa(blk + 1);
+        } else if constexpr (u == 6) {
+            if constexpr (PLO) d1 = mfma_b<BF16>(pa[sl][1], bs[sl], d1);
+        }
+    };
+    // the conv's store of (half, block pair) P of the finished pair whose first row is r
+    auto store_op = [&](auto P_, auto r_) __attribute__((always_inline)) {
+        constexpr int P = decltype(P_)::value, r = decltype(r_)::value;
+        const u32x2 s0 = __builtin_amdgcn_permlane32_swap((unsigned)bs[0].x, (unsigned)bs[1].x, false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane32_swap((unsigned)bs[0].y, (unsigned)bs[1].y, false, false);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)e_n * y_img, 0, (int)y_img, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)s0.x, (int)s1.x, (int)s0.y, (int)s1.y}, yr, e_v[P] + (unsigned)r * rowb, 0, 0);
+    };
+    auto post_act_op = [&](auto pb_, auto m_) __attribute__((always_inline)) {
+        constexpr int pb = decltype(pb_)::value, m = decltype(m_)::value;
+        if constexpr (m == 0) {
+            d1[4 * pb] = act1(d1[4 * pb], p1s); d1[4 * pb + 1] = act1(d1[4 * pb + 1], p1s);
+        } else {
+            d1[4 * pb + 2] = act1(d1[4 * pb + 2], p1s); d1[4 * pb + 3] = act1(d1[4 * pb + 3], p1s);
+            pq[pb].x = pack2<BF16>(d1[4 * pb], d1[4 * pb + 1]); pq[pb].y = pack2<BF16>(d1[4 * pb + 2], d1[4 * pb + 3]);
+        }
+    };
+    auto post_store_op = [&](auto j_, auto r_) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_)::value, r = decltype(r_)::value;
+        const u32x2 s0 = __builtin_amdgcn_permlane32_swap(pq[2 * j].x, pq[2 * j + 1].x, false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane32_swap(pq[2 * j].y, pq[2 * j + 1].y, false, false);
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(p.py1 + (size_t)e_n * p1_img, 0, (int)p1_img, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)s0.x, (int)s1.x, (int)s0.y, (int)s1.y}, r1, e_vP[j] + (unsigned)r * rowb1, 0, 0);
+    };
+    // operation q of the finished pair's epilogue.  POST: block pairs of 15 operations (7 + 7 + the pair's store), three idle slots while
+    // the last post MFMA drains, then the post result (8 + 2).  Plain: 3 + 3 + 1 per block pair.
+    auto op = [&](auto par_, auto r_, auto q_) __attribute__((always_inline)) {
+        constexpr int q = decltype(q_)::value;
+        if constexpr (POST) {
+            if constexpr (q >= 0 && q < 60) {
+                constexpr int P = q / 15, w = q % 15;
+                if constexpr (w < 7) block_op(par_, std::integral_constant<int, 2 * P>{}, std::integral_constant<int, w>{});
+                else if constexpr (w < 14) block_op(par_, std::integral_constant<int, 2 * P + 1>{}, std::integral_constant<int, w - 7>{});
+                else store_op(std::integral_constant<int, P>{}, r_);
+            } else if constexpr (q >= 63 && q < 71) {
+                post_act_op(std::integral_constant<int, (q - 63) / 2>{}, std::integral_constant<int, (q - 63) % 2>{});
+            } else if constexpr (q == 71 || q == 72) {
+                post_store_op(std::integral_constant<int, q - 71>{}, r_);
+            }
+        } else {
+            if constexpr (q >= 0 && q < 28) {
+                constexpr int P = q / 7, w = q % 7;
+                if constexpr (w < 3) block_op(par_, std::integral_constant<int, 2 * P>{}, std::integral_constant<int, w>{});
+                else if constexpr (w < 6) block_op(par_, std::integral_constant<int, 2 * P + 1>{}, std::integral_constant<int, w - 3>{});
+                else store_op(std::integral_constant<int, P>{}, r_);
+            }
+        }
+    };
+    // slot s of a pair (behind its MFMA s, 0 .. 77)
+    auto micro = [&](auto par_, auto r_, auto s_) __attribute__((always_inline)) {
+        constexpr int s = decltype(s_)::value;
+        if constexpr (POST) {
+            if constexpr (s >= 4) op(par_, r_, std::integral_constant<int, s - 4>{});
+        } else {
+            if constexpr (s >= 4 && ((s - 4) & 1) == 0) op(par_, r_, std::integral_constant<int, (s - 4) / 2>{});
+        }
+    };
+
+    for (int k = 0;; ++k) {
+        const int tn = tile_index(k + 1);
+        const bool more = tn >= 0;
+        int nn = 0, nx0 = 0, ny0 = 0;
+        if (more) tile_coords(tn, nn, nx0, ny0);
+        const char* const bb = smem + b_base + (unsigned)((k & 1) * STAGE);
+        // B fragments: a ring of four, read THREE k steps ahead of their MFMAs; chunk 3's A fragments (POST): a ring of three pairs, read
+        // TWO steps ahead.  Linear step index L = 36 rp + g over the tile's 72 steps
+        constexpr int AHEAD = 3;
+        i32x4 b[4];
+        i32x4 a3[3][2];
+        auto read_b = [&](auto L_) __attribute__((always_inline)) {
+            constexpr int L = decltype(L_)::value;
+            constexpr int rp_ = L / NG, g_ = L % NG, c_ = g_ / TAPS, t_ = g_ % TAPS;
+            b[L & 3] = *reinterpret_cast<const i32x4*>(bb + (2 * rp_ + t_ / 3) * ROWB + (t_ % 3) * PIXB + c_ * 32);
+        };
+        auto read_a = [&](auto L_) __attribute__((always_inline)) {
+            constexpr int L = decltype(L_)::value;
+            constexpr int g_ = L % NG;
+            if constexpr (2 * g_ >= NREG) {
+                a3[L % 3][0] = *reinterpret_cast<const i32x4*>(w3 + (2 * g_ - NREG) * 1024);
+                a3[L % 3][1] = *reinterpret_cast<const i32x4*>(w3 + (2 * g_ + 1 - NREG) * 1024);
+            }
+        };
+        static_for<AHEAD>([&](auto L_) __attribute__((always_inline)) { read_b(L_); });
+        auto run_pair = [&](auto rp_tag) __attribute__((always_inline)) {
+            constexpr int rp = decltype(rp_tag)::value;
+            constexpr int par = rp & 1;
+            using PrevPar = std::integral_constant<int, par ^ 1>;
+            using PrevRow = std::integral_constant<int, (rp == 0 ? RW - 2 : 2 * rp - 2)>;
+            if constexpr (rp == 1) store_offsets(n, x0, y0);       // behind the carried epilogue's last store, ahead of this tile's first
+            // slots 0, 1: the bias (the finished pair's accumulators are the other set)
+            mfma_m0<BF16>(acc[par][0], a_bias[0], b_ones);
+            micro(PrevPar{}, PrevRow{}, std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_m0<BF16>(acc[par][1], a_bias[1], b_ones);
+            micro(PrevPar{}, PrevRow{}, std::integral_constant<int, 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<NG>([&](auto g_) __attribute__((always_inline)) {
+                constexpr int g = decltype(g_)::value;
+                constexpr int c = g / TAPS, t = g % TAPS, L = rp * NG + g, cs = L & 3;
+                constexpr int s0 = 2 + 2 * g + (g > 4) + (g > 13) + (g > 22) + (g > 31);
+                if constexpr (L + AHEAD < 2 * NG) read_b(std::integral_constant<int, L + AHEAD>{});
+                if constexpr (L + 2 < 2 * NG) read_a(std::integral_constant<int, L + 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<2>([&](auto hf_) __attribute__((always_inline)) {
+                    constexpr int hf = decltype(hf_)::value, f = 2 * g + hf;
+                    if constexpr (f < NAG) mfma_m<BF16, true>(acc[par][hf], wa[f], b[cs]);
+                    else if constexpr (f < NREG) mfma_m<BF16, false>(acc[par][hf], wx[f - NAG < 0 ? 0 : f - NAG], b[cs]);
+                    else mfma_m<BF16, false>(acc[par][hf], a3[L % 3][hf], b[cs]);
+                    micro(PrevPar{}, PrevRow{}, std::integral_constant<int, s0 + hf>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if constexpr (t == 4) {
+                    // the residual == input: this chunk's 16 channels of the centre pixel onto output channels 16 c .. 16 c + 15
+                    mfma_m<BF16, false>(acc[par][c >> 1], a_id[c & 1], b[cs]);
+                    micro(PrevPar{}, PrevRow{}, std::integral_constant<int, s0 + 2>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (rp == 0 && g < PPW) dma_piece(g, more, nn, nx0, ny0, (k + 1) & 1);      // the next tile's DMA, in the shadow of the matrix pipe
+            });
+        };
+        run_pair(std::integral_constant<int, 0>{});
+        run_pair(std::integral_constant<int, 1>{});
+        // the next tile has landed: younger than its DMA are the stores of this tile's first row pair
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(SPP) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (!more) break;
+        n = nn; x0 = nx0; y0 = ny0;
+    }
+    // the last tile's last row pair: the same operations, back to back
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");     // (asm MFMAs: hipcc does not pad MFMA -> VALU reads of their results)
+    static_for<M_SLOTS>([&](auto s_) __attribute__((always_inline)) { micro(std::integral_constant<int, 1>{}, std::integral_constant<int, RW - 2>{}, s_); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the trailing zero-fill DMA must not outlive the block)
+}
+
+template <bool BF16, bool POST>
+int launch_conv64m(const S16K& k, hipStream_t st)
+{
+    constexpr int LDS = POST ? M_LDS_POST : M_LDS_PLAIN;
+    static std::atomic<unsigned> attr_set[MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
+    if (!attr_set[dev].load(std::memory_order_relaxed)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64m_kernel<BF16, POST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            esr_set_err("hipFuncSetAttribute(conv64m_kernel, MaxDynamicSharedMemorySize)", e);
+            return ESR_ERR_LAUNCH;
+        }
+        attr_set[dev].store(1u, std::memory_order_relaxed);
+    }
+    const int ntiles = k.N * k.tiles_x * k.tiles_y;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    esr_note_kernel("conv64m_kernel<%s, %s>", esr_tf(BF16), esr_tf(POST));
+    hipLaunchKernelGGL((conv64m_kernel<BF16, POST>), dim3(grid), dim3(256), LDS, st, k);
+    return esr_check_launch("conv64m_kernel launch");
+}
+
+}  // namespace
+
+int esr_launch_conv64m(const S16K& k, bool bf16, bool post, hipStream_t st)
+{
+    if (!k.wm32 || (post && (!k.pm32 || !k.pbias1))) return ESR_ERR_BAD_ARG;
+    if (bf16) return post ? launch_conv64m<true, true>(k, st) : launch_conv64m<true, false>(k, st);
+    return post ? launch_conv64m<false, true>(k, st) : launch_conv64m<false, false>(k, st);
+}
+
+// ---- host side: where the 32x32x16 images live inside the packed blobs ----------------------------------------------------------------------
+// esr_pack_conv_s16 blob of a 3x3 over 64 physical input channels with 49 .. 64 outputs: [tap-pair image 80 KB][bias 256 B][this image 72 KB];
+// fragment f = (chunk * 9 + tap) * 2 + half, lane l = 32 h + i, element j: the 16-bit weight of output channel 32 half + i, input slot
+// 16 chunk + 8 h + j at that tap (the same error-diffused values as the tap-pair image)
+size_t esr_m32_conv_bytes(int cin_phys, int cout, int ksize)
+{
+    return (ksize == 3 && esr_round_up(cin_phys, 16) == 64 && esr_round_up(cout, 16) == 64) ? (size_t)M_NFRAG * 1024 : 0;
+}
+size_t esr_m32_conv_offset(int cin_phys, int cout, int ksize)
+{
+    if (!esr_m32_conv_bytes(cin_phys, cout, ksize)) return 0;
+    return (size_t)4 * 5 * 4 * 1024 + 4 * 16 * sizeof(float);
+}
+// esr_pack_post_s16 blob of a 1x1 from 49 .. 64 to 17 .. 32 channels: [hi images][lo images][bias][this image 16 KB]: fragment (step, hi | lo),
+// step = 4 half + block: the eight input channels 32 half + 8 block + 4 h + (j & 3); hi image: the weight's high part in all eight k slots
+// (slots 0 .. 3 meet the activations' high parts, 4 .. 7 their low parts), lo image: its low part in slots 0 .. 3 only
+size_t esr_m32_post_bytes(int cin, int cout)
+{
+    return (esr_round_up(cin, 16) == 64 && esr_round_up(cout, 16) == 32) ? (size_t)M_POST_IMG : 0;
+}
+size_t esr_m32_post_offset(int cin, int cout)
+{
+    if (!esr_m32_post_bytes(cin, cout)) return 0;
+    return (size_t)2 * 4 * 2 * 1024 + 2 * 16 * sizeof(float);
+}

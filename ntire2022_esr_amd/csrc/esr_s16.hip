@@ -48,48 +48,7 @@
 
 namespace {
 
-struct S16K {
-    const char* x;        // NHWC 16-bit input
-    const char* wp;       // esr_pack_conv_s16 blob: weight image, then fp32 bias
-    const float* bias;
-    const char* res;      // NHWC 16-bit residual
-    char* y0;             // NHWC 16-bit output, or NCHW fp32 (ESR_NCHW_SHUFFLE4)
-    char* y1;
-    int N, H, W;
-    int nchunks;          // ceil(cin_phys / 16)
-    int ring;             // input stages in LDS
-    int in_pitch, in_coff;
-    int res_pitch, res_coff;
-    int y0_pitch, y0_coff, y1_pitch, y1_coff;
-    int cout_store;       // NHWC: round_up8(cout) -- channels >= this are never stored; SHUFFLE4: cout
-    int split;
-    int act;
-    float slope;          // LeakyReLU slope; the kernel evaluates max(v, slope * v): 1 = identity, 0 = ReLU
-    int res_mode;         // residual read from HBM (0 = none)
-    int res_in;           // pre-activation residual == the conv input: added from the staged tile in LDS, no loads
-    int nres;             // residual from HBM staged like input chunks: this many extra 16-channel stages per tile (PNT1 == 0 kernels)
-    int out_layout;
-    int tiles_x, tiles_y;
-    unsigned magic_x, magic_y;   // ceil(2^32 / tiles): t / tiles == umulhi(t, magic) for t * tiles < 2^32 (0: tiles == 1)
-    // post chain (PNT1 > 0 kernels): 1x1 convolution(s) of the epilogue result, evaluated in the epilogue (esr_conv_desc.post_*)
-    const char* pw1; const char* pw2;      // esr_pack_post_s16 blobs: hi images, lo images, fp32 bias
-    char* py1; char* py2;
-    int py1_pitch, py1_coff, py2_pitch, py2_coff;
-    int p1_cout8, p2_cout8;                // channels stored (multiples of 8 / 4)
-    float p1_slope;                        // activation of post 1 as max(v, slope v)
-    int p1_gelu;                           // ... or GELU
-    int post_lo;                           // the low-part weight images are resident too (w = hi + lo)
-    int store_main;                        // 0: the conv's own result is consumed by the post chain only
-    const float* border;                   // esr_conv_desc.border_bias, or NULL
-    long long seg_stride;                  // segmented input: bytes between the tensors of the concat (else 0)
-    int seg_chunks;                        // chunks per input segment (one tensor: nchunks)
-    // hi + lo tensors (esr_conv_desc.hilo, HILO kernels): a value is the sum of two 16-bit numbers kept in two dense tensors of the same
-    // shape, the low parts `hilo_stride` bytes behind the high parts
-    int w_chunks;                          // resident weight chunks: input chunk c multiplies weight chunk c mod w_chunks (hi + lo INPUT: nchunks / 2;
-                                           // the input is then a two-segment concat: seg_stride = hilo_stride, seg_chunks = w_chunks)
-    int hilo_out;                          // the epilogue stores the low parts too (through y1 = y0 + hilo_stride)
-    long long res_lo_stride;               // hi + lo RESIDUAL: 2 NT residual stages per tile, the second NT from res + this many bytes (else 0)
-};
+// (struct S16K: esr_s16_dev.h -- shared with esr_c64m.hip)
 
 
 // Pipeline (per block, stages s = (tile, 16-channel chunk) in order; R = ring slots):
@@ -2635,6 +2594,13 @@ static bool conv48rl_takes(const esr_conv_desc* d)
     return (long)d->n * ((d->w + TILE - 1) / TILE) * ((d->h + 15) / 16) >= 256;
 }
 
+// A/B switch of the round-6 kernel family (esr_c64m.hip): ESR_C64M=0 in the environment keeps conv64r / conv64rq_kernel (read once)
+static bool c64m_enabled()
+{
+    static const int on = [] { const char* e = getenv("ESR_C64M"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
+
 // 1: conv48r_kernel / conv48rp_kernel (one 4-wave block per CU, weights in registers), 4: conv_s16_kernel's two-blocks-per-CU shape (4
 // waves, 16 x 16 tiles), 8: one 8-wave block per CU on 16 x 32 tiles
 int s16_block_waves(const esr_conv_desc* d)
@@ -2724,7 +2690,8 @@ size_t esr_packed_conv_s16_bytes(int cin_phys, int cout, int ksize)
     const size_t nt = (size_t)esr_round_up(cout, 16) / 16;
     const size_t nchunks = (size_t)esr_round_up(cin_phys, 16) / 16;
     const size_t pairs = (size_t)(ksize * ksize + 1) / 2;
-    return nchunks * pairs * nt * 1024 + nt * 16 * sizeof(float);
+    // (+ the v_mfma_f32_32x32x16 image of the 64 -> 64 3x3s behind the bias: esr_c64m.hip)
+    return nchunks * pairs * nt * 1024 + nt * 16 * sizeof(float) + esr_m32_conv_bytes(cin_phys, cout, ksize);
 }
 
 int esr_pack_conv_s16(const float* w, const float* bias, int cin, int cout, int ksize, const int32_t* cin_map, int cin_phys,
@@ -2739,6 +2706,8 @@ int esr_pack_conv_s16(const float* w, const float* bias, int cin, int cout, int 
     const int nchunks = esr_round_up(cin_phys, 16) / 16;
     memset(out, 0, need);
     uint16_t* o = static_cast<uint16_t*>(out);
+    const size_t m32_off = esr_m32_conv_offset(cin_phys, cout, ksize);
+    uint16_t* om = m32_off ? reinterpret_cast<uint16_t*>(static_cast<char*>(out) + m32_off) : nullptr;
     for (int s = 0; s < cin_phys; ++s) {
         const int c = cin_map ? cin_map[s] : (s < cin ? s : -1);
         if (c < 0) continue;
@@ -2760,6 +2729,8 @@ int esr_pack_conv_s16(const float* w, const float* bias, int cin, int cout, int 
                     const uint16_t q = to16(t, compute);
                     e = t - from16(q, compute);
                     o[s16_index(nt, pairs, s, tap, oc)] = q;
+                    // the same value in v_mfma_f32_32x32x16's fragment order (esr_c64m.hip): fragment (chunk, tap, half), lane 32 h + i, slot j
+                    if (om) om[(((((size_t)(s / 16) * 9 + tap) * 2 + oc / 32) * 64 + ((s % 16) / 8) * 32 + oc % 32) * 8) + s % 8] = q;
                 }
             }
         }
@@ -2774,7 +2745,7 @@ size_t esr_packed_post_s16_bytes(int cin, int cout)
 {
     if (cin <= 0 || cout <= 0) return 0;
     const size_t kt = (size_t)esr_round_up(cin, 16) / 16, ot = (size_t)esr_round_up(cout, 16) / 16;
-    return 2 * kt * ot * 1024 + ot * 16 * sizeof(float);
+    return 2 * kt * ot * 1024 + ot * 16 * sizeof(float) + esr_m32_post_bytes(cin, cout);
 }
 
 int esr_pack_post_s16(const float* w, const float* bias, int cin, int cout, int compute, void* out, size_t out_bytes)
@@ -2787,6 +2758,8 @@ int esr_pack_post_s16(const float* w, const float* bias, int cin, int cout, int 
     memset(out, 0, need);
     uint16_t* hi = static_cast<uint16_t*>(out);
     uint16_t* lo = hi + (size_t)kt * ot * 512;
+    const size_t pm_off = esr_m32_post_offset(cin, cout);
+    uint16_t* pm = pm_off ? reinterpret_cast<uint16_t*>(static_cast<char*>(out) + pm_off) : nullptr;
     // image [k tile][out tile][lane = kq * 16 + i][j]: input channel 16 kt + 4 kq + (j & 3) for output channel 16 ot + i; the
     // B operand carries the high parts of the four fp32 inputs in slots 0..3 and their low parts in 4..7, so the hi image has
     // the weight's high part in all eight slots, the lo image its low part in slots 0..3 only (lo x lo is dropped)
@@ -2799,6 +2772,13 @@ int esr_pack_post_s16(const float* w, const float* bias, int cin, int cout, int 
             hi[base] = h;
             hi[base + 4] = h;
             lo[base] = l;
+            if (pm) {
+                // v_mfma_f32_32x32x16 order (esr_c64m.hip): step c / 8, images (hi, lo), lane 32 ((c % 8) / 4) + o, slots c % 4 and c % 4 + 4
+                const size_t mb = ((((size_t)(c / 8) * 2) * 64 + ((c % 8) / 4) * 32 + o) * 8) + (c % 4);
+                pm[mb] = h;
+                pm[mb + 4] = h;
+                pm[mb + 512] = l;
+            }
         }
     float* bo = reinterpret_cast<float*>(static_cast<char*>(out) + 2 * (size_t)kt * ot * 1024);
     if (bias)
@@ -3008,6 +2988,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     k.w_chunks = wchunks;
     k.hilo_out = (hilo & ESR_HILO_OUT) ? 1 : 0;
     k.res_lo_stride = (hilo & ESR_HILO_RES) ? d->hilo_stride : 0;
+    k.wm32 = nullptr; k.pm32 = nullptr; k.pbias1 = nullptr;
     if (k.hilo_out) {                                              // the low parts leave through the y1 stores
         k.y1 = k.y0 + d->hilo_stride;
         k.y1_pitch = k.y0_pitch;
@@ -3075,6 +3056,19 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         const double nt_all = (double)d->n * kp.tiles_x * kp.tiles_y;
         if (nt_all * (kp.tiles_x > kp.tiles_y ? kp.tiles_x : kp.tiles_y) < 4294967296.0)
             return bf16 ? launch_conv48rp<true>(kp, st) : launch_conv48rp<false>(kp, st);
+    }
+    if (c64m_enabled() && (conv64rq_takes(d) || (conv64r_takes(d) && nt == 4))) {
+        // round 6: the 64 -> 64 3x3s (RFDB c1_r / c2_r with the next distillation 1x1, c3_r) on v_mfma_f32_32x32x16 (esr_c64m.hip)
+        S16K k4 = k;
+        k4.tiles_y = (d->h + 15) / 16;
+        k4.magic_y = k4.tiles_y > 1 ? (unsigned)((0x100000000ull + k4.tiles_y - 1) / k4.tiles_y) : 0u;
+        k4.wm32 = k.wp + esr_m32_conv_offset(cin_phys, d->cout, 3);
+        if (post) {
+            k4.pm32 = k.pw1 + esr_m32_post_offset(d->cout, d->post_cout);
+            k4.pbias1 = reinterpret_cast<const float*>(k.pw1 + (size_t)2 * 4 * 2 * 1024);
+        }
+        const double nt_all = (double)d->n * k4.tiles_x * k4.tiles_y;
+        if (nt_all * (k4.tiles_x > k4.tiles_y ? k4.tiles_x : k4.tiles_y) < 4294967296.0) return esr_launch_conv64m(k4, bf16, post, st);
     }
     if (conv64rq_takes(d)) {
         S16K k4 = k;

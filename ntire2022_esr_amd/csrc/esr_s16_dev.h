@@ -17,6 +17,61 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
+// Kernel parameter block of every 16-bit-storage convolution kernel (esr_s16.hip, esr_c64m.hip), filled by esr_conv2d_s16.
+struct S16K {
+    const char* x;        // NHWC 16-bit input
+    const char* wp;       // esr_pack_conv_s16 blob: weight image, then fp32 bias
+    const float* bias;
+    const char* res;      // NHWC 16-bit residual
+    char* y0;             // NHWC 16-bit output, or NCHW fp32 (ESR_NCHW_SHUFFLE4)
+    char* y1;
+    int N, H, W;
+    int nchunks;          // ceil(cin_phys / 16)
+    int ring;             // input stages in LDS
+    int in_pitch, in_coff;
+    int res_pitch, res_coff;
+    int y0_pitch, y0_coff, y1_pitch, y1_coff;
+    int cout_store;       // NHWC: round_up8(cout) -- channels >= this are never stored; SHUFFLE4: cout
+    int split;
+    int act;
+    float slope;          // LeakyReLU slope; the kernel evaluates max(v, slope * v): 1 = identity, 0 = ReLU
+    int res_mode;         // residual read from HBM (0 = none)
+    int res_in;           // pre-activation residual == the conv input: added from the staged tile in LDS, no loads
+    int nres;             // residual from HBM staged like input chunks: this many extra 16-channel stages per tile (PNT1 == 0 kernels)
+    int out_layout;
+    int tiles_x, tiles_y;
+    unsigned magic_x, magic_y;   // ceil(2^32 / tiles): t / tiles == umulhi(t, magic) for t * tiles < 2^32 (0: tiles == 1)
+    // post chain (PNT1 > 0 kernels): 1x1 convolution(s) of the epilogue result, evaluated in the epilogue (esr_conv_desc.post_*)
+    const char* pw1; const char* pw2;      // esr_pack_post_s16 blobs: hi images, lo images, fp32 bias
+    char* py1; char* py2;
+    int py1_pitch, py1_coff, py2_pitch, py2_coff;
+    int p1_cout8, p2_cout8;                // channels stored (multiples of 8 / 4)
+    float p1_slope;                        // activation of post 1 as max(v, slope v)
+    int p1_gelu;                           // ... or GELU
+    int post_lo;                           // the low-part weight images are resident too (w = hi + lo)
+    int store_main;                        // 0: the conv's own result is consumed by the post chain only
+    const float* border;                   // esr_conv_desc.border_bias, or NULL
+    long long seg_stride;                  // segmented input: bytes between the tensors of the concat (else 0)
+    int seg_chunks;                        // chunks per input segment (one tensor: nchunks)
+    // hi + lo tensors (esr_conv_desc.hilo, HILO kernels): a value is the sum of two 16-bit numbers kept in two dense tensors of the same
+    // shape, the low parts `hilo_stride` bytes behind the high parts
+    int w_chunks;                          // resident weight chunks: input chunk c multiplies weight chunk c mod w_chunks (hi + lo INPUT: nchunks / 2;
+                                           // the input is then a two-segment concat: seg_stride = hilo_stride, seg_chunks = w_chunks)
+    int hilo_out;                          // the epilogue stores the low parts too (through y1 = y0 + hilo_stride)
+    long long res_lo_stride;               // hi + lo RESIDUAL: 2 NT residual stages per tile, the second NT from res + this many bytes (else 0)
+    // esr_c64m.hip (v_mfma_f32_32x32x16 family): the weight image in that MFMA's fragment order (appended to the esr_pack_conv_s16 blob), the
+    // post 1x1's images likewise (esr_pack_post_s16 blob) and its fp32 bias
+    const char* wm32; const char* pm32; const float* pbias1;
+};
+
+// esr_c64m.hip: the 64 -> 64 3x3 family on v_mfma_f32_32x32x16 (round 6).  `post`: with one post 1x1 of <= 32 outputs (RFDB c{j}_r + c{j+1}_d)
+int esr_launch_conv64m(const S16K& k, bool bf16, bool post, hipStream_t st);
+// byte offsets of the 32x32x16 weight images inside the esr_pack_conv_s16 / esr_pack_post_s16 blobs (0: this shape carries none), and their writers
+size_t esr_m32_conv_offset(int cin_phys, int cout, int ksize);
+size_t esr_m32_conv_bytes(int cin_phys, int cout, int ksize);
+size_t esr_m32_post_offset(int cin, int cout);
+size_t esr_m32_post_bytes(int cin, int cout);
+
 namespace {
 
 // compile-time loops: the body sees its index as a constant expression (std::integral_constant) -- schedules written as `if constexpr`

@@ -40,6 +40,28 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// research builds (tools/r06/build_variant.sh ... "-DC64M_ABL=n"): bit 0 no stores, bit 1 no DMA behind the first tile, bit 2 no epilogue,
+// bit 3 stores to LINEAR addresses (1 KB contiguous per instruction: wrong placement, the cost of perfectly coalesced stores), bit 4 the DMA
+// re-reads the current tile (L2 hits)
+#ifndef C64M_ABL
+#define C64M_ABL 0
+#endif
+// the next tile's DMA piece i (of every wave) is issued behind k step C64M_SPREAD * i of the tile's 72.  Measured at 32 x 256 x 256 (POST / plain,
+// us): 1: 180 / 140, 3: 175 / 139, 5: 177 / 157 (the last pieces land late); all 13 back to back at the top of the tile: 179 / 140; one wave
+// per step in turn: 187 / 148.  What the pieces cost does not depend on where they are issued (LAB_NOTES 11.2)
+#ifndef C64M_SPREAD
+#define C64M_SPREAD 3
+#endif
+
+#ifdef C64M_TRACE
+// research builds: s_memtime stamps at five points of every tile (block 0, wave 0), summed per segment; read back with esr_c64m_trace_read
+__device__ unsigned long long c64m_trace[16];
+extern "C" int esr_c64m_trace_read(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(c64m_trace), sizeof(c64m_trace)) == hipSuccess ? 0 : -1; }
+#define C64M_STAMP(i) { const unsigned long long t_ = __builtin_readcyclecounter(); tr[i] += t_ - tlast; tlast = t_; }
+#else
+#define C64M_STAMP(i) {}
+#endif
+
 namespace {
 
 constexpr int M_NCH = 4, M_TAPS = 9, M_TH = 18, M_RW = 4, M_THY = 4 * M_RW + 2;
@@ -60,7 +82,24 @@ constexpr int M_POST_IMG = 16 * 1024;
 constexpr int M_LDS_PLAIN = 2 * M_STAGE;
 constexpr int M_LDS_POST = M_OFF_POST + M_POST_IMG;
 static_assert(M_LDS_POST <= LDS_LIMIT, "LDS map");
-static_assert(M_PPW <= M_NG, "one DMA piece per k step of the first row pair");
+static_assert(C64M_SPREAD >= 1 && (M_PPW - 1) * C64M_SPREAD < 2 * M_NG, "the DMA pieces fit the tile's k steps");
+
+// slot of k step g's LAST MFMA within its row pair (2 bias slots, two per step, one more behind the centre tap of each chunk)
+constexpr int m_slot_of_step(int g) { return 2 + 2 * g + (g > 4) + (g > 13) + (g > 22) + (g > 31) + 1 + (g % M_TAPS == 4); }
+// slots whose micro-operation issues a store (see `op` in the kernel): POST q = 14, 29, 44, 59, 71, 72 at slot q + 4; plain q = 6, 13, 20, 27 at 2 q + 4
+constexpr int m_stores_behind(bool post, int slot)
+{
+    int n = 0;
+    if (post) { for (int s : {18, 33, 48, 63, 75, 76}) n += s > slot; }
+    else { for (int s : {16, 30, 44, 58}) n += s > slot; }
+    return n;
+}
+// vector-memory instructions a wave has issued behind its last DMA piece by the end of a tile: the tile-end wait
+constexpr int m_tail_stores(bool post, int spread)
+{
+    const int last = spread * (M_PPW - 1), spp = post ? 6 : 4;
+    return last < M_NG ? m_stores_behind(post, m_slot_of_step(last)) + spp : m_stores_behind(post, m_slot_of_step(last - M_NG));
+}
 
 template <bool BF16, bool AG>
 __device__ __forceinline__ void mfma_m(f32x16& acc, const i32x4& a, const i32x4& b)
@@ -147,7 +186,31 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
     auto tile_index = [&](int k) -> int { return s16_tile_index(k, ntiles); };
     auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) { s16_tile_coords(t, p.magic_x, p.magic_y, p.tiles_x, p.tiles_y, (4 * RW), n, x0, y0); };
     const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 2;
-    // piece i of this wave of the tile (n, x0, y0) into stage `slot`; nothing valid (behind the last tile): zeros
+    // DMA pieces.  Piece i of this wave covers 64 consecutive 16-byte slots of the stage; slot -> (row, pixel, part) is lane-constant, so the
+    // offset of the slot's bytes RELATIVE to the tile's first halo pixel is computed once (rel[i]; pad slots: OOB) and a piece costs one
+    // v_add, one s_add into m0 and the load.  Rows above / below the image need nothing: their offsets fall outside the image's buffer
+    // range (a negative offset wraps above 2^31; the host keeps images below 2^31 - 2^20 bytes) and the hardware writes zeros.  Tiles at the
+    // left / right image edge (a halo column outside the row) take the general form with its per-lane column test.
+    unsigned rel[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const unsigned sl = (unsigned)((wv + 4 * i) * 64 + lane);
+        const unsigned row = sl / (unsigned)M_ROWSL, rem = sl - row * (unsigned)M_ROWSL;
+        const unsigned lx = rem / (unsigned)M_LSL, part = rem - lx * (unsigned)M_LSL;
+        const bool real = part < 8u && lx < (unsigned)M_TH && row < (unsigned)M_THY && (i < PPW - 1 || wv + 4 * i < M_NPIECES);
+        rel[i] = real ? (row * (unsigned)p.W + lx) * (unsigned)p.in_pitch * 2u + part * 16u : OOB;
+    }
+    // (m0 is not restored: hipcc keeps nothing in it on gfx950 outside s_set_gpr_idx / s_movrel sequences, and this kernel indexes no register
+    // dynamically; dma_buf16 saves it for kernels that might)
+    auto dma_piece_fast = [&](auto i_, unsigned tbase, i32x4 rsrc, unsigned lds0) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_)::value;
+        if (i < PPW - 1 || wv + 4 * i < M_NPIECES) {                     // wave-uniform
+            const unsigned voff = rel[i] + tbase;
+            asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds"
+                         :: "s"(lds0), "n"(i * 4096), "v"(voff), "s"(rsrc) : "memory");
+        }
+    };
+    // the general form: piece i of this wave of the tile (n, x0, y0) into stage `slot`; nothing valid (behind the last tile): zeros
     auto dma_piece = [&](int i, bool valid, int n, int x0, int y0, int slot) __attribute__((always_inline)) {
         const int pc = wv + 4 * i;
         if (i < PPW - 1 || pc < M_NPIECES) {                             // wave-uniform
@@ -173,8 +236,11 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
     __builtin_amdgcn_s_barrier();
 
     const unsigned b_base = (unsigned)((wv * RW + pe) * ROWB + px * PIXB + hh * 16);       // this lane's B fragments: + stage, + row / tap / chunk immediates
-    const char* const w3 = smem + M_W3 + lane * 16;
-    const char* const img1 = smem + M_OFF_POST + lane * 16;
+    // (laundered through an empty asm: hipcc otherwise re-adds the > 64 KB constant in front of every read instead of using the immediate offset)
+    unsigned w3_off = (unsigned)(M_W3 + lane * 16), img1_off = (unsigned)(M_OFF_POST + lane * 16);
+    asm volatile("" : "+v"(w3_off), "+v"(img1_off));
+    const char* const w3 = smem + w3_off;
+    const char* const img1 = smem + img1_off;
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const float slope = p.slope, p1s = p.p1_slope;
     const size_t y_img = (size_t)p.H * p.W * p.y0_pitch * 2;
@@ -195,6 +261,7 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
     for (int j = 0; j < 4; ++j) e_v[j] = OOB;
     e_vP[0] = e_vP[1] = OOB;
     int e_n = 0;
+    unsigned e_lin = OOB;                // (C64M_ABL & 8)
     auto store_offsets = [&](int nn_, int x0_, int y0_) __attribute__((always_inline)) {
         const bool inx = x0_ + px < p.W;
         const unsigned pix = (unsigned)((y0_ + wv * RW + pe) * p.W + x0_ + px);
@@ -202,17 +269,18 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ch = 16 * j + 8 * hh;               // (half, block pair) j = 2 half + bp: channels 32 half + 16 bp + 8 h .. + 7
-            e_v[j] = (inx && ch < p.cout_store) ? base + (unsigned)ch * 2u : OOB;
+            e_v[j] = (inx && ch < p.cout_store && !(C64M_ABL & 1)) ? base + (unsigned)ch * 2u : OOB;
         }
         if (POST) {
             const unsigned base1 = (pix * (unsigned)p.py1_pitch + (unsigned)p.py1_coff) * 2u;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int ch = 16 * j + 8 * hh;
-                e_vP[j] = (inx && ch < p.p1_cout8) ? base1 + (unsigned)ch * 2u : OOB;
+                e_vP[j] = (inx && ch < p.p1_cout8 && !(C64M_ABL & 1)) ? base1 + (unsigned)ch * 2u : OOB;
             }
         }
         e_n = nn_;
+        if ((C64M_ABL & 8) != 0) e_lin = (unsigned)(((y0_ + wv * RW) * p.W + x0_ * 4) * p.y0_pitch * 2) + (unsigned)lane * 16u;    // the wave's 8 KB of a 16-row band, linear
     };
     auto load_pa = [&](int blk) __attribute__((always_inline)) {
         pa[blk & 1][0] = *reinterpret_cast<const i32x4*>(img1 + (blk * 2) * 1024);
@@ -256,6 +324,9 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
         const u32x2 s0 = __builtin_amdgcn_permlane32_swap((unsigned)bs[0].x, (unsigned)bs[1].x, false, false);
         const u32x2 s1 = __builtin_amdgcn_permlane32_swap((unsigned)bs[0].y, (unsigned)bs[1].y, false, false);
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)e_n * y_img, 0, (int)y_img, 0x00020000);
+        if constexpr ((C64M_ABL & 8) != 0)
+            __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)s0.x, (int)s1.x, (int)s0.y, (int)s1.y}, yr, e_lin + (unsigned)((P * 2 + r / 2) * 1024), 0, 0);
+        else
         __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)s0.x, (int)s1.x, (int)s0.y, (int)s1.y}, yr, e_v[P] + (unsigned)r * rowb, 0, 0);
     };
     auto post_act_op = [&](auto pb_, auto m_) __attribute__((always_inline)) {
@@ -272,6 +343,9 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
         const u32x2 s0 = __builtin_amdgcn_permlane32_swap(pq[2 * j].x, pq[2 * j + 1].x, false, false);
         const u32x2 s1 = __builtin_amdgcn_permlane32_swap(pq[2 * j].y, pq[2 * j + 1].y, false, false);
         const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(p.py1 + (size_t)e_n * p1_img, 0, (int)p1_img, 0x00020000);
+        if constexpr ((C64M_ABL & 8) != 0)
+            __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)s0.x, (int)s1.x, (int)s0.y, (int)s1.y}, r1, e_lin / 2 + (unsigned)((j * 2 + r / 2) * 1024), 0, 0);
+        else
         __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)s0.x, (int)s1.x, (int)s0.y, (int)s1.y}, r1, e_vP[j] + (unsigned)r * rowb1, 0, 0);
     };
     // operation q of the finished pair's epilogue.  POST: block pairs of 15 operations (7 + 7 + the pair's store), three idle slots while
@@ -301,19 +375,31 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
     // slot s of a pair (behind its MFMA s, 0 .. 77)
     auto micro = [&](auto par_, auto r_, auto s_) __attribute__((always_inline)) {
         constexpr int s = decltype(s_)::value;
-        if constexpr (POST) {
+        if constexpr ((C64M_ABL & 4) != 0) {
+        } else if constexpr (POST) {
             if constexpr (s >= 4) op(par_, r_, std::integral_constant<int, s - 4>{});
         } else {
             if constexpr (s >= 4 && ((s - 4) & 1) == 0) op(par_, r_, std::integral_constant<int, (s - 4) / 2>{});
         }
     };
 
+#ifdef C64M_TRACE
+    unsigned long long tr[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     for (int k = 0;; ++k) {
+        C64M_STAMP(0)                       // tile bookkeeping + the B ring's first reads are in segment 1
         const int tn = tile_index(k + 1);
         const bool more = tn >= 0;
         int nn = 0, nx0 = 0, ny0 = 0;
         if (more) tile_coords(tn, nn, nx0, ny0);
         const char* const bb = smem + b_base + (unsigned)((k & 1) * STAGE);
+        // the next tile's DMA: fast pieces unless a halo column leaves the image row (or nothing follows: zero fill through the general form)
+        const bool fast = more && nx0 > 0 && nx0 + TILE < p.W;
+        // (C64M_ABL & 16: the DMA re-reads the CURRENT tile -- L2 hits -- to tell memory latency / bandwidth from issue cost)
+        const unsigned tbase = (C64M_ABL & 16) ? (unsigned)(((y0 - 1) * p.W + (x0 - 1)) * p.in_pitch + p.in_coff) * 2u
+                                               : (unsigned)(((ny0 - 1) * p.W + (nx0 - 1)) * p.in_pitch + p.in_coff) * 2u;
+        const i32x4 nrsrc = make_rsrc(p.x + (size_t)((C64M_ABL & 16) ? n : nn) * img_bytes, img_bytes);
+        const unsigned lds0 = smem_lds + (unsigned)(((k + 1) & 1) * STAGE + wv * 1024);
         // B fragments: a ring of four, read THREE k steps ahead of their MFMAs; chunk 3's A fragments (POST): a ring of three pairs, read
         // TWO steps ahead.  Linear step index L = 36 rp + g over the tile's 72 steps
         constexpr int AHEAD = 3;
@@ -332,9 +418,11 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
                 a3[L % 3][1] = *reinterpret_cast<const i32x4*>(w3 + (2 * g_ + 1 - NREG) * 1024);
             }
         };
+        C64M_STAMP(5)                       // (trace builds) the DMA burst
         static_for<AHEAD>([&](auto L_) __attribute__((always_inline)) { read_b(L_); });
-        auto run_pair = [&](auto rp_tag) __attribute__((always_inline)) {
+        auto run_pair = [&](auto rp_tag, auto fast_tag) __attribute__((always_inline)) {
             constexpr int rp = decltype(rp_tag)::value;
+            constexpr bool FAST = decltype(fast_tag)::value;
             constexpr int par = rp & 1;
             using PrevPar = std::integral_constant<int, par ^ 1>;
             using PrevRow = std::integral_constant<int, (rp == 0 ? RW - 2 : 2 * rp - 2)>;
@@ -367,17 +455,37 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
                     micro(PrevPar{}, PrevRow{}, std::integral_constant<int, s0 + 2>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (rp == 0 && g < PPW) dma_piece(g, more, nn, nx0, ny0, (k + 1) & 1);      // the next tile's DMA, in the shadow of the matrix pipe
+                if constexpr (L == 13) C64M_STAMP(1)        // k steps 0 .. 12 of the first pair: the DMA pieces' steps
+                if constexpr (L == NG) C64M_STAMP(2)        // the rest of the first pair
+                if constexpr (L % C64M_SPREAD == 0 && L / C64M_SPREAD < PPW && !(C64M_ABL & 2)) {       // the next tile's DMA, in the shadow of the matrix pipe
+                    if constexpr (FAST) dma_piece_fast(std::integral_constant<int, L / C64M_SPREAD>{}, tbase, nrsrc, lds0);
+                    else dma_piece(L / C64M_SPREAD, more, nn, nx0, ny0, (k + 1) & 1);
+                }
             });
         };
-        run_pair(std::integral_constant<int, 0>{});
-        run_pair(std::integral_constant<int, 1>{});
-        // the next tile has landed: younger than its DMA are the stores of this tile's first row pair
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(SPP) : "memory");
-        __builtin_amdgcn_s_barrier();
+        if (fast) {                                                                       // (one wave-uniform branch per tile)
+            run_pair(std::integral_constant<int, 0>{}, std::true_type{});
+            run_pair(std::integral_constant<int, 1>{}, std::true_type{});
+        } else {
+            run_pair(std::integral_constant<int, 0>{}, std::false_type{});
+            run_pair(std::integral_constant<int, 1>{}, std::false_type{});
+        }
+        // the next tile has landed: younger than the wave's last DMA piece are exactly m_tail_stores() stores
+        C64M_STAMP(3)                       // the second pair
+        if constexpr ((C64M_ABL & 32) == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(m_tail_stores(POST, C64M_SPREAD)) : "memory");      // (C64M_ABL & 32: no wait -- timing only)
+        if constexpr ((C64M_ABL & 64) == 0) __builtin_amdgcn_s_barrier();                                   // (C64M_ABL & 64: no barrier -- timing only)
+        C64M_STAMP(4)                       // the tile-end wait + barrier
+#ifdef C64M_TRACE
+        tr[6] += 1;
+#endif
         if (!more) break;
         n = nn; x0 = nx0; y0 = ny0;
     }
+#ifdef C64M_TRACE
+    if (blockIdx.x == 0 && tid == 0) {
+        for (int i = 0; i < 7; ++i) c64m_trace[i + (POST ? 8 : 0)] = tr[i];
+    }
+#endif
     // the last tile's last row pair: the same operations, back to back
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");     // (asm MFMAs: hipcc does not pad MFMA -> VALU reads of their results)
     static_for<M_SLOTS>([&](auto s_) __attribute__((always_inline)) { micro(std::integral_constant<int, 1>{}, std::integral_constant<int, RW - 2>{}, s_); });

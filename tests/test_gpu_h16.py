@@ -27,6 +27,20 @@ def _ulp_ok(got, ref, dt):
     return bool(((got.double() - ref).abs() <= tol).all()), float(((got.double() - ref).abs() - tol).max())
 
 
+def _same_or_one_step(a, b, dt, frac=0.03, scale=1.0):
+    """two 16-bit results of the same arithmetic in another fp32 accumulation order (conv64m_kernel against conv_s16_kernel, round 6): equal but for a
+    few values that sat on a rounding boundary, and those differ by one step of the storage type"""
+    af, bf = a.float(), b.float()
+    eps = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    step = torch.maximum(af.abs(), bf.abs()) * eps + 3e-5 * max(1.0, float(af.abs().max()))      # (+ the accumulation noise of values that cancel to ~0)
+    step = step * scale
+    diff = (af - bf).abs()
+    ok = bool((diff <= step).all()) and float((diff > 0).float().mean()) < frac
+    if not ok:
+        print(f"_same_or_one_step: worst diff / step = {float((diff / step).max()):.3f}, differing fraction = {float((diff > 0).float().mean()):.4f} (limit {frac})")
+    return ok
+
+
 ACTS = {0: lambda t: t, 1: lambda t: F.leaky_relu(t, 0.05), 2: F.relu, 3: lambda t: F.gelu(t)}
 
 
@@ -485,7 +499,10 @@ def test_conv64r_equals_conv_s16(compute, cin, cout, act, res_in, hw, n):
         if res_in:
             kw1["res"] = xin[i:i + 1]
         y1 = ops.conv2d(xin[i:i + 1].contiguous(), w, b, **kw1)
-        assert torch.equal(y[i:i + 1], y1), i
+        if cout > 48:      # 64 outputs: the batch runs on conv64m_kernel (32x32x16 MFMAs, nine taps, another accumulation order) since round 6
+            assert _same_or_one_step(y[i:i + 1], y1, dt), i
+        else:
+            assert torch.equal(y[i:i + 1], y1), i
     weff, _ = unpack_conv_s16(blob.cpu(), cin, cout, 3, compute, cin_phys=cp)
     conv = F.conv2d(x.double().to(DEV), weff.double().to(DEV), b.double().to(DEV), padding=1)
     if res_in:
@@ -622,5 +639,8 @@ def test_conv64rq_equals_conv_s16(compute, hw, n, c, pc, res_in):
     for i in range(n):
         xi = x[i:i + 1].contiguous()
         y1, p1 = ops.conv2d(xi, w, b, **(dict(res=xi) if res_in else {}), **kw)
-        assert torch.equal(y[i:i + 1], y1) and torch.equal(yp[i:i + 1], p1), i
+        # (round 6: the batch runs on conv64m_kernel -- same weights and arithmetic in another accumulation order)
+        # (fp16: the 1x1 reads the ROUNDED activations, so a value of y that flipped by one step -- 1e-3 at |y| ~ 1 -- moves every post output it
+        # feeds by up to |w| x that: a few steps of a small output)
+        assert _same_or_one_step(y[i:i + 1], y1, dt) and _same_or_one_step(yp[i:i + 1], p1, dt, 0.03, 1.0 if compute == "bf16" else 10.0), i
     assert bool(torch.isfinite(y.float()).all()) and float(yp.float().abs().max()) > 0

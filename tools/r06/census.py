@@ -16,7 +16,7 @@ for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)\n\s*\.end_amdhsa_kernel", src, re.
     # largest basic-block-ish region between labels
     blocks, cur = [], []
     for l in lines:
-        if l.endswith(":") and l.startswith(".LBB"):
+        if l.startswith(".LBB") and ":" in l.split()[0]:
             blocks.append(cur); cur = []
         elif l and not l.startswith((".", ";", "//")):
             cur.append(l)

@@ -55,7 +55,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifdef C64M_TRACE
 // research builds: s_memtime stamps at five points of every tile (block 0, wave 0), summed per segment; read back with esr_c64m_trace_read
-__device__ unsigned long long c64m_trace[16];
+__device__ unsigned long long c64m_trace[32];
 extern "C" int esr_c64m_trace_read(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(c64m_trace), sizeof(c64m_trace)) == hipSuccess ? 0 : -1; }
 #define C64M_STAMP(i) { const unsigned long long t_ = __builtin_readcyclecounter(); tr[i] += t_ - tlast; tlast = t_; }
 #else
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
     }
 #ifdef C64M_TRACE
     if (blockIdx.x == 0 && tid == 0) {
-        for (int i = 0; i < 7; ++i) c64m_trace[i + (POST ? 8 : 0)] = tr[i];
+        for (int i = 0; i < 7; ++i) c64m_trace[i + (POST ? 16 : 0)] = tr[i];
     }
 #endif
     // the last tile's last row pair: the same operations, back to back

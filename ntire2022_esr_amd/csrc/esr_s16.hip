@@ -29,8 +29,9 @@
 //   conv48r_kernel<bf16|f16, NT, EXT, RW>        3x3 over 48 channels, weights in registers, one wave per SIMD, whole-pixel stages, row pairs
 //   conv48rp_kernel<bf16|f16, LRS>               ... + residual from HBM staged per wave + RLFB's 1x1 chain; LRS: the LR conv on hi + lo pairs
 //   conv48rq_kernel<f16>                         ... + residual == input, border table, GELU and ONE post 1x1 (ESDB c{j}_r + the next distillation conv)
-//   conv64r_kernel<bf16|f16, NT, EXT>            ... over 64 channels (240 weight registers + one chunk from LDS, 160-byte LDS pixels)
-//   conv64rq_kernel<bf16|f16>                    ... + ONE post 1x1 (RFDB c{j}_r + c{j+1}_d): two chunks in registers, two in LDS
+//   conv64r_kernel<bf16|f16, 2, EXT>             ... over 64 channels with two output tiles (RFDB c4; 160-byte LDS pixels)
+//   (the 64 -> 64 shapes, with and without RFDB's post 1x1, moved to esr_c64m.hip in round 6: v_mfma_f32_32x32x16; conv64rq_kernel and
+//   conv64r_kernel<.., 4, ..> of rounds 4 / 5 are gone)
 // The one-wave-per-SIMD kernels run a finished row pair's epilogue as micro-steps behind each MFMA of the next pair (LAB_NOTES 9.5).
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -1605,299 +1606,6 @@ __global__ __launch_bounds__(256, 1) void conv64r_kernel(const S16K p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the trailing zero-fill DMA must not outlive the block)
 }
 
-// ---- conv64rq_kernel: conv64r_kernel<.., 4, EXT> + ONE post 1x1 of two output tiles (round 4) ----------------------------------------------
-// RFDB's c{j}_r -- lrelu(conv3x3(x) + x), stored -- with the next distillation conv c{j+1}_d + LeakyReLU in its epilogue
-// (rfdn_baseline/block.py:150-160): the eight largest launches of RFDN (conv_s16_kernel<4, 3, 8, .., 2, 0>: 0.24 ms at batch 32, 38 us on one
-// image).  conv64r_kernel's plan with TWO weight chunks in registers (160) and two in LDS (40 KB, fragments two groups ahead through a ring of
-// three) -- the 1x1's operands, accumulators and results need the registers a third resident chunk would take -- and the finished pair's
-// epilogue as a list of 110 micro-operations behind the next pair's 160 convolution MFMAs, as conv48rq_kernel.  LDS: two stages (104 KB),
-// chunks 2 / 3 (40 KB), post images hi (+ lo: bf16) 8 (16) KB = 160 KB.  Bit-identical to conv_s16_kernel.
-template <bool BF16>
-__global__ __launch_bounds__(256, 1) void conv64rq_kernel(const S16K p)
-{
-    constexpr int NT = 4, PNT1 = 2;
-    constexpr bool EXT = true, plo = BF16;
-    constexpr int NCH = 4, PAIRS = 5, TH = 18, RW = 4, THY = 4 * RW + 2;
-    constexpr int GSL = NCH * 2;                   // 16-byte slots of a pixel in memory
-    constexpr int LSL = GSL + 2;                   // ... in LDS
-    constexpr int PIXB = LSL * 16;                 // 160
-    constexpr int NSLOT = TH * THY * LSL;          // 3240
-    constexpr int NPIECES = (NSLOT + 63) / 64;     // 51
-    constexpr int STAGE = NPIECES * 1024;
-    constexpr int PPW = (NPIECES + 3) / 4;         // 13 per wave, the last wave one fewer
-    constexpr int NG = NCH * PAIRS;                // 20 tap-pair groups per row pair
-    constexpr int NCR = 2;                         // chunks whose weights live in registers
-    constexpr int SPP = NT + 2;                    // stores per row pair: the conv's four, the post's two
-    constexpr int WSTAGE = STAGE;                  // the blob is staged behind stage 0 (stage 1 is free until the second tile's DMA) ...
-    constexpr int W3 = 2 * STAGE;                  // ... chunks 2, 3 go straight to their place behind stage 1
-    constexpr int P1_IMG = NT * PNT1 * 1024;       // post images [k tile][out tile] (hi, then lo)
-    constexpr int OFF_POST = W3 + (NCH - NCR) * PAIRS * NT * 1024;
-    static_assert(PPW <= NG, "at most one DMA piece per tap-pair group of the first row pair");
-    static_assert(NT == 2 || NT == 4, "shapes");
-    static_assert(NCR * PAIRS * NT * 1024 <= STAGE && OFF_POST + (plo ? 2 : 1) * P1_IMG <= LDS_LIMIT, "LDS map");
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int px = lane & 15, kq = lane >> 4;
-    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const bool res_in = EXT && p.res_in != 0;       // (no GELU here: the 64-channel layers of the path are RFDN's, LeakyReLU)
-
-    constexpr int WPIECES = NCH * PAIRS * NT;      // 1 KB fragments
-#pragma unroll
-    for (int i = 0; i < (WPIECES + 3) / 4; ++i) {
-        const int pc = wv + 4 * i;
-        if (pc < WPIECES) dma_glb16(smem_lds + (unsigned)(pc < NCR * PAIRS * NT ? WSTAGE + pc * 1024 : W3 + (pc - NCR * PAIRS * NT) * 1024), p.wp + (size_t)pc * 1024 + lane * 16);
-    }
-    for (int pc = wv; pc < (plo ? 2 : 1) * (P1_IMG / 1024); pc += 4) dma_glb16(smem_lds + (unsigned)(OFF_POST + pc * 1024), p.pw1 + (size_t)pc * 1024 + lane * 16);
-    i32x4 wr[NCR][PAIRS][NT];
-    f32x4 bia[NT], pb1[PNT1];
-#pragma unroll
-    for (int t = 0; t < PNT1; ++t) pb1[t] = *reinterpret_cast<const f32x4*>(p.pw1 + (size_t)2 * P1_IMG + (t * 16 + kq * 4) * 4);
-    const char* const img1 = smem + OFF_POST + lane * 16;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bia[t] = *reinterpret_cast<const f32x4*>(p.bias + t * 16 + kq * 4);
-
-    const int ntiles = p.N * p.tiles_y * p.tiles_x;
-    const int G = gridDim.x;
-    auto tile_index = [&](int k) -> int { return s16_tile_index(k, ntiles); };
-    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) { s16_tile_coords(t, p.magic_x, p.magic_y, p.tiles_x, p.tiles_y, (4 * RW), n, x0, y0); };
-    const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 2;
-    // piece i of this wave of the tile (n, x0, y0) into stage `slot`; nothing valid (behind the last tile): zeros
-    auto dma_piece = [&](int i, bool valid, int n, int x0, int y0, int slot) __attribute__((always_inline)) {
-        const int pc = wv + 4 * i;
-        if (i < PPW - 1 || pc < NPIECES) {                             // wave-uniform
-            const unsigned sl = (unsigned)(pc * 64 + lane);             // 16-byte slot of the stage: pixel sl / 10, part sl % 10 (parts 8, 9: the pad)
-            const unsigned pixel = sl / (unsigned)LSL, part = sl - pixel * (unsigned)LSL;
-            const unsigned ly = pixel / (unsigned)TH, lx = pixel - ly * (unsigned)TH;
-            const int gy = y0 - 1 + (int)ly, gx = x0 - 1 + (int)lx;
-            const bool ok = valid && part < (unsigned)GSL && sl < (unsigned)NSLOT && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-            const unsigned voff = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff) * 2u + part * 16u : OOB;
-            dma_buf16(smem_lds + (unsigned)(slot * STAGE + pc * 1024), voff, make_rsrc(p.x + (size_t)(valid ? n : 0) * img_bytes, img_bytes), 0u);
-        }
-    };
-
-    int n, x0, y0;
-    {
-        const int t0 = tile_index(0);
-        if (t0 < 0) return;
-        tile_coords(t0, n, x0, y0);
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) dma_piece(i, true, n, x0, y0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int c = 0; c < NCR; ++c)
-#pragma unroll
-        for (int q = 0; q < PAIRS; ++q)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                wr[c][q][t] = *reinterpret_cast<const i32x4*>(smem + WSTAGE + ((c * PAIRS + q) * NT + t) * 1024 + lane * 16);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                 // every wave holds its fragments: stage 1 may be overwritten
-
-    // lane-constant offsets of the B fragments: pair q reads tap min(2q + (kq >> 1), 8), channel half kq & 1 of the chunk
-    int b_off[PAIRS];
-#pragma unroll
-    for (int q = 0; q < PAIRS; ++q) {
-        const int tap = min(2 * q + (kq >> 1), 8);
-        b_off[q] = ((wv * RW + tap / 3) * TH + px + tap % 3) * PIXB + (kq & 1) * 16;
-    }
-    const int c_off = ((wv * RW + 1) * TH + px + 1) * PIXB + kq * 8;      // centre pixel of row 0 of the wave: channels 16 c + 4 kq .. +3 at + 32 c
-    const char* const w3 = smem + W3 + lane * 16;                           // chunk 3's fragments: + (q * NT + t) KB
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    auto swap16 = [&](uint2 X, uint2 Y) __attribute__((always_inline)) -> i32x4 { return s16_swap16(X, Y); };
-    const float slope = p.slope;
-    const size_t y_img = (size_t)p.H * p.W * p.y0_pitch * 2;
-    const unsigned rowb = (unsigned)p.W * (unsigned)p.y0_pitch * 2u;
-
-    f32x4 acc[2][NT][2];                 // [row pair & 1][channel tile][row of the pair]
-    uint2 pk[NT][2], pk1[PNT1][2];       // the finished row pair, rounded: the conv's result, the post 1x1's
-    unsigned e_v[NT / 2], e_vP = OOB;    // store offsets (row 0 of the wave) of the tile whose epilogue is in flight
-#pragma unroll
-    for (int j = 0; j < NT / 2; ++j) e_v[j] = OOB;
-    int e_n = 0;
-    const float p1s = p.p1_slope;
-    const size_t p1_img = (size_t)p.H * p.W * p.py1_pitch * 2;
-    const unsigned rowb1 = (unsigned)p.W * (unsigned)p.py1_pitch * 2u;
-    f32x4 ev = {0.f, 0.f, 0.f, 0.f};
-    u32x2 es0 = {0u, 0u}, es1 = {0u, 0u};
-    i32x4 bsv[2][2];                     // [k tile & 1][row]: the fp32 fragment as the 1x1's B operand (hi parts | lo parts)
-    i32x4 pa[2][PNT1 * 2];               // [k tile & 1][2 ot + lo]
-    f32x4 d1[PNT1][2];
-    auto actf = [&](f32x4& v, int h, float sl) __attribute__((always_inline)) {     // LeakyReLU of a fragment in two halves
-        if (h == 0) { v.x = act1(v.x, sl); v.y = act1(v.y, sl); }
-        else { v.z = act1(v.z, sl); v.w = act1(v.w, sl); }
-    };
-    auto hl = [&](i32x4& o, f32x4 v, int h) __attribute__((always_inline)) {
-        if (h == 0) {
-            o.x = (int)pack2<BF16>(v.x, v.y); o.y = (int)pack2<BF16>(v.z, v.w);
-            if (!BF16) { o.z = 0; o.w = 0; }
-        } else if (BF16) {
-            float a_, b_, c_, d_;
-            unpack2<BF16>((unsigned)o.x, a_, b_);
-            unpack2<BF16>((unsigned)o.y, c_, d_);
-            o.z = (int)pack2<BF16>(v.x - a_, v.y - b_); o.w = (int)pack2<BF16>(v.z - c_, v.w - d_);
-        }
-    };
-    auto load_p1 = [&](int kt) __attribute__((always_inline)) {
-#pragma unroll
-        for (int ot = 0; ot < PNT1; ++ot) {
-            pa[kt & 1][2 * ot] = *reinterpret_cast<const i32x4*>(img1 + (kt * PNT1 + ot) * 1024);
-            if (plo) pa[kt & 1][2 * ot + 1] = *reinterpret_cast<const i32x4*>(img1 + P1_IMG + (kt * PNT1 + ot) * 1024);
-        }
-    };
-    auto pm1 = [&](int kt, int i) __attribute__((always_inline)) {               // post MFMA i of k tile kt: 0 .. 3 high images (ot, e), 4 .. 7 low images
-        const int lo = i >> 2, ot = (i & 3) >> 1, e = i & 1;
-        if (lo && !plo) return;
-        d1[ot][e] = mfma32<BF16>(pa[kt & 1][2 * ot + lo], bsv[kt & 1][e], (kt == 0 && !lo) ? pb1[ot] : d1[ot][e]);
-    };
-    // operation k of the finished pair's epilogue (par = its accumulators, r = its first row)
-    auto op = [&](auto par_, auto r_, auto k_) __attribute__((always_inline)) {
-        constexpr int par = decltype(par_)::value, r = decltype(r_)::value, k = decltype(k_)::value;
-        if constexpr (k >= 0 && k < 32) {                                      // the conv's fragments: activation (fp32 back into acc), rounding
-            constexpr int f = k >> 2, m = k & 3, t = f >> 1, e = f & 1;
-            if constexpr (m == 0) { ev = acc[par][t][e]; actf(ev, 0, slope); }
-            else if constexpr (m == 1) { actf(ev, 1, slope); acc[par][t][e] = ev; }
-            else if constexpr (m == 2) pk[t][e].x = pack2<BF16>(ev.x, ev.y);
-            else pk[t][e].y = pack2<BF16>(ev.z, ev.w);
-        } else if constexpr (k < 44) {                                         // the conv's four stores: tile pair j, row e
-            constexpr int i = (k - 32) / 3, m = (k - 32) % 3, j = i >> 1, e = i & 1;
-            if constexpr (m == 0) es0 = __builtin_amdgcn_permlane16_swap(pk[2 * j][e].x, pk[2 * j + 1][e].x, false, false);
-            else if constexpr (m == 1) es1 = __builtin_amdgcn_permlane16_swap(pk[2 * j][e].y, pk[2 * j + 1][e].y, false, false);
-            else {
-                const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)e_n * y_img, 0, (int)y_img, 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)es0.x, (int)es1.x, (int)es0.y, (int)es1.y}, yr, e_v[j] + (unsigned)(r + e) * rowb, 0, 0);
-            }
-        } else if constexpr (k < 92) {                                         // the 1x1, k tile by k tile: B operands (4 ops), MFMAs (8 ops; fp16: 4)
-            constexpr int kt = (k - 44) / 12, j = (k - 44) % 12;
-            if constexpr (j < 4) hl(bsv[kt & 1][j >> 1], acc[par][kt][j >> 1], j & 1);
-            else pm1(kt, j - 4);
-        } else if constexpr (k < 104) {                                        // the 1x1's result: activation, rounding; row 0's two tiles first
-            constexpr int q = (k - 92) / 3, m = (k - 92) % 3, e = q >> 1, ot = q & 1;
-            if constexpr (m < 2) actf(d1[ot][e], m, p1s);
-            else { pk1[ot][e].x = pack2<BF16>(d1[ot][e].x, d1[ot][e].y); pk1[ot][e].y = pack2<BF16>(d1[ot][e].z, d1[ot][e].w); }
-        } else if constexpr (k < 110) {                                        // its two stores (one per row)
-            constexpr int e = (k - 104) / 3, m = (k - 104) % 3;
-            if constexpr (m == 0) es0 = __builtin_amdgcn_permlane16_swap(pk1[0][e].x, pk1[1][e].x, false, false);
-            else if constexpr (m == 1) es1 = __builtin_amdgcn_permlane16_swap(pk1[0][e].y, pk1[1][e].y, false, false);
-            else {
-                const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(p.py1 + (size_t)e_n * p1_img, 0, (int)p1_img, 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)es0.x, (int)es1.x, (int)es0.y, (int)es1.y}, r1, e_vP + (unsigned)(r + e) * rowb1, 0, 0);
-            }
-        }
-    };
-    // slot s of a pair (behind its convolution MFMA s, 0 .. 159): operation s - 3, and the post images of k tile kt ten slots ahead of its MFMAs
-    auto micro = [&](auto par_, auto r_, auto s_) __attribute__((always_inline)) {
-        constexpr int s = decltype(s_)::value;
-        if constexpr (s >= 3) op(par_, r_, std::integral_constant<int, s - 3>{});
-        if constexpr (s >= 41 && s < 41 + 12 * NT && (s - 41) % 12 == 0) load_p1((s - 41) / 12);
-    };
-    auto store_offsets = [&](int nn_, int x0_, int y0_) __attribute__((always_inline)) {
-        const bool inx = x0_ + px < p.W;
-        const unsigned pix = (unsigned)((y0_ + wv * RW) * p.W + x0_ + px);
-        const unsigned base = (pix * (unsigned)p.y0_pitch + (unsigned)p.y0_coff) * 2u;
-#pragma unroll
-        for (int j = 0; j < NT / 2; ++j) {
-            const int ch = (2 * j + (kq & 1)) * 16 + (kq >> 1) * 8;
-            e_v[j] = (inx && ch < p.cout_store) ? base + (unsigned)ch * 2u : OOB;
-        }
-        const int chP = (kq & 1) * 16 + (kq >> 1) * 8;
-        e_vP = (inx && chP < p.p1_cout8) ? (pix * (unsigned)p.py1_pitch + (unsigned)p.py1_coff) * 2u + (unsigned)chP * 2u : OOB;
-        e_n = nn_;
-    };
-    for (int k = 0;; ++k) {
-        const int tn = tile_index(k + 1);
-        const bool more = tn >= 0;
-        int nn = 0, nx0 = 0, ny0 = 0;
-        if (more) tile_coords(tn, nn, nx0, ny0);
-        const char* sb = smem + (k & 1) * STAGE;
-        // B fragments: a ring of four (two rows each), read THREE groups ahead of their MFMAs; chunk 3's A fragments (NT = 4): a ring of three,
-        // read TWO groups ahead.  Linear group index L = 20 rp + g over the tile's 40 groups
-        constexpr int AHEAD = 3;
-        i32x4 b[4][2];
-        i32x4 a3[3][NCR == NCH ? 1 : NT];
-        auto read_b = [&](int L) __attribute__((always_inline)) {
-            const int rp_ = L / NG, g_ = L % NG, c_ = g_ / PAIRS, q_ = g_ % PAIRS;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) b[L & 3][e] = *reinterpret_cast<const i32x4*>(sb + b_off[q_] + c_ * 32 + (2 * rp_ + e) * (TH * PIXB));
-        };
-        auto read_a = [&](int L) __attribute__((always_inline)) {
-            const int g_ = L % NG, c_ = g_ / PAIRS, q_ = g_ % PAIRS;
-            if (NCR < NCH && c_ >= NCR) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) a3[L % 3][NCR == NCH ? 0 : t] = *reinterpret_cast<const i32x4*>(w3 + (((c_ - NCR) * PAIRS + q_) * NT + t) * 1024);
-            }
-        };
-#pragma unroll
-        for (int L = 0; L < AHEAD; ++L) read_b(L);
-        read_a(0); read_a(1);                  // (no-ops: the first group of an LDS chunk is L = 10)
-        auto run_pair = [&](auto rp_tag) __attribute__((always_inline)) {
-            constexpr int rp = decltype(rp_tag)::value;
-            constexpr int par = rp & 1;
-            if constexpr (rp == 1) store_offsets(n, x0, y0);       // behind the carried epilogue's last store, ahead of this tile's first
-            uint2 cen[NT][2];            // residual == input: the centre pixels of this pair's rows, 4 channels per tile
-            if (EXT && res_in) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) cen[t][e] = *reinterpret_cast<const uint2*>(sb + c_off + t * 32 + (2 * rp + e) * (TH * PIXB));
-            }
-            static_for<NG>([&](auto g_) __attribute__((always_inline)) {
-                constexpr int g = decltype(g_)::value;
-                constexpr int c = g / PAIRS, q = g % PAIRS, L = rp * NG + g, cs = L & 3;
-                if constexpr (L + AHEAD < (RW / 2) * NG) read_b(L + AHEAD);
-                if constexpr (L + 2 < (RW / 2) * NG) read_a(L + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                static_for<2 * NT>([&](auto m_) __attribute__((always_inline)) {
-                    constexpr int t = decltype(m_)::value >> 1, e = decltype(m_)::value & 1;
-                    {
-                        if (c < NCR) {
-                            if (g == 0) {
-                                if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=v"(acc[par][t][e]) : "a"(wr[c < NCR ? c : 0][q][t]), "v"(b[cs][e]), "v"(bia[t]));
-                                else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=v"(acc[par][t][e]) : "a"(wr[c < NCR ? c : 0][q][t]), "v"(b[cs][e]), "v"(bia[t]));
-                            } else {
-                                if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "a"(wr[c < NCR ? c : 0][q][t]), "v"(b[cs][e]));
-                                else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "a"(wr[c < NCR ? c : 0][q][t]), "v"(b[cs][e]));
-                            }
-                        } else {
-                            if (BF16) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "v"(a3[L % 3][NCR == NCH ? 0 : t]), "v"(b[cs][e]));
-                            else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[par][t][e]) : "v"(a3[L % 3][NCR == NCH ? 0 : t]), "v"(b[cs][e]));
-                        }
-                        // the finished pair's epilogue (rp == 0: the previous TILE's last pair; the block's first tile: whatever the registers
-                        // hold, stores out of range)
-                        micro(std::integral_constant<int, par ^ 1>{}, std::integral_constant<int, (rp == 0 ? RW - 2 : 2 * rp - 2)>{}, std::integral_constant<int, 2 * NT * g + 2 * t + e>{});
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                });
-                if (rp == 0 && g < PPW) dma_piece(g, more, nn, nx0, ny0, (k + 1) & 1);      // the next tile's DMA, in the shadow of the matrix pipe
-                if (EXT && q == PAIRS - 1 && res_in && c < NT) {
-                    // conv_s16_kernel's order: act(conv(x) + x) adds the centre pixels of chunk c to channel tile c BEHIND chunk c's
-                    // groups.  The MFMAs above are asm: hipcc pads neither the read of their results (XDL write -> VALU read) nor the
-                    // next group's read of what is written here
-                    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) acc[par][c < NT ? c : 0][e] += unpack4<BF16>(cen[c < NT ? c : 0][e]);
-                    asm volatile("s_nop 3" ::: "memory");
-                }
-            });
-        };
-        run_pair(std::integral_constant<int, 0>{});
-        run_pair(std::integral_constant<int, 1>{});
-        // the next tile has landed: younger than its DMA are the stores of this tile's row pairs but the last
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RW / 2 - 1) * SPP) : "memory");
-        __builtin_amdgcn_s_barrier();
-        if (!more) break;
-        n = nn; x0 = nx0; y0 = ny0;
-    }
-    // the last tile's last row pair: the same operations, back to back
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // (asm MFMAs: hipcc does not pad MFMA -> VALU reads of their results)
-    static_for<2 * NT * NG>([&](auto s_) __attribute__((always_inline)) { micro(std::integral_constant<int, 1>{}, std::integral_constant<int, RW - 2>{}, s_); });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the trailing zero-fill DMA must not outlive the block)
-}
-
-
 // ---- conv48rp_kernel: RLFB's c3_r -- a 48 -> 48 3x3 + LeakyReLU + the block input (residual from HBM, post-activation), whose result
 // only feeds a chain of two 1x1 convolutions (c5 48 -> 48, esa.conv1 48 -> 16: team04_rlfn.py:117-121, 76) -- on conv48r_kernel's plan:
 // weights in accumulation registers, whole-pixel stages, row pairs, the finished pair's epilogue between the next pair's MFMA groups.
@@ -2341,29 +2049,6 @@ int launch_conv48r(const S16K& k, hipStream_t st)
     return launch_conv48r_fx<BF16, NT, EXT, RW, -1>(k, st);
 }
 
-template <bool BF16>
-int launch_conv64rq(const S16K& k, hipStream_t st)
-{
-    // [two input stages 2 x 51 KB][weight chunks 2, 3: 40 KB][post images: hi (+ lo) 8 KB each]
-    constexpr int LDS = 2 * 51 * 1024 + 40 * 1024 + (BF16 ? 2 : 1) * 8 * 1024;
-    static std::atomic<unsigned> attr_set[MAX_DEVICES];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
-    if (!attr_set[dev].load(std::memory_order_relaxed)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64rq_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) {
-            esr_set_err("hipFuncSetAttribute(conv64rq_kernel, MaxDynamicSharedMemorySize)", e);
-            return ESR_ERR_LAUNCH;
-        }
-        attr_set[dev].store(1u, std::memory_order_relaxed);
-    }
-    const int ntiles = k.N * k.tiles_x * k.tiles_y;
-    const int grid = ntiles < 256 ? ntiles : 256;
-    esr_note_kernel("conv64rq_kernel<%s>", esr_tf(BF16));
-    hipLaunchKernelGGL((conv64rq_kernel<BF16>), dim3(grid), dim3(256), LDS, st, k);
-    return esr_check_launch("conv64rq_kernel launch");
-}
-
 template <bool BF16, int FX = -1>
 int launch_conv48rq_fx(const S16K& k, hipStream_t st)
 {
@@ -2592,13 +2277,6 @@ static bool conv48rl_takes(const esr_conv_desc* d)
     if (d->ksize != 3 || nchunks != 3 || nt != 3 || d->out_layout != ESR_NHWC || d->in_seg_stride != 0 || d->post_wpacked || d->border_bias) return false;
     if (d->res_mode != ESR_RES_PRE_ACT || d->act == ESR_ACT_GELU || (d->split > 0 && d->split < d->cout)) return false;
     return (long)d->n * ((d->w + TILE - 1) / TILE) * ((d->h + 15) / 16) >= 256;
-}
-
-// A/B switch of the round-6 kernel family (esr_c64m.hip): ESR_C64M=0 in the environment keeps conv64r / conv64rq_kernel (read once)
-static bool c64m_enabled()
-{
-    static const int on = [] { const char* e = getenv("ESR_C64M"); return (e && e[0] == '0') ? 0 : 1; }();
-    return on != 0;
 }
 
 // 1: conv48r_kernel / conv48rp_kernel (one 4-wave block per CU, weights in registers), 4: conv_s16_kernel's two-blocks-per-CU shape (4
@@ -3057,7 +2735,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         if (nt_all * (kp.tiles_x > kp.tiles_y ? kp.tiles_x : kp.tiles_y) < 4294967296.0)
             return bf16 ? launch_conv48rp<true>(kp, st) : launch_conv48rp<false>(kp, st);
     }
-    if (c64m_enabled() && (conv64rq_takes(d) || (conv64r_takes(d) && nt == 4))) {
+    if (conv64rq_takes(d) || (conv64r_takes(d) && nt == 4)) {
         // round 6: the 64 -> 64 3x3s (RFDB c1_r / c2_r with the next distillation 1x1, c3_r) on v_mfma_f32_32x32x16 (esr_c64m.hip)
         S16K k4 = k;
         k4.tiles_y = (d->h + 15) / 16;
@@ -3069,13 +2747,6 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         }
         const double nt_all = (double)d->n * k4.tiles_x * k4.tiles_y;
         if (nt_all * (k4.tiles_x > k4.tiles_y ? k4.tiles_x : k4.tiles_y) < 4294967296.0) return esr_launch_conv64m(k4, bf16, post, st);
-    }
-    if (conv64rq_takes(d)) {
-        S16K k4 = k;
-        k4.tiles_y = (d->h + 15) / 16;
-        k4.magic_y = k4.tiles_y > 1 ? (unsigned)((0x100000000ull + k4.tiles_y - 1) / k4.tiles_y) : 0u;
-        const double nt_all = (double)d->n * k4.tiles_x * k4.tiles_y;
-        if (nt_all * (k4.tiles_x > k4.tiles_y ? k4.tiles_x : k4.tiles_y) < 4294967296.0) return bf16 ? launch_conv64rq<true>(k4, st) : launch_conv64rq<false>(k4, st);
     }
     if (conv48rq_takes(d)) {
         S16K k4 = k;
@@ -3090,10 +2761,8 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         k4.magic_y = k4.tiles_y > 1 ? (unsigned)((0x100000000ull + k4.tiles_y - 1) / k4.tiles_y) : 0u;
         const double nt_all = (double)d->n * k4.tiles_x * k4.tiles_y;
         if (nt_all * (k4.tiles_x > k4.tiles_y ? k4.tiles_x : k4.tiles_y) < 4294967296.0) {
-            const bool ext = k.res_in != 0;
-            if (nt == 2) return bf16 ? launch_conv64r<true, 2, true>(k4, st) : launch_conv64r<false, 2, true>(k4, st);
-            if (ext) return bf16 ? launch_conv64r<true, 4, true>(k4, st) : launch_conv64r<false, 4, true>(k4, st);
-            return bf16 ? launch_conv64r<true, 4, false>(k4, st) : launch_conv64r<false, 4, false>(k4, st);
+            // (two output tiles -- RFDB's c4; four take conv64m_kernel above)
+            return bf16 ? launch_conv64r<true, 2, true>(k4, st) : launch_conv64r<false, 2, true>(k4, st);
         }
     }
     if (conv48r_takes(d)) {

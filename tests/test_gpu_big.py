@@ -185,7 +185,7 @@ def test_forwards_on_several_streams_equal_serial(name, compute):
 @pytest.mark.parametrize("name,compute", [("team04_rlfn", "bf16"), ("rfdn_baseline", "bf16"), ("team18_bsrn", "f16")])
 def test_full_size_forwards_on_several_streams_equal_serial(name, compute):
     """the same with DIV2K-val-sized images (>= 256 tiles of 16 x 16): these launches take the one-wave-per-SIMD kernels (conv48r / conv48rp /
-    conv48rq / conv64r / conv64rq_kernel, the LR conv on hi + lo pairs), whose 16-bit MFMAs run beside the other streams' packed-fp32 epilogues -- the partner
+    conv48rq / conv64r / conv64m_kernel, the LR conv on hi + lo pairs), whose 16-bit MFMAs run beside the other streams' packed-fp32 epilogues -- the partner
     pattern of the round-3 defect (LAB_NOTES 9.1); 12 rounds = 120 overlapped forwards per network (tools/dbg/streams_race.py ... big: 6000 clean)"""
     m, dr = _model(name, compute)
     g = torch.Generator().manual_seed(5)

@@ -469,10 +469,11 @@ def test_s16_hilo_rejects_what_it_does_not_cover():
     (50, 25, 1, False, (64, 250), 7),
     (64, 64, 0, True, (128, 128), 4)])       # residual == input without activation
 def test_conv64r_equals_conv_s16(compute, cin, cout, act, res_in, hw, n):
-    """conv64r_kernel (3x3 over 64 physical input channels, >= 256 tiles of 16 x 16: 240 weight registers + chunk 3 from LDS, one wave per
-    SIMD, row pairs as the outer loop, 144-byte LDS pixels) against conv_s16_kernel: the batch takes the new kernel
-    (esr_conv_block_waves == 1), each image alone the old one (< 256 tiles), same packed weights -- bit-identical results, and both within
-    storage precision of the fp64 convolution."""
+    """The 3x3s over 64 physical input channels at >= 256 tiles of 16 x 16 (one wave per SIMD, weights in registers, row pairs as the outer
+    loop, 160-byte LDS pixels) against conv_s16_kernel: the batch takes the register-resident kernel (esr_conv_block_waves == 1), each image
+    alone the general one (< 256 tiles), same packed weights.  Two output tiles: conv64r_kernel, bit-identical results; four: conv64m_kernel
+    (round 6, 32x32x16 MFMAs and nine taps: another accumulation order), equal to one storage step.  Both within storage precision of the
+    fp64 convolution."""
     from ntire2022_esr_amd import ops, _lib as L
     from ntire2022_esr_amd.engine import pack_conv_s16, unpack_conv_s16
     dt = DT[compute]
@@ -608,10 +609,11 @@ def test_conv48rq_equals_conv_s16(hw, n, border, act, pact):
 
 @pytest.mark.parametrize("compute", ["bf16", "f16"])
 @pytest.mark.parametrize("hw,n,c,pc,res_in", [((128, 128), 8, 50, 25, True), ((100, 77), 9, 64, 32, True), ((64, 250), 5, 50, 25, False)])
-def test_conv64rq_equals_conv_s16(compute, hw, n, c, pc, res_in):
-    """conv64rq_kernel (RFDB c{j}_r = lrelu(conv(x) + x), stored, with c{j+1}_d + LeakyReLU as 110 micro-operations behind the next row pair's
-    MFMAs; two weight chunks in registers, two in LDS) against conv_s16_kernel<4, 3, 8, .., 2, 0>: the batch takes the new kernel (>= 256 tiles
-    of 16 x 16), each image alone the old one -- both outputs bit-identical, ragged edges included."""
+def test_conv64m_post_agrees_with_conv_s16(compute, hw, n, c, pc, res_in):
+    """conv64m_kernel<.., POST> (esr_c64m.hip, round 6: RFDB c{j}_r = lrelu(conv(x) + x), stored, with c{j+1}_d + LeakyReLU in its epilogue, on
+    v_mfma_f32_32x32x16; rounds 4 / 5: conv64rq_kernel) against conv_s16_kernel<4, 3, 8, .., 2, 0>: the batch takes the register-resident kernel
+    (>= 256 tiles of 16 x 16), each image alone the general one -- same weights, same arithmetic in another fp32 accumulation order: the outputs
+    agree to one step of the storage type, ragged edges included (the fp64-reference check of the new kernel: test_gpu_c64m.py)."""
     from ntire2022_esr_amd import ops, _lib as L
     from ntire2022_esr_amd.engine import pack_conv_s16
     dt = DT[compute]

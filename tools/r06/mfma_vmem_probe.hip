@@ -44,14 +44,14 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* out, char* buf,
             asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[m & 3]) : "v"(a[m]), "v"(b[m & 3]));
             asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[m]) : "v"(seed));
             asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[(m + 3) & 7]) : "v"(seed));
-            if (m % EVERY == EVERY - 1) {
+            if ((EVERY <= 8 && m % EVERY == EVERY - 1) || (EVERY > 8 && m == 7 && (it % (EVERY / 8)) == 0)) {
                 if (KIND == 1) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(data), "v"(strided + rot), "s"(rsrc) : "memory");
                 if (KIND == 2) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(data), "v"(linear + rot), "s"(rsrc) : "memory");
                 if (KIND == 3) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds_dst), "v"(linear + rot), "s"(rsrc) : "memory");
                 if (KIND == 4) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ld) : "v"(linear + rot), "s"(rsrc) : "memory");
-                if (KIND == 6) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ld) : "v"(linear + (unsigned)(it * (8 / EVERY) + m / EVERY) * 1024u), "s"(rsrc2) : "memory");
-                if (KIND == 7) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds_dst), "v"(linear + (unsigned)(it * (8 / EVERY) + m / EVERY) * 1024u), "s"(rsrc2) : "memory");
-                if (KIND == 8) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(data), "v"(linear + (unsigned)(it * (8 / EVERY) + m / EVERY) * 1024u), "s"(rsrc2) : "memory");
+                if (KIND == 6) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ld) : "v"(linear + (unsigned)(EVERY <= 8 ? it * (8 / EVERY) + m / EVERY : it / (EVERY / 8)) * 1024u), "s"(rsrc2) : "memory");
+                if (KIND == 7) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds_dst), "v"(linear + (unsigned)(EVERY <= 8 ? it * (8 / EVERY) + m / EVERY : it / (EVERY / 8)) * 1024u), "s"(rsrc2) : "memory");
+                if (KIND == 8) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(data), "v"(linear + (unsigned)(EVERY <= 8 ? it * (8 / EVERY) + m / EVERY : it / (EVERY / 8)) * 1024u), "s"(rsrc2) : "memory");
                 if (KIND == 5) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(data), "v"(0x80000000u + linear), "s"(rsrc) : "memory");
             }
         }
@@ -80,7 +80,7 @@ void run(unsigned long long* d, char* buf, size_t bytes, const char* name)
     hipEventElapsedTime(&ms, e0, e1);
     unsigned long long t;
     hipMemcpy(&t, d, 8, hipMemcpyDeviceToHost);
-    const double nv = KIND ? 8.0 / EVERY : 0.0;
+
     printf("%-34s every %d MFMAs: %6.1f ticks / MFMA  %6.2f ns / MFMA", name, EVERY, (double)t / (iters * 8.0), ms * 1e6 / (iters * 8.0));
     static double base_ns = 0.0;
     if (!KIND) base_ns = ms * 1e6 / (iters * 8.0);
@@ -113,5 +113,15 @@ int main()
     run<7, 4>(d, buf, bytes, "+ STREAMING load ... lds");
     run<8, 8>(d, buf, bytes, "+ STREAMING store");
     run<8, 4>(d, buf, bytes, "+ STREAMING store");
+    run<0, 8>(d, buf, bytes, "MFMA + 2 v_fma");
+    run<6, 16>(d, buf, bytes, "+ STREAMING load to a register");
+    run<6, 32>(d, buf, bytes, "+ STREAMING load to a register");
+    run<6, 64>(d, buf, bytes, "+ STREAMING load to a register");
+    run<7, 16>(d, buf, bytes, "+ STREAMING load ... lds");
+    run<7, 32>(d, buf, bytes, "+ STREAMING load ... lds");
+    run<8, 16>(d, buf, bytes, "+ STREAMING store");
+    run<8, 32>(d, buf, bytes, "+ STREAMING store");
+    run<4, 16>(d, buf, bytes, "+ L1-hit load to a register");
+    run<4, 32>(d, buf, bytes, "+ L1-hit load to a register");
     return 0;
 }

@@ -9,11 +9,11 @@ x = (torch.rand(32, 3, 256, 256) * 255.0).cuda()
 for _ in range(3):
     m(x)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 32)()
 lib = L.lib()
 assert lib.esr_c64m_trace_read(buf) == 0
 names = ["bookkeeping", "pair 0, k steps 0-12", "pair 0, rest", "pair 1", "wait + barrier", "DMA burst"]
-for base, kn in ((0, "plain"), (8, "post")):
+for base, kn in ((0, "plain"), (16, "post")):
     tiles = buf[base + 6]
     if not tiles:
         continue

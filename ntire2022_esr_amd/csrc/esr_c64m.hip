@@ -46,20 +46,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef C64M_ABL
 #define C64M_ABL 0
 #endif
-// the next tile's DMA piece i (of every wave) is issued behind k step C64M_SPREAD * i of the tile's 72.  Measured at 32 x 256 x 256 (POST / plain,
-// us): 1: 180 / 140, 3: 175 / 139, 5: 177 / 157 (the last pieces land late); all 13 back to back at the top of the tile: 179 / 140; one wave
-// per step in turn: 187 / 148.  What the pieces cost does not depend on where they are issued (LAB_NOTES 11.2)
+// the next tile's DMA piece i (of every wave) is issued behind k step C64M_SPREAD * i of the tile's 72 (pieces every step, every 5th step, all 13
+// at the top of the tile, one wave per step in turn, waves skewed in time: none faster -- what the DMA costs, ~18 % of the tile loop's cycles,
+// comes with the data's arrival, not with the instructions: profiles/r06_c64m_block_ticks.txt, LAB_NOTES 11.2)
 #ifndef C64M_SPREAD
 #define C64M_SPREAD 3
 #endif
 
-#ifdef C64M_TRACE
-// research builds: s_memtime stamps at five points of every tile (block 0, wave 0), summed per segment; read back with esr_c64m_trace_read
-__device__ unsigned long long c64m_trace[32];
-extern "C" int esr_c64m_trace_read(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(c64m_trace), sizeof(c64m_trace)) == hipSuccess ? 0 : -1; }
-#define C64M_STAMP(i) { const unsigned long long t_ = __builtin_readcyclecounter(); tr[i] += t_ - tlast; tlast = t_; }
-#else
-#define C64M_STAMP(i) {}
+#ifdef C64M_TRACE4
+// research builds: every block's tile-loop time and its tile-end waits (wave 0), in s_memtime ticks: [block][0 = loop, 1 = sum of the tile-end waits, 2 = tiles]
+__device__ unsigned long long c64m_trace4[2][256][4];
+extern "C" int esr_c64m_trace4_read(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(c64m_trace4), sizeof(c64m_trace4)) == hipSuccess ? 0 : -1; }
 #endif
 
 namespace {
@@ -156,6 +153,9 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
     const int pn = lane & 31, hh = lane >> 5;              // MFMA column (pixel of the row pair) / k half
     const int px = pn & 15, pe = pn >> 4;
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+#ifdef C64M_TRACE4
+    const unsigned long long t4_entry = __builtin_readcyclecounter();
+#endif
 
     // ---- prologue: weights.  POST: chunk 3's fragments and the post images go to LDS by DMA; everything else straight into registers
     if (POST) {
@@ -187,11 +187,16 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
     auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) { s16_tile_coords(t, p.magic_x, p.magic_y, p.tiles_x, p.tiles_y, (4 * RW), n, x0, y0); };
     const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 2;
     // DMA pieces.  Piece i of this wave covers 64 consecutive 16-byte slots of the stage; slot -> (row, pixel, part) is lane-constant, so the
-    // offset of the slot's bytes RELATIVE to the tile's first halo pixel is computed once (rel[i]; pad slots: OOB) and a piece costs one
-    // v_add, one s_add into m0 and the load.  Rows above / below the image need nothing: their offsets fall outside the image's buffer
-    // range (a negative offset wraps above 2^31; the host keeps images below 2^31 - 2^20 bytes) and the hardware writes zeros.  Tiles at the
-    // left / right image edge (a halo column outside the row) take the general form with its per-lane column test.
-    unsigned rel[PPW];
+    // offset of the slot's bytes RELATIVE to the tile's first halo pixel is computed once (rel[i]; pad slots: OOB) and the tile's origin goes
+    // into the buffer descriptor (base = the first halo pixel, range = what is left of the image behind it).  What lies outside the image:
+    //   * halo rows BELOW it fall outside the descriptor's range: the hardware writes zeros;
+    //   * the halo row ABOVE (tiles with y0 == 0), the halo column LEFT (x0 == 0) and columns at / beyond the image's right edge are
+    //     lane-constant sets of slots: `edge` holds "row 0" (bit i) and "column 0" (bit 13 + i) of piece i, `lxp` the slots' columns
+    //     (5 bits each); once per tile they become `bad` (bit i: piece i's slot is outside), and a piece is v_bfe_i32 + v_or (all ones = out of
+    //     range) + s_add into m0 + the load for EVERY tile.  (Until this form the border tiles took a 22-instruction piece with per-lane
+    //     compares under exec masks; a block keeps its tile position from image to image when an image is a multiple of 256 tiles, so the 60
+    //     border blocks of a 256 x 256 batch -- 2400 cycles per tile slower -- set the launch's time: 180 -> 1xx us, profiles/r06_c64m_*.)
+    unsigned rel[PPW], edge = 0u, lxp[3] = {0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const unsigned sl = (unsigned)((wv + 4 * i) * 64 + lane);
@@ -199,13 +204,15 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
         const unsigned lx = rem / (unsigned)M_LSL, part = rem - lx * (unsigned)M_LSL;
         const bool real = part < 8u && lx < (unsigned)M_TH && row < (unsigned)M_THY && (i < PPW - 1 || wv + 4 * i < M_NPIECES);
         rel[i] = real ? (row * (unsigned)p.W + lx) * (unsigned)p.in_pitch * 2u + part * 16u : OOB;
+        edge |= (row == 0u ? 1u << i : 0u) | (lx == 0u ? 1u << (13 + i) : 0u);
+        lxp[i / 6] |= (lx < 31u ? lx : 31u) << (5 * (i % 6));
     }
     // (m0 is not restored: hipcc keeps nothing in it on gfx950 outside s_set_gpr_idx / s_movrel sequences, and this kernel indexes no register
     // dynamically; dma_buf16 saves it for kernels that might)
-    auto dma_piece_fast = [&](auto i_, unsigned tbase, i32x4 rsrc, unsigned lds0) __attribute__((always_inline)) {
+    auto dma_piece_fast = [&](auto i_, unsigned bad, i32x4 rsrc, unsigned lds0) __attribute__((always_inline)) {
         constexpr int i = decltype(i_)::value;
         if (i < PPW - 1 || wv + 4 * i < M_NPIECES) {                     // wave-uniform
-            const unsigned voff = rel[i] + tbase;
+            const unsigned voff = rel[i] | (unsigned)__builtin_amdgcn_sbfe((int)bad, (unsigned)i, 1u);
             asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds"
                          :: "s"(lds0), "n"(i * 4096), "v"(voff), "s"(rsrc) : "memory");
         }
@@ -383,22 +390,32 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
         }
     };
 
-#ifdef C64M_TRACE
-    unsigned long long tr[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#ifdef C64M_TRACE4
+    const unsigned long long t4_start = __builtin_readcyclecounter();
+    unsigned long long t4_wait = 0, t4_tiles = 0;
 #endif
     for (int k = 0;; ++k) {
-        C64M_STAMP(0)                       // tile bookkeeping + the B ring's first reads are in segment 1
         const int tn = tile_index(k + 1);
         const bool more = tn >= 0;
         int nn = 0, nx0 = 0, ny0 = 0;
         if (more) tile_coords(tn, nn, nx0, ny0);
         const char* const bb = smem + b_base + (unsigned)((k & 1) * STAGE);
-        // the next tile's DMA: fast pieces unless a halo column leaves the image row (or nothing follows: zero fill through the general form)
-        const bool fast = more && nx0 > 0 && nx0 + TILE < p.W;
+        // the next tile's DMA: origin and range into the descriptor, the slots outside the image into `bad` (nothing follows: every slot)
         // (C64M_ABL & 16: the DMA re-reads the CURRENT tile -- L2 hits -- to tell memory latency / bandwidth from issue cost)
-        const unsigned tbase = (C64M_ABL & 16) ? (unsigned)(((y0 - 1) * p.W + (x0 - 1)) * p.in_pitch + p.in_coff) * 2u
-                                               : (unsigned)(((ny0 - 1) * p.W + (nx0 - 1)) * p.in_pitch + p.in_coff) * 2u;
-        const i32x4 nrsrc = make_rsrc(p.x + (size_t)((C64M_ABL & 16) ? n : nn) * img_bytes, img_bytes);
+        const int dx0 = (C64M_ABL & 16) ? x0 : nx0, dy0 = (C64M_ABL & 16) ? y0 : ny0, dn = (C64M_ABL & 16) ? n : nn;
+        const unsigned tbase = (unsigned)(((dy0 - 1) * p.W + (dx0 - 1)) * p.in_pitch + p.in_coff) * 2u;
+        const i32x4 nrsrc = make_rsrc(p.x + (size_t)dn * img_bytes + (size_t)(int)tbase, img_bytes - (size_t)(int)tbase);
+        unsigned bad;
+        {
+            const unsigned sel = (dy0 == 0 ? 0x1fffu : 0u) | (dx0 == 0 ? 0x1fffu << 13 : 0u);
+            const unsigned t = edge & sel;
+            bad = more ? ((t | (t >> 13)) & 0x1fffu) : 0xffffffffu;
+            if (dx0 + TILE + 1 > p.W) {                                   // the tile's right halo column (or more) is outside: per-slot column test
+                const unsigned lim = (unsigned)(p.W - dx0 + 1);
+#pragma unroll
+                for (int i = 0; i < PPW; ++i) bad |= (((lxp[i / 6] >> (5 * (i % 6))) & 31u) >= lim ? 1u : 0u) << i;
+            }
+        }
         const unsigned lds0 = smem_lds + (unsigned)(((k + 1) & 1) * STAGE + wv * 1024);
         // B fragments: a ring of four, read THREE k steps ahead of their MFMAs; chunk 3's A fragments (POST): a ring of three pairs, read
         // TWO steps ahead.  Linear step index L = 36 rp + g over the tile's 72 steps
@@ -418,11 +435,9 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
                 a3[L % 3][1] = *reinterpret_cast<const i32x4*>(w3 + (2 * g_ + 1 - NREG) * 1024);
             }
         };
-        C64M_STAMP(5)                       // (trace builds) the DMA burst
         static_for<AHEAD>([&](auto L_) __attribute__((always_inline)) { read_b(L_); });
-        auto run_pair = [&](auto rp_tag, auto fast_tag) __attribute__((always_inline)) {
+        auto run_pair = [&](auto rp_tag) __attribute__((always_inline)) {
             constexpr int rp = decltype(rp_tag)::value;
-            constexpr bool FAST = decltype(fast_tag)::value;
             constexpr int par = rp & 1;
             using PrevPar = std::integral_constant<int, par ^ 1>;
             using PrevRow = std::integral_constant<int, (rp == 0 ? RW - 2 : 2 * rp - 2)>;
@@ -455,35 +470,30 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
                     micro(PrevPar{}, PrevRow{}, std::integral_constant<int, s0 + 2>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (L == 13) C64M_STAMP(1)        // k steps 0 .. 12 of the first pair: the DMA pieces' steps
-                if constexpr (L == NG) C64M_STAMP(2)        // the rest of the first pair
                 if constexpr (L % C64M_SPREAD == 0 && L / C64M_SPREAD < PPW && !(C64M_ABL & 2)) {       // the next tile's DMA, in the shadow of the matrix pipe
-                    if constexpr (FAST) dma_piece_fast(std::integral_constant<int, L / C64M_SPREAD>{}, tbase, nrsrc, lds0);
-                    else dma_piece(L / C64M_SPREAD, more, nn, nx0, ny0, (k + 1) & 1);
+                    dma_piece_fast(std::integral_constant<int, L / C64M_SPREAD>{}, bad, nrsrc, lds0);
                 }
             });
         };
-        if (fast) {                                                                       // (one wave-uniform branch per tile)
-            run_pair(std::integral_constant<int, 0>{}, std::true_type{});
-            run_pair(std::integral_constant<int, 1>{}, std::true_type{});
-        } else {
-            run_pair(std::integral_constant<int, 0>{}, std::false_type{});
-            run_pair(std::integral_constant<int, 1>{}, std::false_type{});
-        }
+        run_pair(std::integral_constant<int, 0>{});
+        run_pair(std::integral_constant<int, 1>{});
         // the next tile has landed: younger than the wave's last DMA piece are exactly m_tail_stores() stores
-        C64M_STAMP(3)                       // the second pair
+#ifdef C64M_TRACE4
+        const unsigned long long t4_a = __builtin_readcyclecounter();
+#endif
         if constexpr ((C64M_ABL & 32) == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(m_tail_stores(POST, C64M_SPREAD)) : "memory");      // (C64M_ABL & 32: no wait -- timing only)
         if constexpr ((C64M_ABL & 64) == 0) __builtin_amdgcn_s_barrier();                                   // (C64M_ABL & 64: no barrier -- timing only)
-        C64M_STAMP(4)                       // the tile-end wait + barrier
-#ifdef C64M_TRACE
-        tr[6] += 1;
+#ifdef C64M_TRACE4
+        t4_wait += __builtin_readcyclecounter() - t4_a;
+        t4_tiles += 1;
 #endif
         if (!more) break;
         n = nn; x0 = nx0; y0 = ny0;
     }
-#ifdef C64M_TRACE
-    if (blockIdx.x == 0 && tid == 0) {
-        for (int i = 0; i < 7; ++i) c64m_trace[i + (POST ? 16 : 0)] = tr[i];
+#ifdef C64M_TRACE4
+    if (tid == 0 && blockIdx.x < 256) {
+        unsigned long long* o = c64m_trace4[POST ? 1 : 0][blockIdx.x];
+        o[0] = __builtin_readcyclecounter() - t4_start; o[1] = t4_wait; o[2] = t4_tiles; o[3] = __builtin_readcyclecounter() - t4_entry;
     }
 #endif
     // the last tile's last row pair: the same operations, back to back

@@ -66,6 +66,11 @@ struct S16K {
 
 // esr_c64m.hip: the 64 -> 64 3x3 family on v_mfma_f32_32x32x16 (round 6).  `post`: with one post 1x1 of <= 32 outputs (RFDB c{j}_r + c{j+1}_d)
 int esr_launch_conv64m(const S16K& k, bool bf16, bool post, hipStream_t st);
+// esr_r16.hip: the register-resident 48-channel / c4 kernels (weights in accumulation registers, one wave per SIMD)
+int esr_launch_conv48rp(const S16K& k, bool bf16, bool lrs, hipStream_t st);
+int esr_launch_conv48r(const S16K& k, bool bf16, int nt, bool ext, int rw, hipStream_t st);
+int esr_launch_conv48rq(const S16K& k, hipStream_t st);
+int esr_launch_conv64r(const S16K& k, bool bf16, hipStream_t st);
 // byte offsets of the 32x32x16 weight images inside the esr_pack_conv_s16 / esr_pack_post_s16 blobs (0: this shape carries none), and their writers
 size_t esr_m32_conv_offset(int cin_phys, int cout, int ksize);
 size_t esr_m32_conv_bytes(int cin_phys, int cout, int ksize);

@@ -226,14 +226,15 @@ def test_pipeline_equals_serial_loop(tmp_path):
 
 
 @pytest.mark.parametrize("extra,streams,events", [
-    (["--batch", "4"], 1, "inside the timed region"),
+    (["--batch", "4"], 1, "the timed region carries none"),
     (["--batch", "4", "--streams", "2"], 2, "replay"),
     (["--model", "team04_rlfn", "--compute", "bf16", "--sizes", "div2k"], 8, "replay"),
     (["--model", "team04_rlfn", "--compute", "bf16", "--sizes", "div2k", "--streams", "1"], 1, "replay"),
 ])
 def test_bench_json_contract(extra, streams, events):
-    """bench.py prints ONE JSON line with the contract fields; the batch mode on one stream records its per-kernel events inside
-    the timed region, the DIV2K mode / several streams in a replay of the same steps (roofline.events says which)"""
+    """bench.py prints ONE JSON line with the contract fields; the per-kernel events of the roofline leg are recorded in a replay of the
+    same steps behind the timed region in every mode (round 6, VERDICT r05 weak #8: the timed region carries no event pair; roofline.events
+    says so), and the line carries the stored bytes next to the algorithmic ones"""
     import subprocess
     import sys
     from conftest import REPO
@@ -251,3 +252,4 @@ def test_bench_json_contract(extra, streams, events):
     r = j["roofline"]
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] <= 1.2 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert events in r["events"] and r["kernels"][0]["kernel"] == r["kernel"]
+    assert r["stored_mb_per_launch"] >= r["algorithmic_mb_per_launch"] * 0.999

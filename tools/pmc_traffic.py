@@ -69,11 +69,12 @@ def main():
         for sh in shapes:
             m(torch.rand(batch, 3, sh[0], sh[1], device="cuda:0") * dr)
     torch.cuda.synchronize()
-    algo = collections.defaultdict(lambda: [0.0, 0.0, 0])
+    algo = collections.defaultdict(lambda: [0.0, 0.0, 0, 0.0])
     for o in m.collect_profile():
         for sym in o["kernel"].split(" + "):               # (an op lowered to two launches: bytes attributed to the first)
             x = algo[sym]
             x[0] += o["read_bytes"] * o["passes"]; x[1] += o["write_bytes"] * o["passes"]; x[2] += o["passes"]
+            x[3] += o.get("stored_bytes", o["read_bytes"] + o["write_bytes"]) * o["passes"]
             break
     m.disable_profiling()
     fetch, write = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
@@ -88,13 +89,15 @@ def main():
     res["_how"] = __doc__.split("usage:")[1].strip()
     cur = {"_round": tag, "_build": bench.library_build()}       # esr_source_hash(): bench.py replays an entry only for the build it was recorded on
     for lab, (fkb, wkb, n) in tot.items():
-        ar, aw, na = algo[lab]
+        ar, aw, na, st = algo[lab]
         hbm = (2.0 * fkb + wkb) * 1024 / n
         alg = (ar + aw) / na
         cur[lab] = {"FETCH_SIZE_KB": round(fkb / n, 1), "WRITE_SIZE_KB": round(wkb / n, 1),
                     "algorithmic_read_KB": round(ar / na / 1024), "algorithmic_write_KB": round(aw / na / 1024),
                     "hbm_bytes_per_launch": int(hbm), "algorithmic_bytes_per_launch": int(alg),
-                    "traffic_over_algorithmic": round(hbm / alg, 3), "launches_sampled": n}
+                    "traffic_over_algorithmic": round(hbm / alg, 3),
+                    # stored = with the tensors' pad channels (nf = 50 at pitch 64 ...): what the launch has to move as the tensors are laid out
+                    "stored_bytes_per_launch": int(st / na), "traffic_over_stored": round(hbm / (st / na), 3), "launches_sampled": n}
     res[key] = cur
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({key: cur}, indent=1))

@@ -1136,7 +1136,8 @@ class HipSRModel(nn.Module):
                 # a residual that IS the conv's input (RFDB's c1_r..c3_r, RLFB's c3_r: the kernel adds the centre tap of the staged tile)
                 # is not read again: VERDICT r05 weak #2
                 res_read = o["res"] is not None and not _same_view(o["res"], o["src"])
-                rd = npix * (ca * e_in + (o["cout"] * e_act if res_read else 0)) + 4.0 * ca * o["cout"] * o["k"] ** 2
+                wb = 4.0 * ca * o["cout"] * o["k"] ** 2          # weight bytes (part of both the algorithmic and the stored figure)
+                rd = npix * (ca * e_in + (o["cout"] * e_act if res_read else 0)) + wb
                 if o.get("head"):
                     rd += npix * (16 * 2 - ca * e_in)  # the head reads the packed 16-slot copy (esr_pack_input_s16), not the fp32 input
                 wr = float(npix * o["cout"] * e_out) if o["dst"] is not None else 0.0
@@ -1148,7 +1149,8 @@ class HipSRModel(nn.Module):
                 flops = 2.0 * npix * ca * o["cout"] * o["k"] * o["k"]
                 if o.get("bs_of") is not None:      # the BSConvU it stands for: pointwise GEMM + depthwise 3x3
                     flops = 2.0 * npix * (ca * o["cout"] + 9 * o["cout"])
-                    rd = npix * (ca * e_in + (o["cout"] * e_act if res_read else 0)) + 4.0 * (ca * o["cout"] + 10 * o["cout"])
+                    wb = 4.0 * (ca * o["cout"] + 10 * o["cout"])
+                    rd = npix * (ca * e_in + (o["cout"] * e_act if res_read else 0)) + wb
                     if o.get("head"):
                         rd += npix * (16 * 2 - ca * e_in)
                 t = o.get("tail")
@@ -1158,8 +1160,8 @@ class HipSRModel(nn.Module):
                         kern = f"imdb_tail_kernel<FOLD={int(o['res'] is not None)}>"       # esr_hip.hip: imdb_tail_shape()
                     k1 = t["cat_c"] + o["cout"]
                     flops += 2.0 * npix * k1 * t["cout"]
-                    rd = npix * e_act * (o["cin"] + t["cat_c"] + (t["cout"] if res_read else 0)) \
-                        + 4.0 * (o["cin"] * o["cout"] * 9 + k1 * t["cout"])
+                    wb = 4.0 * (o["cin"] * o["cout"] * 9 + k1 * t["cout"])
+                    rd = npix * e_act * (o["cin"] + t["cat_c"] + (t["cout"] if res_read else 0)) + wb
                     wr = float(npix * e_act * t["cout"])
                 t = o.get("post")
                 if t is not None:                   # + the 1x1 of the activated output, stored by the same launch
@@ -1192,7 +1194,9 @@ class HipSRModel(nn.Module):
                     st += npix * e_act * sc(pt["dst"], pt["cout"])
                     if pt.get("post2") is not None:
                         st += npix * e_act * sc(pt["post2"]["dst"], pt["post2"]["cout"])
-                stored = float(st)
+                if pt is not None:
+                    wb += 4.0 * o["cout"] * pt["cout"] + (4.0 * pt["cout"] * pt["post2"]["cout"] if pt.get("post2") is not None else 0.0)
+                stored = float(st) + wb
             elif kind == "chain":                   # the block's 3x3 chain + its two 1x1s in one launch: the input read once, only the 1x1 results written
                 sub = o["replaces"]
                 kern = f"rlfb_chain_kernel<{plan.store}>"

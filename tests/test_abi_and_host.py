@@ -226,6 +226,72 @@ def test_s16_packer_layout_diffusion_and_split():
     assert lib.esr_packed_conv_s16_bytes(64, 64, 2) == 0
 
 
+def test_m32_images_hold_the_same_weights_as_the_tap_pair_images():
+    """Round 6 (csrc/esr_c64m.hip): esr_pack_conv_s16 appends the 64 -> 64 3x3's weights in v_mfma_f32_32x32x16's fragment order -- fragment
+    (chunk, tap, half) of 1 KB, lane 32 h + i, slot j = output channel 32 half + i, input slot 16 chunk + 8 h + j -- and esr_pack_post_s16 the
+    post 1x1's images -- step c / 8, (hi, lo), lane 32 ((c % 8) / 4) + o, slots c % 4 (and + 4 in the hi image).  Both must hold exactly the
+    16-bit values of the tap-pair / 16x16x32 images (what esr_unpack_conv_s16 reads), zeros elsewhere."""
+    import numpy as np
+    from ntire2022_esr_amd.engine import pack_conv_s16, pack_post_s16, unpack_conv_s16
+    g = torch.Generator().manual_seed(11)
+    for mode, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        cin = cout = 50
+        w, b = torch.randn(cout, cin, 3, 3, generator=g) * 0.1, torch.randn(cout, generator=g)
+        blob = pack_conv_s16(w, b, mode, cin_phys=64)
+        weff, beff = unpack_conv_s16(blob, cin, cout, 3, mode, cin_phys=64)
+        raw = blob.numpy().view(np.uint16)
+        off = (4 * 5 * 4 * 1024 + 256) // 2
+        img = torch.from_numpy(raw[off:off + 72 * 512].astype(np.int16)).view(dt).float().reshape(4, 9, 2, 2, 32, 8)   # [chunk][tap][half][h][i][j]
+        got = torch.zeros(64, 64, 9)
+        for c in range(4):
+            for h in range(2):
+                # img[c, tap, half, h, i, j] = W[32 half + i][16 c + 8 h + j][tap]
+                blk = img[c, :, :, h]                                   # [tap][half][i][j]
+                got[:, 16 * c + 8 * h:16 * c + 8 * h + 8, :] = blk.permute(1, 2, 3, 0).reshape(64, 8, 9)
+        assert torch.equal(got[:cout, :cin].reshape(cout, cin, 3, 3), weff)
+        assert torch.all(got[cout:] == 0) and torch.all(got[:, cin:] == 0)
+        assert len(raw) * 2 == 4 * 5 * 4 * 1024 + 256 + 72 * 1024
+        # the post 1x1 (64 -> 32 physical): hi + lo of the m32 images = the fp32 weight to the storage type's hi + lo accuracy
+        pc = 25
+        wp, bp = torch.randn(pc, cin, generator=g) * 0.2, torch.randn(pc, generator=g)
+        pblob = pack_post_s16(wp, bp, mode)
+        praw = pblob.numpy().view(np.uint16)
+        poff = (2 * 4 * 2 * 1024 + 2 * 16 * 4) // 2
+        pim = torch.from_numpy(praw[poff:poff + 16 * 512].astype(np.int16)).view(dt).float().reshape(8, 2, 2, 32, 8)     # [step][hi | lo][h][o][j]
+        hi = torch.zeros(32, 64); lo = torch.zeros(32, 64)
+        for st in range(8):
+            for h in range(2):
+                for jj in range(4):
+                    c = 8 * st + 4 * h + jj
+                    hi[:, c] = pim[st, 0, h, :, jj]
+                    assert torch.equal(pim[st, 0, h, :, jj + 4], pim[st, 0, h, :, jj])         # slots 4 .. 7 meet the activations' low parts
+                    lo[:, c] = pim[st, 1, h, :, jj]
+                    assert torch.all(pim[st, 1, h, :, jj + 4] == 0)
+        assert torch.equal(hi[:pc, :cin], wp.to(dt).float())
+        assert torch.equal(lo[:pc, :cin], (wp - wp.to(dt).float()).to(dt).float())
+        assert torch.all(hi[pc:] == 0) and torch.all(hi[:, cin:] == 0) and torch.all(lo[pc:] == 0)
+
+
+def test_op_costs_count_a_residual_that_is_the_input_once():
+    """RFDB's c{j}_r adds its own input (rfdn_baseline/block.py:150-158) -- 100 B in + 100 B out + 50 B distilled per
+    pixel at nf = 50 / dc = 25 in 16-bit storage, not 350; the stored figure carries the pad channels (pitch 64 / 32: 320 B)."""
+    from ntire2022_esr_amd import RFDN
+    from ntire2022_esr_amd.engine import Plan
+    m = RFDN()
+    m.set_compute("bf16")
+    plan = Plan(1, 64, 64, m._store())
+    m._build_plan(plan, 3)
+    costs = {c["name"]: c for c in m.op_costs(plan)}
+    npx = 64 * 64
+    c1r, c3r = costs["B1.c1_r"], costs["B1.c3_r"]
+    w3, wp = 4.0 * 50 * 50 * 9, 4.0 * 50 * 25                # weight bytes: the 3x3's (both figures), the post 1x1's (stored figure only)
+    assert abs((c1r["read_bytes"] + c1r["write_bytes"] - w3) / npx - 250.0) < 1e-6
+    assert abs((c1r["stored_bytes"] - w3 - wp) / npx - 320.0) < 1e-6
+    assert abs((c3r["read_bytes"] + c3r["write_bytes"] - 4.0 * 50 * 50 * 9) / npx - 200.0) < 1e-6
+    for c in costs.values():
+        assert c["stored_bytes"] >= (c["read_bytes"] + c["write_bytes"]) * 0.9999, c["name"]
+
+
 def test_isa_lint():
     """tools/lint_isa.py over EVERY translation unit of the library (cross-compiled to gfx950 assembly, cached under build/isa; about a
     minute, no GPU): (1) no packed-fp32 instruction with an op_sel that reads a high dword -- the gfx950 erratum behind round 3's

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESR_ABI_VERSION 11
+#define ESR_ABI_VERSION 12
 
 typedef enum esr_status {
     ESR_OK = 0,
@@ -114,7 +114,13 @@ typedef struct esr_conv_desc {
     int32_t tail_cat_c;
     int32_t tail_cout;
     int32_t tail_mid_act;       /* esr_act applied to the 3x3 result before the 1x1 (slope = `slope`) */
-    int32_t reserved2;
+    /* ABI v12 -- the tail in 16-bit storage (csrc/esr_c64m.hip: rfdb_tail_kernel): RFDB's c4 -> cat(d1, d2, d3, r4) -> c5 -> esa.conv1
+     * (models/rfdn_baseline/block.py:161-164, :117) in ONE launch.  The 3x3 (64 physical input channels, cout <= 32) is activated by
+     * tail_mid_act and ROUNDED to the storage type (exactly the tensor the separate launches store) but never stored; tail_cat are
+     * three dense tensors of pitch 32 (tail_cat_c = 96 physical slots) that lie tail_seg_stride16 * 16 bytes apart; the 1x1 (tail_cout
+     * <= 64, no activation, weights from esr_pack_tail_s16) is stored to out0 AND, unrounded, feeds the post 1x1 (post_wpacked from
+     * esr_pack_post_s16, post_cout <= 16, post_out).  esr_conv_tail_supported(d) tells whether a descriptor runs this way. */
+    int32_t tail_seg_stride16;
     /* ABI v3 -- optional "post" 1x1: besides its own output, the conv's ACTIVATED result x' feeds a 1x1 whose output goes to
      * `post_out`:  post_out = post_act(W_p . x' + b_p).  RFDB: r_j = act(c{j}_r(..)), d_{j+1} = lrelu(c{j+1}_d(r_j))
      * (models/rfdn_baseline/block.py:150-160) -- the distillation conv is evaluated by the kernel that produces its input.
@@ -196,6 +202,12 @@ typedef struct esr_conv_desc {
  * `cin_phys` physical input-channel slots, the logical input channel it carries or -1 for a padding
  * slot: that is how padded concat buffers are described.  Pure CPU code: callable without a GPU. */
 size_t esr_packed_conv_bytes(int cin_phys, int cout, int ksize);
+/* ABI v12 -- weights of the 1x1 of a 16-bit-storage tail (esr_conv_desc.tail_*): w [cout][nseg * seg_c + mid_c] fp32 (the reference's
+ * c5.weight: inputs in concat order, the 3x3's mid_c channels last) -> fragment images for v_mfma_f32_32x32x16 (high and low 16-bit parts)
+ * + fp32 bias.  Shapes: nseg == 3, seg_c <= 32, mid_c <= 32, cout <= 64.  Host-side, no GPU needed. */
+size_t esr_packed_tail_s16_bytes(int nseg, int seg_c, int mid_c, int cout);
+int    esr_pack_tail_s16(const float* w, const float* bias, int nseg, int seg_c, int mid_c, int cout, int compute, void* out, size_t out_bytes);
+int    esr_conv_tail_supported(const esr_conv_desc* d);       /* 1: esr_conv2d_f32 runs this 16-bit descriptor's tail fused */
 int    esr_pack_conv_f32(const float* w_oihw, const float* bias, int cin, int cout, int ksize,
                          const int32_t* cin_map, int cin_phys, void* out, size_t out_bytes);
 /* inverse, for tests: recovers OIHW + bias from a packed blob */

@@ -44,7 +44,7 @@ class ConvDesc(ctypes.Structure):
         ("compute", ctypes.c_int32), ("storage", ctypes.c_int32),
         ("tail_wpacked", ctypes.c_void_p), ("tail_cat", View),
         ("tail_cat_c", ctypes.c_int32), ("tail_cout", ctypes.c_int32),
-        ("tail_mid_act", ctypes.c_int32), ("reserved2", ctypes.c_int32),
+        ("tail_mid_act", ctypes.c_int32), ("tail_seg_stride16", ctypes.c_int32),
         ("post_wpacked", ctypes.c_void_p), ("post_out", View),
         ("post_cout", ctypes.c_int32), ("post_act", ctypes.c_int32),
         ("post2_wpacked", ctypes.c_void_p), ("post2_out", View),
@@ -130,6 +130,7 @@ EXPORTS = [
     "esr_packed_conv_bytes", "esr_pack_conv_f32", "esr_unpack_conv_f32",
     "esr_packed_conv_s16_bytes", "esr_pack_conv_s16", "esr_unpack_conv_s16",
     "esr_packed_post_s16_bytes", "esr_pack_post_s16", "esr_conv_post_supported",
+    "esr_packed_tail_s16_bytes", "esr_pack_tail_s16", "esr_conv_tail_supported",
     "esr_packed_wino_bytes", "esr_pack_wino_f32", "esr_unpack_wino_f32", "esr_wino_supported",
     "esr_conv2d_f32", "esr_conv_block_waves", "esr_run_ops", "esr_pack_input_s16",
     "esr_prof_create", "esr_run_ops_profiled", "esr_prof_collect", "esr_prof_destroy", "esr_prof_kernel_symbol",
@@ -180,6 +181,12 @@ def lib():
     L.esr_packed_post_s16_bytes.restype = sz
     L.esr_pack_post_s16.argtypes = [vp, vp, ci, ci, ci, vp, sz]
     L.esr_pack_post_s16.restype = ci
+    L.esr_packed_tail_s16_bytes.argtypes = [ci, ci, ci, ci]
+    L.esr_packed_tail_s16_bytes.restype = sz
+    L.esr_pack_tail_s16.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, sz]
+    L.esr_pack_tail_s16.restype = ci
+    L.esr_conv_tail_supported.argtypes = [ctypes.POINTER(ConvDesc)]
+    L.esr_conv_tail_supported.restype = ci
     L.esr_conv_post_supported.argtypes = [ctypes.POINTER(ConvDesc)]
     L.esr_conv_post_supported.restype = ci
     L.esr_packed_wino_bytes.argtypes = [ci, ci]
@@ -258,7 +265,7 @@ def lib():
     L.esr_event_pair_ms.restype = ci
     L.esr_bw_probe.argtypes = [vp, sz, ci, vp, ctypes.POINTER(ctypes.c_double)]
     L.esr_bw_probe.restype = ci
-    if L.esr_abi_version() != 11:
+    if L.esr_abi_version() != 12:
         raise EsrError("libesr_hip.so ABI version mismatch")
     L.esr_sizeof.argtypes = [ci]
     L.esr_sizeof.restype = ctypes.c_size_t

@@ -524,6 +524,349 @@ int launch_conv64m(const S16K& k, hipStream_t st)
     return esr_check_launch("conv64m_kernel launch");
 }
 
+
+// ---- rfdb_tail_kernel: RFDB's c4 -> cat(d1, d2, d3, r4) -> c5 -> esa.conv1 in ONE launch (round 6, ABI v12; rfdn_baseline/block.py:161-164, :117) -------
+//   r4  = round16(act(conv3x3_c4(r3) + b4))          32 physical channels, never stored -- the tensor the separate launches kept in `cat`
+//   v   = W5 . [d1 | d2 | d3 | r4] + b5               fp32; stored rounded (64 physical channels)
+//   c1  = round16(Wc1 . v + bc1)                      on the UNROUNDED v as hi | lo B operands (bf16; fp16: the rounded v), 16 channels
+// conv64m_kernel's frame: 16 x 16 tiles, a wave = two row pairs, the c4 convolution as the MAIN stream (one output half: 1 bias + 36 MFMAs per
+// pair, all 36 weight fragments in accumulation registers), everything else as the finished pair's epilogue behind it:
+//   * d1 .. d3 never pass through LDS: a lane's B operand of k step (segment s, half-segment u) is 16 bytes of ITS pixel -- one
+//     buffer_load_dwordx4 per step straight into registers, issued at the top of the pair's own main stream (two register sets), consumed a
+//     pair later behind an exact s_waitcnt;
+//   * r4 goes from the D fragment to the B operand inside the lane (two 4-channel blocks per k step; the packer orders c5's rows to match);
+//   * c5's weights as hi + lo (conv_s16_kernel's 1x1 form): the 16 high fragments in accumulation registers, the low ones in LDS next to
+//     esa.conv1's images; v's hi | lo split, conv1's MFMAs, swaps and stores as in conv64m_kernel<.., POST>.
+// 87 MFMAs per pair (37 + 34 + 16; fp16: 63), five stores, six loads; the separate launches moved 608 bytes per pixel, this one 480.
+constexpr int T_OFF_W5LO = 2 * M_STAGE;                   // c5's low-part fragments [ks][half]: 16 KB
+constexpr int T_OFF_C1 = T_OFF_W5LO + 16 * 1024;          // esa.conv1's images [step][hi | lo]: 16 KB
+constexpr int T_LDS = T_OFF_C1 + M_POST_IMG;
+constexpr int T_SPREAD = 2, T_FIRST = 8;                  // the next tile's DMA piece i behind k step T_FIRST + T_SPREAD * i of the FIRST pair
+constexpr int T_OPS = 4;                                  // epilogue operations per k step
+static_assert(T_LDS <= LDS_LIMIT && T_FIRST + T_SPREAD * (M_PPW - 1) < M_NG, "LDS map / the pieces fit the first pair");
+// the epilogue's operation list (index q); see `top` in the kernel
+constexpr int TQ_WAIT = 0, TQ_LOAD = 1, TQ_R4 = 7, TQ_B5 = 19, TQ_D5 = 21, TQ_R5 = 51, TQ_GAP1 = 61, TQ_V = 73, TQ_GAP2 = 125, TQ_C1 = 133, TQ_END = 136;
+static_assert(TQ_END <= T_OPS * M_NG, "the epilogue fits the main stream's k steps");
+constexpr int t_step_of(int q) { return q / T_OPS; }
+// stores: v's four at the end of every second block of the V phase, conv1's at TQ_C1 + 2
+constexpr int t_store_q(int i) { return i < 4 ? TQ_V + 13 * i + 12 : TQ_C1 + 2; }
+constexpr int t_stores_behind_step(int g) { int n = 0; for (int i = 0; i < 5; ++i) n += t_step_of(t_store_q(i)) > g; return n; }
+
+template <bool BF16>
+__global__ __launch_bounds__(256, 1) void rfdb_tail_kernel(const S16K p)
+{
+    constexpr int RW = M_RW, NG = M_NG, TAPS = M_TAPS, STAGE = M_STAGE, ROWB = M_ROWB, PIXB = M_PIXB, PPW = M_PPW;
+    constexpr unsigned ONE = BF16 ? 0x3f80u : 0x3c00u;
+    constexpr bool PLO = BF16;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pn = lane & 31, hh = lane >> 5;
+    const int px = pn & 15, pe = pn >> 4;
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    // ---- prologue: c5's low parts and conv1's images to LDS; c4's 36 fragments and c5's 16 high fragments into accumulation registers
+    for (int pc = wv; pc < 16; pc += 4) {
+        const int ks = pc >> 1, half = pc & 1;
+        dma_glb16(smem_lds + (unsigned)(T_OFF_W5LO + pc * 1024), p.tw + (size_t)((ks * 2 + half) * 2 + 1) * 1024 + lane * 16);
+    }
+    for (int pc = wv; pc < M_POST_IMG / 1024; pc += 4) dma_glb16(smem_lds + (unsigned)(T_OFF_C1 + pc * 1024), p.pm32 + (size_t)pc * 1024 + lane * 16);
+    i32x4 wa4[NG], w5h[16];
+#pragma unroll
+    for (int f = 0; f < NG; ++f) wa4[f] = *reinterpret_cast<const i32x4*>(p.wm32 + (size_t)f * 1024 + lane * 16);
+#pragma unroll
+    for (int f = 0; f < 16; ++f) w5h[f] = *reinterpret_cast<const i32x4*>(p.tw + (size_t)(f * 2) * 1024 + lane * 16);
+    const i32x4 a_b4 = bias_frag<BF16>(p.bias[pn], hh == 0);
+    i32x4 a_b5[2];
+    const float* const b5 = reinterpret_cast<const float*>(p.tw + (size_t)32 * 1024);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) a_b5[hf] = bias_frag<BF16>(b5[32 * hf + pn], hh == 0);
+    const i32x4 a_bc = bias_frag<BF16>(p.pbias1[pn], hh == 0);
+    const i32x4 b_ones = hh == 0 ? i32x4{(int)(ONE | (ONE << 16)), (int)ONE, 0, 0} : i32x4{0, 0, 0, 0};
+
+    const int ntiles = p.N * p.tiles_y * p.tiles_x;
+    auto tile_index = [&](int k) -> int { return s16_tile_index(k, ntiles); };
+    auto tile_coords = [&](int t, int& n, int& x0, int& y0) __attribute__((always_inline)) { s16_tile_coords(t, p.magic_x, p.magic_y, p.tiles_x, p.tiles_y, (4 * RW), n, x0, y0); };
+    const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 2;
+    // DMA pieces of the input halo tile: conv64m_kernel's (lane-constant offsets and edge masks, the origin in the descriptor)
+    unsigned rel[PPW], edge = 0u, lxp[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const unsigned sl = (unsigned)((wv + 4 * i) * 64 + lane);
+        const unsigned row = sl / (unsigned)M_ROWSL, rem = sl - row * (unsigned)M_ROWSL;
+        const unsigned lx = rem / (unsigned)M_LSL, part = rem - lx * (unsigned)M_LSL;
+        const bool real = part < 8u && lx < (unsigned)M_TH && row < (unsigned)M_THY && (i < PPW - 1 || wv + 4 * i < M_NPIECES);
+        rel[i] = real ? (row * (unsigned)p.W + lx) * (unsigned)p.in_pitch * 2u + part * 16u : OOB;
+        edge |= (row == 0u ? 1u << i : 0u) | (lx == 0u ? 1u << (13 + i) : 0u);
+        lxp[i / 6] |= (lx < 31u ? lx : 31u) << (5 * (i % 6));
+    }
+    auto dma_piece_fast = [&](auto i_, unsigned bad, i32x4 rsrc, unsigned lds0) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_)::value;
+        if (i < PPW - 1 || wv + 4 * i < M_NPIECES) {
+            const unsigned voff = rel[i] | (unsigned)__builtin_amdgcn_sbfe((int)bad, (unsigned)i, 1u);
+            asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds"
+                         :: "s"(lds0), "n"(i * 4096), "v"(voff), "s"(rsrc) : "memory");
+        }
+    };
+    auto dma_piece = [&](int i, int n, int x0, int y0) __attribute__((always_inline)) {          // the first tile, into stage 0
+        const int pc = wv + 4 * i;
+        if (i < PPW - 1 || pc < M_NPIECES) {
+            const unsigned sl = (unsigned)(pc * 64 + lane);
+            const unsigned row = sl / (unsigned)M_ROWSL, rem = sl - row * (unsigned)M_ROWSL;
+            const unsigned lx = rem / (unsigned)M_LSL, part = rem - lx * (unsigned)M_LSL;
+            const int gy = y0 - 1 + (int)row, gx = x0 - 1 + (int)lx;
+            const bool ok = part < 8u && lx < (unsigned)M_TH && row < (unsigned)M_THY && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const unsigned voff = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff) * 2u + part * 16u : OOB;
+            dma_buf16(smem_lds + (unsigned)(pc * 1024), voff, make_rsrc(p.x + (size_t)n * img_bytes, img_bytes), 0u);
+        }
+    };
+
+    int n, x0, y0;
+    {
+        const int t0 = tile_index(0);
+        if (t0 < 0) return;
+        tile_coords(t0, n, x0, y0);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma_piece(i, n, x0, y0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const unsigned b_base = (unsigned)((wv * RW + pe) * ROWB + px * PIXB + hh * 16);
+    unsigned w5lo_off = (unsigned)(T_OFF_W5LO + lane * 16), c1img_off = (unsigned)(T_OFF_C1 + lane * 16);
+    asm volatile("" : "+v"(w5lo_off), "+v"(c1img_off));
+    const char* const w5lo = smem + w5lo_off;
+    const char* const c1img = smem + c1img_off;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const float slope = p.slope, p1s = p.p1_slope;
+    const size_t y_img = (size_t)p.H * p.W * p.y0_pitch * 2, p1_img = (size_t)p.H * p.W * p.py1_pitch * 2, cat_img = (size_t)p.H * p.W * p.cat_pitch * 2;
+    const unsigned rowb = (unsigned)p.W * (unsigned)p.y0_pitch * 2u, rowb1 = (unsigned)p.W * (unsigned)p.py1_pitch * 2u, rowbc = (unsigned)p.W * (unsigned)p.cat_pitch * 2u;
+    const unsigned seg1 = (unsigned)p.cat_seg_stride, seg2 = 2u * (unsigned)p.cat_seg_stride;
+
+    f32x16 acc4[2], acc5[2], d1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { acc4[0][j] = 0.f; acc4[1][j] = 0.f; acc5[0][j] = 0.f; acc5[1][j] = 0.f; d1[j] = 0.f; }
+    i32x4 dq[2][6];                      // [pair & 1][k step]: the lane's 16 bytes of d1 .. d3 (two half-segments each)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b_ = 0; b_ < 6; ++b_) dq[a][b_] = i32x4{0, 0, 0, 0};
+    i32x4 rbv[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};     // r4 rounded: k steps 6, 7 of c5
+    i32x4 bs[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};      // v's blocks: rounded (x, y) | low parts (z, w)
+    i32x4 lo5[2], pa[2][2];
+    uint2 pq[2];
+    float tv0 = 0.f, tv1 = 0.f, tv2 = 0.f, tv3 = 0.f, lv0 = 0.f, lv1 = 0.f, lv2 = 0.f, lv3 = 0.f;
+    unsigned e_v[4], e_vP = OOB, d_v = OOB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e_v[j] = OOB;
+    int e_n = 0, d_n = 0;
+    auto store_offsets = [&](int nn_, int x0_, int y0_) __attribute__((always_inline)) {
+        const bool inx = x0_ + px < p.W;
+        const unsigned pix = (unsigned)((y0_ + wv * RW + pe) * p.W + x0_ + px);
+        const unsigned base = (pix * (unsigned)p.y0_pitch + (unsigned)p.y0_coff) * 2u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = 16 * j + 8 * hh;
+            e_v[j] = (inx && ch < p.cout_store) ? base + (unsigned)ch * 2u : OOB;
+        }
+        e_vP = (inx && 8 * hh < p.p1_cout8) ? (pix * (unsigned)p.py1_pitch + (unsigned)p.py1_coff) * 2u + (unsigned)(8 * hh) * 2u : OOB;
+        e_n = nn_;
+    };
+    auto load_offsets = [&](int nn_, int x0_, int y0_) __attribute__((always_inline)) {       // d1 .. d3 of the lane's pixel (first pair's row)
+        const bool inx = x0_ + px < p.W;
+        const unsigned pix = (unsigned)((y0_ + wv * RW + pe) * p.W + x0_ + px);
+        d_v = inx ? (pix * (unsigned)p.cat_pitch + (unsigned)p.cat_coff) * 2u + (unsigned)hh * 16u : OOB;
+        d_n = nn_;
+    };
+    auto load_d = [&](auto rp_, auto ks_) __attribute__((always_inline)) {
+        constexpr int rp = decltype(rp_)::value, ks = decltype(ks_)::value, sg = ks >> 1, u = ks & 1;
+        const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.cat) + (size_t)d_n * cat_img, 0, (int)cat_img, 0x00020000);
+        dq[rp & 1][ks] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(cr, d_v + (unsigned)(2 * rp) * rowbc + (unsigned)(u * 32), sg == 0 ? 0u : (sg == 1 ? seg1 : seg2), 0));
+    };
+    auto load_lo5 = [&](int ks) __attribute__((always_inline)) {
+        lo5[0] = *reinterpret_cast<const i32x4*>(w5lo + (ks * 2) * 1024);
+        lo5[1] = *reinterpret_cast<const i32x4*>(w5lo + (ks * 2 + 1) * 1024);
+    };
+    auto load_pa = [&](int blk) __attribute__((always_inline)) {
+        pa[blk & 1][0] = *reinterpret_cast<const i32x4*>(c1img + (blk * 2) * 1024);
+        if (PLO) pa[blk & 1][1] = *reinterpret_cast<const i32x4*>(c1img + (blk * 2 + 1) * 1024);
+    };
+    // operation q of the finished pair's epilogue (par: its c4 accumulators and d registers; r: its first row; FLUSH: behind the last tile)
+    auto top = [&](auto par_, auto r_, auto q_, auto flush_) __attribute__((always_inline)) {
+        constexpr int par = decltype(par_)::value, r = decltype(r_)::value, q = decltype(q_)::value;
+        constexpr bool FLUSH = decltype(flush_)::value;
+        if constexpr (q >= TQ_R4 && q < TQ_B5) {                                   // r4: activation, rounding -> rbv
+            constexpr int b = (q - TQ_R4) / 3, m = (q - TQ_R4) % 3;
+            f32x16& A = acc4[par];
+            if constexpr (m == 0) { A[4 * b] = act1(A[4 * b], slope); A[4 * b + 1] = act1(A[4 * b + 1], slope); }
+            else if constexpr (m == 1) { A[4 * b + 2] = act1(A[4 * b + 2], slope); A[4 * b + 3] = act1(A[4 * b + 3], slope); }
+            else {
+                const unsigned x = pack2<BF16>(A[4 * b], A[4 * b + 1]), y = pack2<BF16>(A[4 * b + 2], A[4 * b + 3]);
+                if constexpr ((b & 1) == 0) { rbv[b >> 1].x = (int)x; rbv[b >> 1].y = (int)y; }
+                else { rbv[b >> 1].z = (int)x; rbv[b >> 1].w = (int)y; }
+            }
+        } else if constexpr (q >= TQ_B5 && q < TQ_D5) {                            // c5's bias
+            mfma_m0<BF16>(acc5[q - TQ_B5], a_b5[q - TQ_B5], b_ones);
+        } else if constexpr (q >= TQ_D5 && q < TQ_GAP1) {                          // c5: k steps 0 .. 5 on d1 .. d3, 6 / 7 on r4
+            constexpr int ks = (q - TQ_D5) / 5, m = (q - TQ_D5) % 5;
+            const i32x4& B = ks < 6 ? dq[par][ks < 6 ? ks : 0] : rbv[ks >= 6 ? ks - 6 : 0];
+            if constexpr (m == 0) { if constexpr (PLO) load_lo5(ks); }
+            else if constexpr (m == 1) mfma_m<BF16, true>(acc5[0], w5h[2 * ks], B);
+            else if constexpr (m == 2) mfma_m<BF16, true>(acc5[1], w5h[2 * ks + 1], B);
+            else if constexpr (m == 3) { if constexpr (PLO) mfma_m<BF16, false>(acc5[0], lo5[0], B); }
+            else { if constexpr (PLO) mfma_m<BF16, false>(acc5[1], lo5[1], B); }
+        } else if constexpr ((q >= TQ_GAP1 && q < TQ_V) || (q >= TQ_GAP2 && q < TQ_C1)) {
+            // (asm MFMAs: hipcc pads no read of their results; in the stream the main MFMAs of three k steps lie in between)
+            if constexpr (FLUSH && (q == TQ_GAP1 || q == TQ_GAP2)) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+            if constexpr (q == TQ_GAP1 + 1) load_pa(0);
+            if constexpr (q == TQ_GAP1 + 2) d1 = mfma_b<BF16>(a_bc, b_ones, f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
+        } else if constexpr (q >= TQ_V && q < TQ_GAP2) {                           // v: 8 blocks; 13 operations per block pair
+            constexpr int P = (q - TQ_V) / 13, w = (q - TQ_V) % 13;
+            if constexpr (w < 12) {
+                constexpr int blk = 2 * P + w / 6, u = w % 6, hf = blk >> 2, b = blk & 3, sl = blk & 1;
+                f32x16& A = acc5[hf];
+                if constexpr (u == 0) {
+                    bs[sl].x = (int)pack2<BF16>(A[4 * b], A[4 * b + 1]); bs[sl].y = (int)pack2<BF16>(A[4 * b + 2], A[4 * b + 3]);
+                    if constexpr (PLO) unpack2<BF16>((unsigned)bs[sl].x, tv0, tv1);
+                    else { bs[sl].z = 0; bs[sl].w = 0; }
+                } else if constexpr (u == 1) {
+                    if constexpr (PLO) { unpack2<BF16>((unsigned)bs[sl].y, tv2, tv3); lv0 = A[4 * b] - tv0; lv1 = A[4 * b + 1] - tv1; }
+                } else if constexpr (u == 2) {
+                    if constexpr (PLO) {
+                        lv2 = A[4 * b + 2] - tv2; lv3 = A[4 * b + 3] - tv3;
+                        bs[sl].z = (int)pack2<BF16>(lv0, lv1); bs[sl].w = (int)pack2<BF16>(lv2, lv3);
+                    }
+                } else if constexpr (u == 3) {
+                    d1 = mfma_b<BF16>(pa[sl][0], bs[sl], d1);
+                    if constexpr (blk < 7) load_pa(blk + 1);
+                } else if constexpr (u == 4) {
+                    if constexpr (PLO) d1 = mfma_b<BF16>(pa[sl][1], bs[sl], d1);
+                }
+            } else {                                                               // the pair's store: channels 16 P + 8 h .. + 7
+                const u32x2 s0 = __builtin_amdgcn_permlane32_swap((unsigned)bs[0].x, (unsigned)bs[1].x, false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane32_swap((unsigned)bs[0].y, (unsigned)bs[1].y, false, false);
+                const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)e_n * y_img, 0, (int)y_img, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)s0.x, (int)s1.x, (int)s0.y, (int)s1.y}, yr, e_v[P] + (unsigned)r * rowb, 0, 0);
+            }
+        } else if constexpr (q >= TQ_C1 && q < TQ_END) {                           // esa.conv1's 16 channels: blocks 0, 1 of d1
+            constexpr int m = q - TQ_C1;
+            if constexpr (m < 2) {
+                d1[4 * m] = act1(d1[4 * m], p1s); d1[4 * m + 1] = act1(d1[4 * m + 1], p1s); d1[4 * m + 2] = act1(d1[4 * m + 2], p1s); d1[4 * m + 3] = act1(d1[4 * m + 3], p1s);
+                pq[m].x = pack2<BF16>(d1[4 * m], d1[4 * m + 1]); pq[m].y = pack2<BF16>(d1[4 * m + 2], d1[4 * m + 3]);
+            } else {
+                const u32x2 s0 = __builtin_amdgcn_permlane32_swap(pq[0].x, pq[1].x, false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane32_swap(pq[0].y, pq[1].y, false, false);
+                const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(p.py1 + (size_t)e_n * p1_img, 0, (int)p1_img, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)s0.x, (int)s1.x, (int)s0.y, (int)s1.y}, r1, e_vP + (unsigned)r * rowb1, 0, 0);
+            }
+        }
+    };
+
+    for (int k = 0;; ++k) {
+        const int tn = tile_index(k + 1);
+        const bool more = tn >= 0;
+        int nn = 0, nx0 = 0, ny0 = 0;
+        if (more) tile_coords(tn, nn, nx0, ny0);
+        const char* const bb = smem + b_base + (unsigned)((k & 1) * STAGE);
+        const unsigned tbase = (unsigned)(((ny0 - 1) * p.W + (nx0 - 1)) * p.in_pitch + p.in_coff) * 2u;
+        const i32x4 nrsrc = make_rsrc(p.x + (size_t)nn * img_bytes + (size_t)(int)tbase, img_bytes - (size_t)(int)tbase);
+        unsigned bad;
+        {
+            const unsigned sel = (ny0 == 0 ? 0x1fffu : 0u) | (nx0 == 0 ? 0x1fffu << 13 : 0u);
+            const unsigned t = edge & sel;
+            bad = more ? ((t | (t >> 13)) & 0x1fffu) : 0xffffffffu;
+            if (nx0 + TILE + 1 > p.W) {
+                const unsigned lim = (unsigned)(p.W - nx0 + 1);
+#pragma unroll
+                for (int i = 0; i < PPW; ++i) bad |= (((lxp[i / 6] >> (5 * (i % 6))) & 31u) >= lim ? 1u : 0u) << i;
+            }
+        }
+        const unsigned lds0 = smem_lds + (unsigned)(((k + 1) & 1) * STAGE + wv * 1024);
+        constexpr int AHEAD = 3;
+        i32x4 b[4];
+        auto read_b = [&](auto L_) __attribute__((always_inline)) {
+            constexpr int L = decltype(L_)::value;
+            constexpr int rp_ = L / NG, g_ = L % NG, c_ = g_ / TAPS, t_ = g_ % TAPS;
+            b[L & 3] = *reinterpret_cast<const i32x4*>(bb + (2 * rp_ + t_ / 3) * ROWB + (t_ % 3) * PIXB + c_ * 32);
+        };
+        static_for<AHEAD>([&](auto L_) __attribute__((always_inline)) { read_b(L_); });
+        auto run_pair = [&](auto rp_tag) __attribute__((always_inline)) {
+            constexpr int rp = decltype(rp_tag)::value;
+            constexpr int par = rp & 1;
+            using PrevPar = std::integral_constant<int, par ^ 1>;
+            using PrevRow = std::integral_constant<int, (rp == 0 ? RW - 2 : 2 * rp - 2)>;
+            // the finished pair's d registers: younger than its loads are the pieces issued in ITS main stream (first pair: at least 12)
+            // and that stream's five stores
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((rp == 1 ? PPW - 1 : 0) + 5) : "memory");
+            if constexpr (rp == 0) load_offsets(n, x0, y0);        // (this tile's pixels: both pairs' loads)
+            mfma_m0<BF16>(acc4[par], a_b4, b_ones);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<NG>([&](auto g_) __attribute__((always_inline)) {
+                constexpr int g = decltype(g_)::value;
+                constexpr int L = rp * NG + g, cs = L & 3;
+                if constexpr (L + AHEAD < 2 * NG) read_b(std::integral_constant<int, L + AHEAD>{});
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_m<BF16, true>(acc4[par], wa4[g], b[cs]);
+                __builtin_amdgcn_sched_barrier(0);
+                // this pair's own d loads first (k steps 1 .. 6), then the epilogue of the pair before
+                if constexpr (g >= 1 && g <= 6) load_d(rp_tag, std::integral_constant<int, g - 1>{});
+                if constexpr (rp == 1 && g == 7) store_offsets(n, x0, y0);     // behind the carried epilogue's... see below
+                static_for<T_OPS>([&](auto o_) __attribute__((always_inline)) {
+                    constexpr int q = T_OPS * g + decltype(o_)::value;
+                    if constexpr (q >= TQ_R4 && q < TQ_END) top(PrevPar{}, PrevRow{}, std::integral_constant<int, q>{}, std::false_type{});
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if constexpr (rp == 0 && g >= T_FIRST && (g - T_FIRST) % T_SPREAD == 0 && (g - T_FIRST) / T_SPREAD < PPW)
+                    dma_piece_fast(std::integral_constant<int, (g - T_FIRST) / T_SPREAD>{}, bad, nrsrc, lds0);
+            });
+        };
+        run_pair(std::integral_constant<int, 0>{});
+        run_pair(std::integral_constant<int, 1>{});
+        // the next tile has landed: younger than the last DMA piece are the first pair's stores behind it, the second pair's loads and stores
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(t_stores_behind_step(T_FIRST + T_SPREAD * (PPW - 1)) + 6 + 5) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (!more) break;
+        n = nn; x0 = nx0; y0 = ny0;
+    }
+    // the last tile's last row pair
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+    static_for<TQ_END - TQ_R4>([&](auto i_) __attribute__((always_inline)) {
+        top(std::integral_constant<int, 1>{}, std::integral_constant<int, RW - 2>{}, std::integral_constant<int, TQ_R4 + decltype(i_)::value>{}, std::true_type{});
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool BF16>
+int launch_rfdb_tail(const S16K& k, hipStream_t st)
+{
+    static std::atomic<unsigned> attr_set[MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
+    if (!attr_set[dev].load(std::memory_order_relaxed)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfdb_tail_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+        if (e != hipSuccess) {
+            esr_set_err("hipFuncSetAttribute(rfdb_tail_kernel, MaxDynamicSharedMemorySize)", e);
+            return ESR_ERR_LAUNCH;
+        }
+        attr_set[dev].store(1u, std::memory_order_relaxed);
+    }
+    const int ntiles = k.N * k.tiles_x * k.tiles_y;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    esr_note_kernel("rfdb_tail_kernel<%s>", esr_tf(BF16));
+    hipLaunchKernelGGL((rfdb_tail_kernel<BF16>), dim3(grid), dim3(256), T_LDS, st, k);
+    return esr_check_launch("rfdb_tail_kernel launch");
+}
+
+}  // namespace
+
+int esr_launch_rfdb_tail(const S16K& k, bool bf16, hipStream_t st)
+{
+    if (!k.wm32 || !k.pm32 || !k.pbias1 || !k.tw || !k.cat) return ESR_ERR_BAD_ARG;
+    return bf16 ? launch_rfdb_tail<true>(k, st) : launch_rfdb_tail<false>(k, st);
+}
+
+namespace {
 }  // namespace
 
 int esr_launch_conv64m(const S16K& k, bool bf16, bool post, hipStream_t st)
@@ -534,27 +877,108 @@ int esr_launch_conv64m(const S16K& k, bool bf16, bool post, hipStream_t st)
 }
 
 // ---- host side: where the 32x32x16 images live inside the packed blobs ----------------------------------------------------------------------
-// esr_pack_conv_s16 blob of a 3x3 over 64 physical input channels with 49 .. 64 outputs: [tap-pair image 80 KB][bias 256 B][this image 72 KB];
-// fragment f = (chunk * 9 + tap) * 2 + half, lane l = 32 h + i, element j: the 16-bit weight of output channel 32 half + i, input slot
-// 16 chunk + 8 h + j at that tap (the same error-diffused values as the tap-pair image)
+// esr_pack_conv_s16 blob of a 3x3 over 64 physical input channels with 17 .. 32 or 49 .. 64 outputs: [tap-pair image][bias][this image];
+// NH = 1 or 2 output halves; fragment f = (chunk * 9 + tap) * NH + half, lane l = 32 h + i, element j: the 16-bit weight of output channel
+// 32 half + i, input slot 16 chunk + 8 h + j at that tap (the same error-diffused values as the tap-pair image)
 size_t esr_m32_conv_bytes(int cin_phys, int cout, int ksize)
 {
-    return (ksize == 3 && esr_round_up(cin_phys, 16) == 64 && esr_round_up(cout, 16) == 64) ? (size_t)M_NFRAG * 1024 : 0;
+    if (ksize != 3 || esr_round_up(cin_phys, 16) != 64) return 0;
+    const int nt = esr_round_up(cout, 16) / 16;
+    return nt == 4 ? (size_t)M_NFRAG * 1024 : (nt == 2 ? (size_t)M_NG * 1024 : 0);
 }
 size_t esr_m32_conv_offset(int cin_phys, int cout, int ksize)
 {
     if (!esr_m32_conv_bytes(cin_phys, cout, ksize)) return 0;
-    return (size_t)4 * 5 * 4 * 1024 + 4 * 16 * sizeof(float);
+    const size_t nt = (size_t)esr_round_up(cout, 16) / 16;
+    return (size_t)4 * 5 * nt * 1024 + nt * 16 * sizeof(float);
 }
-// esr_pack_post_s16 blob of a 1x1 from 49 .. 64 to 17 .. 32 channels: [hi images][lo images][bias][this image 16 KB]: fragment (step, hi | lo),
+// esr_pack_post_s16 blob of a 1x1 from 49 .. 64 to 1 .. 32 channels: [hi images][lo images][bias][this image 16 KB]: fragment (step, hi | lo),
 // step = 4 half + block: the eight input channels 32 half + 8 block + 4 h + (j & 3); hi image: the weight's high part in all eight k slots
-// (slots 0 .. 3 meet the activations' high parts, 4 .. 7 their low parts), lo image: its low part in slots 0 .. 3 only
+// (slots 0 .. 3 meet the activations' high parts, 4 .. 7 their low parts), lo image: its low part in slots 0 .. 3 only; rows >= cout zero
 size_t esr_m32_post_bytes(int cin, int cout)
 {
-    return (esr_round_up(cin, 16) == 64 && esr_round_up(cout, 16) == 32) ? (size_t)M_POST_IMG : 0;
+    return (esr_round_up(cin, 16) == 64 && cout >= 1 && cout <= 32) ? (size_t)M_POST_IMG : 0;
 }
 size_t esr_m32_post_offset(int cin, int cout)
 {
     if (!esr_m32_post_bytes(cin, cout)) return 0;
-    return (size_t)2 * 4 * 2 * 1024 + 2 * 16 * sizeof(float);
+    const size_t ot = (size_t)esr_round_up(cout, 16) / 16;
+    return (size_t)2 * 4 * ot * 1024 + ot * 16 * sizeof(float);
+}
+
+// ---- esr_pack_tail_s16 (ABI v12): the 1x1 of a 16-bit tail, K = three 32-slot segments + the 3x3's 32 channels, for rfdb_tail_kernel --------
+// blob: 8 k steps x 2 output halves x (hi, lo) fragments of 1 KB, then 64 fp32 biases.  Fragment ((ks * 2 + half) * 2 + lo), lane l = 32 h + i
+// (output channel 32 half + i), element j:
+//   ks = 2 s + u (s = 0 .. 2, u = 0 | 1): slot 16 u + 8 h + j of segment s -- the B operand is 16 bytes of the segment's pixel as stored;
+//   ks = 6 + t (t = 0 | 1): channel 8 (2 t + (j >> 2)) + 4 h + (j & 3) of the 3x3's result -- the B operand is two of its D blocks, rounded
+namespace {
+inline uint16_t m_to16(double v, int compute)
+{
+    if (compute == ESR_COMPUTE_BF16) {
+        const float f = (float)v;
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    }
+    const _Float16 h = (_Float16)(float)v;
+    uint16_t r;
+    memcpy(&r, &h, 2);
+    return r;
+}
+inline double m_from16(uint16_t h, int compute)
+{
+    if (compute == ESR_COMPUTE_BF16) {
+        const uint32_t u = (uint32_t)h << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    }
+    _Float16 v;
+    memcpy(&v, &h, 2);
+    return (double)(float)v;
+}
+}  // namespace
+
+extern "C" size_t esr_packed_tail_s16_bytes(int nseg, int seg_c, int mid_c, int cout)
+{
+    if (nseg != 3 || seg_c <= 0 || seg_c > 32 || mid_c <= 0 || mid_c > 32 || cout <= 0 || cout > 64) return 0;
+    return (size_t)32 * 1024 + 64 * sizeof(float);
+}
+
+extern "C" int esr_pack_tail_s16(const float* w, const float* bias, int nseg, int seg_c, int mid_c, int cout, int compute, void* out, size_t out_bytes)
+{
+    const size_t need = esr_packed_tail_s16_bytes(nseg, seg_c, mid_c, cout);
+    if (!w || !out || need == 0 || out_bytes < need) return ESR_ERR_BAD_ARG;
+    if (compute != ESR_COMPUTE_BF16 && compute != ESR_COMPUTE_F16) return ESR_ERR_BAD_ARG;
+    memset(out, 0, need);
+    uint16_t* o = static_cast<uint16_t*>(out);
+    const int kin = nseg * seg_c + mid_c;
+    for (int ks = 0; ks < 8; ++ks)
+        for (int half = 0; half < 2; ++half)
+            for (int h = 0; h < 2; ++h)
+                for (int i = 0; i < 32; ++i)
+                    for (int j = 0; j < 8; ++j) {
+                        const int oc = 32 * half + i;
+                        int col = -1;                              // column of w (the reference's concat order), -1: a pad slot
+                        if (ks < 6) {
+                            const int sg = ks / 2, slot = 16 * (ks & 1) + 8 * h + j;
+                            if (slot < seg_c) col = sg * seg_c + slot;
+                        } else {
+                            const int ch = 8 * (2 * (ks - 6) + (j >> 2)) + 4 * h + (j & 3);
+                            if (ch < mid_c) col = nseg * seg_c + ch;
+                        }
+                        if (col < 0 || oc >= cout) continue;
+                        const double wv = w[(size_t)oc * kin + col];
+                        const uint16_t hi = m_to16(wv, compute);
+                        const uint16_t lo = m_to16(wv - m_from16(hi, compute), compute);
+                        const size_t e = (size_t)(32 * h + i) * 8 + j;
+                        o[(size_t)((ks * 2 + half) * 2 + 0) * 512 + e] = hi;
+                        o[(size_t)((ks * 2 + half) * 2 + 1) * 512 + e] = lo;
+                    }
+    float* bo = reinterpret_cast<float*>(static_cast<char*>(out) + (size_t)32 * 1024);
+    if (bias)
+        for (int oc = 0; oc < cout; ++oc) bo[oc] = bias[oc];
+    return ESR_OK;
 }

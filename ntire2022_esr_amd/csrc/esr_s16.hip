@@ -953,6 +953,66 @@ static bool conv48rl_takes(const esr_conv_desc* d)
     return (long)d->n * ((d->w + TILE - 1) / TILE) * ((d->h + 15) / 16) >= 256;
 }
 
+// rfdb_tail_kernel's descriptors (ABI v12, esr_c64m.hip): a 3x3 over 64 physical input channels with <= 32 outputs whose rounded result is the
+// last 32 slots of a 1x1 over three more dense 32-slot tensors, <= 64 outputs stored and fed (unrounded) to a post 1x1 of <= 16 outputs; no
+// residual, no activation on the 1x1; from 256 tiles of 16 x 16
+static bool rfdb_tail_takes(const esr_conv_desc* d)
+{
+    if (d->storage != ESR_STORE_BF16 && d->storage != ESR_STORE_F16) return false;
+    if (!d->tail_wpacked || !d->wpacked || d->ksize != 3 || d->in_layout != ESR_NHWC || d->out_layout != ESR_NHWC) return false;
+    if (esr_round_up(d->cin, 16) != 64 || d->cout < 1 || d->cout > 32 || d->tail_cat_c != 96 || d->tail_cout < 49 || d->tail_cout > 64) return false;
+    if (d->res_mode != ESR_RES_NONE || d->border_bias || d->hilo || d->in_seg_stride != 0 || d->act != ESR_ACT_NONE || d->blocked8) return false;
+    if (d->tail_mid_act != ESR_ACT_NONE && d->tail_mid_act != ESR_ACT_LRELU && d->tail_mid_act != ESR_ACT_RELU) return false;
+    if (d->split > 0 && d->split < d->tail_cout) return false;
+    if (!d->post_wpacked || d->post2_wpacked || d->post_cout < 1 || d->post_cout > 16) return false;
+    if (d->post_act != ESR_ACT_NONE && d->post_act != ESR_ACT_LRELU && d->post_act != ESR_ACT_RELU) return false;
+    if (!d->in.ptr || (d->in.pitch & 7) || (d->in.coff & 7) || d->in.coff + 64 > d->in.pitch) return false;
+    if (!d->tail_cat.ptr || (d->tail_cat.pitch & 7) || (d->tail_cat.coff & 7) || d->tail_cat.coff + 32 > d->tail_cat.pitch || d->tail_seg_stride16 <= 0) return false;
+    if (!d->out0.ptr || (d->out0.pitch & 7) || (d->out0.coff & 7) || d->out0.coff + esr_round_up(d->tail_cout, 8) > d->out0.pitch) return false;
+    if (!d->post_out.ptr || (d->post_out.pitch & 7) || (d->post_out.coff & 7) || d->post_out.coff + esr_round_up(d->post_cout, 8) > d->post_out.pitch) return false;
+    const double px = (double)d->h * d->w * 2.0, lim = 2147483647.0 - 1048576.0;
+    if (px * d->in.pitch >= lim || px * d->tail_cat.pitch >= lim || px * d->out0.pitch >= lim || px * d->post_out.pitch >= lim) return false;
+    if (2.0 * 16.0 * d->tail_seg_stride16 >= 4294967295.0) return false;                    // (the third segment's offset travels in a 32-bit scalar)
+    const long tx = (d->w + TILE - 1) / TILE, ty = (d->h + 15) / 16;
+    if ((long)d->n * tx * ty < 256) return false;
+    return (double)d->n * tx * ty * (tx > ty ? tx : ty) < 4294967296.0;
+}
+
+static int run_rfdb_tail(const esr_conv_desc* d, bool bf16, hipStream_t st)
+{
+    S16K k;
+    memset(&k, 0, sizeof(k));
+    const int nt = esr_round_up(d->cout, 16) / 16, ot = esr_round_up(d->post_cout, 16) / 16;
+    k.x = static_cast<const char*>(d->in.ptr);
+    k.wp = static_cast<const char*>(d->wpacked);
+    k.bias = reinterpret_cast<const float*>(k.wp + (size_t)4 * 5 * nt * 1024);
+    k.wm32 = k.wp + esr_m32_conv_offset(64, d->cout, 3);
+    k.N = d->n; k.H = d->h; k.W = d->w;
+    k.nchunks = 4;
+    k.in_pitch = d->in.pitch; k.in_coff = d->in.coff;
+    k.slope = d->tail_mid_act == ESR_ACT_LRELU ? d->slope : (d->tail_mid_act == ESR_ACT_RELU ? 0.f : 1.f);
+    k.tw = static_cast<const char*>(d->tail_wpacked);
+    k.cat = static_cast<const char*>(d->tail_cat.ptr);
+    k.cat_pitch = d->tail_cat.pitch; k.cat_coff = d->tail_cat.coff;
+    k.cat_seg_stride = (long long)d->tail_seg_stride16 * 16;
+    k.y0 = static_cast<char*>(d->out0.ptr);
+    k.y0_pitch = d->out0.pitch; k.y0_coff = d->out0.coff;
+    k.cout_store = esr_round_up(d->tail_cout, 8);
+    k.pw1 = static_cast<const char*>(d->post_wpacked);
+    k.pm32 = k.pw1 + esr_m32_post_offset(d->tail_cout, d->post_cout);
+    k.pbias1 = reinterpret_cast<const float*>(k.pw1 + (size_t)2 * 4 * ot * 1024);
+    k.py1 = static_cast<char*>(d->post_out.ptr);
+    k.py1_pitch = d->post_out.pitch; k.py1_coff = d->post_out.coff;
+    k.p1_cout8 = esr_round_up(d->post_cout, 8);
+    k.p1_slope = d->post_act == ESR_ACT_LRELU ? d->slope : (d->post_act == ESR_ACT_RELU ? 0.f : 1.f);
+    k.out_layout = ESR_NHWC;
+    k.tiles_x = (d->w + TILE - 1) / TILE;
+    k.tiles_y = (d->h + 15) / 16;
+    k.magic_x = k.tiles_x > 1 ? (unsigned)((0x100000000ull + k.tiles_x - 1) / k.tiles_x) : 0u;
+    k.magic_y = k.tiles_y > 1 ? (unsigned)((0x100000000ull + k.tiles_y - 1) / k.tiles_y) : 0u;
+    return esr_launch_rfdb_tail(k, bf16, st);
+}
+
 // 1: conv48r_kernel / conv48rp_kernel (one 4-wave block per CU, weights in registers), 4: conv_s16_kernel's two-blocks-per-CU shape (4
 // waves, 16 x 16 tiles), 8: one 8-wave block per CU on 16 x 32 tiles
 int s16_block_waves(const esr_conv_desc* d)
@@ -1082,7 +1142,7 @@ int esr_pack_conv_s16(const float* w, const float* bias, int cin, int cout, int 
                     e = t - from16(q, compute);
                     o[s16_index(nt, pairs, s, tap, oc)] = q;
                     // the same value in v_mfma_f32_32x32x16's fragment order (esr_c64m.hip): fragment (chunk, tap, half), lane 32 h + i, slot j
-                    if (om) om[(((((size_t)(s / 16) * 9 + tap) * 2 + oc / 32) * 64 + ((s % 16) / 8) * 32 + oc % 32) * 8) + s % 8] = q;
+                    if (om) om[(((((size_t)(s / 16) * 9 + tap) * (nt == 4 ? 2 : 1) + oc / 32) * 64 + ((s % 16) / 8) * 32 + oc % 32) * 8) + s % 8] = q;
                 }
             }
         }
@@ -1137,6 +1197,8 @@ int esr_pack_post_s16(const float* w, const float* bias, int cin, int cout, int 
         for (int o = 0; o < cout; ++o) bo[o] = bias[o];
     return ESR_OK;
 }
+
+int esr_conv_tail_supported(const esr_conv_desc* d) { return d && rfdb_tail_takes(d) ? 1 : 0; }
 
 int esr_conv_post_supported(const esr_conv_desc* d)
 {
@@ -1233,7 +1295,8 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     if (d->storage != ESR_STORE_BF16 && d->storage != ESR_STORE_F16) return ESR_ERR_BAD_ARG;
     if (d->compute != (bf16 ? ESR_COMPUTE_BF16 : ESR_COMPUTE_F16)) return ESR_ERR_BAD_ARG;   // operand type = storage type
     if (d->in_layout != ESR_NHWC) return ESR_ERR_UNSUPPORTED;                                  // the NCHW head runs on conv_f32_kernel
-    if (d->tail_wpacked || d->blocked8) return ESR_ERR_UNSUPPORTED;                            // fp32 features
+    if (d->blocked8) return ESR_ERR_UNSUPPORTED;                                               // an fp32 feature
+    if (d->tail_wpacked) return rfdb_tail_takes(d) ? run_rfdb_tail(d, bf16, static_cast<hipStream_t>(hip_stream)) : ESR_ERR_UNSUPPORTED;
     const bool post = d->post_wpacked != nullptr;
     if (d->border_bias && d->out_layout != ESR_NHWC) return ESR_ERR_UNSUPPORTED;
     if (d->border_bias && ((uintptr_t)d->border_bias & 15)) return ESR_ERR_BAD_ARG;       // (staged by 16-byte LDS-DMA pieces, as the packed weights)
@@ -1417,7 +1480,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         k4.wm32 = k.wp + esr_m32_conv_offset(cin_phys, d->cout, 3);
         if (post) {
             k4.pm32 = k.pw1 + esr_m32_post_offset(d->cout, d->post_cout);
-            k4.pbias1 = reinterpret_cast<const float*>(k.pw1 + (size_t)2 * 4 * 2 * 1024);
+            k4.pbias1 = reinterpret_cast<const float*>(k.pw1 + (size_t)2 * 4 * (esr_round_up(d->post_cout, 16) / 16) * 1024);
         }
         const double nt_all = (double)d->n * k4.tiles_x * k4.tiles_y;
         if (nt_all * (k4.tiles_x > k4.tiles_y ? k4.tiles_x : k4.tiles_y) < 4294967296.0) return esr_launch_conv64m(k4, bf16, post, st);

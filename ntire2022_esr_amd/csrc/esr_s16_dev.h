@@ -62,10 +62,15 @@ struct S16K {
     // esr_c64m.hip (v_mfma_f32_32x32x16 family): the weight image in that MFMA's fragment order (appended to the esr_pack_conv_s16 blob), the
     // post 1x1's images likewise (esr_pack_post_s16 blob) and its fp32 bias
     const char* wm32; const char* pm32; const float* pbias1;
+    // rfdb_tail_kernel (esr_conv_desc.tail_* in 16-bit storage): the 1x1's esr_pack_tail_s16 blob, the three concat segments (first one; the
+    // others cat_seg_stride bytes apart), their pitch / first channel
+    const char* tw; const char* cat; int cat_pitch, cat_coff; long long cat_seg_stride;
 };
 
 // esr_c64m.hip: the 64 -> 64 3x3 family on v_mfma_f32_32x32x16 (round 6).  `post`: with one post 1x1 of <= 32 outputs (RFDB c{j}_r + c{j+1}_d)
 int esr_launch_conv64m(const S16K& k, bool bf16, bool post, hipStream_t st);
+// ... and RFDB's c4 -> cat -> c5 -> esa.conv1 in one launch (round 6, ABI v12)
+int esr_launch_rfdb_tail(const S16K& k, bool bf16, hipStream_t st);
 // esr_r16.hip: the register-resident 48-channel / c4 kernels (weights in accumulation registers, one wave per SIMD)
 int esr_launch_conv48rp(const S16K& k, bool bf16, bool lrs, hipStream_t st);
 int esr_launch_conv48r(const S16K& k, bool bf16, int nt, bool ext, int rw, hipStream_t st);

@@ -139,6 +139,24 @@ def pack_post_s16(weight, bias, compute):
     return out
 
 
+def pack_tail_s16(weight, bias, nseg, seg_c, mid_c, compute):
+    """[cout, nseg * seg_c + mid_c(, 1, 1)] fp32 weights of the 1x1 of a 16-bit tail (esr_conv_desc.tail_*, ABI v12: RFDB's c5 over
+    cat(d1, d2, d3, r4)) -> esr_pack_tail_s16 blob (hi / lo fragment images for v_mfma_f32_32x32x16 + fp32 bias)."""
+    lib = L.lib()
+    w = weight.detach().to("cpu", torch.float32).reshape(weight.shape[0], -1).contiguous()
+    cout, kin = w.shape
+    if kin != nseg * seg_c + mid_c:
+        raise L.EsrError("pack_tail_s16: the 1x1 takes nseg * seg_c + mid_c inputs")
+    b = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
+    nbytes = lib.esr_packed_tail_s16_bytes(nseg, seg_c, mid_c, cout)
+    if not nbytes:
+        raise L.EsrError("pack_tail_s16: unsupported shape")
+    out = torch.empty((nbytes + 3) // 4, dtype=torch.float32)
+    L.check(lib.esr_pack_tail_s16(_ptr(w), _ptr(b) if b is not None else None, nseg, seg_c, mid_c, cout,
+                                  L.COMPUTE[compute] if isinstance(compute, str) else compute, _ptr(out), nbytes), "esr_pack_tail_s16")
+    return out
+
+
 def pack_apply_post(w0, b0, w1, b1, store):
     """Weights of the 1x1 chain riding in esr_esa_apply_f32's launch (esr_esa_desc.post_w): w0 [cout0, cin(, 1, 1)] applied to the
     apply result, w1 [cout1, cout0(, 1, 1)] (or None) applied to w0's result -> esr_pack_apply_post blob."""
@@ -605,8 +623,14 @@ class Plan:
             t = o.get("tail")
             if t is not None:
                 d.tail_wpacked = ctypes.c_void_p(weights[t["w"]].data_ptr())
-                d.tail_cat = self._view(t["cat"], base)
-                d.tail_cat_c, d.tail_cout, d.tail_mid_act = t["cat_c"], t["cout"], t.get("mid_act", L.ACT_NONE)
+                if isinstance(t["cat"], Planar):             # 16-bit tail (ABI v12): three dense tensors one stride apart; the 3x3's own width
+                    d.tail_cat = self._view(t["cat"].seg(0), base)
+                    d.tail_seg_stride16 = t["cat"].stride // 16
+                    d.cout = o["cout"]
+                    d.tail_cat_c, d.tail_cout, d.tail_mid_act = t["cat_c"], full_width(o["dst"], t["cout"]), t.get("mid_act", L.ACT_NONE)
+                else:
+                    d.tail_cat = self._view(t["cat"], base)
+                    d.tail_cat_c, d.tail_cout, d.tail_mid_act = t["cat_c"], t["cout"], t.get("mid_act", L.ACT_NONE)
             t = o.get("post")
             if t is not None:
                 psfx = "#post" if (st and not lowres) else ""     # 16-bit storage: esr_pack_post_s16 images
@@ -618,7 +642,10 @@ class Plan:
                     d.post2_wpacked = ctypes.c_void_p(weights[t2["w"] + psfx].data_ptr())
                     d.post2_out = self._view(t2["dst"], base)
                     d.post2_cout = t2["cout"]
-                if psfx and not L.lib().esr_conv_post_supported(ctypes.byref(d)):
+                if psfx and o.get("tail") is not None:
+                    if not L.lib().esr_conv_tail_supported(ctypes.byref(d)):
+                        raise L.EsrError(f"{o['w']}: no fused tail kernel for this shape (the plan should have built separate ops)")
+                elif psfx and not L.lib().esr_conv_post_supported(ctypes.byref(d)):
                     raise L.EsrError(f"{o['w']}: no fused post-chain kernel for this shape (the plan should have built separate ops)")
         return arr, in_idx, out_idx
 
@@ -724,6 +751,7 @@ class HipSRModel(nn.Module):
         self._fuse_esa_lowres = True  # ESA's low-resolution branch as one esr_esa_lowres_f32 op (two launches) instead of 3 .. 8 launches
         self._winograd = True      # fp32 plans: 3x3 convs whose shape qualifies run as Winograd F(2x2, 3x3) (esr_conv_desc.wino_wpacked)
         self._hilo_skip = True     # bf16 plans: the long skip's tensors (`fea`, `out_lr`) as hi + lo pairs (esr_conv_desc.hilo; Plan.hilo_skip)
+        self._fuse_tail = True     # 16-bit RFDN plans: RFDB's c4 -> cat -> c5 -> esa.conv1 as one launch (rfdb_tail_kernel, ABI v12)
         self._fuse_chain = True    # 16-bit plans: a block's 3x3 chain as one esr_conv_chain_s16 launch where a kernel exists (Plan.chain)
         self.use_graphs = True     # forwards of at most GRAPH_MAX_PIXELS input pixels replay a captured HIP graph (esr_graph_launch)
         self._lock = _ModelLock()       # plan / workspace bookkeeping and the pointer patch + enqueue of one forward (see _forward_impl)
@@ -781,6 +809,7 @@ class HipSRModel(nn.Module):
     winograd = property(lambda self: self._winograd, lambda self, v: self._set_flag("_winograd", v))
     hilo_skip = property(lambda self: self._hilo_skip, lambda self, v: self._set_flag("_hilo_skip", v))
     fuse_chain = property(lambda self: self._fuse_chain, lambda self, v: self._set_flag("_fuse_chain", v))
+    fuse_tail = property(lambda self: self._fuse_tail, lambda self, v: self._set_flag("_fuse_tail", v))
 
     def _skip_hilo(self, plan, c):
         """bf16 plans: keep the long skip `upsampler(LR_conv(body) + fea)` in hi + lo pairs?  (c = its channel count; the hi + lo kernels
@@ -1156,12 +1185,15 @@ class HipSRModel(nn.Module):
                 t = o.get("tail")
                 if t is not None:                   # 3x3 -> 1x1 in one kernel: both GEMMs' flops, the 1x1's traffic
                     kern = f"conv_f32_kernel<NT={nt},KS=3,NCHW_IN=0,NW=4,TAIL={(t['cout'] + 15) // 16}>"
+                    if plan.esize == 2:
+                        kern = f"rfdb_tail_kernel<{plan.store}>"
                     if (o["cin"] + 7) // 8 == 6 and t["cat_c"] == 48 and t["cout"] == 64 and o.get("res_mode", L.RES_NONE) in (L.RES_NONE, L.RES_PRE_ACT):
                         kern = f"imdb_tail_kernel<FOLD={int(o['res'] is not None)}>"       # esr_hip.hip: imdb_tail_shape()
-                    k1 = t["cat_c"] + o["cout"]
+                    cat_alg = t.get("cat_c_alg", t["cat_c"])    # logical channels of the concat (16-bit tail: three dense 32-slot tensors of dc)
+                    k1 = cat_alg + o["cout"]
                     flops += 2.0 * npix * k1 * t["cout"]
-                    wb = 4.0 * (o["cin"] * o["cout"] * 9 + k1 * t["cout"])
-                    rd = npix * e_act * (o["cin"] + t["cat_c"] + (t["cout"] if res_read else 0)) + wb
+                    wb = 4.0 * (ca * o["cout"] * 9 + k1 * t["cout"])
+                    rd = npix * e_act * (ca + cat_alg + (t["cout"] if res_read else 0)) + wb
                     wr = float(npix * e_act * t["cout"])
                 t = o.get("post")
                 if t is not None:                   # + the 1x1 of the activated output, stored by the same launch

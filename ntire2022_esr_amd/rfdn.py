@@ -8,7 +8,7 @@ and the four block outputs as 56-wide slices of one 224-wide buffer, so neither 
 residual + LeakyReLU} x3, 3x3 50->25 + LeakyReLU, 1x1 c5 over the concat, ESA.
 """
 from . import _lib as L
-from .engine import INPUT, OUTPUT, HipSRModel
+from .engine import INPUT, OUTPUT, HipSRModel, Planar
 from .rlfn import FP, _lowres, _pad8
 
 
@@ -93,6 +93,9 @@ class RFDN(HipSRModel):
         res = (lambda v: dict(res=v, res_mode=L.RES_PRE_ACT)) if self.block_residual else (lambda v: {})
         fused_post = (48 < nf <= 64 and 16 < dc <= 32) if plan.esize == 4 else ((nf + 15) // 16 in (3, 4) and 16 < dc <= 32)
         # 16-bit modes: block 1's first distillation conv (c1_d of fea) rides in the head convolution's epilogue
+        # the fused block tail needs rfdb_tail_kernel's shapes (esr_conv_tail_supported has the last word in Plan.finalize)
+        fused_tail = (self.fuse_tail and plan.esize == 2 and fused_post and planar and 48 < nf <= 64 and DP == 32 and f <= 16 and FP == 16
+                      and plan.n * ((plan.w + 15) // 16) * ((plan.h + 15) // 16) >= 256)
         head_d = plan.esize == 2 and fused_post
         plan.conv('fea_conv', INPUT, fea2 if hl else fea, self.in_nc, nf, post=dict(w='B1.c1_d', dst=cs(0), cout=dc, act=L.ACT_LRELU) if head_d else None,
                   hilo=L.HILO_OUT if hl else 0)
@@ -115,8 +118,17 @@ class RFDN(HipSRModel):
                 plan.conv(b + 'c2_r', r1, r2, nf, nf, **res(r1), **act)
                 plan.conv(b + 'c3_d', r2, cs(2), nf, dc, k=1, **act)
             plan.conv(b + 'c3_r', r2, r1, nf, nf, **res(r2), **act)
-            plan.conv(b + 'c4', r1, cs(3), nf, dc, **act)
-            if plan.esize == 2 and (nf + 15) // 16 in (3, 4) and f <= 16:
+            if fused_tail:
+                # round 6 (ABI v12): c4 -> cat(d1, d2, d3, r4) -> c5 -> esa.conv1 in ONE launch (rfdb_tail_kernel; block.py:161-164, :117):
+                # r4 stays in registers, d1 .. d3 are read once, v and esa.conv1's map are the only stores
+                plan.conv(b + 'c4', r1, v, nf, dc, tail=dict(w=b + 'c5#tail', cat=Planar(cat.segs[:3]), cat_c=3 * DP, cat_c_alg=3 * dc, cout=nf,
+                                                             mid_act=L.ACT_LRELU),
+                          post=dict(w=b + 'esa.conv1', dst=c1, cout=f, act=L.ACT_NONE))
+            else:
+                plan.conv(b + 'c4', r1, cs(3), nf, dc, **act)
+            if fused_tail:
+                pass
+            elif plan.esize == 2 and (nf + 15) // 16 in (3, 4) and f <= 16:
                 # 16-bit storage: esa.conv1 rides in c5's epilogue on the fp32 tile (one launch less per block)
                 plan.conv(b + 'c5', cat, v, 4 * DP, nf, k=1, cin_alg=4 * dc, post=dict(w=b + 'esa.conv1', dst=c1, cout=f, act=L.ACT_NONE))
             else:
@@ -151,6 +163,11 @@ class RFDN(HipSRModel):
         return cin_map
 
     def _extra_pack(self, packed, device):
+        if self._store() != "f32" and 48 < self.nf <= 64 and self.dc <= 32:
+            from .engine import pack_tail_s16    # c5 over cat(d1, d2, d3, r4) for rfdb_tail_kernel
+            for k in range(1, 5):
+                leaf = self._leaf(f'B{k}.c5')
+                packed[f'B{k}.c5#tail'] = pack_tail_s16(leaf.weight, leaf.bias, 3, self.dc, self.dc, self._store()).to(device)
         if self._store() != "f32":               # c1_d of blocks 2..4 as the post of the previous block's ESA apply launch
             from .engine import pack_apply_post
             if L.lib().esr_esa_apply_post_supported(self.nf, self.dc, 0):
@@ -168,6 +185,9 @@ class RFDN(HipSRModel):
         r = super()._counted_convs(plan, o)
         if o["kind"] == "apply" and not self.esa_conv_f:
             return r[1:]                         # no conv_f call in the reference graph
+        if o["kind"] == "conv" and o.get("tail") is not None and o["w"].endswith('.c4'):      # the fused block tail: c4, c5, esa.conv1
+            return [(o["cin"], o["cout"], 3, plan.npix, L.ACT_LRELU), (self.dc * 4, o["tail"]["cout"], 1, plan.npix, L.ACT_NONE),
+                    (o["tail"]["cout"], o["post"]["cout"], 1, plan.npix, L.ACT_NONE)]
         if o["kind"] == "conv" and o["w"].endswith('.c5'):
             return [(self.dc * 4, o["cout"], 1, plan.npix, o["act"])]
         if o["kind"] == "conv" and o["w"] == 'c.0':

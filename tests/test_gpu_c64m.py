@@ -104,3 +104,95 @@ def test_conv64m_is_the_kernel_that_runs():
     m.disable_profiling()
     assert any(k.startswith("conv64m_kernel<true, true>") for k in names), names
     assert any(k.startswith("conv64m_kernel<true, false>") for k in names), names
+
+
+def _hilo(w, dt):
+    """the 16-bit hi + lo value of an fp32 weight (what the 1x1 images hold)"""
+    hi = w.to(dt).float()
+    return (hi + (w - hi).to(dt).float()).double()
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
+@pytest.mark.parametrize("n,hw,nf,dc,f", [(1, (339, 510), 50, 25, 16), (4, (128, 144), 50, 25, 16), (2, (250, 203), 64, 32, 16), (32, (64, 64), 50, 25, 12)])
+def test_rfdb_tail_matches_fp64_reference(compute, n, hw, nf, dc, f):
+    """rfdb_tail_kernel (ABI v12, esr_conv_desc.tail_* in 16-bit storage): r4 = round(lrelu(c4(r3))), v = c5 . [d1 d2 d3 r4], c1 = conv1 . v in one
+    launch (rfdn_baseline/block.py:161-164, :117), against fp64 on the same 16-bit inputs and the blobs' effective weights."""
+    from ntire2022_esr_amd import _lib as L
+    from ntire2022_esr_amd.engine import pack_conv_s16, unpack_conv_s16, pack_tail_s16, pack_post_s16
+    dt = DT[compute]
+    g = torch.Generator().manual_seed(n + hw[0] + nf)
+    r3 = F.pad(torch.randn(n, *hw, nf, generator=g), (0, 64 - nf)).to(dt).to(DEV)
+    ds = F.pad(torch.randn(3, n, *hw, dc, generator=g), (0, 32 - dc)).to(dt).to(DEV)
+    w4, b4 = torch.randn(dc, nf, 3, 3, generator=g) * 0.1, torch.randn(dc, generator=g)
+    w5, b5 = torch.randn(nf, 4 * dc, generator=g) * 0.15, torch.randn(nf, generator=g)
+    wc, bc = torch.randn(f, nf, generator=g) * 0.2, torch.randn(f, generator=g)
+    blob4 = pack_conv_s16(w4, b4, compute, cin_phys=64)
+    w4e, _ = unpack_conv_s16(blob4, nf, dc, 3, compute, cin_phys=64)
+    blob5 = pack_tail_s16(w5, b5, 3, dc, dc, compute).to(DEV)
+    blobc = pack_post_s16(wc, bc, compute).to(DEV)
+    blob4 = blob4.to(DEV)
+    v = torch.full((n, *hw, 64), 7.0, dtype=dt, device=DEV)
+    c1 = torch.full((n, *hw, 16), 7.0, dtype=dt, device=DEV)
+    d = L.ConvDesc()
+    d.n, d.h, d.w, d.cin, d.cout, d.ksize = n, hw[0], hw[1], nf, dc, 3
+    d.in_layout = d.out_layout = L.NHWC
+    d.storage = d.compute = L.STORE[compute]
+    d.act, d.slope = L.ACT_NONE, 0.05
+    d.inp = L.View(ctypes.c_void_p(r3.data_ptr()), 64, 0)
+    d.out0 = L.View(ctypes.c_void_p(v.data_ptr()), 64, 0)
+    d.wpacked = ctypes.c_void_p(blob4.data_ptr())
+    d.tail_wpacked = ctypes.c_void_p(blob5.data_ptr())
+    d.tail_cat = L.View(ctypes.c_void_p(ds.data_ptr()), 32, 0)
+    d.tail_cat_c, d.tail_cout, d.tail_mid_act = 96, nf, L.ACT_LRELU
+    d.tail_seg_stride16 = ds[0].numel() * 2 // 16
+    d.post_wpacked = ctypes.c_void_p(blobc.data_ptr())
+    d.post_out = L.View(ctypes.c_void_p(c1.data_ptr()), 16, 0)
+    d.post_cout, d.post_act = f, L.ACT_NONE
+    assert L.lib().esr_conv_tail_supported(ctypes.byref(d)) == 1
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # fp64 reference
+    x = r3[..., :nf].permute(0, 3, 1, 2).double()
+    r4 = F.leaky_relu(F.conv2d(x, w4e.double().to(DEV), b4.double().to(DEV), padding=1), 0.05)
+    r4q = r4.to(dt).double()                                                       # the tensor the separate launches store
+    cat = torch.cat([ds[j, ..., :dc].permute(0, 3, 1, 2).double() for j in range(3)] + [r4q], 1)
+    vref = torch.einsum("oc,nchw->nohw", _hilo(w5, dt).to(DEV), cat) + b5.double().to(DEV)[None, :, None, None]
+    for _ in range(3):
+        L.check(L.lib().esr_conv2d_f32(ctypes.byref(d), st), "tail")
+        torch.cuda.synchronize()
+        got = v.permute(0, 3, 1, 2)[:, :nf].double()
+        # r4 sits on rounding boundaries now and then: a flipped r4 value moves v by |w5| x one step of r4
+        extra = 0.6 * float(w5.abs().max()) * (2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11) * float(r4.abs().max())
+        bad = int(((got - vref).abs() > _tol(vref, dt, extra)).sum())
+        assert bad == 0, (bad, float((got - vref).abs().max()))
+        if compute == "bf16":
+            cref = torch.einsum("oc,nchw->nohw", _hilo(wc, dt).to(DEV), vref) + bc.double().to(DEV)[None, :, None, None]
+        else:
+            cref = torch.einsum("oc,nchw->nohw", wc.to(dt).double().to(DEV), got) + bc.double().to(DEV)[None, :, None, None]
+        gc = c1.permute(0, 3, 1, 2)[:, :f].double()
+        badc = int(((gc - cref).abs() > _tol(cref, dt, 2e-4 + extra * float(wc.abs().max()) * 8)).sum())
+        assert badc == 0, (badc, float((gc - cref).abs().max()))
+    assert torch.all(v[..., (nf + 7) // 8 * 8:] == 7.0) and torch.all(v[..., nf:(nf + 7) // 8 * 8] == 0)
+    assert torch.all(c1[..., f:(f + 7) // 8 * 8] == 0)
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
+def test_rfdn_with_and_without_the_fused_block_tail(compute):
+    """model.fuse_tail: the same network with RFDB's c4 / c5 + esa.conv1 as two launches or as rfdb_tail_kernel -- same arithmetic on the same
+    rounded tensors in another accumulation order: the x4 outputs agree far inside the storage noise of the network"""
+    from ntire2022_esr_amd.registry import select_model
+    m = select_model(0, torch.device(DEV))[0]
+    m.set_compute(compute)
+    x = (torch.rand(1, 3, 339, 510, generator=torch.Generator().manual_seed(3)) * 255.0).to(DEV)
+    y1 = m(x).clone()
+    names = set()
+    m.enable_profiling(1); m(x); torch.cuda.synchronize(); m.collect_profile(); m(x); torch.cuda.synchronize()
+    names = {o["kernel"] for o in m.collect_profile()}
+    m.disable_profiling()
+    assert any(k.startswith("rfdb_tail_kernel") for k in names), names
+    m.fuse_tail = False
+    y0 = m(x).clone()
+    m.fuse_tail = True
+    mse = float(((y1 - y0) ** 2).mean())
+    psnr = 10.0 * torch.log10(torch.tensor(255.0 ** 2 / max(mse, 1e-12)))
+    assert float(psnr) > (62.0 if compute == "bf16" else 80.0), float(psnr)
+    assert torch.equal(m(x), y1)

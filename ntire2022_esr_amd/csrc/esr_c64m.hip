@@ -497,7 +497,9 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
     }
 #endif
     // the last tile's last row pair: the same operations, back to back
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");     // (asm MFMAs: hipcc does not pad MFMA -> VALU reads of their results)
+    // (asm MFMAs: hipcc does not pad MFMA -> VALU reads of their results.  The wait states carry the accumulators as operands: a volatile asm with
+    // a memory clobber orders nothing that lives in registers, and hipcc did hoist the reads above it in rfdb_tail_kernel<fp16>)
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory");
     static_for<M_SLOTS>([&](auto s_) __attribute__((always_inline)) { micro(std::integral_constant<int, 1>{}, std::integral_constant<int, RW - 2>{}, s_); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the trailing zero-fill DMA must not outlive the block)
 }
@@ -642,7 +644,6 @@ __global__ __launch_bounds__(256, 1) void rfdb_tail_kernel(const S16K p)
     const float slope = p.slope, p1s = p.p1_slope;
     const size_t y_img = (size_t)p.H * p.W * p.y0_pitch * 2, p1_img = (size_t)p.H * p.W * p.py1_pitch * 2, cat_img = (size_t)p.H * p.W * p.cat_pitch * 2;
     const unsigned rowb = (unsigned)p.W * (unsigned)p.y0_pitch * 2u, rowb1 = (unsigned)p.W * (unsigned)p.py1_pitch * 2u, rowbc = (unsigned)p.W * (unsigned)p.cat_pitch * 2u;
-    const unsigned seg1 = (unsigned)p.cat_seg_stride, seg2 = 2u * (unsigned)p.cat_seg_stride;
 
     f32x16 acc4[2], acc5[2], d1;
 #pragma unroll
@@ -681,8 +682,9 @@ __global__ __launch_bounds__(256, 1) void rfdb_tail_kernel(const S16K p)
     };
     auto load_d = [&](auto rp_, auto ks_) __attribute__((always_inline)) {
         constexpr int rp = decltype(rp_)::value, ks = decltype(ks_)::value, sg = ks >> 1, u = ks & 1;
-        const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.cat) + (size_t)d_n * cat_img, 0, (int)cat_img, 0x00020000);
-        dq[rp & 1][ks] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(cr, d_v + (unsigned)(2 * rp) * rowbc + (unsigned)(u * 32), sg == 0 ? 0u : (sg == 1 ? seg1 : seg2), 0));
+        // (the segment's offset goes into the descriptor's base: an soffset takes part in the range check on this part -- segments 1 / 2 read zeros)
+        const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.cat) + (size_t)d_n * cat_img + (size_t)sg * (size_t)p.cat_seg_stride, 0, (int)cat_img, 0x00020000);
+        dq[rp & 1][ks] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(cr, d_v + (unsigned)(2 * rp) * rowbc + (unsigned)(u * 32), 0, 0));
     };
     auto load_lo5 = [&](int ks) __attribute__((always_inline)) {
         lo5[0] = *reinterpret_cast<const i32x4*>(w5lo + (ks * 2) * 1024);
@@ -707,18 +709,24 @@ __global__ __launch_bounds__(256, 1) void rfdb_tail_kernel(const S16K p)
                 else { rbv[b >> 1].z = (int)x; rbv[b >> 1].w = (int)y; }
             }
         } else if constexpr (q >= TQ_B5 && q < TQ_D5) {                            // c5's bias
+            // (hipcc gives acc5 the registers of the c4 accumulator that has just been packed.  The fp16 flush once had
+            // `v_cvt_pk_f16_f32 v39, v2, v3` directly in front of `v_mfma .. v[0:15], .., .., 0` and packed the MFMA's result in every lane;
+            // the sequence alone is clean -- tools/r06/mfma_war_probe.hip -- so the cause is not pinned; with two wait states here and the
+            // scheduling barriers between the flush's operations the kernel is right)
+            asm volatile("s_nop 1" : "+v"(rbv[1]));
             mfma_m0<BF16>(acc5[q - TQ_B5], a_b5[q - TQ_B5], b_ones);
         } else if constexpr (q >= TQ_D5 && q < TQ_GAP1) {                          // c5: k steps 0 .. 5 on d1 .. d3, 6 / 7 on r4
             constexpr int ks = (q - TQ_D5) / 5, m = (q - TQ_D5) % 5;
             const i32x4& B = ks < 6 ? dq[par][ks < 6 ? ks : 0] : rbv[ks >= 6 ? ks - 6 : 0];
-            if constexpr (m == 0) { if constexpr (PLO) load_lo5(ks); }
+            // (w5 = hi + lo in fp16 as well: the 1x1 launch this replaces carries the residual in its second tap slot)
+            if constexpr (m == 0) load_lo5(ks);
             else if constexpr (m == 1) mfma_m<BF16, true>(acc5[0], w5h[2 * ks], B);
             else if constexpr (m == 2) mfma_m<BF16, true>(acc5[1], w5h[2 * ks + 1], B);
-            else if constexpr (m == 3) { if constexpr (PLO) mfma_m<BF16, false>(acc5[0], lo5[0], B); }
-            else { if constexpr (PLO) mfma_m<BF16, false>(acc5[1], lo5[1], B); }
+            else if constexpr (m == 3) mfma_m<BF16, false>(acc5[0], lo5[0], B);
+            else mfma_m<BF16, false>(acc5[1], lo5[1], B);
         } else if constexpr ((q >= TQ_GAP1 && q < TQ_V) || (q >= TQ_GAP2 && q < TQ_C1)) {
             // (asm MFMAs: hipcc pads no read of their results; in the stream the main MFMAs of three k steps lie in between)
-            if constexpr (FLUSH && (q == TQ_GAP1 || q == TQ_GAP2)) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+            if constexpr (FLUSH && q == TQ_GAP1) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc5[0]), "+v"(acc5[1]) :: "memory");
             if constexpr (q == TQ_GAP1 + 1) load_pa(0);
             if constexpr (q == TQ_GAP1 + 2) d1 = mfma_b<BF16>(a_bc, b_ones, f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
         } else if constexpr (q >= TQ_V && q < TQ_GAP2) {                           // v: 8 blocks; 13 operations per block pair
@@ -830,9 +838,10 @@ __global__ __launch_bounds__(256, 1) void rfdb_tail_kernel(const S16K p)
         n = nn; x0 = nx0; y0 = ny0;
     }
     // the last tile's last row pair
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc4[1]) :: "memory");     // (operands: see conv64m_kernel's flush)
     static_for<TQ_END - TQ_R4>([&](auto i_) __attribute__((always_inline)) {
         top(std::integral_constant<int, 1>{}, std::integral_constant<int, RW - 2>{}, std::integral_constant<int, TQ_R4 + decltype(i_)::value>{}, std::true_type{});
+        __builtin_amdgcn_sched_barrier(0);
     });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -972,7 +972,6 @@ static bool rfdb_tail_takes(const esr_conv_desc* d)
     if (!d->post_out.ptr || (d->post_out.pitch & 7) || (d->post_out.coff & 7) || d->post_out.coff + esr_round_up(d->post_cout, 8) > d->post_out.pitch) return false;
     const double px = (double)d->h * d->w * 2.0, lim = 2147483647.0 - 1048576.0;
     if (px * d->in.pitch >= lim || px * d->tail_cat.pitch >= lim || px * d->out0.pitch >= lim || px * d->post_out.pitch >= lim) return false;
-    if (2.0 * 16.0 * d->tail_seg_stride16 >= 4294967295.0) return false;                    // (the third segment's offset travels in a 32-bit scalar)
     const long tx = (d->w + TILE - 1) / TILE, ty = (d->h + 15) / 16;
     if ((long)d->n * tx * ty < 256) return false;
     return (double)d->n * tx * ty * (tx > ty ? tx : ty) < 4294967296.0;

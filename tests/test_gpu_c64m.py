@@ -161,7 +161,7 @@ def test_rfdb_tail_matches_fp64_reference(compute, n, hw, nf, dc, f):
         torch.cuda.synchronize()
         got = v.permute(0, 3, 1, 2)[:, :nf].double()
         # r4 sits on rounding boundaries now and then: a flipped r4 value moves v by |w5| x one step of r4
-        extra = 0.6 * float(w5.abs().max()) * (2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11) * float(r4.abs().max())
+        extra = 1.2 * float(w5.abs().max()) * (2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11) * float(r4.abs().max())
         bad = int(((got - vref).abs() > _tol(vref, dt, extra)).sum())
         assert bad == 0, (bad, float((got - vref).abs().max()))
         if compute == "bf16":
@@ -177,14 +177,16 @@ def test_rfdb_tail_matches_fp64_reference(compute, n, hw, nf, dc, f):
 
 @pytest.mark.parametrize("compute", ["bf16", "f16"])
 def test_rfdn_with_and_without_the_fused_block_tail(compute):
-    """model.fuse_tail: the same network with RFDB's c4 / c5 + esa.conv1 as two launches or as rfdb_tail_kernel -- same arithmetic on the same
-    rounded tensors in another accumulation order: the x4 outputs agree far inside the storage noise of the network"""
+    """model.fuse_tail: the same network with RFDB's c4 / c5 + esa.conv1 as two launches or as rfdb_tail_kernel.  The fused form keeps c5's
+    weights as hi + lo and v's low part for conv1 (the launches: one 16-bit value each), so the two differ by storage noise; measured against the
+    fp32 engine the fused network must not be the worse one"""
     from ntire2022_esr_amd.registry import select_model
     m = select_model(0, torch.device(DEV))[0]
-    m.set_compute(compute)
     x = (torch.rand(1, 3, 339, 510, generator=torch.Generator().manual_seed(3)) * 255.0).to(DEV)
+    m.set_compute("f32")
+    y32 = m(x).clone()
+    m.set_compute(compute)
     y1 = m(x).clone()
-    names = set()
     m.enable_profiling(1); m(x); torch.cuda.synchronize(); m.collect_profile(); m(x); torch.cuda.synchronize()
     names = {o["kernel"] for o in m.collect_profile()}
     m.disable_profiling()
@@ -192,7 +194,10 @@ def test_rfdn_with_and_without_the_fused_block_tail(compute):
     m.fuse_tail = False
     y0 = m(x).clone()
     m.fuse_tail = True
-    mse = float(((y1 - y0) ** 2).mean())
-    psnr = 10.0 * torch.log10(torch.tensor(255.0 ** 2 / max(mse, 1e-12)))
-    assert float(psnr) > (62.0 if compute == "bf16" else 80.0), float(psnr)
+
+    def psnr(a, b):
+        return float(10.0 * torch.log10(255.0 ** 2 / ((a - b) ** 2).mean().clamp_min(1e-12)))
+    fused, separate, between = psnr(y1, y32), psnr(y0, y32), psnr(y1, y0)
+    assert fused > separate - 0.5, (fused, separate, between)
+    assert between > (50.0 if compute == "bf16" else 64.0), (fused, separate, between)
     assert torch.equal(m(x), y1)

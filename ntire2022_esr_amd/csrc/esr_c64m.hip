@@ -136,14 +136,16 @@ __device__ __forceinline__ i32x4 bias_frag(float b, bool first_half)
     return first_half ? i32x4{(int)x, (int)y, 0, 0} : i32x4{0, 0, 0, 0};
 }
 
-template <bool BF16, bool POST>
+template <bool BF16, bool POST, bool HL>
 __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
 {
+    static_assert(!HL || (BF16 && !POST), "hi + lo residual / output: bf16, no post chain");
     constexpr int RW = M_RW, NG = M_NG, TAPS = M_TAPS, STAGE = M_STAGE, ROWB = M_ROWB, PIXB = M_PIXB, PPW = M_PPW;
     constexpr int NREG = POST ? 3 * TAPS * 2 : M_NFRAG;    // fragments in registers; the first min(NREG, 64) in accumulation registers
     constexpr int NAG = NREG < 64 ? NREG : 64;
     constexpr int NVG = NREG - NAG;
-    constexpr int SPP = POST ? 6 : 4;                      // stores per row pair
+    constexpr int SPP = POST ? 6 : (HL ? 8 : 4);           // stores per row pair
+    constexpr int S_MAIN = HL ? 10 : 2;                    // slot of the first k step's first MFMA (HL: 2 bias + 8 residual MFMAs in front)
     constexpr unsigned ONE = BF16 ? 0x3f80u : 0x3c00u;
     constexpr bool PLO = BF16;                             // the post 1x1 sees hi + lo activations and weights (bf16), hi only (fp16)
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int j0 = pn - 16 * q - 8 * hh;               // k slot of this lane's half that carries output row pn
-        const bool on = p.res_in != 0 && j0 >= 0 && j0 < 8;
+        const bool on = (HL || p.res_in != 0) && j0 >= 0 && j0 < 8;
         const unsigned v = ONE << ((j0 & 1) * 16);
         a_id[q] = i32x4{(on && (j0 >> 1) == 0) ? (int)v : 0, (on && (j0 >> 1) == 1) ? (int)v : 0, (on && (j0 >> 1) == 2) ? (int)v : 0, (on && (j0 >> 1) == 3) ? (int)v : 0};
     }
@@ -255,6 +257,33 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
     const size_t p1_img = POST ? (size_t)p.H * p.W * p.py1_pitch * 2 : 0;
     const unsigned rowb1 = POST ? (unsigned)p.W * (unsigned)p.py1_pitch * 2u : 0u;
 
+    // HL: the residual is a hi + lo pair of ANOTHER tensor (the long skip: LR_conv's `fea`).  A lane's B operand of the selection MFMA of chunk c
+    // is 16 bytes of ITS pixel (channels 16 c + 8 h ..) -- one buffer_load_dwordx4 per chunk and part straight into registers, issued behind k
+    // steps 4 .. 11 of the pair's own stream, consumed in front of the next pair's first k step behind an exact s_waitcnt.  (asm loads: hipcc
+    // would guard builtin loads with waits that do not count the DMA pieces, i.e. wait for the next tile's pieces as well)
+    const size_t r_img = HL ? (size_t)p.H * p.W * p.res_pitch * 2 : 0;
+    const unsigned rowbr = HL ? (unsigned)p.W * (unsigned)p.res_pitch * 2u : 0u;
+    i32x4 rq[8];                         // [chunk][hi | lo]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rq[i] = i32x4{0, 0, 0, 0};
+    unsigned r_v = OOB;
+    int r_n = 0;
+    auto res_offsets = [&](int nn_, int x0_, int y0_) __attribute__((always_inline)) {
+        const bool inx = x0_ + px < p.W;
+        const unsigned pix = (unsigned)((y0_ + wv * RW + pe) * p.W + x0_ + px);
+        r_v = inx ? (pix * (unsigned)p.res_pitch + (unsigned)p.res_coff) * 2u + (unsigned)hh * 16u : OOB;
+        r_n = nn_;
+    };
+    auto load_res = [&](auto rp_, auto i_) __attribute__((always_inline)) {
+        constexpr int rp = decltype(rp_)::value, i = decltype(i_)::value, c = i >> 1, part = i & 1;
+        // (rows below the image fall outside the descriptor's range: zeros; the part's offset goes into the base -- an soffset is range-checked)
+        const i32x4 rr = make_rsrc(p.res + (size_t)r_n * r_img + (part ? (size_t)p.res_lo_stride : (size_t)0), r_img);
+        const unsigned voff = r_v + (unsigned)(2 * rp) * rowbr + (unsigned)(c * 32);
+        i32x4 t;                         // (asm operands of a lambda must be its own locals; the assignment is a renaming)
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(t) : "v"(voff), "s"(rr) : "memory");
+        rq[i] = t;
+    };
+
     f32x16 acc[2][2];                    // [row pair & 1][output half]
     f32x16 d1;                           // the post 1x1's accumulators (32 outputs x the pair's 32 pixels)
 #pragma unroll
@@ -306,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
             if constexpr (POST && blk == 0) d1 = mfma_b<BF16>(a_pb, b_ones, f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
         } else if constexpr (u == 2) {
             bs[sl].x = (int)pack2<BF16>(A[4 * b], A[4 * b + 1]); bs[sl].y = (int)pack2<BF16>(A[4 * b + 2], A[4 * b + 3]);
-            if constexpr (POST && PLO) unpack2<BF16>((unsigned)bs[sl].x, tv0, tv1);
+            if constexpr ((POST || HL) && PLO) unpack2<BF16>((unsigned)bs[sl].x, tv0, tv1);
             if constexpr (POST && !PLO) { bs[sl].z = 0; bs[sl].w = 0; }
         } else if constexpr (u == 3) {
             if constexpr (PLO) {
@@ -334,6 +363,14 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
         if constexpr ((C64M_ABL & 8) != 0)
             __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)s0.x, (int)s1.x, (int)s0.y, (int)s1.y}, yr, e_lin + (unsigned)((P * 2 + r / 2) * 1024), 0, 0);
         else
+        __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)s0.x, (int)s1.x, (int)s0.y, (int)s1.y}, yr, e_v[P] + (unsigned)r * rowb, 0, 0);
+    };
+    // HL: the low parts of the same block pair, `hilo_stride` bytes behind (S16K.y1)
+    auto store_lo_op = [&](auto P_, auto r_) __attribute__((always_inline)) {
+        constexpr int P = decltype(P_)::value, r = decltype(r_)::value;
+        const u32x2 s0 = __builtin_amdgcn_permlane32_swap((unsigned)bs[0].z, (unsigned)bs[1].z, false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane32_swap((unsigned)bs[0].w, (unsigned)bs[1].w, false, false);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y1 + (size_t)e_n * y_img, 0, (int)y_img, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)s0.x, (int)s1.x, (int)s0.y, (int)s1.y}, yr, e_v[P] + (unsigned)r * rowb, 0, 0);
     };
     auto post_act_op = [&](auto pb_, auto m_) __attribute__((always_inline)) {
@@ -370,6 +407,15 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
             } else if constexpr (q == 71 || q == 72) {
                 post_store_op(std::integral_constant<int, q - 71>{}, r_);
             }
+        } else if constexpr (HL) {
+            // 5 + 5 operations per block pair (activation, rounding, the low parts), its two stores
+            if constexpr (q >= 0 && q < 48) {
+                constexpr int P = q / 12, w = q % 12;
+                if constexpr (w < 5) block_op(par_, std::integral_constant<int, 2 * P>{}, std::integral_constant<int, w>{});
+                else if constexpr (w < 10) block_op(par_, std::integral_constant<int, 2 * P + 1>{}, std::integral_constant<int, w - 5>{});
+                else if constexpr (w == 10) store_op(std::integral_constant<int, P>{}, r_);
+                else store_lo_op(std::integral_constant<int, P>{}, r_);
+            }
         } else {
             if constexpr (q >= 0 && q < 28) {
                 constexpr int P = q / 7, w = q % 7;
@@ -385,6 +431,8 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
         if constexpr ((C64M_ABL & 4) != 0) {
         } else if constexpr (POST) {
             if constexpr (s >= 4) op(par_, r_, std::integral_constant<int, s - 4>{});
+        } else if constexpr (HL) {
+            if constexpr (s >= 10) op(par_, r_, std::integral_constant<int, s - 10>{});        // (behind the residual's MFMAs)
         } else {
             if constexpr (s >= 4 && ((s - 4) & 1) == 0) op(par_, r_, std::integral_constant<int, (s - 4) / 2>{});
         }
@@ -449,10 +497,23 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
             mfma_m0<BF16>(acc[par][1], a_bias[1], b_ones);
             micro(PrevPar{}, PrevRow{}, std::integral_constant<int, 1>{});
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (HL) {
+                // slots 2 .. 9: the FINISHED pair's residual (chunk c, hi | lo) onto its output channels 16 c .. 16 c + 15.  Younger than its last
+                // load (behind k step 11 of its stream) are that stream's stores behind slot 33 (4) and, in a tile's first pair, DMA pieces 4 .. 11
+                i32x4 q0 = rq[0], q1 = rq[1], q2 = rq[2], q3 = rq[3], q4 = rq[4], q5 = rq[5], q6 = rq[6], q7 = rq[7];
+                asm volatile("s_waitcnt vmcnt(%8)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7) : "n"(rp == 1 ? 12 : 4) : "memory");
+                rq[0] = q0; rq[1] = q1; rq[2] = q2; rq[3] = q3; rq[4] = q4; rq[5] = q5; rq[6] = q6; rq[7] = q7;
+                static_for<8>([&](auto i_) __attribute__((always_inline)) {
+                    constexpr int i = decltype(i_)::value, c = i >> 1;
+                    mfma_m<BF16, false>(acc[par ^ 1][c >> 1], a_id[c & 1], rq[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if constexpr (rp == 0) res_offsets(n, x0, y0);         // (this tile's pixels: both pairs' loads)
+            }
             static_for<NG>([&](auto g_) __attribute__((always_inline)) {
                 constexpr int g = decltype(g_)::value;
                 constexpr int c = g / TAPS, t = g % TAPS, L = rp * NG + g, cs = L & 3;
-                constexpr int s0 = 2 + 2 * g + (g > 4) + (g > 13) + (g > 22) + (g > 31);
+                constexpr int s0 = HL ? S_MAIN + 2 * g : 2 + 2 * g + (g > 4) + (g > 13) + (g > 22) + (g > 31);
                 if constexpr (L + AHEAD < 2 * NG) read_b(std::integral_constant<int, L + AHEAD>{});
                 if constexpr (L + 2 < 2 * NG) read_a(std::integral_constant<int, L + 2>{});
                 __builtin_amdgcn_sched_barrier(0);
@@ -464,7 +525,8 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
                     micro(PrevPar{}, PrevRow{}, std::integral_constant<int, s0 + hf>{});
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                if constexpr (t == 4) {
+                if constexpr (HL && g >= 4 && g < 12) load_res(rp_tag, std::integral_constant<int, g - 4>{});
+                if constexpr (t == 4 && !HL) {
                     // the residual == input: this chunk's 16 channels of the centre pixel onto output channels 16 c .. 16 c + 15
                     mfma_m<BF16, false>(acc[par][c >> 1], a_id[c & 1], b[cs]);
                     micro(PrevPar{}, PrevRow{}, std::integral_constant<int, s0 + 2>{});
@@ -481,7 +543,8 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
 #ifdef C64M_TRACE4
         const unsigned long long t4_a = __builtin_readcyclecounter();
 #endif
-        if constexpr ((C64M_ABL & 32) == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(m_tail_stores(POST, C64M_SPREAD)) : "memory");      // (C64M_ABL & 32: no wait -- timing only)
+        // (HL: the second pair's 8 residual loads and 8 stores)
+        if constexpr ((C64M_ABL & 32) == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HL ? 16 : m_tail_stores(POST, C64M_SPREAD)) : "memory");      // (C64M_ABL & 32: no wait -- timing only)
         if constexpr ((C64M_ABL & 64) == 0) __builtin_amdgcn_s_barrier();                                   // (C64M_ABL & 64: no barrier -- timing only)
 #ifdef C64M_TRACE4
         t4_wait += __builtin_readcyclecounter() - t4_a;
@@ -499,12 +562,22 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
     // the last tile's last row pair: the same operations, back to back
     // (asm MFMAs: hipcc does not pad MFMA -> VALU reads of their results.  The wait states carry the accumulators as operands: a volatile asm with
     // a memory clobber orders nothing that lives in registers, and hipcc did hoist the reads above it in rfdb_tail_kernel<fp16>)
+    if constexpr (HL) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rq[0]), "+v"(rq[1]), "+v"(rq[2]), "+v"(rq[3]), "+v"(rq[4]), "+v"(rq[5]), "+v"(rq[6]), "+v"(rq[7]) :: "memory");
+        static_for<8>([&](auto i_) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_)::value, c = i >> 1;
+            mfma_m<BF16, false>(acc[1][c >> 1], a_id[c & 1], rq[i]);
+        });
+    }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory");
-    static_for<M_SLOTS>([&](auto s_) __attribute__((always_inline)) { micro(std::integral_constant<int, 1>{}, std::integral_constant<int, RW - 2>{}, s_); });
+    static_for<M_SLOTS>([&](auto s_) __attribute__((always_inline)) {
+        micro(std::integral_constant<int, 1>{}, std::integral_constant<int, RW - 2>{}, s_);
+        __builtin_amdgcn_sched_barrier(0);
+    });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the trailing zero-fill DMA must not outlive the block)
 }
 
-template <bool BF16, bool POST>
+template <bool BF16, bool POST, bool HL>
 int launch_conv64m(const S16K& k, hipStream_t st)
 {
     constexpr int LDS = POST ? M_LDS_POST : M_LDS_PLAIN;
@@ -512,7 +585,7 @@ int launch_conv64m(const S16K& k, hipStream_t st)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
     if (!attr_set[dev].load(std::memory_order_relaxed)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64m_kernel<BF16, POST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64m_kernel<BF16, POST, HL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             esr_set_err("hipFuncSetAttribute(conv64m_kernel, MaxDynamicSharedMemorySize)", e);
             return ESR_ERR_LAUNCH;
@@ -521,8 +594,8 @@ int launch_conv64m(const S16K& k, hipStream_t st)
     }
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int grid = ntiles < 256 ? ntiles : 256;
-    esr_note_kernel("conv64m_kernel<%s, %s>", esr_tf(BF16), esr_tf(POST));
-    hipLaunchKernelGGL((conv64m_kernel<BF16, POST>), dim3(grid), dim3(256), LDS, st, k);
+    esr_note_kernel("conv64m_kernel<%s, %s, %s>", esr_tf(BF16), esr_tf(POST), esr_tf(HL));
+    hipLaunchKernelGGL((conv64m_kernel<BF16, POST, HL>), dim3(grid), dim3(256), LDS, st, k);
     return esr_check_launch("conv64m_kernel launch");
 }
 
@@ -878,11 +951,15 @@ int esr_launch_rfdb_tail(const S16K& k, bool bf16, hipStream_t st)
 namespace {
 }  // namespace
 
-int esr_launch_conv64m(const S16K& k, bool bf16, bool post, hipStream_t st)
+int esr_launch_conv64m(const S16K& k, bool bf16, bool post, bool hl, hipStream_t st)
 {
     if (!k.wm32 || (post && (!k.pm32 || !k.pbias1))) return ESR_ERR_BAD_ARG;
-    if (bf16) return post ? launch_conv64m<true, true>(k, st) : launch_conv64m<true, false>(k, st);
-    return post ? launch_conv64m<false, true>(k, st) : launch_conv64m<false, false>(k, st);
+    if (hl) {
+        if (!bf16 || post || !k.res || k.res_lo_stride <= 0 || !k.y1) return ESR_ERR_BAD_ARG;
+        return launch_conv64m<true, false, true>(k, st);
+    }
+    if (bf16) return post ? launch_conv64m<true, true, false>(k, st) : launch_conv64m<true, false, false>(k, st);
+    return post ? launch_conv64m<false, true, false>(k, st) : launch_conv64m<false, false, false>(k, st);
 }
 
 // ---- host side: where the 32x32x16 images live inside the packed blobs ----------------------------------------------------------------------

@@ -953,6 +953,18 @@ static bool conv48rl_takes(const esr_conv_desc* d)
     return (long)d->n * ((d->w + TILE - 1) / TILE) * ((d->h + 15) / 16) >= 256;
 }
 
+// conv64m_kernel<bf16, plain, HL>'s descriptors: the LR conv of a 64-channel network on hi + lo pairs (RFDN: LR_conv(out_B) + out_fea,
+// rfdn_baseline/RFDN.py:50-52) -- 64 -> 64 (4 chunks, 4 tiles), residual pair from HBM added before the activation, output pair, no post
+// chain -- from 256 tiles of 16 x 16
+static bool conv64ml_takes(const esr_conv_desc* d)
+{
+    const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
+    if (d->storage != ESR_STORE_BF16 || d->hilo != (ESR_HILO_RES | ESR_HILO_OUT) || d->hilo_stride <= 0) return false;
+    if (d->ksize != 3 || nchunks != 4 || nt != 4 || d->out_layout != ESR_NHWC || d->in_seg_stride != 0 || d->post_wpacked || d->border_bias) return false;
+    if (d->res_mode != ESR_RES_PRE_ACT || !d->res.ptr || d->act == ESR_ACT_GELU || (d->split > 0 && d->split < d->cout)) return false;
+    return (long)d->n * ((d->w + TILE - 1) / TILE) * ((d->h + 15) / 16) >= 256;
+}
+
 // rfdb_tail_kernel's descriptors (ABI v12, esr_c64m.hip): a 3x3 over 64 physical input channels with <= 32 outputs whose rounded result is the
 // last 32 slots of a 1x1 over three more dense 32-slot tensors, <= 64 outputs stored and fed (unrounded) to a post 1x1 of <= 16 outputs; no
 // residual, no activation on the 1x1; from 256 tiles of 16 x 16
@@ -1016,7 +1028,7 @@ static int run_rfdb_tail(const esr_conv_desc* d, bool bf16, hipStream_t st)
 // waves, 16 x 16 tiles), 8: one 8-wave block per CU on 16 x 32 tiles
 int s16_block_waves(const esr_conv_desc* d)
 {
-    if (conv48r_takes(d) || conv48rp_takes(d) || conv64r_takes(d) || conv48rl_takes(d) || conv48rq_takes(d) || conv64rq_takes(d)) return 1;
+    if (conv48r_takes(d) || conv48rp_takes(d) || conv64r_takes(d) || conv48rl_takes(d) || conv48rq_takes(d) || conv64rq_takes(d) || conv64ml_takes(d)) return 1;
     const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
     const bool res_hbm = d->res_mode != ESR_RES_NONE && !s16_res_is_input(d);
     if (d->ksize != 3 || nt != 3 || d->border_bias || d->post_wpacked || res_hbm || d->out_layout != ESR_NHWC || d->in_seg_stride != 0) return 8;
@@ -1440,6 +1452,14 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         const double nt_all = (double)d->n * kp.tiles_x * kp.tiles_y;
         if (nt_all * (kp.tiles_x > kp.tiles_y ? kp.tiles_x : kp.tiles_y) < 4294967296.0) return esr_launch_conv48rp(kp, true, true, st);
     }
+    if (hilo && conv64ml_takes(d)) {
+        S16K k4 = k;
+        k4.tiles_y = (d->h + 15) / 16;
+        k4.magic_y = k4.tiles_y > 1 ? (unsigned)((0x100000000ull + k4.tiles_y - 1) / k4.tiles_y) : 0u;
+        k4.wm32 = k.wp + esr_m32_conv_offset(cin_phys, d->cout, 3);
+        const double nt_all = (double)d->n * k4.tiles_x * k4.tiles_y;
+        if (nt_all * (k4.tiles_x > k4.tiles_y ? k4.tiles_x : k4.tiles_y) < 4294967296.0) return esr_launch_conv64m(k4, true, false, true, st);
+    }
     if (hilo && post) {
         // the head with block 1's first distillation 1x1 in its epilogue (RFDN: 4 main tiles, BSRN: 3; 2 post tiles) + the hi + lo store
         if (pnt2 != 0 || pnt1 != 2 || (nt != 3 && nt != 4)) return ESR_ERR_UNSUPPORTED;
@@ -1482,7 +1502,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
             k4.pbias1 = reinterpret_cast<const float*>(k.pw1 + (size_t)2 * 4 * (esr_round_up(d->post_cout, 16) / 16) * 1024);
         }
         const double nt_all = (double)d->n * k4.tiles_x * k4.tiles_y;
-        if (nt_all * (k4.tiles_x > k4.tiles_y ? k4.tiles_x : k4.tiles_y) < 4294967296.0) return esr_launch_conv64m(k4, bf16, post, st);
+        if (nt_all * (k4.tiles_x > k4.tiles_y ? k4.tiles_x : k4.tiles_y) < 4294967296.0) return esr_launch_conv64m(k4, bf16, post, false, st);
     }
     if (conv48rq_takes(d)) {
         S16K k4 = k;

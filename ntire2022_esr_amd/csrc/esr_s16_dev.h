@@ -67,8 +67,9 @@ struct S16K {
     const char* tw; const char* cat; int cat_pitch, cat_coff; long long cat_seg_stride;
 };
 
-// esr_c64m.hip: the 64 -> 64 3x3 family on v_mfma_f32_32x32x16 (round 6).  `post`: with one post 1x1 of <= 32 outputs (RFDB c{j}_r + c{j+1}_d)
-int esr_launch_conv64m(const S16K& k, bool bf16, bool post, hipStream_t st);
+// esr_c64m.hip: the 64 -> 64 3x3 family on v_mfma_f32_32x32x16 (round 6).  `post`: with one post 1x1 of <= 32 outputs (RFDB c{j}_r + c{j+1}_d);
+// `hl` (bf16, no post): a hi + lo residual pair of another tensor added before the activation, hi + lo output (the LR conv behind the long skip)
+int esr_launch_conv64m(const S16K& k, bool bf16, bool post, bool hl, hipStream_t st);
 // ... and RFDB's c4 -> cat -> c5 -> esa.conv1 in one launch (round 6, ABI v12)
 int esr_launch_rfdb_tail(const S16K& k, bool bf16, hipStream_t st);
 // esr_r16.hip: the register-resident 48-channel / c4 kernels (weights in accumulation registers, one wave per SIMD)

@@ -1199,7 +1199,8 @@ class HipSRModel(nn.Module):
                 if t is not None:                   # + the 1x1 of the activated output, stored by the same launch
                     if nw == 8:
                         kern = kern[:-1] + f",POST={(t['cout'] + 15) // 16}>"
-                    flops += 2.0 * npix * o["cout"] * t["cout"]
+                    post_in = o["cout"] if o.get("tail") is None else o["tail"]["cout"]      # (behind a tail: the 1x1 of the tail's result)
+                    flops += 2.0 * npix * post_in * t["cout"]
                     wr += npix * e_act * t["cout"]
                     t2 = t.get("post2")
                     if t2 is not None:

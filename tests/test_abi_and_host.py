@@ -292,6 +292,74 @@ def test_op_costs_count_a_residual_that_is_the_input_once():
         assert c["stored_bytes"] >= (c["read_bytes"] + c["write_bytes"]) * 0.9999, c["name"]
 
 
+def test_pack_tail_s16_fragment_order():
+    """ABI v12 (csrc/esr_c64m.hip, rfdb_tail_kernel): esr_pack_tail_s16 lays RFDB's c5 (rfdn_baseline/block.py:156, 1x1 over
+    cat(d1, d2, d3, r4)) out as 8 k steps x 2 output halves x (hi, lo) fragments of 1 KB + 64 fp32 biases.  Lane 32 h + i, element j of k step
+    2 s + u holds slot 16 u + 8 h + j of segment s (the B operand is 16 bytes of the stored pixel); k steps 6, 7 hold channel
+    8 (2 t + (j >> 2)) + 4 h + (j & 3) of the 3x3's result (two of its D blocks).  hi + lo = the fp32 weight to hi + lo accuracy, pads zero."""
+    from ntire2022_esr_amd import _lib as L
+    from ntire2022_esr_amd.engine import pack_tail_s16
+    g = torch.Generator().manual_seed(5)
+    for mode, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        for nf, dc in ((50, 25), (64, 32)):
+            w, b = torch.randn(nf, 4 * dc, generator=g) * 0.3, torch.randn(nf, generator=g)
+            blob = pack_tail_s16(w, b, 3, dc, dc, mode)
+            assert blob.numel() * 4 == 32 * 1024 + 256 == L.lib().esr_packed_tail_s16_bytes(3, dc, dc, nf)
+            raw = blob.numpy().view(np.uint16)
+            img = torch.from_numpy(raw[:32 * 512].astype(np.int16)).view(dt).float().reshape(8, 2, 2, 2, 32, 8)     # [ks][half][hi | lo][h][i][j]
+            hi = torch.zeros(64, 4 * 32); lo = torch.zeros(64, 4 * 32)                                             # columns: 4 segments of 32 slots
+            for ks in range(8):
+                for h in range(2):
+                    for j in range(8):
+                        col = (ks // 2) * 32 + 16 * (ks & 1) + 8 * h + j if ks < 6 else 96 + 8 * (2 * (ks - 6) + (j >> 2)) + 4 * h + (j & 3)
+                        hi[:, col] = img[ks, :, 0, h, :, j].reshape(64)
+                        lo[:, col] = img[ks, :, 1, h, :, j].reshape(64)
+            for sgm in range(4):
+                wh = w[:, sgm * dc:(sgm + 1) * dc]
+                assert torch.equal(hi[:nf, 32 * sgm:32 * sgm + dc], wh.to(dt).float())
+                assert torch.equal(lo[:nf, 32 * sgm:32 * sgm + dc], (wh - wh.to(dt).float()).to(dt).float())
+                assert torch.all(hi[:, 32 * sgm + dc:32 * sgm + 32] == 0) and torch.all(lo[:, 32 * sgm + dc:32 * sgm + 32] == 0)
+            assert torch.all(hi[nf:] == 0) and torch.all(lo[nf:] == 0)
+            bias = torch.from_numpy(blob.numpy()[32 * 256:].copy())
+            assert torch.equal(bias[:nf], b) and torch.all(bias[nf:] == 0)
+    assert L.lib().esr_packed_tail_s16_bytes(2, 25, 25, 50) == 0 and L.lib().esr_packed_tail_s16_bytes(3, 33, 25, 50) == 0
+    assert L.lib().esr_packed_tail_s16_bytes(3, 25, 25, 65) == 0
+    with pytest.raises(L.EsrError):
+        pack_tail_s16(torch.zeros(50, 99), None, 3, 25, 25, "bf16")
+
+
+def test_rfdn_plan_folds_the_block_tail_into_one_op():
+    """in RFDN's 16-bit plans RFDB's c4 -> cat -> c5 -> esa.conv1 (rfdn_baseline/block.py:154-157, 76) is ONE op (c4 with a
+    16-bit tail + post) when the launch fills the device; model.fuse_tail = False keeps c4 and c5 (+ conv1) as two ops.  Either way the cost
+    model counts the same convolutions, and the fused op reads r3 + d1 .. d3 and writes v + c1_ -- r4 never reaches memory."""
+    from ntire2022_esr_amd import RFDN
+    from ntire2022_esr_amd.engine import Plan
+    m = RFDN()
+    m.set_compute("bf16")
+    plans = {}
+    for fuse in (True, False):
+        m.fuse_tail = fuse
+        plan = Plan(32, 256, 256, m._store())
+        m._build_plan(plan, 3)
+        plans[fuse] = {c["name"]: c for c in m.op_costs(plan)}
+    fused, separate = plans[True], plans[False]
+    assert "B1.c5" in separate and "B1.c5" not in fused and len(separate) == len(fused) + 4
+    npx = 32 * 256 * 256
+    c4 = fused["B1.c4"]
+    w = 4.0 * (25 * 50 * 9 + 50 * 100)                       # (a post 1x1's weights: stored figure only, as for c1_r above)
+    # 100 B of r3 + 3 x 50 B of d1 .. d3 in, 100 B of v + 24 B of c1_ (f = 12) out per pixel
+    assert abs((c4["read_bytes"] + c4["write_bytes"] - w) / npx - (100 + 150 + 100 + 24)) < 1e-6
+    assert abs(c4["flops"] - separate["B1.c4"]["flops"] - separate["B1.c5"]["flops"]) < 1.0
+    assert abs(sum(c["flops"] for c in fused.values()) - sum(c["flops"] for c in separate.values())) < 1.0
+    both = separate["B1.c4"]["read_bytes"] + separate["B1.c4"]["write_bytes"] + separate["B1.c5"]["read_bytes"] + separate["B1.c5"]["write_bytes"]
+    assert abs((both - w) / npx - (100 + 50 + 50 + 150 + 100 + 24)) < 1e-6          # the two launches write r4 and read it back
+    # one image of 64 x 64 does not fill the device: the plan keeps the two launches
+    m.fuse_tail = True
+    small = Plan(1, 64, 64, m._store())
+    m._build_plan(small, 3)
+    assert "B1.c5" in {c["name"] for c in m.op_costs(small)}
+
+
 def test_isa_lint():
     """tools/lint_isa.py over EVERY translation unit of the library (cross-compiled to gfx950 assembly, cached under build/isa; about a
     minute, no GPU): (1) no packed-fp32 instruction with an op_sel that reads a high dword -- the gfx950 erratum behind round 3's

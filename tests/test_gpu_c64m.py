@@ -201,3 +201,48 @@ def test_rfdn_with_and_without_the_fused_block_tail(compute):
     assert fused > separate - 0.5, (fused, separate, between)
     assert between > (50.0 if compute == "bf16" else 64.0), (fused, separate, between)
     assert torch.equal(m(x), y1)
+
+
+@pytest.mark.parametrize("n,c,hw,act", [(1, 50, (339, 510), 0), (2, 64, (250, 203), 1), (32, 50, (64, 64), 0), (5, 50, (100, 177), 0)])
+def test_conv64m_hilo_lr_conv_matches_fp64_reference(n, c, hw, act):
+    """conv64m_kernel<bf16, plain, HL>: the LR conv behind the long skip on hi + lo pairs (RFDN: LR_conv(out_B) + out_fea, rfdn_baseline/RFDN.py:50-52)
+    -- the residual pair of ANOTHER tensor as eight selection MFMAs in front of the next row pair's stream, the fp32 result stored as a hi + lo
+    pair.  hi + lo is the fp64 result to two bf16 numbers; every image alone (fewer than 256 tiles: conv_s16_kernel's HILO instantiation) agrees
+    to the same bound; rows / columns beyond the image and pad channels stay untouched / zero."""
+    from ntire2022_esr_amd import _lib as L, ops
+    from ntire2022_esr_amd.engine import pack_conv_s16, unpack_conv_s16
+    g = torch.Generator().manual_seed(n * 100 + c + hw[0])
+    cp = 64
+    x = torch.randn(n, c, *hw, generator=g).to(torch.bfloat16)
+    r32 = torch.randn(n, c, *hw, generator=g) * 3.0
+    w, b = torch.randn(c, c, 3, 3, generator=g) * 0.1, torch.randn(c, generator=g)
+    blob = pack_conv_s16(w, b, "bf16", cin_phys=cp).to(DEV)
+    weff, _ = unpack_conv_s16(blob.cpu(), c, c, 3, "bf16", cin_phys=cp)
+    xin = F.pad(x.permute(0, 2, 3, 1), (0, cp - c)).contiguous().to(DEV)
+    t = F.pad(r32.permute(0, 2, 3, 1), (0, cp - c))
+    hi = t.to(torch.bfloat16)
+    rin = torch.stack([hi, (t - hi.float()).to(torch.bfloat16)]).contiguous().to(DEV)
+    d = L.ConvDesc()
+    d.n, d.h, d.w, d.cin, d.cout, d.ksize = n, hw[0], hw[1], c, c, 3
+    d.in_layout = d.out_layout = L.NHWC
+    d.storage, d.act, d.res_mode, d.hilo, d.hilo_stride = L.STORE["bf16"], act, L.RES_PRE_ACT, L.HILO_RES | L.HILO_OUT, 4096
+    d.res = L.View(ctypes.c_void_p(rin.data_ptr()), cp, 0)
+    assert L.lib().esr_conv_block_waves(ctypes.byref(d)) == 1
+    kw = dict(cin=c, packed=blob, act=act, res_mode=L.RES_PRE_ACT, hilo=L.HILO_RES | L.HILO_OUT)
+    rsum = (rin[0].double() + rin[1].double()).permute(0, 3, 1, 2)[:, :c]
+    conv = F.conv2d(x.double().to(DEV), weff.double().to(DEV), b.double().to(DEV), padding=1) + rsum
+    ref = F.leaky_relu(conv, 0.05) if act == 1 else conv
+    tol = ref.abs() * 2.0 ** -15 + 3e-5 * max(1.0, float(ref.abs().max()))
+    for _ in range(2):
+        y = ops.conv2d(xin, w, b, res=rin, **kw)
+        torch.cuda.synchronize()
+        assert tuple(y.shape) == (2, n, *hw, cp)
+        got = (y[0].double() + y[1].double()).permute(0, 3, 1, 2)[:, :c]
+        assert int(((got - ref).abs() > tol).sum()) == 0, float(((got - ref).abs() - tol).max())
+        assert bool((y[1].float().abs() <= y[0].float().abs() * 2.0 ** -7 + 1e-30).all())          # the low parts are remainders of the high ones
+        assert torch.all(y[..., (c + 7) // 8 * 8:] == 0) or c == 64
+    if n > 1 and n <= 5:
+        y1 = ops.conv2d(xin[:1].contiguous(), w, b, res=rin[:, :1].contiguous(), **kw)             # the general kernel
+        g1 = (y1[0].double() + y1[1].double()).permute(0, 3, 1, 2)[:, :c]
+        assert int(((g1 - ref[:1]).abs() > tol[:1]).sum()) == 0
+        assert float((g1 - got[:1]).abs().max()) <= 2.0 * float(tol[:1].max())

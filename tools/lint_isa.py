@@ -10,8 +10,8 @@ Rule 3 -- prologues and wait states (round 5, LAB_NOTES.md 10.8): hipcc keeps ON
     load into the predicated store that uses it, and pads every dependent v_pk_fma_f32 with an s_nop.  Guards for the kernels that were fixed:
     esa_apply_mfma_kernel -- at most 3 waits for an empty load queue in front of the first barrier (24 before); esa_s2pool16_kernel -- every
     16-byte patch load in front of the first LDS store of the patch; conv48r / conv48rq_kernel with the GELU compiled in -- < 160 s_nop (510).
-Rule 4 -- conv64m_kernel (esr_c64m.hip) and rlfb_chain_kernel (esr_chain.hip): no scratch access, no dynamic register indexing -- their
-    s_waitcnt vmcnt(N) count every vector-memory instruction, and conv64m's DMA pieces leave m0 changed.
+Rule 4 -- conv64m_kernel, rfdb_tail_kernel (esr_c64m.hip) and rlfb_chain_kernel (esr_chain.hip): no scratch access, no dynamic register
+    indexing -- their s_waitcnt vmcnt(N) count every vector-memory instruction, and the DMA pieces leave m0 changed.
 Rule 2 -- conv_s16_kernel's wait-count arithmetic (tools/lint_s16_isa.py, unchanged): no scratch / spills, no copies out of registers an
     in-flight asm load writes.
 
@@ -109,7 +109,7 @@ def lint_prologues(path, unit):
         # rule 4 (round 6): kernels that count their vector-memory instructions (exact s_waitcnt vmcnt) or leave m0 changed behind a DMA piece
         # must not spill (a scratch access is a VMEM instruction the count does not know) and must not index registers dynamically (the only
         # sequences in which hipcc keeps a value of its own in m0)
-        if (unit == "esr_c64m.hip" and "conv64m_kernel" in name) or (unit == "esr_chain.hip" and "rlfb_chain_kernel" in name):
+        if (unit == "esr_c64m.hip" and ("conv64m_kernel" in name or "rfdb_tail_kernel" in name)) or (unit == "esr_chain.hip" and "rlfb_chain_kernel" in name):
             bad = [t for t in ins if t.startswith(("scratch_", "s_set_gpr_idx", "s_movrel", "v_movrel"))]
             if bad:
                 problems.append(f"{unit}: {name}: {len(bad)} scratch / dynamic register index instruction(s), first: {bad[0]}")

@@ -16,7 +16,7 @@ through esr_conv_desc.border_bias (a 16-row table indexed by which sides of the 
 import torch
 
 from . import _lib as L
-from .engine import INPUT, OUTPUT, HipSRModel, pack_apply_post, pack_conv, pack_conv_s16, pack_head_s16
+from .engine import INPUT, OUTPUT, HipSRModel, Planar, pack_apply_post, pack_conv, pack_conv_s16, pack_head_s16
 from .rlfn import FP, _lowres, _pad8
 
 
@@ -106,6 +106,11 @@ class BSRN(HipSRModel):
                 w, bias, table = self._merged_bsconv(self._leaf(path + '.pw'), self._leaf(path + '.dw'))
                 packed[path + '#bs3#s16'] = pack_conv_s16(w, bias, self._store()).to(device)
                 packed[path + '#bs3#border'] = table.to(device)
+            if 32 < C <= 48 and self.dc <= 32:               # c5 over cat(d1, d2, d3, r4) for the fused block tail
+                from .engine import pack_tail_s16
+                for k in range(1, self.nb + 1):
+                    leaf = self._leaf(f'B{k}.c5')
+                    packed[f'B{k}.c5#tail'] = pack_tail_s16(leaf.weight, leaf.bias, 3, self.dc, self.dc, self._store()).to(device)
         pw = self._leaf('fea_conv.pw')
         w = pw.weight.detach().float().reshape(C, 4, ic).sum(dim=1)           # [C,4*ic] -> [C,ic]: input replicated x4
         w3 = torch.zeros(C, ic, 3, 3)
@@ -176,6 +181,10 @@ class BSRN(HipSRModel):
         else:
             plan.conv('fea_conv.pw', INPUT, t, self.in_nc, C, counted=False)
             plan.dwconv('fea_conv.dw', t, fea, C)
+        # ESDB's tail -- c4 (BSConvU + GELU) -> cat(d1, d2, d3, r4) -> c5 -> esa.conv1, team18_bsrn.py:165-171, :109 -- as ONE launch
+        # (rfdb_tail_kernel<.., 3, true>, ABI v12): r4 never reaches memory; from 256 tiles of 16 x 16
+        fused_tail = (self.fuse_tail and merged and 32 < C <= 48 and DP == 32 and dc <= 32 and f <= 16 and FP == 16
+                      and plan.n * ((plan.w + 15) // 16) * ((plan.h + 15) // 16) >= 256)
         cur = fea
         for k in range(1, nb + 1):
             b = f'B{k}.'
@@ -196,11 +205,17 @@ class BSRN(HipSRModel):
                     # pointwise result stays in LDS (team18_bsrn.py:150-163)
                     plan.bsconv(b + f'c{j}_r.pw', b + f'c{j}_r.dw', rin, rout, C, C, res=rin, res_mode=L.RES_PRE_ACT,
                                 distill=dict(w=b + f'c{j}_d', dst=cs(j - 1), cout=dc, act=L.ACT_GELU), **g)
-            if merged:
+            if fused_tail:
+                bs3(b + 'c4', r1, v, C, dc,
+                    tail=dict(w=b + 'c5#tail', cat=Planar(cat.segs[:3]), cat_c=3 * DP, cat_c_alg=3 * dc, cout=C, mid_act=L.ACT_GELU),
+                    post=dict(w=b + 'esa.conv1', dst=c1, cout=f, act=L.ACT_NONE))
+            elif merged:
                 bs3(b + 'c4', r1, cs(3), C, dc, **g)
             else:
                 plan.bsconv(b + 'c4.pw', b + 'c4.dw', r1, cs(3), C, dc, **g)
-            if plan.esize == 2 and (C + 15) // 16 in (3, 4) and f <= 16:
+            if fused_tail:
+                pass
+            elif plan.esize == 2 and (C + 15) // 16 in (3, 4) and f <= 16:
                 # 16-bit storage: esa.conv1 rides in c5's epilogue on the fp32 tile (one launch less per block)
                 plan.conv(b + 'c5', cat, v, 4 * DP if merged else 4 * dc, C, k=1, counted=False, cin_alg=4 * dc,
                           post=dict(w=b + 'esa.conv1', dst=c1, cout=f, act=L.ACT_NONE))
@@ -260,7 +275,7 @@ class BSRN(HipSRModel):
             nlin = 1 + (o["distill"] is not None)
             return 9 * o["cout"] * plan.n * h * w + nlin * plan.n * h * h, o["cout"] * plan.n * h * w, 1
         if o["kind"] == "conv" and o.get("bs_of") is not None:           # a BSConvU run as a dense 3x3: one Linear + one depthwise Conv2d
-            nlin = 1 + (o.get("post") is not None)                        # (+ the next distillation Linear in its epilogue)
+            nlin = 1 + (o.get("post") is not None) + (o.get("tail") is not None)     # (+ the Linear(s) riding in its launch)
             return 9 * o["cout"] * plan.n * h * w + nlin * plan.n * h * h, o["cout"] * plan.n * h * w, 1
         if o["kind"] == "conv" and not o.get("counted", True):
             return (1 + (o.get("post") is not None)) * plan.n * h * h, 0, 0      # a Linear call (+ the one in its epilogue)

@@ -615,22 +615,28 @@ int launch_conv64m(const S16K& k, hipStream_t st)
 // 87 MFMAs per pair (37 + 34 + 16; fp16: 63), five stores, six loads; the separate launches moved 608 bytes per pixel, this one 480.
 constexpr int T_OFF_W5LO = 2 * M_STAGE;                   // c5's low-part fragments [ks][half]: 16 KB
 constexpr int T_OFF_C1 = T_OFF_W5LO + 16 * 1024;          // esa.conv1's images [step][hi | lo]: 16 KB
-constexpr int T_LDS = T_OFF_C1 + M_POST_IMG;
-constexpr int T_SPREAD = 2, T_FIRST = 8;                  // the next tile's DMA piece i behind k step T_FIRST + T_SPREAD * i of the FIRST pair
-constexpr int T_OPS = 4;                                  // epilogue operations per k step
-static_assert(T_LDS <= LDS_LIMIT && T_FIRST + T_SPREAD * (M_PPW - 1) < M_NG, "LDS map / the pieces fit the first pair");
+constexpr int T_OFF_BT = T_OFF_C1 + M_POST_IMG;           // GB: c4's border-bias table [16][32] fp32: 2 KB
+constexpr int T_LDS = T_OFF_BT + 2048;
+constexpr int T_FIRST = 8;                                // the next tile's DMA piece i behind k step T_FIRST + t_spread(NCH) * i of the FIRST pair
+constexpr int t_spread(int nch) { return nch == 4 ? 2 : 1; }
+constexpr int t_ops(int nch) { return nch == 4 ? 4 : 6; }                 // epilogue operations per k step (36 | 27 k steps per pair)
+static_assert(T_LDS <= LDS_LIMIT && T_FIRST + t_spread(4) * (M_PPW - 1) < 4 * M_TAPS && T_FIRST + t_spread(3) * (M_PPW - 1) < 3 * M_TAPS, "LDS map / the pieces fit the first pair");
 // the epilogue's operation list (index q); see `top` in the kernel
 constexpr int TQ_WAIT = 0, TQ_LOAD = 1, TQ_R4 = 7, TQ_B5 = 19, TQ_D5 = 21, TQ_R5 = 51, TQ_GAP1 = 61, TQ_V = 73, TQ_GAP2 = 125, TQ_C1 = 133, TQ_END = 136;
-static_assert(TQ_END <= T_OPS * M_NG, "the epilogue fits the main stream's k steps");
-constexpr int t_step_of(int q) { return q / T_OPS; }
+static_assert(TQ_END <= t_ops(4) * 4 * M_TAPS && TQ_END <= t_ops(3) * 3 * M_TAPS, "the epilogue fits the main stream's k steps");
 // stores: v's four at the end of every second block of the V phase, conv1's at TQ_C1 + 2
 constexpr int t_store_q(int i) { return i < 4 ? TQ_V + 13 * i + 12 : TQ_C1 + 2; }
-constexpr int t_stores_behind_step(int g) { int n = 0; for (int i = 0; i < 5; ++i) n += t_step_of(t_store_q(i)) > g; return n; }
+constexpr int t_stores_behind_step(int g, int tops) { int n = 0; for (int i = 0; i < 5; ++i) n += t_store_q(i) / tops > g; return n; }
 
-template <bool BF16>
+// NCH = 3, GB (round 6, last): ESDB's tail (team18_bsrn.py:165-171) -- c4 is a BSConvU run as a dense 3x3 over 48 channels (three chunks: 27 k
+// steps per pair, six epilogue operations behind each; the LDS pixel keeps its 10 slots, 6 used) with the border-bias table of the merged
+// BSConvU added to r4 in front of its GELU (the table in LDS, row = which sides of the pixel lie outside, row 0 = zeros: no branch).
+template <bool BF16, int NCH, bool GB>
 __global__ __launch_bounds__(256, 1) void rfdb_tail_kernel(const S16K p)
 {
-    constexpr int RW = M_RW, NG = M_NG, TAPS = M_TAPS, STAGE = M_STAGE, ROWB = M_ROWB, PIXB = M_PIXB, PPW = M_PPW;
+    static_assert((NCH == 4 && !GB) || (NCH == 3 && GB), "RFDB's tail | ESDB's tail");
+    constexpr int RW = M_RW, TAPS = M_TAPS, NG = NCH * TAPS, STAGE = M_STAGE, ROWB = M_ROWB, PIXB = M_PIXB, PPW = M_PPW;
+    constexpr int T_OPS = t_ops(NCH), T_SPREAD = t_spread(NCH);
     constexpr unsigned ONE = BF16 ? 0x3f80u : 0x3c00u;
     constexpr bool PLO = BF16;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -647,6 +653,7 @@ __global__ __launch_bounds__(256, 1) void rfdb_tail_kernel(const S16K p)
         dma_glb16(smem_lds + (unsigned)(T_OFF_W5LO + pc * 1024), p.tw + (size_t)((ks * 2 + half) * 2 + 1) * 1024 + lane * 16);
     }
     for (int pc = wv; pc < M_POST_IMG / 1024; pc += 4) dma_glb16(smem_lds + (unsigned)(T_OFF_C1 + pc * 1024), p.pm32 + (size_t)pc * 1024 + lane * 16);
+    if (GB && wv < 2) dma_glb16(smem_lds + (unsigned)(T_OFF_BT + wv * 1024), reinterpret_cast<const char*>(p.border) + (size_t)wv * 1024 + lane * 16);
     i32x4 wa4[NG], w5h[16];
 #pragma unroll
     for (int f = 0; f < NG; ++f) wa4[f] = *reinterpret_cast<const i32x4*>(p.wm32 + (size_t)f * 1024 + lane * 16);
@@ -671,7 +678,7 @@ __global__ __launch_bounds__(256, 1) void rfdb_tail_kernel(const S16K p)
         const unsigned sl = (unsigned)((wv + 4 * i) * 64 + lane);
         const unsigned row = sl / (unsigned)M_ROWSL, rem = sl - row * (unsigned)M_ROWSL;
         const unsigned lx = rem / (unsigned)M_LSL, part = rem - lx * (unsigned)M_LSL;
-        const bool real = part < 8u && lx < (unsigned)M_TH && row < (unsigned)M_THY && (i < PPW - 1 || wv + 4 * i < M_NPIECES);
+        const bool real = part < (unsigned)(2 * NCH) && lx < (unsigned)M_TH && row < (unsigned)M_THY && (i < PPW - 1 || wv + 4 * i < M_NPIECES);
         rel[i] = real ? (row * (unsigned)p.W + lx) * (unsigned)p.in_pitch * 2u + part * 16u : OOB;
         edge |= (row == 0u ? 1u << i : 0u) | (lx == 0u ? 1u << (13 + i) : 0u);
         lxp[i / 6] |= (lx < 31u ? lx : 31u) << (5 * (i % 6));
@@ -691,7 +698,7 @@ __global__ __launch_bounds__(256, 1) void rfdb_tail_kernel(const S16K p)
             const unsigned row = sl / (unsigned)M_ROWSL, rem = sl - row * (unsigned)M_ROWSL;
             const unsigned lx = rem / (unsigned)M_LSL, part = rem - lx * (unsigned)M_LSL;
             const int gy = y0 - 1 + (int)row, gx = x0 - 1 + (int)lx;
-            const bool ok = part < 8u && lx < (unsigned)M_TH && row < (unsigned)M_THY && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const bool ok = part < (unsigned)(2 * NCH) && lx < (unsigned)M_TH && row < (unsigned)M_THY && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             const unsigned voff = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff) * 2u + part * 16u : OOB;
             dma_buf16(smem_lds + (unsigned)(pc * 1024), voff, make_rsrc(p.x + (size_t)n * img_bytes, img_bytes), 0u);
         }
@@ -727,6 +734,8 @@ __global__ __launch_bounds__(256, 1) void rfdb_tail_kernel(const S16K p)
 #pragma unroll
         for (int b_ = 0; b_ < 6; ++b_) dq[a][b_] = i32x4{0, 0, 0, 0};
     i32x4 rbv[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};     // r4 rounded: k steps 6, 7 of c5
+    unsigned bt_o[2] = {(unsigned)T_OFF_BT, (unsigned)T_OFF_BT};       // GB: [pair & 1] the lane's row of the border table (+ 16 h bytes)
+    f32x4 btv = {0.f, 0.f, 0.f, 0.f};
     i32x4 bs[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};      // v's blocks: rounded (x, y) | low parts (z, w)
     i32x4 lo5[2], pa[2][2];
     uint2 pq[2];
@@ -774,9 +783,16 @@ __global__ __launch_bounds__(256, 1) void rfdb_tail_kernel(const S16K p)
         if constexpr (q >= TQ_R4 && q < TQ_B5) {                                   // r4: activation, rounding -> rbv
             constexpr int b = (q - TQ_R4) / 3, m = (q - TQ_R4) % 3;
             f32x16& A = acc4[par];
-            if constexpr (m == 0) { A[4 * b] = act1(A[4 * b], slope); A[4 * b + 1] = act1(A[4 * b + 1], slope); }
+            if constexpr (GB) {
+                // block b = channels 8 b + 4 h .. + 3 of the lane's pixel: + the table row, GELU (the polynomial of the other 16-bit kernels)
+                if constexpr (m == 0) btv = *reinterpret_cast<const f32x4*>(smem + bt_o[par] + b * 32);
+                else if constexpr (m == 1) {
+                    const f32x4 t = gelu16x4(f32x4{A[4 * b] + btv.x, A[4 * b + 1] + btv.y, A[4 * b + 2] + btv.z, A[4 * b + 3] + btv.w});
+                    A[4 * b] = t.x; A[4 * b + 1] = t.y; A[4 * b + 2] = t.z; A[4 * b + 3] = t.w;
+                }
+            } else if constexpr (m == 0) { A[4 * b] = act1(A[4 * b], slope); A[4 * b + 1] = act1(A[4 * b + 1], slope); }
             else if constexpr (m == 1) { A[4 * b + 2] = act1(A[4 * b + 2], slope); A[4 * b + 3] = act1(A[4 * b + 3], slope); }
-            else {
+            if constexpr (m == 2) {
                 const unsigned x = pack2<BF16>(A[4 * b], A[4 * b + 1]), y = pack2<BF16>(A[4 * b + 2], A[4 * b + 3]);
                 if constexpr ((b & 1) == 0) { rbv[b >> 1].x = (int)x; rbv[b >> 1].y = (int)y; }
                 else { rbv[b >> 1].z = (int)x; rbv[b >> 1].w = (int)y; }
@@ -881,6 +897,11 @@ __global__ __launch_bounds__(256, 1) void rfdb_tail_kernel(const S16K p)
             // and that stream's five stores
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"((rp == 1 ? PPW - 1 : 0) + 5) : "memory");
             if constexpr (rp == 0) load_offsets(n, x0, y0);        // (this tile's pixels: both pairs' loads)
+            if constexpr (GB) {                                    // this pair's table row (read by its epilogue, a pair later)
+                const int gx = x0 + px, gy = y0 + wv * RW + 2 * rp + pe;
+                const int m = (gx == 0 ? 1 : 0) | (gx == p.W - 1 ? 2 : 0) | (gy == 0 ? 4 : 0) | (gy == p.H - 1 ? 8 : 0);
+                bt_o[par] = (unsigned)(T_OFF_BT + m * 128 + hh * 16);
+            }
             mfma_m0<BF16>(acc4[par], a_b4, b_ones);
             __builtin_amdgcn_sched_barrier(0);
             static_for<NG>([&](auto g_) __attribute__((always_inline)) {
@@ -905,7 +926,7 @@ __global__ __launch_bounds__(256, 1) void rfdb_tail_kernel(const S16K p)
         run_pair(std::integral_constant<int, 0>{});
         run_pair(std::integral_constant<int, 1>{});
         // the next tile has landed: younger than the last DMA piece are the first pair's stores behind it, the second pair's loads and stores
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(t_stores_behind_step(T_FIRST + T_SPREAD * (PPW - 1)) + 6 + 5) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(t_stores_behind_step(T_FIRST + T_SPREAD * (PPW - 1), T_OPS) + 6 + 5) : "memory");
         __builtin_amdgcn_s_barrier();
         if (!more) break;
         n = nn; x0 = nx0; y0 = ny0;
@@ -919,14 +940,14 @@ __global__ __launch_bounds__(256, 1) void rfdb_tail_kernel(const S16K p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <bool BF16>
+template <bool BF16, int NCH, bool GB>
 int launch_rfdb_tail(const S16K& k, hipStream_t st)
 {
     static std::atomic<unsigned> attr_set[MAX_DEVICES];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
     if (!attr_set[dev].load(std::memory_order_relaxed)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfdb_tail_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfdb_tail_kernel<BF16, NCH, GB>), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
         if (e != hipSuccess) {
             esr_set_err("hipFuncSetAttribute(rfdb_tail_kernel, MaxDynamicSharedMemorySize)", e);
             return ESR_ERR_LAUNCH;
@@ -935,8 +956,8 @@ int launch_rfdb_tail(const S16K& k, hipStream_t st)
     }
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int grid = ntiles < 256 ? ntiles : 256;
-    esr_note_kernel("rfdb_tail_kernel<%s>", esr_tf(BF16));
-    hipLaunchKernelGGL((rfdb_tail_kernel<BF16>), dim3(grid), dim3(256), T_LDS, st, k);
+    esr_note_kernel("rfdb_tail_kernel<%s, %d, %s>", esr_tf(BF16), NCH, esr_tf(GB));
+    hipLaunchKernelGGL((rfdb_tail_kernel<BF16, NCH, GB>), dim3(grid), dim3(256), T_LDS, st, k);
     return esr_check_launch("rfdb_tail_kernel launch");
 }
 
@@ -945,7 +966,12 @@ int launch_rfdb_tail(const S16K& k, hipStream_t st)
 int esr_launch_rfdb_tail(const S16K& k, bool bf16, hipStream_t st)
 {
     if (!k.wm32 || !k.pm32 || !k.pbias1 || !k.tw || !k.cat) return ESR_ERR_BAD_ARG;
-    return bf16 ? launch_rfdb_tail<true>(k, st) : launch_rfdb_tail<false>(k, st);
+    if (k.nchunks == 3) {                          // ESDB: 48 input channels, border table + GELU on r4
+        if (!k.border || k.act != ESR_ACT_GELU) return ESR_ERR_UNSUPPORTED;
+        return bf16 ? launch_rfdb_tail<true, 3, true>(k, st) : launch_rfdb_tail<false, 3, true>(k, st);
+    }
+    if (k.nchunks != 4 || k.border || k.act == ESR_ACT_GELU) return ESR_ERR_UNSUPPORTED;
+    return bf16 ? launch_rfdb_tail<true, 4, false>(k, st) : launch_rfdb_tail<false, 4, false>(k, st);
 }
 
 namespace {
@@ -968,28 +994,32 @@ int esr_launch_conv64m(const S16K& k, bool bf16, bool post, bool hl, hipStream_t
 // 32 half + i, input slot 16 chunk + 8 h + j at that tap (the same error-diffused values as the tap-pair image)
 size_t esr_m32_conv_bytes(int cin_phys, int cout, int ksize)
 {
-    if (ksize != 3 || esr_round_up(cin_phys, 16) != 64) return 0;
-    const int nt = esr_round_up(cout, 16) / 16;
+    const int nch = esr_round_up(cin_phys, 16) / 16, nt = esr_round_up(cout, 16) / 16;
+    if (ksize != 3) return 0;
+    if (nch == 3) return nt == 2 ? (size_t)3 * M_TAPS * 1024 : 0;           // ESDB's c4 (rfdb_tail_kernel<.., 3, true>)
+    if (nch != 4) return 0;
     return nt == 4 ? (size_t)M_NFRAG * 1024 : (nt == 2 ? (size_t)M_NG * 1024 : 0);
 }
 size_t esr_m32_conv_offset(int cin_phys, int cout, int ksize)
 {
     if (!esr_m32_conv_bytes(cin_phys, cout, ksize)) return 0;
-    const size_t nt = (size_t)esr_round_up(cout, 16) / 16;
-    return (size_t)4 * 5 * nt * 1024 + nt * 16 * sizeof(float);
+    const size_t nt = (size_t)esr_round_up(cout, 16) / 16, nch = (size_t)esr_round_up(cin_phys, 16) / 16;
+    return nch * 5 * nt * 1024 + nt * 16 * sizeof(float);
 }
 // esr_pack_post_s16 blob of a 1x1 from 49 .. 64 to 1 .. 32 channels: [hi images][lo images][bias][this image 16 KB]: fragment (step, hi | lo),
 // step = 4 half + block: the eight input channels 32 half + 8 block + 4 h + (j & 3); hi image: the weight's high part in all eight k slots
 // (slots 0 .. 3 meet the activations' high parts, 4 .. 7 their low parts), lo image: its low part in slots 0 .. 3 only; rows >= cout zero
 size_t esr_m32_post_bytes(int cin, int cout)
 {
-    return (esr_round_up(cin, 16) == 64 && cout >= 1 && cout <= 32) ? (size_t)M_POST_IMG : 0;
+    // (48 inputs -- ESDB's esa.conv1 behind rfdb_tail_kernel<.., 3, true> -- : the same eight steps, channels 48 .. 63 zero)
+    const int kt = esr_round_up(cin, 16) / 16;
+    return ((kt == 4 && cout >= 1 && cout <= 32) || (kt == 3 && cout >= 1 && cout <= 16)) ? (size_t)M_POST_IMG : 0;
 }
 size_t esr_m32_post_offset(int cin, int cout)
 {
     if (!esr_m32_post_bytes(cin, cout)) return 0;
-    const size_t ot = (size_t)esr_round_up(cout, 16) / 16;
-    return (size_t)2 * 4 * ot * 1024 + ot * 16 * sizeof(float);
+    const size_t ot = (size_t)esr_round_up(cout, 16) / 16, kt = (size_t)esr_round_up(cin, 16) / 16;
+    return (size_t)2 * kt * ot * 1024 + ot * 16 * sizeof(float);
 }
 
 // ---- esr_pack_tail_s16 (ABI v12): the 1x1 of a 16-bit tail, K = three 32-slot segments + the 3x3's 32 channels, for rfdb_tail_kernel --------

@@ -972,13 +972,19 @@ static bool rfdb_tail_takes(const esr_conv_desc* d)
 {
     if (d->storage != ESR_STORE_BF16 && d->storage != ESR_STORE_F16) return false;
     if (!d->tail_wpacked || !d->wpacked || d->ksize != 3 || d->in_layout != ESR_NHWC || d->out_layout != ESR_NHWC) return false;
-    if (esr_round_up(d->cin, 16) != 64 || d->cout < 1 || d->cout > 32 || d->tail_cat_c != 96 || d->tail_cout < 49 || d->tail_cout > 64) return false;
-    if (d->res_mode != ESR_RES_NONE || d->border_bias || d->hilo || d->in_seg_stride != 0 || d->act != ESR_ACT_NONE || d->blocked8) return false;
-    if (d->tail_mid_act != ESR_ACT_NONE && d->tail_mid_act != ESR_ACT_LRELU && d->tail_mid_act != ESR_ACT_RELU) return false;
+    const int nch = esr_round_up(d->cin, 16) / 16;
+    if ((nch != 3 && nch != 4) || d->cout < 1 || d->cout > 32 || d->tail_cat_c != 96) return false;
+    if (d->res_mode != ESR_RES_NONE || d->hilo || d->in_seg_stride != 0 || d->act != ESR_ACT_NONE || d->blocked8) return false;
+    if (nch == 4) {                                 // RFDB: LeakyReLU / ReLU / none on r4, 49 .. 64 outputs
+        if (d->border_bias || d->tail_cout < 49 || d->tail_cout > 64) return false;
+        if (d->tail_mid_act != ESR_ACT_NONE && d->tail_mid_act != ESR_ACT_LRELU && d->tail_mid_act != ESR_ACT_RELU) return false;
+    } else {                                        // ESDB: the merged BSConvU's border table + GELU on r4, 33 .. 48 outputs
+        if (!d->border_bias || d->tail_mid_act != ESR_ACT_GELU || d->tail_cout < 33 || d->tail_cout > 48) return false;
+    }
     if (d->split > 0 && d->split < d->tail_cout) return false;
     if (!d->post_wpacked || d->post2_wpacked || d->post_cout < 1 || d->post_cout > 16) return false;
     if (d->post_act != ESR_ACT_NONE && d->post_act != ESR_ACT_LRELU && d->post_act != ESR_ACT_RELU) return false;
-    if (!d->in.ptr || (d->in.pitch & 7) || (d->in.coff & 7) || d->in.coff + 64 > d->in.pitch) return false;
+    if (!d->in.ptr || (d->in.pitch & 7) || (d->in.coff & 7) || d->in.coff + 16 * nch > d->in.pitch) return false;
     if (!d->tail_cat.ptr || (d->tail_cat.pitch & 7) || (d->tail_cat.coff & 7) || d->tail_cat.coff + 32 > d->tail_cat.pitch || d->tail_seg_stride16 <= 0) return false;
     if (!d->out0.ptr || (d->out0.pitch & 7) || (d->out0.coff & 7) || d->out0.coff + esr_round_up(d->tail_cout, 8) > d->out0.pitch) return false;
     if (!d->post_out.ptr || (d->post_out.pitch & 7) || (d->post_out.coff & 7) || d->post_out.coff + esr_round_up(d->post_cout, 8) > d->post_out.pitch) return false;
@@ -993,13 +999,16 @@ static int run_rfdb_tail(const esr_conv_desc* d, bool bf16, hipStream_t st)
 {
     S16K k;
     memset(&k, 0, sizeof(k));
-    const int nt = esr_round_up(d->cout, 16) / 16, ot = esr_round_up(d->post_cout, 16) / 16;
+    const int nt = esr_round_up(d->cout, 16) / 16, ot = esr_round_up(d->post_cout, 16) / 16, nch = esr_round_up(d->cin, 16) / 16;
+    const int kt = esr_round_up(d->tail_cout, 16) / 16;
     k.x = static_cast<const char*>(d->in.ptr);
     k.wp = static_cast<const char*>(d->wpacked);
-    k.bias = reinterpret_cast<const float*>(k.wp + (size_t)4 * 5 * nt * 1024);
-    k.wm32 = k.wp + esr_m32_conv_offset(64, d->cout, 3);
+    k.bias = reinterpret_cast<const float*>(k.wp + (size_t)nch * 5 * nt * 1024);
+    k.wm32 = k.wp + esr_m32_conv_offset(16 * nch, d->cout, 3);
     k.N = d->n; k.H = d->h; k.W = d->w;
-    k.nchunks = 4;
+    k.nchunks = nch;
+    k.act = d->tail_mid_act;
+    k.border = d->border_bias;
     k.in_pitch = d->in.pitch; k.in_coff = d->in.coff;
     k.slope = d->tail_mid_act == ESR_ACT_LRELU ? d->slope : (d->tail_mid_act == ESR_ACT_RELU ? 0.f : 1.f);
     k.tw = static_cast<const char*>(d->tail_wpacked);
@@ -1011,7 +1020,7 @@ static int run_rfdb_tail(const esr_conv_desc* d, bool bf16, hipStream_t st)
     k.cout_store = esr_round_up(d->tail_cout, 8);
     k.pw1 = static_cast<const char*>(d->post_wpacked);
     k.pm32 = k.pw1 + esr_m32_post_offset(d->tail_cout, d->post_cout);
-    k.pbias1 = reinterpret_cast<const float*>(k.pw1 + (size_t)2 * 4 * ot * 1024);
+    k.pbias1 = reinterpret_cast<const float*>(k.pw1 + (size_t)2 * kt * ot * 1024);
     k.py1 = static_cast<char*>(d->post_out.ptr);
     k.py1_pitch = d->post_out.pitch; k.py1_coff = d->post_out.coff;
     k.p1_cout8 = esr_round_up(d->post_cout, 8);

@@ -246,3 +246,102 @@ def test_conv64m_hilo_lr_conv_matches_fp64_reference(n, c, hw, act):
         g1 = (y1[0].double() + y1[1].double()).permute(0, 3, 1, 2)[:, :c]
         assert int(((g1 - ref[:1]).abs() > tol[:1]).sum()) == 0
         assert float((g1 - got[:1]).abs().max()) <= 2.0 * float(tol[:1].max())
+
+
+@pytest.mark.parametrize("compute", ["f16", "bf16"])
+@pytest.mark.parametrize("n,hw,C,dc,f", [(1, (339, 510), 48, 24, 12), (4, (128, 160), 48, 24, 16), (2, (250, 203), 40, 20, 10)])
+def test_esdb_tail_matches_fp64_reference(compute, n, hw, C, dc, f):
+    """rfdb_tail_kernel<.., 3, true>: ESDB's tail (team18_bsrn.py:165-171, :109) -- c4 = BSConvU as a dense 3x3 over 48 physical channels with
+    the merged pointwise bias's border table and GELU, r4 never stored, v = c5 . [d1 d2 d3 r4], c1_ = esa.conv1 . v -- against fp64 on the
+    same 16-bit inputs, the blobs' effective weights and the exact GELU (the kernel's polynomial: |error| <= 1.3e-4, esr_s16_dev.h)."""
+    from ntire2022_esr_amd import _lib as L, BSRN
+    from ntire2022_esr_amd.engine import pack_conv_s16, unpack_conv_s16, pack_tail_s16, pack_post_s16
+    dt = DT[compute]
+    g = torch.Generator().manual_seed(n + hw[0] + C)
+    pw, dw = torch.nn.Linear(C, dc), torch.nn.Conv2d(dc, dc, 3, padding=1, groups=dc)
+    with torch.no_grad():
+        pw.weight.copy_(torch.randn(dc, C, generator=g) * 0.2); pw.bias.copy_(torch.randn(dc, generator=g))
+        dw.weight.copy_(torch.randn(dc, 1, 3, 3, generator=g) * 0.4); dw.bias.copy_(torch.randn(dc, generator=g) * 0.3)
+    w4, b4, table = BSRN._merged_bsconv(pw, dw)
+    r3 = F.pad(torch.randn(n, *hw, C, generator=g), (0, 48 - C)).to(dt).to(DEV)
+    ds = F.pad(torch.randn(3, n, *hw, dc, generator=g), (0, 32 - dc)).to(dt).to(DEV)
+    w5, b5 = torch.randn(C, 4 * dc, generator=g) * 0.15, torch.randn(C, generator=g)
+    wc, bc = torch.randn(f, C, generator=g) * 0.2, torch.randn(f, generator=g)
+    blob4 = pack_conv_s16(w4, b4, compute, cin_phys=48)
+    w4e, _ = unpack_conv_s16(blob4, C, dc, 3, compute, cin_phys=48)
+    blob5 = pack_tail_s16(w5, b5, 3, dc, dc, compute).to(DEV)
+    blobc = pack_post_s16(wc, bc, compute).to(DEV)
+    blob4, tab = blob4.to(DEV), table.to(DEV)
+    assert tuple(tab.shape) == (16, 32)
+    v = torch.full((n, *hw, 48), 7.0, dtype=dt, device=DEV)
+    c1 = torch.full((n, *hw, 16), 7.0, dtype=dt, device=DEV)
+    d = L.ConvDesc()
+    d.n, d.h, d.w, d.cin, d.cout, d.ksize = n, hw[0], hw[1], C, dc, 3
+    d.in_layout = d.out_layout = L.NHWC
+    d.storage = d.compute = L.STORE[compute]
+    d.act = L.ACT_NONE
+    d.inp = L.View(ctypes.c_void_p(r3.data_ptr()), 48, 0)
+    d.out0 = L.View(ctypes.c_void_p(v.data_ptr()), 48, 0)
+    d.wpacked = ctypes.c_void_p(blob4.data_ptr())
+    d.border_bias = ctypes.c_void_p(tab.data_ptr())
+    d.tail_wpacked = ctypes.c_void_p(blob5.data_ptr())
+    d.tail_cat = L.View(ctypes.c_void_p(ds.data_ptr()), 32, 0)
+    d.tail_cat_c, d.tail_cout, d.tail_mid_act = 96, C, L.ACT_GELU
+    d.tail_seg_stride16 = ds[0].numel() * 2 // 16
+    d.post_wpacked = ctypes.c_void_p(blobc.data_ptr())
+    d.post_out = L.View(ctypes.c_void_p(c1.data_ptr()), 16, 0)
+    d.post_cout, d.post_act = f, L.ACT_NONE
+    assert L.lib().esr_conv_tail_supported(ctypes.byref(d)) == 1
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # fp64 reference: the dense 3x3 + the table row of the pixel's outside sides, exact GELU
+    x = r3[..., :C].permute(0, 3, 1, 2).double()
+    pre = F.conv2d(x, w4e.double().to(DEV), b4.double().to(DEV), padding=1)
+    ys, xs = torch.arange(hw[0], device=DEV), torch.arange(hw[1], device=DEV)
+    mask = ((xs == 0).long() + 2 * (xs == hw[1] - 1).long())[None, :] + (4 * (ys == 0).long() + 8 * (ys == hw[0] - 1).long())[:, None]
+    pre = pre + tab.double()[mask][..., :dc].permute(2, 0, 1)[None]
+    r4 = F.gelu(pre)
+    r4q = r4.to(dt).double()
+    cat = torch.cat([ds[j, ..., :dc].permute(0, 3, 1, 2).double() for j in range(3)] + [r4q], 1)
+    vref = torch.einsum("oc,nchw->nohw", _hilo(w5, dt).to(DEV), cat) + b5.double().to(DEV)[None, :, None, None]
+    step = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    # a flipped rounding of r4 / the polynomial's 1.3e-4 move v by |w5| x that much
+    extra = float(w5.abs().max()) * (1.2 * step * float(r4.abs().max()) + 4 * 1.3e-4)
+    for _ in range(2):
+        L.check(L.lib().esr_conv2d_f32(ctypes.byref(d), st), "tail")
+        torch.cuda.synchronize()
+        got = v.permute(0, 3, 1, 2)[:, :C].double()
+        bad = int(((got - vref).abs() > _tol(vref, dt, extra)).sum())
+        assert bad == 0, (bad, float((got - vref).abs().max()))
+        cref = torch.einsum("oc,nchw->nohw", (_hilo(wc, dt) if compute == "bf16" else wc.to(dt).double()).to(DEV),
+                            vref if compute == "bf16" else got) + bc.double().to(DEV)[None, :, None, None]
+        gc = c1.permute(0, 3, 1, 2)[:, :f].double()
+        badc = int(((gc - cref).abs() > _tol(cref, dt, 2e-4 + extra * float(wc.abs().max()) * 8)).sum())
+        assert badc == 0, (badc, float((gc - cref).abs().max()))
+    assert torch.all(v[..., (C + 7) // 8 * 8:] == 7.0) and torch.all(v[..., C:(C + 7) // 8 * 8] == 0)
+    assert torch.all(c1[..., f:(f + 7) // 8 * 8] == 0)
+
+
+def test_bsrn_with_and_without_the_fused_block_tail():
+    """model.fuse_tail on BSRN fp16 (BASELINE config [4]): ESDB's c4 / c5 + esa.conv1 as two launches or as rfdb_tail_kernel<false, 3, true>;
+    against the fp32 engine the fused network must not be the worse one."""
+    from ntire2022_esr_amd.registry import select_model
+    m = select_model(18, torch.device(DEV))[0]
+    x = (torch.rand(1, 3, 270, 480, generator=torch.Generator().manual_seed(3)) * 255.0).to(DEV)
+    m.set_compute("f32")
+    y32 = m(x).clone()
+    m.set_compute("f16")
+    y1 = m(x).clone()
+    m.enable_profiling(1); m(x); torch.cuda.synchronize(); m.collect_profile(); m(x); torch.cuda.synchronize()
+    names = {o["kernel"] for o in m.collect_profile()}
+    m.disable_profiling()
+    assert any(k.startswith("rfdb_tail_kernel<false, 3, true>") for k in names), names
+    m.fuse_tail = False
+    y0 = m(x).clone()
+    m.fuse_tail = True
+
+    def psnr(a, b):
+        return float(10.0 * torch.log10(255.0 ** 2 / ((a - b) ** 2).mean().clamp_min(1e-12)))
+    fused, separate, between = psnr(y1, y32), psnr(y0, y32), psnr(y1, y0)
+    assert fused > separate - 0.5, (fused, separate, between)
+    assert between > 60.0, (fused, separate, between)
+    assert torch.equal(m(x), y1)

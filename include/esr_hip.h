@@ -119,7 +119,9 @@ typedef struct esr_conv_desc {
      * tail_mid_act and ROUNDED to the storage type (exactly the tensor the separate launches store) but never stored; tail_cat are
      * three dense tensors of pitch 32 (tail_cat_c = 96 physical slots) that lie tail_seg_stride16 * 16 bytes apart; the 1x1 (tail_cout
      * <= 64, no activation, weights from esr_pack_tail_s16) is stored to out0 AND, unrounded, feeds the post 1x1 (post_wpacked from
-     * esr_pack_post_s16, post_cout <= 16, post_out).  esr_conv_tail_supported(d) tells whether a descriptor runs this way. */
+     * esr_pack_post_s16, post_cout <= 16, post_out).  The same with 48 physical input channels, border_bias (the merged BSConvU's table,
+     * added to the 3x3 result in front of the activation) and tail_mid_act = ESR_ACT_GELU is ESDB's tail (models/team18_bsrn.py:165-171,
+     * :109; 33 <= tail_cout <= 48).  esr_conv_tail_supported(d) tells whether a descriptor runs this way. */
     int32_t tail_seg_stride16;
     /* ABI v3 -- optional "post" 1x1: besides its own output, the conv's ACTIVATED result x' feeds a 1x1 whose output goes to
      * `post_out`:  post_out = post_act(W_p . x' + b_p).  RFDB: r_j = act(c{j}_r(..)), d_{j+1} = lrelu(c{j+1}_d(r_j))

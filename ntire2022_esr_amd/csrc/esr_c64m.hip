@@ -98,6 +98,17 @@ constexpr int m_tail_stores(bool post, int spread)
     return last < M_NG ? m_stores_behind(post, m_slot_of_step(last)) + spp : m_stores_behind(post, m_slot_of_step(last - M_NG));
 }
 
+// the three-chunk forms (NCH = 3, GB: ESDB's c{j}_r, 27 k steps): store slots of a pair's stream -- POST q = 8, 17, 26, 36, 37 at slot q + 4,
+// plain q = 6, 13, 20 at 2 q + 4 -- and the tile-end wait: the last DMA piece (L = 36) rides behind k step 9 of the SECOND pair
+constexpr int m3_tail_stores(bool post, int spread)
+{
+    const int slot = m_slot_of_step(spread * (M_PPW - 1) - 3 * M_TAPS);
+    int n = 0;
+    if (post) { for (int s : {12, 21, 30, 40, 41}) n += s > slot; }
+    else { for (int s : {16, 30, 44}) n += s > slot; }
+    return n;
+}
+
 template <bool BF16, bool AG>
 __device__ __forceinline__ void mfma_m(f32x16& acc, const i32x4& a, const i32x4& b)
 {
@@ -136,12 +147,19 @@ __device__ __forceinline__ i32x4 bias_frag(float b, bool first_half)
     return first_half ? i32x4{(int)x, (int)y, 0, 0} : i32x4{0, 0, 0, 0};
 }
 
-template <bool BF16, bool POST, bool HL>
+// NCH = 3, GB (round 6, last): ESDB's c{j}_r (team18_bsrn.py:150-163) -- a BSConvU run as a dense 3x3 over 48 physical channels with 33 .. 48
+// outputs (+ input, GELU; the merged pointwise bias's border table added in front of the GELU), plain or with the next distillation Linear + GELU
+// behind it (fp16).  27 k steps per pair, all 54 weight fragments in accumulation registers, six 4-channel blocks per pixel (the fourth block
+// pair is padding: no operations, no store); the LDS pixel keeps its 10 slots (6 used).
+template <bool BF16, bool POST, bool HL, int NCH, bool GB>
 __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
 {
     static_assert(!HL || (BF16 && !POST), "hi + lo residual / output: bf16, no post chain");
-    constexpr int RW = M_RW, NG = M_NG, TAPS = M_TAPS, STAGE = M_STAGE, ROWB = M_ROWB, PIXB = M_PIXB, PPW = M_PPW;
-    constexpr int NREG = POST ? 3 * TAPS * 2 : M_NFRAG;    // fragments in registers; the first min(NREG, 64) in accumulation registers
+    static_assert((NCH == 4 && !GB) || (NCH == 3 && GB && !HL && !(POST && BF16)), "64 channels | ESDB's 48 with the border table and GELU");
+    constexpr int RW = M_RW, TAPS = M_TAPS, NG = NCH * TAPS, STAGE = M_STAGE, ROWB = M_ROWB, PIXB = M_PIXB, PPW = M_PPW;
+    constexpr int NREG = (POST && NCH == 4) ? 3 * TAPS * 2 : 2 * NG;      // fragments in registers; the first min(NREG, 64) in accumulation registers
+    constexpr int SLOTS = 2 + 2 * NG + NCH;                // MFMAs per pair (not HL)
+    constexpr int OFF_BT = POST ? M_LDS_POST : M_LDS_PLAIN;               // GB: the border table [16][48] fp32
     constexpr int NAG = NREG < 64 ? NREG : 64;
     constexpr int NVG = NREG - NAG;
     constexpr int SPP = POST ? 6 : (HL ? 8 : 4);           // stores per row pair
@@ -161,9 +179,11 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
 
     // ---- prologue: weights.  POST: chunk 3's fragments and the post images go to LDS by DMA; everything else straight into registers
     if (POST) {
-        for (int pc = wv; pc < TAPS * 2; pc += 4) dma_glb16(smem_lds + (unsigned)(M_W3 + pc * 1024), p.wm32 + (size_t)(NREG + pc) * 1024 + lane * 16);
+        if (NREG < 2 * NG)
+            for (int pc = wv; pc < TAPS * 2; pc += 4) dma_glb16(smem_lds + (unsigned)(M_W3 + pc * 1024), p.wm32 + (size_t)(NREG + pc) * 1024 + lane * 16);
         for (int pc = wv; pc < M_POST_IMG / 1024; pc += 4) dma_glb16(smem_lds + (unsigned)(M_OFF_POST + pc * 1024), p.pm32 + (size_t)pc * 1024 + lane * 16);
     }
+    if (GB && wv < 3) dma_glb16(smem_lds + (unsigned)(OFF_BT + wv * 1024), reinterpret_cast<const char*>(p.border) + (size_t)wv * 1024 + lane * 16);
     i32x4 wa[NAG];
     i32x4 wx[NVG > 0 ? NVG : 1];
 #pragma unroll
@@ -204,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
         const unsigned sl = (unsigned)((wv + 4 * i) * 64 + lane);
         const unsigned row = sl / (unsigned)M_ROWSL, rem = sl - row * (unsigned)M_ROWSL;
         const unsigned lx = rem / (unsigned)M_LSL, part = rem - lx * (unsigned)M_LSL;
-        const bool real = part < 8u && lx < (unsigned)M_TH && row < (unsigned)M_THY && (i < PPW - 1 || wv + 4 * i < M_NPIECES);
+        const bool real = part < (unsigned)(2 * NCH) && lx < (unsigned)M_TH && row < (unsigned)M_THY && (i < PPW - 1 || wv + 4 * i < M_NPIECES);
         rel[i] = real ? (row * (unsigned)p.W + lx) * (unsigned)p.in_pitch * 2u + part * 16u : OOB;
         edge |= (row == 0u ? 1u << i : 0u) | (lx == 0u ? 1u << (13 + i) : 0u);
         lxp[i / 6] |= (lx < 31u ? lx : 31u) << (5 * (i % 6));
@@ -227,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
             const unsigned row = sl / (unsigned)M_ROWSL, rem = sl - row * (unsigned)M_ROWSL;
             const unsigned lx = rem / (unsigned)M_LSL, part = rem - lx * (unsigned)M_LSL;
             const int gy = y0 - 1 + (int)row, gx = x0 - 1 + (int)lx;
-            const bool ok = valid && part < 8u && lx < (unsigned)M_TH && row < (unsigned)M_THY && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const bool ok = valid && part < (unsigned)(2 * NCH) && lx < (unsigned)M_TH && row < (unsigned)M_THY && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             const unsigned voff = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff) * 2u + part * 16u : OOB;
             dma_buf16(smem_lds + (unsigned)(slot * STAGE + pc * 1024), voff, make_rsrc(p.x + (size_t)(valid ? n : 0) * img_bytes, img_bytes), 0u);
         }
@@ -290,7 +310,9 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
     for (int j = 0; j < 16; ++j) { d1[j] = 0.f; acc[0][0][j] = 0.f; acc[0][1][j] = 0.f; acc[1][0][j] = 0.f; acc[1][1][j] = 0.f; }
     i32x4 bs[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};     // [block & 1]: the block's four values rounded (x, y) and their low parts (z, w)
     i32x4 pa[2][2];                      // post images of a block: [block & 1][hi, lo]
-    uint2 pq[4];                         // the post result rounded, per 4-channel block
+    uint2 pq[4] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};      // the post result rounded, per 4-channel block
+    unsigned bt_o[2] = {(unsigned)OFF_BT, (unsigned)OFF_BT};       // GB: [pair & 1] the lane's row of the border table (+ 16 h bytes)
+    f32x4 btv = {0.f, 0.f, 0.f, 0.f};
     float tv0 = 0.f, tv1 = 0.f, tv2 = 0.f, tv3 = 0.f, lv0 = 0.f, lv1 = 0.f, lv2 = 0.f, lv3 = 0.f;
     unsigned e_v[4], e_vP[2];            // store offsets of the tile whose epilogue is in flight: (half, block pair) / post block pair
 #pragma unroll
@@ -328,10 +350,15 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
         constexpr int hf = blk >> 2, b = blk & 3, sl = blk & 1;
         f32x16& A = acc[par][hf];
         if constexpr (u == 0) {
-            A[4 * b] = act1(A[4 * b], slope); A[4 * b + 1] = act1(A[4 * b + 1], slope);
+            // (GB: channels 32 hf + 8 b + 4 h .. + 3 of the pixel's table row)
+            if constexpr (GB) btv = *reinterpret_cast<const f32x4*>(smem + bt_o[par] + hf * 128 + b * 32);
+            else { A[4 * b] = act1(A[4 * b], slope); A[4 * b + 1] = act1(A[4 * b + 1], slope); }
             if constexpr (POST && blk == 0) load_pa(0);
         } else if constexpr (u == 1) {
-            A[4 * b + 2] = act1(A[4 * b + 2], slope); A[4 * b + 3] = act1(A[4 * b + 3], slope);
+            if constexpr (GB) {
+                const f32x4 t = gelu16x4(f32x4{A[4 * b] + btv.x, A[4 * b + 1] + btv.y, A[4 * b + 2] + btv.z, A[4 * b + 3] + btv.w});
+                A[4 * b] = t.x; A[4 * b + 1] = t.y; A[4 * b + 2] = t.z; A[4 * b + 3] = t.w;
+            } else { A[4 * b + 2] = act1(A[4 * b + 2], slope); A[4 * b + 3] = act1(A[4 * b + 3], slope); }
             if constexpr (POST && blk == 0) d1 = mfma_b<BF16>(a_pb, b_ones, f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
         } else if constexpr (u == 2) {
             bs[sl].x = (int)pack2<BF16>(A[4 * b], A[4 * b + 1]); bs[sl].y = (int)pack2<BF16>(A[4 * b + 2], A[4 * b + 3]);
@@ -349,7 +376,7 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
             }
         } else if constexpr (u == 5) {
             d1 = mfma_b<BF16>(pa[sl][0], bs[sl], d1);
-            if constexpr (blk < 7) load_pa(blk + 1);
+            if constexpr (blk < 2 * NCH - 1) load_pa(blk + 1);
         } else if constexpr (u == 6) {
             if constexpr (PLO) d1 = mfma_b<BF16>(pa[sl][1], bs[sl], d1);
         }
@@ -375,7 +402,14 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
     };
     auto post_act_op = [&](auto pb_, auto m_) __attribute__((always_inline)) {
         constexpr int pb = decltype(pb_)::value, m = decltype(m_)::value;
-        if constexpr (m == 0) {
+        if constexpr (GB) {                                  // the next distillation Linear's GELU
+            if constexpr (m == 0) {
+                const f32x4 t = gelu16x4(f32x4{d1[4 * pb], d1[4 * pb + 1], d1[4 * pb + 2], d1[4 * pb + 3]});
+                d1[4 * pb] = t.x; d1[4 * pb + 1] = t.y; d1[4 * pb + 2] = t.z; d1[4 * pb + 3] = t.w;
+            } else {
+                pq[pb].x = pack2<BF16>(d1[4 * pb], d1[4 * pb + 1]); pq[pb].y = pack2<BF16>(d1[4 * pb + 2], d1[4 * pb + 3]);
+            }
+        } else if constexpr (m == 0) {
             d1[4 * pb] = act1(d1[4 * pb], p1s); d1[4 * pb + 1] = act1(d1[4 * pb + 1], p1s);
         } else {
             d1[4 * pb + 2] = act1(d1[4 * pb + 2], p1s); d1[4 * pb + 3] = act1(d1[4 * pb + 3], p1s);
@@ -396,7 +430,26 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
     // the last post MFMA drains, then the post result (8 + 2).  Plain: 3 + 3 + 1 per block pair.
     auto op = [&](auto par_, auto r_, auto q_) __attribute__((always_inline)) {
         constexpr int q = decltype(q_)::value;
-        if constexpr (POST) {
+        if constexpr (NCH == 3 && POST) {
+            // three block pairs of 4 + 4 operations (table row | + row, GELU | rounding | the post MFMA) + the pair's store, three idle slots
+            // while the last post MFMA drains, the post result's three blocks (GELU | rounding), its two stores
+            if constexpr (q >= 0 && q < 27) {
+                constexpr int P = q / 9, w = q % 9;
+                if constexpr (w < 8) block_op(par_, std::integral_constant<int, 2 * P + w / 4>{}, std::integral_constant<int, (w % 4) < 3 ? (w % 4) : 5>{});
+                else store_op(std::integral_constant<int, P>{}, r_);
+            } else if constexpr (q >= 30 && q < 36) {
+                post_act_op(std::integral_constant<int, (q - 30) / 2>{}, std::integral_constant<int, (q - 30) % 2>{});
+            } else if constexpr (q == 36 || q == 37) {
+                post_store_op(std::integral_constant<int, q - 36>{}, r_);
+            }
+        } else if constexpr (NCH == 3) {
+            if constexpr (q >= 0 && q < 21) {
+                constexpr int P = q / 7, w = q % 7;
+                if constexpr (w < 3) block_op(par_, std::integral_constant<int, 2 * P>{}, std::integral_constant<int, w>{});
+                else if constexpr (w < 6) block_op(par_, std::integral_constant<int, 2 * P + 1>{}, std::integral_constant<int, w - 3>{});
+                else store_op(std::integral_constant<int, P>{}, r_);
+            }
+        } else if constexpr (POST) {
             if constexpr (q >= 0 && q < 60) {
                 constexpr int P = q / 15, w = q % 15;
                 if constexpr (w < 7) block_op(par_, std::integral_constant<int, 2 * P>{}, std::integral_constant<int, w>{});
@@ -490,6 +543,11 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
             using PrevPar = std::integral_constant<int, par ^ 1>;
             using PrevRow = std::integral_constant<int, (rp == 0 ? RW - 2 : 2 * rp - 2)>;
             if constexpr (rp == 1) store_offsets(n, x0, y0);       // behind the carried epilogue's last store, ahead of this tile's first
+            if constexpr (GB) {                                    // this pair's table row (read by its epilogue, a pair later)
+                const int gx = x0 + px, gy = y0 + wv * RW + 2 * rp + pe;
+                const int m = (gx == 0 ? 1 : 0) | (gx == p.W - 1 ? 2 : 0) | (gy == 0 ? 4 : 0) | (gy == p.H - 1 ? 8 : 0);
+                bt_o[par] = (unsigned)(OFF_BT + m * 192 + hh * 16);
+            }
             // slots 0, 1: the bias (the finished pair's accumulators are the other set)
             mfma_m0<BF16>(acc[par][0], a_bias[0], b_ones);
             micro(PrevPar{}, PrevRow{}, std::integral_constant<int, 0>{});
@@ -544,7 +602,8 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
         const unsigned long long t4_a = __builtin_readcyclecounter();
 #endif
         // (HL: the second pair's 8 residual loads and 8 stores)
-        if constexpr ((C64M_ABL & 32) == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HL ? 16 : m_tail_stores(POST, C64M_SPREAD)) : "memory");      // (C64M_ABL & 32: no wait -- timing only)
+        if constexpr ((C64M_ABL & 32) == 0)
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HL ? 16 : (NCH == 3 ? m3_tail_stores(POST, C64M_SPREAD) : m_tail_stores(POST, C64M_SPREAD))) : "memory");      // (C64M_ABL & 32: no wait -- timing only)
         if constexpr ((C64M_ABL & 64) == 0) __builtin_amdgcn_s_barrier();                                   // (C64M_ABL & 64: no barrier -- timing only)
 #ifdef C64M_TRACE4
         t4_wait += __builtin_readcyclecounter() - t4_a;
@@ -570,22 +629,23 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
         });
     }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory");
-    static_for<M_SLOTS>([&](auto s_) __attribute__((always_inline)) {
+    static_for<(HL ? M_SLOTS : SLOTS)>([&](auto s_) __attribute__((always_inline)) {
         micro(std::integral_constant<int, 1>{}, std::integral_constant<int, RW - 2>{}, s_);
         __builtin_amdgcn_sched_barrier(0);
     });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the trailing zero-fill DMA must not outlive the block)
 }
 
-template <bool BF16, bool POST, bool HL>
+template <bool BF16, bool POST, bool HL, int NCH, bool GB>
 int launch_conv64m(const S16K& k, hipStream_t st)
 {
-    constexpr int LDS = POST ? M_LDS_POST : M_LDS_PLAIN;
+    constexpr int LDS = (POST ? M_LDS_POST : M_LDS_PLAIN) + (GB ? 3072 : 0);
+    static_assert(LDS <= LDS_LIMIT, "LDS map");
     static std::atomic<unsigned> attr_set[MAX_DEVICES];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return ESR_ERR_LAUNCH;
     if (!attr_set[dev].load(std::memory_order_relaxed)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64m_kernel<BF16, POST, HL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64m_kernel<BF16, POST, HL, NCH, GB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             esr_set_err("hipFuncSetAttribute(conv64m_kernel, MaxDynamicSharedMemorySize)", e);
             return ESR_ERR_LAUNCH;
@@ -594,8 +654,9 @@ int launch_conv64m(const S16K& k, hipStream_t st)
     }
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int grid = ntiles < 256 ? ntiles : 256;
-    esr_note_kernel("conv64m_kernel<%s, %s, %s>", esr_tf(BF16), esr_tf(POST), esr_tf(HL));
-    hipLaunchKernelGGL((conv64m_kernel<BF16, POST, HL>), dim3(grid), dim3(256), LDS, st, k);
+    if (NCH == 4) esr_note_kernel("conv64m_kernel<%s, %s, %s>", esr_tf(BF16), esr_tf(POST), esr_tf(HL));
+    else esr_note_kernel("conv64m_kernel<%s, %s, %s, %d, %s>", esr_tf(BF16), esr_tf(POST), esr_tf(HL), NCH, esr_tf(GB));
+    hipLaunchKernelGGL((conv64m_kernel<BF16, POST, HL, NCH, GB>), dim3(grid), dim3(256), LDS, st, k);
     return esr_check_launch("conv64m_kernel launch");
 }
 
@@ -981,11 +1042,17 @@ int esr_launch_conv64m(const S16K& k, bool bf16, bool post, bool hl, hipStream_t
 {
     if (!k.wm32 || (post && (!k.pm32 || !k.pbias1))) return ESR_ERR_BAD_ARG;
     if (hl) {
-        if (!bf16 || post || !k.res || k.res_lo_stride <= 0 || !k.y1) return ESR_ERR_BAD_ARG;
-        return launch_conv64m<true, false, true>(k, st);
+        if (!bf16 || post || !k.res || k.res_lo_stride <= 0 || !k.y1 || k.nchunks != 4) return ESR_ERR_BAD_ARG;
+        return launch_conv64m<true, false, true, 4, false>(k, st);
     }
-    if (bf16) return post ? launch_conv64m<true, true, false>(k, st) : launch_conv64m<true, false, false>(k, st);
-    return post ? launch_conv64m<false, true, false>(k, st) : launch_conv64m<false, false, false>(k, st);
+    if (k.nchunks == 3) {                          // ESDB's c{j}_r: border table + GELU (post: GELU too, fp16 only)
+        if (!k.border || k.act != ESR_ACT_GELU || (post && (bf16 || !k.p1_gelu))) return ESR_ERR_UNSUPPORTED;
+        if (post) return launch_conv64m<false, true, false, 3, true>(k, st);
+        return bf16 ? launch_conv64m<true, false, false, 3, true>(k, st) : launch_conv64m<false, false, false, 3, true>(k, st);
+    }
+    if (k.border || k.act == ESR_ACT_GELU || (post && k.p1_gelu)) return ESR_ERR_UNSUPPORTED;
+    if (bf16) return post ? launch_conv64m<true, true, false, 4, false>(k, st) : launch_conv64m<true, false, false, 4, false>(k, st);
+    return post ? launch_conv64m<false, true, false, 4, false>(k, st) : launch_conv64m<false, false, false, 4, false>(k, st);
 }
 
 // ---- host side: where the 32x32x16 images live inside the packed blobs ----------------------------------------------------------------------
@@ -996,7 +1063,7 @@ size_t esr_m32_conv_bytes(int cin_phys, int cout, int ksize)
 {
     const int nch = esr_round_up(cin_phys, 16) / 16, nt = esr_round_up(cout, 16) / 16;
     if (ksize != 3) return 0;
-    if (nch == 3) return nt == 2 ? (size_t)3 * M_TAPS * 1024 : 0;           // ESDB's c4 (rfdb_tail_kernel<.., 3, true>)
+    if (nch == 3) return nt == 2 ? (size_t)3 * M_TAPS * 1024 : (nt == 3 ? (size_t)3 * M_TAPS * 2 * 1024 : 0);      // ESDB's c4 | c{j}_r
     if (nch != 4) return 0;
     return nt == 4 ? (size_t)M_NFRAG * 1024 : (nt == 2 ? (size_t)M_NG * 1024 : 0);
 }
@@ -1013,7 +1080,7 @@ size_t esr_m32_post_bytes(int cin, int cout)
 {
     // (48 inputs -- ESDB's esa.conv1 behind rfdb_tail_kernel<.., 3, true> -- : the same eight steps, channels 48 .. 63 zero)
     const int kt = esr_round_up(cin, 16) / 16;
-    return ((kt == 4 && cout >= 1 && cout <= 32) || (kt == 3 && cout >= 1 && cout <= 16)) ? (size_t)M_POST_IMG : 0;
+    return ((kt == 4 || kt == 3) && cout >= 1 && cout <= 32) ? (size_t)M_POST_IMG : 0;
 }
 size_t esr_m32_post_offset(int cin, int cout)
 {

@@ -1162,7 +1162,7 @@ int esr_pack_conv_s16(const float* w, const float* bias, int cin, int cout, int 
                     e = t - from16(q, compute);
                     o[s16_index(nt, pairs, s, tap, oc)] = q;
                     // the same value in v_mfma_f32_32x32x16's fragment order (esr_c64m.hip): fragment (chunk, tap, half), lane 32 h + i, slot j
-                    if (om) om[(((((size_t)(s / 16) * 9 + tap) * (nt == 4 ? 2 : 1) + oc / 32) * 64 + ((s % 16) / 8) * 32 + oc % 32) * 8) + s % 8] = q;
+                    if (om) om[(((((size_t)(s / 16) * 9 + tap) * (nt >= 3 ? 2 : 1) + oc / 32) * 64 + ((s % 16) / 8) * 32 + oc % 32) * 8) + s % 8] = q;
                 }
             }
         }
@@ -1500,7 +1500,11 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         if (nt_all * (kp.tiles_x > kp.tiles_y ? kp.tiles_x : kp.tiles_y) < 4294967296.0)
             return esr_launch_conv48rp(kp, bf16, false, st);
     }
-    if (conv64rq_takes(d) || (conv64r_takes(d) && nt == 4)) {
+    // round 6 (last): ESDB's c{j}_r -- the merged BSConvU + input + GELU over 48 channels, plain or (fp16) with the next distillation Linear + GELU --
+    // on conv64m_kernel's three-chunk form
+    const bool esdb_r = d->border_bias && d->act == ESR_ACT_GELU && s16_res_is_input(d) && nt == 3 &&
+                        ((conv48rq_takes(d) && d->post_act == ESR_ACT_GELU) || (conv48r_takes(d) && !post));
+    if (esdb_r || conv64rq_takes(d) || (conv64r_takes(d) && nt == 4)) {
         // round 6: the 64 -> 64 3x3s (RFDB c1_r / c2_r with the next distillation 1x1, c3_r) on v_mfma_f32_32x32x16 (esr_c64m.hip)
         S16K k4 = k;
         k4.tiles_y = (d->h + 15) / 16;
@@ -1508,7 +1512,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
         k4.wm32 = k.wp + esr_m32_conv_offset(cin_phys, d->cout, 3);
         if (post) {
             k4.pm32 = k.pw1 + esr_m32_post_offset(d->cout, d->post_cout);
-            k4.pbias1 = reinterpret_cast<const float*>(k.pw1 + (size_t)2 * 4 * (esr_round_up(d->post_cout, 16) / 16) * 1024);
+            k4.pbias1 = reinterpret_cast<const float*>(k.pw1 + (size_t)2 * (esr_round_up(d->cout, 16) / 16) * (esr_round_up(d->post_cout, 16) / 16) * 1024);
         }
         const double nt_all = (double)d->n * k4.tiles_x * k4.tiles_y;
         if (nt_all * (k4.tiles_x > k4.tiles_y ? k4.tiles_x : k4.tiles_y) < 4294967296.0) return esr_launch_conv64m(k4, bf16, post, false, st);

@@ -188,7 +188,8 @@ __device__ __forceinline__ f32x4 gelu16x4(f32x4 v)
     // tools/r05/mfma_valu_probe.hip -- was measured and LOST: 48 live scalars per fragment push conv48r / conv48rq into scratch (BSRN fp16
     // 2710 -> 1600 images/s), tools/r05/f_gelu.sh)
     // (also measured: the scalar C++ form under -fno-slp-vectorize, conv48rq 0.35 -> 0.39-0.41 ms; -fno-slp-vectorize alone: no difference,
-    // tools/r05/h_slp.sh)
+    // tools/r05/h_slp.sh; round 6, on the 4-value blocks of conv64m_kernel / rfdb_tail_kernel's GB forms, four interleaved plain chains
+    // under -fno-slp-vectorize: 48 instead of 28 instructions per block, conv64m<.., 3, true> 313 -> 343 us -- the packed form stays)
     // The two halves' Horner chains INTERLEAVED, instruction by instruction (round 5).  A v_pk_fma_f32 that reads the previous one's result needs a
     // wait state, and as gelu16x2(lo) followed by gelu16x2(hi) hipcc filled every one of them with an s_nop 0: 510 s_nop per tile of
     // conv48r_kernel<.., 3, EXT, 8>, each an issue slot of a wave that is bound by exactly those (profiles/r05_instruction_census.txt).

@@ -336,6 +336,8 @@ def test_bsrn_with_and_without_the_fused_block_tail():
     names = {o["kernel"] for o in m.collect_profile()}
     m.disable_profiling()
     assert any(k.startswith("rfdb_tail_kernel<false, 3, true>") for k in names), names
+    assert any(k.startswith("conv64m_kernel<false, true, false, 3, true>") for k in names), names         # c1_r / c2_r + the next distillation Linear
+    assert any(k.startswith("conv64m_kernel<false, false, false, 3, true>") for k in names), names        # c3_r
     m.fuse_tail = False
     y0 = m(x).clone()
     m.fuse_tail = True
@@ -346,3 +348,52 @@ def test_bsrn_with_and_without_the_fused_block_tail():
     assert fused > separate - 0.5, (fused, separate, between)
     assert between > 60.0, (fused, separate, between)
     assert torch.equal(m(x), y1)
+
+
+@pytest.mark.parametrize("compute,post", [("f16", True), ("f16", False), ("bf16", False)])
+@pytest.mark.parametrize("n,c,hw", [(1, 48, (270, 480)), (6, 40, (144, 160)), (3, 48, (250, 203))])
+def test_esdb_r_on_conv64m_matches_fp64_reference(compute, post, n, c, hw):
+    """conv64m_kernel<.., 3, true>: ESDB's c{j}_r (team18_bsrn.py:150-163) -- gelu(dense BSConvU(x) + table row + x) over 48 physical channels,
+    plain or (fp16) with the next distillation Linear + GELU behind it -- against fp64 on the same 16-bit inputs, the blob's effective weights and
+    the exact GELU (the kernel's polynomial: |error| <= 1.3e-4)."""
+    from ntire2022_esr_amd import ops, _lib as L
+    from ntire2022_esr_amd.engine import pack_conv_s16, unpack_conv_s16
+    dt = DT[compute]
+    g = torch.Generator().manual_seed(n + c + hw[0] + post)
+    pc = c // 2
+    x = F.pad(torch.randn(n, *hw, c, generator=g), (0, 48 - c)).to(dt).to(DEV)
+    w, b = torch.randn(c, c, 3, 3, generator=g) * 0.1, torch.randn(c, generator=g)
+    wp, bp = torch.randn(pc, c, generator=g) * 0.2, torch.randn(pc, generator=g)
+    table = torch.randn(16, 48, generator=g) * 0.2
+    table[0] = 0
+    table[:, c:] = 0
+    table = table.to(DEV)
+    blob = pack_conv_s16(w, b, compute, cin_phys=48)
+    weff, _ = unpack_conv_s16(blob, c, c, 3, compute, cin_phys=48)
+    kw = dict(act=L.ACT_GELU, cin=c, packed=blob.to(DEV), border=table, res=x, res_mode=L.RES_PRE_ACT)
+    if post:
+        kw.update(post_weight=wp, post_bias=bp, post_act=L.ACT_GELU)
+    d = L.ConvDesc()
+    d.n, d.h, d.w, d.cin, d.cout, d.ksize = n, hw[0], hw[1], c, c, 3
+    d.in_layout = d.out_layout = L.NHWC
+    d.storage = L.STORE[compute]
+    assert L.lib().esr_conv_block_waves(ctypes.byref(d)) == 1
+    xd = x[..., :c].permute(0, 3, 1, 2).double()
+    ys, xs = torch.arange(hw[0], device=DEV), torch.arange(hw[1], device=DEV)
+    mask = ((xs == 0).long() + 2 * (xs == hw[1] - 1).long())[None, :] + (4 * (ys == 0).long() + 8 * (ys == hw[0] - 1).long())[:, None]
+    pre = F.conv2d(xd, weff.double().to(DEV), b.double().to(DEV), padding=1) + table.double()[mask][..., :c].permute(2, 0, 1)[None] + xd
+    ref = F.gelu(pre)
+    for _ in range(2):
+        out = ops.conv2d(x, w, b, **kw)
+        torch.cuda.synchronize()
+        y, yp = out if post else (out, None)
+        got = y.permute(0, 3, 1, 2)[:, :c].double()
+        bad = int(((got - ref).abs() > _tol(ref, dt, 2.6e-4)).sum())
+        assert bad == 0, (bad, float((got - ref).abs().max()))
+        assert torch.all(y[..., c:] == 0)
+        if post:
+            pref = F.gelu(torch.einsum("oc,nchw->nohw", wp.to(dt).double().to(DEV), got) + bp.double().to(DEV)[None, :, None, None])
+            gp = yp.permute(0, 3, 1, 2)[:, :pc].double()
+            badp = int(((gp - pref).abs() > _tol(pref, dt, 4e-4)).sum())
+            assert badp == 0, (badp, float((gp - pref).abs().max()))
+            assert torch.all(yp[..., pc:] == 0)

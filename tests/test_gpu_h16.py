@@ -343,7 +343,12 @@ def test_conv48r_equals_conv_s16(compute, cin, cout, act, res_in, border, hw, n)
         if res_in:
             kw1["res"] = xin[i:i + 1]
         y1 = ops.conv2d(xin[i:i + 1].contiguous(), w, b, **kw1)
-        assert torch.equal(y[i:i + 1], y1), i
+        if act == 3 and res_in and border and cout > 32:
+            # ESDB's c{j}_r shape: since round 6 the batch runs on conv64m_kernel<.., 3, true> (v_mfma_f32_32x32x16, another accumulation order;
+            # its fp64-reference check: test_gpu_c64m.py) -- equal but for values on a rounding boundary, those one storage step apart
+            assert _same_or_one_step(y[i:i + 1], y1, dt), i
+        else:
+            assert torch.equal(y[i:i + 1], y1), i
     if not border:
         weff, _ = unpack_conv_s16(blob.cpu(), cin, cout, 3, compute, cin_phys=cp)
         conv = F.conv2d(x.double().to(DEV), weff.double().to(DEV), b.double().to(DEV), padding=1)
@@ -603,7 +608,11 @@ def test_conv48rq_equals_conv_s16(hw, n, border, act, pact):
     for i in range(n):
         xi = x[i:i + 1].contiguous()
         y1, p1 = ops.conv2d(xi, w, b, res=xi, **kw)
-        assert torch.equal(y[i:i + 1], y1) and torch.equal(yp[i:i + 1], p1), i
+        if border and act == 3 and pact == 3:
+            # (the batch: conv64m_kernel<false, true, false, 3, true> since round 6 -- another accumulation order, see test_conv48r_equals_conv_s16)
+            assert _same_or_one_step(y[i:i + 1], y1, torch.float16) and _same_or_one_step(yp[i:i + 1], p1, torch.float16, frac=0.2, scale=10.0), i
+        else:
+            assert torch.equal(y[i:i + 1], y1) and torch.equal(yp[i:i + 1], p1), i
     assert bool(torch.isfinite(y.float()).all()) and float(yp.float().abs().max()) > 0
 
 

@@ -870,13 +870,32 @@ static bool s16_res_is_input(const esr_conv_desc* d)
 
 // conv48r_kernel's descriptors: a 3x3 over 48 physical input channels with 2 or 3 output tiles, at least one 16 x 32 tile per CU, no
 // residual from HBM, no split, no post chain (measured slower there), NHWC, one input tensor
-static bool conv48r_takes(const esr_conv_desc* d)
+static bool conv48r_shape(const esr_conv_desc* d)
 {
     const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
     if (d->ksize != 3 || nchunks != 3 || (nt != 2 && nt != 3) || d->out_layout != ESR_NHWC || d->in_seg_stride != 0 || d->post_wpacked || d->hilo) return false;
     if (d->res_mode != ESR_RES_NONE && !s16_res_is_input(d)) return false;
     if (d->split > 0 && d->split < d->cout) return false;
-    return (long)d->n * ((d->w + TILE - 1) / TILE) * ((d->h + 31) / 32) >= 256;
+    return true;
+}
+
+static bool conv48rq_takes(const esr_conv_desc* d);
+
+// conv64m_kernel<.., 3, true>'s descriptors (round 6): ESDB's c{j}_r -- the merged BSConvU + input + border table + GELU over 48 channels, plain
+// (conv48r_kernel's shape) or fp16 with the next distillation Linear + GELU (conv48rq_kernel's shape) -- from 256 tiles of 16 x 16: the kernel's
+// OWN tile, so that a 256 x 256 image alone and the same image inside a batch take the same kernel (its accumulation order differs from
+// conv48r_kernel's / conv_s16_kernel's; tests/test_gpu_big.py::test_16bit_batch_equals_per_image)
+static bool esdb_r_takes(const esr_conv_desc* d)
+{
+    const int nt = esr_round_up(d->cout, 16) / 16;
+    if (!d->border_bias || d->act != ESR_ACT_GELU || !s16_res_is_input(d) || nt != 3) return false;
+    if ((long)d->n * ((d->w + TILE - 1) / TILE) * ((d->h + 15) / 16) < 256) return false;
+    return d->post_wpacked ? (conv48rq_takes(d) && d->post_act == ESR_ACT_GELU) : conv48r_shape(d);
+}
+
+static bool conv48r_takes(const esr_conv_desc* d)
+{
+    return conv48r_shape(d) && (long)d->n * ((d->w + TILE - 1) / TILE) * ((d->h + 31) / 32) >= 256;
 }
 
 // conv64r_kernel's descriptors: a 3x3 over 64 physical input channels with 2 or 4 output tiles, at least one 16 x 16 tile per CU, no
@@ -1037,7 +1056,7 @@ static int run_rfdb_tail(const esr_conv_desc* d, bool bf16, hipStream_t st)
 // waves, 16 x 16 tiles), 8: one 8-wave block per CU on 16 x 32 tiles
 int s16_block_waves(const esr_conv_desc* d)
 {
-    if (conv48r_takes(d) || conv48rp_takes(d) || conv64r_takes(d) || conv48rl_takes(d) || conv48rq_takes(d) || conv64rq_takes(d) || conv64ml_takes(d)) return 1;
+    if (esdb_r_takes(d) || conv48r_takes(d) || conv48rp_takes(d) || conv64r_takes(d) || conv48rl_takes(d) || conv48rq_takes(d) || conv64rq_takes(d) || conv64ml_takes(d)) return 1;
     const int nt = esr_round_up(d->cout, 16) / 16, nchunks = esr_round_up(d->cin, 16) / 16;
     const bool res_hbm = d->res_mode != ESR_RES_NONE && !s16_res_is_input(d);
     if (d->ksize != 3 || nt != 3 || d->border_bias || d->post_wpacked || res_hbm || d->out_layout != ESR_NHWC || d->in_seg_stride != 0) return 8;
@@ -1502,8 +1521,7 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     }
     // round 6 (last): ESDB's c{j}_r -- the merged BSConvU + input + GELU over 48 channels, plain or (fp16) with the next distillation Linear + GELU --
     // on conv64m_kernel's three-chunk form
-    const bool esdb_r = d->border_bias && d->act == ESR_ACT_GELU && s16_res_is_input(d) && nt == 3 &&
-                        ((conv48rq_takes(d) && d->post_act == ESR_ACT_GELU) || (conv48r_takes(d) && !post));
+    const bool esdb_r = esdb_r_takes(d);
     if (esdb_r || conv64rq_takes(d) || (conv64r_takes(d) && nt == 4)) {
         // round 6: the 64 -> 64 3x3s (RFDB c1_r / c2_r with the next distillation 1x1, c3_r) on v_mfma_f32_32x32x16 (esr_c64m.hip)
         S16K k4 = k;

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESR_ABI_VERSION 13
+#define ESR_ABI_VERSION 12
 
 typedef enum esr_status {
     ESR_OK = 0,
@@ -243,12 +243,6 @@ int    esr_pack_wino_f32(const float* w_oihw, const float* bias, int cin, int co
 int    esr_unpack_wino_f32(const void* packed, size_t bytes, int cin, int cout, const int32_t* cin_map, int cin_phys,
                            float* u_oc16, float* bias);
 int    esr_wino_supported(const esr_conv_desc* d);   /* 1: a descriptor of this shape runs on wino_f32_kernel when wino_wpacked is set */
-/* ABI v13 -- a TAIL descriptor (tail_wpacked: IMDBlock's conv4 -> cat -> conv1x1 -> + x, models/basicblock.py:263-265) may carry wino_wpacked
- * too (esr_pack_wino_f32 of the 3x3, cout 16): where esr_wino_tail_supported(d) -- fp32, 48 physical input channels (NHWC or blocked), 16
- * outputs, 48 NHWC concat channels, 64 outputs, pre-activation residual, no final activation, >= 8192 strips of 4 x 16 pixels -- esr_conv2d_f32
- * runs wino8_tail_f32_kernel: conv4 as Winograd F(2x2, 3x3) (192 instead of 432 MFMAs per 64 pixels) and the 1x1 in the same wave.  Other
- * shapes (and wino_wpacked == NULL) stay on imdb_tail_kernel / conv_f32_kernel's tail form. */
-int    esr_wino_tail_supported(const esr_conv_desc* d);
 
 int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream);
 /* Diagnostics: waves per block of the conv_f32_kernel variant esr_conv2d_f32 launches for `d` (4 = 16x16-pixel tiles,

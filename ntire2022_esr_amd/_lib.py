@@ -131,7 +131,7 @@ EXPORTS = [
     "esr_packed_conv_s16_bytes", "esr_pack_conv_s16", "esr_unpack_conv_s16",
     "esr_packed_post_s16_bytes", "esr_pack_post_s16", "esr_conv_post_supported",
     "esr_packed_tail_s16_bytes", "esr_pack_tail_s16", "esr_conv_tail_supported",
-    "esr_packed_wino_bytes", "esr_pack_wino_f32", "esr_unpack_wino_f32", "esr_wino_supported", "esr_wino_tail_supported",
+    "esr_packed_wino_bytes", "esr_pack_wino_f32", "esr_unpack_wino_f32", "esr_wino_supported",
     "esr_conv2d_f32", "esr_conv_block_waves", "esr_run_ops", "esr_pack_input_s16",
     "esr_prof_create", "esr_run_ops_profiled", "esr_prof_collect", "esr_prof_destroy", "esr_prof_kernel_symbol",
     "esr_packed_dense_bytes", "esr_pack_dense_f32",
@@ -197,8 +197,6 @@ def lib():
     L.esr_unpack_wino_f32.restype = ci
     L.esr_wino_supported.argtypes = [ctypes.POINTER(ConvDesc)]
     L.esr_wino_supported.restype = ci
-    L.esr_wino_tail_supported.argtypes = [ctypes.POINTER(ConvDesc)]
-    L.esr_wino_tail_supported.restype = ci
     L.esr_conv2d_f32.argtypes = [ctypes.POINTER(ConvDesc), vp]
     L.esr_conv2d_f32.restype = ci
     L.esr_conv_block_waves.argtypes = [ctypes.POINTER(ConvDesc)]
@@ -267,7 +265,7 @@ def lib():
     L.esr_event_pair_ms.restype = ci
     L.esr_bw_probe.argtypes = [vp, sz, ci, vp, ctypes.POINTER(ctypes.c_double)]
     L.esr_bw_probe.restype = ci
-    if L.esr_abi_version() != 13:
+    if L.esr_abi_version() != 12:
         raise EsrError("libesr_hip.so ABI version mismatch")
     L.esr_sizeof.argtypes = [ci]
     L.esr_sizeof.restype = ctypes.c_size_t

@@ -1178,8 +1178,6 @@ int esr_conv2d_f32(const esr_conv_desc* d, void* hip_stream)
     }
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     if (tail) {
-        // round 6: conv4 as Winograd F(2x2, 3x3) in the same launch (wino8_tail_f32_kernel, esr_wino.hip) where the shape qualifies
-        if (d->wino_wpacked && !store16 && esr_wino_tail_supported(d)) return esr_conv2d_wino_tail(d, hip_stream);
         k.wp2 = static_cast<const float*>(d->tail_wpacked);
         k.cat_chunks = d->tail_cat_c / 16;
         k.bias2 = k.wp2 + (size_t)(2 * (k.cat_chunks + 1)) * 4 * 128;       // [chunk of 8][tap = 1][4 tiles][128]

@@ -17,7 +17,6 @@ int esr_s16_block_waves(const esr_conv_desc* d);      // 4: two 4-wave blocks pe
 
 // esr_wino.hip: Winograd F(2x2, 3x3) fp32 convolution (called by esr_conv2d_f32 when d->wino_wpacked is set and the shape qualifies)
 int esr_conv2d_wino(const esr_conv_desc* d, void* hip_stream);
-int esr_conv2d_wino_tail(const esr_conv_desc* d, void* hip_stream);   // the fused IMDB tail with conv4 as Winograd (esr_wino_tail_supported)
 
 // esr_graph.hip: while esr_graph_create captures an op list, a launcher whose kernel can read the network input or write the network
 // output reports the launch it has JUST enqueued on `st`: the pointer values it passed and their byte offsets inside the kernel's first

@@ -27,7 +27,6 @@
 //   LDS reads   per wave and chunk: 16 ds_read_b128 (A) + 16 ds_read_b64 (raw) for 64 MFMAs
 #include <hip/hip_runtime.h>
 #include <stddef.h>
-#include <stdlib.h>
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
@@ -919,397 +918,6 @@ __global__ __launch_bounds__(W8_THREADS, 1) void wino8_f32_kernel(const WinoK p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the out-of-range DMAs issued behind the last strip
 }
 
-
-// ==================================================================================================================================
-// wino8_tail_f32_kernel<Y0BLK> -- IMDBlock's conv4 -> cat -> conv1x1 -> + x (models/basicblock.py:263-265) with conv4 AS WINOGRAD (round 6).
-// imdb_tail_kernel runs conv4 (48 -> 16) in the direct form: 432 of the 688 MFMAs of a wave's 64 pixels, at the same 107 TFLOP/s every fp32
-// kernel of this network reaches -- the launch is bound by the matrix pipe, not by its 940 MB.  Here conv4 is wino8_f32_kernel's plan with ONE
-// cout tile (192 MFMAs per strip of 4 x 16 pixels instead of 432), and the strip's 1x1 follows in the same wave:
-//   conv4    6 chunk stages of 16 positions x 2 MFMAs (the two k steps of a position one MFMA apart: no back-to-back dependent pair); the U of
-//            16 outputs is resident, compacted to 8 KB per chunk ([pos][lane][s0, s1]; the blob's second cout tile is empty)
-//   r4       output transform in registers, bias (position 5), activation: lane (tile j, g) holds channels 4g..4g+3 of its tile's 2 x 2 pixels =
-//            the B operand of the 1x1 for K slots 48 + 4g + s, pixel set (a, b) = pixel (a, b) of the 16 tiles (N = tile)
-//   1x1      acc2[cout tile][a][b] starts at x (loaded in D layout behind the last stage's transform, 16 loads), + bias2, 64 MFMAs on r4, 192 on
-//            the concat's three 16-channel chunks (12 loads issued in front of the r4 part); the weights as a 16 KB LDS image [C][tile][lane][s]
-//   stores   16 per lane: blocked output (Y0BLK) as wino8's whole-line plane pairs, NHWC as 64-byte runs
-// vmcnt: the wave's DMA pieces are counted as in wino8_f32_kernel; a strip adds 16 + 12 register loads (hipcc's own waits: they only ever wait
-// longer, its count misses the younger asm DMAs) and 16 stores between the DMA of chunk 2 of the next strip and its stage 0.
-struct WinoTK {
-    WinoK k;                  // conv4: x = its input (6 chunks), up / bias = its U blob (cout 16: one half), res = the block input, y0 = the 1x1's output
-    const float* w2;          // esr_pack_conv_f32 blob of the 1x1: 64 K slots (concat 0..47, conv4 48..63) -> 64 outputs
-    const float* bias2;
-    const float* cat;         // NHWC concat buffer: 48 channels at cat_coff of cat_pitch
-    int cat_pitch, cat_coff;
-    int res_blk;              // the residual is channel-blocked [n][C/8][h][w][8]
-    int mid_act;              // activation of conv4's result
-};
-#ifndef W8T_STAGGER
-#define W8T_STAGGER 0         // s_sleep units (64 cycles) of start-up delay per wave index
-#endif
-#ifndef W8T_ABL
-#define W8T_ABL 0             // research builds (tools/r06/w8t_abl.sh; results are WRONG): 1 no x loads, 2 no concat loads, 4 no stores, 8 no 1x1 MFMAs, 16 no 3x3 MFMAs
-#endif
-constexpr int W8T_NCH = 6;
-constexpr int W8T_U_CHUNK = 16 * 64 * 8;
-constexpr int W8T_W2_OFF = W8T_NCH * W8T_U_CHUNK;
-constexpr int W8T_RAW_OFF = W8T_W2_OFF + 4 * 4 * 64 * 16;
-constexpr int W8T_BIAS_OFF = W8T_RAW_OFF + 8 * 2 * W8_SLOT_BYTES;
-constexpr int W8T_TOTAL = W8T_BIAS_OFF + 64 + 256;
-constexpr int W8T_STORES = 16;
-static_assert(W8T_TOTAL <= 160 * 1024, "one block per CU");
-
-template <bool Y0BLK>
-__global__ __launch_bounds__(W8_THREADS, 1) void wino8_tail_f32_kernel(const WinoTK q)
-{
-    const WinoK& p = q.k;
-    constexpr int NCH = W8T_NCH;
-    __shared__ __attribute__((aligned(16))) char smem[W8T_TOTAL];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 15, g = lane >> 4;
-    const int tx = j & 7, ty = j >> 3;
-    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-
-    // ---- strips: a block owns a contiguous run, its 8 waves take 8 consecutive ones per step (wino8_f32_kernel with one cout half)
-    const int pidx = (int)blockIdx.x, npair = (int)gridDim.x;
-    const int nstrips = p.N * p.tiles_y * p.tiles_x;
-    const int per_block = (nstrips + npair - 1) / npair;
-    const int s_end = min((pidx + 1) * per_block, nstrips);
-    auto strip_index = [&](int k) -> int {
-        const int s = pidx * per_block + k * 8 + wv;
-        return s < s_end ? s : -1;
-    };
-    struct Ctx { int n, x0, y0; };
-    unsigned dvoff[4];
-    int dn = 0;
-    auto locate = [&](int strip, Ctx& c) {
-        if (strip < 0) { c.n = 0; c.x0 = 0; c.y0 = 0; return; }
-        const unsigned sq = wn_div((unsigned)strip, (unsigned)p.tiles_x, p.magic_x);
-        const unsigned sxi = (unsigned)strip - sq * p.tiles_x;
-        c.n = (int)wn_div(sq, (unsigned)p.tiles_y, p.magic_y);
-        const unsigned syi = sq - (unsigned)c.n * p.tiles_y;
-        c.x0 = (int)sxi * 16;
-        c.y0 = (int)syi * 4;
-    };
-    auto dma_to = [&](int strip, const Ctx& c) {
-        dn = c.n;
-        if (strip < 0) {
-            dvoff[0] = dvoff[1] = dvoff[2] = dvoff[3] = WN_OOB;
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int item = i * 64 + lane;
-            const int plane = item >= W8_PLANE ? 1 : 0;
-            const int slot = item - plane * W8_PLANE;
-            const int pr = slot / WN_PAIR, rem = slot - pr * WN_PAIR;
-            const int odd = rem >= WN_HALO ? 1 : 0;
-            const int ly = 2 * pr + odd, lx = rem - odd * WN_HALO;
-            const int gy = c.y0 - 1 + ly, gx = c.x0 - 1 + lx;
-            const bool ok = item < W8_SLOTS && rem < 2 * WN_HALO && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            dvoff[i] = (ok ? ((unsigned)(gy * p.W + gx) * p.pix_floats + 4u * plane) * 4u + p.in_base : WN_OOB) - (unsigned)(i * 1024);
-        }
-    };
-    const size_t img_bytes = (size_t)p.H * p.W * p.in_pitch * 4;
-    auto image_rsrc = [&](int n) { return wn_rsrc(p.x + (size_t)n * (img_bytes / 4), img_bytes); };
-    const unsigned ring_m0 = smem_lds + (unsigned)(W8T_RAW_OFF + wv * 2 * W8_SLOT_BYTES);
-    const bool live3 = lane < W8_LAST_LANES;
-    auto issue_raw = [&](int par, int chunk) __attribute__((always_inline)) {
-        const wn_i32x4 xr = image_rsrc(dn);
-        const unsigned soff = (unsigned)chunk * p.chunk_stride;
-        const unsigned m = ring_m0 + (unsigned)(par * W8_SLOT_BYTES);
-        wn_dma16<0>(m, dvoff[0], xr, soff);
-        wn_dma16<1024>(m, dvoff[1], xr, soff);
-        wn_dma16<2048>(m, dvoff[2], xr, soff);
-        if (live3) wn_dma16<3072>(m, dvoff[3], xr, soff);
-    };
-
-    int work = strip_index(0);
-    // ---- resident: conv4's U (cout tile 0 of the blob's [chunk][pos][lane][ct0 s0, ct0 s1, ct1 s0, ct1 s1]), the 1x1's image, the biases
-    {
-        const f32x4* const up4 = reinterpret_cast<const f32x4*>(p.up);
-        for (int i = tid; i < NCH * 16 * 64; i += W8_THREADS) {
-            const f32x4 v = up4[i];
-            *reinterpret_cast<f32x2*>(smem + i * 8) = f32x2{v.x, v.y};
-        }
-        // image (C, tile tt, lane (i, kq)) = W2[16 tt + i][K slot 16 C + 4 kq + s], s = 0..3; the blob: esr_hip.hip pack_index (8-slot chunks)
-        for (int i = tid; i < 4 * 4 * 64; i += W8_THREADS) {
-            const int C = i >> 8, tt = (i >> 6) & 3, l = i & 63, ii = l & 15, kq = l >> 4;
-            const float* const s = q.w2 + ((((2 * C + (kq >> 1)) * 4 + tt) * 64 + (2 * (kq & 1)) * 16 + ii) * 2);
-            *reinterpret_cast<f32x4*>(smem + W8T_W2_OFF + i * 16) = f32x4{s[0], s[1], s[32], s[33]};
-        }
-        if (tid < 4) *reinterpret_cast<f32x4*>(smem + W8T_BIAS_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(p.bias + tid * 4);
-        else if (tid < 20) *reinterpret_cast<f32x4*>(smem + W8T_BIAS_OFF + 64 + (tid - 4) * 16) = *reinterpret_cast<const f32x4*>(q.bias2 + (tid - 4) * 4);
-    }
-    Ctx cur, nxt;
-    locate(work, cur);
-    int wn = strip_index(1);
-    locate(wn, nxt);
-    if (work >= 0) {
-        dma_to(work, cur);
-        issue_raw(0, 0);
-        issue_raw(1, 1);
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (work < 0) return;
-
-    const int raw_lane = (g >> 1) * (W8_PLANE * 16) + wn_slot(2 * ty, 2 * tx) * 16 + (g & 1) * 8;
-    const int u_lane = lane * 8;
-    auto raw_row = [&](unsigned rb, int r, f32x2 (&d)[4]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int dx = 0; dx < 4; ++dx)
-            d[dx] = wn_lds_b64(rb + ((r >> 1) * WN_PAIR + (r & 1) * WN_HALO + dx) * 16);
-    };
-    auto row_pass = [&](f32x2 (&V)[16], int r, const f32x2 (&d)[4]) __attribute__((always_inline)) {
-        V[4 * r + 0] = wn_sub2(d[0], d[2]);
-        V[4 * r + 1] = wn_add2(d[1], d[2]);
-        V[4 * r + 2] = wn_sub2(d[2], d[1]);
-        V[4 * r + 3] = wn_sub2(d[1], d[3]);
-    };
-    auto col_pass = [&](f32x2 (&V)[16], int c) __attribute__((always_inline)) {
-        const f32x2 w0 = V[c], w1 = V[4 + c], w2 = V[8 + c], w3 = V[12 + c];
-        V[c] = wn_sub2(w0, w2);
-        V[4 + c] = wn_add2(w1, w2);
-        V[8 + c] = wn_sub2(w2, w1);
-        V[12 + c] = wn_sub2(w1, w3);
-    };
-
-    f32x2 V0[16], V1[16];
-    {
-        unsigned rs = ring_m0 + raw_lane;
-        asm volatile("" : "+v"(rs));
-        f32x2 d[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { raw_row(rs, r, d); row_pass(V0, r, d); }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) col_pass(V0, c);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // slot 0 is free: chunk 2 goes there
-    issue_raw(0, 2);
-    f32x2 a[4];
-    a[0] = *reinterpret_cast<const f32x2*>(smem + u_lane);
-    a[1] = *reinterpret_cast<const f32x2*>(smem + u_lane + 512);
-
-    // Every wave runs the same phases on equal work -- conv4 (little memory traffic), then 28 KB of register loads and 16 KB of stores in a
-    // burst -- and, started together, all 2048 waves of the chip stay in step: the memory system idles through the conv4 phases and is the
-    // bottleneck in between (ablations, tools/r06/w8t_abl.sh: the launch took compute + memory time, not their maximum).  A start-up delay
-    // per wave index spreads the phases over a strip period.
-    if (W8T_STAGGER > 0) {
-        for (int i = 0; i < wv; ++i) __builtin_amdgcn_s_sleep(W8T_STAGGER);
-    }
-    int k = 0;
-    f32x4 acc[16];
-    f32x4 acc2[4][2][2];                          // the 1x1's accumulators [cout tile][a][b]: x from stage NCH - 1 on
-    const size_t hw = (size_t)p.H * p.W;
-    const unsigned plane_b = (unsigned)(hw * 32);
-    // the strip's pixels (a, b) of this lane's tile, and whether they lie inside the image
-    unsigned pix[2][2];
-    bool pok[2][2];
-    auto pixels = [&]() __attribute__((always_inline)) {
-        const int ybase = cur.y0 + 2 * ty, xbase = cur.x0 + 2 * tx;
-#pragma unroll
-        for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                pok[aa][b] = ybase + aa < p.H && xbase + b < p.W;
-                pix[aa][b] = (unsigned)((ybase + aa) * p.W + xbase + b);
-            }
-    };
-    // x in the D layout of the 1x1 (lane (j, g): channels 16 tt + 4 g .. + 3 of its pixels), NHWC or blocked: one load form, the layouts
-    // differ in the lane offset and in the step from one cout tile to the next
-    auto load_x = [&]() __attribute__((always_inline)) {
-        pixels();
-        const size_t rbytes = hw * (size_t)p.res_pitch * 4;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res) + (size_t)cur.n * (rbytes / 4), 0, (int)rbytes, 0x00020000);
-        const unsigned tstep = q.res_blk ? 2u * plane_b : 64u;
-        const unsigned lane_o = q.res_blk ? (unsigned)(g & 1) * 16u + ((unsigned)(p.res_coff >> 3) + (unsigned)(g >> 1)) * plane_b : (unsigned)(p.res_coff + 4 * g) * 4u;
-        const unsigned pstep = q.res_blk ? 32u : (unsigned)p.res_pitch * 4u;
-#pragma unroll
-        for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const unsigned vo = pok[aa][b] ? pix[aa][b] * pstep + lane_o : WN_OOB;
-                if (W8T_ABL & 1) {
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) acc2[tt][aa][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-                } else
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
-                    acc2[tt][aa][b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (unsigned)tt * tstep, 0));
-            }
-    };
-    const char* const bias_lds = smem + W8T_BIAS_OFF + g * 16;
-    for (;;) {
-        const bool has_next = wn >= 0;
-        auto stage = [&](auto first_tag, auto last_tag, int c, f32x2 (&Vc)[16], f32x2 (&Vn)[16]) __attribute__((always_inline)) {
-            constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
-            f32x4 biasv0;
-            const int cn = c + 1 < NCH ? c + 1 : 0;
-            const char* ust = smem + c * W8T_U_CHUNK + u_lane;
-            const char* ust1 = smem + cn * W8T_U_CHUNK + u_lane;
-            unsigned rs = ring_m0 + (unsigned)(((c + 1) & 1) * W8_SLOT_BYTES) + raw_lane;
-            asm volatile("" : "+v"(rs));
-            f32x2 d[2][4];
-#pragma unroll
-            for (int pos = 0; pos < 16; ++pos) {
-                if (pos + 2 < 16) a[(pos + 2) & 3] = *reinterpret_cast<const f32x2*>(ust + (pos + 2) * 512);
-                else a[(pos + 2) & 3] = *reinterpret_cast<const f32x2*>(ust1 + (pos + 2 - 16) * 512);
-                if (pos == W8_TP) {
-                    // chunk c + 1 has landed when only the 4 pieces of chunk c + 2 are younger; in the first two stages of a strip that is not the
-                    // wave's first the previous strip's 16 stores (and its register loads, long complete) lie in between: at least 4 + 16 younger
-                    if (c < 2 && k > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + W8T_STORES) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                }
-                if (pos == W8_TP + 5) {
-                    if (c + 3 == NCH) dma_to(wn, nxt);
-                    issue_raw((c + 1) & 1, c + 3 < NCH ? c + 3 : c + 3 - NCH);
-                }
-                if (pos >= W8_TP && pos < W8_TP + 4) raw_row(rs, pos - W8_TP, d[(pos - W8_TP) & 1]);
-                if (pos >= W8_TP + 1 && pos < W8_TP + 5) {
-                    row_pass(Vn, pos - W8_TP - 1, d[(pos - W8_TP - 1) & 1]);
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) WN_PIN(Vn[4 * (pos - W8_TP - 1) + qq]);
-                }
-                if (pos >= W8_TP + 5 && pos < W8_TP + 9) {
-                    col_pass(Vn, pos - W8_TP - 5);
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) WN_PIN(Vn[4 * qq + pos - W8_TP - 5]);
-                }
-                if (FIRST && pos == 3) biasv0 = *reinterpret_cast<const f32x4*>(bias_lds);
-                if (LAST && pos == 12) load_x();                 // (behind the transform: its 16 registers are free)
-                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                const f32x2 af = a[pos & 3];
-                if (W8T_ABL & 16) {
-                    if (FIRST) acc[pos] = pos == 5 ? biasv0 : zero;
-                    acc[pos].x += af.x * Vc[pos].x + af.y * Vc[pos].y;
-                } else {
-                if (FIRST) acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, Vc[pos].x, pos == 5 ? biasv0 : zero, 0, 0, 0);
-                else wn_mfma(acc[pos], af.x, Vc[pos].x);
-                if (pos > 0) wn_mfma(acc[pos - 1], a[(pos - 1) & 3].y, Vc[pos - 1].y);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (!(W8T_ABL & 16)) wn_mfma(acc[15], a[3].y, Vc[15].y);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        stage(std::true_type{}, std::false_type{}, 0, V0, V1);
-        stage(std::false_type{}, std::false_type{}, 1, V1, V0);
-        stage(std::false_type{}, std::false_type{}, 2, V0, V1);
-        stage(std::false_type{}, std::false_type{}, 3, V1, V0);
-        stage(std::false_type{}, std::false_type{}, 4, V0, V1);
-        stage(std::false_type{}, std::true_type{}, 5, V1, V0);
-
-        // ---- conv4's output transform, bias (in position 5), activation: r4 = the B operand of the 1x1's last 16 K slots
-        wn_mfma_drain(acc[15]);
-        f32x4 r4[2][2];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const f32x4 m0 = acc[jj], m1 = acc[4 + jj], m2 = acc[8 + jj], m3 = acc[12 + jj];
-            const f32x4 t0 = m0 + m1 + m2, t1 = m1 - m2 - m3;
-            if (jj == 0) { r4[0][0] = t0; r4[1][0] = t1; }
-            else if (jj == 1) { r4[0][0] += t0; r4[1][0] += t1; r4[0][1] = t0; r4[1][1] = t1; }
-            else if (jj == 2) { r4[0][0] += t0; r4[1][0] += t1; r4[0][1] -= t0; r4[1][1] -= t1; }
-            else { r4[0][1] -= t0; r4[1][1] -= t1; }
-        }
-#pragma unroll
-        for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) r4[aa][b] = wn_act4<-1>(r4[aa][b], q.mid_act, p.slope);
-        // ---- the concat's three 16-channel chunks of the same pixels
-        f32x4 bc[3][2][2];
-        {
-            const size_t cbytes = hw * (size_t)q.cat_pitch * 4;
-            const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.cat) + (size_t)cur.n * (cbytes / 4), 0, (int)cbytes, 0x00020000);
-#pragma unroll
-            for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const unsigned vo = pok[aa][b] ? (pix[aa][b] * (unsigned)q.cat_pitch + (unsigned)(q.cat_coff + 4 * g)) * 4u : WN_OOB;
-                    if (W8T_ABL & 2) {
-#pragma unroll
-                        for (int C = 0; C < 3; ++C) bc[C][aa][b] = r4[aa][b];
-                    } else
-#pragma unroll
-                    for (int C = 0; C < 3; ++C) bc[C][aa][b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cr, vo, (unsigned)C * 64u, 0));
-                }
-        }
-        // ---- 1x1: x + bias2 + W2 [d1 | d2 | d3 | r4]
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            const f32x4 b2 = *reinterpret_cast<const f32x4*>(smem + W8T_BIAS_OFF + 64 + (tt * 16 + g * 4) * 4);
-#pragma unroll
-            for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc2[tt][aa][b] += b2;
-        }
-        auto part = [&](int C, const f32x4 (&B)[2][2]) __attribute__((always_inline)) {
-            f32x4 A[4];
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) A[tt] = *reinterpret_cast<const f32x4*>(smem + W8T_W2_OFF + ((C * 4 + tt) * 64 + lane) * 16);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                    for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-                        for (int b = 0; b < 2; ++b)
-                            acc2[tt][aa][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tt][s], B[aa][b][s], acc2[tt][aa][b], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        if (!(W8T_ABL & 8)) {
-        part(3, r4);                               // conv4's result first: it is in registers, the concat may still be landing
-        part(0, bc[0]);
-        part(1, bc[1]);
-        part(2, bc[2]);
-        } else {
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) acc2[tt][aa][b] += r4[aa][b] + bc[0][aa][b] + bc[1][aa][b] + bc[2][aa][b];
-        }
-        // ---- 16 unconditional stores (out-of-range offset = dropped)
-        if (!(W8T_ABL & 4) || p.N < 0) {
-            const size_t ybytes = hw * (size_t)p.y0_pitch * 4;
-            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y0 + (size_t)cur.n * (ybytes / 4), 0, (int)ybytes, 0x00020000);
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                if (Y0BLK) {
-                    // whole-line stores of the cout tile's two 8-channel planes (wn_pair_planes): lane (j, g) stores pixel b = g >> 1, slot g & 1
-                    const unsigned plane_a = (unsigned)((p.y0_coff + tt * 16) >> 3) * plane_b + (unsigned)(g & 1) * 16u;
-#pragma unroll
-                    for (int aa = 0; aa < 2; ++aa) {
-                        f32x4 v0 = acc2[tt][aa][0], v1 = acc2[tt][aa][1];
-                        wn_pair_planes(v0, v1);
-                        const bool ok = (g >> 1) ? pok[aa][1] : pok[aa][0];
-                        const unsigned po = ok ? plane_a + ((g >> 1) ? pix[aa][1] : pix[aa][0]) * 32u : WN_OOB;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wn_i32x4, v0), yr, po, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wn_i32x4, v1), yr, po, plane_b, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            const unsigned vo = pok[aa][b] ? (pix[aa][b] * (unsigned)p.y0_pitch + (unsigned)(p.y0_coff + tt * 16 + 4 * g)) * 4u : WN_OOB;
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wn_i32x4, acc2[tt][aa][b]), yr, vo, 0, 0);
-                        }
-                }
-            }
-        }
-        if (!has_next) break;
-        cur = nxt;
-        ++k;
-        wn = strip_index(k + 1);
-        locate(wn, nxt);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the out-of-range DMAs issued behind the last strip
-}
-
 template <int ACT, int OUT, int NCH>
 int w8_launch(const WinoK& k, int grid, hipStream_t st)
 {
@@ -1326,15 +934,6 @@ int wn_launch(const WinoK& k, int grid, hipStream_t st)
     hipLaunchKernelGGL((wino_f32_kernel<ACT, RES, OUT>), dim3(grid), dim3(WN_THREADS), 0, st, k);
     esr_graph_note_io(st, k.x, offsetof(WinoK, x), k.y0, offsetof(WinoK, y0));
     return esr_check_launch("wino_f32_kernel launch");
-}
-
-template <bool Y0BLK>
-int w8t_launch(const WinoTK& k, int grid, hipStream_t st)
-{
-    esr_note_kernel("wino8_tail_f32_kernel<%s>", esr_tf(Y0BLK));
-    hipLaunchKernelGGL((wino8_tail_f32_kernel<Y0BLK>), dim3(grid), dim3(W8_THREADS), 0, st, k);
-    esr_graph_note_io(st, k.k.x, offsetof(WinoTK, k) + offsetof(WinoK, x), k.k.y0, offsetof(WinoTK, k) + offsetof(WinoK, y0));
-    return esr_check_launch("wino8_tail_f32_kernel launch");
 }
 
 bool g_wino8_enabled = true;          // research switch (esr_dbg_wino8): A/B of the two Winograd kernels inside one process
@@ -1523,74 +1122,4 @@ int esr_conv2d_wino(const esr_conv_desc* d, void* hip_stream)
         return a == ESR_ACT_LRELU ? wn_launch<ESR_ACT_LRELU, ESR_RES_PRE_ACT, 0>(k, grid, st)
              : a == ESR_ACT_NONE  ? wn_launch<ESR_ACT_NONE, ESR_RES_PRE_ACT, 0>(k, grid, st) : wn_launch<-1, ESR_RES_PRE_ACT, 0>(k, grid, st);
     return a == ESR_ACT_LRELU ? wn_launch<ESR_ACT_LRELU, ESR_RES_POST_ACT, 0>(k, grid, st) : wn_launch<-1, ESR_RES_POST_ACT, 0>(k, grid, st);
-}
-
-// Shapes wino8_tail_f32_kernel takes (the fused IMDB tail with conv4 as Winograd): fp32, a 3x3 over 48 physical channels (NHWC or
-// channel-blocked) with 16 outputs, the 1x1 over 48 NHWC concat channels + those 16 to 64 outputs, pre-activation residual (NHWC or blocked),
-// no final activation, output NHWC or blocked; enough strips of 4 x 16 pixels that every wave of the 256 blocks walks several.
-extern "C" int esr_wino_tail_supported(const esr_conv_desc* d)
-{
-    if (!d || !d->tail_wpacked || !d->wino_wpacked || !g_wino8_enabled) return 0;
-    if (d->ksize != 3 || d->in_layout != ESR_NHWC || d->out_layout != ESR_NHWC) return 0;
-    if (d->storage != ESR_STORE_F32 || d->compute != ESR_COMPUTE_F32) return 0;
-    if (d->post_wpacked || d->border_bias || d->in_seg_stride || d->hilo) return 0;
-    if (esr_round_up(d->cin, 8) != 8 * W8T_NCH || d->cout != 16 || d->tail_cat_c != 48 || d->tail_cout != 64) return 0;
-    if (d->act != ESR_ACT_NONE || d->res_mode != ESR_RES_PRE_ACT || !d->res.ptr || !d->tail_cat.ptr || !d->out0.ptr) return 0;
-    if (d->split > 0 && d->split < d->tail_cout) return 0;
-    if (d->blocked8 & ~(ESR_BLOCKED_IN | ESR_BLOCKED_OUT0 | ESR_BLOCKED_RES)) return 0;
-    if ((d->blocked8 & ESR_BLOCKED_IN) && ((d->in.coff & 7) || (d->in.pitch & 7))) return 0;
-    if ((d->blocked8 & ESR_BLOCKED_OUT0) && ((d->out0.coff & 7) || (d->out0.pitch & 7))) return 0;
-    if ((d->blocked8 & ESR_BLOCKED_RES) && ((d->res.coff & 7) || (d->res.pitch & 7))) return 0;
-    if ((d->in.pitch & 3) || (d->in.coff & 3) || (d->out0.pitch & 3) || (d->out0.coff & 3) || (d->res.pitch & 3) || (d->res.coff & 3) ||
-        (d->tail_cat.pitch & 3) || (d->tail_cat.coff & 3)) return 0;
-    if (d->in.coff + 48 > d->in.pitch || d->out0.coff + 64 > d->out0.pitch || d->res.coff + 64 > d->res.pitch || d->tail_cat.coff + 48 > d->tail_cat.pitch) return 0;
-    const long sx = (d->w + 15) / 16, sy = (d->h + 3) / 4;
-    const long nstrips = (long)d->n * sx * sy;
-    if (nstrips < 4L * 8 * W8_MAX_BLOCKS) return 0;
-    if ((double)d->n * sx * sy * (sx > sy ? sx : sy) >= 4294967296.0) return 0;
-    int maxpitch = d->in.pitch;
-    maxpitch = maxpitch > d->out0.pitch ? maxpitch : d->out0.pitch;
-    maxpitch = maxpitch > d->res.pitch ? maxpitch : d->res.pitch;
-    maxpitch = maxpitch > d->tail_cat.pitch ? maxpitch : d->tail_cat.pitch;
-    if ((double)d->h * d->w * maxpitch * 4.0 >= 2147482624.0) return 0;
-    return 1;
-}
-
-// Called by esr_conv2d_f32 for a tail descriptor with wino_wpacked when esr_wino_tail_supported(d).
-int esr_conv2d_wino_tail(const esr_conv_desc* d, void* hip_stream)
-{
-    WinoTK t;
-    WinoK& k = t.k;
-    memset(&t, 0, sizeof(t));
-    k.x = static_cast<const float*>(d->in.ptr);
-    k.up = static_cast<const float*>(d->wino_wpacked);
-    k.nchunks = W8T_NCH;
-    k.nhalves = 1;
-    k.up_bytes = (unsigned)esr_packed_wino_bytes(8 * W8T_NCH, d->cout);
-    k.bias = k.up + (size_t)k.nchunks * k.nhalves * 16 * 256;
-    k.res = static_cast<const float*>(d->res.ptr);
-    k.y0 = static_cast<float*>(d->out0.ptr);
-    k.N = d->n; k.H = d->h; k.W = d->w;
-    k.in_pitch = d->in.pitch; k.in_coff = d->in.coff;
-    k.res_pitch = d->res.pitch; k.res_coff = d->res.coff;
-    k.y0_pitch = d->out0.pitch; k.y0_coff = d->out0.coff;
-    k.cout_store = 64; k.split = 64;
-    k.act = d->act; k.slope = d->slope; k.res_mode = d->res_mode;
-    const long sx = (d->w + 15) / 16, sy = (d->h + 3) / 4;
-    k.tiles_x = (int)sx; k.tiles_y = (int)sy;
-    k.magic_x = sx == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)sx) + 1u;
-    k.magic_y = sy == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)sy) + 1u;
-    k.first_share = 8;
-    const bool blocked_in = (d->blocked8 & ESR_BLOCKED_IN) != 0;
-    k.pix_floats = blocked_in ? 8u : (unsigned)d->in.pitch;
-    k.in_base = blocked_in ? (unsigned)(d->in.coff / 8) * (unsigned)(d->h * d->w * 32) : (unsigned)d->in.coff * 4u;
-    k.chunk_stride = blocked_in ? (unsigned)(d->h * d->w * 32) : 32u;
-    t.w2 = static_cast<const float*>(d->tail_wpacked);
-    t.bias2 = t.w2 + (size_t)8 * 4 * 128;                     // [8 chunks of 8 K slots][tap = 1][4 tiles][128]
-    t.cat = static_cast<const float*>(d->tail_cat.ptr);
-    t.cat_pitch = d->tail_cat.pitch; t.cat_coff = d->tail_cat.coff;
-    t.res_blk = (d->blocked8 & ESR_BLOCKED_RES) ? 1 : 0;
-    t.mid_act = d->tail_mid_act;
-    hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    return (d->blocked8 & ESR_BLOCKED_OUT0) ? w8t_launch<true>(t, W8_MAX_BLOCKS, st) : w8t_launch<false>(t, W8_MAX_BLOCKS, st);
 }

@@ -316,8 +316,6 @@ class Plan:
     `store` is the element type of the FULL-RESOLUTION activation buffers ("f32" | "bf16" | "f16"); the ESA
     low-resolution maps (a few hundred KB) are always fp32.  Offsets are bytes into one workspace."""
 
-    winograd_tail = True       # research switch (A/B tests): the fused IMDB tail's 3x3 as Winograd where esr_wino_tail_supported (ABI v13)
-
     def __init__(self, n, h, w, store="f32"):
         self.n, self.h, self.w = n, h, w
         self.npix = n * h * w
@@ -612,7 +610,6 @@ class Plan:
                 return cout
             if o["dst"] is not OUTPUT and o["dst"] is not None and not o["split"]:
                 d.cout = full_width(o["dst"], o["cout"])
-            wn = None
             if st and not lowres and o["kind"] == "conv" and o["src"] is not INPUT:
                 d.wpacked = ctypes.c_void_p(weights[o["w"] + "#s16"].data_ptr())     # conv_s16_kernel
                 d.compute = st
@@ -634,11 +631,6 @@ class Plan:
                 else:
                     d.tail_cat = self._view(t["cat"], base)
                     d.tail_cat_c, d.tail_cout, d.tail_mid_act = t["cat_c"], t["cout"], t.get("mid_act", L.ACT_NONE)
-                    if wn is not None and self.winograd_tail:
-                        # ABI v13: the 3x3 of the fused IMDB tail as Winograd F(2x2, 3x3) too (wino8_tail_f32_kernel) where the shape qualifies
-                        d.wino_wpacked = ctypes.c_void_p(wn.data_ptr())
-                        if not L.lib().esr_wino_tail_supported(ctypes.byref(d)):
-                            d.wino_wpacked = None
             t = o.get("post")
             if t is not None:
                 psfx = "#post" if (st and not lowres) else ""     # 16-bit storage: esr_pack_post_s16 images
@@ -1146,8 +1138,6 @@ class HipSRModel(nn.Module):
             npix = plan.npix if hw is None else plan.n * hw[0] * hw[1]
             e_act = es if hw is None else 4                       # low-resolution maps are fp32
             wino = False
-            wino_tail = False
-            flops_3x3 = None
             stored = None
             if kind == "pack":                      # the network input read once (fp32 NCHW), its 16 16-bit slots per pixel written once
                 out.append(dict(name="pack_input", kernel="pack_input_kernel", cin=o["cin"], cout=16, k=0, flops=0.0, flops_exec=0.0,
@@ -1163,8 +1153,6 @@ class HipSRModel(nn.Module):
                 if isinstance(o.get("dst1"), Buffer) and o["dst1"].blocked:
                     kern = kern[:-1] + ",BLK>"          # the instantiation with the channel-blocked split store
                 wino = arr is not None and bool(arr[i].conv.wino_wpacked) and bool(L.lib().esr_wino_supported(ctypes.byref(arr[i].conv)))
-                wino_tail = arr is not None and bool(arr[i].conv.wino_wpacked) and bool(L.lib().esr_wino_tail_supported(ctypes.byref(arr[i].conv)))
-                flops_3x3 = None
                 if wino:
                     # the device symbol as rocprofv3 prints it: wino_f32_kernel<ACT, RES, Y1BLK> (esr_wino.hip: esr_conv2d_wino)
                     rm = o.get("res_mode", L.RES_NONE) if o["res"] is not None else L.RES_NONE
@@ -1201,11 +1189,8 @@ class HipSRModel(nn.Module):
                         kern = f"rfdb_tail_kernel<{plan.store}>"
                     if (o["cin"] + 7) // 8 == 6 and t["cat_c"] == 48 and t["cout"] == 64 and o.get("res_mode", L.RES_NONE) in (L.RES_NONE, L.RES_PRE_ACT):
                         kern = f"imdb_tail_kernel<FOLD={int(o['res'] is not None)}>"       # esr_hip.hip: imdb_tail_shape()
-                    if wino_tail:
-                        kern = f"wino8_tail_f32_kernel<{'true' if isinstance(o['dst'], Buffer) and o['dst'].blocked else 'false'}>"   # esr_wino.hip: esr_conv2d_wino_tail
                     cat_alg = t.get("cat_c_alg", t["cat_c"])    # logical channels of the concat (16-bit tail: three dense 32-slot tensors of dc)
                     k1 = cat_alg + o["cout"]
-                    flops_3x3 = flops
                     flops += 2.0 * npix * k1 * t["cout"]
                     wb = 4.0 * (ca * o["cout"] * 9 + k1 * t["cout"])
                     rd = npix * e_act * (ca + cat_alg + (t["cout"] if res_read else 0)) + wb
@@ -1303,8 +1288,6 @@ class HipSRModel(nn.Module):
             # flops = ALGORITHMIC (direct-convolution) flops; flops_exec = what the matrix cores execute: Winograd F(2x2,3x3) does 16
             # multiplications per 2x2 outputs where the direct form does 36
             fexec = flops * (16.0 / 36.0) if (kind == "conv" and wino) else flops
-            if kind == "conv" and wino_tail and flops_3x3 is not None:
-                fexec = flops - flops_3x3 * (20.0 / 36.0)       # the tail's 3x3 as Winograd, its 1x1 as it is
             if kind == "conv" and o.get("hilo", 0) & L.HILO_IN:
                 fexec = 2.0 * flops               # both halves of a hi + lo input meet the weights
             out.append(dict(name=o.get("w", kind), kernel=kern, cin=o.get("cin", 0), cout=o.get("cout", 0), k=o.get("k", 0),

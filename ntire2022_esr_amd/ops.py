@@ -152,10 +152,9 @@ def conv2d(x, weight, bias, *, act=L.ACT_NONE, slope=0.05, res=None, res_mode=L.
     d.wpacked = ctypes.c_void_p(packed.data_ptr())
     if wino:
         keepw = pack_wino(w4, bias, cin_map=cin_map).to(x.device)
+        if not lib.esr_wino_supported(ctypes.byref(d)):
+            raise L.EsrError("conv2d: this descriptor does not qualify for the Winograd kernel (esr_wino_supported)")
         d.wino_wpacked = ctypes.c_void_p(keepw.data_ptr())
-        # (a tail descriptor: the 3x3 of the fused IMDB tail as Winograd, ABI v13 -- esr_wino_tail_supported reads wino_wpacked itself)
-        if not (lib.esr_wino_tail_supported(ctypes.byref(d)) if tail_weight is not None else lib.esr_wino_supported(ctypes.byref(d))):
-            raise L.EsrError("conv2d: this descriptor does not qualify for the Winograd kernel (esr_wino_supported / esr_wino_tail_supported)")
     yp = yp2 = None
     if post_weight is not None:
         pw = post_weight if post_weight.dim() == 4 else post_weight[:, :, None, None]

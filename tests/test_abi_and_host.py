@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libesr_hip.so does not export {s}"
     assert set(L.EXPORTS) == set(syms), (set(L.EXPORTS) ^ set(syms))
-    assert lib.esr_abi_version() == 13
+    assert lib.esr_abi_version() == 12
     # the ctypes mirrors of the ABI structs have the library's sizes (also checked by _lib.lib() at load time)
     for which, st in enumerate((L.View, L.ConvDesc, L.EsaDesc, L.BsDesc, L.CaDesc, L.Op, L.EsaLowresDesc, L.ChainDesc)):
         assert lib.esr_sizeof(which) == ctypes.sizeof(st) > 0, st.__name__

@@ -654,8 +654,8 @@ int launch_conv64m(const S16K& k, hipStream_t st)
     }
     const int ntiles = k.N * k.tiles_x * k.tiles_y;
     const int grid = ntiles < 256 ? ntiles : 256;
-    if (NCH == 4) esr_note_kernel("conv64m_kernel<%s, %s, %s>", esr_tf(BF16), esr_tf(POST), esr_tf(HL));
-    else esr_note_kernel("conv64m_kernel<%s, %s, %s, %d, %s>", esr_tf(BF16), esr_tf(POST), esr_tf(HL), NCH, esr_tf(GB));
+    // (the symbol as rocprofv3 prints it -- every template argument, defaulted ones included: tools/pmc_traffic.py joins on it)
+    esr_note_kernel("conv64m_kernel<%s, %s, %s, %d, %s>", esr_tf(BF16), esr_tf(POST), esr_tf(HL), NCH, esr_tf(GB));
     hipLaunchKernelGGL((conv64m_kernel<BF16, POST, HL, NCH, GB>), dim3(grid), dim3(256), LDS, st, k);
     return esr_check_launch("conv64m_kernel launch");
 }

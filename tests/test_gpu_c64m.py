@@ -102,9 +102,9 @@ def test_conv64m_is_the_kernel_that_runs():
     torch.cuda.synchronize()
     names = {o["kernel"] for o in m.collect_profile()}
     m.disable_profiling()
-    assert any(k.startswith("conv64m_kernel<true, true, false>") for k in names), names          # c1_r / c2_r with the next distillation 1x1
-    assert any(k.startswith("conv64m_kernel<true, false, false>") for k in names), names         # c3_r
-    assert any(k.startswith("conv64m_kernel<true, false, true>") for k in names), names          # LR_conv on hi + lo pairs
+    assert any(k.startswith("conv64m_kernel<true, true, false, 4, false>") for k in names), names          # c1_r / c2_r with the next distillation 1x1
+    assert any(k.startswith("conv64m_kernel<true, false, false, 4, false>") for k in names), names         # c3_r
+    assert any(k.startswith("conv64m_kernel<true, false, true, 4, false>") for k in names), names          # LR_conv on hi + lo pairs
 
 
 def _hilo(w, dt):

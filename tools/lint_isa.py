@@ -12,6 +12,8 @@ Rule 3 -- prologues and wait states (round 5, LAB_NOTES.md 10.8): hipcc keeps ON
     16-byte patch load in front of the first LDS store of the patch; conv48r / conv48rq_kernel with the GELU compiled in -- < 160 s_nop (510).
 Rule 4 -- conv64m_kernel, rfdb_tail_kernel (esr_c64m.hip) and rlfb_chain_kernel (esr_chain.hip): no scratch access, no dynamic register
     indexing -- their s_waitcnt vmcnt(N) count every vector-memory instruction, and the DMA pieces leave m0 changed.
+Rule 5 -- rlfb_chain_kernel: the post wave's counted wait (PIECES + STORES) (D - 2) + STORES is in the code, and between two barriers
+    of the step loop there are exactly PIECES LDS-DMA loads and exactly STORES stores (ChGeo<G>): an extra vector-memory instruction would loosen it.
 Rule 2 -- conv_s16_kernel's wait-count arithmetic (tools/lint_s16_isa.py, unchanged): no scratch / spills, no copies out of registers an
     in-flight asm load writes.
 
@@ -113,6 +115,31 @@ def lint_prologues(path, unit):
             bad = [t for t in ins if t.startswith(("scratch_", "s_set_gpr_idx", "s_movrel", "v_movrel"))]
             if bad:
                 problems.append(f"{unit}: {name}: {len(bad)} scratch / dynamic register index instruction(s), first: {bad[0]}")
+        # rule 5 (round 6): rlfb_chain_kernel's post wave waits with a COUNTED vmcnt -- (PIECES + STORES) (D - 2) + STORES -- which is
+        # right only while a step issues exactly PIECES LDS-DMA loads and STORES buffer stores (esr_chain.hip: ChGeo<G>): between two barriers
+        # of the step loop there are exactly that many, and the counted wait is in the code
+        if unit == "esr_chain.hip" and "rlfb_chain_kernel" in name:
+            m = re.search(r"rlfb_chain_kernelILb[01]ELi(\d)E", name)
+            if m:
+                G = int(m.group(1))
+                pieces, stores = ((16 * G + 2) * 6 + 63) // 64, G + 2 * ((G + 1) // 2)
+                D = 8 if (pieces + stores) * 6 + stores <= 63 else 6
+                want = (pieces + stores) * (D - 2) + stores
+                segs = [[]]
+                for t in ins:
+                    if t.startswith("s_barrier"):
+                        segs.append([])
+                    else:
+                        segs[-1].append(t)
+                if not any(t.startswith("s_waitcnt") and f"vmcnt({want})" in t for t in ins):
+                    problems.append(f"{unit}: {name}: the post wave's counted wait s_waitcnt vmcnt({want}) is not in the code")
+                for i, sg in enumerate(segs[1:], 1):          # (segment 0: the prologue -- weights and the first D input rows)
+                    nl = sum(1 for t in sg if t.startswith("buffer_load") and " lds" in t)
+                    ns = sum(1 for t in sg if t.startswith(("buffer_store", "global_store")))
+                    if nl and nl != pieces:
+                        problems.append(f"{unit}: {name}: {nl} LDS-DMA loads between two barriers of the step loop, the counted wait assumes {pieces}")
+                    if ns and ns != stores:
+                        problems.append(f"{unit}: {name}: {ns} stores between two barriers of the step loop, the counted wait assumes {stores}")
     return problems
 
 

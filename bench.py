@@ -53,6 +53,7 @@ DIV2K_LR_SHAPES = [(339, 510), (339, 510), (384, 510), (339, 510), (510, 339), (
 
 
 NO_HILO_SKIP = False           # --no-hilo-skip: bf16 plans keep the long skip in single bf16 numbers (A/B of the hi + lo pairs)
+NO_TIGHT_PITCH = False         # --no-tight-pitch: RFDN's nf-wide 16-bit tensors at pitch 64 instead of 56 (A/B; model.tight_pitch = False)
 NO_FUSE_TAIL = False           # --no-fuse-tail: RFDB's c4 / c5 + esa.conv1 as separate launches (A/B of rfdb_tail_kernel; model.fuse_tail = False)
 NO_FUSE_CHAIN = False          # --no-fuse-chain: a block's 3x3 chain as separate launches (A/B of esr_conv_chain_s16; model.fuse_chain = False)
 
@@ -65,6 +66,7 @@ def build_model(name, device, compute):
     m.hilo_skip = not NO_HILO_SKIP
     m.fuse_chain = not NO_FUSE_CHAIN
     m.fuse_tail = not NO_FUSE_TAIL
+    m.tight_pitch = not NO_TIGHT_PITCH
     return m, "checkpoint"
 
 
@@ -376,6 +378,7 @@ def parse_args():
                          "(DIV2K valid + test).  The total work is fixed, so the line says \"scaling\": \"strong\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hilo-skip", action="store_true", help="bf16: single-bf16 long skip instead of hi + lo pairs (A/B; model.hilo_skip = False)")
+    ap.add_argument("--no-tight-pitch", action="store_true", help="16-bit RFDN plans: nf-wide tensors at whole K chunks (pitch 64) instead of round_up(nf, 8) = 56 (A/B; model.tight_pitch = False)")
     ap.add_argument("--no-fuse-tail", action="store_true", help="16-bit RFDN plans: c4 and c5 + esa.conv1 as separate launches (A/B; model.fuse_tail = False)")
     ap.add_argument("--no-fuse-chain", action="store_true", help="16-bit plans: the 3x3 chain of a block as separate launches (A/B; model.fuse_chain = False)")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -393,8 +396,9 @@ def parse_args():
 
 def main():
     args = parse_args()
-    global NO_HILO_SKIP, NO_FUSE_CHAIN, NO_FUSE_TAIL
+    global NO_HILO_SKIP, NO_FUSE_CHAIN, NO_FUSE_TAIL, NO_TIGHT_PITCH
     NO_FUSE_TAIL = bool(args.no_fuse_tail)
+    NO_TIGHT_PITCH = bool(args.no_tight_pitch)
     NO_HILO_SKIP = bool(args.no_hilo_skip)
     NO_FUSE_CHAIN = bool(args.no_fuse_chain)
     world = int(os.environ.get("WORLD_SIZE", "1"))

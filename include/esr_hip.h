@@ -58,7 +58,10 @@ typedef enum esr_compute { ESR_COMPUTE_F32 = 0, ESR_COMPUTE_BF16 = 1, ESR_COMPUT
  * the memory-bound layers (BASELINE.json configs [2]-[4]); arithmetic stays fp32-accumulate, values are rounded (RNE) once,
  * when stored.  The network input / output (NCHW) and the ESA low-resolution maps (pitch ESR_ESA_FP) are always fp32.
  * For esr_conv2d_f32 on NHWC input, storage BF16 / F16 requires compute BF16 / F16 and weights from esr_pack_conv_s16;
- * views then need pitch and coff in multiples of 8 elements (16 bytes) and in.coff + round_up(cin, 16) <= in.pitch. */
+ * views then need pitch and coff in multiples of 8 elements (16 bytes) and in.coff + round_up(cin, 8) <= in.pitch.
+ * TIGHT PITCH (round 6): the K loop walks 16-channel chunks; where the pixel holds round_up(cin, 8) channels but not round_up(cin, 16) -- nf = 50
+ * at pitch 56 -- the last chunk's second half is the first 16 bytes of the NEXT pixel (zeros behind an image's last pixel) and meets the weight rows
+ * esr_pack_conv_s16 leaves zero.  Values must be finite.  Segmented inputs (in_seg_*): in.coff + 16 in_seg_chunks - 8 <= in.pitch likewise. */
 typedef enum esr_storage { ESR_STORE_F32 = 0, ESR_STORE_BF16 = 1, ESR_STORE_F16 = 2 } esr_storage;
 
 typedef enum esr_layout {

@@ -1003,7 +1003,7 @@ static bool rfdb_tail_takes(const esr_conv_desc* d)
     if (d->split > 0 && d->split < d->tail_cout) return false;
     if (!d->post_wpacked || d->post2_wpacked || d->post_cout < 1 || d->post_cout > 16) return false;
     if (d->post_act != ESR_ACT_NONE && d->post_act != ESR_ACT_LRELU && d->post_act != ESR_ACT_RELU) return false;
-    if (!d->in.ptr || (d->in.pitch & 7) || (d->in.coff & 7) || d->in.coff + 16 * nch > d->in.pitch) return false;
+    if (!d->in.ptr || (d->in.pitch & 7) || (d->in.coff & 7) || d->in.coff + esr_round_up(d->cin, 8) > d->in.pitch) return false;     // (tight pitch: esr_conv2d_s16)
     if (!d->tail_cat.ptr || (d->tail_cat.pitch & 7) || (d->tail_cat.coff & 7) || d->tail_cat.coff + 32 > d->tail_cat.pitch || d->tail_seg_stride16 <= 0) return false;
     if (!d->out0.ptr || (d->out0.pitch & 7) || (d->out0.coff & 7) || d->out0.coff + esr_round_up(d->tail_cout, 8) > d->out0.pitch) return false;
     if (!d->post_out.ptr || (d->post_out.pitch & 7) || (d->post_out.coff & 7) || d->post_out.coff + esr_round_up(d->post_cout, 8) > d->post_out.pitch) return false;
@@ -1345,10 +1345,15 @@ int esr_conv2d_s16(const esr_conv_desc* d, void* hip_stream)
     const bool segmented = d->in_seg_stride != 0;
     if (segmented) {
         if (d->in_seg_chunks <= 0 || (cin_phys / 16) % d->in_seg_chunks || d->in_seg_stride < 0 || (d->in_seg_stride & 15)) return ESR_ERR_BAD_ARG;
-        if (d->in.coff + 16 * d->in_seg_chunks > d->in.pitch) return ESR_ERR_BAD_ARG;
+        // (tight pitch, round 6: a segment's last chunk may run 8 channels into the next pixel, see below)
+        if (d->in.coff + 16 * d->in_seg_chunks - 8 > d->in.pitch) return ESR_ERR_BAD_ARG;
         if (d->ksize != 1) return ESR_ERR_UNSUPPORTED;             // (a 3x3 over a concat does not occur on the path)
-    } else if (d->in.coff + cin_phys > d->in.pitch) {
-        return ESR_ERR_BAD_ARG;                                  // chunk reads stay inside the pixel
+    } else if (d->in.coff + esr_round_up(d->cin, 8) > d->in.pitch) {
+        // TIGHT PITCH (round 6): the pixel holds round_up(cin, 8) channels -- whole 16-byte granules --, not necessarily whole 16-channel K chunks:
+        // the last chunk's second half is then the first 16 bytes of the NEXT pixel (zeros behind the image's last one: the buffer range), and
+        // meets weight rows that the packer left zero (slots >= cin).  nf = 50 at pitch 56 instead of 64: 12.5 % fewer bytes in every
+        // launch of an HBM-bound model (RFDN).  Values must be finite (0 x Inf), as everywhere
+        return ESR_ERR_BAD_ARG;
     }
     const int nt = esr_round_up(d->cout, 16) / 16;
     const bool shuffle = d->out_layout == ESR_NCHW_SHUFFLE4;

@@ -354,7 +354,7 @@ class Plan:
 
     def planar(self, name, nseg, seg_pitch):
         """nseg equal full-resolution buffers back to back (see Planar); 16-bit plans only"""
-        assert self.esize == 2 and seg_pitch % 16 == 0
+        assert self.esize == 2 and seg_pitch % 8 == 0            # (whole 16-byte granules; a tight pitch -- 56 -- is not whole K chunks)
         return Planar([self.buffer(f"{name}.{j}", seg_pitch) for j in range(nseg)])
 
     def pair(self, name, pitch):
@@ -571,7 +571,7 @@ class Plan:
                 pl = o["src"]
                 d.in_layout = L.NHWC
                 d.inp = self._view(pl.seg(0), base)
-                d.in_seg_stride, d.in_seg_chunks = pl.stride, pl.pitch // 16
+                d.in_seg_stride, d.in_seg_chunks = pl.stride, (pl.pitch + 15) // 16      # (a tight pitch -- 56 for nf = 50 -- still reads whole K chunks)
             else:
                 d.in_layout = L.NHWC
                 d.inp = self._view(o["src"], base)
@@ -752,6 +752,7 @@ class HipSRModel(nn.Module):
         self._winograd = True      # fp32 plans: 3x3 convs whose shape qualifies run as Winograd F(2x2, 3x3) (esr_conv_desc.wino_wpacked)
         self._hilo_skip = True     # bf16 plans: the long skip's tensors (`fea`, `out_lr`) as hi + lo pairs (esr_conv_desc.hilo; Plan.hilo_skip)
         self._fuse_tail = True     # 16-bit RFDN plans: RFDB's c4 -> cat -> c5 -> esa.conv1 as one launch (rfdb_tail_kernel, ABI v12)
+        self._tight_pitch = True   # 16-bit RFDN plans: nf-wide tensors at pitch round_up(nf, 8) instead of whole K chunks (56 for nf = 50; esr_conv2d_s16: tight pitch)
         self._fuse_chain = True    # 16-bit plans: a block's 3x3 chain as one esr_conv_chain_s16 launch where a kernel exists (Plan.chain)
         self.use_graphs = True     # forwards of at most GRAPH_MAX_PIXELS input pixels replay a captured HIP graph (esr_graph_launch)
         self._lock = _ModelLock()       # plan / workspace bookkeeping and the pointer patch + enqueue of one forward (see _forward_impl)
@@ -810,6 +811,7 @@ class HipSRModel(nn.Module):
     hilo_skip = property(lambda self: self._hilo_skip, lambda self, v: self._set_flag("_hilo_skip", v))
     fuse_chain = property(lambda self: self._fuse_chain, lambda self, v: self._set_flag("_fuse_chain", v))
     fuse_tail = property(lambda self: self._fuse_tail, lambda self, v: self._set_flag("_fuse_tail", v))
+    tight_pitch = property(lambda self: self._tight_pitch, lambda self, v: self._set_flag("_tight_pitch", v))
 
     def _skip_hilo(self, plan, c):
         """bf16 plans: keep the long skip `upsampler(LR_conv(body) + fea)` in hi + lo pairs?  (c = its channel count; the hi + lo kernels

@@ -272,13 +272,16 @@ def test_m32_images_hold_the_same_weights_as_the_tap_pair_images():
         assert torch.all(hi[pc:] == 0) and torch.all(hi[:, cin:] == 0) and torch.all(lo[pc:] == 0)
 
 
-def test_op_costs_count_a_residual_that_is_the_input_once():
+@pytest.mark.parametrize("tight,stored", [(True, 288.0), (False, 320.0)])
+def test_op_costs_count_a_residual_that_is_the_input_once(tight, stored):
     """RFDB's c{j}_r adds its own input (rfdn_baseline/block.py:150-158) -- 100 B in + 100 B out + 50 B distilled per
-    pixel at nf = 50 / dc = 25 in 16-bit storage, not 350; the stored figure carries the pad channels (pitch 64 / 32: 320 B)."""
+    pixel at nf = 50 / dc = 25 in 16-bit storage, not 350; the stored figure carries the pad channels: pitch 64 / 32 = 320 B with whole K chunks,
+    56 / 32 = 288 B at the tight pitch of round 6 (model.tight_pitch, the default)."""
     from ntire2022_esr_amd import RFDN
     from ntire2022_esr_amd.engine import Plan
     m = RFDN()
     m.set_compute("bf16")
+    m.tight_pitch = tight
     plan = Plan(1, 64, 64, m._store())
     m._build_plan(plan, 3)
     costs = {c["name"]: c for c in m.op_costs(plan)}
@@ -286,7 +289,7 @@ def test_op_costs_count_a_residual_that_is_the_input_once():
     c1r, c3r = costs["B1.c1_r"], costs["B1.c3_r"]
     w3, wp = 4.0 * 50 * 50 * 9, 4.0 * 50 * 25                # weight bytes: the 3x3's (both figures), the post 1x1's (stored figure only)
     assert abs((c1r["read_bytes"] + c1r["write_bytes"] - w3) / npx - 250.0) < 1e-6
-    assert abs((c1r["stored_bytes"] - w3 - wp) / npx - 320.0) < 1e-6
+    assert abs((c1r["stored_bytes"] - w3 - wp) / npx - stored) < 1e-6
     assert abs((c3r["read_bytes"] + c3r["write_bytes"] - 4.0 * 50 * 50 * 9) / npx - 200.0) < 1e-6
     for c in costs.values():
         assert c["stored_bytes"] >= (c["read_bytes"] + c["write_bytes"]) * 0.9999, c["name"]

@@ -265,12 +265,41 @@ def test_s16_post_rfdb(compute, nf):
 
 def test_s16_rejects_bad_descriptors():
     from ntire2022_esr_amd import _lib as L, ops
-    x = torch.zeros(1, 8, 8, 24, dtype=torch.bfloat16, device=DEV)            # pitch 24 < round_up(cin, 16) = 32
+    x = torch.zeros(1, 8, 8, 16, dtype=torch.bfloat16, device=DEV)            # pitch 16 < round_up(cin, 8) = 24: the pixel does not hold the channels
     with pytest.raises(L.EsrError):
         ops.conv2d(x, torch.randn(16, 24, 3, 3), torch.randn(16))
     x = torch.zeros(1, 8, 8, 80, dtype=torch.float16, device=DEV)             # 3x3 with 80 input channels: weights do not fit LDS
     with pytest.raises(L.EsrError):
         ops.conv2d(x, torch.randn(64, 80, 3, 3), torch.randn(64))
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,k,hw,n", [(24, 16, 3, (19, 23), 2), (50, 50, 3, (40, 37), 1), (50, 25, 1, (33, 18), 2), (50, 50, 3, (256, 256), 1), (40, 64, 3, (256, 272), 1)])
+def test_tight_pitch_equals_whole_chunk_pitch(compute, cin, cout, k, hw, n):
+    """TIGHT PITCH (round 6, esr_conv2d_s16): an input whose pixels hold round_up(cin, 8) channels -- 56 for RFDN's nf = 50, 112-byte pixels --
+    instead of whole 16-channel K chunks.  The last chunk's second half is then the next pixel's first 16 bytes (NON-zero here: random data) and
+    meets zero weight rows: the result is bit-identical to the same convolution on the zero-padded whole-chunk tensor, on the general kernel and
+    (>= 256 tiles, 64 -> 64) on conv64m_kernel."""
+    from ntire2022_esr_amd import ops
+    dt = torch.bfloat16 if compute == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(cin + cout + hw[0])
+    p8, p16 = (cin + 7) // 8 * 8, (cin + 15) // 16 * 16
+    xt = torch.randn(n, *hw, p8, generator=g).to(dt)
+    xt[..., cin:] = 0                                   # the pad channels inside the pixel are zeros, as every producer leaves them
+    xp = torch.zeros(n, *hw, p16, dtype=dt)
+    xp[..., :p8] = xt
+    w, b = torch.randn(cout, cin, k, k, generator=g) * 0.1, torch.randn(cout, generator=g)
+    xt_d, xp_d = xt.to(DEV), xp.to(DEV)
+    y_t = ops.conv2d(xt_d, w, b, act=1)
+    y_p = ops.conv2d(xp_d, w, b, act=1)
+    assert y_t.shape[-1] >= cout and bool(torch.isfinite(y_t.float()).all())
+    assert torch.equal(y_t[..., :cout], y_p[..., :cout])
+    if cin == cout and k == 3:
+        # RFDB's c{j}_r: + the input itself, before the activation (taken from the staged tile: the neighbour pixel's bytes land in channels that
+        # are not stored)
+        r_t = ops.conv2d(xt_d, w, b, act=1, res=xt_d, res_mode=1)
+        r_p = ops.conv2d(xp_d, w, b, act=1, res=xp_d, res_mode=1)
+        assert torch.equal(r_t[..., :cout], r_p[..., :cout]) and not torch.equal(r_t[..., :cout], y_t[..., :cout])
 
 
 @pytest.mark.parametrize("mid,compute,max_dpsnr", [(-1, "f16", 0.005), (-1, "bf16", 0.01), (0, "bf16", 0.01), (4, "bf16", 0.01),

@@ -218,13 +218,15 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
     //     range) + s_add into m0 + the load for EVERY tile.  (Until this form the border tiles took a 22-instruction piece with per-lane
     //     compares under exec masks; a block keeps its tile position from image to image when an image is a multiple of 256 tiles, so the 60
     //     border blocks of a 256 x 256 batch -- 2400 cycles per tile slower -- set the launch's time: 180 -> 1xx us, profiles/r06_c64m_*.)
+    // (tight pitch, round 6: a 16-byte part that lies behind the pixel -- channels 56..63 of a 56-channel pitch -- is not requested: zero fill,
+    // like the stage's pad slots, instead of the next pixel's first bytes)
     unsigned rel[PPW], edge = 0u, lxp[3] = {0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const unsigned sl = (unsigned)((wv + 4 * i) * 64 + lane);
         const unsigned row = sl / (unsigned)M_ROWSL, rem = sl - row * (unsigned)M_ROWSL;
         const unsigned lx = rem / (unsigned)M_LSL, part = rem - lx * (unsigned)M_LSL;
-        const bool real = part < (unsigned)(2 * NCH) && lx < (unsigned)M_TH && row < (unsigned)M_THY && (i < PPW - 1 || wv + 4 * i < M_NPIECES);
+        const bool real = part < (unsigned)(2 * NCH) && (unsigned)p.in_coff + 8u * part < (unsigned)p.in_pitch && lx < (unsigned)M_TH && row < (unsigned)M_THY && (i < PPW - 1 || wv + 4 * i < M_NPIECES);
         rel[i] = real ? (row * (unsigned)p.W + lx) * (unsigned)p.in_pitch * 2u + part * 16u : OOB;
         edge |= (row == 0u ? 1u << i : 0u) | (lx == 0u ? 1u << (13 + i) : 0u);
         lxp[i / 6] |= (lx < 31u ? lx : 31u) << (5 * (i % 6));
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void conv64m_kernel(const S16K p)
             const unsigned row = sl / (unsigned)M_ROWSL, rem = sl - row * (unsigned)M_ROWSL;
             const unsigned lx = rem / (unsigned)M_LSL, part = rem - lx * (unsigned)M_LSL;
             const int gy = y0 - 1 + (int)row, gx = x0 - 1 + (int)lx;
-            const bool ok = valid && part < (unsigned)(2 * NCH) && lx < (unsigned)M_TH && row < (unsigned)M_THY && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const bool ok = valid && part < (unsigned)(2 * NCH) && (unsigned)p.in_coff + 8u * part < (unsigned)p.in_pitch && lx < (unsigned)M_TH && row < (unsigned)M_THY && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             const unsigned voff = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff) * 2u + part * 16u : OOB;
             dma_buf16(smem_lds + (unsigned)(slot * STAGE + pc * 1024), voff, make_rsrc(p.x + (size_t)(valid ? n : 0) * img_bytes, img_bytes), 0u);
         }
@@ -739,7 +741,7 @@ __global__ __launch_bounds__(256, 1) void rfdb_tail_kernel(const S16K p)
         const unsigned sl = (unsigned)((wv + 4 * i) * 64 + lane);
         const unsigned row = sl / (unsigned)M_ROWSL, rem = sl - row * (unsigned)M_ROWSL;
         const unsigned lx = rem / (unsigned)M_LSL, part = rem - lx * (unsigned)M_LSL;
-        const bool real = part < (unsigned)(2 * NCH) && lx < (unsigned)M_TH && row < (unsigned)M_THY && (i < PPW - 1 || wv + 4 * i < M_NPIECES);
+        const bool real = part < (unsigned)(2 * NCH) && (unsigned)p.in_coff + 8u * part < (unsigned)p.in_pitch && lx < (unsigned)M_TH && row < (unsigned)M_THY && (i < PPW - 1 || wv + 4 * i < M_NPIECES);
         rel[i] = real ? (row * (unsigned)p.W + lx) * (unsigned)p.in_pitch * 2u + part * 16u : OOB;
         edge |= (row == 0u ? 1u << i : 0u) | (lx == 0u ? 1u << (13 + i) : 0u);
         lxp[i / 6] |= (lx < 31u ? lx : 31u) << (5 * (i % 6));
@@ -759,7 +761,7 @@ __global__ __launch_bounds__(256, 1) void rfdb_tail_kernel(const S16K p)
             const unsigned row = sl / (unsigned)M_ROWSL, rem = sl - row * (unsigned)M_ROWSL;
             const unsigned lx = rem / (unsigned)M_LSL, part = rem - lx * (unsigned)M_LSL;
             const int gy = y0 - 1 + (int)row, gx = x0 - 1 + (int)lx;
-            const bool ok = part < (unsigned)(2 * NCH) && lx < (unsigned)M_TH && row < (unsigned)M_THY && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const bool ok = part < (unsigned)(2 * NCH) && (unsigned)p.in_coff + 8u * part < (unsigned)p.in_pitch && lx < (unsigned)M_TH && row < (unsigned)M_THY && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             const unsigned voff = ok ? (unsigned)((gy * p.W + gx) * p.in_pitch + p.in_coff) * 2u + part * 16u : OOB;
             dma_buf16(smem_lds + (unsigned)(pc * 1024), voff, make_rsrc(p.x + (size_t)n * img_bytes, img_bytes), 0u);
         }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""per-op kernel times of one forward (HIP events around every op): per_op.py <registry id> <compute> [batch] [HxW] [--no-hilo-skip]"""
+"""per-op kernel times of one forward (HIP events around every op): per_op.py <registry id> <compute> [batch] [HxW] [--no-hilo-skip] [--no-tight-pitch]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,6 +12,8 @@ m, name, dr, _ = select_model(mid, dev)
 m.set_compute(comp)
 if "--no-hilo-skip" in sys.argv:
     m.hilo_skip = False
+if "--no-tight-pitch" in sys.argv:
+    m.tight_pitch = False
 x = torch.rand(b, 3, h, w, device=dev) * dr
 for _ in range(3): m(x)
 torch.cuda.synchronize()

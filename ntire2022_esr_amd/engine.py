@@ -1074,6 +1074,8 @@ class HipSRModel(nn.Module):
         n, c, h, w = x.shape
         key = (n, c, h, w, x.device)
         y = torch.empty((n, self.out_nc, h * self.upscale, w * self.upscale), dtype=torch.float32, device=x.device)
+        if n == 0:
+            return y                        # an empty batch: nn.Conv2d returns an empty tensor too (nothing to launch: a grid of 0 blocks is an error)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         # One lock per model around the host-side bookkeeping AND the enqueue: the cached esr_op array of a (stream, shape) carries
         # this call's x / y pointers from the patch below until esr_run_ops has read it (it only enqueues: ~0.1-0.25 ms of host

@@ -45,6 +45,14 @@ def test_vs_c_oracle_ragged(model):
         assert rel_err(y, OM.imdn(sd, x), 1.0) < TOL, shape
 
 
+def test_empty_batch(model):
+    """an empty batch gives an empty x4 tensor, as the reference's nn.Conv2d stack does -- nothing is launched -- and the next forward is unaffected"""
+    y = model(torch.empty(0, 3, 24, 40, device="cuda:0"))
+    assert tuple(y.shape) == (0, 3, 96, 160) and y.dtype == torch.float32 and y.is_cuda
+    x = torch.rand(1, 3, 24, 40, generator=torch.Generator().manual_seed(1)).to("cuda:0")
+    assert tuple(model(x).shape) == (1, 3, 96, 160) and torch.equal(model(x), model(x))
+
+
 def test_natural_image_full_size(model):
     """utils/test.bmp at the bench shape 1x3x256x256 -> 1x3x1024x1024 vs the reference's output."""
     from PIL import Image
